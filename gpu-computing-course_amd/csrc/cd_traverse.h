@@ -1,0 +1,208 @@
+// cd_traverse.h -- BVH overlap traversal + exact triangle test (collision.cuh:19-88).
+#pragma once
+#include "cd_bvh.h"
+
+namespace cd {
+
+struct TravCounters {                 // device-side accumulators of one traversal
+    unsigned long long n_pairs;       // collision.cuh:40 `count`
+    unsigned long long pairs_tested;  // leaf AABB hits (reach neighborCount / SAT)
+    unsigned long long node_visits;
+    uint32_t n_deferred;              // (query, subtree) items the LDS stack could not hold (deep pass redoes them)
+    uint32_t pad;
+};
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One leaf hit (collision.cuh:36-44): neighbour filter, ID rule, exact test, append.
+__device__ __forceinline__ void leaf_hit(uint32_t q_id, uint32_t qa, uint32_t qb, uint32_t qc,
+                                         const d3 &P1, const d3 &P2, const d3 &P3,
+                                         const LeafTri lt, const double *__restrict__ verts,
+                                         uint32_t *__restrict__ pairs, unsigned long long cap, TravCounters *__restrict__ ctr)
+{
+    if (neighbor_count(qa, qb, qc, lt.v0, lt.v1, lt.v2) < 1) {            // collision.cuh:38
+        if (q_id < lt.id) {                                               // tri_contact.cuh:81
+            if (tri_contact(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) {
+                const unsigned long long cur = atomicAdd(&ctr->n_pairs, 1ull);   // collision.cuh:40
+                if (cur < cap) { pairs[2 * cur] = q_id; pairs[2 * cur + 1] = lt.id; }
+            }
+        }
+    }
+}
+
+constexpr int TRAV_THREADS = 256;
+constexpr int TRAV_STACK   = 32;       // LDS entries per lane (the reference's private stack is 32, collision.cuh:21)
+constexpr int DEEP_STACK   = 192;      // global-memory entries per query in the overflow pass
+
+// Variant A ("lane-per-query"): one query per lane, per-lane stack in LDS laid out [depth][thread]
+// (conflict-free: lane l of a wave always hits bank l mod 32 pairs).  Queries are leaves in Morton
+// order, so the 64 lanes of a wave walk neighbouring subtrees and their NodeRec fetches coalesce in L1/L2.
+// EXTERNAL: queries come from a cd_query buffer instead of the local leaves.
+struct QuerySrc {
+    const LeafTri *leaf;          // local: sorted leaves
+    const double  *boxes;         // local: node boxes (query box = boxes[(n-1)+j])
+    const void    *ext;           // external: cd_query records (88 B)
+    const uint2   *list;          // deep pass: deferred (query index, subtree root) work items
+};
+
+struct ExtQuery { double v[9]; uint32_t id; uint32_t vidx[3]; };
+static_assert(sizeof(ExtQuery) == 88, "cd_query layout");
+
+template <bool EXTERNAL, bool DEEP>
+__global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_t nq, int n,
+                                                           const NodeRec *__restrict__ recs, const LeafTri *__restrict__ leaf,
+                                                           const double *__restrict__ verts,
+                                                           uint32_t *__restrict__ pairs, unsigned long long cap,
+                                                           TravCounters *__restrict__ ctr,
+                                                           uint2 *__restrict__ defer_list, uint32_t defer_cap,
+                                                           int32_t *__restrict__ deep_stacks)
+{
+    __shared__ int32_t lds_stack[DEEP ? 1 : TRAV_STACK][TRAV_THREADS];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t gi = blockIdx.x * TRAV_THREADS + tid;
+    unsigned long long tested = 0, visits = 0;
+    if (gi < nq) {
+        const uint32_t qi = DEEP ? src.list[gi].x : gi;
+        uint32_t q_id, qa, qb, qc; d3 P1, P2, P3; Box qbox;
+        if (EXTERNAL) {
+            const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + qi;
+            P1 = d3{q->v[0], q->v[1], q->v[2]}; P2 = d3{q->v[3], q->v[4], q->v[5]}; P3 = d3{q->v[6], q->v[7], q->v[8]};
+            q_id = q->id; qa = q->vidx[0]; qb = q->vidx[1]; qc = q->vidx[2];
+            qbox = box_set(P1, P2, P3);
+        } else {
+            const LeafTri lt = src.leaf[qi];
+            q_id = lt.id; qa = lt.v0; qb = lt.v1; qc = lt.v2;
+            P1 = load_vertex(verts, qa); P2 = load_vertex(verts, qb); P3 = load_vertex(verts, qc);
+            qbox = load_box(src.boxes, (n - 1) + (int)qi);                 // collision.cuh:86 &leaves[i].box
+        }
+        int32_t *gstack = DEEP ? deep_stacks + (size_t)gi * DEEP_STACK : nullptr;
+        int sptr = 0;
+        int32_t node = DEEP ? (int32_t)src.list[gi].y : ((n > 1) ? 0 : -1); // root = internal[0]
+        while (node != -1) {
+            ++visits;
+            const NodeRec *r = recs + node;
+            const Box bl = r->bl, br = r->br;
+            const int32_t cl = r->cl, cr = r->cr;
+            const bool ol = box_overlap(qbox, bl);                         // collision.cuh:31-32
+            const bool orr = box_overlap(qbox, br);
+            int32_t next = -1;
+            if (ol) {
+                if (cl >= n - 1) { ++tested; leaf_hit(q_id, qa, qb, qc, P1, P2, P3, leaf[cl - (n - 1)], verts, pairs, cap, ctr); }
+                else next = cl;
+            }
+            if (orr) {
+                if (cr >= n - 1) { ++tested; leaf_hit(q_id, qa, qb, qc, P1, P2, P3, leaf[cr - (n - 1)], verts, pairs, cap, ctr); }
+                else if (next == -1) next = cr;
+                else {                                                     // both internal: descend left, push right
+                    const int cap_s = DEEP ? DEEP_STACK : TRAV_STACK;
+                    if (sptr < cap_s) { if (DEEP) gstack[sptr] = cr; else lds_stack[sptr][tid] = cr; ++sptr; }
+                    else {
+                        // Stack full: hand the right subtree to the deep pass as its own work item and go on.
+                        // Each subtree is still traversed exactly once, so no pair is reported twice.
+                        const uint32_t k = atomicAdd(&ctr->n_deferred, 1u);
+                        if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)cr);
+                    }
+                }
+            }
+            if (next != -1) node = next;
+            else if (sptr > 0) { --sptr; node = DEEP ? gstack[sptr] : lds_stack[sptr][tid]; }
+            else node = -1;
+        }
+    }
+    tested = wave_sum_u64(tested); visits = wave_sum_u64(visits);
+    if ((tid & 63) == 0) {
+        if (tested) atomicAdd(&ctr->pairs_tested, tested);
+        if (visits) atomicAdd(&ctr->node_visits, visits);
+    }
+}
+
+// ---------------------------------------------------------------- brute force (check.cuh:117-141)
+// Tile of 256 "j" triangles staged in LDS per step; thread i tests its triangle against the tile.
+__global__ __launch_bounds__(256) void k_brute_force(const double *__restrict__ verts, const uint32_t *__restrict__ vidx,
+                                                     const uint32_t *__restrict__ ids, uint32_t n, int box_filter,
+                                                     uint32_t *__restrict__ pairs, unsigned long long cap, TravCounters *__restrict__ ctr)
+{
+    __shared__ double sv[256][9];
+    __shared__ uint32_t si[256][4];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    uint32_t ia = 0, a0 = 0, a1 = 0, a2 = 0; d3 P1{}, P2{}, P3{}; Box bi{};
+    if (live) {
+        a0 = vidx[3 * (size_t)i]; a1 = vidx[3 * (size_t)i + 1]; a2 = vidx[3 * (size_t)i + 2];
+        ia = ids ? ids[i] : i;
+        P1 = load_vertex(verts, a0); P2 = load_vertex(verts, a1); P3 = load_vertex(verts, a2);
+        bi = box_set(P1, P2, P3);
+    }
+    unsigned long long tested = 0;
+    for (uint32_t j0 = 0; j0 < n; j0 += 256) {
+        __syncthreads();
+        const uint32_t j = j0 + threadIdx.x;
+        if (j < n) {
+            const uint32_t b0 = vidx[3 * (size_t)j], b1 = vidx[3 * (size_t)j + 1], b2 = vidx[3 * (size_t)j + 2];
+            si[threadIdx.x][0] = ids ? ids[j] : j; si[threadIdx.x][1] = b0; si[threadIdx.x][2] = b1; si[threadIdx.x][3] = b2;
+            const d3 Q1 = load_vertex(verts, b0), Q2 = load_vertex(verts, b1), Q3 = load_vertex(verts, b2);
+            double *s = sv[threadIdx.x];
+            s[0] = Q1.x; s[1] = Q1.y; s[2] = Q1.z; s[3] = Q2.x; s[4] = Q2.y; s[5] = Q2.z; s[6] = Q3.x; s[7] = Q3.y; s[8] = Q3.z;
+        }
+        __syncthreads();
+        if (!live) continue;
+        const uint32_t lim = min(256u, n - j0);
+        for (uint32_t k = 0; k < lim; ++k) {
+            const double *s = sv[k];
+            const d3 Q1{s[0], s[1], s[2]}, Q2{s[3], s[4], s[5]}, Q3{s[6], s[7], s[8]};
+            if (box_filter && !box_overlap(bi, box_set(Q1, Q2, Q3))) continue;
+            ++tested;
+            if (neighbor_count(a0, a1, a2, si[k][1], si[k][2], si[k][3]) < 1 && ia < si[k][0]) {
+                if (tri_contact(P1, P2, P3, Q1, Q2, Q3)) {
+                    const unsigned long long cur = atomicAdd(&ctr->n_pairs, 1ull);
+                    if (cur < cap) { pairs[2 * cur] = ia; pairs[2 * cur + 1] = si[k][0]; }
+                }
+            }
+        }
+    }
+    tested = wave_sum_u64(tested);
+    if ((threadIdx.x & 63) == 0 && tested) atomicAdd(&ctr->pairs_tested, tested);
+}
+
+// tri_contact.cuh:80-87 over explicit index pairs, with the collision.cuh:38 neighbour gate.
+__global__ __launch_bounds__(256) void k_test_pairs(const double *__restrict__ verts, const uint32_t *__restrict__ vidx,
+                                                    const uint32_t *__restrict__ ids, const uint32_t *__restrict__ pr,
+                                                    unsigned long long np, uint8_t *__restrict__ out)
+{
+    const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= np) return;
+    const uint32_t a = pr[2 * k], b = pr[2 * k + 1];
+    const uint32_t a0 = vidx[3 * (size_t)a], a1 = vidx[3 * (size_t)a + 1], a2 = vidx[3 * (size_t)a + 2];
+    const uint32_t b0 = vidx[3 * (size_t)b], b1 = vidx[3 * (size_t)b + 1], b2 = vidx[3 * (size_t)b + 2];
+    const uint32_t ia = ids ? ids[a] : a, ib = ids ? ids[b] : b;
+    bool r = false;
+    if (neighbor_count(a0, a1, a2, b0, b1, b2) < 1 && ia < ib)
+        r = tri_contact(load_vertex(verts, a0), load_vertex(verts, a1), load_vertex(verts, a2),
+                        load_vertex(verts, b0), load_vertex(verts, b1), load_vertex(verts, b2));
+    out[k] = r ? 1 : 0;
+}
+
+// Leaves whose AABB strictly overlaps `box` -> cd_query records (cross-rank pass).
+__global__ __launch_bounds__(256) void k_pack_queries(const double *__restrict__ verts, const LeafTri *__restrict__ leaf,
+                                                      const double *__restrict__ boxes, int n, Box box,
+                                                      ExtQuery *__restrict__ out, unsigned long long cap, unsigned long long *__restrict__ count)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const Box lb = load_box(boxes, (n - 1) + j);
+    if (!box_overlap(lb, box)) return;
+    const unsigned long long k = atomicAdd(count, 1ull);
+    if (k >= cap) return;
+    const LeafTri lt = leaf[j];
+    const d3 A = load_vertex(verts, lt.v0), B = load_vertex(verts, lt.v1), C = load_vertex(verts, lt.v2);
+    ExtQuery q;
+    q.v[0] = A.x; q.v[1] = A.y; q.v[2] = A.z; q.v[3] = B.x; q.v[4] = B.y; q.v[5] = B.z; q.v[6] = C.x; q.v[7] = C.y; q.v[8] = C.z;
+    q.id = lt.id; q.vidx[0] = lt.v0; q.vidx[1] = lt.v1; q.vidx[2] = lt.v2;
+    out[k] = q;
+}
+
+}  // namespace cd

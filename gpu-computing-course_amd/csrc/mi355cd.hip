@@ -1,0 +1,478 @@
+// mi355cd.hip -- C-ABI implementation of include/mi355cd.h (libmi355cd.so), gfx950 only.
+// Build: hipcc -O3 -ffp-contract=off --offload-arch=gfx950 -shared -fPIC (see ../Makefile).
+#include "../../include/mi355cd.h"
+#include "cd_math.h"
+#include "cd_sort.h"
+#include "cd_bvh.h"
+#include "cd_traverse.h"
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace cd;
+
+namespace {
+
+#define HIPCHK(expr)                                                   \
+    do {                                                               \
+        hipError_t e_ = (expr);                                        \
+        if (e_ != hipSuccess) return -(int)e_;                         \
+    } while (0)
+
+enum Stage { ST_CREATED = 0, ST_SORTED = 1, ST_BUILT = 2, ST_REFIT = 3 };
+
+enum Ev { EV_MORTON0, EV_MORTON1, EV_SORT1, EV_HIER0, EV_HIER1, EV_REFIT0, EV_REFIT1, EV_TRAV0, EV_TRAV1, EV_CHK0, EV_CHK1, EV_COUNT };
+
+}  // namespace
+
+struct cd_ctx {
+    uint32_t nv = 0, nt = 0;
+    int stage = ST_CREATED;
+    int frame_mode = CD_FRAME_REFERENCE;
+    double frame_host[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};   // morton.h:45,51,57
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[EV_COUNT] = {};
+    // inputs
+    double *d_verts = nullptr; uint32_t *d_vidx = nullptr; uint32_t *d_ids = nullptr;
+    // sort
+    uint64_t *d_keys[2] = {nullptr, nullptr}; uint32_t *d_perm[2] = {nullptr, nullptr};
+    uint32_t *d_counts = nullptr; uint32_t ntiles = 0;
+    double *d_frame = nullptr, *d_partial = nullptr;
+    // tree
+    LeafTri *d_leaf = nullptr; int2 *d_children = nullptr; int32_t *d_parent = nullptr;
+    double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec *d_recs = nullptr;
+    uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
+    // traversal
+    TravCounters *d_ctr = nullptr;
+    uint32_t *d_pairs = nullptr; uint64_t pairs_cap = 0;
+    uint2 *d_defer = nullptr; uint32_t defer_cap = 0;
+    int32_t *d_deep = nullptr; uint64_t deep_items = 0;
+    // host mirrors
+    cd_stats stats = {};
+};
+
+namespace {
+
+void free_all(cd_ctx *c)
+{
+    hipFree(c->d_verts); hipFree(c->d_vidx); hipFree(c->d_ids);
+    for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
+    hipFree(c->d_counts); hipFree(c->d_frame); hipFree(c->d_partial);
+    hipFree(c->d_leaf); hipFree(c->d_children); hipFree(c->d_parent); hipFree(c->d_boxes);
+    hipFree(c->d_bounded); hipFree(c->d_recs); hipFree(c->d_small); hipFree(c->d_ctr);
+    hipFree(c->d_pairs); hipFree(c->d_defer); hipFree(c->d_deep);
+    for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->stream) hipStreamDestroy(c->stream);
+}
+
+inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+constexpr int BOUNDS_BLOCKS = 1024;
+
+int ensure_pairs(cd_ctx *c, uint64_t cap)
+{
+    if (cap <= c->pairs_cap) return 0;
+    hipFree(c->d_pairs); c->d_pairs = nullptr; c->pairs_cap = 0;
+    HIPCHK(hipMalloc(&c->d_pairs, sizeof(uint32_t) * 2 * cap));
+    c->pairs_cap = cap;
+    return 0;
+}
+
+float elapsed(cd_ctx *c, int a, int b) { float ms = 0.f; hipEventElapsedTime(&ms, c->ev[a], c->ev[b]); return ms; }
+
+// ---- stage enqueuers (no host synchronisation inside) -------------------------------------------
+int enqueue_morton_sort(cd_ctx *c)
+{
+    const uint32_t n = c->nt;
+    hipStream_t s = c->stream;
+    HIPCHK(hipEventRecord(c->ev[EV_MORTON0], s));
+    if (c->frame_mode == CD_FRAME_AUTO) {
+        k_centroid_bounds<<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_partial);
+        k_frame_from_bounds<<<1, 64, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->d_frame);
+    }
+    k_morton<<<cdiv(n, 256), 256, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_frame, c->d_keys[0]);
+    HIPCHK(hipEventRecord(c->ev[EV_MORTON1], s));
+    int cur = 0;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = pass * RADIX_BITS;
+        k_radix_hist<<<c->ntiles, SORT_THREADS, 0, s>>>(c->d_keys[cur], n, shift, c->d_counts, c->ntiles);
+        k_scan_exclusive<<<1, 1024, 0, s>>>(c->d_counts, RADIX * c->ntiles);
+        k_radix_scatter<<<c->ntiles, SORT_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1],
+                                                          n, shift, c->d_counts, c->ntiles, pass == 0);
+        cur ^= 1;
+    }
+    // 8 passes: sorted data is back in buffer 0
+    HIPCHK(hipEventRecord(c->ev[EV_SORT1], s));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int enqueue_hierarchy(cd_ctx *c)
+{
+    const uint32_t n = c->nt;
+    hipStream_t s = c->stream;
+    HIPCHK(hipEventRecord(c->ev[EV_HIER0], s));
+    HIPCHK(hipMemsetAsync(c->d_small, 0, 16 * sizeof(uint32_t), s));
+    k_fill_leaves<<<cdiv(n, 256), 256, 0, s>>>(c->d_perm[0], c->d_vidx, c->d_ids, n, c->d_leaf, c->d_parent, c->d_bounded);
+    if (n > 1)
+        k_hierarchy<<<cdiv(n - 1, 256), 256, 0, s>>>(c->d_keys[0], (int)n, c->d_children, c->d_parent, nullptr, c->d_small);
+    HIPCHK(hipEventRecord(c->ev[EV_HIER1], s));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int enqueue_refit(cd_ctx *c)
+{
+    const uint32_t n = c->nt;
+    hipStream_t s = c->stream;
+    HIPCHK(hipEventRecord(c->ev[EV_REFIT0], s));
+    HIPCHK(hipMemsetAsync(c->d_boxes, 0xFF, sizeof(double) * 6 * (2 * (size_t)n - 1), s));
+    if (n > 1) HIPCHK(hipMemsetAsync(c->d_bounded, 0, sizeof(uint32_t) * (n - 1), s));
+    k_refit<<<cdiv(n, 256), 256, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_children, c->d_parent, c->d_boxes, c->d_bounded, c->d_recs);
+    HIPCHK(hipEventRecord(c->ev[EV_REFIT1], s));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// Traversal (local leaves or external queries).  Blocks: reads the counters, runs the deep pass when needed.
+int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs)
+{
+    const uint32_t n = c->nt;
+    hipStream_t s = c->stream;
+    const bool external = d_ext != nullptr;
+    const uint32_t nq = external ? (uint32_t)nq_ext : n;
+    int rc = ensure_pairs(c, cap_pairs > 0 ? cap_pairs : 1);
+    if (rc) return rc;
+    uint32_t launches = 0;
+    TravCounters h = {};
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        launches = 0;
+        HIPCHK(hipEventRecord(c->ev[EV_TRAV0], s));
+        HIPCHK(hipMemsetAsync(c->d_ctr, 0, sizeof(TravCounters), s));
+        QuerySrc src{c->d_leaf, c->d_boxes, d_ext, nullptr};
+        if (nq > 0) {
+            if (external)
+                k_traverse<true, false><<<cdiv(nq, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nq, (int)n, c->d_recs, c->d_leaf, c->d_verts,
+                                                                                     c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr);
+            else
+                k_traverse<false, false><<<cdiv(nq, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nq, (int)n, c->d_recs, c->d_leaf, c->d_verts,
+                                                                                      c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr);
+            ++launches;
+        }
+        HIPCHK(hipMemcpyAsync(&h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (h.n_deferred == 0) break;
+        if (h.n_deferred > c->defer_cap) {
+            // the deferred list was too small: grow it and redo the whole traversal (pairs restart at 0)
+            hipFree(c->d_defer); c->d_defer = nullptr; c->defer_cap = 0;
+            HIPCHK(hipMalloc(&c->d_defer, sizeof(uint2) * (size_t)h.n_deferred));
+            c->defer_cap = h.n_deferred;
+            continue;
+        }
+        // deep pass over the deferred (query, subtree) items with global-memory stacks
+        const uint32_t nd = h.n_deferred;
+        if (nd > c->deep_items) {
+            hipFree(c->d_deep); c->d_deep = nullptr; c->deep_items = 0;
+            HIPCHK(hipMalloc(&c->d_deep, sizeof(int32_t) * (size_t)DEEP_STACK * nd));
+            c->deep_items = nd;
+        }
+        HIPCHK(hipMemsetAsync(&c->d_ctr->n_deferred, 0, sizeof(uint32_t), s));
+        src.list = c->d_defer;
+        if (external)
+            k_traverse<true, true><<<cdiv(nd, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nd, (int)n, c->d_recs, c->d_leaf, c->d_verts,
+                                                                                c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep);
+        else
+            k_traverse<false, true><<<cdiv(nd, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nd, (int)n, c->d_recs, c->d_leaf, c->d_verts,
+                                                                                 c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep);
+        ++launches;
+        HIPCHK(hipMemcpyAsync(&h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (h.n_deferred != 0) return CD_ERR_ARG;       // tree deeper than DEEP_STACK: cannot happen (height <= 96)
+        c->stats.stack_overflows = nd;
+        break;
+    }
+    HIPCHK(hipEventRecord(c->ev[EV_TRAV1], s));
+    HIPCHK(hipGetLastError());
+    const uint64_t found = h.n_pairs;
+    const uint64_t ncopy = found < cap_pairs ? found : cap_pairs;
+    if (pairs && ncopy) HIPCHK(hipMemcpyAsync(pairs, c->d_pairs, sizeof(uint32_t) * 2 * ncopy, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    c->stats.ms_traverse = elapsed(c, EV_TRAV0, EV_TRAV1);
+    c->stats.traverse_launches = launches;
+    if (h.n_deferred == 0 && launches <= 1) c->stats.stack_overflows = 0;
+    c->stats.n_pairs = found; c->stats.pairs_tested = h.pairs_tested; c->stats.node_visits = h.node_visits;
+    if (n_pairs) *n_pairs = found;
+    return found > cap_pairs ? CD_OVERFLOW : CD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *cd_version(void) { return "mi355cd 0.1 gfx950"; }
+
+int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t *vidx3, const uint32_t *ids, uint32_t nt)
+{
+    if (!out || !verts_xyz || !vidx3 || nv == 0 || nt == 0) return CD_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return CD_ERR_NO_DEVICE;
+    for (uint64_t k = 0; k < 3ull * nt; ++k) if (vidx3[k] >= nv) return CD_ERR_INDEX;
+    cd_ctx *c = new (std::nothrow) cd_ctx();
+    if (!c) return CD_ERR_ARG;
+    c->nv = nv; c->nt = nt;
+    c->ntiles = cdiv(nt, SORT_TILE);
+    const size_t n = nt;
+#define ALLOC(p, bytes) do { hipError_t e_ = hipMalloc((void **)&(p), (bytes)); if (e_ != hipSuccess) { free_all(c); delete c; return -(int)e_; } } while (0)
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return -(int)e; }
+    for (int i = 0; i < EV_COUNT; ++i) { e = hipEventCreate(&c->ev[i]); if (e != hipSuccess) { free_all(c); delete c; return -(int)e; } }
+    ALLOC(c->d_verts, sizeof(double) * 3 * (size_t)nv);
+    ALLOC(c->d_vidx, sizeof(uint32_t) * 3 * n);
+    if (ids) ALLOC(c->d_ids, sizeof(uint32_t) * n);
+    for (int i = 0; i < 2; ++i) { ALLOC(c->d_keys[i], sizeof(uint64_t) * n); ALLOC(c->d_perm[i], sizeof(uint32_t) * n); }
+    ALLOC(c->d_counts, sizeof(uint32_t) * RADIX * c->ntiles);
+    ALLOC(c->d_frame, sizeof(double) * 6);
+    ALLOC(c->d_partial, sizeof(double) * 6 * BOUNDS_BLOCKS);
+    ALLOC(c->d_leaf, sizeof(LeafTri) * n);
+    ALLOC(c->d_children, sizeof(int2) * n);
+    ALLOC(c->d_parent, sizeof(int32_t) * 2 * n);
+    ALLOC(c->d_boxes, sizeof(double) * 6 * 2 * n);
+    ALLOC(c->d_bounded, sizeof(uint32_t) * n);
+    ALLOC(c->d_recs, sizeof(NodeRec) * n);
+    ALLOC(c->d_small, sizeof(uint32_t) * 16);
+    ALLOC(c->d_ctr, sizeof(TravCounters));
+    c->defer_cap = 1u << 16;
+    ALLOC(c->d_defer, sizeof(uint2) * c->defer_cap);
+#undef ALLOC
+    // main.cu:86-88 H2D
+    bool ok = hipMemcpy(c->d_verts, verts_xyz, sizeof(double) * 3 * (size_t)nv, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(c->d_vidx, vidx3, sizeof(uint32_t) * 3 * n, hipMemcpyHostToDevice) == hipSuccess &&
+              (!ids || hipMemcpy(c->d_ids, ids, sizeof(uint32_t) * n, hipMemcpyHostToDevice) == hipSuccess) &&
+              hipMemcpy(c->d_frame, c->frame_host, sizeof(double) * 6, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { free_all(c); delete c; return -(int)hipGetLastError(); }
+    *out = c;
+    return CD_OK;
+}
+
+void cd_destroy(cd_ctx *c)
+{
+    if (!c) return;
+    hipStreamSynchronize(c->stream);
+    free_all(c);
+    delete c;
+}
+
+int cd_update_vertices(cd_ctx *c, const double *verts_xyz)
+{
+    if (!c || !verts_xyz) return CD_ERR_ARG;
+    HIPCHK(hipMemcpy(c->d_verts, verts_xyz, sizeof(double) * 3 * (size_t)c->nv, hipMemcpyHostToDevice));
+    c->stage = ST_CREATED;
+    return CD_OK;
+}
+
+int cd_set_morton_frame(cd_ctx *c, int mode, const double offset[3], const double span[3])
+{
+    if (!c) return CD_ERR_ARG;
+    if (mode == CD_FRAME_REFERENCE) {
+        const double ref[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};
+        memcpy(c->frame_host, ref, sizeof ref);
+    } else if (mode == CD_FRAME_CUSTOM) {
+        if (!offset || !span) return CD_ERR_ARG;
+        for (int a = 0; a < 3; ++a) { c->frame_host[a] = offset[a]; c->frame_host[3 + a] = span[a]; }
+    } else if (mode != CD_FRAME_AUTO) return CD_ERR_ARG;
+    c->frame_mode = mode;
+    HIPCHK(hipMemcpy(c->d_frame, c->frame_host, sizeof(double) * 6, hipMemcpyHostToDevice));
+    c->stage = ST_CREATED;
+    return CD_OK;
+}
+
+int cd_morton_sort(cd_ctx *c)
+{
+    if (!c) return CD_ERR_ARG;
+    int rc = enqueue_morton_sort(c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
+    c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
+    c->stage = ST_SORTED;
+    return CD_OK;
+}
+
+int cd_build_hierarchy(cd_ctx *c, uint32_t *parent_wrong_num)
+{
+    if (!c) return CD_ERR_ARG;
+    if (c->stage < ST_SORTED) return CD_ERR_ORDER;
+    int rc = enqueue_hierarchy(c);
+    if (rc) return rc;
+    uint32_t wrong = 0;
+    HIPCHK(hipMemcpyAsync(&wrong, c->d_small, sizeof wrong, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);
+    if (parent_wrong_num) *parent_wrong_num = wrong;
+    c->stage = ST_BUILT;
+    return CD_OK;
+}
+
+int cd_refit_boxes(cd_ctx *c)
+{
+    if (!c) return CD_ERR_ARG;
+    if (c->stage < ST_BUILT) return CD_ERR_ORDER;
+    int rc = enqueue_refit(c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stats.ms_refit = elapsed(c, EV_REFIT0, EV_REFIT1);
+    c->stage = ST_REFIT;
+    return CD_OK;
+}
+
+static int run_check(cd_ctx *c, int which, uint32_t maxv, uint32_t *out, int nout)
+{
+    if (!c || !out) return CD_ERR_ARG;
+    if (c->stage < ST_BUILT) return CD_ERR_ORDER;
+    const int n = (int)c->nt;
+    hipStream_t s = c->stream;
+    HIPCHK(hipEventRecord(c->ev[EV_CHK0], s));
+    HIPCHK(hipMemsetAsync(c->d_small + 8, 0, 8 * sizeof(uint32_t), s));           // main.cu:113,121,129
+    if (which == 0) { if (n > 1) k_check_internal<<<cdiv(n - 1, 256), 256, 0, s>>>(n, c->d_children, c->d_parent, c->d_bounded, c->d_boxes, c->d_small + 8); }
+    else if (which == 1) k_check_leaves<<<cdiv(n, 256), 256, 0, s>>>(n, c->d_parent, c->d_leaf, maxv, c->d_boxes, c->d_small + 8);
+    else k_check_triangle_idx<<<cdiv(n, 256), 256, 0, s>>>(n, c->d_leaf, maxv, c->d_small + 8);
+    HIPCHK(hipEventRecord(c->ev[EV_CHK1], s));
+    HIPCHK(hipMemcpyAsync(out, c->d_small + 8, nout * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    c->stats.ms_check = elapsed(c, EV_CHK0, EV_CHK1);
+    return CD_OK;
+}
+int cd_check_internal(cd_ctx *c, uint32_t out[5]) { return run_check(c, 0, 0, out, 5); }
+int cd_check_leaves(cd_ctx *c, uint32_t out[4]) { return run_check(c, 1, c ? c->nv : 0, out, 4); }
+int cd_check_triangle_idx(cd_ctx *c, uint32_t maxv, uint32_t *out) { return run_check(c, 2, maxv, out, 1); }
+
+int cd_find_collisions(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs)
+{
+    if (!c || (cap_pairs && !pairs)) return CD_ERR_ARG;
+    if (c->stage < ST_REFIT) return CD_ERR_ORDER;
+    return run_traversal(c, nullptr, 0, pairs, cap_pairs, n_pairs);
+}
+
+int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs)
+{
+    if (!c || (cap_pairs && !pairs)) return CD_ERR_ARG;
+    int rc;
+    if ((rc = enqueue_morton_sort(c))) return rc;
+    if ((rc = enqueue_hierarchy(c))) return rc;
+    if ((rc = enqueue_refit(c))) return rc;
+    rc = run_traversal(c, nullptr, 0, pairs, cap_pairs, n_pairs);     // synchronises
+    if (rc < 0) return rc;
+    c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
+    c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
+    c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);
+    c->stats.ms_refit = elapsed(c, EV_REFIT0, EV_REFIT1);
+    c->stage = ST_REFIT;
+    return rc;
+}
+
+int cd_brute_force(cd_ctx *c, int box_filter, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs)
+{
+    if (!c || (cap_pairs && !pairs)) return CD_ERR_ARG;
+    int rc = ensure_pairs(c, cap_pairs > 0 ? cap_pairs : 1);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemsetAsync(c->d_ctr, 0, sizeof(TravCounters), s));
+    k_brute_force<<<cdiv(c->nt, 256), 256, 0, s>>>(c->d_verts, c->d_vidx, c->d_ids, c->nt, box_filter, c->d_pairs, cap_pairs, c->d_ctr);
+    TravCounters h;
+    HIPCHK(hipMemcpyAsync(&h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    const uint64_t ncopy = h.n_pairs < cap_pairs ? h.n_pairs : cap_pairs;
+    if (pairs && ncopy) HIPCHK(hipMemcpy(pairs, c->d_pairs, sizeof(uint32_t) * 2 * ncopy, hipMemcpyDeviceToHost));
+    if (n_pairs) *n_pairs = h.n_pairs;
+    return h.n_pairs > cap_pairs ? CD_OVERFLOW : CD_OK;
+}
+
+int cd_test_pairs(cd_ctx *c, const uint32_t *pairs, uint64_t np, uint8_t *out)
+{
+    if (!c || !pairs || !out) return CD_ERR_ARG;
+    if (np == 0) return CD_OK;
+    for (uint64_t k = 0; k < 2 * np; ++k) if (pairs[k] >= c->nt) return CD_ERR_INDEX;
+    uint32_t *d_p = nullptr; uint8_t *d_o = nullptr;
+    HIPCHK(hipMalloc(&d_p, sizeof(uint32_t) * 2 * np));
+    if (hipMalloc(&d_o, np) != hipSuccess) { hipFree(d_p); return -(int)hipErrorOutOfMemory; }
+    int rc = CD_OK;
+    if (hipMemcpy(d_p, pairs, sizeof(uint32_t) * 2 * np, hipMemcpyHostToDevice) != hipSuccess) rc = -(int)hipErrorInvalidValue;
+    if (!rc) {
+        k_test_pairs<<<cdiv(np, 256), 256, 0, c->stream>>>(c->d_verts, c->d_vidx, c->d_ids, d_p, np, d_o);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, d_o, np, hipMemcpyDeviceToHost) != hipSuccess) rc = -(int)hipGetLastError();
+    }
+    hipFree(d_p); hipFree(d_o);
+    return rc;
+}
+
+int cd_export_keys(cd_ctx *c, uint64_t *keys, uint32_t *perm)
+{
+    if (!c) return CD_ERR_ARG;
+    if (c->stage < ST_SORTED) return CD_ERR_ORDER;
+    if (keys) HIPCHK(hipMemcpy(keys, c->d_keys[0], sizeof(uint64_t) * c->nt, hipMemcpyDeviceToHost));
+    if (perm) HIPCHK(hipMemcpy(perm, c->d_perm[0], sizeof(uint32_t) * c->nt, hipMemcpyDeviceToHost));
+    return CD_OK;
+}
+
+int cd_export_tree(cd_ctx *c, int32_t *parent, int32_t *left, int32_t *right, double *boxes, uint32_t *bounded)
+{
+    if (!c) return CD_ERR_ARG;
+    if (c->stage < ST_BUILT) return CD_ERR_ORDER;
+    const size_t n = c->nt;
+    if (parent) HIPCHK(hipMemcpy(parent, c->d_parent, sizeof(int32_t) * (2 * n - 1), hipMemcpyDeviceToHost));
+    if ((left || right) && n > 1) {
+        std::vector<int2> ch(n - 1);
+        HIPCHK(hipMemcpy(ch.data(), c->d_children, sizeof(int2) * (n - 1), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n - 1; ++i) { if (left) left[i] = ch[i].x; if (right) right[i] = ch[i].y; }
+    }
+    if (boxes || bounded) { if (c->stage < ST_REFIT) return CD_ERR_ORDER; }
+    if (boxes) HIPCHK(hipMemcpy(boxes, c->d_boxes, sizeof(double) * 6 * (2 * n - 1), hipMemcpyDeviceToHost));
+    if (bounded && n > 1) HIPCHK(hipMemcpy(bounded, c->d_bounded, sizeof(uint32_t) * (n - 1), hipMemcpyDeviceToHost));
+    return CD_OK;
+}
+
+int cd_get_stats(cd_ctx *c, cd_stats *out) { if (!c || !out) return CD_ERR_ARG; *out = c->stats; return CD_OK; }
+int cd_num_triangles(cd_ctx *c, uint32_t *nt) { if (!c || !nt) return CD_ERR_ARG; *nt = c->nt; return CD_OK; }
+
+int cd_root_box(cd_ctx *c, double box[6])
+{
+    if (!c || !box) return CD_ERR_ARG;
+    if (c->stage < ST_REFIT) return CD_ERR_ORDER;
+    // n == 1: the only node is leaf 0 = node 0 as well
+    HIPCHK(hipMemcpy(box, c->d_boxes, sizeof(double) * 6, hipMemcpyDeviceToHost));
+    return CD_OK;
+}
+
+int cd_pack_queries(cd_ctx *c, const double box[6], void *d_out, uint64_t cap, uint64_t *n)
+{
+    if (!c || !box || !n || (cap && !d_out)) return CD_ERR_ARG;
+    if (c->stage < ST_REFIT) return CD_ERR_ORDER;
+    hipStream_t s = c->stream;
+    unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(c->d_ctr);
+    HIPCHK(hipMemsetAsync(c->d_ctr, 0, sizeof(TravCounters), s));
+    Box b{box[0], box[1], box[2], box[3], box[4], box[5]};
+    k_pack_queries<<<cdiv(c->nt, 256), 256, 0, s>>>(c->d_verts, c->d_leaf, c->d_boxes, (int)c->nt, b,
+                                                     reinterpret_cast<ExtQuery *>(d_out), cap, d_cnt);
+    unsigned long long h = 0;
+    HIPCHK(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    *n = h;
+    return h > cap ? CD_OVERFLOW : CD_OK;
+}
+
+int cd_find_collisions_queries(cd_ctx *c, const void *d_queries, uint64_t nq, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs)
+{
+    if (!c || (cap_pairs && !pairs) || (nq && !d_queries) || nq > 0xffffffffull) return CD_ERR_ARG;
+    if (c->stage < ST_REFIT) return CD_ERR_ORDER;
+    if (nq == 0) { if (n_pairs) *n_pairs = 0; return CD_OK; }
+    return run_traversal(c, d_queries, nq, pairs, cap_pairs, n_pairs);
+}
+
+}  // extern "C"

@@ -1,0 +1,286 @@
+// mi355rt.hip -- C-ABI implementation of include/mi355rt.h (libmi355rt.so), gfx950 only.
+// The per-pixel ray-sphere loop of RayTracing/anime_ray.cu:41-88 + Sphere::hit (sphere.cuh:34-44).
+// Build: hipcc -O3 -ffp-contract=off --offload-arch=gfx950 (float math must not be contracted: the hit
+// predicate dx*dx + dy*dy < r*r and the two sqrtf / one divide decide pixel bytes).
+#include "../../include/mi355rt.h"
+
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <new>
+
+namespace {
+
+#define HIPCHK(expr)                                  \
+    do {                                              \
+        hipError_t e_ = (expr);                       \
+        if (e_ != hipSuccess) return -(int)e_;        \
+    } while (0)
+
+constexpr float RT_INF = 2e10f;        // sphere.cuh:10
+constexpr int TILE = 64;               // pixels per tile edge; one 256-thread workgroup per tile
+constexpr int THREADS = 256;
+
+// Per-sphere values that Sphere::hit recomputes for every pixel but that depend on the sphere only.
+// Each is produced by exactly the float operation of the reference, so reusing it is bit-identical:
+//   cx = x + (float)x_shift   (sphere.cuh:36: `x + x_shift`, int promoted to float)
+//   rr = radius * radius      (sphere.cuh:38,39,40)
+//   sr = sqrtf(radius*radius) (sphere.cuh:40)
+struct alignas(16) SphGeom { float cx, cy, rr, z; };
+struct alignas(16) SphShade { float r, g, b, sr; };
+
+__global__ __launch_bounds__(256) void k_prepare(const RtSphere *__restrict__ s, const int32_t *__restrict__ shifts, int n,
+                                                 SphGeom *__restrict__ geom, SphShade *__restrict__ shade)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RtSphere sp = s[i];
+    const int xs = shifts[4 * sp.idx], ys = shifts[4 * sp.idx + 1];        // sphere.cuh:35
+    SphGeom g; g.cx = sp.x + (float)xs; g.cy = sp.y + (float)ys; g.rr = sp.radius * sp.radius; g.z = sp.z;
+    SphShade h; h.r = sp.r; h.g = sp.g; h.b = sp.b; h.sr = sqrtf(sp.radius * sp.radius);
+    geom[i] = g; shade[i] = h;
+}
+
+struct Px { float r, g, b, maxz; };
+
+// One sphere against one pixel: sphere.cuh:36-43 + anime_ray.cu:75-81.
+__device__ __forceinline__ void shade_one(Px &p, float ox, float oy, const SphGeom g, const SphShade *__restrict__ shade, int i)
+{
+    const float dx = ox - g.cx;
+    const float dy = oy - g.cy;
+    const float dx2 = dx * dx, dy2 = dy * dy;
+    if (dx2 + dy2 < g.rr) {
+        const SphShade h = shade[i];
+        const float dz = sqrtf(g.rr - dx2 - dy2);
+        const float n = dz / h.sr;
+        const float t = dz + g.z;
+        if (t > p.maxz) { p.r = h.r * n; p.g = h.g * n; p.b = h.b * n; p.maxz = t; }   // strict: lowest index wins
+    }
+}
+
+__device__ __forceinline__ uint32_t pack_px(const Px &p)
+{
+    // anime_ray.cu:84-87: (int)(c * 255) stored to unsigned char; alpha 255
+    const uint32_t r = (uint32_t)(unsigned char)(int)(p.r * 255);
+    const uint32_t g = (uint32_t)(unsigned char)(int)(p.g * 255);
+    const uint32_t b = (uint32_t)(unsigned char)(int)(p.b * 255);
+    return r | (g << 8) | (b << 16) | (255u << 24);
+}
+
+// Thread layout inside a 64x64 tile: tx = tid & 15 owns 4 consecutive columns, ty = tid >> 4 owns rows
+// ty, ty+16, ty+32, ty+48 -> each row of the tile is written by 16 lanes x 16 B = 256 contiguous bytes.
+//
+// BINNED == false: anime_ray.cu:70-82 verbatim -- every pixel loops over all spheres.  The sphere index
+// is wave-uniform, so the geometry comes through the scalar cache (s_load), not LDS.
+// BINNED == true: first the workgroup culls spheres that cannot touch the tile, with a bound built from
+// the same float operations as the hit test (below), keeping survivors in index order; pixels then loop
+// over the survivors only.  Identical pixels, ~S/(survivors) times fewer hit() evaluations.
+template <bool BINNED>
+__global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ geom, const SphShade *__restrict__ shade, int n,
+                                                    int dim, int c_shift_x, int c_shift_y, int tile_y0,
+                                                    uint32_t *__restrict__ rgba, unsigned long long *__restrict__ tests)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *list = reinterpret_cast<int *>(smem);              // BINNED: 4 sub-lists of cap = ceil(n/4) entries
+    __shared__ int wcount[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int X0 = blockIdx.x * TILE, Y0 = (blockIdx.y + tile_y0) * TILE;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int x = X0 + 4 * tx;
+    float ox[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ox[k] = (float)(x + k - dim / 2 + c_shift_x);          // anime_ray.cu:65
+    float oy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) oy[k] = (float)(Y0 + ty + 16 * k - dim / 2 + c_shift_y); // anime_ray.cu:66
+    Px px[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) px[a][b] = Px{0.f, 0.f, 0.f, -RT_INF};                // anime_ray.cu:68-69
+
+    if (!BINNED) {
+        for (int i = 0; i < n; ++i) {
+            const SphGeom g = geom[i];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) shade_one(px[a][b], ox[b], oy[a], g, shade, i);
+        }
+    } else {
+        // ---- exact conservative cull.  For a column x of the tile, dx(x) = fl(ox(x) - cx) is monotone in x,
+        // so over the tile |dx| >= m where m = dx(X0) if that is > 0, -dx(X1) if dx(X1) < 0, else 0; likewise y.
+        // fl is monotone, hence fl(dx^2 + dy^2) >= fl(mx^2 + my^2) for every pixel of the tile: if that lower
+        // bound is not < rr the reference's own predicate (sphere.cuh:38) is false on the whole tile.
+        const int sub_cap = (n + 3) >> 2;
+        const float ox0 = (float)(X0 - dim / 2 + c_shift_x), ox1 = (float)(X0 + TILE - 1 - dim / 2 + c_shift_x);
+        const float oy0 = (float)(Y0 - dim / 2 + c_shift_y), oy1 = (float)(Y0 + TILE - 1 - dim / 2 + c_shift_y);
+        int cnt = 0;                                           // wave-uniform running length of this wave's sub-list
+        const int s_begin = w * sub_cap, s_end = min(n, s_begin + sub_cap);
+        for (int base = s_begin; base < s_end; base += 64) {
+            const int i = base + lane;
+            bool keep = false;
+            if (i < s_end) {
+                const SphGeom g = geom[i];
+                const float dx0 = ox0 - g.cx, dx1 = ox1 - g.cx;
+                const float dy0 = oy0 - g.cy, dy1 = oy1 - g.cy;
+                const float mx = dx0 > 0.f ? dx0 : (dx1 < 0.f ? dx1 : 0.f);
+                const float my = dy0 > 0.f ? dy0 : (dy1 < 0.f ? dy1 : 0.f);
+                keep = !(mx * mx + my * my >= g.rr);           // NaN anywhere -> keep (the exact test then rejects)
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) list[w * sub_cap + cnt + __popcll(m & ((1ull << lane) - 1ull))] = i;
+            cnt += __popcll(m);
+        }
+        if (lane == 0) wcount[w] = cnt;
+        __syncthreads();
+        unsigned long long mytests = 0;
+        for (int ww = 0; ww < 4; ++ww) {                       // sub-lists in wave order == ascending sphere index
+            const int c = wcount[ww];
+            for (int k = 0; k < c; ++k) {
+                const int i = list[ww * sub_cap + k];
+                const SphGeom g = geom[i];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) shade_one(px[a][b], ox[b], oy[a], g, shade, i);
+            }
+            mytests += (unsigned long long)c;
+        }
+        if (tid == 0 && tests) atomicAdd(tests, mytests * (unsigned long long)(TILE * TILE));
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int y = Y0 + ty + 16 * a;
+        uint4 o;
+        o.x = pack_px(px[a][0]); o.y = pack_px(px[a][1]); o.z = pack_px(px[a][2]); o.w = pack_px(px[a][3]);
+        *reinterpret_cast<uint4 *>(rgba + (size_t)y * dim + x) = o;                       // offset = x + y*dim, anime_ray.cu:64
+    }
+}
+
+}  // namespace
+
+struct rt_ctx {
+    int32_t n = 0, dim = 0;
+    int mode = RT_MODE_BINNED;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    RtSphere *d_spheres = nullptr; int32_t *d_shifts = nullptr;
+    SphGeom *d_geom = nullptr; SphShade *d_shade = nullptr;
+    uint32_t *d_rgba = nullptr; unsigned long long *d_tests = nullptr;
+    rt_stats stats = {};
+};
+
+namespace {
+void rt_free(rt_ctx *c)
+{
+    hipFree(c->d_spheres); hipFree(c->d_shifts); hipFree(c->d_geom); hipFree(c->d_shade); hipFree(c->d_rgba); hipFree(c->d_tests);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+}
+}  // namespace
+
+extern "C" {
+
+const char *rt_version(void) { return "mi355rt 0.1 gfx950"; }
+
+int rt_create(rt_ctx **out, const RtSphere *spheres, int32_t n_spheres, int32_t dim)
+{
+    if (!out || !spheres || n_spheres <= 0 || dim <= 0 || dim % TILE) return RT_ERR_ARG;
+    for (int i = 0; i < n_spheres; ++i) if (spheres[i].idx < 0 || spheres[i].idx >= n_spheres) return RT_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return RT_ERR_NO_DEVICE;
+    rt_ctx *c = new (std::nothrow) rt_ctx();
+    if (!c) return RT_ERR_ARG;
+    c->n = n_spheres; c->dim = dim;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess && r != hipSuccess) e = r; };
+    ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    ok(hipEventCreate(&c->ev0)); ok(hipEventCreate(&c->ev1));
+    ok(hipMalloc(&c->d_spheres, sizeof(RtSphere) * (size_t)n_spheres));
+    ok(hipMalloc(&c->d_shifts, sizeof(int32_t) * 4 * (size_t)n_spheres));
+    ok(hipMalloc(&c->d_geom, sizeof(SphGeom) * (size_t)n_spheres));
+    ok(hipMalloc(&c->d_shade, sizeof(SphShade) * (size_t)n_spheres));
+    ok(hipMalloc(&c->d_rgba, sizeof(uint32_t) * (size_t)dim * dim));
+    ok(hipMalloc(&c->d_tests, sizeof(unsigned long long)));
+    if (e == hipSuccess) ok(hipMemcpy(c->d_spheres, spheres, sizeof(RtSphere) * (size_t)n_spheres, hipMemcpyHostToDevice));
+    if (e != hipSuccess) { rt_free(c); delete c; return -(int)e; }
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx *c)
+{
+    if (!c) return;
+    hipStreamSynchronize(c->stream);
+    rt_free(c);
+    delete c;
+}
+
+int rt_set_spheres(rt_ctx *c, const RtSphere *spheres)
+{
+    if (!c || !spheres) return RT_ERR_ARG;
+    for (int i = 0; i < c->n; ++i) if (spheres[i].idx < 0 || spheres[i].idx >= c->n) return RT_ERR_ARG;
+    HIPCHK(hipMemcpy(c->d_spheres, spheres, sizeof(RtSphere) * (size_t)c->n, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int rt_set_mode(rt_ctx *c, int mode)
+{
+    if (!c || (mode != RT_MODE_BRUTE && mode != RT_MODE_BINNED)) return RT_ERR_ARG;
+    c->mode = mode;
+    return RT_OK;
+}
+
+int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, int32_t y0, int32_t y1, uint8_t *rgba_out)
+{
+    if (!c || !shifts4 || y0 < 0 || y1 > c->dim || y0 >= y1 || y0 % TILE || y1 % TILE) return RT_ERR_ARG;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(c->d_shifts, shifts4, sizeof(int32_t) * 4 * (size_t)c->n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->d_tests, 0, sizeof(unsigned long long), s));
+    HIPCHK(hipEventRecord(c->ev0, s));
+    k_prepare<<<(c->n + 255) / 256, 256, 0, s>>>(c->d_spheres, c->d_shifts, c->n, c->d_geom, c->d_shade);
+    const dim3 grid(c->dim / TILE, (y1 - y0) / TILE);
+    if (c->mode == RT_MODE_BINNED) {
+        const size_t lds = sizeof(int) * 4 * (size_t)((c->n + 3) / 4);
+        k_render<true><<<grid, THREADS, lds, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, y0 / TILE, c->d_rgba, c->d_tests);
+    } else {
+        k_render<false><<<grid, THREADS, 0, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, y0 / TILE, c->d_rgba, nullptr);
+    }
+    HIPCHK(hipEventRecord(c->ev1, s));
+    HIPCHK(hipGetLastError());
+    unsigned long long tests = 0;
+    HIPCHK(hipMemcpyAsync(&tests, c->d_tests, sizeof tests, hipMemcpyDeviceToHost, s));
+    if (rgba_out)                                                   // anime_ray.cu:128-131 D2H of the frame
+        HIPCHK(hipMemcpyAsync(rgba_out, c->d_rgba + (size_t)y0 * c->dim, sizeof(uint32_t) * (size_t)(y1 - y0) * c->dim, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.ms_render = ms;
+    c->stats.mode = (uint32_t)c->mode;
+    c->stats.sphere_tests = c->mode == RT_MODE_BINNED ? tests : (uint64_t)c->n * (uint64_t)c->dim * (uint64_t)(y1 - y0);
+    return RT_OK;
+}
+
+int rt_render(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, uint8_t *rgba_out)
+{
+    if (!c) return RT_ERR_ARG;
+    return rt_render_rows(c, shifts4, csx, csy, 0, c->dim, rgba_out);
+}
+
+int rt_init_shifts(int32_t n, int32_t *shifts4, double *angles)
+{
+    if (n < 0 || !shifts4) return RT_ERR_ARG;
+    for (int i = 0; i < n; ++i) {                                     // sphere.cuh:54-57
+        shifts4[4 * i] = shifts4[4 * i + 1] = 0;
+        shifts4[4 * i + 2] = (i % 5 + 1) * 5;
+        shifts4[4 * i + 3] = (i % 2) * 2 - 1;
+        if (angles) angles[i] = 0.0;
+    }
+    return RT_OK;
+}
+
+int rt_get_stats(rt_ctx *c, rt_stats *out) { if (!c || !out) return RT_ERR_ARG; *out = c->stats; return RT_OK; }
+
+}  // extern "C"

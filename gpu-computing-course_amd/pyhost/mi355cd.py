@@ -1,0 +1,231 @@
+"""ctypes binding of libmi355cd.so (include/mi355cd.h) -- plumbing for tests/ and bench.py.
+
+This is NOT a second implementation: every method is one call through the C ABI.  There is no CPU
+fallback; if the shared library is missing or no HIP device is present the constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmi355cd.so")
+
+CD_OK, CD_OVERFLOW = 0, 1
+CD_ERR_ARG, CD_ERR_ORDER, CD_ERR_NO_DEVICE, CD_ERR_INDEX = -1001, -1002, -1003, -1004
+CD_FRAME_REFERENCE, CD_FRAME_AUTO, CD_FRAME_CUSTOM = 0, 1, 2
+
+QUERY_DTYPE = np.dtype([("v", "<f8", (9,)), ("id", "<u4"), ("vidx", "<u4", (3,))])
+assert QUERY_DTYPE.itemsize == 88
+
+
+class CdStats(C.Structure):
+    _fields_ = [("ms_morton", C.c_float), ("ms_sort", C.c_float), ("ms_hierarchy", C.c_float),
+                ("ms_refit", C.c_float), ("ms_traverse", C.c_float), ("ms_check", C.c_float),
+                ("traverse_launches", C.c_uint32), ("stack_overflows", C.c_uint32),
+                ("n_pairs", C.c_uint64), ("pairs_tested", C.c_uint64), ("node_visits", C.c_uint64)]
+
+
+# every symbol include/mi355cd.h declares (tests check the library exports exactly these)
+EXPORTS = [
+    "cd_create", "cd_destroy", "cd_update_vertices", "cd_set_morton_frame", "cd_morton_sort",
+    "cd_build_hierarchy", "cd_refit_boxes", "cd_check_internal", "cd_check_leaves",
+    "cd_check_triangle_idx", "cd_find_collisions", "cd_self_collide", "cd_brute_force",
+    "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_num_triangles",
+    "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
+]
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not built: run __graft_entry__.build() (there is no CPU fallback)")
+    lib = C.CDLL(path)
+    vp, u32p, u64p, i32p, dp = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    lib.cd_create.argtypes = [C.POINTER(vp), vp, C.c_uint32, vp, vp, C.c_uint32]
+    lib.cd_destroy.argtypes = [vp]
+    lib.cd_destroy.restype = None
+    lib.cd_update_vertices.argtypes = [vp, vp]
+    lib.cd_set_morton_frame.argtypes = [vp, C.c_int, vp, vp]
+    lib.cd_morton_sort.argtypes = [vp]
+    lib.cd_build_hierarchy.argtypes = [vp, u32p]
+    lib.cd_refit_boxes.argtypes = [vp]
+    lib.cd_check_internal.argtypes = [vp, vp]
+    lib.cd_check_leaves.argtypes = [vp, vp]
+    lib.cd_check_triangle_idx.argtypes = [vp, C.c_uint32, u32p]
+    lib.cd_find_collisions.argtypes = [vp, vp, C.c_uint64, u64p]
+    lib.cd_self_collide.argtypes = [vp, vp, C.c_uint64, u64p]
+    lib.cd_brute_force.argtypes = [vp, C.c_int, vp, C.c_uint64, u64p]
+    lib.cd_test_pairs.argtypes = [vp, vp, C.c_uint64, vp]
+    lib.cd_export_keys.argtypes = [vp, vp, vp]
+    lib.cd_export_tree.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.cd_get_stats.argtypes = [vp, C.POINTER(CdStats)]
+    lib.cd_num_triangles.argtypes = [vp, u32p]
+    lib.cd_root_box.argtypes = [vp, vp]
+    lib.cd_pack_queries.argtypes = [vp, vp, vp, C.c_uint64, u64p]
+    lib.cd_find_collisions_queries.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]
+    lib.cd_version.restype = C.c_char_p
+    for name in EXPORTS:
+        if name not in ("cd_destroy", "cd_version"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class CdError(RuntimeError):
+    def __init__(self, fn: str, rc: int):
+        super().__init__(f"{fn} failed with status {rc}")
+        self.rc = rc
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class CollisionDetector:
+    """One cd_ctx.  Methods mirror the reference harness's stage order (main.cu:64-146)."""
+
+    def __init__(self, verts: np.ndarray, vidx: np.ndarray, ids: np.ndarray | None = None):
+        self.lib = load_library()
+        self.verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+        self.vidx = np.ascontiguousarray(vidx, dtype=np.uint32).reshape(-1, 3)
+        self.ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
+        self.nv, self.nt = self.verts.shape[0], self.vidx.shape[0]
+        self._ctx = C.c_void_p()
+        rc = self.lib.cd_create(C.byref(self._ctx), _ptr(self.verts), self.nv, _ptr(self.vidx), _ptr(self.ids), self.nt)
+        if rc != CD_OK:
+            self._ctx = C.c_void_p()
+            raise CdError("cd_create", rc)
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self.lib.cd_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, fn, rc, allow=(CD_OK,)):
+        if rc not in allow:
+            raise CdError(fn, rc)
+        return rc
+
+    # ---- stages
+    def set_morton_frame(self, mode=CD_FRAME_REFERENCE, offset=None, span=None):
+        off = None if offset is None else np.ascontiguousarray(offset, dtype=np.float64)
+        sp = None if span is None else np.ascontiguousarray(span, dtype=np.float64)
+        self._chk("cd_set_morton_frame", self.lib.cd_set_morton_frame(self._ctx, mode, _ptr(off), _ptr(sp)))
+
+    def update_vertices(self, verts):
+        v = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+        assert v.shape[0] == self.nv
+        self.verts = v
+        self._chk("cd_update_vertices", self.lib.cd_update_vertices(self._ctx, _ptr(v)))
+
+    def morton_sort(self):
+        self._chk("cd_morton_sort", self.lib.cd_morton_sort(self._ctx))
+
+    def build_hierarchy(self) -> int:
+        w = C.c_uint32(0)
+        self._chk("cd_build_hierarchy", self.lib.cd_build_hierarchy(self._ctx, C.byref(w)))
+        return w.value
+
+    def refit_boxes(self):
+        self._chk("cd_refit_boxes", self.lib.cd_refit_boxes(self._ctx))
+
+    def check_internal(self):
+        out = np.zeros(5, dtype=np.uint32)
+        self._chk("cd_check_internal", self.lib.cd_check_internal(self._ctx, _ptr(out)))
+        return out
+
+    def check_leaves(self):
+        out = np.zeros(4, dtype=np.uint32)
+        self._chk("cd_check_leaves", self.lib.cd_check_leaves(self._ctx, _ptr(out)))
+        return out
+
+    def check_triangle_idx(self, maxv: int) -> int:
+        out = C.c_uint32(0)
+        self._chk("cd_check_triangle_idx", self.lib.cd_check_triangle_idx(self._ctx, maxv, C.byref(out)))
+        return out.value
+
+    def _pairs_call(self, fn, name, cap, *pre):
+        n = C.c_uint64(0)
+        buf = np.zeros((max(cap, 0), 2), dtype=np.uint32) if cap else None
+        rc = fn(self._ctx, *pre, _ptr(buf), cap, C.byref(n))
+        self._chk(name, rc, allow=(CD_OK, CD_OVERFLOW))
+        got = min(n.value, cap)
+        return (buf[:got] if buf is not None else np.zeros((0, 2), dtype=np.uint32)), n.value, rc
+
+    def find_collisions(self, cap: int = 1 << 20):
+        return self._pairs_call(self.lib.cd_find_collisions, "cd_find_collisions", cap)
+
+    def self_collide(self, cap: int = 1 << 20):
+        return self._pairs_call(self.lib.cd_self_collide, "cd_self_collide", cap)
+
+    def brute_force(self, box_filter: bool = True, cap: int = 1 << 20):
+        return self._pairs_call(self.lib.cd_brute_force, "cd_brute_force", cap, 1 if box_filter else 0)
+
+    def test_pairs(self, pairs: np.ndarray) -> np.ndarray:
+        p = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        out = np.zeros(p.shape[0], dtype=np.uint8)
+        self._chk("cd_test_pairs", self.lib.cd_test_pairs(self._ctx, _ptr(p), p.shape[0], _ptr(out)))
+        return out
+
+    # ---- read-back
+    def export_keys(self):
+        keys = np.zeros(self.nt, dtype=np.uint64)
+        perm = np.zeros(self.nt, dtype=np.uint32)
+        self._chk("cd_export_keys", self.lib.cd_export_keys(self._ctx, _ptr(keys), _ptr(perm)))
+        return keys, perm
+
+    def export_tree(self, with_boxes: bool = True):
+        n = self.nt
+        parent = np.zeros(2 * n - 1, dtype=np.int32)
+        left = np.zeros(max(n - 1, 0), dtype=np.int32)
+        right = np.zeros(max(n - 1, 0), dtype=np.int32)
+        boxes = np.zeros((2 * n - 1, 6), dtype=np.float64) if with_boxes else None
+        bounded = np.zeros(max(n - 1, 0), dtype=np.uint32) if with_boxes else None
+        self._chk("cd_export_tree", self.lib.cd_export_tree(self._ctx, _ptr(parent), _ptr(left), _ptr(right), _ptr(boxes), _ptr(bounded)))
+        return parent, left, right, boxes, bounded
+
+    def stats(self) -> CdStats:
+        s = CdStats()
+        self._chk("cd_get_stats", self.lib.cd_get_stats(self._ctx, C.byref(s)))
+        return s
+
+    # ---- cross-rank pass
+    def root_box(self) -> np.ndarray:
+        b = np.zeros(6, dtype=np.float64)
+        self._chk("cd_root_box", self.lib.cd_root_box(self._ctx, _ptr(b)))
+        return b
+
+    def pack_queries_into(self, box, d_out_ptr: int, cap: int):
+        """Compact overlapping leaves into a caller-owned DEVICE buffer (e.g. torch tensor data_ptr)."""
+        b = np.ascontiguousarray(box, dtype=np.float64)
+        n = C.c_uint64(0)
+        rc = self.lib.cd_pack_queries(self._ctx, _ptr(b), C.c_void_p(d_out_ptr), cap, C.byref(n))
+        self._chk("cd_pack_queries", rc, allow=(CD_OK, CD_OVERFLOW))
+        return n.value, rc
+
+    def find_collisions_queries(self, d_queries_ptr: int, nq: int, cap: int = 1 << 20):
+        return self._pairs_call(self.lib.cd_find_collisions_queries, "cd_find_collisions_queries", cap,
+                                C.c_void_p(d_queries_ptr), C.c_uint64(nq))
+
+
+def version() -> str:
+    return load_library().cd_version().decode()

@@ -1,0 +1,151 @@
+/*
+ * mi355cd.h -- C ABI of libmi355cd.so: MI355X-native (HIP, gfx950) triangle-mesh collision detection.
+ *
+ * Drop-in boundary for the CollisionDetection hot path of Asichurter/GPU-Computing-Course.  The
+ * reference has no FFI; its boundary is the sequence of kernel call sites in CollisionDetection/main.cu.
+ * Each export below names the call site (reference file:line) it replaces.  Host pointers in, the
+ * library owns all device memory behind an opaque context; plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok; <0 = -(hipError_t) or one of CD_ERR_*; >0 = CD_OVERFLOW
+ *     (the reference prints and exits via HANDLE_ERROR, common/book.h:21-30; this library never exits).
+ *   - one context per device; a context is not thread-safe; different contexts are independent.
+ *   - all calls block until the stage has finished (the reference synchronises after every kernel,
+ *     main.cu:93,100,109,...).  Per-stage device times are measured with HIP events on the
+ *     context's own stream and read back through cd_get_stats().
+ *   - node ids: internal node i -> i (root = 0, main.cu:142 passes &internal_nodes[0]);
+ *     leaf j (Morton-sorted position) -> (n-1)+j.  -1 = NULL.
+ *   - boxes are {x1,x2,y1,y2,z1,z2} doubles, the field order of box.cuh:9.
+ */
+#ifndef MI355CD_H
+#define MI355CD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cd_ctx cd_ctx;
+
+enum {
+    CD_OK            = 0,
+    CD_OVERFLOW      = 1,      /* more pairs than cap_pairs; *n_pairs holds the true count          */
+    CD_ERR_ARG       = -1001,  /* null / zero-sized / inconsistent argument                         */
+    CD_ERR_ORDER     = -1002,  /* stage called before the stage it depends on                       */
+    CD_ERR_NO_DEVICE = -1003,  /* no HIP device: the library has no CPU fallback                    */
+    CD_ERR_INDEX     = -1004   /* a vertex index >= nv (checked at cd_create)                       */
+};
+
+/* Morton normalisation frame (morton.h:43-58 hard-codes one data set's bounds). */
+enum {
+    CD_FRAME_REFERENCE = 0,    /* the constants of morton.h:45,51,57 -> keys bit-identical to morton3D */
+    CD_FRAME_AUTO      = 1,    /* AABB of the centroids, computed on the device                        */
+    CD_FRAME_CUSTOM    = 2     /* caller-supplied offset[3], span[3]                                   */
+};
+
+typedef struct cd_stats {
+    /* device time of the last run of each stage, milliseconds (HIP events on the context stream) */
+    float ms_morton;           /* centroid + Morton keys                    (load_obj.h:89-101)      */
+    float ms_sort;             /* radix sort by key                         (load_obj.h:107)         */
+    float ms_hierarchy;        /* leaf fill + Karras hierarchy              (main.cu:92,99)          */
+    float ms_refit;            /* bottom-up AABB refit                      (main.cu:107)            */
+    float ms_traverse;         /* traversal + exact test                    (main.cu:142)            */
+    float ms_check;            /* verifier kernels                          (main.cu:115,123,131)    */
+    uint32_t traverse_launches;/* kernel launches inside the last traversal                         */
+    uint32_t stack_overflows;  /* queries that needed the deep-stack fallback in the last traversal */
+    uint64_t n_pairs;          /* contacts found by the last traversal      (main.cu:145 test_val)   */
+    uint64_t pairs_tested;     /* (query, leaf) pairs with strictly overlapping AABBs                */
+    uint64_t node_visits;      /* internal nodes visited                                             */
+} cd_stats;
+
+/* main.cu:78-88  cudaMalloc + cudaMemcpy of vec3f[V], Triangle[N], u64[N], Node[N], Node[N-1].
+ * verts_xyz: nv x 3 doubles (vec3f.cuh:14-23).  vidx3: nt x 3 vertex indices (triangle.cuh:9).
+ * ids: nt triangle IDs (triangle.cuh:6; load_obj.h:94 uses the face ordinal) or NULL for 0..nt-1. */
+int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv,
+              const uint32_t *vidx3, const uint32_t *ids, uint32_t nt);
+void cd_destroy(cd_ctx *ctx);                                               /* main.cu:156-163 */
+
+/* Replace vertex positions (same nv, same topology): the per-frame re-run of a cloth simulation. */
+int cd_update_vertices(cd_ctx *ctx, const double *verts_xyz);
+
+/* morton.h:43-58: choose the normalisation frame (default CD_FRAME_REFERENCE). offset/span are
+ * read only for CD_FRAME_CUSTOM. */
+int cd_set_morton_frame(cd_ctx *ctx, int mode, const double offset[3], const double span[3]);
+
+/* load_obj.h:89-107: centroid + morton3D per face, then sort_by_key(mortons, triangles) -- on the GPU. */
+int cd_morton_sort(cd_ctx *ctx);
+
+/* main.cu:92 fillLeafNodes + main.cu:99 generateHierarchyParallel.  *parent_wrong_num is the counter
+ * printed at main.cu:103 (children that already had a parent; 0 for a correct tree). May be NULL. */
+int cd_build_hierarchy(cd_ctx *ctx, uint32_t *parent_wrong_num);
+
+/* main.cu:107 calBoundingBox: leaf boxes (box.cuh:13-22) and bottom-up merge (box.cuh:24-32). */
+int cd_refit_boxes(cd_ctx *ctx);
+
+/* main.cu:115 checkInternalNodes: out = {nullParentNum, wrongBoundNum, nullChildNum, notInternalCount,
+ * uninitBoxCount} in the order printed at main.cu:119. */
+int cd_check_internal(cd_ctx *ctx, uint32_t out[5]);
+/* main.cu:123 checkLeafNodes: out = {nullParentNum, nullTriangleNum, notLeafCount, illegalBoxCount}
+ * (main.cu:127).  Triangle::selfCheck's hard-coded 632674 (triangle.cuh:13) is the context's nv. */
+int cd_check_leaves(cd_ctx *ctx, uint32_t out[4]);
+/* main.cu:131 checkTriangleIdx(leaves, vs, n, maxv, count). */
+int cd_check_triangle_idx(cd_ctx *ctx, uint32_t maxv, uint32_t *out);
+
+/* main.cu:142-146 findCollisions + D2H of count and pair list.  pairs: cap_pairs x 2 uint32,
+ * interleaved (smaller ID, larger ID), unordered (atomicAdd append, collision.cuh:40-42).
+ * pairs may be NULL with cap_pairs 0 (count only).  Returns CD_OVERFLOW when *n_pairs > cap_pairs
+ * (the reference writes past its 500-pair buffer instead, main.cu:81). */
+int cd_find_collisions(cd_ctx *ctx, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs);
+
+/* Fused convenience call: cd_morton_sort -> cd_build_hierarchy -> cd_refit_boxes -> cd_find_collisions
+ * queued back to back on the context stream with a single host synchronisation at the end. */
+int cd_self_collide(cd_ctx *ctx, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs);
+
+/* check.cuh:117-141 checkDirectComp: O(N^2) all-pairs on the device, no tree.  box_filter != 0 also
+ * requires the strict leaf-AABB overlap the BVH path applies (collision.cuh:31-36). Same output format
+ * as cd_find_collisions. */
+int cd_brute_force(cd_ctx *ctx, int box_filter, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs);
+
+/* tri_contact.cuh:80-87 checkTriangleContactHelper over an explicit list of triangle-index pairs
+ * (original triangle order), including the neighborCount<1 gate of collision.cuh:38.  out[k] = 0/1. */
+int cd_test_pairs(cd_ctx *ctx, const uint32_t *pairs, uint64_t n_pairs, uint8_t *out);
+
+/* Read-back for verification (the reference's tree is device pointers and cannot be exported). Any
+ * pointer may be NULL.  keys/perm: nt entries, sorted order (perm[j] = original triangle of leaf j).
+ * parent: 2nt-1; left/right: nt-1; boxes: (2nt-1) x 6; bounded: nt-1 (Node::bounded, bvh.cuh:28). */
+int cd_export_keys(cd_ctx *ctx, uint64_t *keys, uint32_t *perm);
+int cd_export_tree(cd_ctx *ctx, int32_t *parent, int32_t *left, int32_t *right, double *boxes,
+                   uint32_t *bounded);
+
+int cd_get_stats(cd_ctx *ctx, cd_stats *out);
+int cd_num_triangles(cd_ctx *ctx, uint32_t *nt);
+
+/* ---- multi-GPU cross-rank pass (new work defined by the north star; no reference call site) ----
+ * Query record, 88 bytes, device resident: the three vertices, the triangle ID and its three GLOBAL
+ * vertex indices (neighborCount, triangle.cuh:18-30, compares indices). */
+typedef struct cd_query {
+    double   v[9];
+    uint32_t id;
+    uint32_t vidx[3];
+} cd_query;
+
+/* AABB of the whole local tree (box of internal node 0). */
+int cd_root_box(cd_ctx *ctx, double box[6]);
+/* Compact the local leaves whose AABB strictly overlaps `box` (box.cuh:40-43) into d_out, a DEVICE
+ * buffer of cap records owned by the caller (e.g. a torch tensor handed to RCCL). *n = number found
+ * (may exceed cap -> CD_OVERFLOW, nothing beyond cap is written). */
+int cd_pack_queries(cd_ctx *ctx, const double box[6], void *d_out, uint64_t cap, uint64_t *n);
+/* Traverse nq external queries (DEVICE buffer of cd_query) against the local tree; a pair
+ * (q.id, leaf.id) is reported when q.id < leaf.id (tri_contact.cuh:81), no shared vertex index and
+ * the exact test passes.  Output as cd_find_collisions. */
+int cd_find_collisions_queries(cd_ctx *ctx, const void *d_queries, uint64_t nq,
+                               uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs);
+
+/* Library / build identification: "mi355cd <version> gfx950". */
+const char *cd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355CD_H */

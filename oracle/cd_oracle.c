@@ -1,0 +1,579 @@
+/*
+ * cd_oracle.c -- CPU ORACLE for the CollisionDetection hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is a plain-C restatement of the reference algorithm (Asichurter/GPU-Computing-Course,
+ * CollisionDetection/).  It is the *checker*: only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The shipped product (libmi355cd.so) never links,
+ * loads or calls anything in this directory.
+ *
+ * Pinning status: the reference itself is CUDA C++ (needs <cuda_runtime.h>, Thrust, nvcc) and is
+ * unbuildable in this image without writing stand-in headers, which this project does not do.
+ * The oracle is therefore pinned by (i) the reference's own known-answer inputs
+ * (check.cuh:19-27 key set; morton.h masks), (ii) outputs of the reference recorded in SURVEY.md
+ * when the survey ran the reference sources (range/split table, morton3D anchors, pair counts on
+ * seeded soups), and (iii) an independent O(N^2) brute force (check.cuh:117-141 restated).
+ * See tests/test_oracle_pins.py.
+ *
+ * Build: gcc -O2 -std=c99 -ffp-contract=off -fPIC -shared (no FMA contraction: every decision
+ * below is an FP64 compare whose operands must round exactly like the reference's host twin).
+ *
+ * Node numbering (index based, replaces the reference's pointer-linked Node, bvh.cuh:25-43):
+ *   internal node i  -> id i            (0 .. n-2), root = 0        (bvh.cuh:162 "Node 0 is the root")
+ *   leaf j           -> id (n-1) + j    (j = 0 .. n-1, Morton-sorted order)
+ * Box layout: {x1,x2,y1,y2,z1,z2} exactly as box.cuh:9.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ mathop.cuh:17-44 */
+static inline double fmax2_(double a, double b) { return (a > b) ? a : b; }   /* mathop.cuh:17-19 */
+static inline double fmin2_(double a, double b) { return (a < b) ? a : b; }   /* mathop.cuh:21-23 */
+static inline double fmax3_(double a, double b, double c)                      /* mathop.cuh:30-36 */
+{ double t = a; if (b > t) t = b; if (c > t) t = c; return t; }
+static inline double fmin3_(double a, double b, double c)                      /* mathop.cuh:38-44 */
+{ double t = a; if (b < t) t = b; if (c < t) t = c; return t; }
+
+/* ------------------------------------------------------------------ morton.h:7-29 */
+uint64_t orc_expand64(uint64_t v)
+{
+    v &= 0x1fffffULL;
+    v = (v | v << 32) & 0x1f00000000ffffULL;
+    v = (v | v << 16) & 0x1f0000ff0000ffULL;
+    v = (v | v << 8)  & 0x100f00f00f00f00fULL;
+    v = (v | v << 4)  & 0x10c30c30c30c30c3ULL;
+    v = (v | v << 2)  & 0x1249249249249249ULL;
+    return v;
+}
+
+/* The reference's hard-coded normalisation frame, morton.h:43-58. */
+const double ORC_REF_OFF[3]  = { 0.004501, -0.476622, -0.381965 };
+const double ORC_REF_SPAN[3] = { 3.08, 0.76, 2.36 };
+
+/* double -> u64 as the reference does implicitly at morton.h:80-82.  Negative / NaN inputs are
+ * undefined behaviour in the reference (its assert is compiled out); this project defines them
+ * as 0 and values >= 2^63 as 2^63-1 -- the GPU path uses the same rule. */
+static inline uint64_t d2u64(double e)
+{
+    if (!(e > 0.0)) return 0;
+    if (e >= 9223372036854775808.0) return 0x7fffffffffffffffULL;
+    return (uint64_t)e;
+}
+
+/* morton.h:70-89 with the frame made a parameter.  (x - off)/span * 2^20, truncate, interleave. */
+uint64_t orc_morton3d(double x, double y, double z, const double off[3], const double span[3])
+{
+    const unsigned int scale = 1048576;
+    double ex = ((x - off[0]) / span[0]) * scale;
+    double ey = ((y - off[1]) / span[1]) * scale;
+    double ez = ((z - off[2]) / span[2]) * scale;
+    uint64_t xx = orc_expand64(d2u64(ex));
+    uint64_t yy = orc_expand64(d2u64(ey));
+    uint64_t zz = orc_expand64(d2u64(ez));
+    return (xx << 2) | (yy << 1) | zz;
+}
+
+/* load_obj.h:89-101: centroid = (p1+p2+p3)/3 per axis, then morton3D.  centroids may be NULL. */
+void orc_centroid_morton(const double *verts, const uint32_t *vidx, uint32_t n,
+                         const double off[3], const double span[3],
+                         uint64_t *keys, double *centroids)
+{
+    for (uint32_t t = 0; t < n; ++t) {
+        const double *p1 = verts + 3 * (size_t)vidx[3 * t + 0];
+        const double *p2 = verts + 3 * (size_t)vidx[3 * t + 1];
+        const double *p3 = verts + 3 * (size_t)vidx[3 * t + 2];
+        double ax = (p1[0] + p2[0] + p3[0]) / 3;
+        double ay = (p1[1] + p2[1] + p3[1]) / 3;
+        double az = (p1[2] + p2[2] + p3[2]) / 3;
+        keys[t] = orc_morton3d(ax, ay, az, off, span);
+        if (centroids) { centroids[3 * t] = ax; centroids[3 * t + 1] = ay; centroids[3 * t + 2] = az; }
+    }
+}
+
+/* load_obj.h:107 thrust::sort_by_key(mortons, triangles) on host iterators: a stable ascending
+ * sort by key.  LSD radix, 8 x 8 bits; perm[i] = original index of the i-th smallest key. */
+void orc_sort_by_key(uint64_t *keys, uint32_t *perm, uint32_t n)
+{
+    uint64_t *k2 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+    uint32_t *p2 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n);
+    for (uint32_t i = 0; i < n; ++i) perm[i] = i;
+    uint64_t *ks = keys, *kd = k2; uint32_t *ps = perm, *pd = p2;
+    for (int pass = 0; pass < 8; ++pass) {
+        size_t cnt[257]; memset(cnt, 0, sizeof cnt);
+        int sh = pass * 8;
+        for (uint32_t i = 0; i < n; ++i) cnt[((ks[i] >> sh) & 255) + 1]++;
+        for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+        for (uint32_t i = 0; i < n; ++i) { size_t o = cnt[(ks[i] >> sh) & 255]++; kd[o] = ks[i]; pd[o] = ps[i]; }
+        uint64_t *tk = ks; ks = kd; kd = tk; uint32_t *tp = ps; ps = pd; pd = tp;
+    }
+    /* 8 passes: result is back in keys/perm */
+    free(k2); free(p2);
+}
+
+/* ------------------------------------------------------------------ bvh.cuh:48 */
+/* CUDA __clzll(0) == 64. */
+int orc_clz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
+
+/* delta macro, bvh.cuh:48.  tiebreak == 0: literal reference (equal keys -> 64, no index
+ * tie-break, the reference's duplicate-key defect).  tiebreak != 0: equal keys compare by index
+ * (64 + clz32(i^j)), the standard Karras fix; identical to the literal form on unique keys. */
+static inline int delta_(const uint64_t *keys, int n, int i, int j, int tiebreak)
+{
+    if (!(j >= 0 && j < n)) return -1;
+    uint64_t x = keys[i] ^ keys[j];
+    if (x || !tiebreak) return orc_clz64(x);
+    uint32_t y = (uint32_t)i ^ (uint32_t)j;
+    return 64 + (y ? __builtin_clz(y) : 32);
+}
+int orc_delta(const uint64_t *keys, int n, int i, int j, int tiebreak) { return delta_(keys, n, i, j, tiebreak); }
+
+/* findSplit, bvh.cuh:57-98 (cpu.cuh:22-63 is the same code). */
+int orc_find_split(const uint64_t *keys, int n, int first, int last, int tiebreak)
+{
+    uint64_t firstCode = keys[first], lastCode = keys[last];
+    if (!tiebreak) {
+        if (firstCode == lastCode) return (first + last) >> 1;             /* bvh.cuh:66-67 */
+    }
+    int commonPrefix = delta_(keys, n, first, last, tiebreak);             /* bvh.cuh:72 */
+    int split = first;
+    int step = last - first;
+    do {
+        step = (step + 1) >> 1;
+        int newSplit = split + step;
+        if (newSplit < last) {
+            int splitPrefix = delta_(keys, n, first, newSplit, tiebreak);  /* bvh.cuh:88-89 */
+            if (splitPrefix > commonPrefix) split = newSplit;
+        }
+    } while (step > 1);
+    return split;
+}
+
+/* determineRange, bvh.cuh:100-123 (cpu.cuh:65-87). */
+void orc_determine_range(const uint64_t *keys, int n, int i, int tiebreak, int *first, int *last)
+{
+    int d = (delta_(keys, n, i, i + 1, tiebreak) - delta_(keys, n, i, i - 1, tiebreak)) >= 0 ? 1 : -1;
+    int delta_min = delta_(keys, n, i, i - d, tiebreak);
+    int mlen = 2;
+    while (delta_(keys, n, i, i + mlen * d, tiebreak) > delta_min) mlen <<= 1;
+    int l = 0;
+    for (int t = mlen >> 1; t >= 1; t >>= 1)
+        if (delta_(keys, n, i, i + (l + t) * d, tiebreak) > delta_min) l += t;
+    int j = i + l * d;
+    *first = i < j ? i : j;
+    *last  = i < j ? j : i;
+}
+
+/* generateHierarchyParallel, bvh.cuh:146-199 (cpu.cuh:110-165), index based.
+ * left/right: n-1 entries (unified node ids); parent: 2n-1 entries, -1 = NULL.
+ * parent_wrong counts children whose parent was already set (bvh.cuh:192,194). */
+void orc_build_hierarchy(const uint64_t *keys, int n, int tiebreak,
+                         int32_t *left, int32_t *right, int32_t *parent,
+                         int32_t *range_first, int32_t *range_last, uint32_t *parent_wrong)
+{
+    for (int i = 0; i < 2 * n - 1; ++i) parent[i] = -1;
+    uint32_t wrong = 0;
+    for (int idx = 0; idx < n - 1; ++idx) {
+        int first, last;
+        orc_determine_range(keys, n, idx, tiebreak, &first, &last);
+        int split = orc_find_split(keys, n, first, last, tiebreak);
+        int32_t a = (split == first)    ? (n - 1) + split       : split;        /* bvh.cuh:176-179 */
+        int32_t b = (split + 1 == last) ? (n - 1) + (split + 1) : split + 1;    /* bvh.cuh:183-186 */
+        left[idx] = a; right[idx] = b;
+        if (parent[a] != -1) wrong++;
+        parent[a] = idx;
+        if (parent[b] != -1) wrong++;
+        parent[b] = idx;
+        if (range_first) range_first[idx] = first;
+        if (range_last)  range_last[idx]  = last;
+    }
+    if (parent_wrong) *parent_wrong = wrong;
+}
+
+/* ------------------------------------------------------------------ box.cuh */
+/* Box::set, box.cuh:13-22 */
+static inline void box_set(double *b, const double *v1, const double *v2, const double *v3)
+{
+    b[0] = fmin3_(v1[0], v2[0], v3[0]); b[1] = fmax3_(v1[0], v2[0], v3[0]);
+    b[2] = fmin3_(v1[1], v2[1], v3[1]); b[3] = fmax3_(v1[1], v2[1], v3[1]);
+    b[4] = fmin3_(v1[2], v2[2], v3[2]); b[5] = fmax3_(v1[2], v2[2], v3[2]);
+}
+/* Box::merge, box.cuh:24-32 */
+static inline void box_merge(double *o, const double *a, const double *b)
+{
+    o[0] = fmin2_(a[0], b[0]); o[1] = fmax2_(a[1], b[1]);
+    o[2] = fmin2_(a[2], b[2]); o[3] = fmax2_(a[3], b[3]);
+    o[4] = fmin2_(a[4], b[4]); o[5] = fmax2_(a[5], b[5]);
+}
+/* checkBoxOverlap, box.cuh:40-43: strict, product form. */
+int orc_box_overlap(const double *a, const double *b)
+{
+    if ((a[0] - b[1]) * (b[0] - a[1]) > 0 && (a[2] - b[3]) * (b[2] - a[3]) > 0 &&
+        (a[4] - b[5]) * (b[4] - a[5]) > 0) return 1;
+    return 0;
+}
+
+/* calBoundingBox, bvh.cuh:258-285, sequential twin cpu.cuh:167-194.
+ * perm[j] = triangle stored in leaf j.  boxes: (2n-1) x 6.  bounded: n-1 counters (must end 2).
+ * child_count: 2n-1 (bvh.cuh:265,279), may be NULL. */
+void orc_refit(const double *verts, const uint32_t *vidx, const uint32_t *perm, int n,
+               const int32_t *left, const int32_t *right, const int32_t *parent,
+               double *boxes, uint32_t *bounded, uint32_t *child_count)
+{
+    for (int i = 0; i < n - 1; ++i) bounded[i] = 0;
+    for (int j = 0; j < n; ++j) {
+        uint32_t t = perm[j];
+        int node = (n - 1) + j;
+        box_set(boxes + 6 * (size_t)node, verts + 3 * (size_t)vidx[3 * t], verts + 3 * (size_t)vidx[3 * t + 1],
+                verts + 3 * (size_t)vidx[3 * t + 2]);
+        if (child_count) child_count[node] = 1;
+        int cur = parent[node];
+        while (cur != -1) {
+            if (bounded[cur]++ == 0) break;
+            box_merge(boxes + 6 * (size_t)cur, boxes + 6 * (size_t)left[cur], boxes + 6 * (size_t)right[cur]);
+            if (child_count) child_count[cur] = 1 + child_count[left[cur]] + child_count[right[cur]];
+            cur = parent[cur];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ triangle.cuh:18-30 */
+int orc_neighbor_count(const uint32_t *a, const uint32_t *b)
+{
+    int c = 0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c += (a[i] == b[j]);
+    return c;
+}
+
+/* ------------------------------------------------------------------ vec3f.cuh / tri_contact.cuh */
+typedef struct { double x, y, z; } v3;
+static inline v3 v3sub(v3 a, v3 b) { v3 r = { a.x - b.x, a.y - b.y, a.z - b.z }; return r; }      /* vec3f.cuh:100-103 */
+static inline v3 v3neg(v3 a) { v3 r = { -a.x, -a.y, -a.z }; return r; }                           /* vec3f.cuh:91-93 */
+static inline v3 v3cross(v3 a, v3 b)                                                               /* vec3f.cuh:118-121 */
+{ v3 r = { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; return r; }
+static inline double v3dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }               /* vec3f.cuh:123-125 */
+
+/* project3, vec3f.cuh:257-270 */
+static inline int project3(v3 ax, v3 p1, v3 p2, v3 p3)
+{
+    double P1 = v3dot(ax, p1), P2 = v3dot(ax, p2), P3 = v3dot(ax, p3);
+    double mx1 = fmax3_(P1, P2, P3), mn1 = fmin3_(P1, P2, P3);
+    if (mn1 > 0) return 0;
+    if (0 > mx1) return 0;
+    return 1;
+}
+/* project6, vec3f.cuh:272-291 */
+static inline int project6(v3 ax, v3 p1, v3 p2, v3 p3, v3 q1, v3 q2, v3 q3)
+{
+    double P1 = v3dot(ax, p1), P2 = v3dot(ax, p2), P3 = v3dot(ax, p3);
+    double Q1 = v3dot(ax, q1), Q2 = v3dot(ax, q2), Q3 = v3dot(ax, q3);
+    double mx1 = fmax3_(P1, P2, P3), mn1 = fmin3_(P1, P2, P3);
+    double mx2 = fmax3_(Q1, Q2, Q3), mn2 = fmin3_(Q1, Q2, Q3);
+    if (mn1 > mx2) return 0;
+    if (mn2 > mx1) return 0;
+    return 1;
+}
+
+/* checkTriangleContact, tri_contact.cuh:19-78.  P*,Q*: 3 doubles each. */
+int orc_tri_contact(const double *P1, const double *P2, const double *P3,
+                    const double *Q1, const double *Q2, const double *Q3)
+{
+    v3 vP1 = { P1[0], P1[1], P1[2] }, vP2 = { P2[0], P2[1], P2[2] }, vP3 = { P3[0], P3[1], P3[2] };
+    v3 vQ1 = { Q1[0], Q1[1], Q1[2] }, vQ2 = { Q2[0], Q2[1], Q2[2] }, vQ3 = { Q3[0], Q3[1], Q3[2] };
+    v3 p1 = { 0, 0, 0 };                                   /* tri_contact.cuh:21 default ctor */
+    v3 p2 = v3sub(vP2, vP1), p3 = v3sub(vP3, vP1);
+    v3 q1 = v3sub(vQ1, vP1), q2 = v3sub(vQ2, vP1), q3 = v3sub(vQ3, vP1);
+    v3 e1 = v3sub(p2, p1), e2 = v3sub(p3, p2), e3 = v3sub(p1, p3);
+    v3 f1 = v3sub(q2, q1), f2 = v3sub(q3, q2), f3 = v3sub(q1, q3);
+    v3 n1 = v3cross(e1, e2), m1 = v3cross(f1, f2);
+    v3 g1 = v3cross(e1, n1), g2 = v3cross(e2, n1), g3 = v3cross(e3, n1);
+    v3 h1 = v3cross(f1, m1), h2 = v3cross(f2, m1), h3 = v3cross(f3, m1);
+    v3 ef11 = v3cross(e1, f1), ef12 = v3cross(e1, f2), ef13 = v3cross(e1, f3);
+    v3 ef21 = v3cross(e2, f1), ef22 = v3cross(e2, f2), ef23 = v3cross(e2, f3);
+    v3 ef31 = v3cross(e3, f1), ef32 = v3cross(e3, f2), ef33 = v3cross(e3, f3);
+
+    if (!project3(n1, q1, q2, q3)) return 0;
+    if (!project3(m1, v3neg(q1), v3sub(p2, q1), v3sub(p3, q1))) return 0;
+    if (!project6(ef11, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(ef12, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(ef13, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(ef21, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(ef22, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(ef23, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(ef31, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(ef32, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(ef33, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(g1, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(g2, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(g3, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(h1, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(h2, p1, p2, p3, q1, q2, q3)) return 0;
+    if (!project6(h3, p1, p2, p3, q1, q2, q3)) return 0;
+    return 1;
+}
+
+/* checkTriangleContactHelper, tri_contact.cuh:80-87: ID rule, then gather 6 vertices. */
+int orc_tri_contact_helper(uint32_t id_a, const uint32_t *va, uint32_t id_b, const uint32_t *vb,
+                           const double *verts)
+{
+    if (id_a >= id_b) return 0;
+    return orc_tri_contact(verts + 3 * (size_t)va[0], verts + 3 * (size_t)va[1], verts + 3 * (size_t)va[2],
+                           verts + 3 * (size_t)vb[0], verts + 3 * (size_t)vb[1], verts + 3 * (size_t)vb[2]);
+}
+
+/* Batch form used to check the GPU pair-test kernel: out[k] = helper(pair k). */
+void orc_tri_contact_batch(const double *verts, const uint32_t *vidx, const uint32_t *ids,
+                           const uint32_t *pairs, uint64_t np, uint8_t *out)
+{
+    for (uint64_t k = 0; k < np; ++k) {
+        uint32_t a = pairs[2 * k], b = pairs[2 * k + 1];
+        uint32_t ia = ids ? ids[a] : a, ib = ids ? ids[b] : b;
+        out[k] = (uint8_t)(orc_neighbor_count(vidx + 3 * (size_t)a, vidx + 3 * (size_t)b) < 1 &&
+                           orc_tri_contact_helper(ia, vidx + 3 * (size_t)a, ib, vidx + 3 * (size_t)b, verts) > 0);
+    }
+}
+
+/* ------------------------------------------------------------------ collision.cuh:19-88 */
+typedef struct {
+    uint64_t n_pairs;        /* contacts found (count, collision.cuh:40)                      */
+    uint64_t pairs_tested;   /* (query, leaf) pairs whose AABBs strictly overlap  */
+    uint64_t node_visits;    /* internal nodes popped                                         */
+    uint32_t max_stack;      /* deepest stack pointer reached (reference stack is 32)         */
+    uint32_t overflow;       /* pairs beyond cap (not written)                                */
+} orc_stats;
+
+#define ORC_STACK 256
+
+/* findCollisionIterative for one external query (collision.cuh:19-71).
+ * q_id/q_vidx/q_box describe the query triangle; tree triangles are perm/ids/vidx. */
+static void traverse_one(uint32_t q_id, const uint32_t *q_vidx, const double *q_box,
+                         const double *verts, const uint32_t *vidx, const uint32_t *ids,
+                         const uint32_t *perm, int n,
+                         const int32_t *left, const int32_t *right, const double *boxes,
+                         uint32_t *pairs, uint64_t cap, orc_stats *st)
+{
+    int32_t stack[ORC_STACK];
+    unsigned sptr = 0;
+    stack[sptr++] = -1;
+    int32_t node = 0;                                           /* root = internal[0], main.cu:142 */
+    if (n == 1) {                                               /* degenerate: a single leaf, no internal node */
+        node = -1;
+    }
+    while (node != -1) {
+        st->node_visits++;
+        int32_t ch[2] = { left[node], right[node] };
+        int ov[2] = { orc_box_overlap(q_box, boxes + 6 * (size_t)ch[0]),
+                      orc_box_overlap(q_box, boxes + 6 * (size_t)ch[1]) };
+        for (int s = 0; s < 2; ++s) {                           /* L then R, collision.cuh:35,52 */
+            if (ov[s] > 0) {
+                if (ch[s] >= n - 1) {                           /* isLeaf */
+                    st->pairs_tested++;
+                    uint32_t t = perm[ch[s] - (n - 1)];
+                    const uint32_t *tv = vidx + 3 * (size_t)t;
+                    if (orc_neighbor_count(q_vidx, tv) < 1) {
+                        uint32_t tid = ids ? ids[t] : t;
+                        if (orc_tri_contact_helper(q_id, q_vidx, tid, tv, verts) > 0) {
+                            uint64_t cur = st->n_pairs++;
+                            if (cur < cap) { pairs[2 * cur] = q_id; pairs[2 * cur + 1] = tid; }
+                            else st->overflow++;
+                        }
+                    }
+                } else {
+                    if (sptr < ORC_STACK) stack[sptr++] = ch[s];
+                    if (sptr > st->max_stack) st->max_stack = sptr;
+                }
+            }
+        }
+        node = stack[--sptr];
+    }
+}
+
+/* findCollisions, collision.cuh:73-88 / cpu.cuh:247-271: every leaf queries the whole tree. */
+void orc_find_collisions(const double *verts, const uint32_t *vidx, const uint32_t *ids,
+                         const uint32_t *perm, int n,
+                         const int32_t *left, const int32_t *right, const double *boxes,
+                         uint32_t *pairs, uint64_t cap, orc_stats *st)
+{
+    memset(st, 0, sizeof *st);
+    for (int j = 0; j < n; ++j) {
+        uint32_t t = perm[j];
+        traverse_one(ids ? ids[t] : t, vidx + 3 * (size_t)t, boxes + 6 * (size_t)((n - 1) + j),
+                     verts, vidx, ids, perm, n, left, right, boxes, pairs, cap, st);
+    }
+}
+
+/* External queries against a tree (the cross-rank pass of SURVEY 8e uses the same traversal):
+ * q_verts: nq x 9 doubles (three vertices), q_vidx: nq x 3 (global vertex ids), q_ids: nq. */
+void orc_find_collisions_queries(const double *q_verts, const uint32_t *q_vidx, const uint32_t *q_ids, int nq,
+                                 const double *verts, const uint32_t *vidx, const uint32_t *ids,
+                                 const uint32_t *perm, int n,
+                                 const int32_t *left, const int32_t *right, const double *boxes,
+                                 uint32_t *pairs, uint64_t cap, orc_stats *st)
+{
+    memset(st, 0, sizeof *st);
+    /* The exact test reads vertices through indices into one array (tri_contact.cuh:83-84); give the
+     * query its three vertices through a private 3-entry array and local indices. */
+    for (int q = 0; q < nq; ++q) {
+        double qb[6];
+        box_set(qb, q_verts + 9 * (size_t)q, q_verts + 9 * (size_t)q + 3, q_verts + 9 * (size_t)q + 6);
+        int32_t stack[ORC_STACK]; unsigned sptr = 0; stack[sptr++] = -1;
+        int32_t node = (n == 1) ? -1 : 0;
+        while (node != -1) {
+            st->node_visits++;
+            int32_t ch[2] = { left[node], right[node] };
+            int ov[2] = { orc_box_overlap(qb, boxes + 6 * (size_t)ch[0]), orc_box_overlap(qb, boxes + 6 * (size_t)ch[1]) };
+            for (int s = 0; s < 2; ++s) if (ov[s] > 0) {
+                if (ch[s] >= n - 1) {
+                    st->pairs_tested++;
+                    uint32_t t = perm[ch[s] - (n - 1)];
+                    const uint32_t *tv = vidx + 3 * (size_t)t;
+                    if (orc_neighbor_count(q_vidx + 3 * (size_t)q, tv) < 1) {
+                        uint32_t tid = ids ? ids[t] : t;
+                        if (q_ids[q] < tid &&
+                            orc_tri_contact(q_verts + 9 * (size_t)q, q_verts + 9 * (size_t)q + 3, q_verts + 9 * (size_t)q + 6,
+                                            verts + 3 * (size_t)tv[0], verts + 3 * (size_t)tv[1], verts + 3 * (size_t)tv[2]) > 0) {
+                            uint64_t cur = st->n_pairs++;
+                            if (cur < cap) { pairs[2 * cur] = q_ids[q]; pairs[2 * cur + 1] = tid; }
+                            else st->overflow++;
+                        }
+                    }
+                } else {
+                    if (sptr < ORC_STACK) stack[sptr++] = ch[s];
+                    if (sptr > st->max_stack) st->max_stack = sptr;
+                }
+            }
+            node = stack[--sptr];
+        }
+    }
+}
+
+/* checkDirectComp, check.cuh:117-141: O(N^2) all-pairs, no tree.  box_filter != 0 additionally
+ * requires the strict leaf-AABB overlap that the BVH path applies implicitly (collision.cuh:31-36),
+ * which is the set the traversal must reproduce; box_filter == 0 is the literal check.cuh count. */
+uint64_t orc_brute_force(const double *verts, const uint32_t *vidx, const uint32_t *ids, int n,
+                         int box_filter, uint32_t *pairs, uint64_t cap, uint64_t *tested)
+{
+    double *bx = (double *)malloc(sizeof(double) * 6 * (size_t)n);
+    for (int i = 0; i < n; ++i)
+        box_set(bx + 6 * (size_t)i, verts + 3 * (size_t)vidx[3 * i], verts + 3 * (size_t)vidx[3 * i + 1],
+                verts + 3 * (size_t)vidx[3 * i + 2]);
+    uint64_t cnt = 0, tst = 0;
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) {
+            if (box_filter && !orc_box_overlap(bx + 6 * (size_t)i, bx + 6 * (size_t)j)) continue;
+            tst++;
+            if (orc_neighbor_count(vidx + 3 * (size_t)i, vidx + 3 * (size_t)j) < 1) {
+                uint32_t ia = ids ? ids[i] : (uint32_t)i, ib = ids ? ids[j] : (uint32_t)j;
+                if (orc_tri_contact_helper(ia, vidx + 3 * (size_t)i, ib, vidx + 3 * (size_t)j, verts)) {
+                    if (cnt < cap) { pairs[2 * cnt] = ia; pairs[2 * cnt + 1] = ib; }
+                    cnt++;
+                }
+            }
+        }
+    }
+    if (tested) *tested = tst;
+    free(bx);
+    return cnt;
+}
+
+/* ------------------------------------------------------------------ check.cuh:64-96, 29-50 */
+/* checkInternalNodes: out = {nullParentNum, wrongBoundNum, nullChildNum, notInternalCount, uninitBoxCount}
+ * in the order main.cu:115,119 prints them.  box_init: per-node "init" flag (box.cuh:21,31). */
+void orc_check_internal(int n, const int32_t *left, const int32_t *right, const int32_t *parent,
+                        const uint32_t *bounded, const uint8_t *box_init, uint32_t out[5])
+{
+    memset(out, 0, 5 * sizeof(uint32_t));
+    for (int i = 0; i < n - 1; ++i) {
+        if (bounded[i] != 2) out[1]++;
+        if (parent[i] == -1) out[0]++;
+        if (left[i] == -1) out[2]++;
+        if (right[i] == -1) out[2]++;
+        if (box_init && box_init[i] == 0) out[4]++;
+    }
+}
+/* checkLeafNodes: out = {nullParentNum, nullTriangleNum, notLeafCount, illegalBoxCount} (main.cu:123,127).
+ * nullTriangle also counts Triangle::selfCheck failures (vertex index >= maxv; triangle.cuh:11-16
+ * hard-codes 632674, made a parameter here). */
+void orc_check_leaves(int n, const int32_t *parent, const uint32_t *perm, const uint32_t *vidx, uint32_t maxv,
+                      const uint8_t *box_init, uint32_t out[4])
+{
+    memset(out, 0, 4 * sizeof(uint32_t));
+    for (int j = 0; j < n; ++j) {
+        int node = (n - 1) + j;
+        if (parent[node] == -1) out[0]++;
+        const uint32_t *tv = vidx + 3 * (size_t)perm[j];
+        if (tv[0] >= maxv || tv[1] >= maxv || tv[2] >= maxv) out[1]++;
+        if (box_init && box_init[node] == 0) out[3]++;
+    }
+}
+/* checkTriangleIdx, check.cuh:29-50: one count per out-of-range vertex index. */
+uint32_t orc_check_triangle_idx(int n, const uint32_t *perm, const uint32_t *vidx, uint32_t maxv)
+{
+    uint32_t c = 0;
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < 3; ++k) if (vidx[3 * (size_t)perm[j] + k] >= maxv) c++;
+    return c;
+}
+
+/* ------------------------------------------------------------------ whole path, for the CPU baseline */
+typedef struct {
+    double ms_morton, ms_sort, ms_hierarchy, ms_refit, ms_traverse;
+} orc_times;
+
+#include <time.h>
+static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+
+/* main.cu:64-146 minus I/O: morton -> sort -> hierarchy -> refit -> traversal, single thread
+ * (threads == 1), or the traversal loop split over OpenMP threads (threads > 1; pair order then
+ * differs, sets do not). Returns the pair count; pairs may be NULL (count only). */
+uint64_t orc_self_collide(const double *verts, const uint32_t *vidx, const uint32_t *ids, int n,
+                          const double off[3], const double span[3], int threads,
+                          uint32_t *pairs, uint64_t cap, orc_stats *st, orc_times *tm)
+{
+    uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+    uint32_t *perm = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n);
+    int32_t *left = (int32_t *)malloc(sizeof(int32_t) * (size_t)n), *right = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    int32_t *parent = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)n);
+    double *boxes = (double *)malloc(sizeof(double) * 12 * (size_t)n);
+    uint32_t *bounded = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n);
+    double t0 = now_ms();
+    orc_centroid_morton(verts, vidx, (uint32_t)n, off, span, keys, NULL);
+    double t1 = now_ms();
+    orc_sort_by_key(keys, perm, (uint32_t)n);
+    double t2 = now_ms();
+    uint32_t wrong;
+    orc_build_hierarchy(keys, n, 1, left, right, parent, NULL, NULL, &wrong);
+    double t3 = now_ms();
+    orc_refit(verts, vidx, perm, n, left, right, parent, boxes, bounded, NULL);
+    double t4 = now_ms();
+    memset(st, 0, sizeof *st);
+    if (threads <= 1) {
+        orc_find_collisions(verts, vidx, ids, perm, n, left, right, boxes, pairs, pairs ? cap : 0, st);
+    } else {
+#ifdef _OPENMP
+        uint64_t np = 0, ptst = 0, nv = 0; uint32_t mx = 0;
+#pragma omp parallel num_threads(threads) reduction(+ : np, ptst, nv) reduction(max : mx)
+        {
+            orc_stats loc; memset(&loc, 0, sizeof loc);
+#pragma omp for schedule(dynamic, 4096)
+            for (int j = 0; j < n; ++j) {
+                uint32_t t = perm[j];
+                traverse_one(ids ? ids[t] : t, vidx + 3 * (size_t)t, boxes + 6 * (size_t)((n - 1) + j),
+                             verts, vidx, ids, perm, n, left, right, boxes, NULL, 0, &loc);
+            }
+            np += loc.n_pairs; ptst += loc.pairs_tested; nv += loc.node_visits; if (loc.max_stack > mx) mx = loc.max_stack;
+        }
+        st->n_pairs = np; st->pairs_tested = ptst; st->node_visits = nv; st->max_stack = mx;
+#else
+        orc_find_collisions(verts, vidx, ids, perm, n, left, right, boxes, pairs, pairs ? cap : 0, st);
+#endif
+    }
+    double t5 = now_ms();
+    if (tm) { tm->ms_morton = t1 - t0; tm->ms_sort = t2 - t1; tm->ms_hierarchy = t3 - t2; tm->ms_refit = t4 - t3; tm->ms_traverse = t5 - t4; }
+    free(keys); free(perm); free(left); free(right); free(parent); free(boxes); free(bounded);
+    return st->n_pairs;
+}

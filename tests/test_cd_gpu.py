@@ -1,0 +1,284 @@
+"""GPU parity tests for the collision path: every stage of libmi355cd.so (through the C ABI) against
+the CPU oracle on the same seeded inputs.  Bar: bit-exact (integer keys / indices / tree links, FP64
+box bits, pair index SETS -- the reference's own output order is an atomicAdd race, collision.cuh:40)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import mi355_synth as synth
+import mi355cd
+import oracle
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _stagewise(verts, vidx, ids=None, frame=mi355cd.CD_FRAME_REFERENCE, off=None, span=None):
+    cd = mi355cd.CollisionDetector(verts, vidx, ids)
+    cd.set_morton_frame(frame, off, span)
+    cd.morton_sort()
+    keys, perm = cd.export_keys()
+    wrong = cd.build_hierarchy()
+    cd.refit_boxes()
+    parent, left, right, boxes, bounded = cd.export_tree()
+    return cd, dict(keys=keys, perm=perm, wrong=wrong, parent=parent, left=left, right=right, boxes=boxes, bounded=bounded)
+
+
+def _assert_tree_equal(g, r):
+    assert np.array_equal(g["keys"], r["keys"])
+    assert np.array_equal(g["perm"], r["perm"])
+    assert g["wrong"] == r["parent_wrong"] == 0
+    assert np.array_equal(g["left"], r["left"]) and np.array_equal(g["right"], r["right"])
+    assert np.array_equal(g["parent"], r["parent"])
+    assert np.array_equal(g["boxes"].view(np.uint64), r["boxes"].view(np.uint64))     # FP64 bit patterns
+    assert (g["bounded"] == 2).all()
+
+
+@pytest.mark.parametrize("n,e,seed", [(1000, 0.1, 11), (100_000, 0.02, 1234)])
+def test_soup_every_stage_matches_oracle(n, e, seed):
+    """BASELINE config 2 (100 k random-triangle soup) and a small one."""
+    verts, vidx = synth.soup(n, e, seed)
+    cd, g = _stagewise(verts, vidx)
+    r = oracle.pipeline(verts, vidx)
+    _assert_tree_equal(g, r)
+    assert cd.check_internal().tolist() == [1, 0, 0, 0, 0]          # cleanResult.png expectations
+    assert cd.check_leaves().tolist() == [0, 0, 0, 0]
+    assert cd.check_triangle_idx(verts.shape[0]) == 0
+    assert cd.check_triangle_idx(5) == int((vidx >= 5).sum())
+    pairs, npairs, rc = cd.find_collisions(cap=1 << 20)
+    st = cd.stats()
+    assert rc == 0 and npairs == r["stats"].n_pairs
+    assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+    assert st.pairs_tested == r["stats"].pairs_tested
+    assert st.node_visits == r["stats"].node_visits
+    assert (pairs[:, 0] < pairs[:, 1]).all()
+    cd.close()
+
+
+def test_cloth_pair_shared_vertices():
+    """Config-3 geometry at 1/6 scale (80 k triangles): shared vertices exercise neighborCount."""
+    verts, vidx = synth.cloth_pair(100)
+    cd, g = _stagewise(verts, vidx)
+    r = oracle.pipeline(verts, vidx)
+    _assert_tree_equal(g, r)
+    pairs, npairs, rc = cd.find_collisions(cap=1 << 20)
+    assert rc == 0 and npairs == r["stats"].n_pairs > 0
+    assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+    assert cd.stats().pairs_tested == r["stats"].pairs_tested
+    # fused call gives the same set
+    pairs2, n2, rc2 = cd.self_collide(cap=1 << 20)
+    assert rc2 == 0 and np.array_equal(oracle.pair_set(pairs2), oracle.pair_set(pairs))
+    cd.close()
+
+
+def test_auto_frame_and_custom_ids():
+    verts, vidx = synth.soup(20000, 0.04, 5)
+    verts = verts * 37.0 + 1000.0                           # far outside the reference frame
+    ids = (np.arange(vidx.shape[0], dtype=np.uint32)[::-1] * 3 + 7).astype(np.uint32)
+    cen = (verts[vidx[:, 0]] + verts[vidx[:, 1]] + verts[vidx[:, 2]]) / 3
+    lo, hi = cen.min(0), cen.max(0)
+    span = (hi - lo) * (1.0 + 1.0 / 1048576.0)
+    cd, g = _stagewise(verts, vidx, ids, frame=mi355cd.CD_FRAME_AUTO)
+    r = oracle.pipeline(verts, vidx, ids, off=lo, span=span)
+    _assert_tree_equal(g, r)
+    pairs, npairs, rc = cd.find_collisions()
+    assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])) and npairs > 0
+    # custom frame == what auto computed
+    cd2, g2 = _stagewise(verts, vidx, ids, frame=mi355cd.CD_FRAME_CUSTOM, off=lo, span=span)
+    assert np.array_equal(g2["keys"], g["keys"])
+    cd.close(); cd2.close()
+
+
+def test_pair_set_is_frame_independent():
+    verts, vidx = synth.soup(30000, 0.03, 9)
+    sets = []
+    for frame in (mi355cd.CD_FRAME_REFERENCE, mi355cd.CD_FRAME_AUTO):
+        with mi355cd.CollisionDetector(verts, vidx) as cd:
+            cd.set_morton_frame(frame)
+            pairs, n, rc = cd.self_collide()
+            sets.append(oracle.pair_set(pairs))
+    assert np.array_equal(sets[0], sets[1]) and len(sets[0]) > 0
+
+
+def test_duplicate_and_degenerate_triangles():
+    """Identical triangles (duplicate Morton keys -- the case the reference's builder breaks on,
+    load_obj.h:109-115), zero-area triangles, and a triangle listed twice with shared indices."""
+    verts, vidx = synth.soup(500, 0.2, 21)
+    v2 = np.concatenate([verts, verts[:300]], axis=0)                    # copies of the first 100 triangles
+    dup = (np.arange(300, dtype=np.uint32) + verts.shape[0]).reshape(100, 3)
+    degenerate = np.array([[0, 0, 1], [5, 5, 5]], dtype=np.uint32)       # zero-area
+    same_idx = vidx[:50].copy()                                          # same vertex indices -> neighbours, never reported
+    vi = np.concatenate([vidx, dup, degenerate, same_idx], axis=0)
+    cd, g = _stagewise(v2, vi)
+    r = oracle.pipeline(v2, vi)
+    assert len(np.unique(g["keys"])) < len(g["keys"])                    # duplicates really present
+    _assert_tree_equal(g, r)
+    pairs, n, rc = cd.find_collisions()
+    assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])) and n > 0
+    bf, bn, _ = oracle.brute_force(v2, vi, box_filter=True)
+    assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(bf))
+    assert cd.check_internal().tolist() == [1, 0, 0, 0, 0]
+    cd.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 64, 65, 4097])
+def test_tiny_and_ragged_sizes(n):
+    verts, vidx = synth.soup(max(n, 1), 0.5, 100 + n)
+    verts, vidx = verts[: 3 * n], vidx[:n]
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        pairs, cnt, rc = cd.self_collide()
+        st = cd.stats()
+        if n == 1:
+            assert cnt == 0
+            return
+        r = oracle.pipeline(verts, vidx)
+        assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+        assert st.pairs_tested == r["stats"].pairs_tested
+        parent, left, right, boxes, bounded = cd.export_tree()
+        assert np.array_equal(left, r["left"]) and np.array_equal(right, r["right"]) and np.array_equal(parent, r["parent"])
+
+
+def test_capacity_overflow_and_stage_order():
+    verts, vidx = synth.soup(20000, 0.05, 3)
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        with pytest.raises(mi355cd.CdError) as e:
+            cd.build_hierarchy()
+        assert e.value.rc == mi355cd.CD_ERR_ORDER
+        with pytest.raises(mi355cd.CdError):
+            cd.find_collisions()
+        full, n, rc = cd.self_collide(cap=1 << 16)
+        assert rc == 0 and n > 10
+        part, n2, rc2 = cd.find_collisions(cap=10)
+        assert rc2 == mi355cd.CD_OVERFLOW and n2 == n and part.shape[0] == 10
+        assert set(map(tuple, part.tolist())) <= set(map(tuple, full.tolist()))
+        none, n3, rc3 = cd.find_collisions(cap=0)                         # count only
+        assert n3 == n and rc3 == mi355cd.CD_OVERFLOW
+    bad = vidx.copy(); bad[7, 1] = verts.shape[0]
+    with pytest.raises(mi355cd.CdError) as e:
+        mi355cd.CollisionDetector(verts, bad)
+    assert e.value.rc == mi355cd.CD_ERR_INDEX
+
+
+def _comb(codes):
+    """Two tiny triangles per Morton code (decoded to grid cells of a unit-cell frame) + one triangle
+    spanning everything."""
+    tris = []
+    for code in codes:
+        c = np.zeros(3)
+        for p in range(60):
+            if (code >> p) & 1:
+                c[{2: 0, 1: 1, 0: 2}[p % 3]] += float(1 << (p // 3))
+        c += 0.5
+        for s in (0.0, 0.02):
+            tris.append([c + [s, 0, 0], c + [s + 0.2, 0.1, 0], c + [s, 0.1, 0.2]])
+    tris.append([[-1.0, -1.0, -1.0], [4.0e6, -1.0, -1.0], [-1.0, 4.0e6, 4.0e6]])
+    verts = np.asarray(tris, dtype=np.float64).reshape(-1, 3)
+    vidx = np.arange(verts.shape[0], dtype=np.uint32).reshape(-1, 3)
+    return verts, vidx
+
+
+@pytest.mark.parametrize("mirrored", [False, True])
+def test_deep_tree_uses_the_deferred_stack_path(mirrored):
+    """60 two-triangle clusters forming a 60-level comb, plus one triangle overlapping all of them.
+    mirrored=False: the chain hangs on the LEFT child, so this library's descend-left/push-right order
+    needs ~60 pending entries -- more than its 32-entry LDS stack -> deferred (query, subtree) items.
+    mirrored=True: the chain hangs on the RIGHT, which is the orientation that overflows the REFERENCE's
+    unchecked 32-entry stack (push L, push R, pop R; collision.cuh:21,47,64,69)."""
+    off = np.zeros(3); span = np.full(3, 1048576.0)                       # coordinate == grid cell
+    if not mirrored:
+        codes = [1 << (59 - k) for k in range(60)]
+    else:
+        codes = [(1 << 60) - (1 << (60 - k)) for k in range(60)]
+    verts, vidx = _comb(codes)
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, off, span)
+        pairs, n, rc = cd.self_collide()
+        st = cd.stats()
+    r = oracle.pipeline(verts, vidx, off=off, span=span)
+    if mirrored:
+        assert r["stats"].max_stack > 32
+    else:
+        assert st.stack_overflows > 0 and st.traverse_launches == 2
+    assert n == r["stats"].n_pairs > 0
+    assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+    assert st.pairs_tested == r["stats"].pairs_tested and st.node_visits == r["stats"].node_visits
+
+
+def test_exact_test_kernel_one_million_pairs():
+    """tri_contact (17-axis SAT) + neighbour gate + ID rule on 1 M explicit pairs, bit-match vs oracle."""
+    verts, vidx = synth.cloth_pair(60)
+    n = vidx.shape[0]
+    rng = np.random.default_rng(17)
+    a = rng.integers(0, n, 1_000_000, dtype=np.int64)
+    half = n // 2
+    # partner: same quad neighbourhood on the OTHER sheet (mix of hits and near misses) or a near neighbour on the same sheet
+    other = (a + half) % n + rng.integers(-3, 4, a.shape[0])
+    same = a + rng.integers(-2, 3, a.shape[0])
+    b = np.where(rng.random(a.shape[0]) < 0.7, other, same) % n
+    pairs = np.stack([a, b], axis=1).astype(np.uint32)
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        got = cd.test_pairs(pairs)
+    want = oracle.tri_contact_batch(verts, vidx, pairs)
+    assert np.array_equal(got, want)
+    assert 1000 < int(want.sum()) < 900_000
+
+
+def test_gpu_brute_force_agrees_with_traversal():
+    verts, vidx = synth.soup(20000, 0.05, 8)
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        tp, tn, _ = cd.self_collide()
+        st = cd.stats()
+        bp, bn, _ = cd.brute_force(box_filter=True)
+        lp, ln, _ = cd.brute_force(box_filter=False)
+    assert tn == bn == ln > 0
+    assert np.array_equal(oracle.pair_set(tp), oracle.pair_set(bp))
+    assert np.array_equal(oracle.pair_set(tp), oracle.pair_set(lp))
+
+
+def test_golden_pair_sets():
+    """Committed fixtures (tests/golden/make_golden.py): sorted pair lists produced by the oracle."""
+    g = np.load(os.path.join(GOLD, "cd_golden.npz"))
+    for name, gen in (("soup_5k", lambda: synth.soup(5000, 0.06, 42)), ("cloth_30", lambda: synth.cloth_pair(30))):
+        verts, vidx = gen()
+        with mi355cd.CollisionDetector(verts, vidx) as cd:
+            pairs, n, rc = cd.self_collide()
+            st = cd.stats()
+        assert np.array_equal(oracle.pair_set(pairs), g[name + "_pairs"])
+        assert st.pairs_tested == int(g[name + "_tested"])
+
+
+def test_update_vertices_rebuilds():
+    verts, vidx = synth.cloth_pair(40)
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        p0, n0, _ = cd.self_collide()
+        v2 = verts.copy(); v2[verts.shape[0] // 2:, 1] += 0.5          # lift sheet B clear of sheet A
+        cd.update_vertices(v2)
+        p1, n1, _ = cd.self_collide()
+        assert n0 > 0 and n1 == 0
+        cd.update_vertices(verts)
+        p2, n2, _ = cd.self_collide()
+        assert np.array_equal(oracle.pair_set(p2), oracle.pair_set(p0))
+
+
+def test_cd_main_harness_on_generated_obj(tmp_path):
+    """BASELINE config 1, plumbing: the C++ harness (main.cu twin) on a generated OBJ in the reference's dialect."""
+    text = synth.grids_obj_text(32)
+    path = tmp_path / "grids.obj"
+    path.write_text(text)
+    exe = os.path.join(ROOT, "gpu-computing-course_amd", "bin", "cd_main")
+    out = subprocess.run([exe, str(path), "--brute"], check=True, capture_output=True, text=True, timeout=300).stdout
+    verts, vidx = synth.parse_obj_text(text)
+    r = oracle.pipeline(verts, vidx)
+    got = sorted((int(a), int(b)) for a, b in __import__("re").findall(r"^(\d{7}) - (\d{7})$", out, flags=__import__("re").M))
+    want = sorted(map(tuple, r["pairs"].tolist()))
+    assert got == want and len(want) > 0
+    assert "wrongParentNum = 0" in out
+    assert "nullParentnum = 1, wrongBoundCount=0, nullChildCount=0, notInternalCount=0, uninitBoxCount=0" in out
+    assert "nullParentnum = 0, nullTriangle=0, notLeafCount=0, illegalBoxCount=0" in out
+    assert "illegal triangle vidx num = 0" in out
+    assert f"contact count = {len(want)}" in out
+    assert f"First morton code: {int(r['keys'][0])}, last morton code: {int(r['keys'][-1])}" in out
