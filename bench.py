@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the collision hot path on MI355X.
+
+Metric (BASELINE.json): triangle-pairs tested / second (+ total collision time) on 1 M-triangle
+self-collision.  A *step* is one full pass of the hot path over one batch of synthetic input with the
+input already resident in HBM: Morton keys -> radix sort -> LBVH hierarchy -> AABB refit -> BVH traversal
+with the exact triangle test (cd_self_collide through the C ABI).  A *pair tested* is a (query, leaf)
+pair whose AABBs strictly overlap and therefore reaches the neighbour filter / SAT.
+
+N = 1 : BASELINE config 3, the 1 M-triangle synthetic cloth-vs-cloth.
+N > 1 : BASELINE config 4, one 1 M-triangle cloth object per rank, neighbours overlapping by 10 % along
+        x (weak scaling); per step each rank self-collides its object, all-gathers root AABBs over RCCL,
+        exchanges the overlapping leaves with its neighbours and traverses the received queries.
+
+Prints ONE JSON line on rank 0.  Launch for N > 1:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "gpu-computing-course_amd", "pyhost")]
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAVERSAL_BYTES_PER_TRI = 40.0   # box 24 + links 8 + leaf payload ~8 amortised, read once
+TOTAL_BYTES_PER_TRI = 460.0      # whole path, compact layouts
+
+
+def cpu_baseline(verts, vidx, reps=3):
+    """The CPU oracle (a port of the reference's sequential cpu.cuh path) timed on this box's host
+    cores: `reps` full passes over the SAME workload, single thread.  Checker code, used here only as
+    the reported baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    oracle.self_collide(verts[:3000], vidx[:1000], want_pairs=False)          # page in
+    best = None
+    t_all = 0.0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        _, st, tm = oracle.self_collide(verts, vidx, want_pairs=False, threads=1)
+        dt = time.perf_counter() - t0
+        t_all += dt
+        if best is None or dt < best[0]:
+            best = (dt, st, tm)
+    dt, st, tm = best
+    out = {"value": st.pairs_tested / dt, "unit": "pairs_tested/s", "cores": 1, "kind": "port",
+           "sample": f"{reps} full passes of the same workload (best of {reps}; {t_all:.1f} s of CPU work), single thread, gcc -O2 -ffp-contract=off",
+           "total_collision_ms": dt * 1e3, "pairs_tested": int(st.pairs_tested), "n_pairs": int(st.n_pairs),
+           "stage_ms": {"morton": tm.ms_morton, "sort": tm.ms_sort, "hierarchy": tm.ms_hierarchy, "refit": tm.ms_refit, "traverse": tm.ms_traverse}}
+    # multi-core variant: traversal loop split over OpenMP threads (build stages stay sequential)
+    threads = min(16, os.cpu_count() or 1)
+    if threads > 1:
+        t0 = time.perf_counter()
+        _, st2, tm2 = oracle.self_collide(verts, vidx, want_pairs=False, threads=threads)
+        dt2 = time.perf_counter() - t0
+        out["omp"] = {"value": st2.pairs_tested / dt2, "cores": threads, "total_collision_ms": dt2 * 1e3, "traverse_ms": tm2.ms_traverse}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--quads", type=int, default=500, help="quads per sheet edge; 500 -> 1 000 000 triangles per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import mi355_synth as synth
+    import mi355cd
+    import mi355_multi as multi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)            # nccl == RCCL on ROCm
+
+    # ---- workload (synthetic, seeded), resident in HBM before the timed region
+    if world == 1:
+        verts, vidx = synth.cloth_pair(args.quads)
+        ids = None
+        frame = mi355cd.CD_FRAME_REFERENCE                            # geometry lies in the reference's Morton frame
+        workload = f"cloth-vs-cloth, 2 sheets x {args.quads}x{args.quads} quads = {vidx.shape[0]} triangles, self-collision (BASELINE config 3)"
+    else:
+        verts, vidx, ids, vbase = synth.cloth_shard(rank, args.quads)
+        frame = mi355cd.CD_FRAME_AUTO
+        workload = (f"{world} x cloth-vs-cloth objects of {vidx.shape[0]} triangles, 10% x-overlap between neighbours, "
+                    f"sharded by object (BASELINE config 4 shape)")
+    nt = vidx.shape[0]
+    # neighborCount compares vertex INDICES: a per-rank base makes them global for the cross-rank pass
+    engine = multi.HipEngine(verts, vidx, ids, device, frame, vertex_id_base=vbase if world > 1 else 0)
+    cap = 1 << 22
+
+    def step():
+        return multi.collide_step(engine, dist, rank, world, cap)
+
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
+    stage = {"morton": 0.0, "sort": 0.0, "hierarchy": 0.0, "refit": 0.0, "traverse": 0.0}
+    tested_total = 0
+    pairs_found = 0
+    info = {}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pairs, tested, info = step()
+        st = engine.cd.stats()                                        # HIP-event stage times on the library's stream
+        if world == 1:
+            stage["morton"] += st.ms_morton; stage["sort"] += st.ms_sort; stage["hierarchy"] += st.ms_hierarchy
+            stage["refit"] += st.ms_refit; stage["traverse"] += st.ms_traverse
+        tested_total += tested
+        pairs_found = pairs.shape[0]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([tested_total, pairs_found], dtype=torch.int64, device=device)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        tested_total, pairs_found = int(c[0].item()), int(c[1].item())
+
+    if rank == 0:
+        k = args.steps
+        ms_per_step = elapsed * 1e3 / k
+        line = {
+            "metric": "triangle-pairs tested/sec (total collision time in ms_per_step), 1M-tri self-collision",
+            "value": tested_total / elapsed, "unit": "pairs_tested/s", "n_gpus": world, "steps": k, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "triangles_per_gpu": int(nt), "pairs_tested_per_step": tested_total // k,
+                       "colliding_pairs": int(pairs_found), "sharding": "by object" if world > 1 else "none"},
+        }
+        if world == 1:
+            for s in stage:
+                stage[s] /= k
+            dev_total = sum(stage.values())
+            line["total_collision_ms_device"] = dev_total          # sum of the five stages' HIP-event times
+            line["stage_ms"] = stage
+            line["traversal_pairs_tested_per_s"] = (tested_total / k) / (stage["traverse"] * 1e-3)
+            # roofline of the dominant kernel (traversal + exact test): algorithmic bytes per launch
+            # = 40 B/triangle (tree read once) + 8 B per reported pair, over its HIP-event duration
+            dominant = max(stage, key=stage.get)
+            trav_bytes = TRAVERSAL_BYTES_PER_TRI * nt + 8.0 * pairs_found
+            achieved = trav_bytes / (stage["traverse"] * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("triangles") == nt:
+                    traffic = tj.get("traverse_hbm_bytes_per_launch")
+            line["roofline"] = {"bound": "hbm", "kernel": "k_traverse (BVH traversal + tri_contact)", "achieved": achieved,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                "algorithmic_bytes_per_launch": trav_bytes, "avg_launch_ms": stage["traverse"],
+                                "dominant_stage": dominant,
+                                "whole_path": {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9,
+                                               "frac": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(verts, vidx)
+                line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+        else:
+            line["config"]["last_step_rank0"] = info
+        print(json.dumps(line))
+    engine.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,9 +22,12 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 __device__ __forceinline__ void leaf_hit(uint32_t q_id, uint32_t qa, uint32_t qb, uint32_t qc,
                                          const d3 &P1, const d3 &P2, const d3 &P3,
                                          const LeafTri lt, const double *__restrict__ verts,
-                                         uint32_t *__restrict__ pairs, unsigned long long cap, TravCounters *__restrict__ ctr)
+                                         uint32_t *__restrict__ pairs, unsigned long long cap, TravCounters *__restrict__ ctr,
+                                         uint32_t vbase)
 {
-    if (neighbor_count(qa, qb, qc, lt.v0, lt.v1, lt.v2) < 1) {            // collision.cuh:38
+    // vbase: global id of local vertex 0 -- non-zero only for external (cross-rank) queries, whose
+    // vertex ids are global; local queries compare local indices with local indices (vbase = 0).
+    if (neighbor_count(qa, qb, qc, lt.v0 + vbase, lt.v1 + vbase, lt.v2 + vbase) < 1) {   // collision.cuh:38
         if (q_id < lt.id) {                                               // tri_contact.cuh:81
             if (tri_contact(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) {
                 const unsigned long long cur = atomicAdd(&ctr->n_pairs, 1ull);   // collision.cuh:40
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_
                                                            uint32_t *__restrict__ pairs, unsigned long long cap,
                                                            TravCounters *__restrict__ ctr,
                                                            uint2 *__restrict__ defer_list, uint32_t defer_cap,
-                                                           int32_t *__restrict__ deep_stacks)
+                                                           int32_t *__restrict__ deep_stacks, uint32_t vbase)
 {
     __shared__ int32_t lds_stack[DEEP ? 1 : TRAV_STACK][TRAV_THREADS];
     const uint32_t tid = threadIdx.x;
@@ -91,11 +94,11 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_
             const bool orr = box_overlap(qbox, br);
             int32_t next = -1;
             if (ol) {
-                if (cl >= n - 1) { ++tested; leaf_hit(q_id, qa, qb, qc, P1, P2, P3, leaf[cl - (n - 1)], verts, pairs, cap, ctr); }
+                if (cl >= n - 1) { ++tested; leaf_hit(q_id, qa, qb, qc, P1, P2, P3, leaf[cl - (n - 1)], verts, pairs, cap, ctr, vbase); }
                 else next = cl;
             }
             if (orr) {
-                if (cr >= n - 1) { ++tested; leaf_hit(q_id, qa, qb, qc, P1, P2, P3, leaf[cr - (n - 1)], verts, pairs, cap, ctr); }
+                if (cr >= n - 1) { ++tested; leaf_hit(q_id, qa, qb, qc, P1, P2, P3, leaf[cr - (n - 1)], verts, pairs, cap, ctr, vbase); }
                 else if (next == -1) next = cr;
                 else {                                                     // both internal: descend left, push right
                     const int cap_s = DEEP ? DEEP_STACK : TRAV_STACK;
@@ -189,7 +192,8 @@ __global__ __launch_bounds__(256) void k_test_pairs(const double *__restrict__ v
 // Leaves whose AABB strictly overlaps `box` -> cd_query records (cross-rank pass).
 __global__ __launch_bounds__(256) void k_pack_queries(const double *__restrict__ verts, const LeafTri *__restrict__ leaf,
                                                       const double *__restrict__ boxes, int n, Box box,
-                                                      ExtQuery *__restrict__ out, unsigned long long cap, unsigned long long *__restrict__ count)
+                                                      ExtQuery *__restrict__ out, unsigned long long cap, unsigned long long *__restrict__ count,
+                                                      uint32_t vbase)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void k_pack_queries(const double *__restrict__
     const d3 A = load_vertex(verts, lt.v0), B = load_vertex(verts, lt.v1), C = load_vertex(verts, lt.v2);
     ExtQuery q;
     q.v[0] = A.x; q.v[1] = A.y; q.v[2] = A.z; q.v[3] = B.x; q.v[4] = B.y; q.v[5] = B.z; q.v[6] = C.x; q.v[7] = C.y; q.v[8] = C.z;
-    q.id = lt.id; q.vidx[0] = lt.v0; q.vidx[1] = lt.v1; q.vidx[2] = lt.v2;
+    q.id = lt.id; q.vidx[0] = lt.v0 + vbase; q.vidx[1] = lt.v1 + vbase; q.vidx[2] = lt.v2 + vbase;
     out[k] = q;
 }
 

@@ -24,7 +24,7 @@ namespace {
 
 enum Stage { ST_CREATED = 0, ST_SORTED = 1, ST_BUILT = 2, ST_REFIT = 3 };
 
-enum Ev { EV_MORTON0, EV_MORTON1, EV_SORT1, EV_HIER0, EV_HIER1, EV_REFIT0, EV_REFIT1, EV_TRAV0, EV_TRAV1, EV_CHK0, EV_CHK1, EV_COUNT };
+enum Ev { EV_MORTON0, EV_MORTON1, EV_SORT1, EV_HIER0, EV_HIER1, EV_REFIT0, EV_REFIT1, EV_TRAV0, EV_TRAV1, EV_DEEP0, EV_DEEP1, EV_CHK0, EV_CHK1, EV_COUNT };
 
 }  // namespace
 
@@ -32,6 +32,7 @@ struct cd_ctx {
     uint32_t nv = 0, nt = 0;
     int stage = ST_CREATED;
     int frame_mode = CD_FRAME_REFERENCE;
+    uint32_t vbase = 0;                     // global id of local vertex 0 (cross-rank neighbour filter)
     double frame_host[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};   // morton.h:45,51,57
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
@@ -147,6 +148,7 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     int rc = ensure_pairs(c, cap_pairs > 0 ? cap_pairs : 1);
     if (rc) return rc;
     uint32_t launches = 0;
+    float deep_ms = 0.f;
     TravCounters h = {};
     for (int attempt = 0; attempt < 3; ++attempt) {
         launches = 0;
@@ -156,12 +158,13 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
         if (nq > 0) {
             if (external)
                 k_traverse<true, false><<<cdiv(nq, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nq, (int)n, c->d_recs, c->d_leaf, c->d_verts,
-                                                                                     c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr);
+                                                                                     c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr, external ? c->vbase : 0u);
             else
                 k_traverse<false, false><<<cdiv(nq, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nq, (int)n, c->d_recs, c->d_leaf, c->d_verts,
-                                                                                      c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr);
+                                                                                      c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr, external ? c->vbase : 0u);
             ++launches;
         }
+        HIPCHK(hipEventRecord(c->ev[EV_TRAV1], s));      // device time of the kernel only: recorded before the read-back
         HIPCHK(hipMemcpyAsync(&h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         if (h.n_deferred == 0) break;
@@ -179,28 +182,30 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
             HIPCHK(hipMalloc(&c->d_deep, sizeof(int32_t) * (size_t)DEEP_STACK * nd));
             c->deep_items = nd;
         }
+        HIPCHK(hipEventRecord(c->ev[EV_DEEP0], s));
         HIPCHK(hipMemsetAsync(&c->d_ctr->n_deferred, 0, sizeof(uint32_t), s));
         src.list = c->d_defer;
         if (external)
             k_traverse<true, true><<<cdiv(nd, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nd, (int)n, c->d_recs, c->d_leaf, c->d_verts,
-                                                                                c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep);
+                                                                                c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep, external ? c->vbase : 0u);
         else
             k_traverse<false, true><<<cdiv(nd, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nd, (int)n, c->d_recs, c->d_leaf, c->d_verts,
-                                                                                 c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep);
+                                                                                 c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep, external ? c->vbase : 0u);
         ++launches;
+        HIPCHK(hipEventRecord(c->ev[EV_DEEP1], s));
         HIPCHK(hipMemcpyAsync(&h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         if (h.n_deferred != 0) return CD_ERR_ARG;       // tree deeper than DEEP_STACK: cannot happen (height <= 96)
         c->stats.stack_overflows = nd;
+        deep_ms = elapsed(c, EV_DEEP0, EV_DEEP1);
         break;
     }
-    HIPCHK(hipEventRecord(c->ev[EV_TRAV1], s));
     HIPCHK(hipGetLastError());
     const uint64_t found = h.n_pairs;
     const uint64_t ncopy = found < cap_pairs ? found : cap_pairs;
     if (pairs && ncopy) HIPCHK(hipMemcpyAsync(pairs, c->d_pairs, sizeof(uint32_t) * 2 * ncopy, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    c->stats.ms_traverse = elapsed(c, EV_TRAV0, EV_TRAV1);
+    c->stats.ms_traverse = elapsed(c, EV_TRAV0, EV_TRAV1) + deep_ms;
     c->stats.traverse_launches = launches;
     if (h.n_deferred == 0 && launches <= 1) c->stats.stack_overflows = 0;
     c->stats.n_pairs = found; c->stats.pairs_tested = h.pairs_tested; c->stats.node_visits = h.node_visits;
@@ -440,6 +445,8 @@ int cd_export_tree(cd_ctx *c, int32_t *parent, int32_t *left, int32_t *right, do
 int cd_get_stats(cd_ctx *c, cd_stats *out) { if (!c || !out) return CD_ERR_ARG; *out = c->stats; return CD_OK; }
 int cd_num_triangles(cd_ctx *c, uint32_t *nt) { if (!c || !nt) return CD_ERR_ARG; *nt = c->nt; return CD_OK; }
 
+int cd_set_vertex_id_base(cd_ctx *c, uint32_t base) { if (!c) return CD_ERR_ARG; c->vbase = base; return CD_OK; }
+
 int cd_root_box(cd_ctx *c, double box[6])
 {
     if (!c || !box) return CD_ERR_ARG;
@@ -458,7 +465,7 @@ int cd_pack_queries(cd_ctx *c, const double box[6], void *d_out, uint64_t cap, u
     HIPCHK(hipMemsetAsync(c->d_ctr, 0, sizeof(TravCounters), s));
     Box b{box[0], box[1], box[2], box[3], box[4], box[5]};
     k_pack_queries<<<cdiv(c->nt, 256), 256, 0, s>>>(c->d_verts, c->d_leaf, c->d_boxes, (int)c->nt, b,
-                                                     reinterpret_cast<ExtQuery *>(d_out), cap, d_cnt);
+                                                     reinterpret_cast<ExtQuery *>(d_out), cap, d_cnt, c->vbase);
     unsigned long long h = 0;
     HIPCHK(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

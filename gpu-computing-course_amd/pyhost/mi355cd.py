@@ -34,7 +34,7 @@ EXPORTS = [
     "cd_build_hierarchy", "cd_refit_boxes", "cd_check_internal", "cd_check_leaves",
     "cd_check_triangle_idx", "cd_find_collisions", "cd_self_collide", "cd_brute_force",
     "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_num_triangles",
-    "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
+    "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
 ]
 
 _lib = None
@@ -67,6 +67,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_export_tree.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.cd_get_stats.argtypes = [vp, C.POINTER(CdStats)]
     lib.cd_num_triangles.argtypes = [vp, u32p]
+    lib.cd_set_vertex_id_base.argtypes = [vp, C.c_uint32]
     lib.cd_root_box.argtypes = [vp, vp]
     lib.cd_pack_queries.argtypes = [vp, vp, vp, C.c_uint64, u64p]
     lib.cd_find_collisions_queries.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]
@@ -209,6 +210,9 @@ class CollisionDetector:
         return s
 
     # ---- cross-rank pass
+    def set_vertex_id_base(self, base: int):
+        self._chk("cd_set_vertex_id_base", self.lib.cd_set_vertex_id_base(self._ctx, base))
+
     def root_box(self) -> np.ndarray:
         b = np.zeros(6, dtype=np.float64)
         self._chk("cd_root_box", self.lib.cd_root_box(self._ctx, _ptr(b)))

@@ -130,6 +130,10 @@ typedef struct cd_query {
     uint32_t vidx[3];
 } cd_query;
 
+/* Global id of local vertex 0 (default 0).  Local triangles index the context's own vertex array;
+ * across ranks neighborCount must compare GLOBAL vertex ids, so cd_pack_queries adds this base to the
+ * indices it emits and cd_find_collisions_queries adds it to the local leaves' indices before comparing. */
+int cd_set_vertex_id_base(cd_ctx *ctx, uint32_t base);
 /* AABB of the whole local tree (box of internal node 0). */
 int cd_root_box(cd_ctx *ctx, double box[6]);
 /* Compact the local leaves whose AABB strictly overlaps `box` (box.cuh:40-43) into d_out, a DEVICE

@@ -412,9 +412,11 @@ void orc_find_collisions_queries(const double *q_verts, const uint32_t *q_vidx, 
                                  const double *verts, const uint32_t *vidx, const uint32_t *ids,
                                  const uint32_t *perm, int n,
                                  const int32_t *left, const int32_t *right, const double *boxes,
-                                 uint32_t *pairs, uint64_t cap, orc_stats *st)
+                                 uint32_t vbase, uint32_t *pairs, uint64_t cap, orc_stats *st)
 {
     memset(st, 0, sizeof *st);
+    /* vbase: global id of local vertex 0 -- the queries carry GLOBAL vertex ids (they come from another
+     * rank), so the neighbour filter compares them with local index + vbase. */
     /* The exact test reads vertices through indices into one array (tri_contact.cuh:83-84); give the
      * query its three vertices through a private 3-entry array and local indices. */
     for (int q = 0; q < nq; ++q) {
@@ -431,7 +433,8 @@ void orc_find_collisions_queries(const double *q_verts, const uint32_t *q_vidx, 
                     st->pairs_tested++;
                     uint32_t t = perm[ch[s] - (n - 1)];
                     const uint32_t *tv = vidx + 3 * (size_t)t;
-                    if (orc_neighbor_count(q_vidx + 3 * (size_t)q, tv) < 1) {
+                    const uint32_t tvg[3] = { tv[0] + vbase, tv[1] + vbase, tv[2] + vbase };
+                    if (orc_neighbor_count(q_vidx + 3 * (size_t)q, tvg) < 1) {
                         uint32_t tid = ids ? ids[t] : t;
                         if (q_ids[q] < tid &&
                             orc_tri_contact(q_verts + 9 * (size_t)q, q_verts + 9 * (size_t)q + 3, q_verts + 9 * (size_t)q + 6,

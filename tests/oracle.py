@@ -59,7 +59,7 @@ def lib(omp: bool = False) -> C.CDLL:
     L.orc_tri_contact_batch.argtypes = [vp, vp, vp, vp, C.c_uint64, vp]; L.orc_tri_contact_batch.restype = None
     L.orc_find_collisions.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_uint64, C.POINTER(OrcStats)]
     L.orc_find_collisions.restype = None
-    L.orc_find_collisions_queries.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_uint64, C.POINTER(OrcStats)]
+    L.orc_find_collisions_queries.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_uint32, vp, C.c_uint64, C.POINTER(OrcStats)]
     L.orc_find_collisions_queries.restype = None
     L.orc_brute_force.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.orc_brute_force.restype = C.c_uint64
@@ -170,7 +170,7 @@ def find_collisions(verts, vidx, perm, left, right, boxes, ids=None, cap=1 << 22
     return pairs[:min(st.n_pairs, cap)], st
 
 
-def find_collisions_queries(queries, verts, vidx, perm, left, right, boxes, ids=None, cap=1 << 22):
+def find_collisions_queries(queries, verts, vidx, perm, left, right, boxes, ids=None, cap=1 << 22, vbase=0):
     """queries: structured array with fields v[9], id, vidx[3] (cd_query layout)."""
     qv = np.ascontiguousarray(queries["v"], dtype=np.float64)
     qx = np.ascontiguousarray(queries["vidx"], dtype=np.uint32)
@@ -181,7 +181,7 @@ def find_collisions_queries(queries, verts, vidx, perm, left, right, boxes, ids=
     pairs = np.zeros((cap, 2), dtype=np.uint32)
     st = OrcStats()
     lib().orc_find_collisions_queries(_p(qv), _p(qx), _p(qi), qi.shape[0], _p(verts), _p(vidx), _p(ids), _p(perm), perm.shape[0],
-                                      _p(left), _p(right), _p(boxes), _p(pairs), cap, C.byref(st))
+                                      _p(left), _p(right), _p(boxes), int(vbase), _p(pairs), cap, C.byref(st))
     return pairs[:min(st.n_pairs, cap)], st
 
 
