@@ -165,11 +165,44 @@ __device__ __forceinline__ Box load_box(const double *boxes, int node)
     return Box{a.x, a.y, b.x, b.y, c.x, c.y};
 }
 
-__global__ __launch_bounds__(256) void k_refit(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n,
-                                               const int2 *__restrict__ children, const int32_t *__restrict__ parent,
-                                               double *boxes, uint32_t *bounded, NodeRec *__restrict__ recs)
+constexpr int REFIT_BLK = 512;     // leaves per workgroup
+
+// Merge step shared by both refit phases: given my box, my sibling's box and which side I am, write the
+// parent's 128-byte traversal record {bl, br, cl, cr} and return the parent's box (bvh.cuh:277).
+__device__ __forceinline__ Box refit_merge(const Box &mine, const Box &other, bool left, int2 ch, NodeRec *__restrict__ rec)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    Box bl, br;
+    bl.x1 = left ? mine.x1 : other.x1; bl.x2 = left ? mine.x2 : other.x2;
+    bl.y1 = left ? mine.y1 : other.y1; bl.y2 = left ? mine.y2 : other.y2;
+    bl.z1 = left ? mine.z1 : other.z1; bl.z2 = left ? mine.z2 : other.z2;
+    br.x1 = left ? other.x1 : mine.x1; br.x2 = left ? other.x2 : mine.x2;
+    br.y1 = left ? other.y1 : mine.y1; br.y2 = left ? other.y2 : mine.y2;
+    br.z1 = left ? other.z1 : mine.z1; br.z2 = left ? other.z2 : mine.z2;
+    double2 *rp = reinterpret_cast<double2 *>(rec);
+    rp[0] = make_double2(bl.x1, bl.x2); rp[1] = make_double2(bl.y1, bl.y2); rp[2] = make_double2(bl.z1, bl.z2);
+    rp[3] = make_double2(br.x1, br.x2); rp[4] = make_double2(br.y1, br.y2); rp[5] = make_double2(br.z1, br.z2);
+    reinterpret_cast<int2 *>(rp + 6)[0] = ch;
+    return box_merge(bl, br);
+}
+
+// Phase 1 -- block-local subtrees.  Workgroup b owns leaves [b*BLK, (b+1)*BLK).  An internal node whose
+// leaf range (Karras: node i covers [first,last], first <= i < last) lies inside that interval has both
+// children finished by threads of this workgroup, so its arrival counter and the sibling-box hand-off live
+// in LDS (workgroup-scope acq_rel: no cache maintenance).  A thread that reaches a parent spanning
+// workgroups stops and appends its node to `top_list`; phase 2 continues from there after the kernel
+// boundary has made every box visible device-wide.
+__global__ __launch_bounds__(REFIT_BLK) void k_refit_local(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n,
+                                                           const int2 *__restrict__ children, const int32_t *__restrict__ parent,
+                                                           const int2 *__restrict__ ranges,
+                                                           double *__restrict__ boxes, uint32_t *__restrict__ bounded, NodeRec *__restrict__ recs,
+                                                           int32_t *__restrict__ top_list, uint32_t *__restrict__ top_count)
+{
+    __shared__ double lbox[REFIT_BLK][2][6];       // deposit slots: [local node][side] = child box, 48 KB
+    __shared__ uint32_t lcnt[REFIT_BLK];
+    const int b0 = blockIdx.x * REFIT_BLK;
+    lcnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int j = b0 + threadIdx.x;
     if (j >= n) return;
     const LeafTri lt = leaf[j];
     Box mine = box_set(load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2));
@@ -177,27 +210,47 @@ __global__ __launch_bounds__(256) void k_refit(const double *__restrict__ verts,
     store_box(boxes, me, mine);
     int cur = parent[me];
     while (cur != -1) {
-        // release my box, count my arrival, acquire the sibling's box if I am second (bvh.cuh:270)
+        const int2 rg = ranges[cur];
+        if (!(rg.x >= b0 && rg.y < b0 + REFIT_BLK)) {                      // parent spans workgroups: hand over to phase 2
+            top_list[atomicAdd(top_count, 1u)] = me;
+            break;
+        }
+        const int2 ch = children[cur];
+        const bool left = (ch.x == me);
+        const int slot = cur - b0;
+        double *dst = lbox[slot][left ? 0 : 1];
+        dst[0] = mine.x1; dst[1] = mine.x2; dst[2] = mine.y1; dst[3] = mine.y2; dst[4] = mine.z1; dst[5] = mine.z2;
+        const uint32_t old = __hip_atomic_fetch_add(&lcnt[slot], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (old == 0) break;                                               // first arriver leaves (bvh.cuh:270-272)
+        const double *src = lbox[slot][left ? 1 : 0];
+        const Box other{src[0], src[1], src[2], src[3], src[4], src[5]};
+        bounded[cur] = 2;                                                  // Node::bounded: both arrivals seen
+        mine = refit_merge(mine, other, left, ch, recs + cur);
+        me = cur;
+        store_box(boxes, me, mine);
+        cur = parent[me];
+    }
+}
+
+// Phase 2 -- the few nodes that span workgroups (O(N / BLK) for Morton-ordered meshes).  One thread per
+// top_list entry; arrival counter in global memory with agent-scope acq_rel ordering (the reference's
+// atomicAdd at bvh.cuh:270 has no fence at all -- a race on real hardware).
+__global__ __launch_bounds__(256) void k_refit_top(int n, const int2 *__restrict__ children, const int32_t *__restrict__ parent,
+                                                   double *boxes, uint32_t *bounded, NodeRec *__restrict__ recs,
+                                                   const int32_t *__restrict__ top_list, const uint32_t *__restrict__ top_count)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *top_count) return;
+    int me = top_list[k];
+    Box mine = load_box(boxes, me);
+    int cur = parent[me];
+    while (cur != -1) {
         const uint32_t old = __hip_atomic_fetch_add(&bounded[cur], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (old == 0) break;
         const int2 ch = children[cur];
-        const int sib = (ch.x == me) ? ch.y : ch.x;
-        const Box other = load_box(boxes, sib);
         const bool left = (ch.x == me);
-        Box bl, br;
-        bl.x1 = left ? mine.x1 : other.x1; bl.x2 = left ? mine.x2 : other.x2;
-        bl.y1 = left ? mine.y1 : other.y1; bl.y2 = left ? mine.y2 : other.y2;
-        bl.z1 = left ? mine.z1 : other.z1; bl.z2 = left ? mine.z2 : other.z2;
-        br.x1 = left ? other.x1 : mine.x1; br.x2 = left ? other.x2 : mine.x2;
-        br.y1 = left ? other.y1 : mine.y1; br.y2 = left ? other.y2 : mine.y2;
-        br.z1 = left ? other.z1 : mine.z1; br.z2 = left ? other.z2 : mine.z2;
-        {   // one 128-byte record: {bl, br, cl, cr}
-            double2 *rp = reinterpret_cast<double2 *>(recs + cur);
-            rp[0] = make_double2(bl.x1, bl.x2); rp[1] = make_double2(bl.y1, bl.y2); rp[2] = make_double2(bl.z1, bl.z2);
-            rp[3] = make_double2(br.x1, br.x2); rp[4] = make_double2(br.y1, br.y2); rp[5] = make_double2(br.z1, br.z2);
-            reinterpret_cast<int2 *>(rp + 6)[0] = ch;
-        }
-        mine = box_merge(bl, br);                                         // bvh.cuh:277 merge(childA, childB)
+        const Box other = load_box(boxes, left ? ch.y : ch.x);
+        mine = refit_merge(mine, other, left, ch, recs + cur);
         me = cur;
         store_box(boxes, me, mine);
         cur = parent[me];

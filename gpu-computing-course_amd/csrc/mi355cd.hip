@@ -43,7 +43,7 @@ struct cd_ctx {
     uint32_t *d_counts = nullptr; uint32_t ntiles = 0;
     double *d_frame = nullptr, *d_partial = nullptr;
     // tree
-    LeafTri *d_leaf = nullptr; int2 *d_children = nullptr; int32_t *d_parent = nullptr;
+    LeafTri *d_leaf = nullptr; int2 *d_children = nullptr; int2 *d_ranges = nullptr; int32_t *d_parent = nullptr;
     double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec *d_recs = nullptr;
     uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
     // traversal
@@ -62,7 +62,7 @@ void free_all(cd_ctx *c)
     hipFree(c->d_verts); hipFree(c->d_vidx); hipFree(c->d_ids);
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_frame); hipFree(c->d_partial);
-    hipFree(c->d_leaf); hipFree(c->d_children); hipFree(c->d_parent); hipFree(c->d_boxes);
+    hipFree(c->d_leaf); hipFree(c->d_children); hipFree(c->d_ranges); hipFree(c->d_parent); hipFree(c->d_boxes);
     hipFree(c->d_bounded); hipFree(c->d_recs); hipFree(c->d_small); hipFree(c->d_ctr);
     hipFree(c->d_pairs); hipFree(c->d_defer); hipFree(c->d_deep);
     for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -119,7 +119,7 @@ int enqueue_hierarchy(cd_ctx *c)
     HIPCHK(hipMemsetAsync(c->d_small, 0, 16 * sizeof(uint32_t), s));
     k_fill_leaves<<<cdiv(n, 256), 256, 0, s>>>(c->d_perm[0], c->d_vidx, c->d_ids, n, c->d_leaf, c->d_parent, c->d_bounded);
     if (n > 1)
-        k_hierarchy<<<cdiv(n - 1, 256), 256, 0, s>>>(c->d_keys[0], (int)n, c->d_children, c->d_parent, nullptr, c->d_small);
+        k_hierarchy<<<cdiv(n - 1, 256), 256, 0, s>>>(c->d_keys[0], (int)n, c->d_children, c->d_parent, c->d_ranges, c->d_small);
     HIPCHK(hipEventRecord(c->ev[EV_HIER1], s));
     HIPCHK(hipGetLastError());
     return 0;
@@ -132,7 +132,13 @@ int enqueue_refit(cd_ctx *c)
     HIPCHK(hipEventRecord(c->ev[EV_REFIT0], s));
     HIPCHK(hipMemsetAsync(c->d_boxes, 0xFF, sizeof(double) * 6 * (2 * (size_t)n - 1), s));
     if (n > 1) HIPCHK(hipMemsetAsync(c->d_bounded, 0, sizeof(uint32_t) * (n - 1), s));
-    k_refit<<<cdiv(n, 256), 256, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_children, c->d_parent, c->d_boxes, c->d_bounded, c->d_recs);
+    // top list lives in the (now free) second permutation buffer; its counter in d_small[4]
+    int32_t *top_list = reinterpret_cast<int32_t *>(c->d_perm[1]);
+    uint32_t *top_count = c->d_small + 4;
+    HIPCHK(hipMemsetAsync(top_count, 0, sizeof(uint32_t), s));
+    k_refit_local<<<cdiv(n, REFIT_BLK), REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_children, c->d_parent, c->d_ranges,
+                                                          c->d_boxes, c->d_bounded, c->d_recs, top_list, top_count);
+    k_refit_top<<<cdiv(n, 256), 256, 0, s>>>((int)n, c->d_children, c->d_parent, c->d_boxes, c->d_bounded, c->d_recs, top_list, top_count);
     HIPCHK(hipEventRecord(c->ev[EV_REFIT1], s));
     HIPCHK(hipGetLastError());
     return 0;
@@ -244,6 +250,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_partial, sizeof(double) * 6 * BOUNDS_BLOCKS);
     ALLOC(c->d_leaf, sizeof(LeafTri) * n);
     ALLOC(c->d_children, sizeof(int2) * n);
+    ALLOC(c->d_ranges, sizeof(int2) * n);
     ALLOC(c->d_parent, sizeof(int32_t) * 2 * n);
     ALLOC(c->d_boxes, sizeof(double) * 6 * 2 * n);
     ALLOC(c->d_bounded, sizeof(uint32_t) * n);
