@@ -129,4 +129,158 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *
     }
 }
 
+
+// ====================================================================================================
+// Onesweep form (single pass over the data per digit, decoupled look-back): replaces the
+// hist -> scan -> scatter triple above with
+//   k_os_hist      : ONE read of the keys builds all 8 global digit histograms
+//   k_os_scan      : exclusive scan of each 256-bin histogram (digit bases)
+//   k_os_pass x 8  : per tile -- stable local ranking as in k_radix_scatter, then the tile's global
+//                    offsets come from a chained look-back over the preceding tiles' published
+//                    {status, count} granules instead of a separate scan kernel.
+// Hand-off protocol (cdna_hip_programming.md Guideline 16, form R2): the datum IS the flag -- one
+// naturally aligned 8-byte granule {status:2 | value:62} written by ONE relaxed agent-scope atomic store
+// (sc1, write-through) and polled with relaxed agent-scope atomic loads (sc1, L1-bypassing); no fence is
+// needed because nothing else is published.  Tile ids are handed out by an atomic ticket, so every
+// predecessor of a spinning tile is already resident and publishes without waiting on anyone: no deadlock
+// whatever the dispatch order.  Granules are zeroed by one hipMemsetAsync per sort.
+constexpr unsigned long long OS_AGG = 1ull << 62;      // value = this tile's count for the digit
+constexpr unsigned long long OS_PREFIX = 2ull << 62;   // value = inclusive prefix over tiles 0..t
+constexpr unsigned long long OS_VALUE_MASK = (1ull << 62) - 1;
+
+__global__ __launch_bounds__(SORT_THREADS) void k_os_hist(const uint64_t *__restrict__ keys, uint32_t n, uint32_t ntiles,
+                                                          uint32_t *__restrict__ ghist /* [8][256] */)
+{
+    __shared__ uint32_t h[8][RADIX];
+    for (int i = threadIdx.x; i < 8 * RADIX; i += SORT_THREADS) (&h[0][0])[i] = 0;
+    __syncthreads();
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * SORT_TILE;
+#pragma unroll 4
+        for (int it = 0; it < SORT_ITEMS; ++it) {
+            const uint32_t i = base + it * SORT_THREADS + threadIdx.x;
+            if (i < n) {
+                const uint64_t k = keys[i];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * RADIX; i += SORT_THREADS) {
+        const uint32_t v = (&h[0][0])[i];
+        if (v) atomicAdd(&ghist[i], v);
+    }
+}
+
+// ghist[p][d] -> exclusive prefix over d (in place).  One workgroup of 256 threads, thread = digit.
+__global__ __launch_bounds__(RADIX) void k_os_scan(uint32_t *__restrict__ ghist)
+{
+    __shared__ uint32_t ws[4];
+    const int d = threadIdx.x, lane = d & 63, w = d >> 6;
+    for (int p = 0; p < 8; ++p) {
+        const uint32_t c = ghist[p * RADIX + d];
+        uint32_t v = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(v, o); if (lane >= o) v += t; }
+        if (lane == 63) ws[w] = v;
+        __syncthreads();
+        uint32_t add = 0;
+        for (int ww = 0; ww < w; ++ww) add += ws[ww];
+        ghist[p * RADIX + d] = v - c + add;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                          uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                          uint32_t n, int shift, const uint32_t *__restrict__ digit_base /* [256] */,
+                                                          unsigned long long *lookback /* [ntiles][256] */, uint32_t *ticket /* [pass]; ticket[8 - pass] = timeout flag */, int first_pass)
+{
+    __shared__ uint32_t wcnt[SORT_WAVES][RADIX];
+    __shared__ uint32_t gbase[RADIX];
+    __shared__ uint32_t s_tile;
+    const uint32_t tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_THREADS) (&wcnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+
+    const uint32_t base_w = tile * SORT_TILE + w * (SORT_ITEMS * 64);
+    uint64_t k[SORT_ITEMS];
+    uint32_t v[SORT_ITEMS];
+    uint32_t rk[SORT_ITEMS];
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const uint32_t i = base_w + it * 64 + lane;
+        const bool ok = i < n;
+        k[it] = ok ? keys_in[i] : ~0ull;
+        v[it] = ok ? (first_pass ? i : vals_in[i]) : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const uint32_t i = base_w + it * 64 + lane;
+        const bool ok = i < n;
+        const uint32_t d = (uint32_t)(k[it] >> shift) & (RADIX - 1);
+        uint64_t m = __ballot(ok);
+        m = ok ? m : ~m;
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+            const uint64_t bb = __ballot((d >> b) & 1u);
+            m &= ((d >> b) & 1u) ? bb : ~bb;
+        }
+        const uint32_t below = __popcll(m & lt_mask);
+        const uint32_t cnt = __popcll(m);
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        uint32_t old = 0;
+        if (ok && lane == leader) { old = wcnt[w][d]; wcnt[w][d] = old + cnt; }
+        old = __shfl(old, leader);
+        rk[it] = old + below;
+    }
+    __syncthreads();
+    // thread = digit: wave-exclusive bases, the tile's count, publish, look back
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int ww = 0; ww < SORT_WAVES; ++ww) { const uint32_t c = wcnt[ww][tid]; wcnt[ww][tid] = run; run += c; }
+        const unsigned long long count = run;
+        unsigned long long *mine = lookback + (size_t)tile * RADIX + tid;
+        unsigned long long excl = 0;
+        if (tile == 0) {
+            __hip_atomic_store(mine, OS_PREFIX | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(mine, OS_AGG | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int t = (int)tile - 1;
+            uint32_t spins = 0;
+            while (true) {
+                const unsigned long long g = __hip_atomic_load(lookback + (size_t)t * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long st = g & ~OS_VALUE_MASK;
+                if (st == 0) {                                                // predecessor has not published yet
+                    if (++spins > (1u << 24)) { atomicExch(ticket + 8, 1u); break; }   // bounded: give up, flag the sort as failed
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += g & OS_VALUE_MASK;
+                if (st == OS_PREFIX) break;
+                --t;                                                          // aggregate only: keep walking back
+            }
+            __hip_atomic_store(mine, OS_PREFIX | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        gbase[tid] = digit_base[tid] + (uint32_t)excl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const uint32_t i = base_w + it * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(k[it] >> shift) & (RADIX - 1);
+            const uint32_t pos = gbase[d] + wcnt[w][d] + rk[it];
+            keys_out[pos] = k[it];
+            vals_out[pos] = v[it];
+        }
+    }
+}
+
 }  // namespace cd

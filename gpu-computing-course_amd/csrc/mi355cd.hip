@@ -41,6 +41,8 @@ struct cd_ctx {
     // sort
     uint64_t *d_keys[2] = {nullptr, nullptr}; uint32_t *d_perm[2] = {nullptr, nullptr};
     uint32_t *d_counts = nullptr; uint32_t ntiles = 0;
+    // onesweep state: one allocation = [8][256] u32 histograms | 8 u32 tickets (padded) | [8][ntiles][256] u64 granules
+    void *d_os = nullptr; size_t os_bytes = 0; uint32_t *d_os_hist = nullptr; uint32_t *d_os_ticket = nullptr; unsigned long long *d_os_look = nullptr;
     double *d_frame = nullptr, *d_partial = nullptr;
     // tree
     LeafTri *d_leaf = nullptr; int2 *d_children = nullptr; int2 *d_ranges = nullptr; int32_t *d_parent = nullptr;
@@ -61,7 +63,7 @@ void free_all(cd_ctx *c)
 {
     hipFree(c->d_verts); hipFree(c->d_vidx); hipFree(c->d_ids);
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
-    hipFree(c->d_counts); hipFree(c->d_frame); hipFree(c->d_partial);
+    hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_leaf); hipFree(c->d_children); hipFree(c->d_ranges); hipFree(c->d_parent); hipFree(c->d_boxes);
     hipFree(c->d_bounded); hipFree(c->d_recs); hipFree(c->d_small); hipFree(c->d_ctr);
     hipFree(c->d_pairs); hipFree(c->d_defer); hipFree(c->d_deep);
@@ -96,13 +98,15 @@ int enqueue_morton_sort(cd_ctx *c)
     }
     k_morton<<<cdiv(n, 256), 256, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_frame, c->d_keys[0]);
     HIPCHK(hipEventRecord(c->ev[EV_MORTON1], s));
+    // onesweep: one histogram read, then one pass over the data per digit (see cd_sort.h)
+    HIPCHK(hipMemsetAsync(c->d_os, 0, c->os_bytes, s));
+    k_os_hist<<<c->ntiles < 512 ? c->ntiles : 512, SORT_THREADS, 0, s>>>(c->d_keys[0], n, c->ntiles, c->d_os_hist);
+    k_os_scan<<<1, RADIX, 0, s>>>(c->d_os_hist);
     int cur = 0;
     for (int pass = 0; pass < 8; ++pass) {
-        const int shift = pass * RADIX_BITS;
-        k_radix_hist<<<c->ntiles, SORT_THREADS, 0, s>>>(c->d_keys[cur], n, shift, c->d_counts, c->ntiles);
-        k_scan_exclusive<<<1, 1024, 0, s>>>(c->d_counts, RADIX * c->ntiles);
-        k_radix_scatter<<<c->ntiles, SORT_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1],
-                                                          n, shift, c->d_counts, c->ntiles, pass == 0);
+        k_os_pass<<<c->ntiles, SORT_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1], n, pass * RADIX_BITS,
+                                                    c->d_os_hist + pass * RADIX, c->d_os_look + (size_t)pass * c->ntiles * RADIX,
+                                                    c->d_os_ticket + pass, pass == 0);
         cur ^= 1;
     }
     // 8 passes: sorted data is back in buffer 0
@@ -246,6 +250,11 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     if (ids) ALLOC(c->d_ids, sizeof(uint32_t) * n);
     for (int i = 0; i < 2; ++i) { ALLOC(c->d_keys[i], sizeof(uint64_t) * n); ALLOC(c->d_perm[i], sizeof(uint32_t) * n); }
     ALLOC(c->d_counts, sizeof(uint32_t) * RADIX * c->ntiles);
+    c->os_bytes = sizeof(uint32_t) * 8 * RADIX + 64 + sizeof(unsigned long long) * 8 * (size_t)c->ntiles * RADIX;
+    ALLOC(c->d_os, c->os_bytes);
+    c->d_os_hist = reinterpret_cast<uint32_t *>(c->d_os);
+    c->d_os_ticket = c->d_os_hist + 8 * RADIX;
+    c->d_os_look = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_os) + sizeof(uint32_t) * 8 * RADIX + 64);
     ALLOC(c->d_frame, sizeof(double) * 6);
     ALLOC(c->d_partial, sizeof(double) * 6 * BOUNDS_BLOCKS);
     ALLOC(c->d_leaf, sizeof(LeafTri) * n);
@@ -302,12 +311,22 @@ int cd_set_morton_frame(cd_ctx *c, int mode, const double offset[3], const doubl
     return CD_OK;
 }
 
+// the onesweep look-back spins are bounded; a timeout sets one of the words d_os_ticket[8..15]
+static int check_sort_flags(cd_ctx *c)
+{
+    uint32_t f[8] = {};
+    HIPCHK(hipMemcpyAsync(f, c->d_os_ticket + 8, sizeof f, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 8; ++i) if (f[i]) return CD_ERR_SORT;
+    return CD_OK;
+}
+
 int cd_morton_sort(cd_ctx *c)
 {
     if (!c) return CD_ERR_ARG;
     int rc = enqueue_morton_sort(c);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((rc = check_sort_flags(c))) return rc;
     c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
     c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
     c->stage = ST_SORTED;
@@ -379,6 +398,7 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     if ((rc = enqueue_refit(c))) return rc;
     rc = run_traversal(c, nullptr, 0, pairs, cap_pairs, n_pairs);     // synchronises
     if (rc < 0) return rc;
+    { int rs = check_sort_flags(c); if (rs) return rs; }
     c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
     c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
     c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);

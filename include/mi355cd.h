@@ -34,7 +34,8 @@ enum {
     CD_ERR_ARG       = -1001,  /* null / zero-sized / inconsistent argument                         */
     CD_ERR_ORDER     = -1002,  /* stage called before the stage it depends on                       */
     CD_ERR_NO_DEVICE = -1003,  /* no HIP device: the library has no CPU fallback                    */
-    CD_ERR_INDEX     = -1004   /* a vertex index >= nv (checked at cd_create)                       */
+    CD_ERR_INDEX     = -1004,  /* a vertex index >= nv (checked at cd_create)                       */
+    CD_ERR_SORT      = -1005   /* a bounded device-side wait in the sort timed out (results invalid) */
 };
 
 /* Morton normalisation frame (morton.h:43-58 hard-codes one data set's bounds). */
