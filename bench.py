@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--quads", type=int, default=500, help="quads per sheet edge; 500 -> 1 000 000 triangles per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traversal", type=int, default=None, help="CD_OPT_TRAVERSAL override (0 lane-private FP64, 1 wave-queued)")
+    ap.add_argument("--qpw", type=int, default=None, help="CD_OPT_QUERIES_PER_WAVE override")
     args = ap.parse_args()
 
     import torch
@@ -106,6 +108,10 @@ def main():
     nt = vidx.shape[0]
     # neighborCount compares vertex INDICES: a per-rank base makes them global for the cross-rank pass
     engine = multi.HipEngine(verts, vidx, ids, device, frame, vertex_id_base=vbase if world > 1 else 0)
+    if args.traversal is not None:
+        engine.cd.set_option(mi355cd.CD_OPT_TRAVERSAL, args.traversal)
+    if args.qpw is not None:
+        engine.cd.set_option(mi355cd.CD_OPT_QUERIES_PER_WAVE, args.qpw)
     cap = 1 << 22
 
     def step():

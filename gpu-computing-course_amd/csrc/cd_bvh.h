@@ -15,6 +15,17 @@ struct alignas(128) NodeRec {
 };
 static_assert(sizeof(NodeRec) == 128, "NodeRec must be one 128-byte line");
 
+// fp32 traversal record, one 64-byte line: both child boxes rounded OUTWARD to float (lo down, hi up) +
+// both child ids.  Internal-node boxes only cull; a conservative (superset) box can never lose a pair, and
+// every leaf hit is re-decided with the exact FP64 product-form test of box.cuh:40-43 before it counts.
+struct alignas(64) NodeRec32 {
+    float l_lo[3], l_hi[3];
+    float r_lo[3], r_hi[3];
+    int32_t cl, cr;
+    int32_t pad[2];
+};
+static_assert(sizeof(NodeRec32) == 64, "NodeRec32 must be one 64-byte line");
+
 // Sorted-order leaf payload: {ID, vIdx[0..2]} (triangle.cuh:6,9) -- 16 B instead of the 56-byte Triangle.
 struct alignas(16) LeafTri { uint32_t id, v0, v1, v2; };
 
@@ -169,7 +180,16 @@ constexpr int REFIT_BLK = 512;     // leaves per workgroup
 
 // Merge step shared by both refit phases: given my box, my sibling's box and which side I am, write the
 // parent's 128-byte traversal record {bl, br, cl, cr} and return the parent's box (bvh.cuh:277).
-__device__ __forceinline__ Box refit_merge(const Box &mine, const Box &other, bool left, int2 ch, NodeRec *__restrict__ rec)
+__device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ r, const Box &bl, const Box &br, int2 ch)
+{
+    float4 *p = reinterpret_cast<float4 *>(r);
+    p[0] = make_float4(__double2float_rd(bl.x1), __double2float_rd(bl.y1), __double2float_rd(bl.z1), __double2float_ru(bl.x2));
+    p[1] = make_float4(__double2float_ru(bl.y2), __double2float_ru(bl.z2), __double2float_rd(br.x1), __double2float_rd(br.y1));
+    p[2] = make_float4(__double2float_rd(br.z1), __double2float_ru(br.x2), __double2float_ru(br.y2), __double2float_ru(br.z2));
+    reinterpret_cast<int4 *>(r)[3] = make_int4(ch.x, ch.y, 0, 0);
+}
+
+__device__ __forceinline__ Box refit_merge(const Box &mine, const Box &other, bool left, int2 ch, NodeRec *__restrict__ rec, NodeRec32 *__restrict__ rec32)
 {
     Box bl, br;
     bl.x1 = left ? mine.x1 : other.x1; bl.x2 = left ? mine.x2 : other.x2;
@@ -182,6 +202,7 @@ __device__ __forceinline__ Box refit_merge(const Box &mine, const Box &other, bo
     rp[0] = make_double2(bl.x1, bl.x2); rp[1] = make_double2(bl.y1, bl.y2); rp[2] = make_double2(bl.z1, bl.z2);
     rp[3] = make_double2(br.x1, br.x2); rp[4] = make_double2(br.y1, br.y2); rp[5] = make_double2(br.z1, br.z2);
     reinterpret_cast<int2 *>(rp + 6)[0] = ch;
+    store_rec32(rec32, bl, br, ch);
     return box_merge(bl, br);
 }
 
@@ -195,6 +216,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_local(const double *__restr
                                                            const int2 *__restrict__ children, const int32_t *__restrict__ parent,
                                                            const int2 *__restrict__ ranges,
                                                            double *__restrict__ boxes, uint32_t *__restrict__ bounded, NodeRec *__restrict__ recs,
+                                                           NodeRec32 *__restrict__ recs32,
                                                            int32_t *__restrict__ top_list, uint32_t *__restrict__ top_count)
 {
     __shared__ double lbox[REFIT_BLK][2][6];       // deposit slots: [local node][side] = child box, 48 KB
@@ -225,7 +247,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_local(const double *__restr
         const double *src = lbox[slot][left ? 1 : 0];
         const Box other{src[0], src[1], src[2], src[3], src[4], src[5]};
         bounded[cur] = 2;                                                  // Node::bounded: both arrivals seen
-        mine = refit_merge(mine, other, left, ch, recs + cur);
+        mine = refit_merge(mine, other, left, ch, recs + cur, recs32 + cur);
         me = cur;
         store_box(boxes, me, mine);
         cur = parent[me];
@@ -236,7 +258,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_local(const double *__restr
 // top_list entry; arrival counter in global memory with agent-scope acq_rel ordering (the reference's
 // atomicAdd at bvh.cuh:270 has no fence at all -- a race on real hardware).
 __global__ __launch_bounds__(256) void k_refit_top(int n, const int2 *__restrict__ children, const int32_t *__restrict__ parent,
-                                                   double *boxes, uint32_t *bounded, NodeRec *__restrict__ recs,
+                                                   double *boxes, uint32_t *bounded, NodeRec *__restrict__ recs, NodeRec32 *__restrict__ recs32,
                                                    const int32_t *__restrict__ top_list, const uint32_t *__restrict__ top_count)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,7 +272,7 @@ __global__ __launch_bounds__(256) void k_refit_top(int n, const int2 *__restrict
         const int2 ch = children[cur];
         const bool left = (ch.x == me);
         const Box other = load_box(boxes, left ? ch.y : ch.x);
-        mine = refit_merge(mine, other, left, ch, recs + cur);
+        mine = refit_merge(mine, other, left, ch, recs + cur, recs32 + cur);
         me = cur;
         store_box(boxes, me, mine);
         cur = parent[me];

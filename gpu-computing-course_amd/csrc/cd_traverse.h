@@ -123,6 +123,181 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_
     }
 }
 
+// ====================================================================================================
+// Variant B ("wave-queued"): the traversal the north star describes.
+//   * the descent itself is pure fp32 + integer work on 64-byte NodeRec32 lines (conservative boxes);
+//   * every leaf the fp32 test cannot rule out is pushed as a CANDIDATE (query, leaf) onto a wavefront-shared
+//     LDS queue, compacted with __ballot / popcount prefixes of the active lanes;
+//   * whenever the queue holds >= 64 candidates the whole wave drains 64 of them, one per lane: exact FP64
+//     leaf-AABB test (box.cuh:40-43, this is what "pairs tested" counts), neighbour filter
+//     (collision.cuh:38), ID rule (tri_contact.cuh:81) and the 17-axis SAT (tri_contact.cuh:19-78) run
+//     with all lanes busy instead of inside a divergent branch of the descent;
+//   * lanes whose query has finished take the next query of the wave's chunk (dynamic refill), so a wave
+//     stays full until its chunk is exhausted.
+// The per-lane descent stack stays in LDS ([depth][thread], bank-conflict free); overflow hands the subtree
+// to the deep pass exactly like variant A.
+constexpr int WQ_STACK = 16;                 // LDS stack entries per lane
+constexpr int WQ_QCAP  = 192;                // queue slots per wave: < 64 left over + at most 128 new per step
+constexpr int WQ_WAVES = TRAV_THREADS / 64;
+
+struct Candidates { uint32_t q, leaf; };
+
+// One candidate per lane: exact box test -> tested++ ; neighbour filter, ID rule, SAT -> pair append.
+template <bool EXTERNAL>
+__device__ __forceinline__ void wq_exact(uint32_t qi, uint32_t lj, int n, const QuerySrc &src, const LeafTri *__restrict__ leaf,
+                                         const double *__restrict__ boxes, const double *__restrict__ verts, uint32_t vbase,
+                                         uint32_t *__restrict__ pairs, unsigned long long cap, TravCounters *__restrict__ ctr,
+                                         uint32_t &tested)
+{
+    const LeafTri lt = leaf[lj];
+    const Box lb = load_box(boxes, (n - 1) + (int)lj);
+    uint32_t q_id, qa, qb, qc; d3 P1, P2, P3; Box qbox;
+    if (EXTERNAL) {
+        const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + qi;
+        P1 = d3{q->v[0], q->v[1], q->v[2]}; P2 = d3{q->v[3], q->v[4], q->v[5]}; P3 = d3{q->v[6], q->v[7], q->v[8]};
+        q_id = q->id; qa = q->vidx[0]; qb = q->vidx[1]; qc = q->vidx[2];
+        qbox = box_set(P1, P2, P3);
+    } else {
+        const LeafTri ql = leaf[qi];
+        q_id = ql.id; qa = ql.v0; qb = ql.v1; qc = ql.v2;
+        qbox = load_box(boxes, (n - 1) + (int)qi);
+    }
+    if (!box_overlap(qbox, lb)) return;                                    // collision.cuh:31-32, exact
+    ++tested;
+    if (neighbor_count(qa, qb, qc, lt.v0 + vbase, lt.v1 + vbase, lt.v2 + vbase) >= 1) return;   // collision.cuh:38
+    if (!(q_id < lt.id)) return;                                           // tri_contact.cuh:81
+    if (!EXTERNAL) { P1 = load_vertex(verts, qa); P2 = load_vertex(verts, qb); P3 = load_vertex(verts, qc); }
+    if (tri_contact(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) {
+        const unsigned long long cur = atomicAdd(&ctr->n_pairs, 1ull);      // collision.cuh:40
+        if (cur < cap) { pairs[2 * cur] = q_id; pairs[2 * cur + 1] = lt.id; }
+    }
+}
+
+// queries_per_wave: size of the contiguous chunk of queries one wave works through (multiple of 64).
+template <bool EXTERNAL, bool DEEP>
+__global__ __launch_bounds__(TRAV_THREADS) void k_traverse_wq(QuerySrc src, uint32_t nq, int n, uint32_t queries_per_wave,
+                                                              const NodeRec32 *__restrict__ recs, const LeafTri *__restrict__ leaf,
+                                                              const double *__restrict__ boxes, const double *__restrict__ verts,
+                                                              uint32_t *__restrict__ pairs, unsigned long long cap,
+                                                              TravCounters *__restrict__ ctr,
+                                                              uint2 *__restrict__ defer_list, uint32_t defer_cap,
+                                                              int32_t *__restrict__ deep_stacks, uint32_t vbase)
+{
+    __shared__ int32_t lds_stack[DEEP ? 1 : WQ_STACK][TRAV_THREADS];
+    __shared__ Candidates queue[WQ_WAVES][WQ_QCAP];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t wave_id = blockIdx.x * WQ_WAVES + w;
+    // this wave's chunk of work items (queries, or deferred (query, subtree) items in the deep pass)
+    const unsigned long long c0 = (unsigned long long)wave_id * queries_per_wave;
+    const uint32_t chunk_begin = (uint32_t)(c0 < nq ? c0 : nq);
+    const uint32_t chunk_end = (uint32_t)(c0 + queries_per_wave < nq ? c0 + queries_per_wave : nq);
+    uint32_t next = chunk_begin;                        // wave-uniform: next unassigned work item
+    uint32_t qcount = 0;                                // wave-uniform: candidates waiting in the queue
+    uint32_t tested = 0, visits = 0;
+
+    // lane state
+    int32_t node = -1; int sptr = 0; uint32_t qi = 0, self_leaf = 0xffffffffu;
+    float qlo0 = 0, qlo1 = 0, qlo2 = 0, qhi0 = 0, qhi1 = 0, qhi2 = 0;
+    int32_t *gstack = DEEP ? deep_stacks + ((size_t)wave_id * 64 + lane) * DEEP_STACK : nullptr;
+    const int stack_cap = DEEP ? DEEP_STACK : WQ_STACK;
+
+    while (true) {
+        // ---- refill idle lanes with the next work items of the chunk
+        {
+            const bool idle = (node == -1);
+            const unsigned long long mi = __ballot(idle);
+            const uint32_t remaining = chunk_end - next;
+            if (mi != 0ull && remaining != 0u) {
+                const uint32_t rank = __popcll(mi & lt_mask);
+                if (idle && rank < remaining) {
+                    const uint32_t item = next + rank;
+                    Box qb;
+                    if (DEEP) { qi = src.list[item].x; node = (int32_t)src.list[item].y; }
+                    else { qi = item; node = (n > 1) ? 0 : -1; }
+                    if (EXTERNAL) {
+                        const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + qi;
+                        qb = box_set(d3{q->v[0], q->v[1], q->v[2]}, d3{q->v[3], q->v[4], q->v[5]}, d3{q->v[6], q->v[7], q->v[8]});
+                        self_leaf = 0xffffffffu;
+                    } else {
+                        qb = load_box(boxes, (n - 1) + (int)qi);
+                        self_leaf = qi;
+                        // the query meets its own leaf in every traversal: decide that hit here, exactly, once
+                        // (not in the deep pass, which only continues a traversal that already did)
+                        if (!DEEP && box_overlap(qb, qb)) ++tested;
+                    }
+                    qlo0 = __double2float_rd(qb.x1); qhi0 = __double2float_ru(qb.x2);
+                    qlo1 = __double2float_rd(qb.y1); qhi1 = __double2float_ru(qb.y2);
+                    qlo2 = __double2float_rd(qb.z1); qhi2 = __double2float_ru(qb.z2);
+                    sptr = 0;
+                }
+                const uint32_t taken = __popcll(mi);
+                next += (taken < remaining) ? taken : remaining;
+            }
+        }
+        const bool active = (node != -1);
+        if (__ballot(active) == 0ull) break;            // chunk exhausted and every lane finished
+
+        // ---- one descent step per active lane (fp32, conservative)
+        bool candL = false, candR = false; uint32_t leafL = 0, leafR = 0;
+        if (active) {
+            ++visits;
+            const float4 *rp = reinterpret_cast<const float4 *>(recs + node);
+            const float4 a = rp[0], b = rp[1], c = rp[2];
+            const int4 ch = reinterpret_cast<const int4 *>(rp)[3];
+            // left: lo = (a.x, a.y, a.z) hi = (a.w, b.x, b.y); right: lo = (b.z, b.w, c.x) hi = (c.y, c.z, c.w)
+            const bool ol = qlo0 < a.w && a.x < qhi0 && qlo1 < b.x && a.y < qhi1 && qlo2 < b.y && a.z < qhi2;
+            const bool orr = qlo0 < c.y && b.z < qhi0 && qlo1 < c.z && b.w < qhi1 && qlo2 < c.w && c.x < qhi2;
+            int32_t nxt = -1;
+            if (ol) {
+                if (ch.x >= n - 1) { leafL = (uint32_t)(ch.x - (n - 1)); candL = (leafL != self_leaf); }
+                else nxt = ch.x;
+            }
+            if (orr) {
+                if (ch.y >= n - 1) { leafR = (uint32_t)(ch.y - (n - 1)); candR = (leafR != self_leaf); }
+                else if (nxt == -1) nxt = ch.y;
+                else if (sptr < stack_cap) { if (DEEP) gstack[sptr] = ch.y; else lds_stack[sptr][tid] = ch.y; ++sptr; }
+                else {
+                    const uint32_t k = atomicAdd(&ctr->n_deferred, 1u);
+                    if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)ch.y);
+                }
+            }
+            if (nxt != -1) node = nxt;
+            else if (sptr > 0) { --sptr; node = DEEP ? gstack[sptr] : lds_stack[sptr][tid]; }
+            else node = -1;
+        }
+        // ---- enqueue candidates, compacted over the active lanes
+        {
+            const unsigned long long mL = __ballot(candL), mR = __ballot(candR);
+            const uint32_t nL = __popcll(mL);
+            if (candL) queue[w][qcount + __popcll(mL & lt_mask)] = Candidates{qi, leafL};
+            if (candR) queue[w][qcount + nL + __popcll(mR & lt_mask)] = Candidates{qi, leafR};
+            qcount += nL + __popcll(mR);
+        }
+        // ---- drain full batches: one candidate per lane, all 64 lanes busy
+        while (qcount >= 64) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const Candidates cnd = queue[w][qcount - 64 + lane];
+            qcount -= 64;
+            wq_exact<EXTERNAL>(cnd.q, cnd.leaf, n, src, leaf, boxes, verts, vbase, pairs, cap, ctr, tested);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    // ---- final partial batch
+    if (qcount > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < qcount) {
+            const Candidates cnd = queue[w][lane];
+            wq_exact<EXTERNAL>(cnd.q, cnd.leaf, n, src, leaf, boxes, verts, vbase, pairs, cap, ctr, tested);
+        }
+    }
+    unsigned long long t64 = wave_sum_u64(tested), v64 = wave_sum_u64(visits);
+    if (lane == 0) {
+        if (t64) atomicAdd(&ctr->pairs_tested, t64);
+        if (v64) atomicAdd(&ctr->node_visits, v64);
+    }
+}
+
 // ---------------------------------------------------------------- brute force (check.cuh:117-141)
 // Tile of 256 "j" triangles staged in LDS per step; thread i tests its triangle against the tile.
 __global__ __launch_bounds__(256) void k_brute_force(const double *__restrict__ verts, const uint32_t *__restrict__ vidx,

@@ -32,7 +32,9 @@ struct cd_ctx {
     uint32_t nv = 0, nt = 0;
     int stage = ST_CREATED;
     int frame_mode = CD_FRAME_REFERENCE;
-    uint32_t vbase = 0;                     // global id of local vertex 0 (cross-rank neighbour filter)
+    uint32_t vbase = 0;
+    int trav_variant = 1;                   // CD_OPT_TRAVERSAL: 0 = lane-private FP64 (A), 1 = wave-queued fp32 descent (B)
+    uint32_t queries_per_wave = 128;        // CD_OPT_QUERIES_PER_WAVE (variant B chunk size)                     // global id of local vertex 0 (cross-rank neighbour filter)
     double frame_host[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};   // morton.h:45,51,57
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
@@ -46,7 +48,7 @@ struct cd_ctx {
     double *d_frame = nullptr, *d_partial = nullptr;
     // tree
     LeafTri *d_leaf = nullptr; int2 *d_children = nullptr; int2 *d_ranges = nullptr; int32_t *d_parent = nullptr;
-    double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec *d_recs = nullptr;
+    double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec *d_recs = nullptr; NodeRec32 *d_recs32 = nullptr;
     uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
     // traversal
     TravCounters *d_ctr = nullptr;
@@ -65,7 +67,7 @@ void free_all(cd_ctx *c)
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_leaf); hipFree(c->d_children); hipFree(c->d_ranges); hipFree(c->d_parent); hipFree(c->d_boxes);
-    hipFree(c->d_bounded); hipFree(c->d_recs); hipFree(c->d_small); hipFree(c->d_ctr);
+    hipFree(c->d_bounded); hipFree(c->d_recs); hipFree(c->d_recs32); hipFree(c->d_small); hipFree(c->d_ctr);
     hipFree(c->d_pairs); hipFree(c->d_defer); hipFree(c->d_deep);
     for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -141,8 +143,8 @@ int enqueue_refit(cd_ctx *c)
     uint32_t *top_count = c->d_small + 4;
     HIPCHK(hipMemsetAsync(top_count, 0, sizeof(uint32_t), s));
     k_refit_local<<<cdiv(n, REFIT_BLK), REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_children, c->d_parent, c->d_ranges,
-                                                          c->d_boxes, c->d_bounded, c->d_recs, top_list, top_count);
-    k_refit_top<<<cdiv(n, 256), 256, 0, s>>>((int)n, c->d_children, c->d_parent, c->d_boxes, c->d_bounded, c->d_recs, top_list, top_count);
+                                                          c->d_boxes, c->d_bounded, c->d_recs, c->d_recs32, top_list, top_count);
+    k_refit_top<<<cdiv(n, 256), 256, 0, s>>>((int)n, c->d_children, c->d_parent, c->d_boxes, c->d_bounded, c->d_recs, c->d_recs32, top_list, top_count);
     HIPCHK(hipEventRecord(c->ev[EV_REFIT1], s));
     HIPCHK(hipGetLastError());
     return 0;
@@ -166,12 +168,23 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
         HIPCHK(hipMemsetAsync(c->d_ctr, 0, sizeof(TravCounters), s));
         QuerySrc src{c->d_leaf, c->d_boxes, d_ext, nullptr};
         if (nq > 0) {
-            if (external)
-                k_traverse<true, false><<<cdiv(nq, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nq, (int)n, c->d_recs, c->d_leaf, c->d_verts,
-                                                                                     c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr, external ? c->vbase : 0u);
-            else
-                k_traverse<false, false><<<cdiv(nq, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nq, (int)n, c->d_recs, c->d_leaf, c->d_verts,
-                                                                                      c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr, external ? c->vbase : 0u);
+            if (c->trav_variant == 0) {
+                if (external)
+                    k_traverse<true, false><<<cdiv(nq, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nq, (int)n, c->d_recs, c->d_leaf, c->d_verts,
+                                                                                         c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr, c->vbase);
+                else
+                    k_traverse<false, false><<<cdiv(nq, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nq, (int)n, c->d_recs, c->d_leaf, c->d_verts,
+                                                                                          c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr, 0u);
+            } else {
+                const uint32_t qpw = c->queries_per_wave;
+                const uint32_t blocks = cdiv(nq, qpw * WQ_WAVES);
+                if (external)
+                    k_traverse_wq<true, false><<<blocks, TRAV_THREADS, 0, s>>>(src, nq, (int)n, qpw, c->d_recs32, c->d_leaf, c->d_boxes, c->d_verts,
+                                                                            c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr, c->vbase);
+                else
+                    k_traverse_wq<false, false><<<blocks, TRAV_THREADS, 0, s>>>(src, nq, (int)n, qpw, c->d_recs32, c->d_leaf, c->d_boxes, c->d_verts,
+                                                                             c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr, 0u);
+            }
             ++launches;
         }
         HIPCHK(hipEventRecord(c->ev[EV_TRAV1], s));      // device time of the kernel only: recorded before the read-back
@@ -187,20 +200,30 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
         }
         // deep pass over the deferred (query, subtree) items with global-memory stacks
         const uint32_t nd = h.n_deferred;
-        if (nd > c->deep_items) {
+        const uint64_t deep_lanes = (uint64_t)cdiv(nd, 64) * 64 + 256;       // variant B indexes stacks by launched lane
+        if (deep_lanes > c->deep_items) {
             hipFree(c->d_deep); c->d_deep = nullptr; c->deep_items = 0;
-            HIPCHK(hipMalloc(&c->d_deep, sizeof(int32_t) * (size_t)DEEP_STACK * nd));
-            c->deep_items = nd;
+            HIPCHK(hipMalloc(&c->d_deep, sizeof(int32_t) * (size_t)DEEP_STACK * deep_lanes));
+            c->deep_items = deep_lanes;
         }
         HIPCHK(hipEventRecord(c->ev[EV_DEEP0], s));
         HIPCHK(hipMemsetAsync(&c->d_ctr->n_deferred, 0, sizeof(uint32_t), s));
         src.list = c->d_defer;
-        if (external)
-            k_traverse<true, true><<<cdiv(nd, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nd, (int)n, c->d_recs, c->d_leaf, c->d_verts,
-                                                                                c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep, external ? c->vbase : 0u);
-        else
-            k_traverse<false, true><<<cdiv(nd, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nd, (int)n, c->d_recs, c->d_leaf, c->d_verts,
-                                                                                 c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep, external ? c->vbase : 0u);
+        if (c->trav_variant == 0) {
+            if (external)
+                k_traverse<true, true><<<cdiv(nd, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nd, (int)n, c->d_recs, c->d_leaf, c->d_verts,
+                                                                                    c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep, c->vbase);
+            else
+                k_traverse<false, true><<<cdiv(nd, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nd, (int)n, c->d_recs, c->d_leaf, c->d_verts,
+                                                                                     c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep, 0u);
+        } else {
+            if (external)
+                k_traverse_wq<true, true><<<cdiv(nd, 64 * WQ_WAVES), TRAV_THREADS, 0, s>>>(src, nd, (int)n, 64u, c->d_recs32, c->d_leaf, c->d_boxes, c->d_verts,
+                                                                                        c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep, c->vbase);
+            else
+                k_traverse_wq<false, true><<<cdiv(nd, 64 * WQ_WAVES), TRAV_THREADS, 0, s>>>(src, nd, (int)n, 64u, c->d_recs32, c->d_leaf, c->d_boxes, c->d_verts,
+                                                                                         c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep, 0u);
+        }
         ++launches;
         HIPCHK(hipEventRecord(c->ev[EV_DEEP1], s));
         HIPCHK(hipMemcpyAsync(&h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost, s));
@@ -264,6 +287,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_boxes, sizeof(double) * 6 * 2 * n);
     ALLOC(c->d_bounded, sizeof(uint32_t) * n);
     ALLOC(c->d_recs, sizeof(NodeRec) * n);
+    ALLOC(c->d_recs32, sizeof(NodeRec32) * n);
     ALLOC(c->d_small, sizeof(uint32_t) * 16);
     ALLOC(c->d_ctr, sizeof(TravCounters));
     c->defer_cap = 1u << 16;
@@ -471,6 +495,14 @@ int cd_export_tree(cd_ctx *c, int32_t *parent, int32_t *left, int32_t *right, do
 
 int cd_get_stats(cd_ctx *c, cd_stats *out) { if (!c || !out) return CD_ERR_ARG; *out = c->stats; return CD_OK; }
 int cd_num_triangles(cd_ctx *c, uint32_t *nt) { if (!c || !nt) return CD_ERR_ARG; *nt = c->nt; return CD_OK; }
+
+int cd_set_option(cd_ctx *c, int key, int64_t value)
+{
+    if (!c) return CD_ERR_ARG;
+    if (key == CD_OPT_TRAVERSAL) { if (value != 0 && value != 1) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
+    if (key == CD_OPT_QUERIES_PER_WAVE) { if (value < 64 || value > (1 << 20) || value % 64) return CD_ERR_ARG; c->queries_per_wave = (uint32_t)value; return CD_OK; }
+    return CD_ERR_ARG;
+}
 
 int cd_set_vertex_id_base(cd_ctx *c, uint32_t base) { if (!c) return CD_ERR_ARG; c->vbase = base; return CD_OK; }
 

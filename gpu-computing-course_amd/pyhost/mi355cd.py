@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmi355cd.so")
 CD_OK, CD_OVERFLOW = 0, 1
 CD_ERR_ARG, CD_ERR_ORDER, CD_ERR_NO_DEVICE, CD_ERR_INDEX = -1001, -1002, -1003, -1004
 CD_FRAME_REFERENCE, CD_FRAME_AUTO, CD_FRAME_CUSTOM = 0, 1, 2
+CD_ERR_SORT = -1005
+CD_OPT_TRAVERSAL, CD_OPT_QUERIES_PER_WAVE = 0, 1
 
 QUERY_DTYPE = np.dtype([("v", "<f8", (9,)), ("id", "<u4"), ("vidx", "<u4", (3,))])
 assert QUERY_DTYPE.itemsize == 88
@@ -34,7 +36,7 @@ EXPORTS = [
     "cd_build_hierarchy", "cd_refit_boxes", "cd_check_internal", "cd_check_leaves",
     "cd_check_triangle_idx", "cd_find_collisions", "cd_self_collide", "cd_brute_force",
     "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_num_triangles",
-    "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
+    "cd_set_option", "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
 ]
 
 _lib = None
@@ -67,6 +69,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_export_tree.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.cd_get_stats.argtypes = [vp, C.POINTER(CdStats)]
     lib.cd_num_triangles.argtypes = [vp, u32p]
+    lib.cd_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.cd_set_vertex_id_base.argtypes = [vp, C.c_uint32]
     lib.cd_root_box.argtypes = [vp, vp]
     lib.cd_pack_queries.argtypes = [vp, vp, vp, C.c_uint64, u64p]
@@ -131,6 +134,9 @@ class CollisionDetector:
         off = None if offset is None else np.ascontiguousarray(offset, dtype=np.float64)
         sp = None if span is None else np.ascontiguousarray(span, dtype=np.float64)
         self._chk("cd_set_morton_frame", self.lib.cd_set_morton_frame(self._ctx, mode, _ptr(off), _ptr(sp)))
+
+    def set_option(self, key: int, value: int):
+        self._chk("cd_set_option", self.lib.cd_set_option(self._ctx, key, value))
 
     def update_vertices(self, verts):
         v = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
