@@ -4,13 +4,26 @@
 
 namespace cd {
 
-struct TravCounters {                 // device-side accumulators of one traversal
-    unsigned long long n_pairs;       // collision.cuh:40 `count`
-    unsigned long long pairs_tested;  // leaf AABB hits (reach neighborCount / SAT)
+// ---------------------------------------------------------------- device-side counters
+// A returning atomic on ONE address retires at only ~88 per microsecond on this chip (MI355X_MICROARCH.md,
+// "dequeue" row), so nothing on the hot path funnels through a single word: statistics and candidate
+// reservations are spread over NSHARD counters, each on its own 128-byte line (shard = workgroup & 63), and
+// pairs are staged per workgroup in LDS and appended with one atomic per workgroup.
+constexpr int NSHARD = 64;
+struct alignas(128) CtrShard {
+    unsigned long long pairs_tested;   // leaf AABB hits (reach neighborCount / SAT)
     unsigned long long node_visits;
-    uint32_t n_deferred;              // (query, subtree) items the LDS stack could not hold (deep pass redoes them)
-    uint32_t pad;
+    unsigned long long n_candidates;   // candidates reserved in this shard of the candidate buffer (may exceed its capacity)
+    unsigned long long pad[13];
 };
+struct alignas(128) TravState {
+    unsigned long long n_pairs;        // collision.cuh:40 `count`
+    uint32_t n_deferred;               // (query, subtree) items the LDS stack could not hold (deep pass redoes them)
+    uint32_t pad0;
+    unsigned long long pad[14];
+    CtrShard shard[NSHARD];
+};
+static_assert(sizeof(CtrShard) == 128 && sizeof(TravState) == 128 * (NSHARD + 1), "counter layout");
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {
@@ -18,33 +31,10 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
-// One leaf hit (collision.cuh:36-44): neighbour filter, ID rule, exact test, append.
-__device__ __forceinline__ void leaf_hit(uint32_t q_id, uint32_t qa, uint32_t qb, uint32_t qc,
-                                         const d3 &P1, const d3 &P2, const d3 &P3,
-                                         const LeafTri lt, const double *__restrict__ verts,
-                                         uint32_t *__restrict__ pairs, unsigned long long cap, TravCounters *__restrict__ ctr,
-                                         uint32_t vbase)
-{
-    // vbase: global id of local vertex 0 -- non-zero only for external (cross-rank) queries, whose
-    // vertex ids are global; local queries compare local indices with local indices (vbase = 0).
-    if (neighbor_count(qa, qb, qc, lt.v0 + vbase, lt.v1 + vbase, lt.v2 + vbase) < 1) {   // collision.cuh:38
-        if (q_id < lt.id) {                                               // tri_contact.cuh:81
-            if (tri_contact(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) {
-                const unsigned long long cur = atomicAdd(&ctr->n_pairs, 1ull);   // collision.cuh:40
-                if (cur < cap) { pairs[2 * cur] = q_id; pairs[2 * cur + 1] = lt.id; }
-            }
-        }
-    }
-}
-
 constexpr int TRAV_THREADS = 256;
-constexpr int TRAV_STACK   = 32;       // LDS entries per lane (the reference's private stack is 32, collision.cuh:21)
-constexpr int DEEP_STACK   = 192;      // global-memory entries per query in the overflow pass
+constexpr int TRAV_STACK   = 32;       // variant A: LDS entries per lane (the reference's private stack is 32, collision.cuh:21)
+constexpr int DEEP_STACK   = 192;      // global-memory entries per item in the overflow pass (tree height <= 96)
 
-// Variant A ("lane-per-query"): one query per lane, per-lane stack in LDS laid out [depth][thread]
-// (conflict-free: lane l of a wave always hits bank l mod 32 pairs).  Queries are leaves in Morton
-// order, so the 64 lanes of a wave walk neighbouring subtrees and their NodeRec fetches coalesce in L1/L2.
-// EXTERNAL: queries come from a cd_query buffer instead of the local leaves.
 struct QuerySrc {
     const LeafTri *leaf;          // local: sorted leaves
     const double  *boxes;         // local: node boxes (query box = boxes[(n-1)+j])
@@ -55,12 +45,34 @@ struct QuerySrc {
 struct ExtQuery { double v[9]; uint32_t id; uint32_t vidx[3]; };
 static_assert(sizeof(ExtQuery) == 88, "cd_query layout");
 
+// ====================================================================================================
+// Variant A ("lane-private"): the reference's shape (collision.cuh:19-71) -- one query per lane, FP64 boxes
+// (128-byte NodeRec), the exact test inline in the descent.  Kept as the in-process A/B baseline.
+// ====================================================================================================
+__device__ __forceinline__ void leaf_hit(uint32_t q_id, uint32_t qa, uint32_t qb, uint32_t qc,
+                                         const d3 &P1, const d3 &P2, const d3 &P3,
+                                         const LeafTri lt, const double *__restrict__ verts,
+                                         uint32_t *__restrict__ pairs, unsigned long long cap, TravState *__restrict__ st,
+                                         uint32_t vbase)
+{
+    // vbase: global id of local vertex 0 -- non-zero only for external (cross-rank) queries, whose
+    // vertex ids are global; local queries compare local indices with local indices (vbase = 0).
+    if (neighbor_count(qa, qb, qc, lt.v0 + vbase, lt.v1 + vbase, lt.v2 + vbase) < 1) {   // collision.cuh:38
+        if (q_id < lt.id) {                                               // tri_contact.cuh:81
+            if (tri_contact(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) {
+                const unsigned long long cur = atomicAdd(&st->n_pairs, 1ull);   // collision.cuh:40
+                if (cur < cap) { pairs[2 * cur] = q_id; pairs[2 * cur + 1] = lt.id; }
+            }
+        }
+    }
+}
+
 template <bool EXTERNAL, bool DEEP>
 __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_t nq, int n,
                                                            const NodeRec *__restrict__ recs, const LeafTri *__restrict__ leaf,
                                                            const double *__restrict__ verts,
                                                            uint32_t *__restrict__ pairs, unsigned long long cap,
-                                                           TravCounters *__restrict__ ctr,
+                                                           TravState *__restrict__ st,
                                                            uint2 *__restrict__ defer_list, uint32_t defer_cap,
                                                            int32_t *__restrict__ deep_stacks, uint32_t vbase)
 {
@@ -94,11 +106,11 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_
             const bool orr = box_overlap(qbox, br);
             int32_t next = -1;
             if (ol) {
-                if (cl >= n - 1) { ++tested; leaf_hit(q_id, qa, qb, qc, P1, P2, P3, leaf[cl - (n - 1)], verts, pairs, cap, ctr, vbase); }
+                if (cl >= n - 1) { ++tested; leaf_hit(q_id, qa, qb, qc, P1, P2, P3, leaf[cl - (n - 1)], verts, pairs, cap, st, vbase); }
                 else next = cl;
             }
             if (orr) {
-                if (cr >= n - 1) { ++tested; leaf_hit(q_id, qa, qb, qc, P1, P2, P3, leaf[cr - (n - 1)], verts, pairs, cap, ctr, vbase); }
+                if (cr >= n - 1) { ++tested; leaf_hit(q_id, qa, qb, qc, P1, P2, P3, leaf[cr - (n - 1)], verts, pairs, cap, st, vbase); }
                 else if (next == -1) next = cr;
                 else {                                                     // both internal: descend left, push right
                     const int cap_s = DEEP ? DEEP_STACK : TRAV_STACK;
@@ -106,7 +118,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_
                     else {
                         // Stack full: hand the right subtree to the deep pass as its own work item and go on.
                         // Each subtree is still traversed exactly once, so no pair is reported twice.
-                        const uint32_t k = atomicAdd(&ctr->n_deferred, 1u);
+                        const uint32_t k = atomicAdd(&st->n_deferred, 1u);
                         if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)cr);
                     }
                 }
@@ -118,76 +130,51 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_
     }
     tested = wave_sum_u64(tested); visits = wave_sum_u64(visits);
     if ((tid & 63) == 0) {
-        if (tested) atomicAdd(&ctr->pairs_tested, tested);
-        if (visits) atomicAdd(&ctr->node_visits, visits);
+        CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
+        if (tested) atomicAdd(&sh->pairs_tested, tested);
+        if (visits) atomicAdd(&sh->node_visits, visits);
     }
 }
 
 // ====================================================================================================
-// Variant B ("wave-queued"): the traversal the north star describes.
-//   * the descent itself is pure fp32 + integer work on 64-byte NodeRec32 lines (conservative boxes);
-//   * every leaf the fp32 test cannot rule out is pushed as a CANDIDATE (query, leaf) onto a wavefront-shared
-//     LDS queue, compacted with __ballot / popcount prefixes of the active lanes;
-//   * whenever the queue holds >= 64 candidates the whole wave drains 64 of them, one per lane: exact FP64
-//     leaf-AABB test (box.cuh:40-43, this is what "pairs tested" counts), neighbour filter
-//     (collision.cuh:38), ID rule (tri_contact.cuh:81) and the 17-axis SAT (tri_contact.cuh:19-78) run
-//     with all lanes busy instead of inside a divergent branch of the descent;
-//   * lanes whose query has finished take the next query of the wave's chunk (dynamic refill), so a wave
-//     stays full until its chunk is exhausted.
-// The per-lane descent stack stays in LDS ([depth][thread], bank-conflict free); overflow hands the subtree
-// to the deep pass exactly like variant A.
+// Variant B ("split", default): the traversal the north star describes, as two kernels.
+//   k_descend : pure fp32 + integer descent over 64-byte NodeRec32 lines (conservative boxes, ~44 VGPRs).
+//       * per-lane stack in LDS ([depth][thread], bank-conflict free); overflow hands the subtree to the deep pass;
+//       * every leaf the fp32 test cannot rule out becomes a CANDIDATE (query, leaf) on a wavefront-shared LDS
+//         queue, compacted over the active lanes with __ballot / popcount prefixes;
+//       * a full batch of 64 candidates leaves the queue as ONE coalesced 512-byte store into the workgroup's
+//         shard of a global candidate buffer, reserved by ONE lane with a single atomicAdd;
+//       * lanes whose query has finished take the next query of the wave's chunk (dynamic refill), so a wave
+//         stays full until its chunk is exhausted.
+//   k_exact   : one candidate per lane: exact FP64 leaf-AABB test (box.cuh:40-43 -- this is what "pairs tested"
+//       counts), neighbour filter (collision.cuh:38), ID rule (tri_contact.cuh:81), 17-axis SAT
+//       (tri_contact.cuh:19-78), all lanes busy, no descent state kept alive.  Pairs are staged in LDS and
+//       appended with one global atomic per workgroup.
+// Candidate-shard overflow is detected from the reserved counts (nothing is written past a shard's capacity)
+// and handled by the host: grow, redo.
+// ====================================================================================================
 constexpr int WQ_STACK = 16;                 // LDS stack entries per lane
 constexpr int WQ_QCAP  = 192;                // queue slots per wave: < 64 left over + at most 128 new per step
 constexpr int WQ_WAVES = TRAV_THREADS / 64;
 
 struct Candidates { uint32_t q, leaf; };
 
-// One candidate per lane: exact box test -> tested++ ; neighbour filter, ID rule, SAT -> pair append.
-template <bool EXTERNAL>
-__device__ __forceinline__ void wq_exact(uint32_t qi, uint32_t lj, int n, const QuerySrc &src, const LeafTri *__restrict__ leaf,
-                                         const double *__restrict__ boxes, const double *__restrict__ verts, uint32_t vbase,
-                                         uint32_t *__restrict__ pairs, unsigned long long cap, TravCounters *__restrict__ ctr,
-                                         uint32_t &tested)
-{
-    const LeafTri lt = leaf[lj];
-    const Box lb = load_box(boxes, (n - 1) + (int)lj);
-    uint32_t q_id, qa, qb, qc; d3 P1, P2, P3; Box qbox;
-    if (EXTERNAL) {
-        const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + qi;
-        P1 = d3{q->v[0], q->v[1], q->v[2]}; P2 = d3{q->v[3], q->v[4], q->v[5]}; P3 = d3{q->v[6], q->v[7], q->v[8]};
-        q_id = q->id; qa = q->vidx[0]; qb = q->vidx[1]; qc = q->vidx[2];
-        qbox = box_set(P1, P2, P3);
-    } else {
-        const LeafTri ql = leaf[qi];
-        q_id = ql.id; qa = ql.v0; qb = ql.v1; qc = ql.v2;
-        qbox = load_box(boxes, (n - 1) + (int)qi);
-    }
-    if (!box_overlap(qbox, lb)) return;                                    // collision.cuh:31-32, exact
-    ++tested;
-    if (neighbor_count(qa, qb, qc, lt.v0 + vbase, lt.v1 + vbase, lt.v2 + vbase) >= 1) return;   // collision.cuh:38
-    if (!(q_id < lt.id)) return;                                           // tri_contact.cuh:81
-    if (!EXTERNAL) { P1 = load_vertex(verts, qa); P2 = load_vertex(verts, qb); P3 = load_vertex(verts, qc); }
-    if (tri_contact(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) {
-        const unsigned long long cur = atomicAdd(&ctr->n_pairs, 1ull);      // collision.cuh:40
-        if (cur < cap) { pairs[2 * cur] = q_id; pairs[2 * cur + 1] = lt.id; }
-    }
-}
-
 // queries_per_wave: size of the contiguous chunk of queries one wave works through (multiple of 64).
 template <bool EXTERNAL, bool DEEP>
-__global__ __launch_bounds__(TRAV_THREADS) void k_traverse_wq(QuerySrc src, uint32_t nq, int n, uint32_t queries_per_wave,
-                                                              const NodeRec32 *__restrict__ recs, const LeafTri *__restrict__ leaf,
-                                                              const double *__restrict__ boxes, const double *__restrict__ verts,
-                                                              uint32_t *__restrict__ pairs, unsigned long long cap,
-                                                              TravCounters *__restrict__ ctr,
-                                                              uint2 *__restrict__ defer_list, uint32_t defer_cap,
-                                                              int32_t *__restrict__ deep_stacks, uint32_t vbase)
+__global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t nq, int n, uint32_t queries_per_wave,
+                                                          const NodeRec32 *__restrict__ recs, const double *__restrict__ boxes,
+                                                          TravState *__restrict__ st,
+                                                          Candidates *__restrict__ cand, unsigned long long shard_cap,
+                                                          uint2 *__restrict__ defer_list, uint32_t defer_cap,
+                                                          int32_t *__restrict__ deep_stacks)
 {
     __shared__ int32_t lds_stack[DEEP ? 1 : WQ_STACK][TRAV_THREADS];
     __shared__ Candidates queue[WQ_WAVES][WQ_QCAP];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t wave_id = blockIdx.x * WQ_WAVES + w;
+    CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
+    Candidates *my_cand = cand + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_cap;
     // this wave's chunk of work items (queries, or deferred (query, subtree) items in the deep pass)
     const unsigned long long c0 = (unsigned long long)wave_id * queries_per_wave;
     const uint32_t chunk_begin = (uint32_t)(c0 < nq ? c0 : nq);
@@ -195,16 +182,13 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_wq(QuerySrc src, uint
     uint32_t next = chunk_begin;                        // wave-uniform: next unassigned work item
     uint32_t qcount = 0;                                // wave-uniform: candidates waiting in the queue
     uint32_t tested = 0, visits = 0;
-
-    // lane state
     int32_t node = -1; int sptr = 0; uint32_t qi = 0, self_leaf = 0xffffffffu;
     float qlo0 = 0, qlo1 = 0, qlo2 = 0, qhi0 = 0, qhi1 = 0, qhi2 = 0;
     int32_t *gstack = DEEP ? deep_stacks + ((size_t)wave_id * 64 + lane) * DEEP_STACK : nullptr;
     const int stack_cap = DEEP ? DEEP_STACK : WQ_STACK;
 
     while (true) {
-        // ---- refill idle lanes with the next work items of the chunk
-        {
+        {   // ---- refill idle lanes with the next work items of the chunk
             const bool idle = (node == -1);
             const unsigned long long mi = __ballot(idle);
             const uint32_t remaining = chunk_end - next;
@@ -258,7 +242,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_wq(QuerySrc src, uint
                 else if (nxt == -1) nxt = ch.y;
                 else if (sptr < stack_cap) { if (DEEP) gstack[sptr] = ch.y; else lds_stack[sptr][tid] = ch.y; ++sptr; }
                 else {
-                    const uint32_t k = atomicAdd(&ctr->n_deferred, 1u);
+                    const uint32_t k = atomicAdd(&st->n_deferred, 1u);
                     if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)ch.y);
                 }
             }
@@ -266,35 +250,116 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_wq(QuerySrc src, uint
             else if (sptr > 0) { --sptr; node = DEEP ? gstack[sptr] : lds_stack[sptr][tid]; }
             else node = -1;
         }
-        // ---- enqueue candidates, compacted over the active lanes
-        {
+        {   // ---- enqueue candidates, compacted over the active lanes
             const unsigned long long mL = __ballot(candL), mR = __ballot(candR);
             const uint32_t nL = __popcll(mL);
             if (candL) queue[w][qcount + __popcll(mL & lt_mask)] = Candidates{qi, leafL};
             if (candR) queue[w][qcount + nL + __popcll(mR & lt_mask)] = Candidates{qi, leafR};
             qcount += nL + __popcll(mR);
         }
-        // ---- drain full batches: one candidate per lane, all 64 lanes busy
-        while (qcount >= 64) {
+        while (qcount >= 64) {                                   // full batch -> global buffer, 512 B coalesced
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const Candidates cnd = queue[w][qcount - 64 + lane];
             qcount -= 64;
-            wq_exact<EXTERNAL>(cnd.q, cnd.leaf, n, src, leaf, boxes, verts, vbase, pairs, cap, ctr, tested);
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&sh->n_candidates, 64ull);
+            base = __shfl(base, 0);
+            if (base + lane < shard_cap) my_cand[base + lane] = cnd;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
-    // ---- final partial batch
-    if (qcount > 0) {
+    if (qcount > 0) {                                            // final partial batch
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane < qcount) {
-            const Candidates cnd = queue[w][lane];
-            wq_exact<EXTERNAL>(cnd.q, cnd.leaf, n, src, leaf, boxes, verts, vbase, pairs, cap, ctr, tested);
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&sh->n_candidates, (unsigned long long)qcount);
+        base = __shfl(base, 0);
+        if (lane < qcount && base + lane < shard_cap) my_cand[base + lane] = queue[w][lane];
+    }
+    const unsigned long long t64 = wave_sum_u64(tested), v64 = wave_sum_u64(visits);
+    if (lane == 0) {
+        if (t64) atomicAdd(&sh->pairs_tested, t64);
+        if (v64) atomicAdd(&sh->node_visits, v64);
+    }
+}
+
+constexpr int EXACT_THREADS = 256;
+constexpr int EXACT_PB = 2048;               // pairs staged in LDS per workgroup before the single global append
+
+template <bool EXTERNAL>
+__global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, const LeafTri *__restrict__ leaf, const double *__restrict__ boxes,
+                                                         const double *__restrict__ verts, uint32_t vbase,
+                                                         const Candidates *__restrict__ cand, unsigned long long shard_cap,
+                                                         uint32_t *__restrict__ pairs, unsigned long long cap, TravState *__restrict__ st)
+{
+    __shared__ unsigned long long pre[NSHARD + 1];      // exclusive prefix of the shard counts
+    __shared__ uint2 pbuf[EXACT_PB];
+    __shared__ uint32_t pcount;
+    __shared__ unsigned long long pbase;
+    __shared__ uint32_t wtested[EXACT_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) pcount = 0;
+    if (tid < 64) {
+        unsigned long long c = st->shard[tid].n_candidates;
+        const bool over = c > shard_cap;                        // the host will grow the buffer and redo
+        if (__ballot(over) != 0ull) c = 0;
+        unsigned long long v = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(v, o); if ((int)lane >= o) v += t; }
+        pre[tid + 1] = v;
+        if (tid == 0) pre[0] = 0;
+    }
+    __syncthreads();
+    const unsigned long long total = pre[NSHARD];
+    const unsigned long long stride = (unsigned long long)gridDim.x * EXACT_THREADS;
+    uint32_t tested = 0;
+    for (unsigned long long k0 = (unsigned long long)blockIdx.x * EXACT_THREADS; k0 < total; k0 += stride) {
+        const unsigned long long k = k0 + tid;
+        if (k >= total) continue;
+        int lo = 0, hi = NSHARD;                                // largest s with pre[s] <= k
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= k) lo = mid; else hi = mid; }
+        const Candidates c = cand[(size_t)lo * shard_cap + (k - pre[lo])];
+        const uint32_t qi = c.q, lj = c.leaf;
+        const LeafTri lt = leaf[lj];
+        const Box lb = load_box(boxes, (n - 1) + (int)lj);
+        uint32_t q_id, qa, qb, qc; d3 P1, P2, P3; Box qbox;
+        if (EXTERNAL) {
+            const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + qi;
+            P1 = d3{q->v[0], q->v[1], q->v[2]}; P2 = d3{q->v[3], q->v[4], q->v[5]}; P3 = d3{q->v[6], q->v[7], q->v[8]};
+            q_id = q->id; qa = q->vidx[0]; qb = q->vidx[1]; qc = q->vidx[2];
+            qbox = box_set(P1, P2, P3);
+        } else {
+            const LeafTri ql = leaf[qi];
+            q_id = ql.id; qa = ql.v0; qb = ql.v1; qc = ql.v2;
+            qbox = load_box(boxes, (n - 1) + (int)qi);
+        }
+        if (!box_overlap(qbox, lb)) continue;                                  // collision.cuh:31-32, exact
+        ++tested;
+        if (neighbor_count(qa, qb, qc, lt.v0 + vbase, lt.v1 + vbase, lt.v2 + vbase) >= 1) continue;   // collision.cuh:38
+        if (!(q_id < lt.id)) continue;                                         // tri_contact.cuh:81
+        if (!EXTERNAL) { P1 = load_vertex(verts, qa); P2 = load_vertex(verts, qb); P3 = load_vertex(verts, qc); }
+        if (tri_contact(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) {
+            const uint32_t slot = atomicAdd(&pcount, 1u);                      // LDS
+            if (slot < EXACT_PB) pbuf[slot] = make_uint2(q_id, lt.id);
+            else {                                                             // staging full: append directly (collision.cuh:40)
+                const unsigned long long cur = atomicAdd(&st->n_pairs, 1ull);
+                if (cur < cap) { pairs[2 * cur] = q_id; pairs[2 * cur + 1] = lt.id; }
+            }
         }
     }
-    unsigned long long t64 = wave_sum_u64(tested), v64 = wave_sum_u64(visits);
-    if (lane == 0) {
-        if (t64) atomicAdd(&ctr->pairs_tested, t64);
-        if (v64) atomicAdd(&ctr->node_visits, v64);
+    const unsigned long long t64 = wave_sum_u64(tested);
+    if (lane == 0) wtested[tid >> 6] = (uint32_t)t64;
+    __syncthreads();
+    const uint32_t staged = pcount < EXACT_PB ? pcount : EXACT_PB;
+    if (tid == 0) {
+        if (staged) pbase = atomicAdd(&st->n_pairs, (unsigned long long)staged);
+        uint32_t t = 0;
+        for (int i = 0; i < EXACT_THREADS / 64; ++i) t += wtested[i];
+        if (t) atomicAdd(&st->shard[blockIdx.x & (NSHARD - 1)].pairs_tested, (unsigned long long)t);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < staged; i += EXACT_THREADS) {
+        const unsigned long long cur = pbase + i;
+        if (cur < cap) { pairs[2 * cur] = pbuf[i].x; pairs[2 * cur + 1] = pbuf[i].y; }
     }
 }
 
@@ -302,7 +367,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_wq(QuerySrc src, uint
 // Tile of 256 "j" triangles staged in LDS per step; thread i tests its triangle against the tile.
 __global__ __launch_bounds__(256) void k_brute_force(const double *__restrict__ verts, const uint32_t *__restrict__ vidx,
                                                      const uint32_t *__restrict__ ids, uint32_t n, int box_filter,
-                                                     uint32_t *__restrict__ pairs, unsigned long long cap, TravCounters *__restrict__ ctr)
+                                                     uint32_t *__restrict__ pairs, unsigned long long cap, TravState *__restrict__ st)
 {
     __shared__ double sv[256][9];
     __shared__ uint32_t si[256][4];
@@ -336,14 +401,14 @@ __global__ __launch_bounds__(256) void k_brute_force(const double *__restrict__ 
             ++tested;
             if (neighbor_count(a0, a1, a2, si[k][1], si[k][2], si[k][3]) < 1 && ia < si[k][0]) {
                 if (tri_contact(P1, P2, P3, Q1, Q2, Q3)) {
-                    const unsigned long long cur = atomicAdd(&ctr->n_pairs, 1ull);
+                    const unsigned long long cur = atomicAdd(&st->n_pairs, 1ull);
                     if (cur < cap) { pairs[2 * cur] = ia; pairs[2 * cur + 1] = si[k][0]; }
                 }
             }
         }
     }
     tested = wave_sum_u64(tested);
-    if ((threadIdx.x & 63) == 0 && tested) atomicAdd(&ctr->pairs_tested, tested);
+    if ((threadIdx.x & 63) == 0 && tested) atomicAdd(&st->shard[blockIdx.x & (NSHARD - 1)].pairs_tested, tested);
 }
 
 // tri_contact.cuh:80-87 over explicit index pairs, with the collision.cuh:38 neighbour gate.

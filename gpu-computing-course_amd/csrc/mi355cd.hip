@@ -33,8 +33,9 @@ struct cd_ctx {
     int stage = ST_CREATED;
     int frame_mode = CD_FRAME_REFERENCE;
     uint32_t vbase = 0;
-    int trav_variant = 1;                   // CD_OPT_TRAVERSAL: 0 = lane-private FP64 (A), 1 = wave-queued fp32 descent (B)
-    uint32_t queries_per_wave = 128;        // CD_OPT_QUERIES_PER_WAVE (variant B chunk size)                     // global id of local vertex 0 (cross-rank neighbour filter)
+    int trav_variant = 1;                   // CD_OPT_TRAVERSAL: 0 = lane-private FP64 (A), 1 = split fp32 descent + exact kernel (B)
+    uint32_t queries_per_wave = 128;
+    uint32_t dbg_lds_pad = 0;               // CD_OPT_DEBUG_LDS_PAD: extra dynamic LDS bytes per traversal workgroup (occupancy experiments)        // CD_OPT_QUERIES_PER_WAVE (variant B chunk size)                     // global id of local vertex 0 (cross-rank neighbour filter)
     double frame_host[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};   // morton.h:45,51,57
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
@@ -51,9 +52,11 @@ struct cd_ctx {
     double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec *d_recs = nullptr; NodeRec32 *d_recs32 = nullptr;
     uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
     // traversal
-    TravCounters *d_ctr = nullptr;
+    TravState *d_state = nullptr;
+    int exact_blocks = 1024;
     uint32_t *d_pairs = nullptr; uint64_t pairs_cap = 0;
     uint2 *d_defer = nullptr; uint32_t defer_cap = 0;
+    Candidates *d_cand = nullptr; uint64_t cand_cap = 0;    // variant C candidate buffer
     int32_t *d_deep = nullptr; uint64_t deep_items = 0;
     // host mirrors
     cd_stats stats = {};
@@ -67,8 +70,8 @@ void free_all(cd_ctx *c)
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_leaf); hipFree(c->d_children); hipFree(c->d_ranges); hipFree(c->d_parent); hipFree(c->d_boxes);
-    hipFree(c->d_bounded); hipFree(c->d_recs); hipFree(c->d_recs32); hipFree(c->d_small); hipFree(c->d_ctr);
-    hipFree(c->d_pairs); hipFree(c->d_defer); hipFree(c->d_deep);
+    hipFree(c->d_bounded); hipFree(c->d_recs); hipFree(c->d_recs32); hipFree(c->d_small); hipFree(c->d_state);
+    hipFree(c->d_pairs); hipFree(c->d_defer); hipFree(c->d_deep); hipFree(c->d_cand);
     for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);
 }
@@ -150,6 +153,50 @@ int enqueue_refit(cd_ctx *c)
     return 0;
 }
 
+// Launch one traversal pass (shallow: all queries from the root; deep: the deferred (query, subtree) items).
+template <bool EXTERNAL, bool DEEP>
+void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pairs)
+{
+    const int n = (int)c->nt;
+    hipStream_t s = c->stream;
+    const uint32_t vb = EXTERNAL ? c->vbase : 0u;
+    if (c->trav_variant == 0) {
+        k_traverse<EXTERNAL, DEEP><<<cdiv(items, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, items, n, c->d_recs, c->d_leaf, c->d_verts, c->d_pairs, cap_pairs, c->d_state,
+                                                                                       DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr, vb);
+    } else {
+        const uint32_t qpw = DEEP ? 64u : c->queries_per_wave;
+        const uint64_t shard_cap = c->cand_cap / NSHARD;
+        k_descend<EXTERNAL, DEEP><<<cdiv(items, qpw * WQ_WAVES), TRAV_THREADS, DEEP ? 0 : c->dbg_lds_pad, s>>>(src, items, n, qpw, c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
+                                                                                                               DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr);
+        k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, c->d_cand, shard_cap, c->d_pairs, cap_pairs, c->d_state);
+    }
+}
+
+struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_candidates; uint32_t n_deferred; };
+
+int read_state(cd_ctx *c, HostCounters &h)
+{
+    static_assert(sizeof(TravState) <= 16384, "state read-back size");
+    TravState hs;
+    HIPCHK(hipMemcpyAsync(&hs, c->d_state, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    h = HostCounters{hs.n_pairs, 0, 0, 0, hs.n_deferred};
+    for (int i = 0; i < NSHARD; ++i) {
+        h.pairs_tested += hs.shard[i].pairs_tested; h.node_visits += hs.shard[i].node_visits;
+        if (hs.shard[i].n_candidates > h.max_shard_candidates) h.max_shard_candidates = hs.shard[i].n_candidates;
+    }
+    return 0;
+}
+
+int grow_candidates(cd_ctx *c, uint64_t max_shard)
+{
+    hipFree(c->d_cand); c->d_cand = nullptr; c->cand_cap = 0;
+    const uint64_t want = (max_shard + max_shard / 4 + 1024) * NSHARD;
+    HIPCHK(hipMalloc(&c->d_cand, sizeof(Candidates) * want));
+    c->cand_cap = want;
+    return 0;
+}
+
 // Traversal (local leaves or external queries).  Blocks: reads the counters, runs the deep pass when needed.
 int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs)
 {
@@ -159,80 +206,56 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     const uint32_t nq = external ? (uint32_t)nq_ext : n;
     int rc = ensure_pairs(c, cap_pairs > 0 ? cap_pairs : 1);
     if (rc) return rc;
+    const int per_pass = c->trav_variant == 0 ? 1 : 2;
     uint32_t launches = 0;
     float deep_ms = 0.f;
-    TravCounters h = {};
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        launches = 0;
-        HIPCHK(hipEventRecord(c->ev[EV_TRAV0], s));
-        HIPCHK(hipMemsetAsync(c->d_ctr, 0, sizeof(TravCounters), s));
+    HostCounters h = {};
+    bool done = false;
+    c->stats.stack_overflows = 0;
+    for (int attempt = 0; attempt < 8 && !done; ++attempt) {
+        launches = 0; deep_ms = 0.f;
         QuerySrc src{c->d_leaf, c->d_boxes, d_ext, nullptr};
+        HIPCHK(hipEventRecord(c->ev[EV_TRAV0], s));
+        HIPCHK(hipMemsetAsync(c->d_state, 0, sizeof(TravState), s));
         if (nq > 0) {
-            if (c->trav_variant == 0) {
-                if (external)
-                    k_traverse<true, false><<<cdiv(nq, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nq, (int)n, c->d_recs, c->d_leaf, c->d_verts,
-                                                                                         c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr, c->vbase);
-                else
-                    k_traverse<false, false><<<cdiv(nq, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nq, (int)n, c->d_recs, c->d_leaf, c->d_verts,
-                                                                                          c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr, 0u);
-            } else {
-                const uint32_t qpw = c->queries_per_wave;
-                const uint32_t blocks = cdiv(nq, qpw * WQ_WAVES);
-                if (external)
-                    k_traverse_wq<true, false><<<blocks, TRAV_THREADS, 0, s>>>(src, nq, (int)n, qpw, c->d_recs32, c->d_leaf, c->d_boxes, c->d_verts,
-                                                                            c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr, c->vbase);
-                else
-                    k_traverse_wq<false, false><<<blocks, TRAV_THREADS, 0, s>>>(src, nq, (int)n, qpw, c->d_recs32, c->d_leaf, c->d_boxes, c->d_verts,
-                                                                             c->d_pairs, cap_pairs, c->d_ctr, c->d_defer, c->defer_cap, nullptr, 0u);
-            }
-            ++launches;
+            if (external) launch_pass<true, false>(c, src, nq, cap_pairs); else launch_pass<false, false>(c, src, nq, cap_pairs);
+            launches += per_pass;
         }
-        HIPCHK(hipEventRecord(c->ev[EV_TRAV1], s));      // device time of the kernel only: recorded before the read-back
-        HIPCHK(hipMemcpyAsync(&h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (h.n_deferred == 0) break;
-        if (h.n_deferred > c->defer_cap) {
-            // the deferred list was too small: grow it and redo the whole traversal (pairs restart at 0)
+        HIPCHK(hipEventRecord(c->ev[EV_TRAV1], s));      // device time of the kernels only: recorded before the read-back
+        if ((rc = read_state(c, h))) return rc;
+        if (h.max_shard_candidates > c->cand_cap / NSHARD) { if ((rc = grow_candidates(c, h.max_shard_candidates))) return rc; continue; }
+        if (h.n_deferred > c->defer_cap) {               // the deferred list was too small: grow it and redo (pairs restart at 0)
             hipFree(c->d_defer); c->d_defer = nullptr; c->defer_cap = 0;
             HIPCHK(hipMalloc(&c->d_defer, sizeof(uint2) * (size_t)h.n_deferred));
             c->defer_cap = h.n_deferred;
             continue;
         }
-        // deep pass over the deferred (query, subtree) items with global-memory stacks
-        const uint32_t nd = h.n_deferred;
-        const uint64_t deep_lanes = (uint64_t)cdiv(nd, 64) * 64 + 256;       // variant B indexes stacks by launched lane
-        if (deep_lanes > c->deep_items) {
-            hipFree(c->d_deep); c->d_deep = nullptr; c->deep_items = 0;
-            HIPCHK(hipMalloc(&c->d_deep, sizeof(int32_t) * (size_t)DEEP_STACK * deep_lanes));
-            c->deep_items = deep_lanes;
+        if (h.n_deferred > 0) {                          // deep pass over the deferred (query, subtree) items
+            const uint32_t nd = h.n_deferred;
+            const uint64_t deep_lanes = (uint64_t)cdiv(nd, 64) * 64 + 256;
+            if (deep_lanes > c->deep_items) {
+                hipFree(c->d_deep); c->d_deep = nullptr; c->deep_items = 0;
+                HIPCHK(hipMalloc(&c->d_deep, sizeof(int32_t) * (size_t)DEEP_STACK * deep_lanes));
+                c->deep_items = deep_lanes;
+            }
+            HIPCHK(hipEventRecord(c->ev[EV_DEEP0], s));
+            HIPCHK(hipMemsetAsync(&c->d_state->n_deferred, 0, sizeof(uint32_t), s));
+            // candidate shards restart from 0: the shallow pass's candidates have all been consumed by k_exact
+            for (int i = 0; i < NSHARD; ++i) { /* one memset per shard would be 64 calls: clear them with a 2-D memset */ }
+            HIPCHK(hipMemset2DAsync(&c->d_state->shard[0].n_candidates, sizeof(CtrShard), 0, sizeof(unsigned long long), NSHARD, s));
+            src.list = c->d_defer;
+            if (external) launch_pass<true, true>(c, src, nd, cap_pairs); else launch_pass<false, true>(c, src, nd, cap_pairs);
+            launches += per_pass;
+            HIPCHK(hipEventRecord(c->ev[EV_DEEP1], s));
+            if ((rc = read_state(c, h))) return rc;
+            if (h.n_deferred != 0) return CD_ERR_ARG;    // tree deeper than DEEP_STACK: cannot happen (height <= 96)
+            if (h.max_shard_candidates > c->cand_cap / NSHARD) { if ((rc = grow_candidates(c, h.max_shard_candidates))) return rc; continue; }
+            c->stats.stack_overflows = nd;
+            deep_ms = elapsed(c, EV_DEEP0, EV_DEEP1);
         }
-        HIPCHK(hipEventRecord(c->ev[EV_DEEP0], s));
-        HIPCHK(hipMemsetAsync(&c->d_ctr->n_deferred, 0, sizeof(uint32_t), s));
-        src.list = c->d_defer;
-        if (c->trav_variant == 0) {
-            if (external)
-                k_traverse<true, true><<<cdiv(nd, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nd, (int)n, c->d_recs, c->d_leaf, c->d_verts,
-                                                                                    c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep, c->vbase);
-            else
-                k_traverse<false, true><<<cdiv(nd, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, nd, (int)n, c->d_recs, c->d_leaf, c->d_verts,
-                                                                                     c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep, 0u);
-        } else {
-            if (external)
-                k_traverse_wq<true, true><<<cdiv(nd, 64 * WQ_WAVES), TRAV_THREADS, 0, s>>>(src, nd, (int)n, 64u, c->d_recs32, c->d_leaf, c->d_boxes, c->d_verts,
-                                                                                        c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep, c->vbase);
-            else
-                k_traverse_wq<false, true><<<cdiv(nd, 64 * WQ_WAVES), TRAV_THREADS, 0, s>>>(src, nd, (int)n, 64u, c->d_recs32, c->d_leaf, c->d_boxes, c->d_verts,
-                                                                                         c->d_pairs, cap_pairs, c->d_ctr, nullptr, 0, c->d_deep, 0u);
-        }
-        ++launches;
-        HIPCHK(hipEventRecord(c->ev[EV_DEEP1], s));
-        HIPCHK(hipMemcpyAsync(&h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (h.n_deferred != 0) return CD_ERR_ARG;       // tree deeper than DEEP_STACK: cannot happen (height <= 96)
-        c->stats.stack_overflows = nd;
-        deep_ms = elapsed(c, EV_DEEP0, EV_DEEP1);
-        break;
+        done = true;
     }
+    if (!done) return CD_ERR_ARG;
     HIPCHK(hipGetLastError());
     const uint64_t found = h.n_pairs;
     const uint64_t ncopy = found < cap_pairs ? found : cap_pairs;
@@ -240,7 +263,6 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     HIPCHK(hipStreamSynchronize(s));
     c->stats.ms_traverse = elapsed(c, EV_TRAV0, EV_TRAV1) + deep_ms;
     c->stats.traverse_launches = launches;
-    if (h.n_deferred == 0 && launches <= 1) c->stats.stack_overflows = 0;
     c->stats.n_pairs = found; c->stats.pairs_tested = h.pairs_tested; c->stats.node_visits = h.node_visits;
     if (n_pairs) *n_pairs = found;
     return found > cap_pairs ? CD_OVERFLOW : CD_OK;
@@ -289,7 +311,9 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_recs, sizeof(NodeRec) * n);
     ALLOC(c->d_recs32, sizeof(NodeRec32) * n);
     ALLOC(c->d_small, sizeof(uint32_t) * 16);
-    ALLOC(c->d_ctr, sizeof(TravCounters));
+    ALLOC(c->d_state, sizeof(TravState));
+    c->cand_cap = ((4 * n > (1u << 20) ? 4 * n : (1u << 20)) + NSHARD - 1) / NSHARD * NSHARD;
+    ALLOC(c->d_cand, sizeof(Candidates) * c->cand_cap);
     c->defer_cap = 1u << 16;
     ALLOC(c->d_defer, sizeof(uint2) * c->defer_cap);
 #undef ALLOC
@@ -437,11 +461,10 @@ int cd_brute_force(cd_ctx *c, int box_filter, uint32_t *pairs, uint64_t cap_pair
     int rc = ensure_pairs(c, cap_pairs > 0 ? cap_pairs : 1);
     if (rc) return rc;
     hipStream_t s = c->stream;
-    HIPCHK(hipMemsetAsync(c->d_ctr, 0, sizeof(TravCounters), s));
-    k_brute_force<<<cdiv(c->nt, 256), 256, 0, s>>>(c->d_verts, c->d_vidx, c->d_ids, c->nt, box_filter, c->d_pairs, cap_pairs, c->d_ctr);
-    TravCounters h;
-    HIPCHK(hipMemcpyAsync(&h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemsetAsync(c->d_state, 0, sizeof(TravState), s));
+    k_brute_force<<<cdiv(c->nt, 256), 256, 0, s>>>(c->d_verts, c->d_vidx, c->d_ids, c->nt, box_filter, c->d_pairs, cap_pairs, c->d_state);
+    HostCounters h;
+    { int r = read_state(c, h); if (r) return r; }
     HIPCHK(hipGetLastError());
     const uint64_t ncopy = h.n_pairs < cap_pairs ? h.n_pairs : cap_pairs;
     if (pairs && ncopy) HIPCHK(hipMemcpy(pairs, c->d_pairs, sizeof(uint32_t) * 2 * ncopy, hipMemcpyDeviceToHost));
@@ -499,8 +522,10 @@ int cd_num_triangles(cd_ctx *c, uint32_t *nt) { if (!c || !nt) return CD_ERR_ARG
 int cd_set_option(cd_ctx *c, int key, int64_t value)
 {
     if (!c) return CD_ERR_ARG;
-    if (key == CD_OPT_TRAVERSAL) { if (value != 0 && value != 1) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
+    if (key == CD_OPT_TRAVERSAL) { if (value < 0 || value > 1) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
     if (key == CD_OPT_QUERIES_PER_WAVE) { if (value < 64 || value > (1 << 20) || value % 64) return CD_ERR_ARG; c->queries_per_wave = (uint32_t)value; return CD_OK; }
+    if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
+    if (key == 101) { if (value < 1 || value > 65535) return CD_ERR_ARG; c->exact_blocks = (int)value; return CD_OK; }
     return CD_ERR_ARG;
 }
 
@@ -520,8 +545,8 @@ int cd_pack_queries(cd_ctx *c, const double box[6], void *d_out, uint64_t cap, u
     if (!c || !box || !n || (cap && !d_out)) return CD_ERR_ARG;
     if (c->stage < ST_REFIT) return CD_ERR_ORDER;
     hipStream_t s = c->stream;
-    unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(c->d_ctr);
-    HIPCHK(hipMemsetAsync(c->d_ctr, 0, sizeof(TravCounters), s));
+    unsigned long long *d_cnt = &c->d_state->n_pairs;
+    HIPCHK(hipMemsetAsync(c->d_state, 0, sizeof(TravState), s));
     Box b{box[0], box[1], box[2], box[3], box[4], box[5]};
     k_pack_queries<<<cdiv(c->nt, 256), 256, 0, s>>>(c->d_verts, c->d_leaf, c->d_boxes, (int)c->nt, b,
                                                      reinterpret_cast<ExtQuery *>(d_out), cap, d_cnt, c->vbase);

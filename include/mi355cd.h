@@ -122,8 +122,8 @@ int cd_export_tree(cd_ctx *ctx, int32_t *parent, int32_t *left, int32_t *right, 
 /* Tuning knobs; none of them changes results (pair sets, pairs_tested are identical for every setting). */
 enum {
     CD_OPT_TRAVERSAL        = 0,   /* 0: lane-private FP64 descent, exact test inline (the reference's shape,        */
-                                   /*    collision.cuh:19-71); 1 (default): fp32 conservative descent + wavefront-shared */
-                                   /*    LDS candidate queue, exact tests run on compacted batches of 64              */
+                                   /*    collision.cuh:19-71); 1 (default): fp32 conservative descent with a          */
+                                   /*    wavefront-shared LDS candidate queue + a second kernel for the exact tests   */
     CD_OPT_QUERIES_PER_WAVE = 1    /* variant 1: queries one wave works through with dynamic lane refill (x64)         */
 };
 int cd_set_option(cd_ctx *ctx, int key, int64_t value);
