@@ -6,14 +6,11 @@
 
 namespace cd {
 
-// Traversal record of an internal node: both child boxes + both child ids in one 128-byte line, so
-// a visit costs one aligned 128 B fetch (the reference touches >= 4 lines of two 112-byte Nodes).
-struct alignas(128) NodeRec {
-    Box   bl, br;            // 96 B
-    int32_t cl, cr;          // 8 B
-    int32_t pad[6];
-};
-static_assert(sizeof(NodeRec) == 128, "NodeRec must be one 128-byte line");
+// Topology of an internal node in one 16-byte record, written with one store by the node's own thread:
+//   x = left child, y = right child (unified ids), z = the other end of the node's leaf range (Karras: node i
+//   covers [min(i,z), max(i,z)]), w = 0.  Parent links live in parent[] (2n-1 entries, unified ids) because they
+//   are written by the PARENT's thread.  Replaces the reference's pointer-linked 112-byte Node (bvh.cuh:25-43).
+typedef int4 NodeMeta;
 
 // fp32 traversal record, one 64-byte line: both child boxes rounded OUTWARD to float (lo down, hi up) +
 // both child ids.  Internal-node boxes only cull; a conservative (superset) box can never lose a pair, and
@@ -123,8 +120,7 @@ __device__ __forceinline__ int delta_k(const uint64_t *__restrict__ keys, int n,
 
 // generateHierarchyParallel, bvh.cuh:146-199.  One thread per internal node.
 __global__ __launch_bounds__(256) void k_hierarchy(const uint64_t *__restrict__ keys, int n,
-                                                   int2 *__restrict__ children, int32_t *__restrict__ parent,
-                                                   int2 *__restrict__ ranges, uint32_t *__restrict__ parent_wrong)
+                                                   NodeMeta *__restrict__ meta, int32_t *__restrict__ parent, uint32_t *__restrict__ parent_wrong)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
@@ -153,8 +149,7 @@ __global__ __launch_bounds__(256) void k_hierarchy(const uint64_t *__restrict__ 
     // bvh.cuh:174-195
     const int a = (split == first) ? (n - 1) + split : split;
     const int b = (split + 1 == last) ? (n - 1) + split + 1 : split + 1;
-    children[i] = make_int2(a, b);
-    if (ranges) ranges[i] = make_int2(first, last);
+    meta[i] = make_int4(a, b, j, 0);
     if (atomicExch(&parent[a], i) != -1) atomicAdd(parent_wrong, 1u);     // bvh.cuh:192-195
     if (atomicExch(&parent[b], i) != -1) atomicAdd(parent_wrong, 1u);
 }
@@ -189,7 +184,9 @@ __device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ r, const Box
     reinterpret_cast<int4 *>(r)[3] = make_int4(ch.x, ch.y, 0, 0);
 }
 
-__device__ __forceinline__ Box refit_merge(const Box &mine, const Box &other, bool left, int2 ch, NodeRec *__restrict__ rec, NodeRec32 *__restrict__ rec32)
+// Merge step shared by both refit phases: given my box, my sibling's box and which side I am, write the
+// parent's 64-byte fp32 traversal record and return the parent's exact box (bvh.cuh:277 merge(childA, childB)).
+__device__ __forceinline__ Box refit_merge(const Box &mine, const Box &other, bool left, int cl, int cr, NodeRec32 *__restrict__ rec32)
 {
     Box bl, br;
     bl.x1 = left ? mine.x1 : other.x1; bl.x2 = left ? mine.x2 : other.x2;
@@ -198,26 +195,22 @@ __device__ __forceinline__ Box refit_merge(const Box &mine, const Box &other, bo
     br.x1 = left ? other.x1 : mine.x1; br.x2 = left ? other.x2 : mine.x2;
     br.y1 = left ? other.y1 : mine.y1; br.y2 = left ? other.y2 : mine.y2;
     br.z1 = left ? other.z1 : mine.z1; br.z2 = left ? other.z2 : mine.z2;
-    double2 *rp = reinterpret_cast<double2 *>(rec);
-    rp[0] = make_double2(bl.x1, bl.x2); rp[1] = make_double2(bl.y1, bl.y2); rp[2] = make_double2(bl.z1, bl.z2);
-    rp[3] = make_double2(br.x1, br.x2); rp[4] = make_double2(br.y1, br.y2); rp[5] = make_double2(br.z1, br.z2);
-    reinterpret_cast<int2 *>(rp + 6)[0] = ch;
-    store_rec32(rec32, bl, br, ch);
+    store_rec32(rec32, bl, br, make_int2(cl, cr));
     return box_merge(bl, br);
 }
 
+constexpr int REFIT_SB = 64 * REFIT_BLK;     // leaves per super-block (phase 2 workgroup): 32 768
+
 // Phase 1 -- block-local subtrees.  Workgroup b owns leaves [b*BLK, (b+1)*BLK).  An internal node whose
-// leaf range (Karras: node i covers [first,last], first <= i < last) lies inside that interval has both
-// children finished by threads of this workgroup, so its arrival counter and the sibling-box hand-off live
-// in LDS (workgroup-scope acq_rel: no cache maintenance).  A thread that reaches a parent spanning
-// workgroups stops and appends its node to `top_list`; phase 2 continues from there after the kernel
-// boundary has made every box visible device-wide.
+// leaf range lies inside that interval has both children finished by threads of this workgroup, so its
+// arrival counter and the sibling-box hand-off live in LDS (workgroup-scope acq_rel: no cache maintenance).
+// A thread that reaches a parent spanning workgroups stops and appends its node to the list of its
+// super-block; the next phase continues from there after the kernel boundary has made every box visible.
 __global__ __launch_bounds__(REFIT_BLK) void k_refit_local(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n,
-                                                           const int2 *__restrict__ children, const int32_t *__restrict__ parent,
-                                                           const int2 *__restrict__ ranges,
-                                                           double *__restrict__ boxes, uint32_t *__restrict__ bounded, NodeRec *__restrict__ recs,
+                                                           const NodeMeta *__restrict__ meta, const int32_t *__restrict__ parent,
+                                                           double *__restrict__ boxes, uint32_t *__restrict__ bounded,
                                                            NodeRec32 *__restrict__ recs32,
-                                                           int32_t *__restrict__ top_list, uint32_t *__restrict__ top_count)
+                                                           int32_t *__restrict__ sb_list /* [n], region sb*REFIT_SB */, uint32_t *__restrict__ sb_count)
 {
     __shared__ double lbox[REFIT_BLK][2][6];       // deposit slots: [local node][side] = child box, 48 KB
     __shared__ uint32_t lcnt[REFIT_BLK];
@@ -232,50 +225,69 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_local(const double *__restr
     store_box(boxes, me, mine);
     int cur = parent[me];
     while (cur != -1) {
-        const int2 rg = ranges[cur];
-        if (!(rg.x >= b0 && rg.y < b0 + REFIT_BLK)) {                      // parent spans workgroups: hand over to phase 2
-            top_list[atomicAdd(top_count, 1u)] = me;
+        const NodeMeta m = meta[cur];
+        const int up = parent[cur];                                        // independent of m: both loads in flight together
+        const int first = min(cur, m.z), last = max(cur, m.z);
+        if (!(first >= b0 && last < b0 + REFIT_BLK)) {                     // parent spans workgroups: hand over to the next phase
+            const int sb = b0 / REFIT_SB;
+            sb_list[(size_t)sb * REFIT_SB + atomicAdd(&sb_count[sb], 1u)] = me;
             break;
         }
-        const int2 ch = children[cur];
-        const bool left = (ch.x == me);
+        const bool left = (m.x == me);
         const int slot = cur - b0;
         double *dst = lbox[slot][left ? 0 : 1];
         dst[0] = mine.x1; dst[1] = mine.x2; dst[2] = mine.y1; dst[3] = mine.y2; dst[4] = mine.z1; dst[5] = mine.z2;
-        const uint32_t old = __hip_atomic_fetch_add(&lcnt[slot], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // Deposit and arrival are both LDS operations of this wave, and the LDS executes one wave's operations
+        // in issue order: whoever observes the incremented counter also observes the deposit.  So the atomic can
+        // be relaxed -- an acq_rel one would also drain this wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0))
+        // at every level.  The wavefront-scope fences emit no instruction; they pin the compiler's order.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const uint32_t old = __hip_atomic_fetch_add(&lcnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (old == 0) break;                                               // first arriver leaves (bvh.cuh:270-272)
         const double *src = lbox[slot][left ? 1 : 0];
         const Box other{src[0], src[1], src[2], src[3], src[4], src[5]};
         bounded[cur] = 2;                                                  // Node::bounded: both arrivals seen
-        mine = refit_merge(mine, other, left, ch, recs + cur, recs32 + cur);
+        mine = refit_merge(mine, other, left, m.x, m.y, recs32 + cur);
         me = cur;
         store_box(boxes, me, mine);
-        cur = parent[me];
+        cur = up;
     }
 }
 
-// Phase 2 -- the few nodes that span workgroups (O(N / BLK) for Morton-ordered meshes).  One thread per
-// top_list entry; arrival counter in global memory with agent-scope acq_rel ordering (the reference's
-// atomicAdd at bvh.cuh:270 has no fence at all -- a race on real hardware).
-__global__ __launch_bounds__(256) void k_refit_top(int n, const int2 *__restrict__ children, const int32_t *__restrict__ parent,
-                                                   double *boxes, uint32_t *bounded, NodeRec *__restrict__ recs, NodeRec32 *__restrict__ recs32,
-                                                   const int32_t *__restrict__ top_list, const uint32_t *__restrict__ top_count)
+// Phases 2 and 3 -- nodes that span phase-1 workgroups.  One workgroup per super-block climbs the nodes whose
+// range stays inside [sb*span, (sb+1)*span): every arrival at such a node comes from THIS workgroup, so the
+// arrival counters (global memory) and the box hand-offs need only workgroup-scope ordering -- same CU, same
+// L1, no L2 write-back / invalidate per step.  A thread that reaches a parent leaving the super-block appends
+// its node to out_list for the next phase.  Phase 3 is the same kernel with ONE workgroup and span = everything.
+// (The reference's atomicAdd at bvh.cuh:270 has no ordering at all -- a race on real hardware.)
+__global__ __launch_bounds__(1024) void k_refit_mid(int n, const NodeMeta *__restrict__ meta, const int32_t *__restrict__ parent,
+                                                    double *boxes, uint32_t *bounded, NodeRec32 *__restrict__ recs32,
+                                                    const int32_t *__restrict__ in_list, const uint32_t *__restrict__ in_count,
+                                                    size_t in_stride, long long span,
+                                                    int32_t *__restrict__ out_list, uint32_t *__restrict__ out_count)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= *top_count) return;
-    int me = top_list[k];
-    Box mine = load_box(boxes, me);
-    int cur = parent[me];
-    while (cur != -1) {
-        const uint32_t old = __hip_atomic_fetch_add(&bounded[cur], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == 0) break;
-        const int2 ch = children[cur];
-        const bool left = (ch.x == me);
-        const Box other = load_box(boxes, left ? ch.y : ch.x);
-        mine = refit_merge(mine, other, left, ch, recs + cur, recs32 + cur);
-        me = cur;
-        store_box(boxes, me, mine);
-        cur = parent[me];
+    const uint32_t count = in_count[blockIdx.x];
+    const long long lo = (long long)blockIdx.x * span, hi = lo + span;
+    const int32_t *list = in_list + (size_t)blockIdx.x * in_stride;
+    for (uint32_t k = threadIdx.x; k < count; k += blockDim.x) {
+        int me = list[k];
+        Box mine = load_box(boxes, me);
+        int cur = parent[me];
+        while (cur != -1) {
+            const NodeMeta m = meta[cur];
+            const int up = parent[cur];
+            const int first = min(cur, m.z), last = max(cur, m.z);
+            if (!(first >= lo && last < hi)) { out_list[atomicAdd(out_count, 1u)] = me; break; }
+            const uint32_t old = __hip_atomic_fetch_add(&bounded[cur], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == 0) break;
+            const bool left = (m.x == me);
+            const Box other = load_box(boxes, left ? m.y : m.x);
+            mine = refit_merge(mine, other, left, m.x, m.y, recs32 + cur);
+            me = cur;
+            store_box(boxes, me, mine);
+            cur = up;
+        }
     }
 }
 
@@ -283,15 +295,16 @@ __global__ __launch_bounds__(256) void k_refit_top(int n, const int2 *__restrict
 constexpr uint64_t BOX_UNINIT_BITS = 0xFFFFFFFFFFFFFFFFull;   // boxes are memset to 0xFF before refit
 
 // checkInternalNodes, check.cuh:64-79: out[0]=nullParent out[1]=wrongBound out[2]=nullChild out[3]=notInternal out[4]=uninitBox
-__global__ __launch_bounds__(256) void k_check_internal(int n, const int2 *__restrict__ children, const int32_t *__restrict__ parent,
+__global__ __launch_bounds__(256) void k_check_internal(int n, const NodeMeta *__restrict__ meta, const int32_t *__restrict__ parent,
                                                         const uint32_t *__restrict__ bounded, const double *__restrict__ boxes,
                                                         uint32_t *__restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     if (bounded[i] != 2) atomicAdd(&out[1], 1u);
+    const NodeMeta m = meta[i];
     if (parent[i] == -1) atomicAdd(&out[0], 1u);
-    const int2 ch = children[i];
+    const int2 ch = make_int2(m.x, m.y);
     if (ch.x == -1) atomicAdd(&out[2], 1u);
     if (ch.y == -1) atomicAdd(&out[2], 1u);
     if (ch.x >= 2 * n - 1 || ch.y >= 2 * n - 1 || ch.x < -1 || ch.y < -1) atomicAdd(&out[3], 1u);

@@ -252,19 +252,32 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint64_t *__rest
             __hip_atomic_store(mine, OS_PREFIX | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             __hip_atomic_store(mine, OS_AGG | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // Walk back over the predecessors LB at a time: the LB granule loads are independent and in flight
+            // together, so a step costs one L2 round trip instead of LB of them.
+            constexpr int LB = 8;
             int t = (int)tile - 1;
             uint32_t spins = 0;
-            while (true) {
-                const unsigned long long g = __hip_atomic_load(lookback + (size_t)t * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long st = g & ~OS_VALUE_MASK;
-                if (st == 0) {                                                // predecessor has not published yet
-                    if (++spins > (1u << 24)) { atomicExch(ticket + 8, 1u); break; }   // bounded: give up, flag the sort as failed
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
+            bool done = false;
+            while (!done) {
+                unsigned long long g[LB];
+#pragma unroll
+                for (int b = 0; b < LB; ++b)
+                    g[b] = (t - b >= 0) ? __hip_atomic_load(lookback + (size_t)(t - b) * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : OS_PREFIX;
+                int used = 0;
+#pragma unroll
+                for (int b = 0; b < LB; ++b) {
+                    if (done || used != b) continue;                          // stop at the first unpublished granule
+                    const unsigned long long st = g[b] & ~OS_VALUE_MASK;
+                    if (st == 0) continue;
+                    excl += g[b] & OS_VALUE_MASK;
+                    used = b + 1;
+                    if (st == OS_PREFIX) done = true;
                 }
-                excl += g & OS_VALUE_MASK;
-                if (st == OS_PREFIX) break;
-                --t;                                                          // aggregate only: keep walking back
+                t -= used;
+                if (!done && used < LB) {                                     // hit an unpublished predecessor: wait a little
+                    if (++spins > (1u << 22)) { atomicExch(ticket + 8, 1u); break; }   // bounded: give up, flag the sort as failed
+                    __builtin_amdgcn_s_sleep(1);
+                }
             }
             __hip_atomic_store(mine, OS_PREFIX | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

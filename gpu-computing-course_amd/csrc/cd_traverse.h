@@ -47,7 +47,8 @@ static_assert(sizeof(ExtQuery) == 88, "cd_query layout");
 
 // ====================================================================================================
 // Variant A ("lane-private"): the reference's shape (collision.cuh:19-71) -- one query per lane, FP64 boxes
-// (128-byte NodeRec), the exact test inline in the descent.  Kept as the in-process A/B baseline.
+// (node topology record + two 48-byte child boxes per visit), the exact test inline in the descent.
+// Kept as the in-process A/B baseline and as an independent second implementation for the tests.
 // ====================================================================================================
 __device__ __forceinline__ void leaf_hit(uint32_t q_id, uint32_t qa, uint32_t qb, uint32_t qc,
                                          const d3 &P1, const d3 &P2, const d3 &P3,
@@ -69,8 +70,8 @@ __device__ __forceinline__ void leaf_hit(uint32_t q_id, uint32_t qa, uint32_t qb
 
 template <bool EXTERNAL, bool DEEP>
 __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_t nq, int n,
-                                                           const NodeRec *__restrict__ recs, const LeafTri *__restrict__ leaf,
-                                                           const double *__restrict__ verts,
+                                                           const NodeMeta *__restrict__ meta, const double *__restrict__ boxes,
+                                                           const LeafTri *__restrict__ leaf, const double *__restrict__ verts,
                                                            uint32_t *__restrict__ pairs, unsigned long long cap,
                                                            TravState *__restrict__ st,
                                                            uint2 *__restrict__ defer_list, uint32_t defer_cap,
@@ -99,9 +100,9 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_
         int32_t node = DEEP ? (int32_t)src.list[gi].y : ((n > 1) ? 0 : -1); // root = internal[0]
         while (node != -1) {
             ++visits;
-            const NodeRec *r = recs + node;
-            const Box bl = r->bl, br = r->br;
-            const int32_t cl = r->cl, cr = r->cr;
+            const NodeMeta m = meta[node];
+            const int32_t cl = m.x, cr = m.y;
+            const Box bl = load_box(boxes, cl), br = load_box(boxes, cr);
             const bool ol = box_overlap(qbox, bl);                         // collision.cuh:31-32
             const bool orr = box_overlap(qbox, br);
             int32_t next = -1;
@@ -160,7 +161,7 @@ constexpr int WQ_WAVES = TRAV_THREADS / 64;
 struct Candidates { uint32_t q, leaf; };
 
 // queries_per_wave: size of the contiguous chunk of queries one wave works through (multiple of 64).
-template <bool EXTERNAL, bool DEEP>
+template <bool EXTERNAL, bool DEEP, bool REFILL>
 __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t nq, int n, uint32_t queries_per_wave,
                                                           const NodeRec32 *__restrict__ recs, const double *__restrict__ boxes,
                                                           TravState *__restrict__ st,
@@ -187,8 +188,10 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
     int32_t *gstack = DEEP ? deep_stacks + ((size_t)wave_id * 64 + lane) * DEEP_STACK : nullptr;
     const int stack_cap = DEEP ? DEEP_STACK : WQ_STACK;
 
+    bool first_round = true;
     while (true) {
-        {   // ---- refill idle lanes with the next work items of the chunk
+        if (REFILL || first_round) {   // ---- (re)fill idle lanes with the next work items of the chunk
+            first_round = false;
             const bool idle = (node == -1);
             const unsigned long long mi = __ballot(idle);
             const uint32_t remaining = chunk_end - next;
@@ -250,8 +253,10 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
             else if (sptr > 0) { --sptr; node = DEEP ? gstack[sptr] : lds_stack[sptr][tid]; }
             else node = -1;
         }
-        {   // ---- enqueue candidates, compacted over the active lanes
-            const unsigned long long mL = __ballot(candL), mR = __ballot(candR);
+        // ---- enqueue candidates, compacted over the active lanes (skipped wave-uniformly when there are none)
+        const unsigned long long mL = __ballot(candL), mR = __ballot(candR);
+        if ((mL | mR) == 0ull) continue;
+        {
             const uint32_t nL = __popcll(mL);
             if (candL) queue[w][qcount + __popcll(mL & lt_mask)] = Candidates{qi, leafL};
             if (candR) queue[w][qcount + nL + __popcll(mR & lt_mask)] = Candidates{qi, leafR};

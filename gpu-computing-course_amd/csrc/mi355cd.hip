@@ -34,7 +34,7 @@ struct cd_ctx {
     int frame_mode = CD_FRAME_REFERENCE;
     uint32_t vbase = 0;
     int trav_variant = 1;                   // CD_OPT_TRAVERSAL: 0 = lane-private FP64 (A), 1 = split fp32 descent + exact kernel (B)
-    uint32_t queries_per_wave = 128;
+    uint32_t queries_per_wave = 64; 
     uint32_t dbg_lds_pad = 0;               // CD_OPT_DEBUG_LDS_PAD: extra dynamic LDS bytes per traversal workgroup (occupancy experiments)        // CD_OPT_QUERIES_PER_WAVE (variant B chunk size)                     // global id of local vertex 0 (cross-rank neighbour filter)
     double frame_host[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};   // morton.h:45,51,57
     hipStream_t stream = nullptr;
@@ -48,8 +48,8 @@ struct cd_ctx {
     void *d_os = nullptr; size_t os_bytes = 0; uint32_t *d_os_hist = nullptr; uint32_t *d_os_ticket = nullptr; unsigned long long *d_os_look = nullptr;
     double *d_frame = nullptr, *d_partial = nullptr;
     // tree
-    LeafTri *d_leaf = nullptr; int2 *d_children = nullptr; int2 *d_ranges = nullptr; int32_t *d_parent = nullptr;
-    double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec *d_recs = nullptr; NodeRec32 *d_recs32 = nullptr;
+    LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; uint32_t *d_sbcount = nullptr; uint32_t nsb = 0;
+    double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec32 *d_recs32 = nullptr;
     uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
     // traversal
     TravState *d_state = nullptr;
@@ -69,8 +69,8 @@ void free_all(cd_ctx *c)
     hipFree(c->d_verts); hipFree(c->d_vidx); hipFree(c->d_ids);
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
-    hipFree(c->d_leaf); hipFree(c->d_children); hipFree(c->d_ranges); hipFree(c->d_parent); hipFree(c->d_boxes);
-    hipFree(c->d_bounded); hipFree(c->d_recs); hipFree(c->d_recs32); hipFree(c->d_small); hipFree(c->d_state);
+    hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_sbcount); hipFree(c->d_boxes);
+    hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_small); hipFree(c->d_state);
     hipFree(c->d_pairs); hipFree(c->d_defer); hipFree(c->d_deep); hipFree(c->d_cand);
     for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -128,7 +128,7 @@ int enqueue_hierarchy(cd_ctx *c)
     HIPCHK(hipMemsetAsync(c->d_small, 0, 16 * sizeof(uint32_t), s));
     k_fill_leaves<<<cdiv(n, 256), 256, 0, s>>>(c->d_perm[0], c->d_vidx, c->d_ids, n, c->d_leaf, c->d_parent, c->d_bounded);
     if (n > 1)
-        k_hierarchy<<<cdiv(n - 1, 256), 256, 0, s>>>(c->d_keys[0], (int)n, c->d_children, c->d_parent, c->d_ranges, c->d_small);
+        k_hierarchy<<<cdiv(n - 1, 256), 256, 0, s>>>(c->d_keys[0], (int)n, c->d_meta, c->d_parent, c->d_small);
     HIPCHK(hipEventRecord(c->ev[EV_HIER1], s));
     HIPCHK(hipGetLastError());
     return 0;
@@ -141,13 +141,18 @@ int enqueue_refit(cd_ctx *c)
     HIPCHK(hipEventRecord(c->ev[EV_REFIT0], s));
     HIPCHK(hipMemsetAsync(c->d_boxes, 0xFF, sizeof(double) * 6 * (2 * (size_t)n - 1), s));
     if (n > 1) HIPCHK(hipMemsetAsync(c->d_bounded, 0, sizeof(uint32_t) * (n - 1), s));
-    // top list lives in the (now free) second permutation buffer; its counter in d_small[4]
-    int32_t *top_list = reinterpret_cast<int32_t *>(c->d_perm[1]);
-    uint32_t *top_count = c->d_small + 4;
-    HIPCHK(hipMemsetAsync(top_count, 0, sizeof(uint32_t), s));
-    k_refit_local<<<cdiv(n, REFIT_BLK), REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_children, c->d_parent, c->d_ranges,
-                                                          c->d_boxes, c->d_bounded, c->d_recs, c->d_recs32, top_list, top_count);
-    k_refit_top<<<cdiv(n, 256), 256, 0, s>>>((int)n, c->d_children, c->d_parent, c->d_boxes, c->d_bounded, c->d_recs, c->d_recs32, top_list, top_count);
+    // hand-over lists live in buffers the sort no longer needs: per-super-block lists in the second permutation
+    // buffer (region sb*REFIT_SB), the phase-2 -> phase-3 list in the second key buffer
+    int32_t *sb_list = reinterpret_cast<int32_t *>(c->d_perm[1]);
+    int32_t *l3_list = reinterpret_cast<int32_t *>(c->d_keys[1]);
+    uint32_t *l3_count = c->d_sbcount + c->nsb;         // [nsb] per-super-block counts, then the phase-3 count, then a dummy
+    HIPCHK(hipMemsetAsync(c->d_sbcount, 0, sizeof(uint32_t) * (c->nsb + 2), s));
+    k_refit_local<<<cdiv(n, REFIT_BLK), REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_parent,
+                                                          c->d_boxes, c->d_bounded, c->d_recs32, sb_list, c->d_sbcount);
+    k_refit_mid<<<c->nsb, 1024, 0, s>>>((int)n, c->d_meta, c->d_parent, c->d_boxes, c->d_bounded, c->d_recs32,
+                                        sb_list, c->d_sbcount, (size_t)REFIT_SB, (long long)REFIT_SB, l3_list, l3_count);
+    k_refit_mid<<<1, 1024, 0, s>>>((int)n, c->d_meta, c->d_parent, c->d_boxes, c->d_bounded, c->d_recs32,
+                                   l3_list, l3_count, 0, (long long)1 << 40, sb_list /* unused: nothing leaves the root span */, l3_count + 1);
     HIPCHK(hipEventRecord(c->ev[EV_REFIT1], s));
     HIPCHK(hipGetLastError());
     return 0;
@@ -161,13 +166,19 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
     hipStream_t s = c->stream;
     const uint32_t vb = EXTERNAL ? c->vbase : 0u;
     if (c->trav_variant == 0) {
-        k_traverse<EXTERNAL, DEEP><<<cdiv(items, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, items, n, c->d_recs, c->d_leaf, c->d_verts, c->d_pairs, cap_pairs, c->d_state,
+        k_traverse<EXTERNAL, DEEP><<<cdiv(items, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, items, n, c->d_meta, c->d_boxes, c->d_leaf, c->d_verts, c->d_pairs, cap_pairs, c->d_state,
                                                                                        DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr, vb);
     } else {
         const uint32_t qpw = DEEP ? 64u : c->queries_per_wave;
         const uint64_t shard_cap = c->cand_cap / NSHARD;
-        k_descend<EXTERNAL, DEEP><<<cdiv(items, qpw * WQ_WAVES), TRAV_THREADS, DEEP ? 0 : c->dbg_lds_pad, s>>>(src, items, n, qpw, c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
-                                                                                                               DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr);
+        const dim3 grid(cdiv(items, qpw * WQ_WAVES));
+        const size_t pad = DEEP ? 0 : c->dbg_lds_pad;
+        if (qpw == 64)
+            k_descend<EXTERNAL, DEEP, false><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw, c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
+                                                                            DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr);
+        else
+            k_descend<EXTERNAL, DEEP, true><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw, c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
+                                                                           DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr);
         k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, c->d_cand, shard_cap, c->d_pairs, cap_pairs, c->d_state);
     }
 }
@@ -303,12 +314,12 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_frame, sizeof(double) * 6);
     ALLOC(c->d_partial, sizeof(double) * 6 * BOUNDS_BLOCKS);
     ALLOC(c->d_leaf, sizeof(LeafTri) * n);
-    ALLOC(c->d_children, sizeof(int2) * n);
-    ALLOC(c->d_ranges, sizeof(int2) * n);
+    ALLOC(c->d_meta, sizeof(NodeMeta) * n);
     ALLOC(c->d_parent, sizeof(int32_t) * 2 * n);
+    c->nsb = cdiv(nt, REFIT_SB);
+    ALLOC(c->d_sbcount, sizeof(uint32_t) * (c->nsb + 2));
     ALLOC(c->d_boxes, sizeof(double) * 6 * 2 * n);
     ALLOC(c->d_bounded, sizeof(uint32_t) * n);
-    ALLOC(c->d_recs, sizeof(NodeRec) * n);
     ALLOC(c->d_recs32, sizeof(NodeRec32) * n);
     ALLOC(c->d_small, sizeof(uint32_t) * 16);
     ALLOC(c->d_state, sizeof(TravState));
@@ -416,7 +427,7 @@ static int run_check(cd_ctx *c, int which, uint32_t maxv, uint32_t *out, int nou
     hipStream_t s = c->stream;
     HIPCHK(hipEventRecord(c->ev[EV_CHK0], s));
     HIPCHK(hipMemsetAsync(c->d_small + 8, 0, 8 * sizeof(uint32_t), s));           // main.cu:113,121,129
-    if (which == 0) { if (n > 1) k_check_internal<<<cdiv(n - 1, 256), 256, 0, s>>>(n, c->d_children, c->d_parent, c->d_bounded, c->d_boxes, c->d_small + 8); }
+    if (which == 0) { if (n > 1) k_check_internal<<<cdiv(n - 1, 256), 256, 0, s>>>(n, c->d_meta, c->d_parent, c->d_bounded, c->d_boxes, c->d_small + 8); }
     else if (which == 1) k_check_leaves<<<cdiv(n, 256), 256, 0, s>>>(n, c->d_parent, c->d_leaf, maxv, c->d_boxes, c->d_small + 8);
     else k_check_triangle_idx<<<cdiv(n, 256), 256, 0, s>>>(n, c->d_leaf, maxv, c->d_small + 8);
     HIPCHK(hipEventRecord(c->ev[EV_CHK1], s));
@@ -506,9 +517,9 @@ int cd_export_tree(cd_ctx *c, int32_t *parent, int32_t *left, int32_t *right, do
     const size_t n = c->nt;
     if (parent) HIPCHK(hipMemcpy(parent, c->d_parent, sizeof(int32_t) * (2 * n - 1), hipMemcpyDeviceToHost));
     if ((left || right) && n > 1) {
-        std::vector<int2> ch(n - 1);
-        HIPCHK(hipMemcpy(ch.data(), c->d_children, sizeof(int2) * (n - 1), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n - 1; ++i) { if (left) left[i] = ch[i].x; if (right) right[i] = ch[i].y; }
+        std::vector<int4> m(n - 1);
+        HIPCHK(hipMemcpy(m.data(), c->d_meta, sizeof(int4) * (n - 1), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n - 1; ++i) { if (left) left[i] = m[i].x; if (right) right[i] = m[i].y; }
     }
     if (boxes || bounded) { if (c->stage < ST_REFIT) return CD_ERR_ORDER; }
     if (boxes) HIPCHK(hipMemcpy(boxes, c->d_boxes, sizeof(double) * 6 * (2 * n - 1), hipMemcpyDeviceToHost));
