@@ -14,7 +14,8 @@ struct alignas(128) CtrShard {
     unsigned long long pairs_tested;   // leaf AABB hits (reach neighborCount / SAT)
     unsigned long long node_visits;
     unsigned long long n_candidates;   // candidates reserved in this shard of the candidate buffer (may exceed its capacity)
-    unsigned long long pad[13];
+    unsigned long long wave_steps;     // descent-loop iterations summed over waves (lane utilisation = node_visits / (64 * wave_steps))
+    unsigned long long pad[12];
 };
 struct alignas(128) TravState {
     unsigned long long n_pairs;        // collision.cuh:40 `count`
@@ -173,7 +174,13 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
     __shared__ Candidates queue[WQ_WAVES][WQ_QCAP];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t wave_id = blockIdx.x * WQ_WAVES + w;
+    // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD and
+    // its 4 MiB L2).  Give each XCD one CONTIGUOUS eighth of the Morton-ordered queries, so the subtrees its
+    // waves walk overlap and stay in that L2, instead of every L2 seeing the whole tree.  Speed only: any
+    // mapping that is a permutation of the workgroups gives the same results.
+    const uint32_t nb = gridDim.x, per = nb >> 3;
+    const uint32_t vblock = (blockIdx.x < (per << 3)) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t wave_id = vblock * WQ_WAVES + w;
     CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
     Candidates *my_cand = cand + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_cap;
     // this wave's chunk of work items (queries, or deferred (query, subtree) items in the deep pass)
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
     const uint32_t chunk_end = (uint32_t)(c0 + queries_per_wave < nq ? c0 + queries_per_wave : nq);
     uint32_t next = chunk_begin;                        // wave-uniform: next unassigned work item
     uint32_t qcount = 0;                                // wave-uniform: candidates waiting in the queue
-    uint32_t tested = 0, visits = 0;
+    uint32_t tested = 0, visits = 0, steps = 0;
     int32_t node = -1; int sptr = 0; uint32_t qi = 0, self_leaf = 0xffffffffu;
     float qlo0 = 0, qlo1 = 0, qlo2 = 0, qhi0 = 0, qhi1 = 0, qhi2 = 0;
     int32_t *gstack = DEEP ? deep_stacks + ((size_t)wave_id * 64 + lane) * DEEP_STACK : nullptr;
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
         }
         const bool active = (node != -1);
         if (__ballot(active) == 0ull) break;            // chunk exhausted and every lane finished
+        ++steps;
 
         // ---- one descent step per active lane (fp32, conservative)
         bool candL = false, candR = false; uint32_t leafL = 0, leafR = 0;
@@ -284,6 +292,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
     if (lane == 0) {
         if (t64) atomicAdd(&sh->pairs_tested, t64);
         if (v64) atomicAdd(&sh->node_visits, v64);
+        if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
     }
 }
 

@@ -183,7 +183,7 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
     }
 }
 
-struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_candidates; uint32_t n_deferred; };
+struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_candidates; uint32_t n_deferred; uint64_t wave_steps, candidates; };
 
 int read_state(cd_ctx *c, HostCounters &h)
 {
@@ -191,9 +191,10 @@ int read_state(cd_ctx *c, HostCounters &h)
     TravState hs;
     HIPCHK(hipMemcpyAsync(&hs, c->d_state, sizeof hs, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    h = HostCounters{hs.n_pairs, 0, 0, 0, hs.n_deferred};
+    h = HostCounters{hs.n_pairs, 0, 0, 0, hs.n_deferred, 0, 0};
     for (int i = 0; i < NSHARD; ++i) {
         h.pairs_tested += hs.shard[i].pairs_tested; h.node_visits += hs.shard[i].node_visits;
+        h.wave_steps += hs.shard[i].wave_steps; h.candidates += hs.shard[i].n_candidates;
         if (hs.shard[i].n_candidates > h.max_shard_candidates) h.max_shard_candidates = hs.shard[i].n_candidates;
     }
     return 0;
@@ -275,6 +276,7 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     c->stats.ms_traverse = elapsed(c, EV_TRAV0, EV_TRAV1) + deep_ms;
     c->stats.traverse_launches = launches;
     c->stats.n_pairs = found; c->stats.pairs_tested = h.pairs_tested; c->stats.node_visits = h.node_visits;
+    c->stats.wave_steps = h.wave_steps; c->stats.candidates = h.candidates;
     if (n_pairs) *n_pairs = found;
     return found > cap_pairs ? CD_OVERFLOW : CD_OK;
 }

@@ -27,7 +27,8 @@ class CdStats(C.Structure):
     _fields_ = [("ms_morton", C.c_float), ("ms_sort", C.c_float), ("ms_hierarchy", C.c_float),
                 ("ms_refit", C.c_float), ("ms_traverse", C.c_float), ("ms_check", C.c_float),
                 ("traverse_launches", C.c_uint32), ("stack_overflows", C.c_uint32),
-                ("n_pairs", C.c_uint64), ("pairs_tested", C.c_uint64), ("node_visits", C.c_uint64)]
+                ("n_pairs", C.c_uint64), ("pairs_tested", C.c_uint64), ("node_visits", C.c_uint64),
+                ("wave_steps", C.c_uint64), ("candidates", C.c_uint64)]
 
 
 # every symbol include/mi355cd.h declares (tests check the library exports exactly these)

@@ -58,6 +58,9 @@ typedef struct cd_stats {
     uint64_t n_pairs;          /* contacts found by the last traversal      (main.cu:145 test_val)   */
     uint64_t pairs_tested;     /* (query, leaf) pairs with strictly overlapping AABBs                */
     uint64_t node_visits;      /* internal nodes visited                                             */
+    uint64_t wave_steps;       /* descent-loop iterations summed over wavefronts (lane utilisation =  */
+                               /* node_visits / (64 * wave_steps)); 0 for CD_OPT_TRAVERSAL 0           */
+    uint64_t candidates;       /* (query, leaf) candidates the fp32 descent handed to the exact kernel */
 } cd_stats;
 
 /* main.cu:78-88  cudaMalloc + cudaMemcpy of vec3f[V], Triangle[N], u64[N], Node[N], Node[N-1].

@@ -19,7 +19,8 @@ def main():
                     cd.find_collisions(cap=1 << 22)
                     times[s].append(cd.stats().ms_traverse)
             st = cd.stats()
-            print(f"{name}: pairs={st.n_pairs} tested={st.pairs_tested} visits={st.node_visits}")
+            print(f"{name}: pairs={st.n_pairs} tested={st.pairs_tested} visits={st.node_visits} wave_steps={st.wave_steps} "
+                  f"candidates={st.candidates} lane_util={st.node_visits / max(1, 64 * st.wave_steps):.3f} steps/wave={st.wave_steps / (len(vidx) / 64):.1f}")
             for s in settings:
                 print(f"  variant={s[0]} qpw={s[1]:5d}  median={statistics.median(times[s])*1e3:8.1f} us  min={min(times[s])*1e3:8.1f} us")
 
