@@ -181,12 +181,12 @@ __device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ r, const Box
     p[0] = make_float4(__double2float_rd(bl.x1), __double2float_rd(bl.y1), __double2float_rd(bl.z1), __double2float_ru(bl.x2));
     p[1] = make_float4(__double2float_ru(bl.y2), __double2float_ru(bl.z2), __double2float_rd(br.x1), __double2float_rd(br.y1));
     p[2] = make_float4(__double2float_rd(br.z1), __double2float_ru(br.x2), __double2float_ru(br.y2), __double2float_ru(br.z2));
-    reinterpret_cast<int4 *>(r)[3] = make_int4(ch.x, ch.y, 0, 0);
+    reinterpret_cast<int4 *>(r)[3] = make_int4(ch.x, ch.y, 0, 0);      // ch already encoded: internal i >= 0, leaf j -> ~j
 }
 
 // Merge step shared by both refit phases: given my box, my sibling's box and which side I am, write the
 // parent's 64-byte fp32 traversal record and return the parent's exact box (bvh.cuh:277 merge(childA, childB)).
-__device__ __forceinline__ Box refit_merge(const Box &mine, const Box &other, bool left, int cl, int cr, NodeRec32 *__restrict__ rec32)
+__device__ __forceinline__ Box refit_merge(const Box &mine, const Box &other, bool left, int cl, int cr, NodeRec32 *__restrict__ rec32, int nleaf_base)
 {
     Box bl, br;
     bl.x1 = left ? mine.x1 : other.x1; bl.x2 = left ? mine.x2 : other.x2;
@@ -195,7 +195,8 @@ __device__ __forceinline__ Box refit_merge(const Box &mine, const Box &other, bo
     br.x1 = left ? other.x1 : mine.x1; br.x2 = left ? other.x2 : mine.x2;
     br.y1 = left ? other.y1 : mine.y1; br.y2 = left ? other.y2 : mine.y2;
     br.z1 = left ? other.z1 : mine.z1; br.z2 = left ? other.z2 : mine.z2;
-    store_rec32(rec32, bl, br, make_int2(cl, cr));
+    // child ids in the traversal record: internal node i >= 0, leaf j -> ~j (sign bit = leaf flag)
+    store_rec32(rec32, bl, br, make_int2(cl >= nleaf_base ? ~(cl - nleaf_base) : cl, cr >= nleaf_base ? ~(cr - nleaf_base) : cr));
     return box_merge(bl, br);
 }
 
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_local(const double *__restr
         const double *src = lbox[slot][left ? 1 : 0];
         const Box other{src[0], src[1], src[2], src[3], src[4], src[5]};
         bounded[cur] = 2;                                                  // Node::bounded: both arrivals seen
-        mine = refit_merge(mine, other, left, m.x, m.y, recs32 + cur);
+        mine = refit_merge(mine, other, left, m.x, m.y, recs32 + cur, n - 1);
         me = cur;
         store_box(boxes, me, mine);
         cur = up;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(1024) void k_refit_mid(int n, const NodeMeta *__res
             if (old == 0) break;
             const bool left = (m.x == me);
             const Box other = load_box(boxes, left ? m.y : m.x);
-            mine = refit_merge(mine, other, left, m.x, m.y, recs32 + cur);
+            mine = refit_merge(mine, other, left, m.x, m.y, recs32 + cur, n - 1);
             me = cur;
             store_box(boxes, me, mine);
             cur = up;

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_
 // Candidate-shard overflow is detected from the reserved counts (nothing is written past a shard's capacity)
 // and handled by the host: grow, redo.
 // ====================================================================================================
-constexpr int WQ_STACK = 16;                 // LDS stack entries per lane
+constexpr int WQ_STACK = 12;                 // LDS stack entries per lane (12 KB + 6 KB queue per workgroup -> 8 workgroups = 32 waves per CU)
 constexpr int WQ_QCAP  = 192;                // queue slots per wave: < 64 left over + at most 128 new per step
 constexpr int WQ_WAVES = TRAV_THREADS / 64;
 
@@ -184,9 +184,10 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
     CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
     Candidates *my_cand = cand + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_cap;
     // this wave's chunk of work items (queries, or deferred (query, subtree) items in the deep pass)
-    const unsigned long long c0 = (unsigned long long)wave_id * queries_per_wave;
+    const uint32_t qpw_ = queries_per_wave & 0x7fffffffu;
+    const unsigned long long c0 = (unsigned long long)wave_id * qpw_;
     const uint32_t chunk_begin = (uint32_t)(c0 < nq ? c0 : nq);
-    const uint32_t chunk_end = (uint32_t)(c0 + queries_per_wave < nq ? c0 + queries_per_wave : nq);
+    const uint32_t chunk_end = (uint32_t)(c0 + qpw_ < nq ? c0 + qpw_ : nq);
     uint32_t next = chunk_begin;                        // wave-uniform: next unassigned work item
     uint32_t qcount = 0;                                // wave-uniform: candidates waiting in the queue
     uint32_t tested = 0, visits = 0, steps = 0;
@@ -233,34 +234,31 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
         if (__ballot(active) == 0ull) break;            // chunk exhausted and every lane finished
         ++steps;
 
-        // ---- one descent step per active lane (fp32, conservative)
-        bool candL = false, candR = false; uint32_t leafL = 0, leafR = 0;
-        if (active) {
-            ++visits;
-            const float4 *rp = reinterpret_cast<const float4 *>(recs + node);
-            const float4 a = rp[0], b = rp[1], c = rp[2];
-            const int4 ch = reinterpret_cast<const int4 *>(rp)[3];
-            // left: lo = (a.x, a.y, a.z) hi = (a.w, b.x, b.y); right: lo = (b.z, b.w, c.x) hi = (c.y, c.z, c.w)
-            const bool ol = qlo0 < a.w && a.x < qhi0 && qlo1 < b.x && a.y < qhi1 && qlo2 < b.y && a.z < qhi2;
-            const bool orr = qlo0 < c.y && b.z < qhi0 && qlo1 < c.z && b.w < qhi1 && qlo2 < c.w && c.x < qhi2;
-            int32_t nxt = -1;
-            if (ol) {
-                if (ch.x >= n - 1) { leafL = (uint32_t)(ch.x - (n - 1)); candL = (leafL != self_leaf); }
-                else nxt = ch.x;
+        // ---- one descent step per active lane (fp32, conservative).  Written as straight-line selects: the
+        // kernel is instruction-issue bound (SQ_ACTIVE_INST_ANY ~ 70 % of its duration), so every exec-mask
+        // save/restore the compiler does not have to emit is time.  Idle lanes fetch the root record and ignore it.
+        const float4 *rp = reinterpret_cast<const float4 *>(recs + (active ? node : 0));
+        const float4 a = rp[0], b = rp[1], c = rp[2];
+        const int4 ch = reinterpret_cast<const int4 *>(rp)[3];         // child ids: internal i >= 0, leaf j -> ~j
+        // left: lo = (a.x, a.y, a.z) hi = (a.w, b.x, b.y); right: lo = (b.z, b.w, c.x) hi = (c.y, c.z, c.w)
+        const bool ol  = active && qlo0 < a.w && a.x < qhi0 && qlo1 < b.x && a.y < qhi1 && qlo2 < b.y && a.z < qhi2;
+        const bool orr = active && qlo0 < c.y && b.z < qhi0 && qlo1 < c.z && b.w < qhi1 && qlo2 < c.w && c.x < qhi2;
+        visits += active ? 1u : 0u;
+        const bool intL = ol && ch.x >= 0, intR = orr && ch.y >= 0;
+        const uint32_t leafL = (uint32_t)~ch.x, leafR = (uint32_t)~ch.y;
+        const bool candL = ol && ch.x < 0 && leafL != self_leaf, candR = orr && ch.y < 0 && leafR != self_leaf;
+        int32_t nxt = intL ? ch.x : (intR ? ch.y : -1);
+        if (intL && intR) {                                                // both internal: descend left, push right
+            if (sptr < stack_cap) { if (DEEP) gstack[sptr] = ch.y; else lds_stack[sptr][tid] = ch.y; ++sptr; }
+            else {
+                // Stack full: hand the right subtree to the deep pass as its own work item and go on.
+                // Each subtree is still traversed exactly once, so no pair is reported twice.
+                const uint32_t k = atomicAdd(&st->n_deferred, 1u);
+                if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)ch.y);
             }
-            if (orr) {
-                if (ch.y >= n - 1) { leafR = (uint32_t)(ch.y - (n - 1)); candR = (leafR != self_leaf); }
-                else if (nxt == -1) nxt = ch.y;
-                else if (sptr < stack_cap) { if (DEEP) gstack[sptr] = ch.y; else lds_stack[sptr][tid] = ch.y; ++sptr; }
-                else {
-                    const uint32_t k = atomicAdd(&st->n_deferred, 1u);
-                    if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)ch.y);
-                }
-            }
-            if (nxt != -1) node = nxt;
-            else if (sptr > 0) { --sptr; node = DEEP ? gstack[sptr] : lds_stack[sptr][tid]; }
-            else node = -1;
         }
+        if (active && nxt < 0 && sptr > 0) { --sptr; nxt = DEEP ? gstack[sptr] : lds_stack[sptr][tid]; }
+        node = active ? nxt : -1;
         // ---- enqueue candidates, compacted over the active lanes (skipped wave-uniformly when there are none)
         const unsigned long long mL = __ballot(candL), mR = __ballot(candR);
         if ((mL | mR) == 0ull) continue;
@@ -293,6 +291,131 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
         if (t64) atomicAdd(&sh->pairs_tested, t64);
         if (v64) atomicAdd(&sh->node_visits, v64);
         if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
+    }
+}
+
+// ====================================================================================================
+// Variant C ("packet"): wavefront-shared traversal.  A wave walks the tree ONCE for its 64 Morton-adjacent
+// queries: the current node is wave-uniform, so its 64-byte record comes through the SCALAR cache
+// (s_load, no per-lane address traffic at all -- the per-lane descents above are bound by the texture
+// addresser's rate for divergent 16-byte accesses), every lane tests ITS query box against both children,
+// and a child is visited if ANY lane overlaps it (__ballot).  The DFS stack is one wave-uniform LDS array;
+// lanes that stopped overlapping a subtree simply fail the tests below it (child boxes nest, also after the
+// monotone outward rounding).  Leaf children are handled exactly as in variant B: overlapping lanes push
+// (query, leaf) candidates onto the wavefront-shared LDS queue with __ballot compaction, full batches of 64
+// go to the global candidate buffer, k_exact decides them exactly.
+// The union of nodes 64 neighbouring queries touch is a few hundred, against ~27 per query x 64 in the
+// per-lane form.  The wave-uniform stack needs at most tree-height entries (<= 96), so there is no overflow path.
+// ====================================================================================================
+constexpr int PK_STACK = 128;
+
+template <bool EXTERNAL>
+__global__ __launch_bounds__(TRAV_THREADS) void k_descend_packet(QuerySrc src, uint32_t nq, int n,
+                                                                 const NodeRec32 *__restrict__ recs, const double *__restrict__ boxes,
+                                                                 TravState *__restrict__ st,
+                                                                 Candidates *__restrict__ cand, unsigned long long shard_cap)
+{
+    __shared__ int32_t stack[WQ_WAVES][PK_STACK];
+    __shared__ Candidates queue[WQ_WAVES][WQ_QCAP];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t nb = gridDim.x, per = nb >> 3;                          // XCD-aware mapping, see k_descend
+    const uint32_t vblock = (blockIdx.x < (per << 3)) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t wave_id = vblock * WQ_WAVES + w;
+    CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
+    Candidates *cand_shard = cand + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_cap;
+    const unsigned long long q0 = (unsigned long long)wave_id * 64ull;
+    if (q0 >= nq || n < 2) return;                                         // whole wave idle (wave-uniform)
+    const uint32_t qi = (uint32_t)q0 + lane;
+    const bool valid = qi < nq;
+    uint32_t tested = 0, visits = 0, steps = 0, qcount = 0;
+    uint32_t self_leaf = 0xffffffffu;
+    // an invalid lane carries an empty box: it overlaps nothing
+    float qlo0 = 3.0e38f, qlo1 = 3.0e38f, qlo2 = 3.0e38f, qhi0 = -3.0e38f, qhi1 = -3.0e38f, qhi2 = -3.0e38f;
+    if (valid) {
+        Box qb;
+        if (EXTERNAL) {
+            const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + qi;
+            qb = box_set(d3{q->v[0], q->v[1], q->v[2]}, d3{q->v[3], q->v[4], q->v[5]}, d3{q->v[6], q->v[7], q->v[8]});
+        } else {
+            qb = load_box(boxes, (n - 1) + (int)qi);
+            self_leaf = qi;
+            if (box_overlap(qb, qb)) ++tested;                             // the query's own leaf: decided here, exactly, once
+        }
+        qlo0 = __double2float_rd(qb.x1); qhi0 = __double2float_ru(qb.x2);
+        qlo1 = __double2float_rd(qb.y1); qhi1 = __double2float_ru(qb.y2);
+        qlo2 = __double2float_rd(qb.z1); qhi2 = __double2float_ru(qb.z2);
+        ++visits;                                                          // the root
+    }
+    int sptr = 0;
+    int node = 0;                                                          // wave-uniform
+    while (true) {
+        ++steps;
+        // Fetch the wave-uniform 64-byte record through the VECTOR path: lanes 0..15 load one dword each (one
+        // coalesced 64-byte access), then v_readlane broadcasts the 16 dwords into scalar registers.  (A scalar
+        // s_load of the record measured ~1.25 us per step here: scalar-cache misses on a 64 MB tree are slow.)
+        const int un = __builtin_amdgcn_readfirstlane(node);
+        const int rv = reinterpret_cast<const int *>(recs + un)[lane & 15u];
+        struct { float l_lo[3], l_hi[3], r_lo[3], r_hi[3]; int cl, cr; } r;
+        r.l_lo[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 0));  r.l_lo[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 1));
+        r.l_lo[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 2));  r.l_hi[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 3));
+        r.l_hi[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 4));  r.l_hi[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 5));
+        r.r_lo[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 6));  r.r_lo[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 7));
+        r.r_lo[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 8));  r.r_hi[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 9));
+        r.r_hi[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 10)); r.r_hi[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 11));
+        r.cl = __builtin_amdgcn_readlane(rv, 12); r.cr = __builtin_amdgcn_readlane(rv, 13);
+        const bool ol  = qlo0 < r.l_hi[0] && r.l_lo[0] < qhi0 && qlo1 < r.l_hi[1] && r.l_lo[1] < qhi1 && qlo2 < r.l_hi[2] && r.l_lo[2] < qhi2;
+        const bool orr = qlo0 < r.r_hi[0] && r.r_lo[0] < qhi0 && qlo1 < r.r_hi[1] && r.r_lo[1] < qhi1 && qlo2 < r.r_hi[2] && r.r_lo[2] < qhi2;
+        const unsigned long long mL = __ballot(ol), mR = __ballot(orr);
+        const bool leafL = r.cl < 0, leafR = r.cr < 0;                    // wave-uniform (leaf j is stored as ~j)
+        // ---- leaf children: candidates, compacted over the overlapping lanes
+        if ((leafL && mL) || (leafR && mR)) {
+            const uint32_t ll = (uint32_t)~r.cl, lr = (uint32_t)~r.cr;
+            const bool cL = leafL && ol && ll != self_leaf, cR = leafR && orr && lr != self_leaf;
+            const unsigned long long kL = __ballot(cL), kR = __ballot(cR);
+            const uint32_t nL = __popcll(kL);
+            if (cL) queue[w][qcount + __popcll(kL & lt_mask)] = Candidates{qi, ll};
+            if (cR) queue[w][qcount + nL + __popcll(kR & lt_mask)] = Candidates{qi, lr};
+            qcount += nL + __popcll(kR);
+            // self hits that were filtered still count as overlaps of this lane with a leaf: already counted at setup
+            while (qcount >= 64) {                                         // full batch -> global buffer, 512 B coalesced
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const Candidates cnd = queue[w][qcount - 64 + lane];
+                qcount -= 64;
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&sh->n_candidates, 64ull);
+                base = __shfl(base, 0);
+                if (base + lane < shard_cap) cand_shard[base + lane] = cnd;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+        // ---- internal children: visited if ANY lane overlaps them (wave-uniform control flow)
+        const bool goL = !leafL && mL != 0ull, goR = !leafR && mR != 0ull;
+        visits += (uint32_t)(!leafL && ol) + (uint32_t)(!leafR && orr);    // per-lane count == the per-query traversal's visits
+        if (goL && goR) {
+            if (lane == 0) stack[w][sptr] = r.cr;
+            ++sptr;                                                        // <= tree height <= 96 < PK_STACK
+            node = r.cl;
+        } else if (goL) node = r.cl;
+        else if (goR) node = r.cr;
+        else if (sptr > 0) {
+            --sptr;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            node = stack[w][sptr];
+        } else break;
+    }
+    if (qcount > 0) {                                                      // final partial batch
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&sh->n_candidates, (unsigned long long)qcount);
+        base = __shfl(base, 0);
+        if (lane < qcount && base + lane < shard_cap) cand_shard[base + lane] = queue[w][lane];
+    }
+    const unsigned long long t64 = wave_sum_u64(tested), v64 = wave_sum_u64(visits);
+    if (lane == 0) {
+        if (t64) atomicAdd(&sh->pairs_tested, t64);
+        if (v64) atomicAdd(&sh->node_visits, v64);
+        atomicAdd(&sh->wave_steps, (unsigned long long)steps);
     }
 }
 

@@ -35,6 +35,7 @@ struct cd_ctx {
     uint32_t vbase = 0;
     int trav_variant = 1;                   // CD_OPT_TRAVERSAL: 0 = lane-private FP64 (A), 1 = split fp32 descent + exact kernel (B)
     uint32_t queries_per_wave = 64; 
+    uint32_t dbg_halfload = 0;
     uint32_t dbg_lds_pad = 0;               // CD_OPT_DEBUG_LDS_PAD: extra dynamic LDS bytes per traversal workgroup (occupancy experiments)        // CD_OPT_QUERIES_PER_WAVE (variant B chunk size)                     // global id of local vertex 0 (cross-rank neighbour filter)
     double frame_host[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};   // morton.h:45,51,57
     hipStream_t stream = nullptr;
@@ -165,7 +166,11 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
     const int n = (int)c->nt;
     hipStream_t s = c->stream;
     const uint32_t vb = EXTERNAL ? c->vbase : 0u;
-    if (c->trav_variant == 0) {
+    if (c->trav_variant == 2 && !DEEP) {
+        const uint64_t shard_cap = c->cand_cap / NSHARD;
+        k_descend_packet<EXTERNAL><<<cdiv(items, 64 * WQ_WAVES), TRAV_THREADS, c->dbg_lds_pad, s>>>(src, items, n, c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap);
+        k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, c->d_cand, shard_cap, c->d_pairs, cap_pairs, c->d_state);
+    } else if (c->trav_variant == 0) {
         k_traverse<EXTERNAL, DEEP><<<cdiv(items, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, items, n, c->d_meta, c->d_boxes, c->d_leaf, c->d_verts, c->d_pairs, cap_pairs, c->d_state,
                                                                                        DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr, vb);
     } else {
@@ -174,10 +179,10 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
         const dim3 grid(cdiv(items, qpw * WQ_WAVES));
         const size_t pad = DEEP ? 0 : c->dbg_lds_pad;
         if (qpw == 64)
-            k_descend<EXTERNAL, DEEP, false><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw, c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
+            k_descend<EXTERNAL, DEEP, false><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw | (c->dbg_halfload ? 0x80000000u : 0u), c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
                                                                             DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr);
         else
-            k_descend<EXTERNAL, DEEP, true><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw, c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
+            k_descend<EXTERNAL, DEEP, true><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw | (c->dbg_halfload ? 0x80000000u : 0u), c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
                                                                            DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr);
         k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, c->d_cand, shard_cap, c->d_pairs, cap_pairs, c->d_state);
     }
@@ -535,9 +540,10 @@ int cd_num_triangles(cd_ctx *c, uint32_t *nt) { if (!c || !nt) return CD_ERR_ARG
 int cd_set_option(cd_ctx *c, int key, int64_t value)
 {
     if (!c) return CD_ERR_ARG;
-    if (key == CD_OPT_TRAVERSAL) { if (value < 0 || value > 1) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
+    if (key == CD_OPT_TRAVERSAL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
     if (key == CD_OPT_QUERIES_PER_WAVE) { if (value < 64 || value > (1 << 20) || value % 64) return CD_ERR_ARG; c->queries_per_wave = (uint32_t)value; return CD_OK; }
     if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
+    if (key == 102) { c->dbg_halfload = (uint32_t)value; return CD_OK; }
     if (key == 101) { if (value < 1 || value > 65535) return CD_ERR_ARG; c->exact_blocks = (int)value; return CD_OK; }
     return CD_ERR_ARG;
 }

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-VARIANTS = [0, 1]        # CD_OPT_TRAVERSAL: lane-private FP64 descent / wave-queued fp32 descent
+VARIANTS = [0, 1, 2]     # CD_OPT_TRAVERSAL: lane-private FP64 descent / per-lane fp32 descent + exact kernel / packet descent + exact kernel
 
 
 def _check_visits(st, ref_stats, variant):
@@ -247,6 +247,8 @@ def test_deep_tree_uses_the_deferred_stack_path(mirrored, variant):
     r = oracle.pipeline(verts, vidx, off=off, span=span)
     if mirrored:
         assert r["stats"].max_stack > 32
+    elif variant == 2:
+        assert st.stack_overflows == 0 and st.traverse_launches == 2     # wave-uniform stack holds the whole height
     else:
         assert st.stack_overflows > 0 and st.traverse_launches == (4 if variant == 1 else 2)
     assert n == r["stats"].n_pairs > 0

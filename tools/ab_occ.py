@@ -8,11 +8,11 @@ verts, vidx = synth.cloth_pair(500)
 with mi355cd.CollisionDetector(verts, vidx) as cd:
     cd.self_collide()
     for variant in (1,):
-        for qpw in (128, 256):
-            for pad in (0, 4096, 10240, 18432, 31744, 59392):
+        for qpw in (64,):
+            for pad in (0, 8192, 16384, 24576, 36864, 65536):
                 cd.set_option(0, variant); cd.set_option(1, qpw); cd.set_option(100, pad)
                 t = []
                 for _ in range(6):
                     cd.find_collisions(cap=1 << 22); t.append(cd.stats().ms_traverse)
-                blocks = 160 * 1024 // (22528 + pad)
+                blocks = 160 * 1024 // (18432 + pad)
                 print(f"variant={variant} qpw={qpw} pad={pad:6d} (<= {blocks} wg/CU)  median={statistics.median(t)*1e3:7.1f} us")
