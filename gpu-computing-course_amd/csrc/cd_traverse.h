@@ -241,14 +241,15 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
         const float4 a = rp[0], b = rp[1], c = rp[2];
         const int4 ch = reinterpret_cast<const int4 *>(rp)[3];         // child ids: internal i >= 0, leaf j -> ~j
         // left: lo = (a.x, a.y, a.z) hi = (a.w, b.x, b.y); right: lo = (b.z, b.w, c.x) hi = (c.y, c.z, c.w)
-        const bool ol  = active && qlo0 < a.w && a.x < qhi0 && qlo1 < b.x && a.y < qhi1 && qlo2 < b.y && a.z < qhi2;
-        const bool orr = active && qlo0 < c.y && b.z < qhi0 && qlo1 < c.z && b.w < qhi1 && qlo2 < c.w && c.x < qhi2;
+        // (bitwise & on purpose: && would be lowered to short-circuit branches with exec-mask juggling)
+        const bool ol  = active & (qlo0 < a.w) & (a.x < qhi0) & (qlo1 < b.x) & (a.y < qhi1) & (qlo2 < b.y) & (a.z < qhi2);
+        const bool orr = active & (qlo0 < c.y) & (b.z < qhi0) & (qlo1 < c.z) & (b.w < qhi1) & (qlo2 < c.w) & (c.x < qhi2);
         visits += active ? 1u : 0u;
-        const bool intL = ol && ch.x >= 0, intR = orr && ch.y >= 0;
+        const bool intL = ol & (ch.x >= 0), intR = orr & (ch.y >= 0);
         const uint32_t leafL = (uint32_t)~ch.x, leafR = (uint32_t)~ch.y;
-        const bool candL = ol && ch.x < 0 && leafL != self_leaf, candR = orr && ch.y < 0 && leafR != self_leaf;
+        const bool candL = ol & (ch.x < 0) & (leafL != self_leaf), candR = orr & (ch.y < 0) & (leafR != self_leaf);
         int32_t nxt = intL ? ch.x : (intR ? ch.y : -1);
-        if (intL && intR) {                                                // both internal: descend left, push right
+        if (intL & intR) {                                                 // both internal: descend left, push right
             if (sptr < stack_cap) { if (DEEP) gstack[sptr] = ch.y; else lds_stack[sptr][tid] = ch.y; ++sptr; }
             else {
                 // Stack full: hand the right subtree to the deep pass as its own work item and go on.
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                 if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)ch.y);
             }
         }
-        if (active && nxt < 0 && sptr > 0) { --sptr; nxt = DEEP ? gstack[sptr] : lds_stack[sptr][tid]; }
+        if (active & (nxt < 0) & (sptr > 0)) { --sptr; nxt = DEEP ? gstack[sptr] : lds_stack[sptr][tid]; }
         node = active ? nxt : -1;
         // ---- enqueue candidates, compacted over the active lanes (skipped wave-uniformly when there are none)
         const unsigned long long mL = __ballot(candL), mR = __ballot(candR);
