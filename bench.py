@@ -121,6 +121,7 @@ def main():
         step()
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
     stage = {"morton": 0.0, "sort": 0.0, "hierarchy": 0.0, "refit": 0.0, "traverse": 0.0}
+    kern = {"descend": 0.0, "exact": 0.0}                                # the two kernels inside "traverse"
     tested_total = 0
     pairs_found = 0
     info = {}
@@ -134,6 +135,7 @@ def main():
         if world == 1:
             stage["morton"] += st.ms_morton; stage["sort"] += st.ms_sort; stage["hierarchy"] += st.ms_hierarchy
             stage["refit"] += st.ms_refit; stage["traverse"] += st.ms_traverse
+            kern["descend"] += st.ms_descend; kern["exact"] += st.ms_exact
         tested_total += tested
         pairs_found = pairs.shape[0]
     torch.cuda.synchronize()
@@ -166,20 +168,24 @@ def main():
             line["total_collision_ms_device"] = dev_total          # sum of the five stages' HIP-event times
             line["stage_ms"] = stage
             line["traversal_pairs_tested_per_s"] = (tested_total / k) / (stage["traverse"] * 1e-3)
-            # roofline of the dominant kernel (traversal + exact test): algorithmic bytes per launch
-            # = 40 B/triangle (tree read once) + 8 B per reported pair, over its HIP-event duration
+            # roofline of the dominant kernel = k_descend (largest single launch of the step): ALGORITHMIC bytes per
+            # launch = 40 B/triangle (the tree -- boxes, links, leaf payload -- read once) over its
+            # average launch duration from HIP events recorded on the library's stream around that kernel
+            for k_ in kern:
+                kern[k_] /= k
             dominant = max(stage, key=stage.get)
-            trav_bytes = TRAVERSAL_BYTES_PER_TRI * nt + 8.0 * pairs_found
-            achieved = trav_bytes / (stage["traverse"] * 1e-3) / 1e9
+            desc_bytes = TRAVERSAL_BYTES_PER_TRI * nt
+            achieved = desc_bytes / (kern["descend"] * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if tj.get("triangles") == nt:
                     traffic = tj.get("traverse_hbm_bytes_per_launch")
-            line["roofline"] = {"bound": "hbm", "kernel": "k_traverse (BVH traversal + tri_contact)", "achieved": achieved,
+            line["kernel_ms"] = kern
+            line["roofline"] = {"bound": "hbm", "kernel": "k_descend (fp32 BVH descent; its candidates go to k_exact)", "achieved": achieved,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                                "algorithmic_bytes_per_launch": trav_bytes, "avg_launch_ms": stage["traverse"],
+                                "algorithmic_bytes_per_launch": desc_bytes, "avg_launch_ms": kern["descend"],
                                 "dominant_stage": dominant,
                                 "whole_path": {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9,
                                                "frac": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9 / HBM_PEAK_GBS}}

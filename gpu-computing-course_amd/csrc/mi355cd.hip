@@ -24,7 +24,7 @@ namespace {
 
 enum Stage { ST_CREATED = 0, ST_SORTED = 1, ST_BUILT = 2, ST_REFIT = 3 };
 
-enum Ev { EV_MORTON0, EV_MORTON1, EV_SORT1, EV_HIER0, EV_HIER1, EV_REFIT0, EV_REFIT1, EV_TRAV0, EV_TRAV1, EV_DEEP0, EV_DEEP1, EV_CHK0, EV_CHK1, EV_COUNT };
+enum Ev { EV_MORTON0, EV_MORTON1, EV_SORT1, EV_HIER0, EV_HIER1, EV_REFIT0, EV_REFIT1, EV_TRAV0, EV_TRAV1, EV_DESC1, EV_DEEP0, EV_DEEP1, EV_CHK0, EV_CHK1, EV_COUNT };
 
 }  // namespace
 
@@ -169,6 +169,7 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
     if (c->trav_variant == 2 && !DEEP) {
         const uint64_t shard_cap = c->cand_cap / NSHARD;
         k_descend_packet<EXTERNAL><<<cdiv(items, 64 * WQ_WAVES), TRAV_THREADS, c->dbg_lds_pad, s>>>(src, items, n, c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap);
+        hipEventRecord(c->ev[EV_DESC1], s);
         k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, c->d_cand, shard_cap, c->d_pairs, cap_pairs, c->d_state);
     } else if (c->trav_variant == 0) {
         k_traverse<EXTERNAL, DEEP><<<cdiv(items, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, items, n, c->d_meta, c->d_boxes, c->d_leaf, c->d_verts, c->d_pairs, cap_pairs, c->d_state,
@@ -184,6 +185,7 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
         else
             k_descend<EXTERNAL, DEEP, true><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw | (c->dbg_halfload ? 0x80000000u : 0u), c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
                                                                            DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr);
+        if (!DEEP) hipEventRecord(c->ev[EV_DESC1], s);
         k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, c->d_cand, shard_cap, c->d_pairs, cap_pairs, c->d_state);
     }
 }
@@ -279,6 +281,8 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     if (pairs && ncopy) HIPCHK(hipMemcpyAsync(pairs, c->d_pairs, sizeof(uint32_t) * 2 * ncopy, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     c->stats.ms_traverse = elapsed(c, EV_TRAV0, EV_TRAV1) + deep_ms;
+    c->stats.ms_descend = (c->trav_variant != 0 && nq > 0) ? elapsed(c, EV_TRAV0, EV_DESC1) : 0.f;
+    c->stats.ms_exact = (c->trav_variant != 0 && nq > 0) ? elapsed(c, EV_DESC1, EV_TRAV1) : 0.f;
     c->stats.traverse_launches = launches;
     c->stats.n_pairs = found; c->stats.pairs_tested = h.pairs_tested; c->stats.node_visits = h.node_visits;
     c->stats.wave_steps = h.wave_steps; c->stats.candidates = h.candidates;

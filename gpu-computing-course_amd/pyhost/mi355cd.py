@@ -28,7 +28,8 @@ class CdStats(C.Structure):
                 ("ms_refit", C.c_float), ("ms_traverse", C.c_float), ("ms_check", C.c_float),
                 ("traverse_launches", C.c_uint32), ("stack_overflows", C.c_uint32),
                 ("n_pairs", C.c_uint64), ("pairs_tested", C.c_uint64), ("node_visits", C.c_uint64),
-                ("wave_steps", C.c_uint64), ("candidates", C.c_uint64)]
+                ("wave_steps", C.c_uint64), ("candidates", C.c_uint64),
+                ("ms_descend", C.c_float), ("ms_exact", C.c_float)]
 
 
 # every symbol include/mi355cd.h declares (tests check the library exports exactly these)

@@ -61,6 +61,8 @@ typedef struct cd_stats {
     uint64_t wave_steps;       /* descent-loop iterations summed over wavefronts (lane utilisation =  */
                                /* node_visits / (64 * wave_steps)); 0 for CD_OPT_TRAVERSAL 0           */
     uint64_t candidates;       /* (query, leaf) candidates the fp32 descent handed to the exact kernel */
+    float ms_descend;          /* shallow pass: memset + descent kernel (part of ms_traverse)          */
+    float ms_exact;            /* shallow pass: exact-test kernel        (part of ms_traverse)          */
 } cd_stats;
 
 /* main.cu:78-88  cudaMalloc + cudaMemcpy of vec3f[V], Triangle[N], u64[N], Node[N], Node[N-1].

@@ -331,3 +331,41 @@ def test_cd_main_harness_on_generated_obj(tmp_path):
     assert "illegal triangle vidx num = 0" in out
     assert f"contact count = {len(want)}" in out
     assert f"First morton code: {int(r['keys'][0])}, last morton code: {int(r['keys'][-1])}" in out
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_cross_rank_pass_two_contexts_one_gpu(variant):
+    """The multi-GPU step's device side on ONE GPU: two object shards in two contexts (HipEngine, the product
+    engine), root boxes exchanged by hand, cd_pack_queries -> device buffer -> cd_find_collisions_queries on the
+    peer.  Union of local + cross pairs must equal the single-tree oracle on the merged mesh, no duplicates."""
+    import torch
+    import mi355_multi as multi
+    dev = torch.device("cuda", 0)
+    shards = [synth.cloth_shard(r, 40, overlap=0.10) for r in range(2)]
+    engines = [multi.HipEngine(v, t, i, dev, vertex_id_base=vb) for (v, t, i, vb) in shards]
+    for e in engines:
+        e.cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
+    got = []
+    roots = []
+    for e in engines:
+        pairs, n, tested = e.self_collide(1 << 20)
+        got.append(pairs)
+        roots.append(e.root_box())
+    assert multi.boxes_overlap(roots[0], roots[1])
+    sent = 0
+    for me, peer in ((0, 1), (1, 0)):
+        q = engines[me].pack_queries(roots[peer])                  # my leaves overlapping the peer's root
+        sent += q.numel() // multi.QUERY_BYTES
+        cross, n, tested = engines[peer].find_collisions_queries(q, 1 << 20)
+        got.append(cross)
+    got = np.concatenate(got, axis=0)
+    verts = np.concatenate([s[0] for s in shards]); vidx = np.concatenate([s[1] + np.uint32(s[3]) for s in shards])
+    ids = np.concatenate([s[2] for s in shards])
+    cen = (verts[vidx[:, 0]] + verts[vidx[:, 1]] + verts[vidx[:, 2]]) / 3
+    ref = oracle.pipeline(verts, vidx, ids, off=cen.min(0), span=(cen.max(0) - cen.min(0)) * (1 + 2.0 ** -20))
+    gs = oracle.pair_set(got)
+    assert len(gs) == len(np.unique(gs))
+    assert np.array_equal(gs, oracle.pair_set(ref["pairs"]))
+    assert sent > 0 and len(gs) > 0
+    for e in engines:
+        e.close()
