@@ -64,6 +64,32 @@ def cpu_baseline(verts, vidx, reps=3):
     return out
 
 
+def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5):
+    """Secondary path (BASELINE config 5): 4096^2 image, 4096 spheres, frame kept on the device (the reference
+    copies every frame to the host for glDrawPixels, anime_ray.cu:128-131; that PCIe copy is not kernel time)."""
+    import statistics
+    import mi355_synth as synth
+    import mi355rt
+    spheres, shifts = synth.sphere_scene(n_spheres, dim, seed=7)
+    out = {"workload": f"{dim}x{dim} RGBA8 frame, {n_spheres} spheres (BASELINE config 5), pixel-exact vs oracle in tests/test_rt_gpu.py"}
+    with mi355rt.RayTracer(spheres, dim) as rt:
+        for name, mode in (("binned", mi355rt.RT_MODE_BINNED), ("brute", mi355rt.RT_MODE_BRUTE)):
+            rt.set_mode(mode)
+            rt.render(shifts, download=False)
+            ms = []
+            for _ in range(frames):
+                rt.render(shifts, download=False)
+                ms.append(rt.stats().ms_render)
+            st = rt.stats()
+            m = statistics.median(ms)
+            out[name] = {"ms_per_frame": m, "sphere_tests_per_frame": int(st.sphere_tests), "sphere_tests_per_s": st.sphere_tests / (m * 1e-3)}
+    frame_bytes = dim * dim * 4 + n_spheres * 32
+    a = frame_bytes / (out["binned"]["ms_per_frame"] * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "kernel": "k_render<binned>", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                       "algorithmic_bytes_per_launch": frame_bytes}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +97,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--quads", type=int, default=500, help="quads per sheet edge; 500 -> 1 000 000 triangles per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ray", action="store_true", help="skip the secondary ray-tracer measurement (BASELINE config 5)")
     ap.add_argument("--traversal", type=int, default=None, help="CD_OPT_TRAVERSAL override (0 lane-private FP64, 1 wave-queued)")
     ap.add_argument("--qpw", type=int, default=None, help="CD_OPT_QUERIES_PER_WAVE override")
     args = ap.parse_args()
@@ -192,6 +219,8 @@ def main():
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(verts, vidx)
                 line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+            if not args.no_ray:
+                line["ray_tracer"] = ray_tracer_measurement()
         else:
             line["config"]["last_step_rank0"] = info
         print(json.dumps(line))
