@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void k_morton(const double *__restrict__ verts
 // reference gets from zero-initialised cudaMalloc memory (main.cu:84-85).
 __global__ __launch_bounds__(256) void k_fill_leaves(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ vidx,
                                                      const uint32_t *__restrict__ ids, uint32_t n,
-                                                     LeafTri *__restrict__ leaf, int32_t *__restrict__ parent, uint32_t *__restrict__ bounded)
+                                                     LeafTri *__restrict__ leaf, int32_t *__restrict__ parent, uint32_t *__restrict__ bounded,
+                                                     double *__restrict__ boxes)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) {
@@ -102,7 +103,9 @@ __global__ __launch_bounds__(256) void k_fill_leaves(const uint32_t *__restrict_
         lt.v0 = vidx[3 * (size_t)t]; lt.v1 = vidx[3 * (size_t)t + 1]; lt.v2 = vidx[3 * (size_t)t + 2];
         leaf[j] = lt;
         parent[(n - 1) + j] = -1;
-        if (j < n - 1) { parent[j] = -1; bounded[j] = 0; }
+        // boxes are "uninitialised" until the refit writes them (Box::init, box.cuh:10,21,31): poison x1
+        reinterpret_cast<uint64_t *>(boxes)[6 * (size_t)((n - 1) + j)] = 0xFFFFFFFFFFFFFFFFull;
+        if (j < n - 1) { parent[j] = -1; bounded[j] = 0; reinterpret_cast<uint64_t *>(boxes)[6 * (size_t)j] = 0xFFFFFFFFFFFFFFFFull; }
     }
 }
 
@@ -171,129 +174,168 @@ __device__ __forceinline__ Box load_box(const double *boxes, int node)
     return Box{a.x, a.y, b.x, b.y, c.x, c.y};
 }
 
-constexpr int REFIT_BLK = 512;     // leaves per workgroup
-
-// Merge step shared by both refit phases: given my box, my sibling's box and which side I am, write the
-// parent's 128-byte traversal record {bl, br, cl, cr} and return the parent's box (bvh.cuh:277).
+// fp32 traversal record of one internal node (64 bytes): both child boxes rounded outward, both child ids
+// already encoded (internal i >= 0, leaf j -> ~j).
 __device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ r, const Box &bl, const Box &br, int2 ch)
 {
     float4 *p = reinterpret_cast<float4 *>(r);
     p[0] = make_float4(__double2float_rd(bl.x1), __double2float_rd(bl.y1), __double2float_rd(bl.z1), __double2float_ru(bl.x2));
     p[1] = make_float4(__double2float_ru(bl.y2), __double2float_ru(bl.z2), __double2float_rd(br.x1), __double2float_rd(br.y1));
     p[2] = make_float4(__double2float_rd(br.z1), __double2float_ru(br.x2), __double2float_ru(br.y2), __double2float_ru(br.z2));
-    reinterpret_cast<int4 *>(r)[3] = make_int4(ch.x, ch.y, 0, 0);      // ch already encoded: internal i >= 0, leaf j -> ~j
+    reinterpret_cast<int4 *>(r)[3] = make_int4(ch.x, ch.y, 0, 0);
 }
 
-// Merge step shared by both refit phases: given my box, my sibling's box and which side I am, write the
-// parent's 64-byte fp32 traversal record and return the parent's exact box (bvh.cuh:277 merge(childA, childB)).
-__device__ __forceinline__ Box refit_merge(const Box &mine, const Box &other, bool left, int cl, int cr, NodeRec32 *__restrict__ rec32, int nleaf_base)
+// ---------------------------------------------------------------- calBoundingBox as RANGE QUERIES
+// The reference climbs from every leaf with an (unfenced) atomic arrival counter per node, bvh.cuh:258-285.
+// On MI355X that shape is a chain of ~20 dependent, atomically synchronised steps (a literal port with
+// agent-scope ordering: 5 ms at 1 M; a three-phase LDS / workgroup-scope version: 250 us).  A Karras node i is
+// nothing but the leaf range [first,last] it covers, and its box is the min/max over those leaves, so the
+// refit is restated as order-preserving range queries over an implicit segment tree of the leaf boxes:
+//   * comb(L, R) = box_merge(L, R) (box.cuh:24-32) with the LEFT range first.  fmin2/fmax2 return the right
+//     operand on ties, so any left-to-right tree of merges yields the value of the rightmost extremal leaf --
+//     bit-identical to the reference's merge(childA, childB) recursion whatever the tree shape (+-0 included).
+//   * k_refit_seg_local: one workgroup per 512 consecutive leaves builds its 9-level segment tree in LDS
+//     (also written to global memory), then thread t answers node b0+t: childA box = query(first, split),
+//     childB box = query(split+1, last) -> the 64-byte traversal record, the node's box, bounded = 2.
+//     No atomics, no dependent global loads, every node of the block in parallel.
+//   * k_refit_seg_top: one workgroup builds the levels above the 512-leaf blocks.
+//   * k_refit_seg_cross: the few nodes whose range leaves their block (O(N/512)) query the global tree.
+constexpr int REFIT_BLK = 512;     // leaves per workgroup
+constexpr int REFIT_LOG = 9;
+
+__device__ __forceinline__ Box box_identity()
 {
-    Box bl, br;
-    bl.x1 = left ? mine.x1 : other.x1; bl.x2 = left ? mine.x2 : other.x2;
-    bl.y1 = left ? mine.y1 : other.y1; bl.y2 = left ? mine.y2 : other.y2;
-    bl.z1 = left ? mine.z1 : other.z1; bl.z2 = left ? mine.z2 : other.z2;
-    br.x1 = left ? other.x1 : mine.x1; br.x2 = left ? other.x2 : mine.x2;
-    br.y1 = left ? other.y1 : mine.y1; br.y2 = left ? other.y2 : mine.y2;
-    br.z1 = left ? other.z1 : mine.z1; br.z2 = left ? other.z2 : mine.z2;
-    // child ids in the traversal record: internal node i >= 0, leaf j -> ~j (sign bit = leaf flag)
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    return Box{inf, -inf, inf, -inf, inf, -inf};
+}
+
+// Given the exact boxes of both children, write the parent's 64-byte fp32 traversal record and return the
+// parent's exact box (bvh.cuh:277 merge(childA, childB)).  Child ids in the record: internal i >= 0, leaf j -> ~j.
+__device__ __forceinline__ Box emit_node(const Box &bl, const Box &br, int cl, int cr, NodeRec32 *__restrict__ rec32, int nleaf_base)
+{
     store_rec32(rec32, bl, br, make_int2(cl >= nleaf_base ? ~(cl - nleaf_base) : cl, cr >= nleaf_base ? ~(cr - nleaf_base) : cr));
     return box_merge(bl, br);
 }
 
-constexpr int REFIT_SB = 64 * REFIT_BLK;     // leaves per super-block (phase 2 workgroup): 32 768
+__device__ __forceinline__ Box lds_box(const double (*t)[6], int k) { return Box{t[k][0], t[k][1], t[k][2], t[k][3], t[k][4], t[k][5]}; }
 
-// Phase 1 -- block-local subtrees.  Workgroup b owns leaves [b*BLK, (b+1)*BLK).  An internal node whose
-// leaf range lies inside that interval has both children finished by threads of this workgroup, so its
-// arrival counter and the sibling-box hand-off live in LDS (workgroup-scope acq_rel: no cache maintenance).
-// A thread that reaches a parent spanning workgroups stops and appends its node to the list of its
-// super-block; the next phase continues from there after the kernel boundary has made every box visible.
-__global__ __launch_bounds__(REFIT_BLK) void k_refit_local(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n,
-                                                           const NodeMeta *__restrict__ meta, const int32_t *__restrict__ parent,
-                                                           double *__restrict__ boxes, uint32_t *__restrict__ bounded,
-                                                           NodeRec32 *__restrict__ recs32,
-                                                           int32_t *__restrict__ sb_list /* [n], region sb*REFIT_SB */, uint32_t *__restrict__ sb_count)
+// Ordered range query [l, r] (inclusive, local leaf indices) over the block's LDS segment tree `t`
+// (1-based heap layout, leaves at REFIT_BLK + j).
+__device__ __forceinline__ Box seg_query_lds(const double (*t)[6], int l, int r)
 {
-    __shared__ double lbox[REFIT_BLK][2][6];       // deposit slots: [local node][side] = child box, 48 KB
-    __shared__ uint32_t lcnt[REFIT_BLK];
-    const int b0 = blockIdx.x * REFIT_BLK;
-    lcnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int j = b0 + threadIdx.x;
-    if (j >= n) return;
-    const LeafTri lt = leaf[j];
-    Box mine = box_set(load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2));
-    int me = (n - 1) + j;
-    store_box(boxes, me, mine);
-    int cur = parent[me];
-    while (cur != -1) {
-        const NodeMeta m = meta[cur];
-        const int up = parent[cur];                                        // independent of m: both loads in flight together
-        const int first = min(cur, m.z), last = max(cur, m.z);
-        if (!(first >= b0 && last < b0 + REFIT_BLK)) {                     // parent spans workgroups: hand over to the next phase
-            const int sb = b0 / REFIT_SB;
-            sb_list[(size_t)sb * REFIT_SB + atomicAdd(&sb_count[sb], 1u)] = me;
-            break;
+    Box accL = box_identity(), accR = box_identity();
+    l += REFIT_BLK; r += REFIT_BLK + 1;
+    while (l < r) {
+        if (l & 1) { accL = box_merge(accL, lds_box(t, l)); ++l; }
+        if (r & 1) { --r; accR = box_merge(lds_box(t, r), accR); }
+        l >>= 1; r >>= 1;
+    }
+    return box_merge(accL, accR);
+}
+
+__global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n,
+                                                               const NodeMeta *__restrict__ meta,
+                                                               double *__restrict__ boxes, uint32_t *__restrict__ bounded,
+                                                               NodeRec32 *__restrict__ recs32,
+                                                               double *__restrict__ seg /* P x 6, heap order, node 0 unused */, int nbp2)
+{
+    __shared__ double t[2 * REFIT_BLK][6];          // 48 KB
+    const int b = blockIdx.x, b0 = b * REFIT_BLK, tid = threadIdx.x;
+    const int j = b0 + tid;
+    Box mine = box_identity();
+    if (j < n) {
+        const LeafTri lt = leaf[j];
+        mine = box_set(load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2));   // box.cuh:13-22
+        store_box(boxes, (n - 1) + j, mine);
+    }
+    {
+        double *d = t[REFIT_BLK + tid];
+        d[0] = mine.x1; d[1] = mine.x2; d[2] = mine.y1; d[3] = mine.y2; d[4] = mine.z1; d[5] = mine.z2;
+    }
+    // build the 9 levels above the leaves; global index of local node k at depth dd: ((nbp2 + b) << dd) + (k - 2^dd)
+    for (int dd = REFIT_LOG - 1; dd >= 0; --dd) {
+        __syncthreads();
+        const int cnt = 1 << dd;
+        if (tid < cnt) {
+            const int k = cnt + tid;
+            const Box m = box_merge(lds_box(t, 2 * k), lds_box(t, 2 * k + 1));
+            double *d = t[k];
+            d[0] = m.x1; d[1] = m.x2; d[2] = m.y1; d[3] = m.y2; d[4] = m.z1; d[5] = m.z2;
+            store_box(seg, (int)((((size_t)nbp2 + b) << dd) + tid), m);
         }
-        const bool left = (m.x == me);
-        const int slot = cur - b0;
-        double *dst = lbox[slot][left ? 0 : 1];
-        dst[0] = mine.x1; dst[1] = mine.x2; dst[2] = mine.y1; dst[3] = mine.y2; dst[4] = mine.z1; dst[5] = mine.z2;
-        // Deposit and arrival are both LDS operations of this wave, and the LDS executes one wave's operations
-        // in issue order: whoever observes the incremented counter also observes the deposit.  So the atomic can
-        // be relaxed -- an acq_rel one would also drain this wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0))
-        // at every level.  The wavefront-scope fences emit no instruction; they pin the compiler's order.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        const uint32_t old = __hip_atomic_fetch_add(&lcnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (old == 0) break;                                               // first arriver leaves (bvh.cuh:270-272)
-        const double *src = lbox[slot][left ? 1 : 0];
-        const Box other{src[0], src[1], src[2], src[3], src[4], src[5]};
-        bounded[cur] = 2;                                                  // Node::bounded: both arrivals seen
-        mine = refit_merge(mine, other, left, m.x, m.y, recs32 + cur, n - 1);
-        me = cur;
-        store_box(boxes, me, mine);
-        cur = up;
+    }
+    __syncthreads();
+    const int i = j;                                                   // internal node with the same index
+    if (i >= n - 1) return;
+    const NodeMeta m = meta[i];
+    const int first = min(i, m.z), last = max(i, m.z);
+    if (first < b0 || last >= b0 + REFIT_BLK) return;                  // leaves the block: k_refit_seg_cross
+    const int split = (m.x >= n - 1) ? m.x - (n - 1) : m.x;            // childA covers [first, split], childB [split+1, last]
+    const Box bl = seg_query_lds(t, first - b0, split - b0);
+    const Box br = seg_query_lds(t, split + 1 - b0, last - b0);
+    store_box(boxes, i, emit_node(bl, br, m.x, m.y, recs32 + i, n - 1));
+    bounded[i] = 2;                                                    // Node::bounded (bvh.cuh:270): both children merged
+}
+
+// Levels above the 512-leaf blocks: heap nodes [1, nbp2).  One workgroup; children at or beyond the last real
+// block are the identity.  (nbp2 = blocks rounded up to a power of two.)
+__global__ __launch_bounds__(1024) void k_refit_seg_top(double *seg, int nbp2, int nblocks)
+{
+    for (int cnt = nbp2 >> 1; cnt >= 1; cnt >>= 1) {                    // level with `cnt` nodes: k in [cnt, 2 cnt)
+        for (int u = threadIdx.x; u < cnt; u += blockDim.x) {
+            const int k = cnt + u;
+            // a child 2k / 2k+1 on the block level (>= nbp2) exists only if its block index < nblocks
+            const int c0 = 2 * k, c1 = 2 * k + 1;
+            const bool blocklevel = c0 >= nbp2;
+            const Box L = (blocklevel && c0 - nbp2 >= nblocks) ? box_identity() : load_box(seg, c0);
+            const Box R = (blocklevel && c1 - nbp2 >= nblocks) ? box_identity() : load_box(seg, c1);
+            store_box(seg, k, box_merge(L, R));
+        }
+        __syncthreads();                                                // workgroup-scope: the next level reads these
     }
 }
 
-// Phases 2 and 3 -- nodes that span phase-1 workgroups.  One workgroup per super-block climbs the nodes whose
-// range stays inside [sb*span, (sb+1)*span): every arrival at such a node comes from THIS workgroup, so the
-// arrival counters (global memory) and the box hand-offs need only workgroup-scope ordering -- same CU, same
-// L1, no L2 write-back / invalidate per step.  A thread that reaches a parent leaving the super-block appends
-// its node to out_list for the next phase.  Phase 3 is the same kernel with ONE workgroup and span = everything.
-// (The reference's atomicAdd at bvh.cuh:270 has no ordering at all -- a race on real hardware.)
-__global__ __launch_bounds__(1024) void k_refit_mid(int n, const NodeMeta *__restrict__ meta, const int32_t *__restrict__ parent,
-                                                    double *boxes, uint32_t *bounded, NodeRec32 *__restrict__ recs32,
-                                                    const int32_t *__restrict__ in_list, const uint32_t *__restrict__ in_count,
-                                                    size_t in_stride, long long span,
-                                                    int32_t *__restrict__ out_list, uint32_t *__restrict__ out_count)
+// Ordered range query [l, r] (inclusive leaf positions) over the global tree: internal heap nodes in `seg`
+// (P = nbp2 * 512 leaves), leaf level = boxes[(n-1)+j] (identity beyond n).
+__device__ __forceinline__ Box seg_query_global(const double *__restrict__ seg, const double *__restrict__ boxes, int n, long long P, int l0, int r0)
 {
-    const uint32_t count = in_count[blockIdx.x];
-    const long long lo = (long long)blockIdx.x * span, hi = lo + span;
-    const int32_t *list = in_list + (size_t)blockIdx.x * in_stride;
-    for (uint32_t k = threadIdx.x; k < count; k += blockDim.x) {
-        int me = list[k];
-        Box mine = load_box(boxes, me);
-        int cur = parent[me];
-        while (cur != -1) {
-            const NodeMeta m = meta[cur];
-            const int up = parent[cur];
-            const int first = min(cur, m.z), last = max(cur, m.z);
-            if (!(first >= lo && last < hi)) { out_list[atomicAdd(out_count, 1u)] = me; break; }
-            const uint32_t old = __hip_atomic_fetch_add(&bounded[cur], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (old == 0) break;
-            const bool left = (m.x == me);
-            const Box other = load_box(boxes, left ? m.y : m.x);
-            mine = refit_merge(mine, other, left, m.x, m.y, recs32 + cur, n - 1);
-            me = cur;
-            store_box(boxes, me, mine);
-            cur = up;
+    Box accL = box_identity(), accR = box_identity();
+    long long l = l0 + P, r = r0 + P + 1;
+    while (l < r) {
+        if (l & 1) {
+            const Box x = (l >= P) ? ((l - P) < n ? load_box(boxes, (n - 1) + (int)(l - P)) : box_identity()) : load_box(seg, (int)l);
+            accL = box_merge(accL, x); ++l;
         }
+        if (r & 1) {
+            --r;
+            const Box x = (r >= P) ? ((r - P) < n ? load_box(boxes, (n - 1) + (int)(r - P)) : box_identity()) : load_box(seg, (int)r);
+            accR = box_merge(x, accR);
+        }
+        l >>= 1; r >>= 1;
     }
+    return box_merge(accL, accR);
+}
+
+__global__ __launch_bounds__(256) void k_refit_seg_cross(int n, const NodeMeta *__restrict__ meta, const double *__restrict__ seg, int nbp2,
+                                                         double *boxes, uint32_t *__restrict__ bounded, NodeRec32 *__restrict__ recs32)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const NodeMeta m = meta[i];
+    const int first = min(i, m.z), last = max(i, m.z);
+    const int b0 = (i / REFIT_BLK) * REFIT_BLK;
+    if (first >= b0 && last < b0 + REFIT_BLK) return;                  // done by k_refit_seg_local
+    const int split = (m.x >= n - 1) ? m.x - (n - 1) : m.x;
+    const long long P = (long long)nbp2 * REFIT_BLK;
+    // queries read only leaf boxes and segment-tree nodes, never another cross node's output: no ordering needed
+    const Box bl = seg_query_global(seg, boxes, n, P, first, split);
+    const Box br = seg_query_global(seg, boxes, n, P, split + 1, last);
+    store_box(boxes, i, emit_node(bl, br, m.x, m.y, recs32 + i, n - 1));
+    bounded[i] = 2;
 }
 
 // ---------------------------------------------------------------- verifier counters (check.cuh)
-constexpr uint64_t BOX_UNINIT_BITS = 0xFFFFFFFFFFFFFFFFull;   // boxes are memset to 0xFF before refit
+constexpr uint64_t BOX_UNINIT_BITS = 0xFFFFFFFFFFFFFFFFull;   // x1 of every box is poisoned by k_fill_leaves until the refit writes it
 
 // checkInternalNodes, check.cuh:64-79: out[0]=nullParent out[1]=wrongBound out[2]=nullChild out[3]=notInternal out[4]=uninitBox
 __global__ __launch_bounds__(256) void k_check_internal(int n, const NodeMeta *__restrict__ meta, const int32_t *__restrict__ parent,

@@ -49,7 +49,7 @@ struct cd_ctx {
     void *d_os = nullptr; size_t os_bytes = 0; uint32_t *d_os_hist = nullptr; uint32_t *d_os_ticket = nullptr; unsigned long long *d_os_look = nullptr;
     double *d_frame = nullptr, *d_partial = nullptr;
     // tree
-    LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; uint32_t *d_sbcount = nullptr; uint32_t nsb = 0;
+    LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; double *d_seg = nullptr; uint32_t nbp2 = 1;   // segment tree over leaf boxes: nbp2*512 heap nodes
     double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec32 *d_recs32 = nullptr;
     uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
     // traversal
@@ -70,7 +70,7 @@ void free_all(cd_ctx *c)
     hipFree(c->d_verts); hipFree(c->d_vidx); hipFree(c->d_ids);
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
-    hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_sbcount); hipFree(c->d_boxes);
+    hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_boxes);
     hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_small); hipFree(c->d_state);
     hipFree(c->d_pairs); hipFree(c->d_defer); hipFree(c->d_deep); hipFree(c->d_cand);
     for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -127,7 +127,7 @@ int enqueue_hierarchy(cd_ctx *c)
     hipStream_t s = c->stream;
     HIPCHK(hipEventRecord(c->ev[EV_HIER0], s));
     HIPCHK(hipMemsetAsync(c->d_small, 0, 16 * sizeof(uint32_t), s));
-    k_fill_leaves<<<cdiv(n, 256), 256, 0, s>>>(c->d_perm[0], c->d_vidx, c->d_ids, n, c->d_leaf, c->d_parent, c->d_bounded);
+    k_fill_leaves<<<cdiv(n, 256), 256, 0, s>>>(c->d_perm[0], c->d_vidx, c->d_ids, n, c->d_leaf, c->d_parent, c->d_bounded, c->d_boxes);
     if (n > 1)
         k_hierarchy<<<cdiv(n - 1, 256), 256, 0, s>>>(c->d_keys[0], (int)n, c->d_meta, c->d_parent, c->d_small);
     HIPCHK(hipEventRecord(c->ev[EV_HIER1], s));
@@ -140,20 +140,10 @@ int enqueue_refit(cd_ctx *c)
     const uint32_t n = c->nt;
     hipStream_t s = c->stream;
     HIPCHK(hipEventRecord(c->ev[EV_REFIT0], s));
-    HIPCHK(hipMemsetAsync(c->d_boxes, 0xFF, sizeof(double) * 6 * (2 * (size_t)n - 1), s));
-    if (n > 1) HIPCHK(hipMemsetAsync(c->d_bounded, 0, sizeof(uint32_t) * (n - 1), s));
-    // hand-over lists live in buffers the sort no longer needs: per-super-block lists in the second permutation
-    // buffer (region sb*REFIT_SB), the phase-2 -> phase-3 list in the second key buffer
-    int32_t *sb_list = reinterpret_cast<int32_t *>(c->d_perm[1]);
-    int32_t *l3_list = reinterpret_cast<int32_t *>(c->d_keys[1]);
-    uint32_t *l3_count = c->d_sbcount + c->nsb;         // [nsb] per-super-block counts, then the phase-3 count, then a dummy
-    HIPCHK(hipMemsetAsync(c->d_sbcount, 0, sizeof(uint32_t) * (c->nsb + 2), s));
-    k_refit_local<<<cdiv(n, REFIT_BLK), REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_parent,
-                                                          c->d_boxes, c->d_bounded, c->d_recs32, sb_list, c->d_sbcount);
-    k_refit_mid<<<c->nsb, 1024, 0, s>>>((int)n, c->d_meta, c->d_parent, c->d_boxes, c->d_bounded, c->d_recs32,
-                                        sb_list, c->d_sbcount, (size_t)REFIT_SB, (long long)REFIT_SB, l3_list, l3_count);
-    k_refit_mid<<<1, 1024, 0, s>>>((int)n, c->d_meta, c->d_parent, c->d_boxes, c->d_bounded, c->d_recs32,
-                                   l3_list, l3_count, 0, (long long)1 << 40, sb_list /* unused: nothing leaves the root span */, l3_count + 1);
+    const int nblocks = (int)cdiv(n, REFIT_BLK);
+    k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded, c->d_recs32, c->d_seg, (int)c->nbp2);
+    k_refit_seg_top<<<1, 1024, 0, s>>>(c->d_seg, (int)c->nbp2, nblocks);
+    if (n > 1) k_refit_seg_cross<<<cdiv(n - 1, 256), 256, 0, s>>>((int)n, c->d_meta, c->d_seg, (int)c->nbp2, c->d_boxes, c->d_bounded, c->d_recs32);
     HIPCHK(hipEventRecord(c->ev[EV_REFIT1], s));
     HIPCHK(hipGetLastError());
     return 0;
@@ -327,8 +317,8 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_leaf, sizeof(LeafTri) * n);
     ALLOC(c->d_meta, sizeof(NodeMeta) * n);
     ALLOC(c->d_parent, sizeof(int32_t) * 2 * n);
-    c->nsb = cdiv(nt, REFIT_SB);
-    ALLOC(c->d_sbcount, sizeof(uint32_t) * (c->nsb + 2));
+    { uint32_t nb = cdiv(nt, REFIT_BLK); c->nbp2 = 1; while (c->nbp2 < nb) c->nbp2 <<= 1; }
+    ALLOC(c->d_seg, sizeof(double) * 6 * (size_t)c->nbp2 * REFIT_BLK);
     ALLOC(c->d_boxes, sizeof(double) * 6 * 2 * n);
     ALLOC(c->d_bounded, sizeof(uint32_t) * n);
     ALLOC(c->d_recs32, sizeof(NodeRec32) * n);
