@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_morton(const double *__restrict__ verts
 __global__ __launch_bounds__(256) void k_fill_leaves(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ vidx,
                                                      const uint32_t *__restrict__ ids, uint32_t n,
                                                      LeafTri *__restrict__ leaf, int32_t *__restrict__ parent, uint32_t *__restrict__ bounded,
-                                                     double *__restrict__ boxes)
+                                                     double *__restrict__ boxes /* nullptr: do not poison (fused path: the refit follows at once) */)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) {
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void k_fill_leaves(const uint32_t *__restrict_
         leaf[j] = lt;
         parent[(n - 1) + j] = -1;
         // boxes are "uninitialised" until the refit writes them (Box::init, box.cuh:10,21,31): poison x1
-        reinterpret_cast<uint64_t *>(boxes)[6 * (size_t)((n - 1) + j)] = 0xFFFFFFFFFFFFFFFFull;
-        if (j < n - 1) { parent[j] = -1; bounded[j] = 0; reinterpret_cast<uint64_t *>(boxes)[6 * (size_t)j] = 0xFFFFFFFFFFFFFFFFull; }
+        if (boxes) reinterpret_cast<uint64_t *>(boxes)[6 * (size_t)((n - 1) + j)] = 0xFFFFFFFFFFFFFFFFull;
+        if (j < n - 1) { parent[j] = -1; bounded[j] = 0; if (boxes) reinterpret_cast<uint64_t *>(boxes)[6 * (size_t)j] = 0xFFFFFFFFFFFFFFFFull; }
     }
 }
 
@@ -237,9 +237,14 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
                                                                const NodeMeta *__restrict__ meta,
                                                                double *__restrict__ boxes, uint32_t *__restrict__ bounded,
                                                                NodeRec32 *__restrict__ recs32,
-                                                               double *__restrict__ seg /* P x 6, heap order, node 0 unused */, int nbp2)
+                                                               double *__restrict__ seg /* P x 6, heap order, node 0 unused */, int nbp2,
+                                                               int32_t *__restrict__ cross_list /* 64 shards x cross_cap */, uint32_t *__restrict__ cross_count /* [64] */,
+                                                               uint32_t cross_cap)
 {
     __shared__ double t[2 * REFIT_BLK][6];          // 48 KB
+    __shared__ int32_t lcross[REFIT_BLK];
+    __shared__ uint32_t lcount, lbase;
+    if (threadIdx.x == 0) lcount = 0;
     const int b = blockIdx.x, b0 = b * REFIT_BLK, tid = threadIdx.x;
     const int j = b0 + tid;
     Box mine = box_identity();
@@ -266,15 +271,26 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
     }
     __syncthreads();
     const int i = j;                                                   // internal node with the same index
-    if (i >= n - 1) return;
-    const NodeMeta m = meta[i];
-    const int first = min(i, m.z), last = max(i, m.z);
-    if (first < b0 || last >= b0 + REFIT_BLK) return;                  // leaves the block: k_refit_seg_cross
-    const int split = (m.x >= n - 1) ? m.x - (n - 1) : m.x;            // childA covers [first, split], childB [split+1, last]
-    const Box bl = seg_query_lds(t, first - b0, split - b0);
-    const Box br = seg_query_lds(t, split + 1 - b0, last - b0);
-    store_box(boxes, i, emit_node(bl, br, m.x, m.y, recs32 + i, n - 1));
-    bounded[i] = 2;                                                    // Node::bounded (bvh.cuh:270): both children merged
+    if (i < n - 1) {
+        const NodeMeta m = meta[i];
+        const int first = min(i, m.z), last = max(i, m.z);
+        if (first < b0 || last >= b0 + REFIT_BLK) {
+            lcross[atomicAdd(&lcount, 1u)] = i;                        // leaves the block: k_refit_seg_cross
+        } else {
+            const int split = (m.x >= n - 1) ? m.x - (n - 1) : m.x;    // childA covers [first, split], childB [split+1, last]
+            const Box bl = seg_query_lds(t, first - b0, split - b0);
+            const Box br = seg_query_lds(t, split + 1 - b0, last - b0);
+            store_box(boxes, i, emit_node(bl, br, m.x, m.y, recs32 + i, n - 1));
+            bounded[i] = 2;                                            // Node::bounded (bvh.cuh:270): both children merged
+        }
+    }
+    __syncthreads();
+    // hand the block's cross nodes over: one global atomic per workgroup, on its shard's counter
+    const uint32_t shard = b & 63u, cnt = lcount;
+    if (cnt == 0) return;
+    if (tid == 0) lbase = atomicAdd(&cross_count[shard], cnt);
+    __syncthreads();
+    if ((uint32_t)tid < cnt && lbase + tid < cross_cap) cross_list[(size_t)shard * cross_cap + lbase + tid] = lcross[tid];
 }
 
 // Levels above the 512-leaf blocks: heap nodes [1, nbp2).  One workgroup; children at or beyond the last real
@@ -295,43 +311,74 @@ __global__ __launch_bounds__(1024) void k_refit_seg_top(double *seg, int nbp2, i
     }
 }
 
-// Ordered range query [l, r] (inclusive leaf positions) over the global tree: internal heap nodes in `seg`
-// (P = nbp2 * 512 leaves), leaf level = boxes[(n-1)+j] (identity beyond n).
-__device__ __forceinline__ Box seg_query_global(const double *__restrict__ seg, const double *__restrict__ boxes, int n, long long P, int l0, int r0)
+// Ordered range query [l0, r0] (inclusive leaf positions) over the global tree by ONE WAVE: the iterative
+// bottom-up query takes at most one left piece and one right piece per level; lane p < 32 owns the left piece
+// of level p, lane 32+q the right piece of level 31-q, so lane order == left-to-right order of the pieces.
+// Every lane loads its piece (all loads in flight together), then an order-preserving shuffle reduction
+// (lower lanes are the LEFT operand) combines them.  Internal heap nodes come from `seg` (P = nbp2*512
+// leaves), level-0 pieces from boxes[(n-1)+j].  Returns the result in every lane.
+__device__ __forceinline__ Box seg_query_wave(const double *__restrict__ seg, const double *__restrict__ boxes, int n, long long P, int l0, int r0, int lane)
 {
-    Box accL = box_identity(), accR = box_identity();
-    long long l = l0 + P, r = r0 + P + 1;
-    while (l < r) {
-        if (l & 1) {
-            const Box x = (l >= P) ? ((l - P) < n ? load_box(boxes, (n - 1) + (int)(l - P)) : box_identity()) : load_box(seg, (int)l);
-            accL = box_merge(accL, x); ++l;
+    const bool is_left = lane < 32;
+    const int p = is_left ? lane : 63 - lane;                              // level of this lane's piece
+    const long long lp = ((long long)l0 + P + ((1ll << p) - 1)) >> p;      // l at level p  (ceil)
+    const long long rp = ((long long)r0 + P + 1) >> p;                     // r at level p  (floor), half-open
+    Box x = box_identity();
+    if (lp < rp) {
+        const long long k = is_left ? lp : rp - 1;
+        const bool take = is_left ? (lp & 1) : (rp & 1);
+        if (take) {
+            if (p == 0) { const long long j = k - P; if (j < n) x = load_box(boxes, (n - 1) + (int)j); }
+            else x = load_box(seg, (int)k);
         }
-        if (r & 1) {
-            --r;
-            const Box x = (r >= P) ? ((r - P) < n ? load_box(boxes, (n - 1) + (int)(r - P)) : box_identity()) : load_box(seg, (int)r);
-            accR = box_merge(x, accR);
-        }
-        l >>= 1; r >>= 1;
     }
-    return box_merge(accL, accR);
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {                                      // after the step, lanes that are multiples of 2s hold [lane, lane+2s)
+        Box y;
+        y.x1 = __shfl_down(x.x1, s); y.x2 = __shfl_down(x.x2, s); y.y1 = __shfl_down(x.y1, s);
+        y.y2 = __shfl_down(x.y2, s); y.z1 = __shfl_down(x.z1, s); y.z2 = __shfl_down(x.z2, s);
+        x = box_merge(x, y);                                               // mine is LEFT of the one s lanes up
+    }
+    Box r;
+    r.x1 = __shfl(x.x1, 0); r.x2 = __shfl(x.x2, 0); r.y1 = __shfl(x.y1, 0);
+    r.y2 = __shfl(x.y2, 0); r.z1 = __shfl(x.z1, 0); r.z2 = __shfl(x.z2, 0);
+    return r;
 }
 
+// Nodes whose range leaves their 512-leaf block: one WAVE per node, two wave-parallel range queries.
+// Queries read only leaf boxes and segment-tree nodes, never another cross node's output: no ordering needed.
 __global__ __launch_bounds__(256) void k_refit_seg_cross(int n, const NodeMeta *__restrict__ meta, const double *__restrict__ seg, int nbp2,
-                                                         double *boxes, uint32_t *__restrict__ bounded, NodeRec32 *__restrict__ recs32)
+                                                         double *boxes, uint32_t *__restrict__ bounded, NodeRec32 *__restrict__ recs32,
+                                                         const int32_t *__restrict__ cross_list, const uint32_t *__restrict__ cross_count, uint32_t cross_cap)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
-    const NodeMeta m = meta[i];
-    const int first = min(i, m.z), last = max(i, m.z);
-    const int b0 = (i / REFIT_BLK) * REFIT_BLK;
-    if (first >= b0 && last < b0 + REFIT_BLK) return;                  // done by k_refit_seg_local
-    const int split = (m.x >= n - 1) ? m.x - (n - 1) : m.x;
+    __shared__ uint32_t pre[65];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) {
+        uint32_t c = cross_count[tid];
+        if (c > cross_cap) c = cross_cap;
+        uint32_t v = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(v, o); if (lane >= o) v += u; }
+        pre[tid + 1] = v;
+        if (tid == 0) pre[0] = 0;
+    }
+    __syncthreads();
+    const uint32_t total = pre[64];
     const long long P = (long long)nbp2 * REFIT_BLK;
-    // queries read only leaf boxes and segment-tree nodes, never another cross node's output: no ordering needed
-    const Box bl = seg_query_global(seg, boxes, n, P, first, split);
-    const Box br = seg_query_global(seg, boxes, n, P, split + 1, last);
-    store_box(boxes, i, emit_node(bl, br, m.x, m.y, recs32 + i, n - 1));
-    bounded[i] = 2;
+    for (uint32_t k = blockIdx.x * 4 + (tid >> 6); k < total; k += gridDim.x * 4) {   // one wave per node (k is wave-uniform)
+        int lo = 0, hi = 64;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= k) lo = mid; else hi = mid; }
+        const int i = cross_list[(size_t)lo * cross_cap + (k - pre[lo])];
+        const NodeMeta m = meta[i];
+        const int first = min(i, m.z), last = max(i, m.z);
+        const int split = (m.x >= n - 1) ? m.x - (n - 1) : m.x;
+        const Box bl = seg_query_wave(seg, boxes, n, P, first, split, lane);
+        const Box br = seg_query_wave(seg, boxes, n, P, split + 1, last, lane);
+        if (lane == 0) {
+            store_box(boxes, i, emit_node(bl, br, m.x, m.y, recs32 + i, n - 1));
+            bounded[i] = 2;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- verifier counters (check.cuh)

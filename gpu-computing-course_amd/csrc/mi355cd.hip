@@ -49,7 +49,7 @@ struct cd_ctx {
     void *d_os = nullptr; size_t os_bytes = 0; uint32_t *d_os_hist = nullptr; uint32_t *d_os_ticket = nullptr; unsigned long long *d_os_look = nullptr;
     double *d_frame = nullptr, *d_partial = nullptr;
     // tree
-    LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; double *d_seg = nullptr; uint32_t nbp2 = 1;   // segment tree over leaf boxes: nbp2*512 heap nodes
+    LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; double *d_seg = nullptr; uint32_t nbp2 = 1; int32_t *d_cross = nullptr; uint32_t cross_cap = 0;   // segment tree over leaf boxes: nbp2*512 heap nodes
     double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec32 *d_recs32 = nullptr;
     uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
     // traversal
@@ -70,7 +70,7 @@ void free_all(cd_ctx *c)
     hipFree(c->d_verts); hipFree(c->d_vidx); hipFree(c->d_ids);
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
-    hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_boxes);
+    hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_cross); hipFree(c->d_boxes);
     hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_small); hipFree(c->d_state);
     hipFree(c->d_pairs); hipFree(c->d_defer); hipFree(c->d_deep); hipFree(c->d_cand);
     for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -121,13 +121,13 @@ int enqueue_morton_sort(cd_ctx *c)
     return 0;
 }
 
-int enqueue_hierarchy(cd_ctx *c)
+int enqueue_hierarchy(cd_ctx *c, bool poison_boxes)
 {
     const uint32_t n = c->nt;
     hipStream_t s = c->stream;
     HIPCHK(hipEventRecord(c->ev[EV_HIER0], s));
     HIPCHK(hipMemsetAsync(c->d_small, 0, 16 * sizeof(uint32_t), s));
-    k_fill_leaves<<<cdiv(n, 256), 256, 0, s>>>(c->d_perm[0], c->d_vidx, c->d_ids, n, c->d_leaf, c->d_parent, c->d_bounded, c->d_boxes);
+    k_fill_leaves<<<cdiv(n, 256), 256, 0, s>>>(c->d_perm[0], c->d_vidx, c->d_ids, n, c->d_leaf, c->d_parent, c->d_bounded, poison_boxes ? c->d_boxes : nullptr);
     if (n > 1)
         k_hierarchy<<<cdiv(n - 1, 256), 256, 0, s>>>(c->d_keys[0], (int)n, c->d_meta, c->d_parent, c->d_small);
     HIPCHK(hipEventRecord(c->ev[EV_HIER1], s));
@@ -141,9 +141,16 @@ int enqueue_refit(cd_ctx *c)
     hipStream_t s = c->stream;
     HIPCHK(hipEventRecord(c->ev[EV_REFIT0], s));
     const int nblocks = (int)cdiv(n, REFIT_BLK);
-    k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded, c->d_recs32, c->d_seg, (int)c->nbp2);
+    // cross-node lists: 64 shards x cross_cap entries (a shard takes the blocks b with b % 64 == shard, each
+    // contributing at most 512 nodes); their 64 counters in d_small[16..79]
+    int32_t *cross_list = c->d_cross;
+    uint32_t *cross_count = c->d_small + 16;
+    HIPCHK(hipMemsetAsync(cross_count, 0, 64 * sizeof(uint32_t), s));
+    k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded, c->d_recs32, c->d_seg, (int)c->nbp2,
+                                                   cross_list, cross_count, c->cross_cap);
     k_refit_seg_top<<<1, 1024, 0, s>>>(c->d_seg, (int)c->nbp2, nblocks);
-    if (n > 1) k_refit_seg_cross<<<cdiv(n - 1, 256), 256, 0, s>>>((int)n, c->d_meta, c->d_seg, (int)c->nbp2, c->d_boxes, c->d_bounded, c->d_recs32);
+    if (n > 1) k_refit_seg_cross<<<1024, 256, 0, s>>>((int)n, c->d_meta, c->d_seg, (int)c->nbp2, c->d_boxes, c->d_bounded, c->d_recs32,
+                                                      c->d_cross, cross_count, c->cross_cap);
     HIPCHK(hipEventRecord(c->ev[EV_REFIT1], s));
     HIPCHK(hipGetLastError());
     return 0;
@@ -319,10 +326,12 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_parent, sizeof(int32_t) * 2 * n);
     { uint32_t nb = cdiv(nt, REFIT_BLK); c->nbp2 = 1; while (c->nbp2 < nb) c->nbp2 <<= 1; }
     ALLOC(c->d_seg, sizeof(double) * 6 * (size_t)c->nbp2 * REFIT_BLK);
+    c->cross_cap = (cdiv(nt, REFIT_BLK) / 64 + 1) * REFIT_BLK;
+    ALLOC(c->d_cross, sizeof(int32_t) * 64 * (size_t)c->cross_cap);
     ALLOC(c->d_boxes, sizeof(double) * 6 * 2 * n);
     ALLOC(c->d_bounded, sizeof(uint32_t) * n);
     ALLOC(c->d_recs32, sizeof(NodeRec32) * n);
-    ALLOC(c->d_small, sizeof(uint32_t) * 16);
+    ALLOC(c->d_small, sizeof(uint32_t) * 128);
     ALLOC(c->d_state, sizeof(TravState));
     c->cand_cap = ((4 * n > (1u << 20) ? 4 * n : (1u << 20)) + NSHARD - 1) / NSHARD * NSHARD;
     ALLOC(c->d_cand, sizeof(Candidates) * c->cand_cap);
@@ -397,7 +406,7 @@ int cd_build_hierarchy(cd_ctx *c, uint32_t *parent_wrong_num)
 {
     if (!c) return CD_ERR_ARG;
     if (c->stage < ST_SORTED) return CD_ERR_ORDER;
-    int rc = enqueue_hierarchy(c);
+    int rc = enqueue_hierarchy(c, true);
     if (rc) return rc;
     uint32_t wrong = 0;
     HIPCHK(hipMemcpyAsync(&wrong, c->d_small, sizeof wrong, hipMemcpyDeviceToHost, c->stream));
@@ -454,7 +463,7 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     if (!c || (cap_pairs && !pairs)) return CD_ERR_ARG;
     int rc;
     if ((rc = enqueue_morton_sort(c))) return rc;
-    if ((rc = enqueue_hierarchy(c))) return rc;
+    if ((rc = enqueue_hierarchy(c, false))) return rc;
     if ((rc = enqueue_refit(c))) return rc;
     rc = run_traversal(c, nullptr, 0, pairs, cap_pairs, n_pairs);     // synchronises
     if (rc < 0) return rc;
