@@ -144,6 +144,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *
 // needed because nothing else is published.  Tile ids are handed out by an atomic ticket, so every
 // predecessor of a spinning tile is already resident and publishes without waiting on anyone: no deadlock
 // whatever the dispatch order.  Granules are zeroed by one hipMemsetAsync per sort.
+// Measured alternatives at 1 M keys (profiles/r01_experiments/): wider look-back batches (32) and a flat sum
+// over all predecessors' aggregates did not help -- the ~10 us a pass spends here is the rendezvous itself (a
+// tile cannot scatter before every earlier tile has ranked), not the walk; forwarding each key into the NEXT
+// pass's per-tile histogram with global atomics while scattering (no look-back at all) cost 3x (1 M scattered
+// atomics per pass).
+constexpr int OS_THREADS = 512;                        // 8 waves x 8 keys per lane = the same 4096-key tile, half the serial ranking per wave
+constexpr int OS_WAVES   = OS_THREADS / 64;
+constexpr int OS_ITEMS   = SORT_TILE / OS_THREADS;
 constexpr unsigned long long OS_AGG = 1ull << 62;      // value = this tile's count for the digit
 constexpr unsigned long long OS_PREFIX = 2ull << 62;   // value = inclusive prefix over tiles 0..t
 constexpr unsigned long long OS_VALUE_MASK = (1ull << 62) - 1;
@@ -192,35 +200,35 @@ __global__ __launch_bounds__(RADIX) void k_os_scan(uint32_t *__restrict__ ghist)
     }
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+__global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                           uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                           uint32_t n, int shift, const uint32_t *__restrict__ digit_base /* [256] */,
                                                           unsigned long long *lookback /* [ntiles][256] */, uint32_t *ticket /* [pass]; ticket[8 - pass] = timeout flag */, int first_pass)
 {
-    __shared__ uint32_t wcnt[SORT_WAVES][RADIX];
+    __shared__ uint32_t wcnt[OS_WAVES][RADIX];
     __shared__ uint32_t gbase[RADIX];
     __shared__ uint32_t s_tile;
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-    for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_THREADS) (&wcnt[0][0])[i] = 0;
+    for (int i = tid; i < OS_WAVES * RADIX; i += OS_THREADS) (&wcnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
 
-    const uint32_t base_w = tile * SORT_TILE + w * (SORT_ITEMS * 64);
-    uint64_t k[SORT_ITEMS];
-    uint32_t v[SORT_ITEMS];
-    uint32_t rk[SORT_ITEMS];
+    const uint32_t base_w = tile * SORT_TILE + w * (OS_ITEMS * 64);
+    uint64_t k[OS_ITEMS];
+    uint32_t v[OS_ITEMS];
+    uint32_t rk[OS_ITEMS];
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-    for (int it = 0; it < SORT_ITEMS; ++it) {
+    for (int it = 0; it < OS_ITEMS; ++it) {
         const uint32_t i = base_w + it * 64 + lane;
         const bool ok = i < n;
         k[it] = ok ? keys_in[i] : ~0ull;
         v[it] = ok ? (first_pass ? i : vals_in[i]) : 0u;
     }
 #pragma unroll
-    for (int it = 0; it < SORT_ITEMS; ++it) {
+    for (int it = 0; it < OS_ITEMS; ++it) {
         const uint32_t i = base_w + it * 64 + lane;
         const bool ok = i < n;
         const uint32_t d = (uint32_t)(k[it] >> shift) & (RADIX - 1);
@@ -240,11 +248,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint64_t *__rest
         rk[it] = old + below;
     }
     __syncthreads();
-    // thread = digit: wave-exclusive bases, the tile's count, publish, look back
-    {
+    // thread = digit (the first RADIX threads): wave-exclusive bases, the tile's count, publish, look back
+    if (tid < RADIX) {
         uint32_t run = 0;
 #pragma unroll
-        for (int ww = 0; ww < SORT_WAVES; ++ww) { const uint32_t c = wcnt[ww][tid]; wcnt[ww][tid] = run; run += c; }
+        for (int ww = 0; ww < OS_WAVES; ++ww) { const uint32_t c = wcnt[ww][tid]; wcnt[ww][tid] = run; run += c; }
         const unsigned long long count = run;
         unsigned long long *mine = lookback + (size_t)tile * RADIX + tid;
         unsigned long long excl = 0;
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint64_t *__rest
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < SORT_ITEMS; ++it) {
+    for (int it = 0; it < OS_ITEMS; ++it) {
         const uint32_t i = base_w + it * 64 + lane;
         if (i < n) {
             const uint32_t d = (uint32_t)(k[it] >> shift) & (RADIX - 1);

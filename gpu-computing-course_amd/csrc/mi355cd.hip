@@ -110,7 +110,7 @@ int enqueue_morton_sort(cd_ctx *c)
     k_os_scan<<<1, RADIX, 0, s>>>(c->d_os_hist);
     int cur = 0;
     for (int pass = 0; pass < 8; ++pass) {
-        k_os_pass<<<c->ntiles, SORT_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1], n, pass * RADIX_BITS,
+        k_os_pass<<<c->ntiles, OS_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1], n, pass * RADIX_BITS,
                                                     c->d_os_hist + pass * RADIX, c->d_os_look + (size_t)pass * c->ntiles * RADIX,
                                                     c->d_os_ticket + pass, pass == 0);
         cur ^= 1;
