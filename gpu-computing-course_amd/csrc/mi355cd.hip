@@ -61,6 +61,7 @@ struct cd_ctx {
     int32_t *d_deep = nullptr; uint64_t deep_items = 0;
     // host mirrors
     cd_stats stats = {};
+    uint32_t sort_flags[8] = {};            // look-back time-out words of the last sort, refreshed by read_state()
 };
 
 namespace {
@@ -189,11 +190,16 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
 
 struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_candidates; uint32_t n_deferred; uint64_t wave_steps, candidates; };
 
-int read_state(cd_ctx *c, HostCounters &h)
+constexpr uint64_t SPEC_PAIRS = 1u << 15;     // pairs copied back speculatively together with the counters (256 KB)
+
+// One host round trip: counters, the sort's time-out flags, and (if asked) the first SPEC_PAIRS pairs.
+int read_state(cd_ctx *c, HostCounters &h, uint32_t *spec_pairs = nullptr, uint64_t spec_n = 0)
 {
     static_assert(sizeof(TravState) <= 16384, "state read-back size");
     TravState hs;
     HIPCHK(hipMemcpyAsync(&hs, c->d_state, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));
+    if (spec_pairs && spec_n) HIPCHK(hipMemcpyAsync(spec_pairs, c->d_pairs, sizeof(uint32_t) * 2 * spec_n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     h = HostCounters{hs.n_pairs, 0, 0, 0, hs.n_deferred, 0, 0};
     for (int i = 0; i < NSHARD; ++i) {
@@ -226,6 +232,7 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     uint32_t launches = 0;
     float deep_ms = 0.f;
     HostCounters h = {};
+    uint64_t spec_valid = 0;
     bool done = false;
     c->stats.stack_overflows = 0;
     for (int attempt = 0; attempt < 8 && !done; ++attempt) {
@@ -238,7 +245,9 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
             launches += per_pass;
         }
         HIPCHK(hipEventRecord(c->ev[EV_TRAV1], s));      // device time of the kernels only: recorded before the read-back
-        if ((rc = read_state(c, h))) return rc;
+        const uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
+        if ((rc = read_state(c, h, pairs, spec_n))) return rc;
+        spec_valid = spec_n;
         if (h.max_shard_candidates > c->cand_cap / NSHARD) { if ((rc = grow_candidates(c, h.max_shard_candidates))) return rc; continue; }
         if (h.n_deferred > c->defer_cap) {               // the deferred list was too small: grow it and redo (pairs restart at 0)
             hipFree(c->d_defer); c->d_defer = nullptr; c->defer_cap = 0;
@@ -275,8 +284,12 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     HIPCHK(hipGetLastError());
     const uint64_t found = h.n_pairs;
     const uint64_t ncopy = found < cap_pairs ? found : cap_pairs;
-    if (pairs && ncopy) HIPCHK(hipMemcpyAsync(pairs, c->d_pairs, sizeof(uint32_t) * 2 * ncopy, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    // the first spec_valid pairs came back with the counters -- unless a deep pass appended more afterwards
+    const uint64_t have = (c->stats.stack_overflows == 0) ? spec_valid : 0;
+    if (pairs && ncopy > have) {
+        HIPCHK(hipMemcpyAsync(pairs + 2 * have, c->d_pairs + 2 * have, sizeof(uint32_t) * 2 * (ncopy - have), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
     c->stats.ms_traverse = elapsed(c, EV_TRAV0, EV_TRAV1) + deep_ms;
     c->stats.ms_descend = (c->trav_variant != 0 && nq > 0) ? elapsed(c, EV_TRAV0, EV_DESC1) : 0.f;
     c->stats.ms_exact = (c->trav_variant != 0 && nq > 0) ? elapsed(c, EV_DESC1, EV_TRAV1) : 0.f;
@@ -467,7 +480,7 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     if ((rc = enqueue_refit(c))) return rc;
     rc = run_traversal(c, nullptr, 0, pairs, cap_pairs, n_pairs);     // synchronises
     if (rc < 0) return rc;
-    { int rs = check_sort_flags(c); if (rs) return rs; }
+    for (int i = 0; i < 8; ++i) if (c->sort_flags[i]) return CD_ERR_SORT;    // fetched with the traversal counters
     c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
     c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
     c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);

@@ -174,11 +174,17 @@ class CollisionDetector:
 
     def _pairs_call(self, fn, name, cap, *pre):
         n = C.c_uint64(0)
-        buf = np.zeros((max(cap, 0), 2), dtype=np.uint32) if cap else None
+        # the output buffer is kept between calls (a 4 M-pair buffer is 32 MB; allocating it per step costs more
+        # than the step); callers get a copy of the filled prefix
+        buf = None
+        if cap:
+            if getattr(self, "_pairbuf", None) is None or self._pairbuf.shape[0] != cap:
+                self._pairbuf = np.empty((cap, 2), dtype=np.uint32)
+            buf = self._pairbuf
         rc = fn(self._ctx, *pre, _ptr(buf), cap, C.byref(n))
         self._chk(name, rc, allow=(CD_OK, CD_OVERFLOW))
         got = min(n.value, cap)
-        return (buf[:got] if buf is not None else np.zeros((0, 2), dtype=np.uint32)), n.value, rc
+        return (buf[:got].copy() if buf is not None else np.zeros((0, 2), dtype=np.uint32)), n.value, rc
 
     def find_collisions(self, cap: int = 1 << 20):
         return self._pairs_call(self.lib.cd_find_collisions, "cd_find_collisions", cap)
