@@ -66,6 +66,61 @@ __device__ __forceinline__ uint32_t pack_px(const Px &p)
     return r | (g << 8) | (b << 16) | (255u << 24);
 }
 
+// Exact conservative cull of one sphere against the pixel rectangle [X0,X1] x [Y0,Y1] (inclusive).  For a column x
+// of the rectangle dx(x) = fl(ox(x) - cx) is monotone in x, so over the rectangle |dx| >= m where m = dx(X0) if that
+// is > 0, -dx(X1) if dx(X1) < 0, else 0; likewise y.  fl is monotone, hence fl(dx^2 + dy^2) >= fl(mx^2 + my^2) for
+// every pixel: if that lower bound is not < rr, the reference's own predicate (sphere.cuh:38) is false on the whole
+// rectangle.  A larger rectangle has smaller or equal m: whatever survives for a tile survives for its super-tile.
+// NaN anywhere -> keep (the exact per-pixel test then rejects).
+__device__ __forceinline__ bool may_touch(const SphGeom g, float ox0, float ox1, float oy0, float oy1)
+{
+    const float dx0 = ox0 - g.cx, dx1 = ox1 - g.cx;
+    const float dy0 = oy0 - g.cy, dy1 = oy1 - g.cy;
+    const float mx = dx0 > 0.f ? dx0 : (dx1 < 0.f ? dx1 : 0.f);
+    const float my = dy0 > 0.f ? dy0 : (dy1 < 0.f ? dy1 : 0.f);
+    return !(mx * mx + my * my >= g.rr);
+}
+
+constexpr int SUPER = 256;             // super-tile edge in pixels (4 x 4 tiles)
+
+// Level 1 of the binning: one workgroup per 256x256 super-tile culls ALL spheres and writes the survivors, in
+// ascending sphere index (wave-ordered __ballot compaction), to super_list[st][0..count).  Tiles then cull only
+// their super-tile's few dozen survivors instead of all S spheres.
+__global__ __launch_bounds__(THREADS) void k_bin_super(const SphGeom *__restrict__ geom, int n, int dim, int c_shift_x, int c_shift_y,
+                                                       int nsx, int sy0, int *__restrict__ super_list, int *__restrict__ super_count)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *list = reinterpret_cast<int *>(smem);              // 4 sub-lists of cap = ceil(n/4) entries
+    __shared__ int wcount[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int sx = blockIdx.x, sy = blockIdx.y + sy0;
+    const int X0 = sx * SUPER, Y0 = sy * SUPER;
+    const int X1 = min(X0 + SUPER, dim) - 1, Y1 = min(Y0 + SUPER, dim) - 1;
+    const float ox0 = (float)(X0 - dim / 2 + c_shift_x), ox1 = (float)(X1 - dim / 2 + c_shift_x);
+    const float oy0 = (float)(Y0 - dim / 2 + c_shift_y), oy1 = (float)(Y1 - dim / 2 + c_shift_y);
+    const int sub_cap = (n + 3) >> 2;
+    int cnt = 0;
+    const int s_begin = w * sub_cap, s_end = min(n, s_begin + sub_cap);
+    for (int base = s_begin; base < s_end; base += 64) {
+        const int i = base + lane;
+        const bool keep = (i < s_end) && may_touch(geom[i], ox0, ox1, oy0, oy1);
+        const unsigned long long m = __ballot(keep);
+        if (keep) list[w * sub_cap + cnt + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        cnt += __popcll(m);
+    }
+    if (lane == 0) wcount[w] = cnt;
+    __syncthreads();
+    const int st = sy * nsx + sx;
+    int *out = super_list + (size_t)st * n;
+    int off = 0;
+    for (int ww = 0; ww < 4; ++ww) {                        // concatenate in wave order == ascending sphere index
+        const int c = wcount[ww];
+        for (int k = tid; k < c; k += THREADS) out[off + k] = list[ww * sub_cap + k];
+        off += c;
+    }
+    if (tid == 0) super_count[st] = off;
+}
+
 // Thread layout inside a 64x64 tile: tx = tid & 15 owns 4 consecutive columns, ty = tid >> 4 owns rows
 // ty, ty+16, ty+32, ty+48 -> each row of the tile is written by 16 lanes x 16 B = 256 contiguous bytes.
 //
@@ -73,11 +128,13 @@ __device__ __forceinline__ uint32_t pack_px(const Px &p)
 // is wave-uniform, so the geometry comes through the scalar cache (s_load), not LDS.
 // BINNED == true: first the workgroup culls spheres that cannot touch the tile, with a bound built from
 // the same float operations as the hit test (below), keeping survivors in index order; pixels then loop
-// over the survivors only.  Identical pixels, ~S/(survivors) times fewer hit() evaluations.
+// over the survivors only.  Identical pixels, ~S/(survivors) times fewer hit() evaluations.  The cull itself is
+// two-level: k_bin_super reduces the S spheres to a few dozen per 256x256 super-tile, the tile culls only those.
 template <bool BINNED>
 __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ geom, const SphShade *__restrict__ shade, int n,
                                                     int dim, int c_shift_x, int c_shift_y, int tile_y0,
-                                                    uint32_t *__restrict__ rgba, unsigned long long *__restrict__ tests)
+                                                    uint32_t *__restrict__ rgba, unsigned long long *__restrict__ tests,
+                                                    const int *__restrict__ super_list, const int *__restrict__ super_count, int nsx)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *list = reinterpret_cast<int *>(smem);              // BINNED: 4 sub-lists of cap = ceil(n/4) entries
@@ -107,26 +164,19 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
                 for (int b = 0; b < 4; ++b) shade_one(px[a][b], ox[b], oy[a], g, shade, i);
         }
     } else {
-        // ---- exact conservative cull.  For a column x of the tile, dx(x) = fl(ox(x) - cx) is monotone in x,
-        // so over the tile |dx| >= m where m = dx(X0) if that is > 0, -dx(X1) if dx(X1) < 0, else 0; likewise y.
-        // fl is monotone, hence fl(dx^2 + dy^2) >= fl(mx^2 + my^2) for every pixel of the tile: if that lower
-        // bound is not < rr the reference's own predicate (sphere.cuh:38) is false on the whole tile.
-        const int sub_cap = (n + 3) >> 2;
+        // ---- level 2 of the binning: cull this tile's super-tile survivors (may_touch above), keeping index order
         const float ox0 = (float)(X0 - dim / 2 + c_shift_x), ox1 = (float)(X0 + TILE - 1 - dim / 2 + c_shift_x);
         const float oy0 = (float)(Y0 - dim / 2 + c_shift_y), oy1 = (float)(Y0 + TILE - 1 - dim / 2 + c_shift_y);
+        const int st = (Y0 / SUPER) * nsx + (X0 / SUPER);
+        const int *slist = super_list + (size_t)st * n;
+        const int scount = super_count[st];
+        const int sub_cap = (scount + 3) >> 2;                   // wave w takes list positions [w*sub_cap, (w+1)*sub_cap)
         int cnt = 0;                                           // wave-uniform running length of this wave's sub-list
-        const int s_begin = w * sub_cap, s_end = min(n, s_begin + sub_cap);
+        const int s_begin = w * sub_cap, s_end = min(scount, s_begin + sub_cap);
         for (int base = s_begin; base < s_end; base += 64) {
-            const int i = base + lane;
-            bool keep = false;
-            if (i < s_end) {
-                const SphGeom g = geom[i];
-                const float dx0 = ox0 - g.cx, dx1 = ox1 - g.cx;
-                const float dy0 = oy0 - g.cy, dy1 = oy1 - g.cy;
-                const float mx = dx0 > 0.f ? dx0 : (dx1 < 0.f ? dx1 : 0.f);
-                const float my = dy0 > 0.f ? dy0 : (dy1 < 0.f ? dy1 : 0.f);
-                keep = !(mx * mx + my * my >= g.rr);           // NaN anywhere -> keep (the exact test then rejects)
-            }
+            const int pos = base + lane;
+            bool keep = false; int i = 0;
+            if (pos < s_end) { i = slist[pos]; keep = may_touch(geom[i], ox0, ox1, oy0, oy1); }
             const unsigned long long m = __ballot(keep);
             if (keep) list[w * sub_cap + cnt + __popcll(m & ((1ull << lane) - 1ull))] = i;
             cnt += __popcll(m);
@@ -167,13 +217,14 @@ struct rt_ctx {
     RtSphere *d_spheres = nullptr; int32_t *d_shifts = nullptr;
     SphGeom *d_geom = nullptr; SphShade *d_shade = nullptr;
     uint32_t *d_rgba = nullptr; unsigned long long *d_tests = nullptr;
+    int *d_super_list = nullptr, *d_super_count = nullptr;      // [nsuper][n] ordered survivor lists, [nsuper] counts
     rt_stats stats = {};
 };
 
 namespace {
 void rt_free(rt_ctx *c)
 {
-    hipFree(c->d_spheres); hipFree(c->d_shifts); hipFree(c->d_geom); hipFree(c->d_shade); hipFree(c->d_rgba); hipFree(c->d_tests);
+    hipFree(c->d_spheres); hipFree(c->d_shifts); hipFree(c->d_geom); hipFree(c->d_shade); hipFree(c->d_rgba); hipFree(c->d_tests); hipFree(c->d_super_list); hipFree(c->d_super_count);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -204,6 +255,8 @@ int rt_create(rt_ctx **out, const RtSphere *spheres, int32_t n_spheres, int32_t 
     ok(hipMalloc(&c->d_shade, sizeof(SphShade) * (size_t)n_spheres));
     ok(hipMalloc(&c->d_rgba, sizeof(uint32_t) * (size_t)dim * dim));
     ok(hipMalloc(&c->d_tests, sizeof(unsigned long long)));
+    { const size_t ns = (size_t)((dim + SUPER - 1) / SUPER) * ((dim + SUPER - 1) / SUPER);
+      ok(hipMalloc(&c->d_super_list, sizeof(int) * ns * (size_t)n_spheres)); ok(hipMalloc(&c->d_super_count, sizeof(int) * ns)); }
     if (e == hipSuccess) ok(hipMemcpy(c->d_spheres, spheres, sizeof(RtSphere) * (size_t)n_spheres, hipMemcpyHostToDevice));
     if (e != hipSuccess) { rt_free(c); delete c; return -(int)e; }
     *out = c;
@@ -244,9 +297,13 @@ int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, 
     const dim3 grid(c->dim / TILE, (y1 - y0) / TILE);
     if (c->mode == RT_MODE_BINNED) {
         const size_t lds = sizeof(int) * 4 * (size_t)((c->n + 3) / 4);
-        k_render<true><<<grid, THREADS, lds, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, y0 / TILE, c->d_rgba, c->d_tests);
+        const int nsx = (c->dim + SUPER - 1) / SUPER;
+        const int sy0 = y0 / SUPER, sy1 = (y1 + SUPER - 1) / SUPER;
+        k_bin_super<<<dim3(nsx, sy1 - sy0), THREADS, lds, s>>>(c->d_geom, c->n, c->dim, csx, csy, nsx, sy0, c->d_super_list, c->d_super_count);
+        k_render<true><<<grid, THREADS, lds, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, y0 / TILE, c->d_rgba, c->d_tests,
+                                                  c->d_super_list, c->d_super_count, nsx);
     } else {
-        k_render<false><<<grid, THREADS, 0, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, y0 / TILE, c->d_rgba, nullptr);
+        k_render<false><<<grid, THREADS, 0, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, y0 / TILE, c->d_rgba, nullptr, nullptr, nullptr, 0);
     }
     HIPCHK(hipEventRecord(c->ev1, s));
     HIPCHK(hipGetLastError());
