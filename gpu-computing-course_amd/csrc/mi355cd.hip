@@ -5,6 +5,7 @@
 #include "cd_sort.h"
 #include "cd_bvh.h"
 #include "cd_traverse.h"
+#include "cd_post.h"
 
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -59,6 +60,10 @@ struct cd_ctx {
     uint2 *d_defer = nullptr; uint32_t defer_cap = 0;
     Candidates *d_cand = nullptr; uint64_t cand_cap = 0;    // variant C candidate buffer
     int32_t *d_deep = nullptr; uint64_t deep_items = 0;
+    // pair-list post-processing (cd_sorted_pairs / cd_collision_triangles): sort buffers sized on demand
+    uint64_t *pp_keys[2] = {nullptr, nullptr}; uint32_t *pp_vals[2] = {nullptr, nullptr}; uint32_t *pp_flags = nullptr;
+    void *pp_os = nullptr; size_t pp_os_bytes = 0; uint32_t pp_cap = 0;
+    uint64_t last_pairs_on_device = 0;      // pairs of the last traversal that are resident in d_pairs
     // host mirrors
     cd_stats stats = {};
     uint32_t sort_flags[8] = {};            // look-back time-out words of the last sort, refreshed by read_state()
@@ -74,6 +79,8 @@ void free_all(cd_ctx *c)
     hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_cross); hipFree(c->d_boxes);
     hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_small); hipFree(c->d_state);
     hipFree(c->d_pairs); hipFree(c->d_defer); hipFree(c->d_deep); hipFree(c->d_cand);
+    for (int i = 0; i < 2; ++i) { hipFree(c->pp_keys[i]); hipFree(c->pp_vals[i]); }
+    hipFree(c->pp_flags); hipFree(c->pp_os);
     for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);
 }
@@ -296,8 +303,46 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     c->stats.traverse_launches = launches;
     c->stats.n_pairs = found; c->stats.pairs_tested = h.pairs_tested; c->stats.node_visits = h.node_visits;
     c->stats.wave_steps = h.wave_steps; c->stats.candidates = h.candidates;
+    c->last_pairs_on_device = found <= cap_pairs ? found : cap_pairs;
     if (n_pairs) *n_pairs = found;
     return found > cap_pairs ? CD_OVERFLOW : CD_OK;
+}
+
+
+// ---- pair-list post-processing -----------------------------------------------------------------------
+int pp_reserve(cd_ctx *c, uint32_t m)
+{
+    if (m <= c->pp_cap) return 0;
+    for (int i = 0; i < 2; ++i) { hipFree(c->pp_keys[i]); hipFree(c->pp_vals[i]); c->pp_keys[i] = nullptr; c->pp_vals[i] = nullptr; }
+    hipFree(c->pp_flags); hipFree(c->pp_os); c->pp_flags = nullptr; c->pp_os = nullptr; c->pp_cap = 0;
+    const uint32_t cap = m + m / 4 + 4096;
+    const uint32_t ntiles = cdiv(cap, SORT_TILE);
+    for (int i = 0; i < 2; ++i) { HIPCHK(hipMalloc(&c->pp_keys[i], sizeof(uint64_t) * cap)); HIPCHK(hipMalloc(&c->pp_vals[i], sizeof(uint32_t) * cap)); }
+    HIPCHK(hipMalloc(&c->pp_flags, sizeof(uint32_t) * cap));
+    c->pp_os_bytes = sizeof(uint32_t) * 8 * RADIX + 64 + sizeof(unsigned long long) * 8 * (size_t)ntiles * RADIX;
+    HIPCHK(hipMalloc(&c->pp_os, c->pp_os_bytes));
+    c->pp_cap = cap;
+    return 0;
+}
+
+// Ascending radix sort of pp_keys[0][0..m) (onesweep, cd_sort.h); result back in pp_keys[0].
+int pp_sort(cd_ctx *c, uint32_t m)
+{
+    hipStream_t s = c->stream;
+    const uint32_t ntiles = cdiv(m, SORT_TILE);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(c->pp_os);
+    uint32_t *ticket = hist + 8 * RADIX;
+    unsigned long long *look = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->pp_os) + sizeof(uint32_t) * 8 * RADIX + 64);
+    HIPCHK(hipMemsetAsync(c->pp_os, 0, sizeof(uint32_t) * 8 * RADIX + 64 + sizeof(unsigned long long) * 8 * (size_t)ntiles * RADIX, s));
+    k_os_hist<<<ntiles < 512 ? ntiles : 512, SORT_THREADS, 0, s>>>(c->pp_keys[0], m, ntiles, hist);
+    k_os_scan<<<1, RADIX, 0, s>>>(hist);
+    int cur = 0;
+    for (int pass = 0; pass < 8; ++pass) {
+        k_os_pass<<<ntiles, OS_THREADS, 0, s>>>(c->pp_keys[cur], c->pp_vals[cur], c->pp_keys[cur ^ 1], c->pp_vals[cur ^ 1], m, pass * RADIX_BITS,
+                                                hist + pass * RADIX, look + (size_t)pass * ntiles * RADIX, ticket + pass, pass == 0);
+        cur ^= 1;
+    }
+    return 0;
 }
 
 }  // namespace
@@ -522,6 +567,61 @@ int cd_test_pairs(cd_ctx *c, const uint32_t *pairs, uint64_t np, uint8_t *out)
     }
     hipFree(d_p); hipFree(d_o);
     return rc;
+}
+
+int cd_sorted_pairs(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs)
+{
+    if (!c || !n_pairs || (cap_pairs && !pairs)) return CD_ERR_ARG;
+    if (c->stage < ST_REFIT) return CD_ERR_ORDER;
+    if (c->stats.n_pairs > c->last_pairs_on_device) return CD_OVERFLOW;     // the last traversal's list was truncated: rerun it with a larger cap
+    const uint32_t m = (uint32_t)c->last_pairs_on_device;
+    *n_pairs = m;
+    if (m == 0) return CD_OK;
+    int rc = pp_reserve(c, m);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    k_pairs_to_keys<<<cdiv(m, 256), 256, 0, s>>>(c->d_pairs, m, c->pp_keys[0]);
+    if ((rc = pp_sort(c, m))) return rc;
+    k_keys_to_pairs<<<cdiv(m, 256), 256, 0, s>>>(c->pp_keys[0], m, reinterpret_cast<uint32_t *>(c->pp_keys[1]));
+    const uint64_t ncopy = m < cap_pairs ? m : cap_pairs;
+    if (ncopy) HIPCHK(hipMemcpyAsync(pairs, c->pp_keys[1], sizeof(uint32_t) * 2 * ncopy, hipMemcpyDeviceToHost, s));
+    uint32_t f[8];
+    HIPCHK(hipMemcpyAsync(f, reinterpret_cast<uint32_t *>(c->pp_os) + 8 * RADIX + 8, sizeof f, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < 8; ++i) if (f[i]) return CD_ERR_SORT;
+    return m > cap_pairs ? CD_OVERFLOW : CD_OK;
+}
+
+int cd_collision_triangles(cd_ctx *c, uint32_t *ids, uint64_t cap, uint64_t *n)
+{
+    if (!c || !n || (cap && !ids)) return CD_ERR_ARG;
+    if (c->stage < ST_REFIT) return CD_ERR_ORDER;
+    if (c->stats.n_pairs > c->last_pairs_on_device) return CD_OVERFLOW;
+    const uint64_t m2_64 = 2 * c->last_pairs_on_device;
+    *n = 0;
+    if (m2_64 == 0) return CD_OK;
+    if (m2_64 > 0xfffffff0ull) return CD_ERR_ARG;
+    const uint32_t m2 = (uint32_t)m2_64;
+    int rc = pp_reserve(c, m2);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    k_ids_to_keys<<<cdiv(m2, 256), 256, 0, s>>>(c->d_pairs, m2, c->pp_keys[0]);
+    if ((rc = pp_sort(c, m2))) return rc;
+    k_unique_flags<<<cdiv(m2, 256), 256, 0, s>>>(c->pp_keys[0], m2, c->pp_flags);
+    k_scan_exclusive<<<1, 1024, 0, s>>>(c->pp_flags, m2);
+    uint32_t *out = c->pp_vals[0], *d_count = reinterpret_cast<uint32_t *>(c->pp_os) + 8 * RADIX;   // ticket word 0 is free after the sort
+    k_unique_scatter<<<cdiv(m2, 256), 256, 0, s>>>(c->pp_keys[0], c->pp_flags, m2, out, c->pp_cap, d_count);
+    uint32_t cnt = 0, f[8];
+    HIPCHK(hipMemcpyAsync(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(f, reinterpret_cast<uint32_t *>(c->pp_os) + 8 * RADIX + 8, sizeof f, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < 8; ++i) if (f[i]) return CD_ERR_SORT;
+    *n = cnt;
+    const uint64_t ncopy = cnt < cap ? cnt : cap;
+    if (ncopy) HIPCHK(hipMemcpy(ids, out, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
+    return cnt > cap ? CD_OVERFLOW : CD_OK;
 }
 
 int cd_export_keys(cd_ctx *c, uint64_t *keys, uint32_t *perm)

@@ -102,7 +102,17 @@ int main(int argc, char **argv)
     const uint64_t shown = n_pairs < cap ? n_pairs : cap;
     std::printf("\nCollision pair (%llu triangle pairs in total):\n", (unsigned long long)n_pairs);  // main.cu:149
     for (uint64_t i = 0; i < shown; ++i) std::printf("%07u - %07u\n", pairs[2 * i], pairs[2 * i + 1]);   // main.cu:151
-    make_and_print_set(pairs.data(), 2 * shown, "Collision Triangles:");                             // main.cu:154
+    {   // main.cu:154 makeAndPrintSet -- the set is built on the device (sort + unique), printed in the reference's format
+        std::vector<uint32_t> ids(2 * shown + 1);
+        uint64_t n_ids = 0;
+        const int rs = cd_collision_triangles(ctx, ids.data(), ids.size(), &n_ids);
+        if (rs == CD_OK) {
+            std::printf("\n\n%s (%llu points in total):\n", "Collision Triangles:", (unsigned long long)n_ids);
+            for (uint64_t i = 0; i < n_ids; ++i) std::printf("%u\n", ids[i]);
+        } else {
+            make_and_print_set(pairs.data(), 2 * shown, "Collision Triangles:");     // truncated list: host fallback on what was returned
+        }
+    }
     std::printf("\n- pairs tested (leaf AABB hits) = %llu, node visits = %llu\n", (unsigned long long)st.pairs_tested, (unsigned long long)st.node_visits);
 
     if (brute) {                                                                                     // check.cuh:117-141

@@ -36,7 +36,7 @@ class CdStats(C.Structure):
 EXPORTS = [
     "cd_create", "cd_destroy", "cd_update_vertices", "cd_set_morton_frame", "cd_morton_sort",
     "cd_build_hierarchy", "cd_refit_boxes", "cd_check_internal", "cd_check_leaves",
-    "cd_check_triangle_idx", "cd_find_collisions", "cd_self_collide", "cd_brute_force",
+    "cd_check_triangle_idx", "cd_find_collisions", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
     "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_num_triangles",
     "cd_set_option", "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
 ]
@@ -65,6 +65,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_check_triangle_idx.argtypes = [vp, C.c_uint32, u32p]
     lib.cd_find_collisions.argtypes = [vp, vp, C.c_uint64, u64p]
     lib.cd_self_collide.argtypes = [vp, vp, C.c_uint64, u64p]
+    lib.cd_sorted_pairs.argtypes = [vp, vp, C.c_uint64, u64p]
+    lib.cd_collision_triangles.argtypes = [vp, vp, C.c_uint64, u64p]
     lib.cd_brute_force.argtypes = [vp, C.c_int, vp, C.c_uint64, u64p]
     lib.cd_test_pairs.argtypes = [vp, vp, C.c_uint64, vp]
     lib.cd_export_keys.argtypes = [vp, vp, vp]
@@ -191,6 +193,18 @@ class CollisionDetector:
 
     def self_collide(self, cap: int = 1 << 20):
         return self._pairs_call(self.lib.cd_self_collide, "cd_self_collide", cap)
+
+    def sorted_pairs(self, cap: int = 1 << 20):
+        """Pair list of the last traversal, sorted by (a, b) on the device."""
+        return self._pairs_call(self.lib.cd_sorted_pairs, "cd_sorted_pairs", cap)
+
+    def collision_triangles(self, cap: int = 1 << 21):
+        """Sorted distinct triangle IDs of the last traversal's pairs (main.cu:33-45), built on the device."""
+        n = C.c_uint64(0)
+        buf = np.empty(cap, dtype=np.uint32)
+        rc = self.lib.cd_collision_triangles(self._ctx, _ptr(buf), cap, C.byref(n))
+        self._chk("cd_collision_triangles", rc, allow=(CD_OK, CD_OVERFLOW))
+        return buf[:min(n.value, cap)].copy(), n.value, rc
 
     def brute_force(self, box_filter: bool = True, cap: int = 1 << 20):
         return self._pairs_call(self.lib.cd_brute_force, "cd_brute_force", cap, 1 if box_filter else 0)

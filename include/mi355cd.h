@@ -108,6 +108,14 @@ int cd_find_collisions(cd_ctx *ctx, uint32_t *pairs, uint64_t cap_pairs, uint64_
  * queued back to back on the context stream with a single host synchronisation at the end. */
 int cd_self_collide(cd_ctx *ctx, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs);
 
+/* main.cu:149-154: the pair list of the LAST traversal, sorted ascending by (smaller ID, larger ID) on the device --
+ * a deterministic order for diffing (the reference prints in atomicAdd arrival order).  Needs the last
+ * cd_find_collisions / cd_self_collide to have had cap_pairs >= its n_pairs (else CD_OVERFLOW). */
+int cd_sorted_pairs(cd_ctx *ctx, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs);
+/* main.cu:33-45 makeAndPrintSet: the sorted set of distinct triangle IDs that occur in the pair list,
+ * built on the device (sort + unique).  *n = number of distinct IDs (may exceed cap -> CD_OVERFLOW). */
+int cd_collision_triangles(cd_ctx *ctx, uint32_t *ids, uint64_t cap, uint64_t *n);
+
 /* check.cuh:117-141 checkDirectComp: O(N^2) all-pairs on the device, no tree.  box_filter != 0 also
  * requires the strict leaf-AABB overlap the BVH path applies (collision.cuh:31-36). Same output format
  * as cd_find_collisions. */

@@ -369,3 +369,27 @@ def test_cross_rank_pass_two_contexts_one_gpu(variant):
     assert sent > 0 and len(gs) > 0
     for e in engines:
         e.close()
+
+
+def test_device_pair_post_processing():
+    """SURVEY 8f row 2 (main.cu:33-45,149-154): sorted pair list and the set of colliding triangle IDs, on the device."""
+    verts, vidx = synth.soup(30000, 0.05, 12)
+    ids = (np.arange(vidx.shape[0], dtype=np.uint32) * 7 + 3).astype(np.uint32)      # non-trivial IDs
+    with mi355cd.CollisionDetector(verts, vidx, ids) as cd:
+        pairs, n, rc = cd.self_collide(cap=1 << 20)
+        assert rc == 0 and n > 100
+        sp, ns, rcs = cd.sorted_pairs(cap=1 << 20)
+        tri, nt, rct = cd.collision_triangles()
+        assert rcs == 0 and rct == 0 and ns == n
+        want = pairs[np.lexsort((pairs[:, 1], pairs[:, 0]))]
+        assert np.array_equal(sp, want)
+        assert np.array_equal(tri, np.unique(pairs)) and nt == len(np.unique(pairs))
+        # truncated traversal -> the post-processing refuses instead of returning a partial set
+        cd.find_collisions(cap=10)
+        assert cd.sorted_pairs()[2] == mi355cd.CD_OVERFLOW
+        # nothing colliding
+    v2, t2 = synth.soup(2000, 0.001, 13)
+    with mi355cd.CollisionDetector(v2, t2) as cd:
+        pairs, n, rc = cd.self_collide()
+        assert n == 0
+        assert cd.sorted_pairs()[1] == 0 and cd.collision_triangles()[1] == 0
