@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmi355cd.so")
 CD_OK, CD_OVERFLOW = 0, 1
 CD_ERR_ARG, CD_ERR_ORDER, CD_ERR_NO_DEVICE, CD_ERR_INDEX = -1001, -1002, -1003, -1004
 CD_FRAME_REFERENCE, CD_FRAME_AUTO, CD_FRAME_CUSTOM = 0, 1, 2
-CD_ERR_SORT = -1005
+CD_ERR_SORT, CD_ERR_IO, CD_ERR_FORMAT = -1005, -1006, -1007
 CD_OPT_TRAVERSAL, CD_OPT_QUERIES_PER_WAVE = 0, 1
 
 QUERY_DTYPE = np.dtype([("v", "<f8", (9,)), ("id", "<u4"), ("vidx", "<u4", (3,))])
@@ -34,7 +34,7 @@ class CdStats(C.Structure):
 
 # every symbol include/mi355cd.h declares (tests check the library exports exactly these)
 EXPORTS = [
-    "cd_create", "cd_destroy", "cd_update_vertices", "cd_set_morton_frame", "cd_morton_sort",
+    "cd_load_obj", "cd_free_obj", "cd_create", "cd_destroy", "cd_update_vertices", "cd_set_morton_frame", "cd_morton_sort",
     "cd_build_hierarchy", "cd_refit_boxes", "cd_check_internal", "cd_check_leaves",
     "cd_check_triangle_idx", "cd_find_collisions", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
     "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_num_triangles",
@@ -52,6 +52,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         raise RuntimeError(f"{path} not built: run __graft_entry__.build() (there is no CPU fallback)")
     lib = C.CDLL(path)
     vp, u32p, u64p, i32p, dp = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    lib.cd_load_obj.argtypes = [C.c_char_p, C.POINTER(dp), u32p, C.POINTER(u32p), u32p, C.c_int]
+    lib.cd_free_obj.argtypes = [dp, u32p]
+    lib.cd_free_obj.restype = None
     lib.cd_create.argtypes = [C.POINTER(vp), vp, C.c_uint32, vp, vp, C.c_uint32]
     lib.cd_destroy.argtypes = [vp]
     lib.cd_destroy.restype = None
@@ -80,7 +83,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_find_collisions_queries.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]
     lib.cd_version.restype = C.c_char_p
     for name in EXPORTS:
-        if name not in ("cd_destroy", "cd_version"):
+        if name not in ("cd_destroy", "cd_version", "cd_free_obj"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -257,6 +260,22 @@ class CollisionDetector:
     def find_collisions_queries(self, d_queries_ptr: int, nq: int, cap: int = 1 << 20):
         return self._pairs_call(self.lib.cd_find_collisions_queries, "cd_find_collisions_queries", cap,
                                 C.c_void_p(d_queries_ptr), C.c_uint64(nq))
+
+
+def load_obj(path: str, threads: int = 0):
+    """cd_load_obj through the C ABI -> (verts float64[V,3], vidx uint32[N,3]).  Host only, needs no GPU."""
+    lib = load_library()
+    pv, pf = C.POINTER(C.c_double)(), C.POINTER(C.c_uint32)()
+    nv, nt = C.c_uint32(0), C.c_uint32(0)
+    rc = lib.cd_load_obj(path.encode(), C.byref(pv), C.byref(nv), C.byref(pf), C.byref(nt), threads)
+    if rc != CD_OK:
+        raise CdError("cd_load_obj", rc)
+    try:
+        verts = np.ctypeslib.as_array(pv, shape=(nv.value, 3)).copy()
+        vidx = np.ctypeslib.as_array(pf, shape=(nt.value, 3)).copy()
+    finally:
+        lib.cd_free_obj(pv, pf)
+    return verts, vidx
 
 
 def version() -> str:

@@ -35,7 +35,9 @@ enum {
     CD_ERR_ORDER     = -1002,  /* stage called before the stage it depends on                       */
     CD_ERR_NO_DEVICE = -1003,  /* no HIP device: the library has no CPU fallback                    */
     CD_ERR_INDEX     = -1004,  /* a vertex index >= nv (checked at cd_create)                       */
-    CD_ERR_SORT      = -1005   /* a bounded device-side wait in the sort timed out (results invalid) */
+    CD_ERR_SORT      = -1005,  /* a bounded device-side wait in the sort timed out (results invalid) */
+    CD_ERR_IO        = -1006,  /* file cannot be opened / read                                      */
+    CD_ERR_FORMAT    = -1007   /* a `v` / `f` line is not in the reference's dialect, or no geometry */
 };
 
 /* Morton normalisation frame (morton.h:43-58 hard-codes one data set's bounds). */
@@ -64,6 +66,13 @@ typedef struct cd_stats {
     float ms_descend;          /* shallow pass: memset + descent kernel (part of ms_traverse)          */
     float ms_exact;            /* shallow pass: exact-test kernel        (part of ms_traverse)          */
 } cd_stats;
+
+/* main.cu:64 loadObj (load_obj.h:24-103), host side, multi-threaded: parse `v x y z` (as float, widened to double)
+ * and `f a/ta b/tb c/tc` (1-based) lines in file order.  Unlike the reference it does not compute Morton codes
+ * or sort (cd_morton_sort does, on the GPU) and it returns an error instead of exiting.  The arrays are
+ * malloc'ed; release them with cd_free_obj.  threads <= 0: one per hardware thread.  Needs no GPU. */
+int cd_load_obj(const char *path, double **verts_xyz, uint32_t *nv, uint32_t **vidx3, uint32_t *nt, int threads);
+void cd_free_obj(double *verts_xyz, uint32_t *vidx3);
 
 /* main.cu:78-88  cudaMalloc + cudaMemcpy of vec3f[V], Triangle[N], u64[N], Node[N], Node[N-1].
  * verts_xyz: nv x 3 doubles (vec3f.cuh:14-23).  vidx3: nt x 3 vertex indices (triangle.cuh:9).

@@ -1,0 +1,72 @@
+"""OBJ ingest through the C ABI (cd_load_obj; reference: load_obj.h:24-103).  Host code only:
+runs without a GPU.  Parity target: the reference's parse semantics -- `%f` floats widened to double, 1-based
+`f a/ta b/tb c/tc` faces, file order kept -- independent of the number of parser threads."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import mi355_synth as synth
+import mi355cd
+
+
+def test_generated_obj_round_trip(tmp_path):
+    text = synth.grids_obj_text(48)
+    p = tmp_path / "grids.obj"
+    p.write_text(text)
+    want_v, want_f = synth.parse_obj_text(text)
+    for threads in (1, 3, 8, 0):
+        v, f = mi355cd.load_obj(str(p), threads)
+        assert v.dtype == np.float64 and f.dtype == np.uint32
+        assert np.array_equal(v.view(np.uint64), want_v.view(np.uint64))     # float-parsed, widened: exact bits
+        assert np.array_equal(f, want_f)
+
+
+def test_float_parsing_matches_percent_f(tmp_path):
+    """`%f` reads a float: 0.1 must become float32(0.1) widened, not the double 0.1 (load_obj.h:38,50-52)."""
+    lines = ["# comment", "vt 0.5 0.5", "v 0.1 -0.2 3.0000001", "v 1e-3 2.5E2 -7", "v   4   5\t6  ", "vn 0 0 1",
+             "f 1/1 2/2 3/3", "g group", "f 3/9 2/8 1/7"]
+    p = tmp_path / "a.obj"
+    p.write_text("\n".join(lines))                                           # no trailing newline on purpose
+    v, f = mi355cd.load_obj(str(p), 1)
+    want = np.array([[0.1, -0.2, 3.0000001], [1e-3, 2.5e2, -7], [4, 5, 6]], dtype=np.float32).astype(np.float64)
+    assert np.array_equal(v, want)
+    assert f.tolist() == [[0, 1, 2], [2, 1, 0]]
+
+
+def test_large_file_many_threads_keeps_order(tmp_path):
+    verts, vidx = synth.cloth_pair(150)                                       # 45 602 vertices, 90 000 faces, ~4 MB of text
+    p = tmp_path / "cloth.obj"
+    with open(p, "w") as fh:
+        for v in verts:
+            fh.write("v %.9g %.9g %.9g\n" % (v[0], v[1], v[2]))
+        for t in vidx:
+            fh.write("f %d/1 %d/2 %d/3\n" % (t[0] + 1, t[1] + 1, t[2] + 1))
+    t0 = time.perf_counter(); v1, f1 = mi355cd.load_obj(str(p), 1); t1 = time.perf_counter()
+    v8, f8 = mi355cd.load_obj(str(p), 8); t8 = time.perf_counter()
+    assert np.array_equal(v1, verts) and np.array_equal(f1, vidx)           # %.9g round-trips a float exactly
+    assert np.array_equal(v8, v1) and np.array_equal(f8, f1)
+    print(f"cd_load_obj {os.path.getsize(p) / 1e6:.1f} MB: 1 thread {1e3 * (t1 - t0):.1f} ms, 8 threads {1e3 * (t8 - t1):.1f} ms")
+
+
+@pytest.mark.parametrize("body,code", [
+    ("v 1 2\nf 1/1 1/1 1/1\n", mi355cd.CD_ERR_FORMAT),                  # load_obj.h:57-61 vertex not in wanted format
+    ("v 1 2 3\nf 1 1 1\n", mi355cd.CD_ERR_FORMAT),                      # load_obj.h:69-74 only `a/ta` faces are known
+    ("v 1 2 3\nf 1/1 2/1 1/1\n", mi355cd.CD_ERR_INDEX),                 # load_obj.h:76-79 vertex of face out of bound
+    ("v 1 2 3\nf 0/1 1/1 1/1\n", mi355cd.CD_ERR_INDEX),
+    ("f 1/1 1/1 1/1\nv 1 2 3\n", mi355cd.CD_ERR_INDEX),                 # face before its vertices (load_obj.h:86 NOTE)
+    ("# nothing\n", mi355cd.CD_ERR_FORMAT),
+])
+def test_malformed_files_are_errors_not_exits(tmp_path, body, code):
+    p = tmp_path / "bad.obj"
+    p.write_text(body)
+    with pytest.raises(mi355cd.CdError) as e:
+        mi355cd.load_obj(str(p), 2)
+    assert e.value.rc == code
+
+
+def test_missing_file():
+    with pytest.raises(mi355cd.CdError) as e:
+        mi355cd.load_obj("/nonexistent/dir/x.obj")
+    assert e.value.rc == mi355cd.CD_ERR_IO
