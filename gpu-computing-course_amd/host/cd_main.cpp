@@ -3,7 +3,6 @@
 // print, with the reference's stage lines and result format, every stage one call through the C ABI
 // (include/mi355cd.h).  Usage: cd_main <file.obj> [--frame ref|auto] [--cap N] [--brute]
 #include "mi355cd.h"
-#include "load_obj.h"
 
 #include <chrono>
 #include <cstdio>
@@ -43,14 +42,26 @@ int main(int argc, char **argv)
     }
     const auto t_begin = std::chrono::steady_clock::now();                       // main.cu:55 m_start
 
-    ObjMesh mesh; std::string err;
-    if (load_obj(argv[1], mesh, err)) { std::printf("%s\n", err.c_str()); return 1; }
-    const uint32_t nv = (uint32_t)(mesh.verts.size() / 3), nt = (uint32_t)(mesh.vidx.size() / 3);
+    double *verts = nullptr; uint32_t *vidx = nullptr; uint32_t nv = 0, nt = 0;
+    {   // main.cu:64 loadObj -- multi-threaded parse through the C ABI; Morton codes and the sort moved to the GPU
+        const int rc = cd_load_obj(argv[1], &verts, &nv, &vidx, &nt, 0);
+        if (rc == CD_ERR_IO) { std::printf("* ERROR: loading obj:(%s) file is not good\n", argv[1]); return 1; }                 // load_obj.h:33
+        if (rc == CD_ERR_FORMAT) { std::printf("* ERROR: vertex / FaceMtl not in wanted format in OBJLoader\n"); return 1; }      // load_obj.h:59,71
+        if (rc == CD_ERR_INDEX) { std::printf("* ERROR: Vertex of face out of bound\n"); return 1; }                             // load_obj.h:78
+        CD_CHECK(rc);
+    }
+    float xmin = 1000, ymin = 1000, zmin = 1000;                                                      // load_obj.h:39,53-55
+    for (uint32_t i = 0; i < nv; ++i) {
+        if ((float)verts[3 * i] < xmin) xmin = (float)verts[3 * i];
+        if ((float)verts[3 * i + 1] < ymin) ymin = (float)verts[3 * i + 1];
+        if ((float)verts[3 * i + 2] < zmin) zmin = (float)verts[3 * i + 2];
+    }
     std::printf("\nObj File Loaded:\n- %u vertexes loaded\n- %u triangles loaded\n", nv, nt);       // load_obj.h:117-119
-    std::printf("- xmin=%f, ymin=%f, z=%f\n", mesh.xmin, mesh.ymin, mesh.zmin);                      // load_obj.h:122
+    std::printf("- xmin=%f, ymin=%f, z=%f\n", xmin, ymin, zmin);                                       // load_obj.h:122
 
     cd_ctx *ctx = nullptr;
-    CD_CHECK(cd_create(&ctx, mesh.verts.data(), nv, mesh.vidx.data(), nullptr, nt));                 // main.cu:78-88
+    CD_CHECK(cd_create(&ctx, verts, nv, vidx, nullptr, nt));                                          // main.cu:78-88
+    cd_free_obj(verts, vidx);
     CD_CHECK(cd_set_morton_frame(ctx, frame, nullptr, nullptr));
     cd_stats st;
 
