@@ -422,7 +422,17 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend_packet(QuerySrc src, u
 
 constexpr int EXACT_THREADS = 256;
 constexpr int EXACT_PB = 2048;               // pairs staged in LDS per workgroup before the single global append
+constexpr int EXACT_ITEMS = 4;               // candidates per lane per round (independent loads in flight together)
+constexpr int EXACT_SQ = 256 * (EXACT_ITEMS + 1);   // SAT queue slots per workgroup: < 256 left over + at most 256*ITEMS new per round
 
+struct SatItem { uint32_t q, leaf; };
+
+// k_exact, two stages per workgroup round so that the expensive part runs with full lanes:
+//   stage 1 (one candidate per lane): exact FP64 leaf-AABB test (box.cuh:40-43) -> counts as "tested";
+//            neighbour filter (collision.cuh:38), ID rule (tri_contact.cuh:81).  Cheap, rejects ~90 %.
+//   stage 2: survivors wait on a workgroup-shared LDS queue; whenever >= 256 are queued every thread takes one
+//            and runs the 17-axis SAT (tri_contact.cuh:19-78).  Running the SAT inside stage 1's branch kept
+//            ~8 % of the lanes busy for ~1100 FP64 operations per wave -- it was most of this kernel's time.
 template <bool EXTERNAL>
 __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, const LeafTri *__restrict__ leaf, const double *__restrict__ boxes,
                                                          const double *__restrict__ verts, uint32_t vbase,
@@ -431,11 +441,12 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
 {
     __shared__ unsigned long long pre[NSHARD + 1];      // exclusive prefix of the shard counts
     __shared__ uint2 pbuf[EXACT_PB];
-    __shared__ uint32_t pcount;
+    __shared__ SatItem sq[EXACT_SQ];
+    __shared__ uint32_t pcount, sqcount;
     __shared__ unsigned long long pbase;
     __shared__ uint32_t wtested[EXACT_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    if (tid == 0) pcount = 0;
+    if (tid == 0) { pcount = 0; sqcount = 0; }
     if (tid < 64) {
         unsigned long long c = st->shard[tid].n_candidates;
         const bool over = c > shard_cap;                        // the host will grow the buffer and redo
@@ -450,31 +461,20 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
     const unsigned long long total = pre[NSHARD];
     const unsigned long long stride = (unsigned long long)gridDim.x * EXACT_THREADS;
     uint32_t tested = 0;
-    for (unsigned long long k0 = (unsigned long long)blockIdx.x * EXACT_THREADS; k0 < total; k0 += stride) {
-        const unsigned long long k = k0 + tid;
-        if (k >= total) continue;
-        int lo = 0, hi = NSHARD;                                // largest s with pre[s] <= k
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= k) lo = mid; else hi = mid; }
-        const Candidates c = cand[(size_t)lo * shard_cap + (k - pre[lo])];
-        const uint32_t qi = c.q, lj = c.leaf;
-        const LeafTri lt = leaf[lj];
-        const Box lb = load_box(boxes, (n - 1) + (int)lj);
-        uint32_t q_id, qa, qb, qc; d3 P1, P2, P3; Box qbox;
+
+    // SAT of one queued survivor; hit -> LDS pair staging (or direct append when the staging area is full)
+    auto run_sat = [&](const SatItem it) {
+        const LeafTri lt = leaf[it.leaf];
+        uint32_t q_id; d3 P1, P2, P3;
         if (EXTERNAL) {
-            const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + qi;
+            const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + it.q;
             P1 = d3{q->v[0], q->v[1], q->v[2]}; P2 = d3{q->v[3], q->v[4], q->v[5]}; P3 = d3{q->v[6], q->v[7], q->v[8]};
-            q_id = q->id; qa = q->vidx[0]; qb = q->vidx[1]; qc = q->vidx[2];
-            qbox = box_set(P1, P2, P3);
+            q_id = q->id;
         } else {
-            const LeafTri ql = leaf[qi];
-            q_id = ql.id; qa = ql.v0; qb = ql.v1; qc = ql.v2;
-            qbox = load_box(boxes, (n - 1) + (int)qi);
+            const LeafTri ql = leaf[it.q];
+            q_id = ql.id;
+            P1 = load_vertex(verts, ql.v0); P2 = load_vertex(verts, ql.v1); P3 = load_vertex(verts, ql.v2);
         }
-        if (!box_overlap(qbox, lb)) continue;                                  // collision.cuh:31-32, exact
-        ++tested;
-        if (neighbor_count(qa, qb, qc, lt.v0 + vbase, lt.v1 + vbase, lt.v2 + vbase) >= 1) continue;   // collision.cuh:38
-        if (!(q_id < lt.id)) continue;                                         // tri_contact.cuh:81
-        if (!EXTERNAL) { P1 = load_vertex(verts, qa); P2 = load_vertex(verts, qb); P3 = load_vertex(verts, qc); }
         if (tri_contact(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) {
             const uint32_t slot = atomicAdd(&pcount, 1u);                      // LDS
             if (slot < EXACT_PB) pbuf[slot] = make_uint2(q_id, lt.id);
@@ -483,7 +483,60 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
                 if (cur < cap) { pairs[2 * cur] = q_id; pairs[2 * cur + 1] = lt.id; }
             }
         }
+    };
+
+    for (unsigned long long k0 = (unsigned long long)blockIdx.x * (EXACT_THREADS * EXACT_ITEMS); k0 < total; k0 += stride * EXACT_ITEMS) {   // uniform trip count per workgroup
+        // stage 1 on EXACT_ITEMS candidates per lane at once: their loads are independent and in flight together
+        // (the stage is a chain of two dependent round trips per candidate -- latency, not bandwidth)
+        Candidates c[EXACT_ITEMS]; bool ok[EXACT_ITEMS];
+#pragma unroll
+        for (int j = 0; j < EXACT_ITEMS; ++j) {
+            const unsigned long long k = k0 + (unsigned long long)j * EXACT_THREADS + tid;
+            ok[j] = k < total;
+            c[j] = Candidates{0, 0};
+            if (ok[j]) {
+                int lo = 0, hi = NSHARD;                        // largest s with pre[s] <= k
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= k) lo = mid; else hi = mid; }
+                c[j] = cand[(size_t)lo * shard_cap + (k - pre[lo])];
+            }
+        }
+        LeafTri lt[EXACT_ITEMS]; Box lb[EXACT_ITEMS], qbox[EXACT_ITEMS]; uint32_t q_id[EXACT_ITEMS], qa[EXACT_ITEMS], qb[EXACT_ITEMS], qc[EXACT_ITEMS];
+#pragma unroll
+        for (int j = 0; j < EXACT_ITEMS; ++j) {
+            const uint32_t qi = c[j].q, lj = c[j].leaf;        // (0, 0) for lanes past the end: harmless in-bounds loads
+            lt[j] = leaf[lj];
+            lb[j] = load_box(boxes, (n - 1) + (int)lj);
+            if (EXTERNAL) {
+                const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + qi;
+                q_id[j] = q->id; qa[j] = q->vidx[0]; qb[j] = q->vidx[1]; qc[j] = q->vidx[2];
+                qbox[j] = box_set(d3{q->v[0], q->v[1], q->v[2]}, d3{q->v[3], q->v[4], q->v[5]}, d3{q->v[6], q->v[7], q->v[8]});
+            } else {
+                const LeafTri ql = leaf[qi];
+                q_id[j] = ql.id; qa[j] = ql.v0; qb[j] = ql.v1; qc[j] = ql.v2;
+                qbox[j] = load_box(boxes, (n - 1) + (int)qi);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < EXACT_ITEMS; ++j) {
+            if (ok[j] && box_overlap(qbox[j], lb[j])) {                        // collision.cuh:31-32, exact
+                ++tested;
+                const bool survive = neighbor_count(qa[j], qb[j], qc[j], lt[j].v0 + vbase, lt[j].v1 + vbase, lt[j].v2 + vbase) < 1   // collision.cuh:38
+                                     && q_id[j] < lt[j].id;                    // tri_contact.cuh:81
+                if (survive) sq[atomicAdd(&sqcount, 1u)] = SatItem{c[j].q, c[j].leaf};   // < 256 left over + <= 256*ITEMS new: fits EXACT_SQ
+            }
+        }
+        __syncthreads();
+        while (sqcount >= EXACT_THREADS) {                                     // workgroup-uniform: full batch, every lane runs one SAT
+            const uint32_t base = sqcount - EXACT_THREADS;
+            const SatItem it = sq[base + tid];
+            __syncthreads();
+            if (tid == 0) sqcount = base;
+            run_sat(it);
+            __syncthreads();
+        }
     }
+    __syncthreads();
+    if (tid < sqcount) run_sat(sq[tid]);                                       // final partial batch (< 256)
     const unsigned long long t64 = wave_sum_u64(tested);
     if (lane == 0) wtested[tid >> 6] = (uint32_t)t64;
     __syncthreads();
