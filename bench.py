@@ -111,6 +111,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MI355_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = 0                                                # rehearsal: every rank on cuda:0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
@@ -118,8 +120,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # MI355_DIST_BACKEND=gloo is a single-GPU REHEARSAL of the multi-process flow (ranks share cuda:0, payloads
+    # staged through the host); the measured configuration is always nccl (= RCCL over xGMI), one rank per GPU.
+    backend = os.environ.get("MI355_DIST_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)            # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)        # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     # ---- workload (synthetic, seeded), resident in HBM before the timed region
     if world == 1:
@@ -141,8 +149,10 @@ def main():
         engine.cd.set_option(mi355cd.CD_OPT_QUERIES_PER_WAVE, args.qpw)
     cap = 1 << 22
 
+    comm_device = None if backend == "nccl" else "cpu"
+
     def step():
-        return multi.collide_step(engine, dist, rank, world, cap)
+        return multi.collide_step(engine, dist, rank, world, cap, comm_device)
 
     for _ in range(args.warmup):
         step()
@@ -170,10 +180,11 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        rdev = device if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([tested_total, pairs_found], dtype=torch.int64, device=device)
+        c = torch.tensor([tested_total, pairs_found], dtype=torch.int64, device=rdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         tested_total, pairs_found = int(c[0].item()), int(c[1].item())
 

@@ -67,6 +67,8 @@ struct cd_ctx {
     // host mirrors
     cd_stats stats = {};
     uint32_t sort_flags[8] = {};            // look-back time-out words of the last sort, refreshed by read_state()
+    double root_box_host[6] = {};           // AABB of the whole tree, fetched together with other read-backs
+    bool root_box_valid = false;
 };
 
 namespace {
@@ -206,6 +208,7 @@ int read_state(cd_ctx *c, HostCounters &h, uint32_t *spec_pairs = nullptr, uint6
     TravState hs;
     HIPCHK(hipMemcpyAsync(&hs, c->d_state, sizeof hs, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->root_box_host, c->d_boxes, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
     if (spec_pairs && spec_n) HIPCHK(hipMemcpyAsync(spec_pairs, c->d_pairs, sizeof(uint32_t) * 2 * spec_n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     h = HostCounters{hs.n_pairs, 0, 0, 0, hs.n_deferred, 0, 0};
@@ -419,6 +422,7 @@ int cd_update_vertices(cd_ctx *c, const double *verts_xyz)
     if (!c || !verts_xyz) return CD_ERR_ARG;
     HIPCHK(hipMemcpy(c->d_verts, verts_xyz, sizeof(double) * 3 * (size_t)c->nv, hipMemcpyHostToDevice));
     c->stage = ST_CREATED;
+    c->root_box_valid = false;
     return CD_OK;
 }
 
@@ -478,6 +482,7 @@ int cd_build_hierarchy(cd_ctx *c, uint32_t *parent_wrong_num)
 int cd_refit_boxes(cd_ctx *c)
 {
     if (!c) return CD_ERR_ARG;
+    c->root_box_valid = false;
     if (c->stage < ST_BUILT) return CD_ERR_ORDER;
     int rc = enqueue_refit(c);
     if (rc) return rc;
@@ -516,6 +521,26 @@ int cd_find_collisions(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t 
     return run_traversal(c, nullptr, 0, pairs, cap_pairs, n_pairs);
 }
 
+int cd_build_tree(cd_ctx *c)
+{
+    if (!c) return CD_ERR_ARG;
+    int rc;
+    if ((rc = enqueue_morton_sort(c))) return rc;
+    if ((rc = enqueue_hierarchy(c, false))) return rc;
+    if ((rc = enqueue_refit(c))) return rc;
+    HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->root_box_host, c->d_boxes, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 8; ++i) if (c->sort_flags[i]) return CD_ERR_SORT;
+    c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
+    c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
+    c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);
+    c->stats.ms_refit = elapsed(c, EV_REFIT0, EV_REFIT1);
+    c->root_box_valid = true;
+    c->stage = ST_REFIT;
+    return CD_OK;
+}
+
 int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs)
 {
     if (!c || (cap_pairs && !pairs)) return CD_ERR_ARG;
@@ -531,6 +556,7 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);
     c->stats.ms_refit = elapsed(c, EV_REFIT0, EV_REFIT1);
     c->stage = ST_REFIT;
+    c->root_box_valid = true;
     return rc;
 }
 
@@ -670,6 +696,7 @@ int cd_root_box(cd_ctx *c, double box[6])
 {
     if (!c || !box) return CD_ERR_ARG;
     if (c->stage < ST_REFIT) return CD_ERR_ORDER;
+    if (c->root_box_valid) { memcpy(box, c->root_box_host, sizeof(double) * 6); return CD_OK; }   // came back with an earlier read-back
     // n == 1: the only node is leaf 0 = node 0 as well
     HIPCHK(hipMemcpy(box, c->d_boxes, sizeof(double) * 6, hipMemcpyDeviceToHost));
     return CD_OK;

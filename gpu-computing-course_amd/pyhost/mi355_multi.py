@@ -48,6 +48,14 @@ class HipEngine:
         st = self.cd.stats()
         return pairs, n, st.pairs_tested
 
+    def build_tree(self):
+        """Morton keys, sort, hierarchy, refit -- everything the exchange needs -- without the traversal."""
+        self.cd.build_tree()
+
+    def find_collisions(self, cap):
+        pairs, n, rc = self.cd.find_collisions(cap)
+        return pairs, n, self.cd.stats().pairs_tested
+
     def root_box(self):
         return self.cd.root_box()
 
@@ -77,19 +85,26 @@ class HipEngine:
         self.cd.close()
 
 
-def collide_step(engine, dist, rank, world, cap=1 << 22):
+def collide_step(engine, dist, rank, world, cap=1 << 22, comm_device=None):
     """One multi-GPU step.  Returns (pairs ndarray[k,2] found by THIS rank, pairs_tested by this rank,
-    info dict).  `dist` is torch.distributed (nccl == RCCL on GPUs, gloo in CPU tests)."""
+    info dict).  `dist` is torch.distributed (nccl == RCCL on GPUs, gloo in CPU tests).
+    comm_device: where the collectives' tensors live; default = the engine's device (RCCL moves device buffers
+    directly over xGMI).  A rehearsal with the gloo backend passes "cpu": payloads are staged through the host."""
     import torch
-    local_pairs, n_local, tested = engine.self_collide(cap)
-    if n_local > cap:
-        raise RuntimeError(f"pair capacity {cap} too small for {n_local} local pairs")
-    info = {"local_pairs": int(n_local), "cross_pairs": 0, "sent_queries": 0, "recv_queries": 0, "peers": []}
+    info = {"local_pairs": 0, "cross_pairs": 0, "sent_queries": 0, "recv_queries": 0, "peers": []}
     if world == 1:
+        local_pairs, n_local, tested = engine.self_collide(cap)
+        if n_local > cap:
+            raise RuntimeError(f"pair capacity {cap} too small for {n_local} local pairs")
+        info["local_pairs"] = int(n_local)
         return local_pairs, int(tested), info
 
+    # 1a. the local tree (no traversal yet: the exchange below overlaps with it)
+    engine.build_tree()
+
     # 2. all-gather of root AABBs
-    dev = engine.empty_queries().device
+    edev = engine.empty_queries().device
+    dev = edev if comm_device is None else torch.device(comm_device)
     mine = torch.from_numpy(np.ascontiguousarray(engine.root_box())).to(dev)
     roots = torch.empty(world * 6, dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(roots, mine)
@@ -97,17 +112,28 @@ def collide_step(engine, dist, rank, world, cap=1 << 22):
     peers = [s for s in range(world) if s != rank and boxes_overlap(roots[rank], roots[s])]
     info["peers"] = peers
 
-    # 3. query exchange: counts first, then the records (variable-size all-to-all)
+    # 3. query exchange: counts first, then the records (variable-size all-to-all), started asynchronously
     send = [engine.pack_queries(roots[s]) if s in peers else engine.empty_queries() for s in range(world)]
     send_counts = torch.tensor([t.numel() for t in send], dtype=torch.int64, device=dev)
     recv_counts = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(recv_counts, send_counts)
     recv_counts = recv_counts.cpu().tolist()
-    sendbuf = torch.cat(send) if send else engine.empty_queries()
-    recvbuf = engine.empty_queries(int(sum(recv_counts)))
-    dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=recv_counts, input_split_sizes=[t.numel() for t in send])
+    sendbuf = (torch.cat(send) if send else engine.empty_queries()).to(dev)
+    recvbuf = torch.empty(int(sum(recv_counts)), dtype=torch.uint8, device=dev)
+    if sendbuf.is_cuda:
+        torch.cuda.synchronize()                     # pack_queries wrote sendbuf on the library's stream (already synchronised); be explicit
+    work = dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=recv_counts, input_split_sizes=[t.numel() for t in send],
+                                  async_op=True)
     info["sent_queries"] = int(sendbuf.numel() // QUERY_BYTES)
     info["recv_queries"] = int(recvbuf.numel() // QUERY_BYTES)
+
+    # 1b. local traversal while the records travel (RCCL runs on its own stream, the library on its own)
+    local_pairs, n_local, tested = engine.find_collisions(cap)
+    if n_local > cap:
+        raise RuntimeError(f"pair capacity {cap} too small for {n_local} local pairs")
+    info["local_pairs"] = int(n_local)
+    work.wait()
+    recvbuf = recvbuf.to(edev)
 
     # 4. received queries against the local tree
     cross_pairs, n_cross, tested_cross = engine.find_collisions_queries(recvbuf, cap)

@@ -36,7 +36,7 @@ class CdStats(C.Structure):
 EXPORTS = [
     "cd_load_obj", "cd_free_obj", "cd_create", "cd_destroy", "cd_update_vertices", "cd_set_morton_frame", "cd_morton_sort",
     "cd_build_hierarchy", "cd_refit_boxes", "cd_check_internal", "cd_check_leaves",
-    "cd_check_triangle_idx", "cd_find_collisions", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
+    "cd_check_triangle_idx", "cd_find_collisions", "cd_build_tree", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
     "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_num_triangles",
     "cd_set_option", "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
 ]
@@ -67,6 +67,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_check_leaves.argtypes = [vp, vp]
     lib.cd_check_triangle_idx.argtypes = [vp, C.c_uint32, u32p]
     lib.cd_find_collisions.argtypes = [vp, vp, C.c_uint64, u64p]
+    lib.cd_build_tree.argtypes = [vp]
     lib.cd_self_collide.argtypes = [vp, vp, C.c_uint64, u64p]
     lib.cd_sorted_pairs.argtypes = [vp, vp, C.c_uint64, u64p]
     lib.cd_collision_triangles.argtypes = [vp, vp, C.c_uint64, u64p]
@@ -158,6 +159,9 @@ class CollisionDetector:
         w = C.c_uint32(0)
         self._chk("cd_build_hierarchy", self.lib.cd_build_hierarchy(self._ctx, C.byref(w)))
         return w.value
+
+    def build_tree(self):
+        self._chk("cd_build_tree", self.lib.cd_build_tree(self._ctx))
 
     def refit_boxes(self):
         self._chk("cd_refit_boxes", self.lib.cd_refit_boxes(self._ctx))

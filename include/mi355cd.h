@@ -113,6 +113,10 @@ int cd_check_triangle_idx(cd_ctx *ctx, uint32_t maxv, uint32_t *out);
  * (the reference writes past its 500-pair buffer instead, main.cu:81). */
 int cd_find_collisions(cd_ctx *ctx, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs);
 
+/* cd_morton_sort -> cd_build_hierarchy -> cd_refit_boxes queued back to back, one host synchronisation: the tree
+ * without the traversal (the multi-GPU step exchanges query leaves while the local traversal runs). */
+int cd_build_tree(cd_ctx *ctx);
+
 /* Fused convenience call: cd_morton_sort -> cd_build_hierarchy -> cd_refit_boxes -> cd_find_collisions
  * queued back to back on the context stream with a single host synchronisation at the end. */
 int cd_self_collide(cd_ctx *ctx, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs);

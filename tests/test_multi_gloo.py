@@ -34,6 +34,12 @@ class OracleEngine:
         self.tree = oracle.pipeline(self.verts, self.vidx, self.ids, off=self.off, span=self.span)
         return self.tree["pairs"], self.tree["stats"].n_pairs, self.tree["stats"].pairs_tested
 
+    def build_tree(self):
+        self.tree = oracle.pipeline(self.verts, self.vidx, self.ids, off=self.off, span=self.span)
+
+    def find_collisions(self, cap):
+        return self.tree["pairs"], self.tree["stats"].n_pairs, self.tree["stats"].pairs_tested
+
     def root_box(self):
         return self.tree["boxes"][0].copy()
 
