@@ -304,4 +304,47 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
     }
 }
 
+
+// ====================================================================================================
+// Half-key sort + fix-up.  The onesweep passes are latency-bound at 1 M keys (~25 us each), so the cheapest pass
+// is the one not run: sort (stably) by the HIGH 32 bits only -- 4 passes -- and repair the order inside every run
+// of equal high halves with a stable insertion sort on the full key.  The result is exactly the stable sort by
+// the full 64-bit key (ties of the full key keep input order in both), so keys / permutation stay bit-identical
+// to the 8-pass sort.  Morton codes of distinct triangles rarely share their top 32 bits (~10.7 bits per axis),
+// so runs are 1-3 long; a run longer than FIX_MAX sets `overflow` and the host redoes the sort with all 8 passes
+// (and keeps doing so for that context).
+// ====================================================================================================
+constexpr int FIX_MAX = 16;
+
+__global__ __launch_bounds__(256) void k_sort_fixup(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t n, uint32_t *__restrict__ overflow)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k0 = keys[i];
+    const uint32_t h = (uint32_t)(k0 >> 32);
+    if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == h) return;            // not the first key of its run
+    if (i + 1 >= n || (uint32_t)(keys[i + 1] >> 32) != h) return;       // run of one: already in place
+    uint64_t k[FIX_MAX]; uint32_t v[FIX_MAX];
+    int len = 0;
+#pragma unroll
+    for (int u = 0; u < FIX_MAX; ++u) {
+        const bool in = (i + u < n) && (len == u) && (uint32_t)(keys[i + u] >> 32) == h;
+        if (in) { k[u] = keys[i + u]; v[u] = vals[i + u]; len = u + 1; } else { k[u] = ~0ull; v[u] = 0; }
+    }
+    if (len == FIX_MAX && i + FIX_MAX < n && (uint32_t)(keys[i + FIX_MAX] >> 32) == h) { atomicExch(overflow, 1u); return; }
+    // stable insertion sort of k[0..len) by the full key, fully unrolled (registers, no scratch)
+#pragma unroll
+    for (int a = 1; a < FIX_MAX; ++a) {
+#pragma unroll
+        for (int b = a; b > 0; --b) {
+            const bool sw = (b < len) && (k[b] < k[b - 1]);             // strict: equal keys never pass each other
+            const uint64_t ka = sw ? k[b - 1] : k[b], kb = sw ? k[b] : k[b - 1];
+            const uint32_t va = sw ? v[b - 1] : v[b], vb = sw ? v[b] : v[b - 1];
+            k[b] = ka; k[b - 1] = kb; v[b] = va; v[b - 1] = vb;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < FIX_MAX; ++u) if (u < len) { keys[i + u] = k[u]; vals[i + u] = v[u]; }
+}
+
 }  // namespace cd

@@ -66,7 +66,8 @@ struct cd_ctx {
     uint64_t last_pairs_on_device = 0;      // pairs of the last traversal that are resident in d_pairs
     // host mirrors
     cd_stats stats = {};
-    uint32_t sort_flags[8] = {};            // look-back time-out words of the last sort, refreshed by read_state()
+    uint32_t sort_flags[9] = {};            // [0..7] look-back time-out words of the last sort, [8] half-key fix-up overflow; refreshed by read_state()
+    bool sort_full = false;                 // true: all 8 digit passes (forced, or after a fix-up overflow on this context)
     double root_box_host[6] = {};           // AABB of the whole tree, fetched together with other read-backs
     bool root_box_valid = false;
 };
@@ -118,14 +119,18 @@ int enqueue_morton_sort(cd_ctx *c)
     HIPCHK(hipMemsetAsync(c->d_os, 0, c->os_bytes, s));
     k_os_hist<<<c->ntiles < 512 ? c->ntiles : 512, SORT_THREADS, 0, s>>>(c->d_keys[0], n, c->ntiles, c->d_os_hist);
     k_os_scan<<<1, RADIX, 0, s>>>(c->d_os_hist);
+    // half-key mode: 4 passes on the high 32 bits + a fix-up of equal-high-half runs (cd_sort.h); full mode: 8 passes
+    const int first_digit = c->sort_full ? 0 : 4;
     int cur = 0;
-    for (int pass = 0; pass < 8; ++pass) {
+    for (int pass = first_digit; pass < 8; ++pass) {
         k_os_pass<<<c->ntiles, OS_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1], n, pass * RADIX_BITS,
                                                     c->d_os_hist + pass * RADIX, c->d_os_look + (size_t)pass * c->ntiles * RADIX,
-                                                    c->d_os_ticket + pass, pass == 0);
+                                                    c->d_os_ticket + pass, pass == first_digit);
         cur ^= 1;
     }
-    // 8 passes: sorted data is back in buffer 0
+    // an even number of passes: sorted data is back in buffer 0
+    if (!c->sort_full) k_sort_fixup<<<cdiv(n, 256), 256, 0, s>>>(c->d_keys[0], c->d_perm[0], n, c->d_os_ticket + 16);
+    c->stats.sort_passes = c->sort_full ? 8 : 4;
     HIPCHK(hipEventRecord(c->ev[EV_SORT1], s));
     HIPCHK(hipGetLastError());
     return 0;
@@ -207,7 +212,7 @@ int read_state(cd_ctx *c, HostCounters &h, uint32_t *spec_pairs = nullptr, uint6
     static_assert(sizeof(TravState) <= 16384, "state read-back size");
     TravState hs;
     HIPCHK(hipMemcpyAsync(&hs, c->d_state, sizeof hs, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));   // words 8..16
     HIPCHK(hipMemcpyAsync(c->root_box_host, c->d_boxes, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
     if (spec_pairs && spec_n) HIPCHK(hipMemcpyAsync(spec_pairs, c->d_pairs, sizeof(uint32_t) * 2 * spec_n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -375,11 +380,11 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     if (ids) ALLOC(c->d_ids, sizeof(uint32_t) * n);
     for (int i = 0; i < 2; ++i) { ALLOC(c->d_keys[i], sizeof(uint64_t) * n); ALLOC(c->d_perm[i], sizeof(uint32_t) * n); }
     ALLOC(c->d_counts, sizeof(uint32_t) * RADIX * c->ntiles);
-    c->os_bytes = sizeof(uint32_t) * 8 * RADIX + 64 + sizeof(unsigned long long) * 8 * (size_t)c->ntiles * RADIX;
+    c->os_bytes = sizeof(uint32_t) * 8 * RADIX + 128 + sizeof(unsigned long long) * 8 * (size_t)c->ntiles * RADIX;   // hist | 8 tickets, 8 time-out flags, fix-up flag, pad | granules
     ALLOC(c->d_os, c->os_bytes);
     c->d_os_hist = reinterpret_cast<uint32_t *>(c->d_os);
     c->d_os_ticket = c->d_os_hist + 8 * RADIX;
-    c->d_os_look = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_os) + sizeof(uint32_t) * 8 * RADIX + 64);
+    c->d_os_look = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_os) + sizeof(uint32_t) * 8 * RADIX + 128);
     ALLOC(c->d_frame, sizeof(double) * 6);
     ALLOC(c->d_partial, sizeof(double) * 6 * BOUNDS_BLOCKS);
     ALLOC(c->d_leaf, sizeof(LeafTri) * n);
@@ -443,13 +448,18 @@ int cd_set_morton_frame(cd_ctx *c, int mode, const double offset[3], const doubl
 }
 
 // the onesweep look-back spins are bounded; a timeout sets one of the words d_os_ticket[8..15]
+constexpr int SORT_REDO = 77;                   // internal: the half-key fix-up overflowed, redo with all 8 passes
+static int judge_sort_flags(cd_ctx *c)
+{
+    for (int i = 0; i < 8; ++i) if (c->sort_flags[i]) return CD_ERR_SORT;
+    if (c->sort_flags[8]) { c->sort_full = true; return SORT_REDO; }
+    return CD_OK;
+}
 static int check_sort_flags(cd_ctx *c)
 {
-    uint32_t f[8] = {};
-    HIPCHK(hipMemcpyAsync(f, c->d_os_ticket + 8, sizeof f, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 8; ++i) if (f[i]) return CD_ERR_SORT;
-    return CD_OK;
+    return judge_sort_flags(c);
 }
 
 int cd_morton_sort(cd_ctx *c)
@@ -457,7 +467,9 @@ int cd_morton_sort(cd_ctx *c)
     if (!c) return CD_ERR_ARG;
     int rc = enqueue_morton_sort(c);
     if (rc) return rc;
-    if ((rc = check_sort_flags(c))) return rc;
+    rc = check_sort_flags(c);
+    if (rc == SORT_REDO) { if ((rc = enqueue_morton_sort(c))) return rc; rc = check_sort_flags(c); }
+    if (rc) return rc;
     c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
     c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
     c->stage = ST_SORTED;
@@ -528,10 +540,12 @@ int cd_build_tree(cd_ctx *c)
     if ((rc = enqueue_morton_sort(c))) return rc;
     if ((rc = enqueue_hierarchy(c, false))) return rc;
     if ((rc = enqueue_refit(c))) return rc;
-    HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));   // words 8..16
     HIPCHK(hipMemcpyAsync(c->root_box_host, c->d_boxes, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 8; ++i) if (c->sort_flags[i]) return CD_ERR_SORT;
+    rc = judge_sort_flags(c);
+    if (rc == SORT_REDO) return cd_build_tree(c);                    // once: sort_full is now set
+    if (rc) return rc;
     c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
     c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
     c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);
@@ -550,7 +564,9 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     if ((rc = enqueue_refit(c))) return rc;
     rc = run_traversal(c, nullptr, 0, pairs, cap_pairs, n_pairs);     // synchronises
     if (rc < 0) return rc;
-    for (int i = 0; i < 8; ++i) if (c->sort_flags[i]) return CD_ERR_SORT;    // fetched with the traversal counters
+    { const int rs = judge_sort_flags(c);                                   // flags came back with the traversal counters
+      if (rs == SORT_REDO) return cd_self_collide(c, pairs, cap_pairs, n_pairs);   // once: sort_full is now set
+      if (rs) return rs; }
     c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
     c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
     c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);
@@ -684,6 +700,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (!c) return CD_ERR_ARG;
     if (key == CD_OPT_TRAVERSAL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
     if (key == CD_OPT_QUERIES_PER_WAVE) { if (value < 64 || value > (1 << 20) || value % 64) return CD_ERR_ARG; c->queries_per_wave = (uint32_t)value; return CD_OK; }
+    if (key == CD_OPT_SORT_FULL) { c->sort_full = value != 0; return CD_OK; }
     if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
     if (key == 102) { c->dbg_halfload = (uint32_t)value; return CD_OK; }
     if (key == 101) { if (value < 1 || value > 65535) return CD_ERR_ARG; c->exact_blocks = (int)value; return CD_OK; }

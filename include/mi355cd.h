@@ -65,6 +65,8 @@ typedef struct cd_stats {
     uint64_t candidates;       /* (query, leaf) candidates the fp32 descent handed to the exact kernel */
     float ms_descend;          /* shallow pass: memset + descent kernel (part of ms_traverse)          */
     float ms_exact;            /* shallow pass: exact-test kernel        (part of ms_traverse)          */
+    uint32_t sort_passes;      /* digit passes of the last sort: 4 (half-key + fix-up) or 8              */
+    uint32_t pad_;
 } cd_stats;
 
 /* main.cu:64 loadObj (load_obj.h:24-103), host side, multi-threaded: parse `v x y z` (as float, widened to double)
@@ -150,6 +152,9 @@ enum {
     CD_OPT_TRAVERSAL        = 0,   /* 0: lane-private FP64 descent, exact test inline (the reference's shape,        */
                                    /*    collision.cuh:19-71); 1 (default): fp32 conservative descent with a          */
                                    /*    wavefront-shared LDS candidate queue + a second kernel for the exact tests   */
+    CD_OPT_SORT_FULL        = 2,   /* 0 (default): sort the high 32 key bits (4 passes) + stable fix-up of equal-high-half   */
+                                   /*    runs; falls back to 1 by itself when a run is too long.  1: all 8 digit passes.    */
+                                   /*    Both give the identical stable order by the full 64-bit key.                        */
     CD_OPT_QUERIES_PER_WAVE = 1    /* variant 1: queries one wave works through with dynamic lane refill (x64)         */
 };
 int cd_set_option(cd_ctx *ctx, int key, int64_t value);

@@ -433,3 +433,35 @@ def test_eight_million_soup_variants_agree():
     p = (sets[0][:: max(1, len(sets[0]) // 2000)])
     pr = np.stack([(p >> np.uint64(32)).astype(np.uint32), (p & np.uint64(0xffffffff)).astype(np.uint32)], axis=1)
     assert oracle.tri_contact_batch(verts, vidx, pr).all()
+
+
+def test_half_key_sort_equals_full_sort_and_falls_back():
+    """CD_OPT_SORT_FULL: the default (4 passes on the high 32 key bits + stable fix-up of equal-high-half runs) must give
+    the same keys AND permutation as all 8 passes (= the oracle's stable sort); a run of equal high halves longer than
+    the fix-up handles makes the library redo the sort with 8 passes by itself."""
+    verts, vidx = synth.soup(200_000, 0.01, 31)
+    r_keys, r_perm = oracle.sort_by_key(oracle.centroid_morton(verts, vidx))
+    for full in (0, 1):
+        with mi355cd.CollisionDetector(verts, vidx) as cd:
+            cd.set_option(mi355cd.CD_OPT_SORT_FULL, full)
+            cd.morton_sort()
+            keys, perm = cd.export_keys()
+            assert cd.stats().sort_passes == (8 if full else 4)
+            assert np.array_equal(keys, r_keys) and np.array_equal(perm, r_perm)
+    # keys that differ ONLY in their low 32 bits: one long run of equal high halves (200 triangles inside one coarse cell)
+    rng = np.random.default_rng(5)
+    c = np.array([1.0, 0.0, 0.5]) + (rng.random((200, 1, 3)) - 0.5) * 1e-5
+    v2 = (c + (rng.random((200, 3, 3)) - 0.5) * 1e-6).reshape(-1, 3)
+    t2 = np.arange(600, dtype=np.uint32).reshape(200, 3)
+    k2 = oracle.centroid_morton(v2, t2)
+    assert len(np.unique(k2 >> np.uint64(32))) < 10 and len(np.unique(k2)) > 100
+    with mi355cd.CollisionDetector(v2, t2) as cd:
+        pairs, n, rc = cd.self_collide()
+        keys, perm = cd.export_keys()
+        assert cd.stats().sort_passes == 8                                  # fell back
+        rk, rp = oracle.sort_by_key(k2)
+        assert np.array_equal(keys, rk) and np.array_equal(perm, rp)
+        r = oracle.pipeline(v2, t2)
+        assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+        cd.self_collide()
+        assert cd.stats().sort_passes == 8                                  # and stays in full mode for this context
