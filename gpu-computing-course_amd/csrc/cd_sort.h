@@ -157,7 +157,7 @@ constexpr unsigned long long OS_PREFIX = 2ull << 62;   // value = inclusive pref
 constexpr unsigned long long OS_VALUE_MASK = (1ull << 62) - 1;
 
 __global__ __launch_bounds__(SORT_THREADS) void k_os_hist(const uint64_t *__restrict__ keys, uint32_t n, uint32_t ntiles,
-                                                          uint32_t *__restrict__ ghist /* [8][256] */)
+                                                          uint32_t *__restrict__ ghist /* [8][256] */, int first_digit = 0)
 {
     __shared__ uint32_t h[8][RADIX];
     for (int i = threadIdx.x; i < 8 * RADIX; i += SORT_THREADS) (&h[0][0])[i] = 0;
@@ -169,8 +169,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_hist(const uint64_t *__rest
             const uint32_t i = base + it * SORT_THREADS + threadIdx.x;
             if (i < n) {
                 const uint64_t k = keys[i];
+                if (first_digit == 0) {
 #pragma unroll
-                for (int p = 0; p < 8; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255], 1u);
+                    for (int p = 0; p < 4; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255], 1u);
+                }
+#pragma unroll
+                for (int p = 4; p < 8; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255], 1u);
             }
         }
     }

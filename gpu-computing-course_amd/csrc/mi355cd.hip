@@ -47,7 +47,7 @@ struct cd_ctx {
     uint64_t *d_keys[2] = {nullptr, nullptr}; uint32_t *d_perm[2] = {nullptr, nullptr};
     uint32_t *d_counts = nullptr; uint32_t ntiles = 0;
     // onesweep state: one allocation = [8][256] u32 histograms | 8 u32 tickets (padded) | [8][ntiles][256] u64 granules
-    void *d_os = nullptr; size_t os_bytes = 0; uint32_t *d_os_hist = nullptr; uint32_t *d_os_ticket = nullptr; unsigned long long *d_os_look = nullptr;
+    void *d_os = nullptr; size_t os_bytes = 0, zero_bytes = 0; uint32_t *d_os_hist = nullptr; uint32_t *d_os_ticket = nullptr; unsigned long long *d_os_look = nullptr;
     double *d_frame = nullptr, *d_partial = nullptr;
     // tree
     LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; double *d_seg = nullptr; uint32_t nbp2 = 1; int32_t *d_cross = nullptr; uint32_t cross_cap = 0;   // segment tree over leaf boxes: nbp2*512 heap nodes
@@ -67,6 +67,8 @@ struct cd_ctx {
     // host mirrors
     cd_stats stats = {};
     uint32_t sort_flags[9] = {};            // [0..7] look-back time-out words of the last sort, [8] half-key fix-up overflow; refreshed by read_state()
+    bool stage_events = true;               // CD_OPT_STAGE_TIMING
+    bool prezeroed = false;                 // fused path: the scratch block was zeroed by one memset at pipeline start
     bool sort_full = false;                 // true: all 8 digit passes (forced, or after a fix-up overflow on this context)
     double root_box_host[6] = {};           // AABB of the whole tree, fetched together with other read-backs
     bool root_box_valid = false;
@@ -80,7 +82,7 @@ void free_all(cd_ctx *c)
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_cross); hipFree(c->d_boxes);
-    hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_small); hipFree(c->d_state);
+    hipFree(c->d_bounded); hipFree(c->d_recs32); 
     hipFree(c->d_pairs); hipFree(c->d_defer); hipFree(c->d_deep); hipFree(c->d_cand);
     for (int i = 0; i < 2; ++i) { hipFree(c->pp_keys[i]); hipFree(c->pp_vals[i]); }
     hipFree(c->pp_flags); hipFree(c->pp_os);
@@ -103,21 +105,37 @@ int ensure_pairs(cd_ctx *c, uint64_t cap)
 
 float elapsed(cd_ctx *c, int a, int b) { float ms = 0.f; hipEventElapsedTime(&ms, c->ev[a], c->ev[b]); return ms; }
 
+// Per-stage events cost a few microseconds of idle GPU each (two per stage boundary).  With CD_OPT_STAGE_TIMING 0
+// only the events the roofline needs are recorded: pipeline start, descent start / end, pipeline end.
+inline hipError_t evrec(cd_ctx *c, int idx)
+{
+    if (!c->stage_events && !(idx == EV_MORTON0 || idx == EV_TRAV0 || idx == EV_DESC1 || idx == EV_TRAV1)) return hipSuccess;
+    return hipEventRecord(c->ev[idx], c->stream);
+}
+
+struct Prezeroed {                          // scope of a fused call: stage memsets are replaced by the one in enqueue_morton_sort
+    cd_ctx *c;
+    explicit Prezeroed(cd_ctx *c_) : c(c_) { c->prezeroed = true; }
+    void done() { c->prezeroed = false; }
+    ~Prezeroed() { c->prezeroed = false; }
+};
+
 // ---- stage enqueuers (no host synchronisation inside) -------------------------------------------
 int enqueue_morton_sort(cd_ctx *c)
 {
     const uint32_t n = c->nt;
     hipStream_t s = c->stream;
-    HIPCHK(hipEventRecord(c->ev[EV_MORTON0], s));
+    HIPCHK(evrec(c, EV_MORTON0));
     if (c->frame_mode == CD_FRAME_AUTO) {
         k_centroid_bounds<<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_partial);
         k_frame_from_bounds<<<1, 64, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->d_frame);
     }
     k_morton<<<cdiv(n, 256), 256, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_frame, c->d_keys[0]);
-    HIPCHK(hipEventRecord(c->ev[EV_MORTON1], s));
+    HIPCHK(evrec(c, EV_MORTON1));
     // onesweep: one histogram read, then one pass over the data per digit (see cd_sort.h)
-    HIPCHK(hipMemsetAsync(c->d_os, 0, c->os_bytes, s));
-    k_os_hist<<<c->ntiles < 512 ? c->ntiles : 512, SORT_THREADS, 0, s>>>(c->d_keys[0], n, c->ntiles, c->d_os_hist);
+    // fused pipeline: the sort scratch, the small counters and the traversal state are one block, zeroed once here
+    HIPCHK(hipMemsetAsync(c->d_os, 0, c->prezeroed ? c->zero_bytes : c->os_bytes, s));
+    k_os_hist<<<c->ntiles < 512 ? c->ntiles : 512, SORT_THREADS, 0, s>>>(c->d_keys[0], n, c->ntiles, c->d_os_hist, c->sort_full ? 0 : 4);
     k_os_scan<<<1, RADIX, 0, s>>>(c->d_os_hist);
     // half-key mode: 4 passes on the high 32 bits + a fix-up of equal-high-half runs (cd_sort.h); full mode: 8 passes
     const int first_digit = c->sort_full ? 0 : 4;
@@ -131,7 +149,7 @@ int enqueue_morton_sort(cd_ctx *c)
     // an even number of passes: sorted data is back in buffer 0
     if (!c->sort_full) k_sort_fixup<<<cdiv(n, 256), 256, 0, s>>>(c->d_keys[0], c->d_perm[0], n, c->d_os_ticket + 16);
     c->stats.sort_passes = c->sort_full ? 8 : 4;
-    HIPCHK(hipEventRecord(c->ev[EV_SORT1], s));
+    HIPCHK(evrec(c, EV_SORT1));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -140,12 +158,12 @@ int enqueue_hierarchy(cd_ctx *c, bool poison_boxes)
 {
     const uint32_t n = c->nt;
     hipStream_t s = c->stream;
-    HIPCHK(hipEventRecord(c->ev[EV_HIER0], s));
-    HIPCHK(hipMemsetAsync(c->d_small, 0, 16 * sizeof(uint32_t), s));
+    HIPCHK(evrec(c, EV_HIER0));
+    if (!c->prezeroed) HIPCHK(hipMemsetAsync(c->d_small, 0, 16 * sizeof(uint32_t), s));
     k_fill_leaves<<<cdiv(n, 256), 256, 0, s>>>(c->d_perm[0], c->d_vidx, c->d_ids, n, c->d_leaf, c->d_parent, c->d_bounded, poison_boxes ? c->d_boxes : nullptr);
     if (n > 1)
         k_hierarchy<<<cdiv(n - 1, 256), 256, 0, s>>>(c->d_keys[0], (int)n, c->d_meta, c->d_parent, c->d_small);
-    HIPCHK(hipEventRecord(c->ev[EV_HIER1], s));
+    HIPCHK(evrec(c, EV_HIER1));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -154,19 +172,19 @@ int enqueue_refit(cd_ctx *c)
 {
     const uint32_t n = c->nt;
     hipStream_t s = c->stream;
-    HIPCHK(hipEventRecord(c->ev[EV_REFIT0], s));
+    HIPCHK(evrec(c, EV_REFIT0));
     const int nblocks = (int)cdiv(n, REFIT_BLK);
     // cross-node lists: 64 shards x cross_cap entries (a shard takes the blocks b with b % 64 == shard, each
     // contributing at most 512 nodes); their 64 counters in d_small[16..79]
     int32_t *cross_list = c->d_cross;
     uint32_t *cross_count = c->d_small + 16;
-    HIPCHK(hipMemsetAsync(cross_count, 0, 64 * sizeof(uint32_t), s));
+    if (!c->prezeroed) HIPCHK(hipMemsetAsync(cross_count, 0, 64 * sizeof(uint32_t), s));
     k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded, c->d_recs32, c->d_seg, (int)c->nbp2,
                                                    cross_list, cross_count, c->cross_cap);
     k_refit_seg_top<<<1, 1024, 0, s>>>(c->d_seg, (int)c->nbp2, nblocks);
     if (n > 1) k_refit_seg_cross<<<1024, 256, 0, s>>>((int)n, c->d_meta, c->d_seg, (int)c->nbp2, c->d_boxes, c->d_bounded, c->d_recs32,
                                                       c->d_cross, cross_count, c->cross_cap);
-    HIPCHK(hipEventRecord(c->ev[EV_REFIT1], s));
+    HIPCHK(evrec(c, EV_REFIT1));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -181,7 +199,7 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
     if (c->trav_variant == 2 && !DEEP) {
         const uint64_t shard_cap = c->cand_cap / NSHARD;
         k_descend_packet<EXTERNAL><<<cdiv(items, 64 * WQ_WAVES), TRAV_THREADS, c->dbg_lds_pad, s>>>(src, items, n, c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap);
-        hipEventRecord(c->ev[EV_DESC1], s);
+        evrec(c, EV_DESC1);
         k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, c->d_cand, shard_cap, c->d_pairs, cap_pairs, c->d_state);
     } else if (c->trav_variant == 0) {
         k_traverse<EXTERNAL, DEEP><<<cdiv(items, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, items, n, c->d_meta, c->d_boxes, c->d_leaf, c->d_verts, c->d_pairs, cap_pairs, c->d_state,
@@ -197,7 +215,7 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
         else
             k_descend<EXTERNAL, DEEP, true><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw | (c->dbg_halfload ? 0x80000000u : 0u), c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
                                                                            DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr);
-        if (!DEEP) hipEventRecord(c->ev[EV_DESC1], s);
+        if (!DEEP) evrec(c, EV_DESC1);
         k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, c->d_cand, shard_cap, c->d_pairs, cap_pairs, c->d_state);
     }
 }
@@ -253,13 +271,13 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     for (int attempt = 0; attempt < 8 && !done; ++attempt) {
         launches = 0; deep_ms = 0.f;
         QuerySrc src{c->d_leaf, c->d_boxes, d_ext, nullptr};
-        HIPCHK(hipEventRecord(c->ev[EV_TRAV0], s));
-        HIPCHK(hipMemsetAsync(c->d_state, 0, sizeof(TravState), s));
+        HIPCHK(evrec(c, EV_TRAV0));
+        if (!(c->prezeroed && attempt == 0)) HIPCHK(hipMemsetAsync(c->d_state, 0, sizeof(TravState), s));
         if (nq > 0) {
             if (external) launch_pass<true, false>(c, src, nq, cap_pairs); else launch_pass<false, false>(c, src, nq, cap_pairs);
             launches += per_pass;
         }
-        HIPCHK(hipEventRecord(c->ev[EV_TRAV1], s));      // device time of the kernels only: recorded before the read-back
+        HIPCHK(evrec(c, EV_TRAV1));      // device time of the kernels only: recorded before the read-back
         const uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
         if ((rc = read_state(c, h, pairs, spec_n))) return rc;
         spec_valid = spec_n;
@@ -278,7 +296,7 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
                 HIPCHK(hipMalloc(&c->d_deep, sizeof(int32_t) * (size_t)DEEP_STACK * deep_lanes));
                 c->deep_items = deep_lanes;
             }
-            HIPCHK(hipEventRecord(c->ev[EV_DEEP0], s));
+            HIPCHK(evrec(c, EV_DEEP0));
             HIPCHK(hipMemsetAsync(&c->d_state->n_deferred, 0, sizeof(uint32_t), s));
             // candidate shards restart from 0: the shallow pass's candidates have all been consumed by k_exact
             for (int i = 0; i < NSHARD; ++i) { /* one memset per shard would be 64 calls: clear them with a 2-D memset */ }
@@ -286,12 +304,12 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
             src.list = c->d_defer;
             if (external) launch_pass<true, true>(c, src, nd, cap_pairs); else launch_pass<false, true>(c, src, nd, cap_pairs);
             launches += per_pass;
-            HIPCHK(hipEventRecord(c->ev[EV_DEEP1], s));
+            HIPCHK(evrec(c, EV_DEEP1));
             if ((rc = read_state(c, h))) return rc;
             if (h.n_deferred != 0) return CD_ERR_ARG;    // tree deeper than DEEP_STACK: cannot happen (height <= 96)
             if (h.max_shard_candidates > c->cand_cap / NSHARD) { if ((rc = grow_candidates(c, h.max_shard_candidates))) return rc; continue; }
             c->stats.stack_overflows = nd;
-            deep_ms = elapsed(c, EV_DEEP0, EV_DEEP1);
+            if (c->stage_events) deep_ms = elapsed(c, EV_DEEP0, EV_DEEP1);
         }
         done = true;
     }
@@ -305,7 +323,7 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
         HIPCHK(hipMemcpyAsync(pairs + 2 * have, c->d_pairs + 2 * have, sizeof(uint32_t) * 2 * (ncopy - have), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     }
-    c->stats.ms_traverse = elapsed(c, EV_TRAV0, EV_TRAV1) + deep_ms;
+    c->stats.ms_traverse = elapsed(c, EV_TRAV0, EV_TRAV1) + (c->stage_events ? deep_ms : 0.f);
     c->stats.ms_descend = (c->trav_variant != 0 && nq > 0) ? elapsed(c, EV_TRAV0, EV_DESC1) : 0.f;
     c->stats.ms_exact = (c->trav_variant != 0 && nq > 0) ? elapsed(c, EV_DESC1, EV_TRAV1) : 0.f;
     c->stats.traverse_launches = launches;
@@ -381,7 +399,14 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     for (int i = 0; i < 2; ++i) { ALLOC(c->d_keys[i], sizeof(uint64_t) * n); ALLOC(c->d_perm[i], sizeof(uint32_t) * n); }
     ALLOC(c->d_counts, sizeof(uint32_t) * RADIX * c->ntiles);
     c->os_bytes = sizeof(uint32_t) * 8 * RADIX + 128 + sizeof(unsigned long long) * 8 * (size_t)c->ntiles * RADIX;   // hist | 8 tickets, 8 time-out flags, fix-up flag, pad | granules
-    ALLOC(c->d_os, c->os_bytes);
+    // one scratch block so that the fused pipeline zeroes everything with ONE memset:
+    //   [onesweep: histograms | tickets, flags | look-back granules] [small counters: 128 words] [TravState]
+    const size_t os_only = c->os_bytes;
+    const size_t small_off = (os_only + 127) & ~(size_t)127, state_off = small_off + 512;
+    c->zero_bytes = state_off + sizeof(TravState);
+    ALLOC(c->d_os, c->zero_bytes);
+    c->d_small = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(c->d_os) + small_off);
+    c->d_state = reinterpret_cast<TravState *>(reinterpret_cast<char *>(c->d_os) + state_off);
     c->d_os_hist = reinterpret_cast<uint32_t *>(c->d_os);
     c->d_os_ticket = c->d_os_hist + 8 * RADIX;
     c->d_os_look = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_os) + sizeof(uint32_t) * 8 * RADIX + 128);
@@ -397,8 +422,6 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_boxes, sizeof(double) * 6 * 2 * n);
     ALLOC(c->d_bounded, sizeof(uint32_t) * n);
     ALLOC(c->d_recs32, sizeof(NodeRec32) * n);
-    ALLOC(c->d_small, sizeof(uint32_t) * 128);
-    ALLOC(c->d_state, sizeof(TravState));
     c->cand_cap = ((4 * n > (1u << 20) ? 4 * n : (1u << 20)) + NSHARD - 1) / NSHARD * NSHARD;
     ALLOC(c->d_cand, sizeof(Candidates) * c->cand_cap);
     c->defer_cap = 1u << 16;
@@ -537,19 +560,23 @@ int cd_build_tree(cd_ctx *c)
 {
     if (!c) return CD_ERR_ARG;
     int rc;
-    if ((rc = enqueue_morton_sort(c))) return rc;
-    if ((rc = enqueue_hierarchy(c, false))) return rc;
-    if ((rc = enqueue_refit(c))) return rc;
+    Prezeroed fused(c);                                                    // one memset for every counter of the pipeline
+    rc = enqueue_morton_sort(c);
+    if (!rc) rc = enqueue_hierarchy(c, false);
+    if (!rc) rc = enqueue_refit(c);
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));   // words 8..16
     HIPCHK(hipMemcpyAsync(c->root_box_host, c->d_boxes, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     rc = judge_sort_flags(c);
     if (rc == SORT_REDO) return cd_build_tree(c);                    // once: sort_full is now set
     if (rc) return rc;
-    c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
-    c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
-    c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);
-    c->stats.ms_refit = elapsed(c, EV_REFIT0, EV_REFIT1);
+    if (c->stage_events) {
+        c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
+        c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
+        c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);
+        c->stats.ms_refit = elapsed(c, EV_REFIT0, EV_REFIT1);
+    }
     c->root_box_valid = true;
     c->stage = ST_REFIT;
     return CD_OK;
@@ -559,18 +586,23 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
 {
     if (!c || (cap_pairs && !pairs)) return CD_ERR_ARG;
     int rc;
-    if ((rc = enqueue_morton_sort(c))) return rc;
-    if ((rc = enqueue_hierarchy(c, false))) return rc;
-    if ((rc = enqueue_refit(c))) return rc;
-    rc = run_traversal(c, nullptr, 0, pairs, cap_pairs, n_pairs);     // synchronises
+    Prezeroed fused(c);                                                    // one memset for every counter of the pipeline
+    rc = enqueue_morton_sort(c);
+    if (!rc) rc = enqueue_hierarchy(c, false);
+    if (!rc) rc = enqueue_refit(c);
+    if (!rc) rc = run_traversal(c, nullptr, 0, pairs, cap_pairs, n_pairs);     // synchronises
+    fused.done();
     if (rc < 0) return rc;
     { const int rs = judge_sort_flags(c);                                   // flags came back with the traversal counters
       if (rs == SORT_REDO) return cd_self_collide(c, pairs, cap_pairs, n_pairs);   // once: sort_full is now set
       if (rs) return rs; }
-    c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
-    c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
-    c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);
-    c->stats.ms_refit = elapsed(c, EV_REFIT0, EV_REFIT1);
+    if (c->stage_events) {
+        c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
+        c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
+        c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);
+        c->stats.ms_refit = elapsed(c, EV_REFIT0, EV_REFIT1);
+    } else c->stats.ms_morton = c->stats.ms_sort = c->stats.ms_hierarchy = c->stats.ms_refit = 0.f;
+    c->stats.ms_pipeline = elapsed(c, EV_MORTON0, EV_TRAV1) + (c->stats.ms_traverse - elapsed(c, EV_TRAV0, EV_TRAV1));   // + deep pass, if any
     c->stage = ST_REFIT;
     c->root_box_valid = true;
     return rc;
@@ -701,6 +733,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (key == CD_OPT_TRAVERSAL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
     if (key == CD_OPT_QUERIES_PER_WAVE) { if (value < 64 || value > (1 << 20) || value % 64) return CD_ERR_ARG; c->queries_per_wave = (uint32_t)value; return CD_OK; }
     if (key == CD_OPT_SORT_FULL) { c->sort_full = value != 0; return CD_OK; }
+    if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }
     if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
     if (key == 102) { c->dbg_halfload = (uint32_t)value; return CD_OK; }
     if (key == 101) { if (value < 1 || value > 65535) return CD_ERR_ARG; c->exact_blocks = (int)value; return CD_OK; }

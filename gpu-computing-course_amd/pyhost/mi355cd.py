@@ -17,7 +17,7 @@ CD_OK, CD_OVERFLOW = 0, 1
 CD_ERR_ARG, CD_ERR_ORDER, CD_ERR_NO_DEVICE, CD_ERR_INDEX = -1001, -1002, -1003, -1004
 CD_FRAME_REFERENCE, CD_FRAME_AUTO, CD_FRAME_CUSTOM = 0, 1, 2
 CD_ERR_SORT, CD_ERR_IO, CD_ERR_FORMAT = -1005, -1006, -1007
-CD_OPT_TRAVERSAL, CD_OPT_QUERIES_PER_WAVE, CD_OPT_SORT_FULL = 0, 1, 2
+CD_OPT_TRAVERSAL, CD_OPT_QUERIES_PER_WAVE, CD_OPT_SORT_FULL, CD_OPT_STAGE_TIMING = 0, 1, 2, 3
 
 QUERY_DTYPE = np.dtype([("v", "<f8", (9,)), ("id", "<u4"), ("vidx", "<u4", (3,))])
 assert QUERY_DTYPE.itemsize == 88
@@ -29,7 +29,7 @@ class CdStats(C.Structure):
                 ("traverse_launches", C.c_uint32), ("stack_overflows", C.c_uint32),
                 ("n_pairs", C.c_uint64), ("pairs_tested", C.c_uint64), ("node_visits", C.c_uint64),
                 ("wave_steps", C.c_uint64), ("candidates", C.c_uint64),
-                ("ms_descend", C.c_float), ("ms_exact", C.c_float), ("sort_passes", C.c_uint32), ("pad_", C.c_uint32)]
+                ("ms_descend", C.c_float), ("ms_exact", C.c_float), ("sort_passes", C.c_uint32), ("ms_pipeline", C.c_float)]
 
 
 # every symbol include/mi355cd.h declares (tests check the library exports exactly these)

@@ -66,7 +66,7 @@ typedef struct cd_stats {
     float ms_descend;          /* shallow pass: memset + descent kernel (part of ms_traverse)          */
     float ms_exact;            /* shallow pass: exact-test kernel        (part of ms_traverse)          */
     uint32_t sort_passes;      /* digit passes of the last sort: 4 (half-key + fix-up) or 8              */
-    uint32_t pad_;
+    float ms_pipeline;         /* fused calls: pipeline start -> end of the traversal kernels, one event pair */
 } cd_stats;
 
 /* main.cu:64 loadObj (load_obj.h:24-103), host side, multi-threaded: parse `v x y z` (as float, widened to double)
@@ -155,6 +155,9 @@ enum {
     CD_OPT_SORT_FULL        = 2,   /* 0 (default): sort the high 32 key bits (4 passes) + stable fix-up of equal-high-half   */
                                    /*    runs; falls back to 1 by itself when a run is too long.  1: all 8 digit passes.    */
                                    /*    Both give the identical stable order by the full 64-bit key.                        */
+    CD_OPT_STAGE_TIMING     = 3,   /* 1 (default): HIP events around every stage (cd_stats.ms_morton ... ms_refit); 0: only the  */
+                                   /*    events of the pipeline as a whole and of the descent kernel (ms_pipeline, ms_traverse,   */
+                                   /*    ms_descend, ms_exact) -- each stage boundary costs a few idle microseconds                */
     CD_OPT_QUERIES_PER_WAVE = 1    /* variant 1: queries one wave works through with dynamic lane refill (x64)         */
 };
 int cd_set_option(cd_ctx *ctx, int key, int64_t value);

@@ -465,3 +465,27 @@ def test_half_key_sort_equals_full_sort_and_falls_back():
         assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
         cd.self_collide()
         assert cd.stats().sort_passes == 8                                  # and stays in full mode for this context
+
+
+def test_stage_timing_switch_changes_only_the_timers():
+    """CD_OPT_STAGE_TIMING 0 drops the per-stage HIP events (and the fused call zeroes its counters with one memset):
+    results, counters and repeated calls must be unaffected; ms_pipeline / ms_descend stay measured."""
+    verts, vidx = synth.cloth_pair(60)
+    r = oracle.pipeline(verts, vidx)
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        for timing in (0, 1, 0):
+            cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, timing)
+            for _ in range(2):
+                pairs, n, rc = cd.self_collide()
+                st = cd.stats()
+                assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+                assert st.pairs_tested == r["stats"].pairs_tested
+                assert st.ms_pipeline > 0 and 0 < st.ms_descend <= st.ms_traverse <= st.ms_pipeline
+                assert (st.ms_sort > 0) == bool(timing)
+                if timing:
+                    assert st.ms_morton + st.ms_sort + st.ms_hierarchy + st.ms_refit + st.ms_traverse <= st.ms_pipeline * 1.001
+        # the stage-wise API after a fused call zeroes its own counters again
+        cd.morton_sort(); cd.build_hierarchy(); cd.refit_boxes()
+        assert cd.check_internal().tolist() == [1, 0, 0, 0, 0]
+        pairs, n, rc = cd.find_collisions()
+        assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
