@@ -3,6 +3,7 @@
 //   internal node i -> id i (root 0), leaf j -> id (n-1)+j, -1 = NULL.
 #pragma once
 #include "cd_math.h"
+#include "cd_sort.h"
 
 namespace cd {
 
@@ -77,14 +78,26 @@ __global__ void k_frame_from_bounds(const double *__restrict__ partial, uint32_t
 }
 
 // ---------------------------------------------------------------- Morton keys (load_obj.h:89-101, morton.h:70-89)
-__global__ __launch_bounds__(256) void k_morton(const double *__restrict__ verts, const uint32_t *__restrict__ vidx, uint32_t n,
-                                                const double *__restrict__ frame /* off[3], span[3] */,
-                                                uint64_t *__restrict__ keys)
+// Grid-stride; the workgroup also accumulates the radix sort's digit histograms (cd_sort.h) of the keys it writes.
+constexpr int MORTON_THREADS = 512;
+__global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restrict__ verts, const uint32_t *__restrict__ vidx, uint32_t n,
+                                                           const double *__restrict__ frame /* off[3], span[3] */,
+                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ ghist /* [8][256] */, int first_digit)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const d3 c = centroid_of(verts, vidx, t);
-    keys[t] = morton3d(c.x, c.y, c.z, frame, frame + 3);
+    __shared__ uint32_t h[8][RADIX];
+    for (int i = threadIdx.x; i < 8 * RADIX; i += MORTON_THREADS) (&h[0][0])[i] = 0;
+    __syncthreads();
+    for (uint32_t t = blockIdx.x * MORTON_THREADS + threadIdx.x; t < n; t += gridDim.x * MORTON_THREADS) {
+        const d3 c = centroid_of(verts, vidx, t);
+        const uint64_t k = morton3d(c.x, c.y, c.z, frame, frame + 3);
+        keys[t] = k;
+        hist_add(h, k, first_digit);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x + first_digit * RADIX; i < 8 * RADIX; i += MORTON_THREADS) {
+        const uint32_t v = (&h[0][0])[i];
+        if (v) atomicAdd(&ghist[i], v);
+    }
 }
 
 // ---------------------------------------------------------------- fillLeafNodes (bvh.cuh:125-144)

@@ -133,8 +133,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *
 // ====================================================================================================
 // Onesweep form (single pass over the data per digit, decoupled look-back): replaces the
 // hist -> scan -> scatter triple above with
-//   k_os_hist      : ONE read of the keys builds all 8 global digit histograms
-//   k_os_scan      : exclusive scan of each 256-bin histogram (digit bases)
+//   (k_morton)     : builds the global digit histograms while it writes the keys
 //   k_os_pass x 8  : per tile -- stable local ranking as in k_radix_scatter, then the tile's global
 //                    offsets come from a chained look-back over the preceding tiles' published
 //                    {status, count} granules instead of a separate scan kernel.
@@ -156,28 +155,26 @@ constexpr unsigned long long OS_AGG = 1ull << 62;      // value = this tile's co
 constexpr unsigned long long OS_PREFIX = 2ull << 62;   // value = inclusive prefix over tiles 0..t
 constexpr unsigned long long OS_VALUE_MASK = (1ull << 62) - 1;
 
-__global__ __launch_bounds__(SORT_THREADS) void k_os_hist(const uint64_t *__restrict__ keys, uint32_t n, uint32_t ntiles,
-                                                          uint32_t *__restrict__ ghist /* [8][256] */, int first_digit = 0)
+// Digit histograms: ghist[p][d] = number of keys whose digit p equals d, accumulated by k_morton (cd_bvh.h) while it
+// writes the keys -- workgroup-local LDS histograms flushed with one global atomic per non-empty bin.  hist_add() is
+// the per-key part.
+__device__ __forceinline__ void hist_add(uint32_t (*h)[RADIX], uint64_t k, int first_digit)
+{
+    if (first_digit == 0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255], 1u);
+    }
+#pragma unroll
+    for (int p = 4; p < 8; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255], 1u);
+}
+
+// Stand-alone histogram kernel for keys that do not come from k_morton (the pair post-processing sort).
+__global__ __launch_bounds__(SORT_THREADS) void k_os_hist(const uint64_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ ghist /* [8][256] */)
 {
     __shared__ uint32_t h[8][RADIX];
     for (int i = threadIdx.x; i < 8 * RADIX; i += SORT_THREADS) (&h[0][0])[i] = 0;
     __syncthreads();
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t base = tile * SORT_TILE;
-#pragma unroll 4
-        for (int it = 0; it < SORT_ITEMS; ++it) {
-            const uint32_t i = base + it * SORT_THREADS + threadIdx.x;
-            if (i < n) {
-                const uint64_t k = keys[i];
-                if (first_digit == 0) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255], 1u);
-                }
-#pragma unroll
-                for (int p = 4; p < 8; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255], 1u);
-            }
-        }
-    }
+    for (uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x; i < n; i += gridDim.x * SORT_THREADS) hist_add(h, keys[i], 0);
     __syncthreads();
     for (int i = threadIdx.x; i < 8 * RADIX; i += SORT_THREADS) {
         const uint32_t v = (&h[0][0])[i];
@@ -185,38 +182,31 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_hist(const uint64_t *__rest
     }
 }
 
-// ghist[p][d] -> exclusive prefix over d (in place).  One workgroup of 256 threads, thread = digit.
-__global__ __launch_bounds__(RADIX) void k_os_scan(uint32_t *__restrict__ ghist)
-{
-    __shared__ uint32_t ws[4];
-    const int d = threadIdx.x, lane = d & 63, w = d >> 6;
-    for (int p = 0; p < 8; ++p) {
-        const uint32_t c = ghist[p * RADIX + d];
-        uint32_t v = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(v, o); if (lane >= o) v += t; }
-        if (lane == 63) ws[w] = v;
-        __syncthreads();
-        uint32_t add = 0;
-        for (int ww = 0; ww < w; ++ww) add += ws[ww];
-        ghist[p * RADIX + d] = v - c + add;
-        __syncthreads();
-    }
-}
-
 __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                           uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-                                                          uint32_t n, int shift, const uint32_t *__restrict__ digit_base /* [256] */,
+                                                          uint32_t n, int shift, const uint32_t *__restrict__ digit_hist /* [256] raw counts of this digit */,
                                                           unsigned long long *lookback /* [ntiles][256] */, uint32_t *ticket /* [pass]; ticket[8 - pass] = timeout flag */, int first_pass)
 {
     __shared__ uint32_t wcnt[OS_WAVES][RADIX];
     __shared__ uint32_t gbase[RADIX];
     __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_wsum[RADIX / 64];
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     for (int i = tid; i < OS_WAVES * RADIX; i += OS_THREADS) (&wcnt[0][0])[i] = 0;
+    // digit bases = exclusive scan of the 256 raw counts; every tile does it for itself (no scan kernel)
+    uint32_t dbase = 0;
+    if (tid < RADIX) {
+        const uint32_t c = digit_hist[tid];
+        uint32_t v = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(v, o); if (lane >= o) v += t; }
+        if (lane == 63) s_wsum[w] = v;
+        dbase = v - c;
+    }
     __syncthreads();
+    if (tid < RADIX) for (int ww = 0; ww < w; ++ww) dbase += s_wsum[ww];
     const uint32_t tile = s_tile;
 
     const uint32_t base_w = tile * SORT_TILE + w * (OS_ITEMS * 64);
@@ -293,7 +283,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
             }
             __hip_atomic_store(mine, OS_PREFIX | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        gbase[tid] = digit_base[tid] + (uint32_t)excl;
+        gbase[tid] = dbase + (uint32_t)excl;
     }
     __syncthreads();
 #pragma unroll
@@ -320,35 +310,35 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
 // ====================================================================================================
 constexpr int FIX_MAX = 16;
 
-__global__ __launch_bounds__(256) void k_sort_fixup(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t n, uint32_t *__restrict__ overflow)
+// Out of place (in -> out): thread i finds its run by looking at most FIX_MAX keys back and forward and counts the
+// keys of the run that must precede its own -- earlier ones with key <= mine, later ones with key < mine (stable) --
+// which is its position inside the run.  Typical cost: two neighbour reads and one copy.
+__global__ __launch_bounds__(256) void k_sort_fixup(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                    uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n,
+                                                    uint32_t *__restrict__ overflow)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint64_t k0 = keys[i];
+    const uint64_t k0 = keys_in[i];
     const uint32_t h = (uint32_t)(k0 >> 32);
-    if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == h) return;            // not the first key of its run
-    if (i + 1 >= n || (uint32_t)(keys[i + 1] >> 32) != h) return;       // run of one: already in place
-    uint64_t k[FIX_MAX]; uint32_t v[FIX_MAX];
-    int len = 0;
-#pragma unroll
-    for (int u = 0; u < FIX_MAX; ++u) {
-        const bool in = (i + u < n) && (len == u) && (uint32_t)(keys[i + u] >> 32) == h;
-        if (in) { k[u] = keys[i + u]; v[u] = vals[i + u]; len = u + 1; } else { k[u] = ~0ull; v[u] = 0; }
+    uint32_t back = 0, before = 0;
+    while (back < (uint32_t)FIX_MAX && back < i) {
+        const uint64_t kb = keys_in[i - 1 - back];
+        if ((uint32_t)(kb >> 32) != h) break;
+        before += kb <= k0;
+        ++back;
     }
-    if (len == FIX_MAX && i + FIX_MAX < n && (uint32_t)(keys[i + FIX_MAX] >> 32) == h) { atomicExch(overflow, 1u); return; }
-    // stable insertion sort of k[0..len) by the full key, fully unrolled (registers, no scratch)
-#pragma unroll
-    for (int a = 1; a < FIX_MAX; ++a) {
-#pragma unroll
-        for (int b = a; b > 0; --b) {
-            const bool sw = (b < len) && (k[b] < k[b - 1]);             // strict: equal keys never pass each other
-            const uint64_t ka = sw ? k[b - 1] : k[b], kb = sw ? k[b] : k[b - 1];
-            const uint32_t va = sw ? v[b - 1] : v[b], vb = sw ? v[b] : v[b - 1];
-            k[b] = ka; k[b - 1] = kb; v[b] = va; v[b - 1] = vb;
-        }
+    uint32_t fwd = 0;
+    while (fwd < (uint32_t)FIX_MAX && i + 1 + fwd < n) {
+        const uint64_t kf = keys_in[i + 1 + fwd];
+        if ((uint32_t)(kf >> 32) != h) break;
+        before += kf < k0;
+        ++fwd;
     }
-#pragma unroll
-    for (int u = 0; u < FIX_MAX; ++u) if (u < len) { keys[i + u] = k[u]; vals[i + u] = v[u]; }
+    if (back == (uint32_t)FIX_MAX || fwd == (uint32_t)FIX_MAX) { atomicExch(overflow, 1u); return; }   // run may be longer than FIX_MAX
+    const uint32_t pos = i - back + before;
+    keys_out[pos] = k0;
+    vals_out[pos] = vals_in[i];
 }
 
 }  // namespace cd

@@ -32,6 +32,33 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
+// What the host needs after a traversal, gathered into ONE 256-byte record that sits directly in front of the pair
+// list, so that counters + sort flags + root box + the first pairs come back in a single device-to-host copy.
+struct alignas(256) Report {
+    unsigned long long n_pairs, pairs_tested, node_visits, max_shard_candidates, wave_steps, candidates;
+    uint32_t n_deferred, pad0;
+    uint32_t sort_flags[9]; uint32_t pad1;
+    double root_box[6];
+};
+static_assert(sizeof(Report) == 256, "report layout");
+
+__global__ __launch_bounds__(64) void k_report(const TravState *__restrict__ st, const uint32_t *__restrict__ sort_flags /* 9 words */,
+                                               const double *__restrict__ root_box, Report *__restrict__ out)
+{
+    const int lane = threadIdx.x;                                       // NSHARD == 64: lane = shard
+    const CtrShard sh = st->shard[lane];
+    const unsigned long long tested = wave_sum_u64(sh.pairs_tested), visits = wave_sum_u64(sh.node_visits);
+    const unsigned long long steps = wave_sum_u64(sh.wave_steps), cands = wave_sum_u64(sh.n_candidates);
+    unsigned long long mx = sh.n_candidates;
+    for (int o = 32; o; o >>= 1) { const unsigned long long u = __shfl_xor(mx, o); mx = u > mx ? u : mx; }
+    if (lane == 0) {
+        out->n_pairs = st->n_pairs; out->pairs_tested = tested; out->node_visits = visits; out->max_shard_candidates = mx;
+        out->wave_steps = steps; out->candidates = cands; out->n_deferred = st->n_deferred;
+    }
+    if (lane < 9) out->sort_flags[lane] = sort_flags[lane];
+    if (lane < 6) out->root_box[lane] = root_box[lane];
+}
+
 constexpr int TRAV_THREADS = 256;
 constexpr int TRAV_STACK   = 32;       // variant A: LDS entries per lane (the reference's private stack is 32, collision.cuh:21)
 constexpr int DEEP_STACK   = 192;      // global-memory entries per item in the overflow pass (tree height <= 96)

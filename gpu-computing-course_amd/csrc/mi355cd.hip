@@ -56,7 +56,8 @@ struct cd_ctx {
     // traversal
     TravState *d_state = nullptr;
     int exact_blocks = 1024;
-    uint32_t *d_pairs = nullptr; uint64_t pairs_cap = 0;
+    uint32_t *d_pairs = nullptr; uint64_t pairs_cap = 0;   // d_pairs points sizeof(Report) bytes into its allocation: [Report][pairs]
+    char *h_report = nullptr;               // pinned: Report + SPEC_PAIRS pairs, target of the single read-back copy
     uint2 *d_defer = nullptr; uint32_t defer_cap = 0;
     Candidates *d_cand = nullptr; uint64_t cand_cap = 0;    // variant C candidate buffer
     int32_t *d_deep = nullptr; uint64_t deep_items = 0;
@@ -83,7 +84,9 @@ void free_all(cd_ctx *c)
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_cross); hipFree(c->d_boxes);
     hipFree(c->d_bounded); hipFree(c->d_recs32); 
-    hipFree(c->d_pairs); hipFree(c->d_defer); hipFree(c->d_deep); hipFree(c->d_cand);
+    if (c->d_pairs) hipFree(reinterpret_cast<char *>(c->d_pairs) - sizeof(Report));
+    if (c->h_report) hipHostFree(c->h_report);
+    hipFree(c->d_defer); hipFree(c->d_deep); hipFree(c->d_cand);
     for (int i = 0; i < 2; ++i) { hipFree(c->pp_keys[i]); hipFree(c->pp_vals[i]); }
     hipFree(c->pp_flags); hipFree(c->pp_os);
     for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -97,8 +100,11 @@ constexpr int BOUNDS_BLOCKS = 1024;
 int ensure_pairs(cd_ctx *c, uint64_t cap)
 {
     if (cap <= c->pairs_cap) return 0;
-    hipFree(c->d_pairs); c->d_pairs = nullptr; c->pairs_cap = 0;
-    HIPCHK(hipMalloc(&c->d_pairs, sizeof(uint32_t) * 2 * cap));
+    if (c->d_pairs) hipFree(reinterpret_cast<char *>(c->d_pairs) - sizeof(Report));
+    c->d_pairs = nullptr; c->pairs_cap = 0;
+    char *block = nullptr;
+    HIPCHK(hipMalloc(&block, sizeof(Report) + sizeof(uint32_t) * 2 * cap));
+    c->d_pairs = reinterpret_cast<uint32_t *>(block + sizeof(Report));
     c->pairs_cap = cap;
     return 0;
 }
@@ -130,24 +136,23 @@ int enqueue_morton_sort(cd_ctx *c)
         k_centroid_bounds<<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_partial);
         k_frame_from_bounds<<<1, 64, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->d_frame);
     }
-    k_morton<<<cdiv(n, 256), 256, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_frame, c->d_keys[0]);
-    HIPCHK(evrec(c, EV_MORTON1));
-    // onesweep: one histogram read, then one pass over the data per digit (see cd_sort.h)
     // fused pipeline: the sort scratch, the small counters and the traversal state are one block, zeroed once here
     HIPCHK(hipMemsetAsync(c->d_os, 0, c->prezeroed ? c->zero_bytes : c->os_bytes, s));
-    k_os_hist<<<c->ntiles < 512 ? c->ntiles : 512, SORT_THREADS, 0, s>>>(c->d_keys[0], n, c->ntiles, c->d_os_hist, c->sort_full ? 0 : 4);
-    k_os_scan<<<1, RADIX, 0, s>>>(c->d_os_hist);
-    // half-key mode: 4 passes on the high 32 bits + a fix-up of equal-high-half runs (cd_sort.h); full mode: 8 passes
+    // half-key mode: 4 passes on the high 32 bits + a fix-up of equal-high-half runs (cd_sort.h); full mode: 8 passes.
+    // The keys start in the buffer that leaves the sorted data in buffer 0 (the fix-up is one more hop).
     const int first_digit = c->sort_full ? 0 : 4;
-    int cur = 0;
+    int cur = c->sort_full ? 0 : 1;
+    const uint32_t mblocks = cdiv(n, MORTON_THREADS * 4) < 1024u ? cdiv(n, MORTON_THREADS * 4) : 1024u;
+    k_morton<<<mblocks, MORTON_THREADS, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_frame, c->d_keys[cur], c->d_os_hist, first_digit);
+    HIPCHK(evrec(c, EV_MORTON1));
+    // onesweep: one pass over the data per digit (see cd_sort.h); the digit histograms came with the keys
     for (int pass = first_digit; pass < 8; ++pass) {
         k_os_pass<<<c->ntiles, OS_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1], n, pass * RADIX_BITS,
                                                     c->d_os_hist + pass * RADIX, c->d_os_look + (size_t)pass * c->ntiles * RADIX,
                                                     c->d_os_ticket + pass, pass == first_digit);
         cur ^= 1;
     }
-    // an even number of passes: sorted data is back in buffer 0
-    if (!c->sort_full) k_sort_fixup<<<cdiv(n, 256), 256, 0, s>>>(c->d_keys[0], c->d_perm[0], n, c->d_os_ticket + 16);
+    if (!c->sort_full) k_sort_fixup<<<cdiv(n, 256), 256, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, c->d_os_ticket + 16);
     c->stats.sort_passes = c->sort_full ? 8 : 4;
     HIPCHK(evrec(c, EV_SORT1));
     HIPCHK(hipGetLastError());
@@ -224,21 +229,23 @@ struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_can
 
 constexpr uint64_t SPEC_PAIRS = 1u << 15;     // pairs copied back speculatively together with the counters (256 KB)
 
-// One host round trip: counters, the sort's time-out flags, and (if asked) the first SPEC_PAIRS pairs.
+// One host round trip and ONE copy: k_report gathers counters, the sort's time-out flags and the root box into the
+// record in front of the pair list; record + the first spec_n pairs land in pinned memory.
 int read_state(cd_ctx *c, HostCounters &h, uint32_t *spec_pairs = nullptr, uint64_t spec_n = 0)
 {
-    static_assert(sizeof(TravState) <= 16384, "state read-back size");
-    TravState hs;
-    HIPCHK(hipMemcpyAsync(&hs, c->d_state, sizeof hs, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));   // words 8..16
-    HIPCHK(hipMemcpyAsync(c->root_box_host, c->d_boxes, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
-    if (spec_pairs && spec_n) HIPCHK(hipMemcpyAsync(spec_pairs, c->d_pairs, sizeof(uint32_t) * 2 * spec_n, hipMemcpyDeviceToHost, c->stream));
+    if (!c->h_report) HIPCHK(hipHostMalloc(&c->h_report, sizeof(Report) + sizeof(uint32_t) * 2 * SPEC_PAIRS, hipHostMallocDefault));
+    if (!spec_pairs || spec_n > SPEC_PAIRS) spec_n = spec_pairs ? SPEC_PAIRS : 0;
+    Report *d_rep = reinterpret_cast<Report *>(reinterpret_cast<char *>(c->d_pairs) - sizeof(Report));
+    k_report<<<1, 64, 0, c->stream>>>(c->d_state, c->d_os_ticket + 8, c->d_boxes, d_rep);
+    HIPCHK(hipMemcpyAsync(c->h_report, d_rep, sizeof(Report) + sizeof(uint32_t) * 2 * spec_n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    h = HostCounters{hs.n_pairs, 0, 0, 0, hs.n_deferred, 0, 0};
-    for (int i = 0; i < NSHARD; ++i) {
-        h.pairs_tested += hs.shard[i].pairs_tested; h.node_visits += hs.shard[i].node_visits;
-        h.wave_steps += hs.shard[i].wave_steps; h.candidates += hs.shard[i].n_candidates;
-        if (hs.shard[i].n_candidates > h.max_shard_candidates) h.max_shard_candidates = hs.shard[i].n_candidates;
+    const Report &r = *reinterpret_cast<const Report *>(c->h_report);
+    h = HostCounters{r.n_pairs, r.pairs_tested, r.node_visits, r.max_shard_candidates, r.n_deferred, r.wave_steps, r.candidates};
+    std::memcpy(c->sort_flags, r.sort_flags, sizeof c->sort_flags);
+    std::memcpy(c->root_box_host, r.root_box, sizeof(double) * 6);
+    if (spec_n) {
+        const uint64_t take = r.n_pairs < spec_n ? r.n_pairs : spec_n;
+        std::memcpy(spec_pairs, c->h_report + sizeof(Report), sizeof(uint32_t) * 2 * take);
     }
     return 0;
 }
@@ -360,8 +367,7 @@ int pp_sort(cd_ctx *c, uint32_t m)
     uint32_t *ticket = hist + 8 * RADIX;
     unsigned long long *look = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->pp_os) + sizeof(uint32_t) * 8 * RADIX + 64);
     HIPCHK(hipMemsetAsync(c->pp_os, 0, sizeof(uint32_t) * 8 * RADIX + 64 + sizeof(unsigned long long) * 8 * (size_t)ntiles * RADIX, s));
-    k_os_hist<<<ntiles < 512 ? ntiles : 512, SORT_THREADS, 0, s>>>(c->pp_keys[0], m, ntiles, hist);
-    k_os_scan<<<1, RADIX, 0, s>>>(hist);
+    k_os_hist<<<cdiv(m, SORT_THREADS * 8) < 1024u ? cdiv(m, SORT_THREADS * 8) : 1024u, SORT_THREADS, 0, s>>>(c->pp_keys[0], m, hist);
     int cur = 0;
     for (int pass = 0; pass < 8; ++pass) {
         k_os_pass<<<ntiles, OS_THREADS, 0, s>>>(c->pp_keys[cur], c->pp_vals[cur], c->pp_keys[cur ^ 1], c->pp_vals[cur ^ 1], m, pass * RADIX_BITS,
