@@ -211,7 +211,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
     CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
     Candidates *my_cand = cand + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_cap;
     // this wave's chunk of work items (queries, or deferred (query, subtree) items in the deep pass)
-    const uint32_t qpw_ = queries_per_wave & 0x7fffffffu;
+    const uint32_t qpw_ = queries_per_wave & 0x3fffffffu;       // bit 30: debug switch (no shared root path)
     const unsigned long long c0 = (unsigned long long)wave_id * qpw_;
     const uint32_t chunk_begin = (uint32_t)(c0 < nq ? c0 : nq);
     const uint32_t chunk_end = (uint32_t)(c0 + qpw_ < nq ? c0 + qpw_ : nq);
@@ -223,6 +223,9 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
     int32_t *gstack = DEEP ? deep_stacks + ((size_t)wave_id * 64 + lane) * DEEP_STACK : nullptr;
     const int stack_cap = DEEP ? DEEP_STACK : WQ_STACK;
 
+    // shared root path (below): only for a wave whose queries are 64 consecutive leaves of the tree itself
+    constexpr bool SHARED_PATH = !EXTERNAL && !DEEP && !REFILL;
+    bool shared_path_pending = SHARED_PATH && n > 1 && !(queries_per_wave & 0x40000000u) && chunk_begin < chunk_end;
     bool first_round = true;
     while (true) {
         if (REFILL || first_round) {   // ---- (re)fill idle lanes with the next work items of the chunk
@@ -256,6 +259,63 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                 const uint32_t taken = __popcll(mi);
                 next += (taken < remaining) ? taken : remaining;
             }
+        }
+        if (SHARED_PATH && shared_path_pending) {
+            // ---- shared root path.  The 64 queries of this wave are the leaves [g0, g0 + 64) of the very tree they
+            // query, so each of them would walk down (nearly) the same ~20 ancestors, one divergent 64-byte fetch and
+            // ~50 instructions per lane and level.  Instead the WAVE walks from the root to leaf g0 once, fetching
+            // each record through the scalar cache, and every lane only tests its box against the SIBLING hanging off
+            // that path: the siblings plus leaf g0 partition all leaves, child boxes nest (also after the monotone
+            // outward rounding), so the lanes reach exactly the subtrees a private descent from the root would.
+            shared_path_pending = false;
+            const bool valid = (node != -1);
+            // (readfirstlane: the compiler cannot see that chunk_begin is wave-uniform, and would select per lane)
+            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk_begin);
+            int32_t pn = 0;                                                  // wave-uniform path node
+            node = -1;
+            while (true) {
+                const int4 *rq = reinterpret_cast<const int4 *>(recs + pn);
+                const int4 r0 = rq[0], r1 = rq[1], r2 = rq[2], r3 = rq[3];
+                const int32_t chl = r3.x, chr = r3.y;
+                const uint32_t split = (uint32_t)(chl >= 0 ? chl : ~chl);      // the left child's id IS the split position
+                const bool go_left = g0 <= split;                             // uniform
+                const int32_t sib = go_left ? chr : chl, onp = go_left ? chl : chr;
+                // record layout: left = lo(r0.x,r0.y,r0.z) hi(r0.w,r1.x,r1.y), right = lo(r1.z,r1.w,r2.x) hi(r2.y,r2.z,r2.w).
+                // The selects are done on the raw words, so that they stay scalar (s_cselect) like their condition.
+                const float slo0 = __int_as_float(go_left ? r1.z : r0.x), slo1 = __int_as_float(go_left ? r1.w : r0.y), slo2 = __int_as_float(go_left ? r2.x : r0.z);
+                const float shi0 = __int_as_float(go_left ? r2.y : r0.w), shi1 = __int_as_float(go_left ? r2.z : r1.x), shi2 = __int_as_float(go_left ? r2.w : r1.y);
+                const bool hit = valid & (qlo0 < shi0) & (slo0 < qhi0) & (qlo1 < shi1) & (slo1 < qhi1) & (qlo2 < shi2) & (slo2 < qhi2);
+                visits += valid ? 1u : 0u;
+                bool cnd = false; uint32_t cleaf = 0;
+                if (sib >= 0) {                                               // uniform branch
+                    if (hit) {
+                        if (sptr < stack_cap) { lds_stack[sptr][tid] = sib; ++sptr; }
+                        else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)sib); }
+                    }
+                } else { cleaf = (uint32_t)~sib; cnd = hit & (cleaf != self_leaf); }
+                if (onp < 0) {                                                // the path ends at leaf g0 (uniform): its box is the on-path child's
+                    const float plo0 = __int_as_float(go_left ? r0.x : r1.z), plo1 = __int_as_float(go_left ? r0.y : r1.w), plo2 = __int_as_float(go_left ? r0.z : r2.x);
+                    const float phi0 = __int_as_float(go_left ? r0.w : r2.y), phi1 = __int_as_float(go_left ? r1.x : r2.z), phi2 = __int_as_float(go_left ? r1.y : r2.w);
+                    const bool ph = valid & (qi != g0) & (qlo0 < phi0) & (plo0 < qhi0) & (qlo1 < phi1) & (plo1 < qhi1) & (qlo2 < phi2) & (plo2 < qhi2);
+                    const unsigned long long mP = __ballot(ph);
+                    if (mP) { if (ph) queue[w][qcount + __popcll(mP & lt_mask)] = Candidates{qi, g0}; qcount += __popcll(mP); }
+                }
+                const unsigned long long mC = __ballot(cnd);
+                if (mC) { if (cnd) queue[w][qcount + __popcll(mC & lt_mask)] = Candidates{qi, cleaf}; qcount += __popcll(mC); }
+                while (qcount >= 64) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const Candidates cd0 = queue[w][qcount - 64 + lane];
+                    qcount -= 64;
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(&sh->n_candidates, 64ull);
+                    base = __shfl(base, 0);
+                    if (base + lane < shard_cap) my_cand[base + lane] = cd0;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                if (onp < 0) break;
+                pn = __builtin_amdgcn_readfirstlane(onp);
+            }
+            if (valid & (sptr > 0)) { --sptr; node = lds_stack[sptr][tid]; }
         }
         const bool active = (node != -1);
         if (__ballot(active) == 0ull) break;            // chunk exhausted and every lane finished

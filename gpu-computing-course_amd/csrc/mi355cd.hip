@@ -36,7 +36,7 @@ struct cd_ctx {
     uint32_t vbase = 0;
     int trav_variant = 1;                   // CD_OPT_TRAVERSAL: 0 = lane-private FP64 (A), 1 = split fp32 descent + exact kernel (B)
     uint32_t queries_per_wave = 64; 
-    uint32_t dbg_halfload = 0;
+    uint32_t dbg_halfload = 0;              // debug key 102: 1 = k_descend without the shared root path (A/B)
     uint32_t dbg_lds_pad = 0;               // CD_OPT_DEBUG_LDS_PAD: extra dynamic LDS bytes per traversal workgroup (occupancy experiments)        // CD_OPT_QUERIES_PER_WAVE (variant B chunk size)                     // global id of local vertex 0 (cross-rank neighbour filter)
     double frame_host[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};   // morton.h:45,51,57
     hipStream_t stream = nullptr;
@@ -187,7 +187,9 @@ int enqueue_refit(cd_ctx *c)
     k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded, c->d_recs32, c->d_seg, (int)c->nbp2,
                                                    cross_list, cross_count, c->cross_cap);
     k_refit_seg_top<<<1, 1024, 0, s>>>(c->d_seg, (int)c->nbp2, nblocks);
-    if (n > 1) k_refit_seg_cross<<<1024, 256, 0, s>>>((int)n, c->d_meta, c->d_seg, (int)c->nbp2, c->d_boxes, c->d_bounded, c->d_recs32,
+    // about 13 cross nodes per 512-leaf block: ~one node per wave, every load chain in flight at once
+    const uint32_t xblocks = nblocks * 4 < 256u ? 256u : (nblocks * 4 > 16384u ? 16384u : nblocks * 4);
+    if (n > 1) k_refit_seg_cross<<<xblocks, 256, 0, s>>>((int)n, c->d_meta, c->d_seg, (int)c->nbp2, c->d_boxes, c->d_bounded, c->d_recs32,
                                                       c->d_cross, cross_count, c->cross_cap);
     HIPCHK(evrec(c, EV_REFIT1));
     HIPCHK(hipGetLastError());
@@ -215,10 +217,10 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
         const dim3 grid(cdiv(items, qpw * WQ_WAVES));
         const size_t pad = DEEP ? 0 : c->dbg_lds_pad;
         if (qpw == 64)
-            k_descend<EXTERNAL, DEEP, false><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw | (c->dbg_halfload ? 0x80000000u : 0u), c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
+            k_descend<EXTERNAL, DEEP, false><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw | (c->dbg_halfload ? 0x40000000u : 0u), c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
                                                                             DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr);
         else
-            k_descend<EXTERNAL, DEEP, true><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw | (c->dbg_halfload ? 0x80000000u : 0u), c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
+            k_descend<EXTERNAL, DEEP, true><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw | (c->dbg_halfload ? 0x40000000u : 0u), c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
                                                                            DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr);
         if (!DEEP) evrec(c, EV_DESC1);
         k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, c->d_cand, shard_cap, c->d_pairs, cap_pairs, c->d_state);

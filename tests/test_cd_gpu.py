@@ -21,10 +21,13 @@ VARIANTS = [0, 1, 2]     # CD_OPT_TRAVERSAL: lane-private FP64 descent / per-lan
 
 
 def _check_visits(st, ref_stats, variant):
-    """Variant 0 walks exactly the oracle's nodes; variant 1 descends with conservative fp32 boxes, so it may
-    visit a few more internal nodes (never fewer) -- a diagnostic, not a result."""
+    """Variant 0 walks exactly the oracle's nodes; variant 2 descends with conservative fp32 boxes, so it may visit a
+    few more internal nodes (never fewer); variant 1 also walks the root-to-first-leaf path once per wave and counts
+    those (cheap, scalar-fetched) steps per lane, so its count is of the same order only -- a diagnostic, not a result."""
     if variant == 0:
         assert st.node_visits == ref_stats.node_visits
+    elif variant == 1:
+        assert 0.5 * ref_stats.node_visits <= st.node_visits <= ref_stats.node_visits * 2 + 64
     else:
         assert ref_stats.node_visits <= st.node_visits <= ref_stats.node_visits * 1.02 + 16
 
