@@ -148,7 +148,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *
 // tile cannot scatter before every earlier tile has ranked), not the walk; forwarding each key into the NEXT
 // pass's per-tile histogram with global atomics while scattering (no look-back at all) cost 3x (1 M scattered
 // atomics per pass).
-constexpr int OS_THREADS = 512;                        // 8 waves x 8 keys per lane = the same 4096-key tile, half the serial ranking per wave
+constexpr int OS_THREADS = 1024;                       // 16 waves x 4 keys per lane = the same 4096-key tile; the serial ranking chain per wave is what a pass waits for
 constexpr int OS_WAVES   = OS_THREADS / 64;
 constexpr int OS_ITEMS   = SORT_TILE / OS_THREADS;
 constexpr unsigned long long OS_AGG = 1ull << 62;      // value = this tile's count for the digit
