@@ -8,6 +8,7 @@
 #include "cd_post.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -69,6 +70,7 @@ struct cd_ctx {
     cd_stats stats = {};
     uint32_t sort_flags[9] = {};            // [0..7] look-back time-out words of the last sort, [8] half-key fix-up overflow; refreshed by read_state()
     bool stage_events = true;               // CD_OPT_STAGE_TIMING
+    bool events_ride = false;               // the last pass recorded EV_TRAV0 / EV_DESC1 / EV_TRAV1 through its kernels' dispatch packets
     bool prezeroed = false;                 // fused path: the scratch block was zeroed by one memset at pipeline start
     bool sort_full = false;                 // true: all 8 digit passes (forced, or after a fix-up overflow on this context)
     double root_box_host[6] = {};           // AABB of the whole tree, fetched together with other read-backs
@@ -216,14 +218,24 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
         const uint64_t shard_cap = c->cand_cap / NSHARD;
         const dim3 grid(cdiv(items, qpw * WQ_WAVES));
         const size_t pad = DEEP ? 0 : c->dbg_lds_pad;
+        // Timing of the two kernels: with stage events on, hipEventRecord before / between / after (each record is a
+        // barrier packet and ~6 us of idle GPU); off, the events ride on the kernels' own dispatch packets
+        // (hipExtLaunchKernelGGL start / stop events): same timestamps, no gaps.
+        const bool ride = !DEEP && !c->stage_events;
+        hipEvent_t e0 = ride ? c->ev[EV_TRAV0] : nullptr, e1 = ride ? c->ev[EV_DESC1] : nullptr, e2 = ride ? c->ev[EV_TRAV1] : nullptr;
+        const uint32_t qarg = qpw | (c->dbg_halfload ? 0x40000000u : 0u);
+        uint2 *dl = DEEP ? nullptr : c->d_defer; const uint32_t dcap = DEEP ? 0u : c->defer_cap; int32_t *deep = DEEP ? c->d_deep : nullptr;
         if (qpw == 64)
-            k_descend<EXTERNAL, DEEP, false><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw | (c->dbg_halfload ? 0x40000000u : 0u), c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
-                                                                            DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr);
+            hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, false>), grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
+                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, deep);
         else
-            k_descend<EXTERNAL, DEEP, true><<<grid, TRAV_THREADS, pad, s>>>(src, items, n, qpw | (c->dbg_halfload ? 0x40000000u : 0u), c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap,
-                                                                           DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr);
-        if (!DEEP) evrec(c, EV_DESC1);
-        k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, c->d_cand, shard_cap, c->d_pairs, cap_pairs, c->d_state);
+            hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, true>), grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
+                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, deep);
+        if (!DEEP && !ride) evrec(c, EV_DESC1);
+        hipExtLaunchKernelGGL((k_exact<EXTERNAL>), dim3(c->exact_blocks), dim3(EXACT_THREADS), 0u, s, nullptr, e2, 0u,
+                              src, n, (const LeafTri *)c->d_leaf, (const double *)c->d_boxes, (const double *)c->d_verts, vb, (const Candidates *)c->d_cand,
+                              (unsigned long long)shard_cap, c->d_pairs, (unsigned long long)cap_pairs, c->d_state);
+        c->events_ride = ride;
     }
 }
 
@@ -280,13 +292,15 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     for (int attempt = 0; attempt < 8 && !done; ++attempt) {
         launches = 0; deep_ms = 0.f;
         QuerySrc src{c->d_leaf, c->d_boxes, d_ext, nullptr};
-        HIPCHK(evrec(c, EV_TRAV0));
+        const bool will_ride = !c->stage_events && c->trav_variant == 1 && nq > 0;   // see launch_pass: events on the dispatch packets
+        c->events_ride = false;
+        if (!will_ride) HIPCHK(evrec(c, EV_TRAV0));
         if (!(c->prezeroed && attempt == 0)) HIPCHK(hipMemsetAsync(c->d_state, 0, sizeof(TravState), s));
         if (nq > 0) {
             if (external) launch_pass<true, false>(c, src, nq, cap_pairs); else launch_pass<false, false>(c, src, nq, cap_pairs);
             launches += per_pass;
         }
-        HIPCHK(evrec(c, EV_TRAV1));      // device time of the kernels only: recorded before the read-back
+        if (!c->events_ride) HIPCHK(evrec(c, EV_TRAV1));      // device time of the kernels only: recorded before the read-back
         const uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
         if ((rc = read_state(c, h, pairs, spec_n))) return rc;
         spec_valid = spec_n;
