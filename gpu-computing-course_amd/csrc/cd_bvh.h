@@ -103,23 +103,46 @@ __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restr
 // ---------------------------------------------------------------- fillLeafNodes (bvh.cuh:125-144)
 // leaf j <- triangle perm[j]; also resets the parent links and the refit arrival counters that the
 // reference gets from zero-initialised cudaMalloc memory (main.cu:84-85).
+__device__ __forceinline__ void fill_leaf(uint32_t j, uint32_t t, const uint32_t *__restrict__ vidx, const uint32_t *__restrict__ ids, uint32_t n,
+                                          LeafTri *__restrict__ leaf, int32_t *__restrict__ parent, uint32_t *__restrict__ bounded, double *__restrict__ boxes)
+{
+    LeafTri lt;
+    lt.id = ids ? ids[t] : t;
+    lt.v0 = vidx[3 * (size_t)t]; lt.v1 = vidx[3 * (size_t)t + 1]; lt.v2 = vidx[3 * (size_t)t + 2];
+    leaf[j] = lt;
+    parent[(n - 1) + j] = -1;
+    // boxes are "uninitialised" until the refit writes them (Box::init, box.cuh:10,21,31): poison x1
+    if (boxes) reinterpret_cast<uint64_t *>(boxes)[6 * (size_t)((n - 1) + j)] = 0xFFFFFFFFFFFFFFFFull;
+    if (j < n - 1) { parent[j] = -1; bounded[j] = 0; if (boxes) reinterpret_cast<uint64_t *>(boxes)[6 * (size_t)j] = 0xFFFFFFFFFFFFFFFFull; }
+}
+
 __global__ __launch_bounds__(256) void k_fill_leaves(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ vidx,
                                                      const uint32_t *__restrict__ ids, uint32_t n,
                                                      LeafTri *__restrict__ leaf, int32_t *__restrict__ parent, uint32_t *__restrict__ bounded,
                                                      double *__restrict__ boxes /* nullptr: do not poison (fused path: the refit follows at once) */)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) {
-        const uint32_t t = perm[j];
-        LeafTri lt;
-        lt.id = ids ? ids[t] : t;
-        lt.v0 = vidx[3 * (size_t)t]; lt.v1 = vidx[3 * (size_t)t + 1]; lt.v2 = vidx[3 * (size_t)t + 2];
-        leaf[j] = lt;
-        parent[(n - 1) + j] = -1;
-        // boxes are "uninitialised" until the refit writes them (Box::init, box.cuh:10,21,31): poison x1
-        if (boxes) reinterpret_cast<uint64_t *>(boxes)[6 * (size_t)((n - 1) + j)] = 0xFFFFFFFFFFFFFFFFull;
-        if (j < n - 1) { parent[j] = -1; bounded[j] = 0; if (boxes) reinterpret_cast<uint64_t *>(boxes)[6 * (size_t)j] = 0xFFFFFFFFFFFFFFFFull; }
-    }
+    if (j < n) fill_leaf(j, perm[j], vidx, ids, n, leaf, parent, bounded, boxes);
+}
+
+// Half-key sort: the fix-up hop (cd_sort.h) knows the final position of every triangle, so it fills the leaves too.
+__global__ __launch_bounds__(256) void k_sort_fixup_fill(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                         uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n,
+                                                         uint32_t *__restrict__ overflow,
+                                                         const uint32_t *__restrict__ vidx, const uint32_t *__restrict__ ids,
+                                                         LeafTri *__restrict__ leaf, int32_t *__restrict__ parent, uint32_t *__restrict__ bounded)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k0 = keys_in[i];
+    const uint32_t t = vals_in[i];
+    uint32_t pos;
+    // run too long: flag it (the host redoes the sort with 8 passes) but still emit a VALID permutation and valid
+    // leaves -- the rest of the fused pipeline runs on this output before the host sees the flag
+    if (!fixup_position(keys_in, n, i, k0, pos)) { atomicExch(overflow, 1u); pos = i; }
+    keys_out[pos] = k0;
+    vals_out[pos] = t;
+    fill_leaf(pos, t, vidx, ids, n, leaf, parent, bounded, nullptr);
 }
 
 // ---------------------------------------------------------------- delta / determineRange / findSplit
@@ -307,10 +330,15 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
 }
 
 // Levels above the 512-leaf blocks: heap nodes [1, nbp2).  One workgroup; children at or beyond the last real
-// block are the identity.  (nbp2 = blocks rounded up to a power of two.)
+// block are the identity.  (nbp2 = blocks rounded up to a power of two.)  A level is a dependent step, so the
+// levels with at most TOP_LDS nodes live in LDS (a workgroup barrier + LDS latency per level instead of an L2 round
+// trip): at 1 M triangles that is all 11 of them; wider levels of larger inputs go through memory first.
+constexpr int TOP_LDS = 1024;
 __global__ __launch_bounds__(1024) void k_refit_seg_top(double *seg, int nbp2, int nblocks)
 {
-    for (int cnt = nbp2 >> 1; cnt >= 1; cnt >>= 1) {                    // level with `cnt` nodes: k in [cnt, 2 cnt)
+    __shared__ double t[2 * TOP_LDS][6];                                // heap slots [1, 2 TOP_LDS): 96 KB of the CU's 160 KB
+    int cnt = nbp2 >> 1;
+    for (; cnt > TOP_LDS; cnt >>= 1) {                                  // level with `cnt` nodes: k in [cnt, 2 cnt)
         for (int u = threadIdx.x; u < cnt; u += blockDim.x) {
             const int k = cnt + u;
             // a child 2k / 2k+1 on the block level (>= nbp2) exists only if its block index < nblocks
@@ -321,6 +349,31 @@ __global__ __launch_bounds__(1024) void k_refit_seg_top(double *seg, int nbp2, i
             store_box(seg, k, box_merge(L, R));
         }
         __syncthreads();                                                // workgroup-scope: the next level reads these
+    }
+    if (cnt < 1) return;
+    {   // first LDS level: children still come from memory
+        const int u = threadIdx.x;
+        if (u < cnt) {
+            const int k = cnt + u, c0 = 2 * k, c1 = 2 * k + 1;
+            const bool blocklevel = c0 >= nbp2;
+            const Box L = (blocklevel && c0 - nbp2 >= nblocks) ? box_identity() : load_box(seg, c0);
+            const Box R = (blocklevel && c1 - nbp2 >= nblocks) ? box_identity() : load_box(seg, c1);
+            const Box m = box_merge(L, R);
+            double *d = t[k];
+            d[0] = m.x1; d[1] = m.x2; d[2] = m.y1; d[3] = m.y2; d[4] = m.z1; d[5] = m.z2;
+            store_box(seg, k, m);
+        }
+    }
+    for (cnt >>= 1; cnt >= 1; cnt >>= 1) {
+        __syncthreads();
+        const int u = threadIdx.x;
+        if (u < cnt) {
+            const int k = cnt + u;
+            const Box m = box_merge(lds_box(t, 2 * k), lds_box(t, 2 * k + 1));
+            double *d = t[k];
+            d[0] = m.x1; d[1] = m.x2; d[2] = m.y1; d[3] = m.y2; d[4] = m.z1; d[5] = m.z2;
+            store_box(seg, k, m);
+        }
     }
 }
 

@@ -313,6 +313,35 @@ constexpr int FIX_MAX = 16;
 // Out of place (in -> out): thread i finds its run by looking at most FIX_MAX keys back and forward and counts the
 // keys of the run that must precede its own -- earlier ones with key <= mine, later ones with key < mine (stable) --
 // which is its position inside the run.  Typical cost: two neighbour reads and one copy.
+// Final position of key i (value k0) inside its run of equal high halves; false if the run may exceed FIX_MAX.
+// The two neighbours are fetched up front (independent loads): for most keys they already end the run.
+__device__ __forceinline__ bool fixup_position(const uint64_t *__restrict__ keys_in, uint32_t n, uint32_t i, uint64_t k0, uint32_t &pos)
+{
+    const uint32_t h = (uint32_t)(k0 >> 32);
+    const uint64_t kp = i > 0 ? keys_in[i - 1] : ~k0, kn = i + 1 < n ? keys_in[i + 1] : ~k0;   // ~k0: a different high half
+    uint32_t back = 0, before = 0, fwd = 0;
+    if ((uint32_t)(kp >> 32) == h) {
+        before += kp <= k0; back = 1;
+        while (back < (uint32_t)FIX_MAX && back < i) {
+            const uint64_t kb = keys_in[i - 1 - back];
+            if ((uint32_t)(kb >> 32) != h) break;
+            before += kb <= k0;
+            ++back;
+        }
+    }
+    if ((uint32_t)(kn >> 32) == h) {
+        before += kn < k0; fwd = 1;
+        while (fwd < (uint32_t)FIX_MAX && i + 1 + fwd < n) {
+            const uint64_t kf = keys_in[i + 1 + fwd];
+            if ((uint32_t)(kf >> 32) != h) break;
+            before += kf < k0;
+            ++fwd;
+        }
+    }
+    pos = i - back + before;
+    return back < (uint32_t)FIX_MAX && fwd < (uint32_t)FIX_MAX;
+}
+
 __global__ __launch_bounds__(256) void k_sort_fixup(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                     uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n,
                                                     uint32_t *__restrict__ overflow)
@@ -320,25 +349,11 @@ __global__ __launch_bounds__(256) void k_sort_fixup(const uint64_t *__restrict__
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint64_t k0 = keys_in[i];
-    const uint32_t h = (uint32_t)(k0 >> 32);
-    uint32_t back = 0, before = 0;
-    while (back < (uint32_t)FIX_MAX && back < i) {
-        const uint64_t kb = keys_in[i - 1 - back];
-        if ((uint32_t)(kb >> 32) != h) break;
-        before += kb <= k0;
-        ++back;
-    }
-    uint32_t fwd = 0;
-    while (fwd < (uint32_t)FIX_MAX && i + 1 + fwd < n) {
-        const uint64_t kf = keys_in[i + 1 + fwd];
-        if ((uint32_t)(kf >> 32) != h) break;
-        before += kf < k0;
-        ++fwd;
-    }
-    if (back == (uint32_t)FIX_MAX || fwd == (uint32_t)FIX_MAX) { atomicExch(overflow, 1u); return; }   // run may be longer than FIX_MAX
-    const uint32_t pos = i - back + before;
+    const uint32_t v0 = vals_in[i];
+    uint32_t pos;
+    if (!fixup_position(keys_in, n, i, k0, pos)) { atomicExch(overflow, 1u); pos = i; }   // run may be longer than FIX_MAX: flag, keep a valid permutation
     keys_out[pos] = k0;
-    vals_out[pos] = vals_in[i];
+    vals_out[pos] = v0;
 }
 
 }  // namespace cd

@@ -68,7 +68,21 @@ struct QuerySrc {
     const double  *boxes;         // local: node boxes (query box = boxes[(n-1)+j])
     const void    *ext;           // external: cd_query records (88 B)
     const uint2   *list;          // deep pass: deferred (query index, subtree root) work items
+    const uint32_t *sort_flags;   // 9 words, non-zero = the sort of this pipeline run failed (look-back time-out, or a half-key
+                                  // run longer than the fix-up handles): the tree behind it is not a tree, do not walk it
 };
+
+// A fused call enqueues the traversal before the host has seen the sort's flags; keys that are not sorted can give
+// child links with cycles, and a descent over them would never end.  Every traversal kernel starts with this
+// (wave-uniform, 9 scalar loads); the host reads the same flags afterwards and redoes the whole step.
+__device__ __forceinline__ bool sort_failed(const QuerySrc &src)
+{
+    if (!src.sort_flags) return false;
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) any |= src.sort_flags[i];
+    return any != 0;
+}
 
 struct ExtQuery { double v[9]; uint32_t id; uint32_t vidx[3]; };
 static_assert(sizeof(ExtQuery) == 88, "cd_query layout");
@@ -105,6 +119,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_
                                                            uint2 *__restrict__ defer_list, uint32_t defer_cap,
                                                            int32_t *__restrict__ deep_stacks, uint32_t vbase)
 {
+    if (sort_failed(src)) return;
     __shared__ int32_t lds_stack[DEEP ? 1 : TRAV_STACK][TRAV_THREADS];
     const uint32_t tid = threadIdx.x;
     const uint32_t gi = blockIdx.x * TRAV_THREADS + tid;
@@ -197,6 +212,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                                                           uint2 *__restrict__ defer_list, uint32_t defer_cap,
                                                           int32_t *__restrict__ deep_stacks)
 {
+    if (sort_failed(src)) return;
     __shared__ int32_t lds_stack[DEEP ? 1 : WQ_STACK][TRAV_THREADS];
     __shared__ Candidates queue[WQ_WAVES][WQ_QCAP];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -403,6 +419,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend_packet(QuerySrc src, u
                                                                  TravState *__restrict__ st,
                                                                  Candidates *__restrict__ cand, unsigned long long shard_cap)
 {
+    if (sort_failed(src)) return;
     __shared__ int32_t stack[WQ_WAVES][PK_STACK];
     __shared__ Candidates queue[WQ_WAVES][WQ_QCAP];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

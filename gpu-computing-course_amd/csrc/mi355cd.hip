@@ -70,6 +70,7 @@ struct cd_ctx {
     cd_stats stats = {};
     uint32_t sort_flags[9] = {};            // [0..7] look-back time-out words of the last sort, [8] half-key fix-up overflow; refreshed by read_state()
     bool stage_events = true;               // CD_OPT_STAGE_TIMING
+    bool leaves_filled = false;             // the sort's fix-up hop already wrote leaf[], parent = -1, bounded = 0
     bool events_ride = false;               // the last pass recorded EV_TRAV0 / EV_DESC1 / EV_TRAV1 through its kernels' dispatch packets
     bool prezeroed = false;                 // fused path: the scratch block was zeroed by one memset at pipeline start
     bool sort_full = false;                 // true: all 8 digit passes (forced, or after a fix-up overflow on this context)
@@ -154,7 +155,12 @@ int enqueue_morton_sort(cd_ctx *c)
                                                     c->d_os_ticket + pass, pass == first_digit);
         cur ^= 1;
     }
-    if (!c->sort_full) k_sort_fixup<<<cdiv(n, 256), 256, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, c->d_os_ticket + 16);
+    c->leaves_filled = false;
+    if (!c->sort_full) {
+        k_sort_fixup_fill<<<cdiv(n, 256), 256, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, c->d_os_ticket + 16,
+                                                       c->d_vidx, c->d_ids, c->d_leaf, c->d_parent, c->d_bounded);
+        c->leaves_filled = true;                // by the fix-up hop; enqueue_hierarchy runs k_fill_leaves otherwise
+    }
     c->stats.sort_passes = c->sort_full ? 8 : 4;
     HIPCHK(evrec(c, EV_SORT1));
     HIPCHK(hipGetLastError());
@@ -167,7 +173,10 @@ int enqueue_hierarchy(cd_ctx *c, bool poison_boxes)
     hipStream_t s = c->stream;
     HIPCHK(evrec(c, EV_HIER0));
     if (!c->prezeroed) HIPCHK(hipMemsetAsync(c->d_small, 0, 16 * sizeof(uint32_t), s));
-    k_fill_leaves<<<cdiv(n, 256), 256, 0, s>>>(c->d_perm[0], c->d_vidx, c->d_ids, n, c->d_leaf, c->d_parent, c->d_bounded, poison_boxes ? c->d_boxes : nullptr);
+    // (a repeated cd_build_hierarchy needs the parent links reset again: the flag is good for one use)
+    if (!c->leaves_filled || poison_boxes)
+        k_fill_leaves<<<cdiv(n, 256), 256, 0, s>>>(c->d_perm[0], c->d_vidx, c->d_ids, n, c->d_leaf, c->d_parent, c->d_bounded, poison_boxes ? c->d_boxes : nullptr);
+    c->leaves_filled = false;
     if (n > 1)
         k_hierarchy<<<cdiv(n - 1, 256), 256, 0, s>>>(c->d_keys[0], (int)n, c->d_meta, c->d_parent, c->d_small);
     HIPCHK(evrec(c, EV_HIER1));
@@ -291,7 +300,7 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     c->stats.stack_overflows = 0;
     for (int attempt = 0; attempt < 8 && !done; ++attempt) {
         launches = 0; deep_ms = 0.f;
-        QuerySrc src{c->d_leaf, c->d_boxes, d_ext, nullptr};
+        QuerySrc src{c->d_leaf, c->d_boxes, d_ext, nullptr, c->d_os_ticket + 8};
         const bool will_ride = !c->stage_events && c->trav_variant == 1 && nq > 0;   // see launch_pass: events on the dispatch packets
         c->events_ride = false;
         if (!will_ride) HIPCHK(evrec(c, EV_TRAV0));
@@ -435,6 +444,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_frame, sizeof(double) * 6);
     ALLOC(c->d_partial, sizeof(double) * 6 * BOUNDS_BLOCKS);
     ALLOC(c->d_leaf, sizeof(LeafTri) * n);
+    HIPCHK(hipMemset(c->d_leaf, 0, sizeof(LeafTri) * n));      // a failed sort may leave slots unwritten for one (discarded) run: keep their vertex ids in range
     ALLOC(c->d_meta, sizeof(NodeMeta) * n);
     ALLOC(c->d_parent, sizeof(int32_t) * 2 * n);
     { uint32_t nb = cdiv(nt, REFIT_BLK); c->nbp2 = 1; while (c->nbp2 < nb) c->nbp2 <<= 1; }

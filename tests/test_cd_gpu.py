@@ -468,6 +468,20 @@ def test_half_key_sort_equals_full_sort_and_falls_back():
         assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
         cd.self_collide()
         assert cd.stats().sort_passes == 8                                  # and stays in full mode for this context
+    # the same on a FRESH context with thousands of triangles in one cell: the fused call has already enqueued
+    # hierarchy / refit / traversal behind the failed half-key sort -- they must stay in bounds and terminate
+    # (the traversal kernels skip on the sort's flags), and the redo must give the oracle's result
+    c3 = np.array([1.0, 0.0, 0.5]) + (rng.random((4000, 1, 3)) - 0.5) * 1e-5
+    v3 = (c3 + (rng.random((4000, 3, 3)) - 0.5) * 1e-6).reshape(-1, 3)
+    t3 = np.arange(12000, dtype=np.uint32).reshape(4000, 3)
+    r3 = oracle.pipeline(v3, t3)
+    for variant in VARIANTS:
+        with mi355cd.CollisionDetector(v3, t3) as cd:
+            cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
+            pairs, n, rc = cd.self_collide(cap=1 << 22)
+            assert rc == 0 and cd.stats().sort_passes == 8
+            assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r3["pairs"]))
+            assert cd.stats().pairs_tested == r3["stats"].pairs_tested
 
 
 def test_stage_timing_switch_changes_only_the_timers():
