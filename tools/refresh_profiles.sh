@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): rocprofv3 summaries of the default bench command + HBM counters.
+# Output lands in gpurun_out/prof_final/ ; tools/summarise_profiles.py turns it into profiles/<round>/.
+set -e
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_final; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench_plain.json 2> $O/bench_plain.err
+echo "plain bench done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o run -- python3 $R/bench.py > $O/bench_under_rocprof.json 2> $O/trace.err
+echo "kernel trace done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+echo "FETCH_SIZE pass done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_write.json 2> $O/pmc_write.err
+echo "WRITE_SIZE pass done"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -o run -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_sq.json 2> $O/pmc_sq.err
+echo "SQ pass done"
+rm -f $O/trace/run_kernel_trace.csv        # tens of MB; the stats file is the summary
+ls -la $O $O/trace
