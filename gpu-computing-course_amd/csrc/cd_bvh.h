@@ -212,13 +212,23 @@ __device__ __forceinline__ Box load_box(const double *boxes, int node)
 
 // fp32 traversal record of one internal node (64 bytes): both child boxes rounded outward, both child ids
 // already encoded (internal i >= 0, leaf j -> ~j).
+// A box whose six coordinates are fp32 values (the reference parses OBJ coordinates as float, load_obj.h:38, so that
+// is the normal case): its outward-rounded fp32 copy IS the box, and an fp32 overlap test against another such box
+// decides exactly what box.cuh:40-43 decides in FP64.
+__device__ __forceinline__ bool box_is_fp32(const Box &b)
+{
+    return (double)(float)b.x1 == b.x1 && (double)(float)b.x2 == b.x2 && (double)(float)b.y1 == b.y1 &&
+           (double)(float)b.y2 == b.y2 && (double)(float)b.z1 == b.z1 && (double)(float)b.z2 == b.z2;
+}
+
 __device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ r, const Box &bl, const Box &br, int2 ch)
 {
     float4 *p = reinterpret_cast<float4 *>(r);
     p[0] = make_float4(__double2float_rd(bl.x1), __double2float_rd(bl.y1), __double2float_rd(bl.z1), __double2float_ru(bl.x2));
     p[1] = make_float4(__double2float_ru(bl.y2), __double2float_ru(bl.z2), __double2float_rd(br.x1), __double2float_rd(br.y1));
     p[2] = make_float4(__double2float_rd(br.z1), __double2float_ru(br.x2), __double2float_ru(br.y2), __double2float_ru(br.z2));
-    reinterpret_cast<int4 *>(r)[3] = make_int4(ch.x, ch.y, 0, 0);
+    // word 2 of the last quad: bit 0 / bit 1 = the left / right child box is exactly representable (box_is_fp32)
+    reinterpret_cast<int4 *>(r)[3] = make_int4(ch.x, ch.y, (box_is_fp32(bl) ? 1 : 0) | (box_is_fp32(br) ? 2 : 0), 0);
 }
 
 // ---------------------------------------------------------------- calBoundingBox as RANGE QUERIES

@@ -201,7 +201,10 @@ constexpr int WQ_STACK = 12;                 // LDS stack entries per lane (12 K
 constexpr int WQ_QCAP  = 192;                // queue slots per wave: < 64 left over + at most 128 new per step
 constexpr int WQ_WAVES = TRAV_THREADS / 64;
 
+// leaf: bit 31 set = both boxes are exact in fp32 (cd_bvh.h box_is_fp32), so the fp32 overlap found by the descent IS
+// the exact leaf-AABB test and k_exact need not fetch the two FP64 boxes again
 struct Candidates { uint32_t q, leaf; };
+constexpr uint32_t CAND_CERTAIN = 0x80000000u;
 
 // queries_per_wave: size of the contiguous chunk of queries one wave works through (multiple of 64).
 template <bool EXTERNAL, bool DEEP, bool REFILL>
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
     uint32_t tested = 0, visits = 0, steps = 0;
     int32_t node = -1; int sptr = 0; uint32_t qi = 0, self_leaf = 0xffffffffu;
     float qlo0 = 0, qlo1 = 0, qlo2 = 0, qhi0 = 0, qhi1 = 0, qhi2 = 0;
+    uint32_t qcertain = 0;                              // CAND_CERTAIN if the query box is exact in fp32
     int32_t *gstack = DEEP ? deep_stacks + ((size_t)wave_id * 64 + lane) * DEEP_STACK : nullptr;
     const int stack_cap = DEEP ? DEEP_STACK : WQ_STACK;
 
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                     qlo0 = __double2float_rd(qb.x1); qhi0 = __double2float_ru(qb.x2);
                     qlo1 = __double2float_rd(qb.y1); qhi1 = __double2float_ru(qb.y2);
                     qlo2 = __double2float_rd(qb.z1); qhi2 = __double2float_ru(qb.z2);
+                    qcertain = box_is_fp32(qb) ? CAND_CERTAIN : 0u;
                     sptr = 0;
                 }
                 const uint32_t taken = __popcll(mi);
@@ -314,10 +319,10 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                     const float phi0 = __int_as_float(go_left ? r0.w : r2.y), phi1 = __int_as_float(go_left ? r1.x : r2.z), phi2 = __int_as_float(go_left ? r1.y : r2.w);
                     const bool ph = valid & (qi != g0) & (qlo0 < phi0) & (plo0 < qhi0) & (qlo1 < phi1) & (plo1 < qhi1) & (qlo2 < phi2) & (plo2 < qhi2);
                     const unsigned long long mP = __ballot(ph);
-                    if (mP) { if (ph) queue[w][qcount + __popcll(mP & lt_mask)] = Candidates{qi, g0}; qcount += __popcll(mP); }
+                    if (mP) { if (ph) queue[w][qcount + __popcll(mP & lt_mask)] = Candidates{qi, g0 | ((r3.z & (go_left ? 1 : 2)) ? qcertain : 0u)}; qcount += __popcll(mP); }
                 }
                 const unsigned long long mC = __ballot(cnd);
-                if (mC) { if (cnd) queue[w][qcount + __popcll(mC & lt_mask)] = Candidates{qi, cleaf}; qcount += __popcll(mC); }
+                if (mC) { if (cnd) queue[w][qcount + __popcll(mC & lt_mask)] = Candidates{qi, cleaf | ((r3.z & (go_left ? 2 : 1)) ? qcertain : 0u)}; qcount += __popcll(mC); }
                 while (qcount >= 64) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     const Candidates cd0 = queue[w][qcount - 64 + lane];
@@ -368,8 +373,8 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
         if ((mL | mR) == 0ull) continue;
         {
             const uint32_t nL = __popcll(mL);
-            if (candL) queue[w][qcount + __popcll(mL & lt_mask)] = Candidates{qi, leafL};
-            if (candR) queue[w][qcount + nL + __popcll(mR & lt_mask)] = Candidates{qi, leafR};
+            if (candL) queue[w][qcount + __popcll(mL & lt_mask)] = Candidates{qi, leafL | ((ch.z & 1) ? qcertain : 0u)};
+            if (candR) queue[w][qcount + nL + __popcll(mR & lt_mask)] = Candidates{qi, leafR | ((ch.z & 2) ? qcertain : 0u)};
             qcount += nL + __popcll(mR);
         }
         while (qcount >= 64) {                                   // full batch -> global buffer, 512 B coalesced
@@ -604,25 +609,28 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
                 c[j] = cand[(size_t)lo * shard_cap + (k - pre[lo])];
             }
         }
-        LeafTri lt[EXACT_ITEMS]; Box lb[EXACT_ITEMS], qbox[EXACT_ITEMS]; uint32_t q_id[EXACT_ITEMS], qa[EXACT_ITEMS], qb[EXACT_ITEMS], qc[EXACT_ITEMS];
+        LeafTri lt[EXACT_ITEMS]; Box lb[EXACT_ITEMS], qbox[EXACT_ITEMS]; bool certain[EXACT_ITEMS]; uint32_t q_id[EXACT_ITEMS], qa[EXACT_ITEMS], qb[EXACT_ITEMS], qc[EXACT_ITEMS];
 #pragma unroll
         for (int j = 0; j < EXACT_ITEMS; ++j) {
-            const uint32_t qi = c[j].q, lj = c[j].leaf;        // (0, 0) for lanes past the end: harmless in-bounds loads
+            const uint32_t qi = c[j].q, lj = c[j].leaf & ~CAND_CERTAIN;   // (0, 0) for lanes past the end: harmless in-bounds loads
+            certain[j] = (c[j].leaf & CAND_CERTAIN) != 0;
+            c[j].leaf = lj;
             lt[j] = leaf[lj];
-            lb[j] = load_box(boxes, (n - 1) + (int)lj);
+            lb[j] = qbox[j] = Box{0, 0, 0, 0, 0, 0};
+            if (!certain[j]) lb[j] = load_box(boxes, (n - 1) + (int)lj);
             if (EXTERNAL) {
                 const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + qi;
                 q_id[j] = q->id; qa[j] = q->vidx[0]; qb[j] = q->vidx[1]; qc[j] = q->vidx[2];
-                qbox[j] = box_set(d3{q->v[0], q->v[1], q->v[2]}, d3{q->v[3], q->v[4], q->v[5]}, d3{q->v[6], q->v[7], q->v[8]});
+                if (!certain[j]) qbox[j] = box_set(d3{q->v[0], q->v[1], q->v[2]}, d3{q->v[3], q->v[4], q->v[5]}, d3{q->v[6], q->v[7], q->v[8]});
             } else {
                 const LeafTri ql = leaf[qi];
                 q_id[j] = ql.id; qa[j] = ql.v0; qb[j] = ql.v1; qc[j] = ql.v2;
-                qbox[j] = load_box(boxes, (n - 1) + (int)qi);
+                if (!certain[j]) qbox[j] = load_box(boxes, (n - 1) + (int)qi);
             }
         }
 #pragma unroll
         for (int j = 0; j < EXACT_ITEMS; ++j) {
-            if (ok[j] && box_overlap(qbox[j], lb[j])) {                        // collision.cuh:31-32, exact
+            if (ok[j] && (certain[j] || box_overlap(qbox[j], lb[j]))) {        // collision.cuh:31-32, exact (certain: already decided exactly by the descent)
                 ++tested;
                 const bool survive = neighbor_count(qa[j], qb[j], qc[j], lt[j].v0 + vbase, lt[j].v1 + vbase, lt[j].v2 + vbase) < 1   // collision.cuh:38
                                      && q_id[j] < lt[j].id;                    // tri_contact.cuh:81

@@ -506,3 +506,29 @@ def test_stage_timing_switch_changes_only_the_timers():
         assert cd.check_internal().tolist() == [1, 0, 0, 0, 0]
         pairs, n, rc = cd.find_collisions()
         assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+
+
+@pytest.mark.parametrize("kind", ["double", "mixed", "float"])
+def test_exact_leaf_test_with_and_without_fp32_representable_boxes(kind):
+    """Boxes whose coordinates are fp32 values are decided exactly by the fp32 descent (flagged candidates skip the
+    FP64 box fetch in k_exact); anything else goes through the FP64 test.  Full-precision doubles, float-rounded
+    input and a half-and-half mix must all give the oracle's pairs-tested count and pair set -- including meshes,
+    whose neighbour boxes touch exactly (strict overlap says no)."""
+    rng = np.random.default_rng(99)
+    verts, vidx = synth.cloth_pair(40)
+    sv, st = synth.soup(3000, 0.05, 17)
+    if kind == "double":
+        verts = verts + (rng.random(verts.shape) - 0.5) * 1e-9              # no longer fp32 values; mesh neighbours still share vertices
+        sv = sv + (rng.random(sv.shape) - 0.5) * 1e-9
+    elif kind == "mixed":
+        sv = sv + (rng.random(sv.shape) - 0.5) * 1e-9
+    assert (verts.astype(np.float32).astype(np.float64) == verts).all() == (kind != "double")
+    v = np.concatenate([verts, sv]); t = np.concatenate([vidx, st + verts.shape[0]]).astype(np.uint32)
+    r = oracle.pipeline(v, t)
+    for variant in VARIANTS:
+        with mi355cd.CollisionDetector(v, t) as cd:
+            cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
+            pairs, n, rc = cd.self_collide(cap=1 << 22)
+            assert rc == 0 and n == r["stats"].n_pairs
+            assert cd.stats().pairs_tested == r["stats"].pairs_tested
+            assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
