@@ -40,30 +40,38 @@ __global__ __launch_bounds__(256) void k_prepare(const RtSphere *__restrict__ s,
     geom[i] = g; shade[i] = h;
 }
 
-struct Px { float r, g, b, maxz; };
+// Per pixel only the winner is tracked -- its index, its dz and the running maximum of t: the normalisation
+// n = dz / sqrtf(r*r) and the three colour products (sphere.cuh:41, anime_ray.cu:77-80) depend on nothing but the
+// winning sphere, so they are evaluated once per pixel after the loop instead of once per hit (same operands, same
+// operations, same bits).  That takes the IEEE division and the shade fetch out of the divergent hit branch.
+struct Px { float maxz, dz; int win; };
 
 // One sphere against one pixel: sphere.cuh:36-43 + anime_ray.cu:75-81.
-__device__ __forceinline__ void shade_one(Px &p, float ox, float oy, const SphGeom g, const SphShade *__restrict__ shade, int i)
+__device__ __forceinline__ void shade_one(Px &p, float ox, float oy, const SphGeom g, int i)
 {
     const float dx = ox - g.cx;
     const float dy = oy - g.cy;
     const float dx2 = dx * dx, dy2 = dy * dy;
     if (dx2 + dy2 < g.rr) {
-        const SphShade h = shade[i];
         const float dz = sqrtf(g.rr - dx2 - dy2);
-        const float n = dz / h.sr;
         const float t = dz + g.z;
-        if (t > p.maxz) { p.r = h.r * n; p.g = h.g * n; p.b = h.b * n; p.maxz = t; }   // strict: lowest index wins
+        if (t > p.maxz) { p.maxz = t; p.dz = dz; p.win = i; }                           // strict: lowest index wins
     }
 }
 
-__device__ __forceinline__ uint32_t pack_px(const Px &p)
+__device__ __forceinline__ uint32_t pack_px(const Px &p, const SphShade *__restrict__ shade)
 {
+    float r = 0.f, g = 0.f, b = 0.f;                                                   // anime_ray.cu:68
+    if (p.win >= 0) {
+        const SphShade h = shade[p.win];
+        const float n = p.dz / h.sr;                                                   // sphere.cuh:41
+        r = h.r * n; g = h.g * n; b = h.b * n;                                         // anime_ray.cu:77-79
+    }
     // anime_ray.cu:84-87: (int)(c * 255) stored to unsigned char; alpha 255
-    const uint32_t r = (uint32_t)(unsigned char)(int)(p.r * 255);
-    const uint32_t g = (uint32_t)(unsigned char)(int)(p.g * 255);
-    const uint32_t b = (uint32_t)(unsigned char)(int)(p.b * 255);
-    return r | (g << 8) | (b << 16) | (255u << 24);
+    const uint32_t ri = (uint32_t)(unsigned char)(int)(r * 255);
+    const uint32_t gi = (uint32_t)(unsigned char)(int)(g * 255);
+    const uint32_t bi = (uint32_t)(unsigned char)(int)(b * 255);
+    return ri | (gi << 8) | (bi << 16) | (255u << 24);
 }
 
 // Exact conservative cull of one sphere against the pixel rectangle [X0,X1] x [Y0,Y1] (inclusive).  For a column x
@@ -81,6 +89,7 @@ __device__ __forceinline__ bool may_touch(const SphGeom g, float ox0, float ox1,
     return !(mx * mx + my * my >= g.rr);
 }
 
+constexpr int TEST_SHARDS = 64;         // sphere-test counter shards, 128 bytes apart
 constexpr int SUPER = 256;             // super-tile edge in pixels (4 x 4 tiles)
 
 // Level 1 of the binning: one workgroup per 256x256 super-tile culls ALL spheres and writes the survivors, in
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) px[a][b] = Px{0.f, 0.f, 0.f, -RT_INF};                // anime_ray.cu:68-69
+        for (int b = 0; b < 4; ++b) px[a][b] = Px{-RT_INF, 0.f, -1};                // anime_ray.cu:68-69
 
     if (!BINNED) {
         for (int i = 0; i < n; ++i) {
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) shade_one(px[a][b], ox[b], oy[a], g, shade, i);
+                for (int b = 0; b < 4; ++b) shade_one(px[a][b], ox[b], oy[a], g, i);
         }
     } else {
         // ---- level 2 of the binning: cull this tile's super-tile survivors (may_touch above), keeping index order
@@ -192,17 +201,18 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) shade_one(px[a][b], ox[b], oy[a], g, shade, i);
+                    for (int b = 0; b < 4; ++b) shade_one(px[a][b], ox[b], oy[a], g, i);
             }
             mytests += (unsigned long long)c;
         }
-        if (tid == 0 && tests) atomicAdd(tests, mytests * (unsigned long long)(TILE * TILE));
+        // 64 counter shards on separate 128-B lines: one word for all 4096 workgroups serialises them (~10 ns each)
+        if (tid == 0 && tests) atomicAdd(tests + 16 * ((blockIdx.y * gridDim.x + blockIdx.x) & (TEST_SHARDS - 1)), mytests * (unsigned long long)(TILE * TILE));
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int y = Y0 + ty + 16 * a;
         uint4 o;
-        o.x = pack_px(px[a][0]); o.y = pack_px(px[a][1]); o.z = pack_px(px[a][2]); o.w = pack_px(px[a][3]);
+        o.x = pack_px(px[a][0], shade); o.y = pack_px(px[a][1], shade); o.z = pack_px(px[a][2], shade); o.w = pack_px(px[a][3], shade);
         *reinterpret_cast<uint4 *>(rgba + (size_t)y * dim + x) = o;                       // offset = x + y*dim, anime_ray.cu:64
     }
 }
@@ -254,7 +264,7 @@ int rt_create(rt_ctx **out, const RtSphere *spheres, int32_t n_spheres, int32_t 
     ok(hipMalloc(&c->d_geom, sizeof(SphGeom) * (size_t)n_spheres));
     ok(hipMalloc(&c->d_shade, sizeof(SphShade) * (size_t)n_spheres));
     ok(hipMalloc(&c->d_rgba, sizeof(uint32_t) * (size_t)dim * dim));
-    ok(hipMalloc(&c->d_tests, sizeof(unsigned long long)));
+    ok(hipMalloc(&c->d_tests, sizeof(unsigned long long) * 16 * TEST_SHARDS));
     { const size_t ns = (size_t)((dim + SUPER - 1) / SUPER) * ((dim + SUPER - 1) / SUPER);
       ok(hipMalloc(&c->d_super_list, sizeof(int) * ns * (size_t)n_spheres)); ok(hipMalloc(&c->d_super_count, sizeof(int) * ns)); }
     if (e == hipSuccess) ok(hipMemcpy(c->d_spheres, spheres, sizeof(RtSphere) * (size_t)n_spheres, hipMemcpyHostToDevice));
@@ -291,7 +301,7 @@ int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, 
     if (!c || !shifts4 || y0 < 0 || y1 > c->dim || y0 >= y1 || y0 % TILE || y1 % TILE) return RT_ERR_ARG;
     hipStream_t s = c->stream;
     HIPCHK(hipMemcpyAsync(c->d_shifts, shifts4, sizeof(int32_t) * 4 * (size_t)c->n, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(c->d_tests, 0, sizeof(unsigned long long), s));
+    HIPCHK(hipMemsetAsync(c->d_tests, 0, sizeof(unsigned long long) * 16 * TEST_SHARDS, s));
     HIPCHK(hipEventRecord(c->ev0, s));
     k_prepare<<<(c->n + 255) / 256, 256, 0, s>>>(c->d_spheres, c->d_shifts, c->n, c->d_geom, c->d_shade);
     const dim3 grid(c->dim / TILE, (y1 - y0) / TILE);
@@ -307,11 +317,13 @@ int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, 
     }
     HIPCHK(hipEventRecord(c->ev1, s));
     HIPCHK(hipGetLastError());
-    unsigned long long tests = 0;
-    HIPCHK(hipMemcpyAsync(&tests, c->d_tests, sizeof tests, hipMemcpyDeviceToHost, s));
+    unsigned long long shard[16 * TEST_SHARDS];
+    HIPCHK(hipMemcpyAsync(shard, c->d_tests, sizeof shard, hipMemcpyDeviceToHost, s));
     if (rgba_out)                                                   // anime_ray.cu:128-131 D2H of the frame
         HIPCHK(hipMemcpyAsync(rgba_out, c->d_rgba + (size_t)y0 * c->dim, sizeof(uint32_t) * (size_t)(y1 - y0) * c->dim, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    unsigned long long tests = 0;
+    for (int i = 0; i < TEST_SHARDS; ++i) tests += shard[16 * i];
     float ms = 0.f;
     hipEventElapsedTime(&ms, c->ev0, c->ev1);
     c->stats.ms_render = ms;

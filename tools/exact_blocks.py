@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, "gpu-computing-course_amd/pyhost")
+import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-computing-course_amd", "pyhost"))
 import mi355cd, mi355_synth as synth
 v, t = synth.cloth_pair(500)
 with mi355cd.CollisionDetector(v, t) as cd:

@@ -1,6 +1,6 @@
 """Where the wall time of one step goes beyond the device pipeline: raw C-ABI call vs the Python step."""
-import sys, time, ctypes as C
-sys.path.insert(0, "gpu-computing-course_amd/pyhost")
+import os, sys, time, ctypes as C
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-computing-course_amd", "pyhost"))
 import numpy as np, mi355cd, mi355_synth as synth, mi355_multi as multi
 v, t = synth.cloth_pair(500)
 import torch
