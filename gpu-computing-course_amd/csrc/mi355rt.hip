@@ -28,15 +28,22 @@ constexpr int THREADS = 256;
 struct alignas(16) SphGeom { float cx, cy, rr, z; };
 struct alignas(16) SphShade { float r, g, b, sr; };
 
+__device__ __forceinline__ void prepare_one(const RtSphere *__restrict__ s, const int32_t *__restrict__ shifts, int i, SphGeom &g, SphShade &h)
+{
+    const RtSphere sp = s[i];
+    const int xs = shifts[4 * sp.idx], ys = shifts[4 * sp.idx + 1];        // sphere.cuh:35
+    g.cx = sp.x + (float)xs; g.cy = sp.y + (float)ys; g.rr = sp.radius * sp.radius; g.z = sp.z;
+    h.r = sp.r; h.g = sp.g; h.b = sp.b; h.sr = sqrtf(sp.radius * sp.radius);
+}
+
+// Brute mode only; in binned mode k_bin_super does this on the fly (one launch less per frame).
 __global__ __launch_bounds__(256) void k_prepare(const RtSphere *__restrict__ s, const int32_t *__restrict__ shifts, int n,
                                                  SphGeom *__restrict__ geom, SphShade *__restrict__ shade)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const RtSphere sp = s[i];
-    const int xs = shifts[4 * sp.idx], ys = shifts[4 * sp.idx + 1];        // sphere.cuh:35
-    SphGeom g; g.cx = sp.x + (float)xs; g.cy = sp.y + (float)ys; g.rr = sp.radius * sp.radius; g.z = sp.z;
-    SphShade h; h.r = sp.r; h.g = sp.g; h.b = sp.b; h.sr = sqrtf(sp.radius * sp.radius);
+    SphGeom g; SphShade h;
+    prepare_one(s, shifts, i, g, h);
     geom[i] = g; shade[i] = h;
 }
 
@@ -95,7 +102,8 @@ constexpr int SUPER = 256;             // super-tile edge in pixels (4 x 4 tiles
 // Level 1 of the binning: one workgroup per 256x256 super-tile culls ALL spheres and writes the survivors, in
 // ascending sphere index (wave-ordered __ballot compaction), to super_list[st][0..count).  Tiles then cull only
 // their super-tile's few dozen survivors instead of all S spheres.
-__global__ __launch_bounds__(THREADS) void k_bin_super(const SphGeom *__restrict__ geom, int n, int dim, int c_shift_x, int c_shift_y,
+__global__ __launch_bounds__(THREADS) void k_bin_super(const RtSphere *__restrict__ spheres, const int32_t *__restrict__ shifts,
+                                                       SphGeom *__restrict__ geom, SphShade *__restrict__ shade, int n, int dim, int c_shift_x, int c_shift_y,
                                                        int nsx, int sy0, int *__restrict__ super_list, int *__restrict__ super_count)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -103,6 +111,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_super(const SphGeom *__restrict
     __shared__ int wcount[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int sx = blockIdx.x, sy = blockIdx.y + sy0;
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0;
     const int X0 = sx * SUPER, Y0 = sy * SUPER;
     const int X1 = min(X0 + SUPER, dim) - 1, Y1 = min(Y0 + SUPER, dim) - 1;
     const float ox0 = (float)(X0 - dim / 2 + c_shift_x), ox1 = (float)(X1 - dim / 2 + c_shift_x);
@@ -112,7 +121,13 @@ __global__ __launch_bounds__(THREADS) void k_bin_super(const SphGeom *__restrict
     const int s_begin = w * sub_cap, s_end = min(n, s_begin + sub_cap);
     for (int base = s_begin; base < s_end; base += 64) {
         const int i = base + lane;
-        const bool keep = (i < s_end) && may_touch(geom[i], ox0, ox1, oy0, oy1);
+        bool keep = false;
+        if (i < s_end) {
+            SphGeom g; SphShade h;
+            prepare_one(spheres, shifts, i, g, h);              // the per-sphere prepass, fused: every super-tile recomputes it,
+            if (first) { geom[i] = g; shade[i] = h; }           // the first workgroup of the launch stores it for k_render
+            keep = may_touch(g, ox0, ox1, oy0, oy1);
+        }
         const unsigned long long m = __ballot(keep);
         if (keep) list[w * sub_cap + cnt + __popcll(m & ((1ull << lane) - 1ull))] = i;
         cnt += __popcll(m);
@@ -303,16 +318,16 @@ int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, 
     HIPCHK(hipMemcpyAsync(c->d_shifts, shifts4, sizeof(int32_t) * 4 * (size_t)c->n, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(c->d_tests, 0, sizeof(unsigned long long) * 16 * TEST_SHARDS, s));
     HIPCHK(hipEventRecord(c->ev0, s));
-    k_prepare<<<(c->n + 255) / 256, 256, 0, s>>>(c->d_spheres, c->d_shifts, c->n, c->d_geom, c->d_shade);
     const dim3 grid(c->dim / TILE, (y1 - y0) / TILE);
     if (c->mode == RT_MODE_BINNED) {
         const size_t lds = sizeof(int) * 4 * (size_t)((c->n + 3) / 4);
         const int nsx = (c->dim + SUPER - 1) / SUPER;
         const int sy0 = y0 / SUPER, sy1 = (y1 + SUPER - 1) / SUPER;
-        k_bin_super<<<dim3(nsx, sy1 - sy0), THREADS, lds, s>>>(c->d_geom, c->n, c->dim, csx, csy, nsx, sy0, c->d_super_list, c->d_super_count);
+        k_bin_super<<<dim3(nsx, sy1 - sy0), THREADS, lds, s>>>(c->d_spheres, c->d_shifts, c->d_geom, c->d_shade, c->n, c->dim, csx, csy, nsx, sy0, c->d_super_list, c->d_super_count);
         k_render<true><<<grid, THREADS, lds, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, y0 / TILE, c->d_rgba, c->d_tests,
                                                   c->d_super_list, c->d_super_count, nsx);
     } else {
+        k_prepare<<<(c->n + 255) / 256, 256, 0, s>>>(c->d_spheres, c->d_shifts, c->n, c->d_geom, c->d_shade);
         k_render<false><<<grid, THREADS, 0, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, y0 / TILE, c->d_rgba, nullptr, nullptr, nullptr, 0);
     }
     HIPCHK(hipEventRecord(c->ev1, s));
