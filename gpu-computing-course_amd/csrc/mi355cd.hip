@@ -106,7 +106,7 @@ int ensure_pairs(cd_ctx *c, uint64_t cap)
     if (c->d_pairs) hipFree(reinterpret_cast<char *>(c->d_pairs) - sizeof(Report));
     c->d_pairs = nullptr; c->pairs_cap = 0;
     char *block = nullptr;
-    HIPCHK(hipMalloc(&block, sizeof(Report) + sizeof(uint32_t) * 2 * cap));
+    HIPCHK(hipMalloc(&block, sizeof(Report) + sizeof(uint32_t) * 2 * cap + 16));      // +16: k_report moves pairs as 16-byte quads
     c->d_pairs = reinterpret_cast<uint32_t *>(block + sizeof(Report));
     c->pairs_cap = cap;
     return 0;
@@ -252,15 +252,15 @@ struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_can
 
 constexpr uint64_t SPEC_PAIRS = 1u << 15;     // pairs copied back speculatively together with the counters (256 KB)
 
-// One host round trip and ONE copy: k_report gathers counters, the sort's time-out flags and the root box into the
-// record in front of the pair list; record + the first spec_n pairs land in pinned memory.
+// One host round trip and NO copy: k_report writes counters, the sort's time-out flags, the root box and the first
+// spec_n pairs straight into pinned host memory.
 int read_state(cd_ctx *c, HostCounters &h, uint32_t *spec_pairs = nullptr, uint64_t spec_n = 0)
 {
     if (!c->h_report) HIPCHK(hipHostMalloc(&c->h_report, sizeof(Report) + sizeof(uint32_t) * 2 * SPEC_PAIRS, hipHostMallocDefault));
     if (!spec_pairs || spec_n > SPEC_PAIRS) spec_n = spec_pairs ? SPEC_PAIRS : 0;
-    Report *d_rep = reinterpret_cast<Report *>(reinterpret_cast<char *>(c->d_pairs) - sizeof(Report));
-    k_report<<<1, 64, 0, c->stream>>>(c->d_state, c->d_os_ticket + 8, c->d_boxes, d_rep);
-    HIPCHK(hipMemcpyAsync(c->h_report, d_rep, sizeof(Report) + sizeof(uint32_t) * 2 * spec_n, hipMemcpyDeviceToHost, c->stream));
+    // (the pair list is allocated with an even capacity + slack, so the quad copy may read one pair past `take`)
+    k_report<<<spec_n ? 32 : 1, REPORT_THREADS, 0, c->stream>>>(c->d_state, c->d_os_ticket + 8, c->d_boxes, reinterpret_cast<Report *>(c->h_report),
+                                                              c->d_pairs, reinterpret_cast<uint32_t *>(c->h_report + sizeof(Report)), (unsigned long long)spec_n);
     HIPCHK(hipStreamSynchronize(c->stream));
     const Report &r = *reinterpret_cast<const Report *>(c->h_report);
     h = HostCounters{r.n_pairs, r.pairs_tested, r.node_visits, r.max_shard_candidates, r.n_deferred, r.wave_steps, r.candidates};
