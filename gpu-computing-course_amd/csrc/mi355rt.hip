@@ -232,6 +232,84 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- animation state (sphere.cuh:50-118)
+// XORWOW as <curand_kernel.h> implements it for curand_init(seed, 0, 0): no skip-ahead, seed scrambled by two odd
+// multipliers, five xorshift words + a Weyl counter.  Restated from the published algorithm (the header is not in the
+// reference tree); see oracle/rt_oracle.c for the parity status of the random stream.
+struct Xorwow { uint32_t v[5]; uint32_t d; };
+
+__device__ __forceinline__ void xorwow_init(Xorwow &s, unsigned long long seed)
+{
+    const uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u, s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    const uint32_t t0 = 1099087573u * s0, t1 = 2591861531u * s1;
+    s.d = 6615241u + t1 + t0;
+    s.v[0] = 123456789u + t0; s.v[1] = 362436069u ^ t0; s.v[2] = 521288629u + t1; s.v[3] = 88675123u ^ t1; s.v[4] = 5783321u + t0;
+}
+__device__ __forceinline__ uint32_t xorwow_next(Xorwow &s)
+{
+    const uint32_t t = s.v[0] ^ (s.v[0] >> 2);
+    s.v[0] = s.v[1]; s.v[1] = s.v[2]; s.v[2] = s.v[3]; s.v[3] = s.v[4];
+    s.v[4] = (s.v[4] ^ (s.v[4] << 4)) ^ (t ^ (t << 1));
+    s.d += 362437u;
+    return s.v[4] + s.d;
+}
+// dev_rnd(x, s), sphere.cuh:26
+__device__ __forceinline__ double dev_rnd(int x, Xorwow &s) { return xorwow_next(s) % 1000000u * 1.0 / 1000000 * x; }
+
+constexpr double ANIM_PI = 3.1415926535898;                           // sphere.cuh:19
+
+// The reference launches these with <<<128, 1>>> and a block-stride loop; one thread per sphere gives the same state.
+__global__ __launch_bounds__(256) void k_anim_init(int n, Xorwow *__restrict__ st, int32_t *__restrict__ shifts, double *__restrict__ angles)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Xorwow s; xorwow_init(s, (unsigned long long)i);                   // curand_init(i, 0, 0, &states[i]), sphere.cuh:53
+    st[i] = s;
+    shifts[4 * i] = shifts[4 * i + 1] = 0;
+    shifts[4 * i + 2] = (i % 5 + 1) * 5;
+    shifts[4 * i + 3] = (i % 2) * 2 - 1;
+    angles[i] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_anim_axis(int n, Xorwow *__restrict__ st, int32_t *__restrict__ shifts, int shake_width)   // sphere.cuh:66-77
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Xorwow s = st[i];
+    const int x_shift = (int)dev_rnd(shake_width, s);
+    const int y_shift = (int)dev_rnd(shake_width, s);
+    shifts[4 * i] = x_shift; shifts[4 * i + 1] = y_shift;
+    st[i] = s;
+}
+
+__global__ __launch_bounds__(256) void k_anim_curve(int n, int32_t *__restrict__ shifts, double *__restrict__ angles)              // sphere.cuh:82-97
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int speed = shifts[4 * i + 2];
+    const float a = (float)angles[i];
+    // correctly rounded float cosine / sine (through the double functions); CUDA's cosf / sinf are within 2 ulp of these
+    const int x_shift = (int)((float)speed * (float)cos((double)a));
+    const int y_shift = (int)((float)speed * (float)sin((double)a));
+    shifts[4 * i] += x_shift; shifts[4 * i + 1] += y_shift;
+    angles[i] = fmod(angles[i] + ANIM_PI / 12 * shifts[4 * i + 3], 2 * ANIM_PI);
+}
+
+__global__ __launch_bounds__(256) void k_anim_speed_angle(int n, Xorwow *__restrict__ st, int32_t *__restrict__ shifts, double *__restrict__ angles,
+                                                          int update_prob, int max_speed)                                       // sphere.cuh:102-118
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Xorwow s = st[i];
+    const int p = (int)dev_rnd(10, s);
+    if (p < update_prob) {
+        shifts[4 * i + 2] = (int)dev_rnd(max_speed, s);
+        shifts[4 * i + 3] = ((int)dev_rnd(2, s)) * 2 - 1;
+        angles[i] = fmod(angles[i] + ((int)dev_rnd(2, s)) * ANIM_PI, 2 * ANIM_PI);
+    }
+    st[i] = s;
+}
+
 }  // namespace
 
 struct rt_ctx {
@@ -240,6 +318,7 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     RtSphere *d_spheres = nullptr; int32_t *d_shifts = nullptr;
+    Xorwow *d_rng = nullptr; double *d_angles = nullptr; bool anim_ready = false;   // animation state, sphere.cuh:50-61
     SphGeom *d_geom = nullptr; SphShade *d_shade = nullptr;
     uint32_t *d_rgba = nullptr; unsigned long long *d_tests = nullptr;
     int *d_super_list = nullptr, *d_super_count = nullptr;      // [nsuper][n] ordered survivor lists, [nsuper] counts
@@ -249,6 +328,7 @@ struct rt_ctx {
 namespace {
 void rt_free(rt_ctx *c)
 {
+    hipFree(c->d_rng); hipFree(c->d_angles);
     hipFree(c->d_spheres); hipFree(c->d_shifts); hipFree(c->d_geom); hipFree(c->d_shade); hipFree(c->d_rgba); hipFree(c->d_tests); hipFree(c->d_super_list); hipFree(c->d_super_count);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -276,6 +356,8 @@ int rt_create(rt_ctx **out, const RtSphere *spheres, int32_t n_spheres, int32_t 
     ok(hipEventCreate(&c->ev0)); ok(hipEventCreate(&c->ev1));
     ok(hipMalloc(&c->d_spheres, sizeof(RtSphere) * (size_t)n_spheres));
     ok(hipMalloc(&c->d_shifts, sizeof(int32_t) * 4 * (size_t)n_spheres));
+    ok(hipMalloc(&c->d_rng, sizeof(Xorwow) * (size_t)n_spheres));
+    ok(hipMalloc(&c->d_angles, sizeof(double) * (size_t)n_spheres));
     ok(hipMalloc(&c->d_geom, sizeof(SphGeom) * (size_t)n_spheres));
     ok(hipMalloc(&c->d_shade, sizeof(SphShade) * (size_t)n_spheres));
     ok(hipMalloc(&c->d_rgba, sizeof(uint32_t) * (size_t)dim * dim));
@@ -313,9 +395,9 @@ int rt_set_mode(rt_ctx *c, int mode)
 
 int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, int32_t y0, int32_t y1, uint8_t *rgba_out)
 {
-    if (!c || !shifts4 || y0 < 0 || y1 > c->dim || y0 >= y1 || y0 % TILE || y1 % TILE) return RT_ERR_ARG;
+    if (!c || (!shifts4 && !c->anim_ready) || y0 < 0 || y1 > c->dim || y0 >= y1 || y0 % TILE || y1 % TILE) return RT_ERR_ARG;
     hipStream_t s = c->stream;
-    HIPCHK(hipMemcpyAsync(c->d_shifts, shifts4, sizeof(int32_t) * 4 * (size_t)c->n, hipMemcpyHostToDevice, s));
+    if (shifts4) HIPCHK(hipMemcpyAsync(c->d_shifts, shifts4, sizeof(int32_t) * 4 * (size_t)c->n, hipMemcpyHostToDevice, s));   // NULL: the device-resident animation state
     HIPCHK(hipMemsetAsync(c->d_tests, 0, sizeof(unsigned long long) * 16 * TEST_SHARDS, s));
     HIPCHK(hipEventRecord(c->ev0, s));
     const dim3 grid(c->dim / TILE, (y1 - y0) / TILE);
@@ -362,6 +444,50 @@ int rt_init_shifts(int32_t n, int32_t *shifts4, double *angles)
         shifts4[4 * i + 3] = (i % 2) * 2 - 1;
         if (angles) angles[i] = 0.0;
     }
+    return RT_OK;
+}
+
+int rt_anim_init(rt_ctx *c)
+{
+    if (!c) return RT_ERR_ARG;
+    k_anim_init<<<(c->n + 255) / 256, 256, 0, c->stream>>>(c->n, c->d_rng, c->d_shifts, c->d_angles);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->anim_ready = true;
+    return RT_OK;
+}
+
+int rt_anim_axis_move(rt_ctx *c, int32_t shake_width)
+{
+    if (!c || !c->anim_ready) return RT_ERR_ARG;
+    k_anim_axis<<<(c->n + 255) / 256, 256, 0, c->stream>>>(c->n, c->d_rng, c->d_shifts, shake_width);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_anim_curve_move(rt_ctx *c)
+{
+    if (!c || !c->anim_ready) return RT_ERR_ARG;
+    k_anim_curve<<<(c->n + 255) / 256, 256, 0, c->stream>>>(c->n, c->d_shifts, c->d_angles);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_anim_update_speed_angle(rt_ctx *c, int32_t update_prob, int32_t max_speed)
+{
+    if (!c || !c->anim_ready) return RT_ERR_ARG;
+    k_anim_speed_angle<<<(c->n + 255) / 256, 256, 0, c->stream>>>(c->n, c->d_rng, c->d_shifts, c->d_angles, update_prob, max_speed);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_anim_get_state(rt_ctx *c, int32_t *shifts4, double *angles, uint32_t *rng6)
+{
+    if (!c || !c->anim_ready) return RT_ERR_ARG;
+    if (shifts4) HIPCHK(hipMemcpyAsync(shifts4, c->d_shifts, sizeof(int32_t) * 4 * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    if (angles) HIPCHK(hipMemcpyAsync(angles, c->d_angles, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    if (rng6) HIPCHK(hipMemcpyAsync(rng6, c->d_rng, sizeof(Xorwow) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 

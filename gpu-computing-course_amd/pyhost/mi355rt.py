@@ -22,7 +22,8 @@ class RtStats(C.Structure):
 
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_spheres", "rt_set_mode", "rt_render", "rt_render_rows",
-           "rt_init_shifts", "rt_get_stats", "rt_version"]
+           "rt_init_shifts", "rt_anim_init", "rt_anim_axis_move", "rt_anim_curve_move", "rt_anim_update_speed_angle",
+           "rt_anim_get_state", "rt_get_stats", "rt_version"]
 
 _lib = None
 
@@ -42,6 +43,11 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.rt_render.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     lib.rt_render_rows.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.rt_init_shifts.argtypes = [C.c_int32, vp, vp]
+    lib.rt_anim_init.argtypes = [vp]
+    lib.rt_anim_axis_move.argtypes = [vp, C.c_int32]
+    lib.rt_anim_curve_move.argtypes = [vp]
+    lib.rt_anim_update_speed_angle.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.rt_anim_get_state.argtypes = [vp, vp, vp, vp]
     lib.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
     lib.rt_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -94,9 +100,34 @@ class RayTracer:
         if rc:
             raise RtError("rt_set_mode", rc)
 
+    # ---- device-resident animation state (sphere.cuh:50-118)
+    def _chk(self, fn, rc):
+        if rc:
+            raise RtError(fn, rc)
+
+    def anim_init(self):
+        self._chk("rt_anim_init", self.lib.rt_anim_init(self._ctx))
+
+    def anim_axis_move(self, shake_width=35):
+        self._chk("rt_anim_axis_move", self.lib.rt_anim_axis_move(self._ctx, shake_width))
+
+    def anim_curve_move(self):
+        self._chk("rt_anim_curve_move", self.lib.rt_anim_curve_move(self._ctx))
+
+    def anim_update_speed_angle(self, update_prob=1, max_speed=18):
+        self._chk("rt_anim_update_speed_angle", self.lib.rt_anim_update_speed_angle(self._ctx, update_prob, max_speed))
+
+    def anim_state(self):
+        sh = np.zeros((self.n, 4), dtype=np.int32); ang = np.zeros(self.n, dtype=np.float64); rng = np.zeros((self.n, 6), dtype=np.uint32)
+        self._chk("rt_anim_get_state", self.lib.rt_anim_get_state(self._ctx, _ptr(sh), _ptr(ang), _ptr(rng)))
+        return sh, ang, rng
+
     def render(self, shifts, c_shift_x=0, c_shift_y=0, rows=None, download=True):
-        sh = np.ascontiguousarray(shifts, dtype=np.int32).reshape(-1, 4)
-        assert sh.shape[0] == self.n
+        """shifts=None: render from the device-resident animation state (after anim_init)."""
+        sh = None
+        if shifts is not None:
+            sh = np.ascontiguousarray(shifts, dtype=np.int32).reshape(-1, 4)
+            assert sh.shape[0] == self.n
         y0, y1 = (0, self.dim) if rows is None else rows
         img = np.zeros((y1 - y0, self.dim, 4), dtype=np.uint8) if download else None
         rc = self.lib.rt_render_rows(self._ctx, _ptr(sh), c_shift_x, c_shift_y, y0, y1, _ptr(img))

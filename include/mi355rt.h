@@ -65,6 +65,17 @@ int rt_render_rows(rt_ctx *ctx, const int32_t *shifts4, int32_t c_shift_x, int32
 /* sphere.cuh:50-61 initSpheres, the deterministic part: shifts = {0,0,(i%5+1)*5,(i%2)*2-1}, angles = 0. */
 int rt_init_shifts(int32_t n_spheres, int32_t *shifts4, double *angles);
 
+/* Device-resident animation state.  After rt_anim_init, rt_render / rt_render_rows accept
+ * shifts4 == NULL and read the state the kernels below maintain; generate_frame's frame counters
+ * (anime_ray.cu:101-125: camera shake, SPHERE_FRAME_PER_SHAKE, SPHERE_SHAKE_TYPE) stay with the caller.
+ * Random stream: XORWOW as cuRAND's curand_init(i, 0, 0) / curand() (see oracle/rt_oracle.c for its parity status). */
+int rt_anim_init(rt_ctx *ctx);                                                     /* anime_ray.cu:251 initSpheres<<<128,1>>>, sphere.cuh:50-61 */
+int rt_anim_axis_move(rt_ctx *ctx, int32_t shake_width);                           /* anime_ray.cu:119 updateSphereShiftsWithAxisMove, sphere.cuh:66-77 (SPHERE_SHAKE_WIDTH 35) */
+int rt_anim_curve_move(rt_ctx *ctx);                                               /* anime_ray.cu:121 updateSphereShiftsWithCurveMove, sphere.cuh:82-97 */
+int rt_anim_update_speed_angle(rt_ctx *ctx, int32_t update_prob, int32_t max_speed); /* anime_ray.cu:122 updateSphereCurveSpeedAngle, sphere.cuh:102-118 (1, 18) */
+/* Read the state back (any pointer may be NULL): shifts4 n x 4 int32, angles n doubles, rng6 n x 6 uint32 {v[5], d}. */
+int rt_anim_get_state(rt_ctx *ctx, int32_t *shifts4, double *angles, uint32_t *rng6);
+
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 const char *rt_version(void);
 

@@ -89,3 +89,82 @@ void orc_rt_init_shifts(int n_spheres, int32_t *shifts, double *angles)
         angles[i] = 0.0;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Animation state kernels, sphere.cuh:50-118.  TEST INFRASTRUCTURE like the rest.
+ *
+ * PARITY UNPINNED for the random stream: curandStateXORWOW / curand_init / curand come from NVIDIA's
+ * <curand_kernel.h>, which is not in /root/reference and not in this image.  The generator below is a
+ * restatement of the published XORWOW algorithm as that header implements it (Marsaglia's xorwow: five
+ * 32-bit xorshift words + a Weyl counter stepping by 362437; curand_init(seed, 0, 0) scrambles the seed
+ * with two odd multipliers and applies no skip-ahead for subsequence 0 / offset 0).  rocRAND's XORWOW,
+ * the only other implementation on this box, seeds differently (different xor constants), so there is
+ * nothing here to check the seeding constants against; everything downstream of curand() -- dev_rnd,
+ * the shift / speed / direction / angle updates -- is plain IEEE double / int arithmetic and is exact.
+ * cosf / sinf (sphere.cuh:88-89): CUDA's device cosf / sinf are not correctly rounded (<= 2 ulp); here
+ * they are the correctly rounded float cosine / sine of (float)angle.  `speed * cosf(a)` is truncated to
+ * int, so at exact boundaries (e.g. speed 10, a = pi/3) the reference may differ by one pixel.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { uint32_t v[5]; uint32_t d; } orc_xorwow;
+
+void orc_xorwow_init(orc_xorwow *s, uint64_t seed)                  /* curand_init(seed, 0, 0, s), sphere.cuh:53 */
+{
+    const uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u, s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    const uint32_t t0 = 1099087573u * s0, t1 = 2591861531u * s1;
+    s->d = 6615241u + t1 + t0;
+    s->v[0] = 123456789u + t0; s->v[1] = 362436069u ^ t0; s->v[2] = 521288629u + t1;
+    s->v[3] = 88675123u ^ t1;  s->v[4] = 5783321u + t0;
+}
+
+uint32_t orc_xorwow_next(orc_xorwow *s)                             /* curand(&state) */
+{
+    const uint32_t t = s->v[0] ^ (s->v[0] >> 2);
+    s->v[0] = s->v[1]; s->v[1] = s->v[2]; s->v[2] = s->v[3]; s->v[3] = s->v[4];
+    s->v[4] = (s->v[4] ^ (s->v[4] << 4)) ^ (t ^ (t << 1));
+    s->d += 362437u;
+    return s->v[4] + s->d;
+}
+
+/* dev_rnd(x, s), sphere.cuh:26: curand(&s) % 1000000 * 1.0 / 1000000 * x  (double) */
+static double orc_dev_rnd(int x, orc_xorwow *s) { return orc_xorwow_next(s) % 1000000u * 1.0 / 1000000 * x; }
+
+#define ORC_PI 3.1415926535898                                      /* sphere.cuh:19 */
+
+void orc_rt_anim_init(int n, orc_xorwow *states, int32_t *shifts, double *angles)          /* initSpheres, sphere.cuh:50-61 */
+{
+    for (int i = 0; i < n; ++i) orc_xorwow_init(&states[i], (uint64_t)i);
+    orc_rt_init_shifts(n, shifts, angles);
+}
+
+void orc_rt_anim_axis_move(int n, orc_xorwow *states, int32_t *shifts, int shake_width)    /* sphere.cuh:66-77 */
+{
+    for (int i = 0; i < n; ++i) {
+        const int x_shift = (int)orc_dev_rnd(shake_width, &states[i]);
+        const int y_shift = (int)orc_dev_rnd(shake_width, &states[i]);
+        shifts[RT_SHIFT_W * i] = x_shift; shifts[RT_SHIFT_W * i + 1] = y_shift;
+    }
+}
+
+void orc_rt_anim_curve_move(int n, int32_t *shifts, double *angles)                        /* sphere.cuh:82-97 */
+{
+    for (int i = 0; i < n; ++i) {
+        const int speed = shifts[RT_SHIFT_W * i + 2];
+        const float a = (float)angles[i];                           /* cosf(double) converts its argument */
+        const int x_shift = (int)((float)speed * (float)cos((double)a));
+        const int y_shift = (int)((float)speed * (float)sin((double)a));
+        shifts[RT_SHIFT_W * i] += x_shift; shifts[RT_SHIFT_W * i + 1] += y_shift;
+        angles[i] = fmod(angles[i] + ORC_PI / 12 * shifts[RT_SHIFT_W * i + 3], 2 * ORC_PI);
+    }
+}
+
+void orc_rt_anim_speed_angle(int n, orc_xorwow *states, int32_t *shifts, double *angles,
+                             int update_prob, int max_speed)                                /* sphere.cuh:102-118 */
+{
+    for (int i = 0; i < n; ++i) {
+        const int p = (int)orc_dev_rnd(10, &states[i]);
+        if (p >= update_prob) continue;
+        shifts[RT_SHIFT_W * i + 2] = (int)orc_dev_rnd(max_speed, &states[i]);
+        shifts[RT_SHIFT_W * i + 3] = ((int)orc_dev_rnd(2, &states[i])) * 2 - 1;
+        angles[i] = fmod(angles[i] + ((int)orc_dev_rnd(2, &states[i])) * ORC_PI, 2 * ORC_PI);
+    }
+}

@@ -73,6 +73,12 @@ def lib(omp: bool = False) -> C.CDLL:
     L.orc_rt_render_rows.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.orc_rt_render_rows.restype = None
     L.orc_rt_init_shifts.argtypes = [C.c_int, vp, vp]; L.orc_rt_init_shifts.restype = None
+    L.orc_xorwow_init.argtypes = [vp, C.c_uint64]; L.orc_xorwow_init.restype = None
+    L.orc_xorwow_next.argtypes = [vp]; L.orc_xorwow_next.restype = C.c_uint32
+    L.orc_rt_anim_init.argtypes = [C.c_int, vp, vp, vp]; L.orc_rt_anim_init.restype = None
+    L.orc_rt_anim_axis_move.argtypes = [C.c_int, vp, vp, C.c_int]; L.orc_rt_anim_axis_move.restype = None
+    L.orc_rt_anim_curve_move.argtypes = [C.c_int, vp, vp]; L.orc_rt_anim_curve_move.restype = None
+    L.orc_rt_anim_speed_angle.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int]; L.orc_rt_anim_speed_angle.restype = None
     _libs[name] = L
     return L
 
@@ -239,3 +245,27 @@ def rt_render(spheres, shifts, dim, c_shift_x=0, c_shift_y=0, rows=None):
     else:
         lib().orc_rt_render_rows(_p(s), s.shape[0], _p(sh), dim, c_shift_x, c_shift_y, rows[0], rows[1], _p(img))
     return img
+
+
+class RtAnim:
+    """Oracle twin of the animation state kernels (sphere.cuh:50-118): rng[n,6] uint32, shifts[n,4] int32, angles[n] f64."""
+
+    def __init__(self, n):
+        self.n = n
+        self.rng = np.zeros((n, 6), dtype=np.uint32); self.shifts = np.zeros((n, 4), dtype=np.int32); self.angles = np.zeros(n, dtype=np.float64)
+        lib().orc_rt_anim_init(n, _p(self.rng), _p(self.shifts), _p(self.angles))
+
+    def axis_move(self, shake_width=35):
+        lib().orc_rt_anim_axis_move(self.n, _p(self.rng), _p(self.shifts), shake_width)
+
+    def curve_move(self):
+        lib().orc_rt_anim_curve_move(self.n, _p(self.shifts), _p(self.angles))
+
+    def speed_angle(self, update_prob=1, max_speed=18):
+        lib().orc_rt_anim_speed_angle(self.n, _p(self.rng), _p(self.shifts), _p(self.angles), update_prob, max_speed)
+
+
+def xorwow_stream(seed, count):
+    st = np.zeros(6, dtype=np.uint32)
+    lib().orc_xorwow_init(_p(st), seed)
+    return np.array([lib().orc_xorwow_next(_p(st)) for _ in range(count)], dtype=np.uint32), st

@@ -203,3 +203,42 @@ def test_sat_simple_cases():
     assert oracle.tri_contact(A, far) == 0
     assert oracle.tri_contact(A, touch) == 1                      # vec3f.cuh:288-289 uses >, touching counts
     assert oracle.tri_contact(A, coplanar_apart) == 0
+
+
+def test_xorwow_restatement_structure():
+    """The XORWOW generator behind the animation kernels (oracle/rt_oracle.c; random stream: parity unpinned, see the
+    header there).  What CAN be checked without cuRAND: the recurrence is Marsaglia's xorwow (period structure: the
+    Weyl counter advances by 362437 per draw and is added to the xorshift word), seeds give distinct streams, and the
+    state after k draws is reproducible."""
+    a, sa = oracle.xorwow_stream(0, 8)
+    b, sb = oracle.xorwow_stream(0, 8)
+    c, _ = oracle.xorwow_stream(1, 8)
+    assert np.array_equal(a, b) and np.array_equal(sa, sb) and not np.array_equal(a, c)
+    # independent restatement in Python integers
+    def stream(seed, k):
+        M = 0xFFFFFFFF
+        s0 = (seed & M) ^ 0xaad26b49; s1 = ((seed >> 32) & M) ^ 0xf7dcefdd
+        t0 = (1099087573 * s0) & M; t1 = (2591861531 * s1) & M
+        d = (6615241 + t1 + t0) & M
+        v = [(123456789 + t0) & M, 362436069 ^ t0, (521288629 + t1) & M, 88675123 ^ t1, (5783321 + t0) & M]
+        out = []
+        for _ in range(k):
+            t = v[0] ^ (v[0] >> 2)
+            v = v[1:] + [((v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1))) & M]
+            d = (d + 362437) & M
+            out.append((v[4] + d) & M)
+        return out
+    assert a.tolist() == stream(0, 8) and c.tolist() == stream(1, 8)
+    big, _ = oracle.xorwow_stream(0x1234567890, 4)
+    assert big.tolist() == stream(0x1234567890, 4)
+
+
+def test_animation_oracle_basics():
+    an = oracle.RtAnim(10)
+    assert an.shifts[:, 2].tolist() == [5, 10, 15, 20, 25, 5, 10, 15, 20, 25]          # sphere.cuh:56
+    assert an.shifts[:, 3].tolist() == [-1, 1] * 5                                     # sphere.cuh:57
+    an.curve_move()                                                                    # angle 0: x += speed, y += 0
+    assert an.shifts[:, 0].tolist() == [5, 10, 15, 20, 25, 5, 10, 15, 20, 25] and not an.shifts[:, 1].any()
+    assert np.allclose(np.abs(an.angles), 3.1415926535898 / 12)
+    an.axis_move(35)
+    assert ((an.shifts[:, :2] >= 0) & (an.shifts[:, :2] < 35)).all()

@@ -108,3 +108,51 @@ def test_config5_shape_binned_equals_brute_and_oracle_rows():
     y0 = 2048
     want = oracle.rt_render(spheres, shifts, dim, rows=(y0, y0 + 64))[y0:y0 + 64]
     assert np.array_equal(a[y0:y0 + 64], want)
+
+
+def test_animation_state_kernels_follow_the_oracle():
+    """sphere.cuh:50-118 on the device: initSpheres, axis move, curve move, speed / direction / angle update.
+    State (XORWOW words, shifts, angles) must equal the oracle's after every step of a generate_frame-like schedule
+    (anime_ray.cu:115-125), and a frame rendered from the device-resident state equals one rendered from the
+    read-back shifts."""
+    n, dim = 500, 512                                                      # SPHERES = 500, sphere.cuh:22
+    spheres, _ = synth.sphere_scene(n, dim, seed=11)
+    ref = oracle.RtAnim(n)
+    with mi355rt.RayTracer(spheres, dim) as rt:
+        with pytest.raises(mi355rt.RtError):
+            rt.render(None)                                                # no device state yet
+        rt.anim_init()
+        sh, ang, rng = rt.anim_state()
+        assert np.array_equal(sh, ref.shifts) and np.array_equal(ang, ref.angles) and np.array_equal(rng, ref.rng)
+        assert sh[:6, 2].tolist() == [5, 10, 15, 20, 25, 5] and sh[:4, 3].tolist() == [-1, 1, -1, 1]
+        for frame in range(1, 41):
+            if frame % 4 == 0:                                             # SPHERE_FRAME_PER_SHAKE 4, SPHERE_SHAKE_TYPE 1
+                rt.anim_curve_move(); ref.curve_move()
+                rt.anim_update_speed_angle(1, 18); ref.speed_angle(1, 18)
+            if frame % 10 == 0:                                            # exercise the other shake type too
+                rt.anim_axis_move(35); ref.axis_move(35)
+            sh, ang, rng = rt.anim_state()
+            assert np.array_equal(rng, ref.rng), frame
+            assert np.array_equal(sh, ref.shifts), frame
+            assert np.array_equal(ang.view(np.uint64), ref.angles.view(np.uint64)), frame
+        assert len(np.unique(sh[:, 2])) > 5 and (np.abs(sh[:, :2]) > 0).any()      # the state really moved
+        img_dev = rt.render(None, 3, -2)
+        img_host = rt.render(sh, 3, -2)
+        assert np.array_equal(img_dev, img_host)
+        assert np.array_equal(img_dev, oracle.rt_render(spheres, sh, dim, 3, -2))
+
+
+def test_rt_main_harness_animates(tmp_path):
+    """host/rt_main.cpp, the headless twin of anime_ray.cu's main / generate_frame: init, per-frame animation kernels,
+    render from the device-resident shifts, the reference's timing line per frame, last frame as PPM."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-computing-course_amd", "bin", "rt_main")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    ppm = tmp_path / "f.ppm"
+    out = subprocess.run([exe, "--dim", "256", "--spheres", "120", "--frames", "9", "--shake", "curve", "--ppm", str(ppm)],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("Time to generate a frame:") == 9
+    data = ppm.read_bytes()
+    assert data.startswith(b"P6\n256 256\n255\n") and len(data) == len(b"P6\n256 256\n255\n") + 256 * 256 * 3
+    assert any(data[15:])                                                  # not a black frame
