@@ -421,7 +421,43 @@ __device__ __forceinline__ Box seg_query_wave(const double *__restrict__ seg, co
     return r;
 }
 
-// Nodes whose range leaves their 512-leaf block: one WAVE per node, two wave-parallel range queries.
+// Both child queries of a node in ONE pass: lanes 0-31 answer [la, ra], lanes 32-63 answer [lb, rb].  Inside a half,
+// lane h < 16 owns the left piece of level h and lane 31 - q the right piece of level q, so lane order is again
+// left-to-right order; 16 levels cover every range shorter than 65536 leaves (the caller checks).  One 5-step
+// segmented reduction instead of two 6-step ones: the shuffles (ds_bpermute) are what this kernel issues most.
+// Returns [la, ra] in lane 0 and [lb, rb] in lane 32.
+__device__ __forceinline__ Box seg_query_halves(const double *__restrict__ seg, const double *__restrict__ boxes, int n, long long P,
+                                                int la, int ra, int lb, int rb, int lane)
+{
+    const int hl = lane & 31;
+    const bool second = lane >= 32, is_left = hl < 16;
+    const int l0 = second ? lb : la, r0 = second ? rb : ra;
+    const int p = is_left ? hl : 31 - hl;                                  // level of this lane's piece
+    const long long lp = ((long long)l0 + P + ((1ll << p) - 1)) >> p;      // l at level p  (ceil)
+    const long long rp = ((long long)r0 + P + 1) >> p;                     // r at level p  (floor), half-open
+    Box x = box_identity();
+    if (lp < rp) {
+        const long long k = is_left ? lp : rp - 1;
+        const bool take = is_left ? (lp & 1) : (rp & 1);
+        if (take) {
+            if (p == 0) { const long long j = k - P; if (j < n) x = load_box(boxes, (n - 1) + (int)j); }
+            else x = load_box(seg, (int)k);
+        }
+    }
+    const Box id = box_identity();
+#pragma unroll
+    for (int s = 1; s < 32; s <<= 1) {                                      // lanes that are multiples of 2s hold [hl, hl + 2s) of their half
+        Box y;
+        y.x1 = __shfl_down(x.x1, s); y.x2 = __shfl_down(x.x2, s); y.y1 = __shfl_down(x.y1, s);
+        y.y2 = __shfl_down(x.y2, s); y.z1 = __shfl_down(x.z1, s); y.z2 = __shfl_down(x.z2, s);
+        if (hl + s >= 32) y = id;                                          // never pull from the other half
+        x = box_merge(x, y);                                               // mine is LEFT of the one s lanes up
+    }
+    return x;
+}
+
+// Nodes whose range leaves their 512-leaf block: one WAVE per node, its two range queries side by side in the two
+// halves of the wave (seg_query_halves; ranges of 65536 leaves or more take two full-wave queries).
 // Queries read only leaf boxes and segment-tree nodes, never another cross node's output: no ordering needed.
 __global__ __launch_bounds__(256) void k_refit_seg_cross(int n, const NodeMeta *__restrict__ meta, const double *__restrict__ seg, int nbp2,
                                                          double *boxes, uint32_t *__restrict__ bounded, NodeRec32 *__restrict__ recs32,
@@ -448,8 +484,16 @@ __global__ __launch_bounds__(256) void k_refit_seg_cross(int n, const NodeMeta *
         const NodeMeta m = meta[i];
         const int first = min(i, m.z), last = max(i, m.z);
         const int split = (m.x >= n - 1) ? m.x - (n - 1) : m.x;
-        const Box bl = seg_query_wave(seg, boxes, n, P, first, split, lane);
-        const Box br = seg_query_wave(seg, boxes, n, P, split + 1, last, lane);
+        Box bl, br;
+        if (last - first < 65535) {                                         // (wave-uniform) nearly all of them
+            const Box h = seg_query_halves(seg, boxes, n, P, first, split, split + 1, last, lane);
+            bl = h;                                                         // valid in lane 0, the only lane that stores
+            br.x1 = __shfl(h.x1, 32); br.x2 = __shfl(h.x2, 32); br.y1 = __shfl(h.y1, 32);
+            br.y2 = __shfl(h.y2, 32); br.z1 = __shfl(h.z1, 32); br.z2 = __shfl(h.z2, 32);
+        } else {
+            bl = seg_query_wave(seg, boxes, n, P, first, split, lane);
+            br = seg_query_wave(seg, boxes, n, P, split + 1, last, lane);
+        }
         if (lane == 0) {
             store_box(boxes, i, emit_node(bl, br, m.x, m.y, recs32 + i, n - 1));
             bounded[i] = 2;
