@@ -421,6 +421,25 @@ __device__ __forceinline__ Box seg_query_wave(const double *__restrict__ seg, co
     return r;
 }
 
+// One step of the ordered reduction: x = merge(x, x of the lane `shift` to the right inside the 16-lane row).
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_shl(double v, double fill)
+{
+    const long long b = __double_as_longlong(v), f = __double_as_longlong(fill);
+    const int lo = __builtin_amdgcn_update_dpp((int)f, (int)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(f >> 32), (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ Box dpp_step(const Box &x)
+{
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    Box y;
+    y.x1 = dpp_row_shl<CTRL>(x.x1, inf); y.x2 = dpp_row_shl<CTRL>(x.x2, -inf); y.y1 = dpp_row_shl<CTRL>(x.y1, inf);
+    y.y2 = dpp_row_shl<CTRL>(x.y2, -inf); y.z1 = dpp_row_shl<CTRL>(x.z1, inf); y.z2 = dpp_row_shl<CTRL>(x.z2, -inf);
+    return box_merge(x, y);                                                // mine is LEFT of the one to the right
+}
+
 // Both child queries of a node in ONE pass: lanes 0-31 answer [la, ra], lanes 32-63 answer [lb, rb].  Inside a half,
 // lane h < 16 owns the left piece of level h and lane 31 - q the right piece of level q, so lane order is again
 // left-to-right order; 16 levels cover every range shorter than 65536 leaves (the caller checks).  One 5-step
@@ -444,14 +463,14 @@ __device__ __forceinline__ Box seg_query_halves(const double *__restrict__ seg, 
             else x = load_box(seg, (int)k);
         }
     }
-    const Box id = box_identity();
-#pragma unroll
-    for (int s = 1; s < 32; s <<= 1) {                                      // lanes that are multiples of 2s hold [hl, hl + 2s) of their half
+    // Steps 1, 2, 4, 8 stay inside a row of 16 lanes: DPP row_shl (a VALU move, no LDS traffic); a lane whose source
+    // would be outside its row keeps the identity -- only lanes whose result is never consumed are affected.
+    x = dpp_step<0x101>(x); x = dpp_step<0x102>(x); x = dpp_step<0x104>(x); x = dpp_step<0x108>(x);
+    {                                                                       // step 16: lanes 0 and 32 pull rows 1 and 3 of their half
         Box y;
-        y.x1 = __shfl_down(x.x1, s); y.x2 = __shfl_down(x.x2, s); y.y1 = __shfl_down(x.y1, s);
-        y.y2 = __shfl_down(x.y2, s); y.z1 = __shfl_down(x.z1, s); y.z2 = __shfl_down(x.z2, s);
-        if (hl + s >= 32) y = id;                                          // never pull from the other half
-        x = box_merge(x, y);                                               // mine is LEFT of the one s lanes up
+        y.x1 = __shfl_down(x.x1, 16); y.x2 = __shfl_down(x.x2, 16); y.y1 = __shfl_down(x.y1, 16);
+        y.y2 = __shfl_down(x.y2, 16); y.z1 = __shfl_down(x.z1, 16); y.z2 = __shfl_down(x.z2, 16);
+        x = box_merge(x, y);                                               // consumed only in lanes 0 and 32, whose source is their own half
     }
     return x;
 }
