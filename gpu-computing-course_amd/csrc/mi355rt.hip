@@ -36,17 +36,6 @@ __device__ __forceinline__ void prepare_one(const RtSphere *__restrict__ s, cons
     h.r = sp.r; h.g = sp.g; h.b = sp.b; h.sr = sqrtf(sp.radius * sp.radius);
 }
 
-// Brute mode only; in binned mode k_bin_super does this on the fly (one launch less per frame).
-__global__ __launch_bounds__(256) void k_prepare(const RtSphere *__restrict__ s, const int32_t *__restrict__ shifts, int n,
-                                                 SphGeom *__restrict__ geom, SphShade *__restrict__ shade)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    SphGeom g; SphShade h;
-    prepare_one(s, shifts, i, g, h);
-    geom[i] = g; shade[i] = h;
-}
-
 // Per pixel only the winner is tracked -- its index, its dz and the running maximum of t: the normalisation
 // n = dz / sqrtf(r*r) and the three colour products (sphere.cuh:41, anime_ray.cu:77-80) depend on nothing but the
 // winning sphere, so they are evaluated once per pixel after the loop instead of once per hit (same operands, same
@@ -62,7 +51,9 @@ __device__ __forceinline__ void shade_one(Px &p, float ox, float oy, const SphGe
     if (dx2 + dy2 < g.rr) {
         const float dz = sqrtf(g.rr - dx2 - dy2);
         const float t = dz + g.z;
-        if (t > p.maxz) { p.maxz = t; p.dz = dz; p.win = i; }                           // strict: lowest index wins
+        // anime_ray.cu:75 is a strict > in ascending sphere order, i.e. the lowest index wins a tie; stated
+        // explicitly so that the spheres may arrive in any order (binned lists are unordered)
+        if (t > p.maxz || (t == p.maxz && i < p.win)) { p.maxz = t; p.dz = dz; p.win = i; }
     }
 }
 
@@ -99,50 +90,51 @@ __device__ __forceinline__ bool may_touch(const SphGeom g, float ox0, float ox1,
 constexpr int TEST_SHARDS = 64;         // sphere-test counter shards, 128 bytes apart
 constexpr int SUPER = 256;             // super-tile edge in pixels (4 x 4 tiles)
 
-// Level 1 of the binning: one workgroup per 256x256 super-tile culls ALL spheres and writes the survivors, in
-// ascending sphere index (wave-ordered __ballot compaction), to super_list[st][0..count).  Tiles then cull only
-// their super-tile's few dozen survivors instead of all S spheres.
-__global__ __launch_bounds__(THREADS) void k_bin_super(const RtSphere *__restrict__ spheres, const int32_t *__restrict__ shifts,
-                                                       SphGeom *__restrict__ geom, SphShade *__restrict__ shade, int n, int dim, int c_shift_x, int c_shift_y,
-                                                       int nsx, int sy0, int *__restrict__ super_list, int *__restrict__ super_count)
+// Level 1 of the binning (bin_sphere, called by k_prepare for the sphere it has just prepared): every SPHERE appends itself to the lists of
+// the 256x256 super-tiles it may touch -- a handful of candidates from a conservative bound, decided by the exact
+// may_touch -- with one atomic per (sphere, super-tile).  List order is arbitrary: the tie rule of anime_ray.cu:75
+// ("strict >, so the lowest index wins a tie in t") is applied explicitly in shade_one instead of through the
+// processing order.  Tiles then cull only their super-tile's few dozen survivors instead of all S spheres.
+__device__ __forceinline__ void bin_sphere(const SphGeom g, const SphShade h, int i, int n, int dim,
+                                           int c_shift_x, int c_shift_y, int nsx, int sy0, int sy1,
+                                           int *__restrict__ super_list, int *__restrict__ super_count)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *list = reinterpret_cast<int *>(smem);              // 4 sub-lists of cap = ceil(n/4) entries
-    __shared__ int wcount[4];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int sx = blockIdx.x, sy = blockIdx.y + sy0;
-    const bool first = blockIdx.x == 0 && blockIdx.y == 0;
-    const int X0 = sx * SUPER, Y0 = sy * SUPER;
-    const int X1 = min(X0 + SUPER, dim) - 1, Y1 = min(Y0 + SUPER, dim) - 1;
-    const float ox0 = (float)(X0 - dim / 2 + c_shift_x), ox1 = (float)(X1 - dim / 2 + c_shift_x);
-    const float oy0 = (float)(Y0 - dim / 2 + c_shift_y), oy1 = (float)(Y1 - dim / 2 + c_shift_y);
-    const int sub_cap = (n + 3) >> 2;
-    int cnt = 0;
-    const int s_begin = w * sub_cap, s_end = min(n, s_begin + sub_cap);
-    for (int base = s_begin; base < s_end; base += 64) {
-        const int i = base + lane;
-        bool keep = false;
-        if (i < s_end) {
-            SphGeom g; SphShade h;
-            prepare_one(spheres, shifts, i, g, h);              // the per-sphere prepass, fused: every super-tile recomputes it,
-            if (first) { geom[i] = g; shade[i] = h; }           // the first workgroup of the launch stores it for k_render
-            keep = may_touch(g, ox0, ox1, oy0, oy1);
+    const double sr = (double)h.sr, cx = (double)g.cx, cy = (double)g.cy;
+    // pixel x sees ox = x - dim/2 + c_shift_x; the sphere can only touch |ox - cx| < sr (+ float rounding: margin)
+    int bx0 = 0, bx1 = nsx - 1, by0 = sy0, by1 = sy1 - 1;
+    const double mx = 2.0 + 1e-6 * (fabs(cx) + sr), my = 2.0 + 1e-6 * (fabs(cy) + sr);
+    const double xlo = cx - sr - mx + dim / 2 - c_shift_x, xhi = cx + sr + mx + dim / 2 - c_shift_x;
+    const double ylo = cy - sr - my + dim / 2 - c_shift_y, yhi = cy + sr + my + dim / 2 - c_shift_y;
+    if (xlo == xlo && xhi == xhi && ylo == ylo && yhi == yhi) {            // NaN anywhere: keep the full range (may_touch keeps NaN too)
+        if (xhi < 0.0 || yhi < 0.0 || xlo > (double)(dim - 1) || ylo > (double)(dim - 1)) return;
+        bx0 = max(bx0, (int)(fmax(xlo, 0.0) / SUPER)); bx1 = min(bx1, (int)(fmin(xhi, (double)(dim - 1)) / SUPER));
+        by0 = max(by0, (int)(fmax(ylo, 0.0) / SUPER)); by1 = min(by1, (int)(fmin(yhi, (double)(dim - 1)) / SUPER));
+    }
+    for (int sy = by0; sy <= by1; ++sy)
+        for (int sx = bx0; sx <= bx1; ++sx) {
+            const int X0 = sx * SUPER, Y0 = sy * SUPER;
+            const int X1 = min(X0 + SUPER, dim) - 1, Y1 = min(Y0 + SUPER, dim) - 1;
+            const float ox0 = (float)(X0 - dim / 2 + c_shift_x), ox1 = (float)(X1 - dim / 2 + c_shift_x);
+            const float oy0 = (float)(Y0 - dim / 2 + c_shift_y), oy1 = (float)(Y1 - dim / 2 + c_shift_y);
+            if (may_touch(g, ox0, ox1, oy0, oy1)) {
+                const int st = sy * nsx + sx;
+                super_list[(size_t)st * n + atomicAdd(&super_count[st], 1)] = i;
+            }
         }
-        const unsigned long long m = __ballot(keep);
-        if (keep) list[w * sub_cap + cnt + __popcll(m & ((1ull << lane) - 1ull))] = i;
-        cnt += __popcll(m);
-    }
-    if (lane == 0) wcount[w] = cnt;
-    __syncthreads();
-    const int st = sy * nsx + sx;
-    int *out = super_list + (size_t)st * n;
-    int off = 0;
-    for (int ww = 0; ww < 4; ++ww) {                        // concatenate in wave order == ascending sphere index
-        const int c = wcount[ww];
-        for (int k = tid; k < c; k += THREADS) out[off + k] = list[ww * sub_cap + k];
-        off += c;
-    }
-    if (tid == 0) super_count[st] = off;
+}
+
+// The per-sphere prepass; in binned mode (super_list != nullptr) the same thread also bins its sphere.
+__global__ __launch_bounds__(256) void k_prepare(const RtSphere *__restrict__ s, const int32_t *__restrict__ shifts, int n,
+                                                 SphGeom *__restrict__ geom, SphShade *__restrict__ shade,
+                                                 int dim, int c_shift_x, int c_shift_y, int nsx, int sy0, int sy1,
+                                                 int *__restrict__ super_list, int *__restrict__ super_count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    SphGeom g; SphShade h;
+    prepare_one(s, shifts, i, g, h);
+    geom[i] = g; shade[i] = h;
+    if (super_list) bin_sphere(g, h, i, n, dim, c_shift_x, c_shift_y, nsx, sy0, sy1, super_list, super_count);
 }
 
 // Thread layout inside a 64x64 tile: tx = tid & 15 owns 4 consecutive columns, ty = tid >> 4 owns rows
@@ -321,7 +313,8 @@ struct rt_ctx {
     Xorwow *d_rng = nullptr; double *d_angles = nullptr; bool anim_ready = false;   // animation state, sphere.cuh:50-61
     SphGeom *d_geom = nullptr; SphShade *d_shade = nullptr;
     uint32_t *d_rgba = nullptr; unsigned long long *d_tests = nullptr;
-    int *d_super_list = nullptr, *d_super_count = nullptr;      // [nsuper][n] ordered survivor lists, [nsuper] counts
+    int *d_super_list = nullptr, *d_super_count = nullptr;      // [nsuper][n] survivor lists (unordered), [nsuper] counts (inside d_tests' allocation)
+    size_t zero_bytes = 0;
     rt_stats stats = {};
 };
 
@@ -329,7 +322,7 @@ namespace {
 void rt_free(rt_ctx *c)
 {
     hipFree(c->d_rng); hipFree(c->d_angles);
-    hipFree(c->d_spheres); hipFree(c->d_shifts); hipFree(c->d_geom); hipFree(c->d_shade); hipFree(c->d_rgba); hipFree(c->d_tests); hipFree(c->d_super_list); hipFree(c->d_super_count);
+    hipFree(c->d_spheres); hipFree(c->d_shifts); hipFree(c->d_geom); hipFree(c->d_shade); hipFree(c->d_rgba); hipFree(c->d_tests); hipFree(c->d_super_list);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -361,9 +354,12 @@ int rt_create(rt_ctx **out, const RtSphere *spheres, int32_t n_spheres, int32_t 
     ok(hipMalloc(&c->d_geom, sizeof(SphGeom) * (size_t)n_spheres));
     ok(hipMalloc(&c->d_shade, sizeof(SphShade) * (size_t)n_spheres));
     ok(hipMalloc(&c->d_rgba, sizeof(uint32_t) * (size_t)dim * dim));
-    ok(hipMalloc(&c->d_tests, sizeof(unsigned long long) * 16 * TEST_SHARDS));
+    
     { const size_t ns = (size_t)((dim + SUPER - 1) / SUPER) * ((dim + SUPER - 1) / SUPER);
-      ok(hipMalloc(&c->d_super_list, sizeof(int) * ns * (size_t)n_spheres)); ok(hipMalloc(&c->d_super_count, sizeof(int) * ns)); }
+      c->zero_bytes = sizeof(unsigned long long) * 16 * TEST_SHARDS + sizeof(int) * ns;     // test counter shards + list lengths: one memset per frame
+      ok(hipMalloc(&c->d_tests, c->zero_bytes));
+      c->d_super_count = reinterpret_cast<int *>(c->d_tests + 16 * TEST_SHARDS);
+      ok(hipMalloc(&c->d_super_list, sizeof(int) * ns * (size_t)n_spheres)); }
     if (e == hipSuccess) ok(hipMemcpy(c->d_spheres, spheres, sizeof(RtSphere) * (size_t)n_spheres, hipMemcpyHostToDevice));
     if (e != hipSuccess) { rt_free(c); delete c; return -(int)e; }
     *out = c;
@@ -398,18 +394,18 @@ int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, 
     if (!c || (!shifts4 && !c->anim_ready) || y0 < 0 || y1 > c->dim || y0 >= y1 || y0 % TILE || y1 % TILE) return RT_ERR_ARG;
     hipStream_t s = c->stream;
     if (shifts4) HIPCHK(hipMemcpyAsync(c->d_shifts, shifts4, sizeof(int32_t) * 4 * (size_t)c->n, hipMemcpyHostToDevice, s));   // NULL: the device-resident animation state
-    HIPCHK(hipMemsetAsync(c->d_tests, 0, sizeof(unsigned long long) * 16 * TEST_SHARDS, s));
+    HIPCHK(hipMemsetAsync(c->d_tests, 0, c->zero_bytes, s));
     HIPCHK(hipEventRecord(c->ev0, s));
     const dim3 grid(c->dim / TILE, (y1 - y0) / TILE);
     if (c->mode == RT_MODE_BINNED) {
         const size_t lds = sizeof(int) * 4 * (size_t)((c->n + 3) / 4);
         const int nsx = (c->dim + SUPER - 1) / SUPER;
         const int sy0 = y0 / SUPER, sy1 = (y1 + SUPER - 1) / SUPER;
-        k_bin_super<<<dim3(nsx, sy1 - sy0), THREADS, lds, s>>>(c->d_spheres, c->d_shifts, c->d_geom, c->d_shade, c->n, c->dim, csx, csy, nsx, sy0, c->d_super_list, c->d_super_count);
+        k_prepare<<<(c->n + 255) / 256, 256, 0, s>>>(c->d_spheres, c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, csx, csy, nsx, sy0, sy1, c->d_super_list, c->d_super_count);
         k_render<true><<<grid, THREADS, lds, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, y0 / TILE, c->d_rgba, c->d_tests,
                                                   c->d_super_list, c->d_super_count, nsx);
     } else {
-        k_prepare<<<(c->n + 255) / 256, 256, 0, s>>>(c->d_spheres, c->d_shifts, c->n, c->d_geom, c->d_shade);
+        k_prepare<<<(c->n + 255) / 256, 256, 0, s>>>(c->d_spheres, c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, csx, csy, 0, 0, 0, nullptr, nullptr);
         k_render<false><<<grid, THREADS, 0, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, y0 / TILE, c->d_rgba, nullptr, nullptr, nullptr, 0);
     }
     HIPCHK(hipEventRecord(c->ev1, s));
