@@ -48,6 +48,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    path = os.environ.get("MI355CD_LIB", path)          # A/B runs of two builds (tools/)
     if not os.path.exists(path):
         raise RuntimeError(f"{path} not built: run __graft_entry__.build() (there is no CPU fallback)")
     lib = C.CDLL(path)
