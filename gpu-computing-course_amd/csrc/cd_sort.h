@@ -76,12 +76,9 @@ constexpr unsigned long long OS_VALUE_MASK = (1ull << 62) - 1;
 // the per-key part.
 __device__ __forceinline__ void hist_add(uint32_t (*h)[RADIX], uint64_t k, int first_digit)
 {
-    if (first_digit == 0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255], 1u);
-    }
-#pragma unroll
-    for (int p = 4; p < 8; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255], 1u);
+    for (int p = 0; p < 8; ++p)
+        if (p >= first_digit) atomicAdd(&h[p][(k >> (8 * p)) & 255], 1u);      // (first_digit is workgroup-uniform)
 }
 
 // Stand-alone histogram kernel for keys that do not come from k_morton (the pair post-processing sort).
@@ -214,6 +211,177 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
     }
 }
 
+
+// ====================================================================================================
+// Hybrid sort (default).  The onesweep passes cost ~20 us each at 1 M keys, nearly all of it the cross-XCD hand-off
+// between tiles; a pass that stays inside a workgroup has no hand-off.  So only the TOP 16 key bits are sorted
+// globally (2 onesweep passes); that leaves runs of equal top-16 bits (tens to thousands of keys: ~2^16 cells over
+// the Morton frame), contiguous and in input order, and k_local_sort finishes bits 32..63 inside LDS:
+//   * workgroup b takes the window [s_b, s_{b+1}), where s_b is the last run start at or before b * LOCAL_W -- no run
+//     straddles two windows, so sorting the windows independently sorts the array;
+//   * inside the window: stable LSD passes over digits 4..7 with the same __ballot ranking as k_os_pass, {high key
+//     half, position} held in registers and permuted through LDS; a pass whose digit is the same for the whole
+//     window is skipped; keys and values are gathered once at the end.
+// The result is the stable order by the high 32 bits, exactly what 4 global passes give; k_sort_fixup_fill then places
+// every key by its low half as before, so keys and permutation stay bit-identical to the full 8-pass sort.  A run
+// longer than LOCAL_LIMIT cannot be windowed: the kernel flags it (same word as the fix-up's overflow) and the host
+// falls back to the 4-pass half-key sort, then to 8 passes.
+// ====================================================================================================
+constexpr int LOCAL_THREADS = 1024;
+constexpr int LOCAL_WAVES   = LOCAL_THREADS / 64;
+constexpr int LOCAL_W       = 4096;                     // nominal keys per workgroup
+constexpr int LOCAL_LIMIT   = 6144;                     // longest run of equal top-16 bits that can be windowed (a planar 1 M cloth in the
+                                                        // reference's frame: 441 runs, the longest 4590)
+constexpr int LOCAL_ITEMS   = (LOCAL_W + LOCAL_LIMIT) / LOCAL_THREADS;   // 10 keys per lane
+constexpr int LOCAL_CAP     = LOCAL_ITEMS * LOCAL_THREADS;               // 10240 keys: 80 KB of LDS + 16 KB of counters
+
+__global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                              uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n,
+                                                              uint32_t *__restrict__ overflow)
+{
+    __shared__ uint2 sitem[LOCAL_CAP];                   // 80 KB: {high 32 key bits, position inside the window}
+    __shared__ uint32_t wcnt[LOCAL_WAVES][RADIX];        // 16 KB
+    __shared__ uint32_t s_wsum[RADIX / 64];
+    __shared__ int s_lo, s_hi;
+    __shared__ uint32_t s_and, s_or;
+    const uint32_t tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const uint32_t p0 = blockIdx.x * LOCAL_W, p1 = min(p0 + (uint32_t)LOCAL_W, n);
+    if (tid == 0) { s_lo = p0 == 0 ? 0 : -1; s_hi = p1 >= n ? (int)n : -1; }
+    __syncthreads();
+    // window ends: the last run start at or before p0 and p1 (a run starts where the top 16 bits change).  All the
+    // probes of a thread (LOCAL_LIMIT / LOCAL_THREADS positions per end, two keys each) are issued before any is used.
+    {
+        constexpr int PROBES = LOCAL_LIMIT / LOCAL_THREADS;
+        uint32_t top[2][PROBES][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t p = e ? p1 : p0;
+#pragma unroll
+            for (int u = 0; u < PROBES; ++u) {
+                const uint32_t t = u * LOCAL_THREADS + tid;
+                const bool live = p != 0 && p < n && t <= p;
+                const uint32_t q = live ? p - t : 0u;
+                top[e][u][0] = (live && q > 0) ? (uint32_t)(keys_in[q - 1] >> 48) : 0x10000u;    // 0x10000: "differs" (q == 0 is a start)
+                top[e][u][1] = live ? (uint32_t)(keys_in[q] >> 48) : 0x10000u;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t p = e ? p1 : p0;
+#pragma unroll
+            for (int u = 0; u < PROBES; ++u) {
+                const uint32_t t = u * LOCAL_THREADS + tid;
+                const bool live = p != 0 && p < n && t <= p;
+                if (live && top[e][u][0] != top[e][u][1]) atomicMax(e ? &s_hi : &s_lo, (int)(p - t));
+            }
+        }
+    }
+    __syncthreads();
+    const int lo = s_lo, hi = s_hi;
+    if (lo < 0 || hi < 0) {                              // a run longer than LOCAL_LIMIT: flag it, pass the nominal range through
+        if (tid == 0) atomicExch(overflow, 1u);
+        for (uint32_t i = p0 + tid; i < p1; i += LOCAL_THREADS) { keys_out[i] = keys_in[i]; vals_out[i] = vals_in[i]; }
+        return;
+    }
+    const uint32_t cnt = (uint32_t)(hi - lo);            // <= LOCAL_W + LOCAL_LIMIT - 1
+    // Only {high key half, position} travels through the passes (3 registers per key with its rank; whole keys and
+    // values spilled); keys and values are gathered from the window once, at the end.
+    // Wave w owns the contiguous items [w * per, (w + 1) * per), per = the window spread evenly over the 16 waves
+    // (item order == position order, as stability needs); a window of 4096 keys costs 4 item rounds per pass, not
+    // the 10 its capacity allows: every sweep below stops at `nit` (workgroup-uniform).
+    const uint32_t per = (((cnt + LOCAL_WAVES - 1) / LOCAL_WAVES) + 63u) & ~63u;
+    const int nit = (int)(per >> 6);                     // <= LOCAL_ITEMS
+    const uint32_t base_w = w * per;
+    uint32_t kh[LOCAL_ITEMS], ix[LOCAL_ITEMS], rk[LOCAL_ITEMS];
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit) {
+        const uint32_t j = base_w + it * 64 + lane;
+        kh[it] = j < cnt ? (uint32_t)(keys_in[lo + j] >> 32) : ~0u;
+        ix[it] = j;
+    }
+    // which digits vary at all inside the window (typically not the top one): one AND / OR reduction for all four
+    if (tid == 0) { s_and = 0xffffffffu; s_or = 0u; }
+    __syncthreads();
+    {
+        uint32_t a = 0xffffffffu, o = 0u;
+#pragma unroll
+        for (int it = 0; it < LOCAL_ITEMS; ++it)
+            if (it < nit && base_w + it * 64 + lane < cnt) { a &= kh[it]; o |= kh[it]; }
+        for (int off = 32; off; off >>= 1) { a &= __shfl_xor(a, off); o |= __shfl_xor(o, off); }
+        if (lane == 0) { atomicAnd(&s_and, a); atomicOr(&s_or, o); }
+    }
+    __syncthreads();
+    const uint32_t varying = s_and ^ s_or;
+    for (int digit = 0; digit < 4; ++digit) {            // digits 4..7 of the key = digits 0..3 of its high half
+        const int shift = digit * RADIX_BITS;
+        if (((varying >> shift) & (RADIX - 1)) == 0) continue;            // (workgroup-uniform) one value in this digit: already in order
+        for (int i = tid; i < LOCAL_WAVES * RADIX; i += LOCAL_THREADS) (&wcnt[0][0])[i] = 0;
+        __syncthreads();
+        // Stable rank of every item among the items of its wave with the same digit (k_os_pass's scheme), arranged so
+        // that no item waits for the previous one's LDS round trip: one returning LDS add per match group (the LDS
+        // executes a wave's atomics in order, so a later group of the same digit sees the earlier add), and the old
+        // counts are broadcast in a second sweep.
+        uint32_t old[LOCAL_ITEMS]; int lead[LOCAL_ITEMS];
+#pragma unroll
+        for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit) {
+            const bool ok = base_w + it * 64 + lane < cnt;
+            const uint32_t d = (kh[it] >> shift) & (RADIX - 1);
+            uint64_t m = __ballot(ok);
+            m = ok ? m : ~m;
+#pragma unroll
+            for (int b = 0; b < RADIX_BITS; ++b) {
+                const uint64_t bb = __ballot((d >> b) & 1u);
+                m &= ((d >> b) & 1u) ? bb : ~bb;
+            }
+            rk[it] = __popcll(m & lt_mask);
+            lead[it] = __ffsll((unsigned long long)m) - 1;
+            old[it] = 0;
+            if (ok && lane == lead[it]) old[it] = atomicAdd(&wcnt[w][d], (uint32_t)__popcll(m));   // result not needed before the sweep below
+        }
+#pragma unroll
+        for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit) rk[it] += __shfl(old[it], lead[it]);
+        __syncthreads();
+        // thread = digit: exclusive offsets of (digit, wave) in digit-major order
+        uint32_t dtot = 0, dincl = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int ww = 0; ww < LOCAL_WAVES; ++ww) { const uint32_t c = wcnt[ww][tid]; wcnt[ww][tid] = dtot; dtot += c; }
+            dincl = dtot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(dincl, o); if (lane >= o) dincl += t; }
+            if (lane == 63) s_wsum[w] = dincl;
+        }
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t dbase = dincl - dtot;
+            for (int ww = 0; ww < w; ++ww) dbase += s_wsum[ww];
+#pragma unroll
+            for (int ww = 0; ww < LOCAL_WAVES; ++ww) wcnt[ww][tid] += dbase;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit) {
+            if (base_w + it * 64 + lane < cnt) {
+                const uint32_t d = (kh[it] >> shift) & (RADIX - 1);
+                sitem[wcnt[w][d] + rk[it]] = make_uint2(kh[it], ix[it]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit) {
+            const uint32_t j = base_w + it * 64 + lane;
+            if (j < cnt) { const uint2 t = sitem[j]; kh[it] = t.x; ix[it] = t.y; }
+        }
+        __syncthreads();                                                   // sitem / wcnt are rewritten by the next pass
+    }
+#pragma unroll
+    for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit) {
+        const uint32_t j = base_w + it * 64 + lane;
+        if (j < cnt) { keys_out[lo + j] = keys_in[lo + ix[it]]; vals_out[lo + j] = vals_in[lo + ix[it]]; }
+    }
+}
 
 // ====================================================================================================
 // Half-key sort + fix-up.  The onesweep passes are latency-bound at 1 M keys (~25 us each), so the cheapest pass

@@ -73,7 +73,8 @@ struct cd_ctx {
     bool leaves_filled = false;             // the sort's fix-up hop already wrote leaf[], parent = -1, bounded = 0
     bool events_ride = false;               // the last pass recorded EV_TRAV0 / EV_DESC1 / EV_TRAV1 through its kernels' dispatch packets
     bool prezeroed = false;                 // fused path: the scratch block was zeroed by one memset at pipeline start
-    bool sort_full = false;                 // true: all 8 digit passes (forced, or after a fix-up overflow on this context)
+    int sort_mode = 0;                      // 0 hybrid (2 global passes + in-LDS sort of the windows + fix-up), 1 half-key (4 passes + fix-up),
+                                            // 2 full (8 passes); forced by CD_OPT_SORT_FULL, or escalated after an overflow on this context
     double root_box_host[6] = {};           // AABB of the whole tree, fetched together with other read-backs
     bool root_box_valid = false;
 };
@@ -141,27 +142,32 @@ int enqueue_morton_sort(cd_ctx *c)
     }
     // fused pipeline: the sort scratch, the small counters and the traversal state are one block, zeroed once here
     HIPCHK(hipMemsetAsync(c->d_os, 0, c->prezeroed ? c->zero_bytes : c->os_bytes, s));
-    // half-key mode: 4 passes on the high 32 bits + a fix-up of equal-high-half runs (cd_sort.h); full mode: 8 passes.
-    // The keys start in the buffer that leaves the sorted data in buffer 0 (the fix-up is one more hop).
-    const int first_digit = c->sort_full ? 0 : 4;
-    int cur = c->sort_full ? 0 : 1;
+    // Three forms of the same stable 64-bit sort (cd_sort.h): hybrid = 2 global passes on the top 16 bits + an in-LDS
+    // sort of run-aligned windows + the fix-up hop; half-key = 4 global passes on the high 32 bits + the fix-up hop;
+    // full = 8 global passes.  The keys start in the buffer that leaves the sorted data in buffer 0.
+    const int mode = c->sort_mode;
+    const int first_digit = mode == 0 ? 6 : (mode == 1 ? 4 : 0);
+    int cur = mode == 1 ? 1 : 0;
     const uint32_t mblocks = cdiv(n, MORTON_THREADS * 4) < 1024u ? cdiv(n, MORTON_THREADS * 4) : 1024u;
     k_morton<<<mblocks, MORTON_THREADS, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_frame, c->d_keys[cur], c->d_os_hist, first_digit);
     HIPCHK(evrec(c, EV_MORTON1));
-    // onesweep: one pass over the data per digit (see cd_sort.h); the digit histograms came with the keys
+    // onesweep: one pass over the data per digit; the digit histograms came with the keys
     for (int pass = first_digit; pass < 8; ++pass) {
         k_os_pass<<<c->ntiles, OS_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1], n, pass * RADIX_BITS,
                                                     c->d_os_hist + pass * RADIX, c->d_os_look + (size_t)pass * c->ntiles * RADIX,
                                                     c->d_os_ticket + pass, pass == first_digit);
         cur ^= 1;
     }
+    if (mode == 0) {                            // data is in buffer 0 again; windows go 0 -> 1, the fix-up hop 1 -> 0
+        k_local_sort<<<cdiv(n, LOCAL_W), LOCAL_THREADS, 0, s>>>(c->d_keys[0], c->d_perm[0], c->d_keys[1], c->d_perm[1], n, c->d_os_ticket + 16);
+    }
     c->leaves_filled = false;
-    if (!c->sort_full) {
+    if (mode != 2) {
         k_sort_fixup_fill<<<cdiv(n, 256), 256, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, c->d_os_ticket + 16,
                                                        c->d_vidx, c->d_ids, c->d_leaf, c->d_parent, c->d_bounded);
         c->leaves_filled = true;                // by the fix-up hop; enqueue_hierarchy runs k_fill_leaves otherwise
     }
-    c->stats.sort_passes = c->sort_full ? 8 : 4;
+    c->stats.sort_passes = mode == 0 ? 2 : (mode == 1 ? 4 : 8);
     HIPCHK(evrec(c, EV_SORT1));
     HIPCHK(hipGetLastError());
     return 0;
@@ -503,11 +509,11 @@ int cd_set_morton_frame(cd_ctx *c, int mode, const double offset[3], const doubl
 }
 
 // the onesweep look-back spins are bounded; a timeout sets one of the words d_os_ticket[8..15]
-constexpr int SORT_REDO = 77;                   // internal: the half-key fix-up overflowed, redo with all 8 passes
+constexpr int SORT_REDO = 77;                   // internal: a run was too long for this form of the sort, redo with the next one
 static int judge_sort_flags(cd_ctx *c)
 {
     for (int i = 0; i < 8; ++i) if (c->sort_flags[i]) return CD_ERR_SORT;
-    if (c->sort_flags[8]) { c->sort_full = true; return SORT_REDO; }
+    if (c->sort_flags[8]) { if (c->sort_mode >= 2) return CD_ERR_SORT; ++c->sort_mode; return SORT_REDO; }
     return CD_OK;
 }
 static int check_sort_flags(cd_ctx *c)
@@ -523,7 +529,7 @@ int cd_morton_sort(cd_ctx *c)
     int rc = enqueue_morton_sort(c);
     if (rc) return rc;
     rc = check_sort_flags(c);
-    if (rc == SORT_REDO) { if ((rc = enqueue_morton_sort(c))) return rc; rc = check_sort_flags(c); }
+    for (int redo = 0; rc == SORT_REDO && redo < 2; ++redo) { if ((rc = enqueue_morton_sort(c))) return rc; rc = check_sort_flags(c); }
     if (rc) return rc;
     c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
     c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
@@ -601,7 +607,7 @@ int cd_build_tree(cd_ctx *c)
     HIPCHK(hipMemcpyAsync(c->root_box_host, c->d_boxes, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     rc = judge_sort_flags(c);
-    if (rc == SORT_REDO) return cd_build_tree(c);                    // once: sort_full is now set
+    if (rc == SORT_REDO) return cd_build_tree(c);                    // at most twice: sort_mode has been escalated
     if (rc) return rc;
     if (c->stage_events) {
         c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
@@ -626,7 +632,7 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     fused.done();
     if (rc < 0) return rc;
     { const int rs = judge_sort_flags(c);                                   // flags came back with the traversal counters
-      if (rs == SORT_REDO) return cd_self_collide(c, pairs, cap_pairs, n_pairs);   // once: sort_full is now set
+      if (rs == SORT_REDO) return cd_self_collide(c, pairs, cap_pairs, n_pairs);   // at most twice: sort_mode has been escalated
       if (rs) return rs; }
     if (c->stage_events) {
         c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
@@ -764,7 +770,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (!c) return CD_ERR_ARG;
     if (key == CD_OPT_TRAVERSAL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
     if (key == CD_OPT_QUERIES_PER_WAVE) { if (value < 64 || value > (1 << 20) || value % 64) return CD_ERR_ARG; c->queries_per_wave = (uint32_t)value; return CD_OK; }
-    if (key == CD_OPT_SORT_FULL) { c->sort_full = value != 0; return CD_OK; }
+    if (key == CD_OPT_SORT_FULL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->sort_mode = value == 0 ? 0 : (value == 1 ? 2 : 1); return CD_OK; }
     if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }
     if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
     if (key == 102) { c->dbg_halfload = (uint32_t)value; return CD_OK; }

@@ -65,7 +65,7 @@ typedef struct cd_stats {
     uint64_t candidates;       /* (query, leaf) candidates the fp32 descent handed to the exact kernel */
     float ms_descend;          /* shallow pass: memset + descent kernel (part of ms_traverse)          */
     float ms_exact;            /* shallow pass: exact-test kernel        (part of ms_traverse)          */
-    uint32_t sort_passes;      /* digit passes of the last sort: 4 (half-key + fix-up) or 8              */
+    uint32_t sort_passes;      /* global digit passes of the last sort: 2 (hybrid), 4 (half-key) or 8     */
     float ms_pipeline;         /* fused calls: pipeline start -> end of the traversal kernels, one event pair */
 } cd_stats;
 
@@ -152,9 +152,10 @@ enum {
     CD_OPT_TRAVERSAL        = 0,   /* 0: lane-private FP64 descent, exact test inline (the reference's shape,        */
                                    /*    collision.cuh:19-71); 1 (default): fp32 conservative descent with a          */
                                    /*    wavefront-shared LDS candidate queue + a second kernel for the exact tests   */
-    CD_OPT_SORT_FULL        = 2,   /* 0 (default): sort the high 32 key bits (4 passes) + stable fix-up of equal-high-half   */
-                                   /*    runs; falls back to 1 by itself when a run is too long.  1: all 8 digit passes.    */
-                                   /*    Both give the identical stable order by the full 64-bit key.                        */
+    CD_OPT_SORT_FULL        = 2,   /* 0 (default): hybrid -- 2 global passes on the top 16 key bits, the rest of the high half     */
+                                   /*    sorted inside LDS windows, stable fix-up of equal-high-half runs; falls back to 2, then  */
+                                   /*    to 1, by itself when a run is too long.  2: half-key -- 4 global passes + the fix-up.   */
+                                   /*    1: all 8 digit passes.  All give the identical stable order by the full 64-bit key.     */
     CD_OPT_STAGE_TIMING     = 3,   /* 1 (default): HIP events around every stage (cd_stats.ms_morton ... ms_refit); 0: only the  */
                                    /*    events of the pipeline as a whole and of the descent kernel (ms_pipeline, ms_traverse,   */
                                    /*    ms_descend, ms_exact) -- each stage boundary costs a few idle microseconds                */

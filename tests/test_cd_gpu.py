@@ -439,18 +439,41 @@ def test_eight_million_soup_variants_agree():
 
 
 def test_half_key_sort_equals_full_sort_and_falls_back():
-    """CD_OPT_SORT_FULL: the default (4 passes on the high 32 key bits + stable fix-up of equal-high-half runs) must give
-    the same keys AND permutation as all 8 passes (= the oracle's stable sort); a run of equal high halves longer than
-    the fix-up handles makes the library redo the sort with 8 passes by itself."""
+    """CD_OPT_SORT_FULL: the default hybrid (2 global passes on the top 16 key bits + in-LDS sort of run-aligned
+    windows + stable fix-up of equal-high-half runs), the half-key form (4 global passes + fix-up) and all 8 passes
+    must give the same keys AND permutation (= the oracle's stable sort); a run too long for one form makes the
+    library redo the sort with the next one by itself."""
     verts, vidx = synth.soup(200_000, 0.01, 31)
     r_keys, r_perm = oracle.sort_by_key(oracle.centroid_morton(verts, vidx))
-    for full in (0, 1):
+    for opt, passes in ((0, 2), (2, 4), (1, 8)):
         with mi355cd.CollisionDetector(verts, vidx) as cd:
-            cd.set_option(mi355cd.CD_OPT_SORT_FULL, full)
+            cd.set_option(mi355cd.CD_OPT_SORT_FULL, opt)
             cd.morton_sort()
             keys, perm = cd.export_keys()
-            assert cd.stats().sort_passes == (8 if full else 4)
+            assert cd.stats().sort_passes == passes
             assert np.array_equal(keys, r_keys) and np.array_equal(perm, r_perm)
+    # the cloth's keys form long runs of equal top-16 bits (hundreds of keys): the window logic of the hybrid form
+    cv, ct = synth.cloth_pair(150)
+    ck, cp = oracle.sort_by_key(oracle.centroid_morton(cv, ct))
+    with mi355cd.CollisionDetector(cv, ct) as cd:
+        cd.morton_sort()
+        keys, perm = cd.export_keys()
+        assert cd.stats().sort_passes == 2 and np.array_equal(keys, ck) and np.array_equal(perm, cp)
+    # 60 000 triangles in a few cells of the top-16-bit grid (a run longer than any window) but spread over the high half:
+    # hybrid -> half-key
+    rng0 = np.random.default_rng(8)
+    c1 = np.array([1.0, 0.0, 0.5]) + (rng0.random((60000, 1, 3)) - 0.5) * 0.1
+    v1 = (c1 + (rng0.random((60000, 3, 3)) - 0.5) * 1e-4).reshape(-1, 3)
+    t1 = np.arange(180000, dtype=np.uint32).reshape(60000, 3)
+    k1 = oracle.centroid_morton(v1, t1)
+    top16, cnt16 = np.unique(k1 >> np.uint64(48), return_counts=True)
+    _, cnt32 = np.unique(k1 >> np.uint64(32), return_counts=True)
+    assert cnt16.max() > 10240 and cnt32.max() <= 16                                  # a run too long to window, short equal-high-half runs
+    with mi355cd.CollisionDetector(v1, t1) as cd:
+        cd.morton_sort()
+        keys, perm = cd.export_keys()
+        rk1, rp1 = oracle.sort_by_key(k1)
+        assert cd.stats().sort_passes == 4 and np.array_equal(keys, rk1) and np.array_equal(perm, rp1)
     # keys that differ ONLY in their low 32 bits: one long run of equal high halves (200 triangles inside one coarse cell)
     rng = np.random.default_rng(5)
     c = np.array([1.0, 0.0, 0.5]) + (rng.random((200, 1, 3)) - 0.5) * 1e-5
