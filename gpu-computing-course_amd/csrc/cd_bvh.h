@@ -248,6 +248,7 @@ __device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ r, const Box
 //   * k_refit_seg_cross: the few nodes whose range leaves their block (O(N/512)) query the global tree.
 constexpr int REFIT_BLK = 512;     // leaves per workgroup
 constexpr int REFIT_LOG = 9;
+constexpr int SEG_MIN_LEVEL = 3;   // lowest level of the segment tree that is stored in memory (see seg_piece)
 
 __device__ __forceinline__ Box box_identity()
 {
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
             const Box m = box_merge(lds_box(t, 2 * k), lds_box(t, 2 * k + 1));
             double *d = t[k];
             d[0] = m.x1; d[1] = m.x2; d[2] = m.y1; d[3] = m.y2; d[4] = m.z1; d[5] = m.z2;
-            store_box(seg, (int)((((size_t)nbp2 + b) << dd) + tid), m);
+            if (REFIT_LOG - dd >= SEG_MIN_LEVEL) store_box(seg, (int)((((size_t)nbp2 + b) << dd) + tid), m);   // cross queries rebuild the lowest levels from leaves
         }
     }
     __syncthreads();
@@ -387,6 +388,17 @@ __global__ __launch_bounds__(1024) void k_refit_seg_top(double *seg, int nbp2, i
     }
 }
 
+// Box of heap node k at level p (2^p leaves).  Levels below SEG_MIN_LEVEL are not stored (three quarters of the tree's
+// bytes for a handful of reads): such a piece is merged from its 1, 2 or 4 leaf boxes, left to right.
+__device__ __forceinline__ Box seg_piece(const double *__restrict__ seg, const double *__restrict__ boxes, int n, long long P, long long k, int p)
+{
+    if (p >= SEG_MIN_LEVEL) return load_box(seg, (int)k);
+    const long long j0 = (k << p) - P;
+    Box x = box_identity();
+    for (int u = 0; u < (1 << p); ++u) { const long long j = j0 + u; if (j < n) x = box_merge(x, load_box(boxes, (n - 1) + (int)j)); }
+    return x;
+}
+
 // Ordered range query [l0, r0] (inclusive leaf positions) over the global tree by ONE WAVE: the iterative
 // bottom-up query takes at most one left piece and one right piece per level; lane p < 32 owns the left piece
 // of level p, lane 32+q the right piece of level 31-q, so lane order == left-to-right order of the pieces.
@@ -404,8 +416,7 @@ __device__ __forceinline__ Box seg_query_wave(const double *__restrict__ seg, co
         const long long k = is_left ? lp : rp - 1;
         const bool take = is_left ? (lp & 1) : (rp & 1);
         if (take) {
-            if (p == 0) { const long long j = k - P; if (j < n) x = load_box(boxes, (n - 1) + (int)j); }
-            else x = load_box(seg, (int)k);
+            x = seg_piece(seg, boxes, n, P, k, p);
         }
     }
 #pragma unroll
@@ -459,8 +470,7 @@ __device__ __forceinline__ Box seg_query_halves(const double *__restrict__ seg, 
         const long long k = is_left ? lp : rp - 1;
         const bool take = is_left ? (lp & 1) : (rp & 1);
         if (take) {
-            if (p == 0) { const long long j = k - P; if (j < n) x = load_box(boxes, (n - 1) + (int)j); }
-            else x = load_box(seg, (int)k);
+            x = seg_piece(seg, boxes, n, P, k, p);
         }
     }
     // Steps 1, 2, 4, 8 stay inside a row of 16 lanes: DPP row_shl (a VALU move, no LDS traffic); a lane whose source
