@@ -272,7 +272,8 @@ __device__ __forceinline__ Box seg_query_lds(const double (*t)[6], int l, int r)
 {
     Box accL = box_identity(), accR = box_identity();
     l += REFIT_BLK; r += REFIT_BLK + 1;
-    while (l < r) {
+    // (the level bound only matters for arguments outside [0, REFIT_BLK): a negative l would never reach r)
+    for (int lev = 0; lev <= REFIT_LOG && l < r; ++lev) {
         if (l & 1) { accL = box_merge(accL, lds_box(t, l)); ++l; }
         if (r & 1) { --r; accR = box_merge(lds_box(t, r), accR); }
         l >>= 1; r >>= 1;
