@@ -76,6 +76,9 @@ constexpr int TRAV_THREADS = 256;
 constexpr int TRAV_STACK   = 32;       // variant A: LDS entries per lane (the reference's private stack is 32, collision.cuh:21)
 constexpr int DEEP_STACK   = 192;      // global-memory entries per item in the overflow pass (tree height <= 96)
 
+__device__ __forceinline__ bool band(bool a, bool b) { return a ? b : false; }
+__device__ __forceinline__ bool bor(bool a, bool b) { return a ? true : b; }
+
 struct QuerySrc {
     const LeafTri *leaf;          // local: sorted leaves
     const double  *boxes;         // local: node boxes (query box = boxes[(n-1)+j])
@@ -331,10 +334,10 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                     const float plo0 = __int_as_float(go_left ? r0.x : r1.z), plo1 = __int_as_float(go_left ? r0.y : r1.w), plo2 = __int_as_float(go_left ? r0.z : r2.x);
                     const float phi0 = __int_as_float(go_left ? r0.w : r2.y), phi1 = __int_as_float(go_left ? r1.x : r2.z), phi2 = __int_as_float(go_left ? r1.y : r2.w);
                     const bool ph = valid & (qi != g0) & (qlo0 < phi0) & (plo0 < qhi0) & (qlo1 < phi1) & (plo1 < qhi1) & (qlo2 < phi2) & (plo2 < qhi2);
-                    const unsigned long long mP = __ballot(ph);
+                    const unsigned long long mP = __builtin_amdgcn_ballot_w64(ph);
                     if (mP) { if (ph) queue[w][qcount + __popcll(mP & lt_mask)] = Candidates{qi, g0 | ((r3.z & (go_left ? 1 : 2)) ? qcertain : 0u)}; qcount += __popcll(mP); }
                 }
-                const unsigned long long mC = __ballot(cnd);
+                const unsigned long long mC = __builtin_amdgcn_ballot_w64(cnd);
                 if (mC) { if (cnd) queue[w][qcount + __popcll(mC & lt_mask)] = Candidates{qi, cleaf | ((r3.z & (go_left ? 2 : 1)) ? qcertain : 0u)}; qcount += __popcll(mC); }
                 while (qcount >= 64) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
             if (valid & (sptr > 0)) { --sptr; node = lds_stack[sptr][tid]; }
         }
         const bool active = (node != -1);
-        if (__ballot(active) == 0ull) break;            // chunk exhausted and every lane finished
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;            // chunk exhausted and every lane finished
         ++steps;
 
         // ---- one descent step per active lane (fp32, conservative).  Written as straight-line selects: the
@@ -366,11 +369,13 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
         const bool ol  = active & (qlo0 < a.w) & (a.x < qhi0) & (qlo1 < b.x) & (a.y < qhi1) & (qlo2 < b.y) & (a.z < qhi2);
         const bool orr = active & (qlo0 < c.y) & (b.z < qhi0) & (qlo1 < c.z) & (b.w < qhi1) & (qlo2 < c.w) & (c.x < qhi2);
         visits += active ? 1u : 0u;
-        const bool intL = ol & (ch.x >= 0), intR = orr & (ch.y >= 0);
+        // (selects on i1, not integer & of promoted bools: the masks then stay in SGPR pairs instead of being
+        // materialised as 0 / 1 in VGPRs and compared again)
+        const bool intL = band(ol, ch.x >= 0), intR = band(orr, ch.y >= 0);
         const uint32_t leafL = (uint32_t)~ch.x, leafR = (uint32_t)~ch.y;
-        const bool candL = ol & (ch.x < 0) & (leafL != self_leaf), candR = orr & (ch.y < 0) & (leafR != self_leaf);
+        const bool candL = band(band(ol, ch.x < 0), leafL != self_leaf), candR = band(band(orr, ch.y < 0), leafR != self_leaf);
         int32_t nxt = intL ? ch.x : (intR ? ch.y : -1);
-        if (intL & intR) {                                                 // both internal: descend left, push right
+        if (band(intL, intR)) {                                            // both internal: descend left, push right
             if (sptr < stack_cap) { if (DEEP) gstack[sptr] = ch.y; else lds_stack[sptr][tid] = ch.y; ++sptr; }
             else {
                 // Stack full: hand the right subtree to the deep pass as its own work item and go on.
@@ -379,10 +384,11 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                 if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)ch.y);
             }
         }
-        if (active & (nxt < 0) & (sptr > 0)) { --sptr; nxt = DEEP ? gstack[sptr] : lds_stack[sptr][tid]; }
+        if (band(band(active, !bor(intL, intR)), sptr > 0)) { --sptr; nxt = DEEP ? gstack[sptr] : lds_stack[sptr][tid]; }   // (nxt < 0, said with the masks at hand)
         node = active ? nxt : -1;
         // ---- enqueue candidates, compacted over the active lanes (skipped wave-uniformly when there are none)
-        const unsigned long long mL = __ballot(candL), mR = __ballot(candR);
+        // (the builtin takes the i1 as it is; __ballot(int) makes the compiler materialise 0 / 1 and compare again)
+        const unsigned long long mL = __builtin_amdgcn_ballot_w64(candL), mR = __builtin_amdgcn_ballot_w64(candR);
         if ((mL | mR) == 0ull) continue;
         {
             const uint32_t nL = __popcll(mL);
