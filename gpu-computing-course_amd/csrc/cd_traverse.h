@@ -216,6 +216,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_
 constexpr int WQ_STACK = 12;                 // LDS stack entries per lane (12 KB + 6 KB queue per workgroup -> 8 workgroups = 32 waves per CU)
 constexpr int WQ_QCAP  = 192;                // queue slots per wave: < 64 left over + at most 128 new per step
 constexpr int WQ_WAVES = TRAV_THREADS / 64;
+constexpr int SHARE_MIN_IDLE = 16;           // idle lanes in a wave before busy lanes hand subtrees over (65 = never); 4 .. 16 measured equal, 1 and 32 worse
 
 // leaf: bit 31 set = both boxes are exact in fp32 (cd_bvh.h box_is_fp32), so the fp32 overlap found by the descent IS
 // the exact leaf-AABB test and k_exact need not fetch the two FP64 boxes again
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
     if (sort_failed(src)) return;
     __shared__ int32_t lds_stack[DEEP ? 1 : WQ_STACK][TRAV_THREADS];
     __shared__ Candidates queue[WQ_WAVES][WQ_QCAP];
+    __shared__ uint8_t share_map[WQ_WAVES][64];        // work sharing: lane id of the k-th donor
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD and
@@ -353,6 +355,31 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                 pn = __builtin_amdgcn_readfirstlane(onp);
             }
             if (valid & (sptr > 0)) { --sptr; node = lds_stack[sptr][tid]; }
+        }
+        // ---- work sharing inside the wave.  After the shared path a lane only has the few subtrees its own query
+        // overlaps: lanes finish at very different times (24 of 64 busy on average; the busiest wave ran 78 steps
+        // against a mean of 26, and the kernel ends with its last wave).  A busy lane that still has a subtree on
+        // its stack hands the top one, together with its query (index, fp32 box, flags), to an idle lane, which
+        // descends it as if it were its own: every (query, subtree) is still descended exactly once, by someone.
+        if (!DEEP && SHARE_MIN_IDLE <= 64) {
+            const bool idle = (node == -1), donor = (node != -1) & (sptr > 0);
+            const unsigned long long m_idle = __builtin_amdgcn_ballot_w64(idle), m_don = __builtin_amdgcn_ballot_w64(donor);
+            if (m_don != 0ull && __popcll(m_idle) >= SHARE_MIN_IDLE && (REFILL ? next >= chunk_end : true)) {   // (wave-uniform)
+                const uint32_t nx = min((uint32_t)__popcll(m_don), (uint32_t)__popcll(m_idle));
+                const uint32_t rank_d = __popcll(m_don & lt_mask), rank_r = __popcll(m_idle & lt_mask);
+                const bool give = donor & (rank_d < nx), take = idle & (rank_r < nx);
+                int32_t top = -1;
+                // (giving the OLDEST entry instead -- the highest in the tree, the biggest piece of work -- measured the same)
+                if (give) { share_map[w][rank_d] = (uint8_t)lane; --sptr; top = lds_stack[sptr][tid]; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int src = take ? (int)share_map[w][rank_r] : (int)lane;
+                const int32_t e = __shfl(top, src);
+                const uint32_t s_qi = __shfl(qi, src), s_self = __shfl(self_leaf, src), s_cert = __shfl(qcertain, src);
+                const float f0 = __shfl(qlo0, src), f1 = __shfl(qlo1, src), f2 = __shfl(qlo2, src);
+                const float f3 = __shfl(qhi0, src), f4 = __shfl(qhi1, src), f5 = __shfl(qhi2, src);
+                if (take) { node = e; qi = s_qi; self_leaf = s_self; qcertain = s_cert; qlo0 = f0; qlo1 = f1; qlo2 = f2; qhi0 = f3; qhi1 = f4; qhi2 = f5; sptr = 0; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
         }
         const bool active = (node != -1);
         if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;            // chunk exhausted and every lane finished
