@@ -222,6 +222,10 @@ constexpr int SHARE_MIN_IDLE = 16;           // idle lanes in a wave before busy
 // the exact leaf-AABB test and k_exact need not fetch the two FP64 boxes again
 struct Candidates { uint32_t q, leaf; };
 constexpr uint32_t CAND_CERTAIN = 0x80000000u;
+// bit 30 (only together with bit 31): the descent has also applied the neighbour filter and the ID rule, and counted
+// the pair as tested -- k_exact sends it straight to the SAT
+constexpr uint32_t CAND_FILTERED = 0x40000000u;
+constexpr uint32_t CAND_LEAF_MASK = 0x3fffffffu;
 
 // queries_per_wave: size of the contiguous chunk of queries one wave works through (multiple of 64).
 template <bool EXTERNAL, bool DEEP, bool REFILL>
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                                                           TravState *__restrict__ st,
                                                           Candidates *__restrict__ cand, unsigned long long shard_cap,
                                                           uint2 *__restrict__ defer_list, uint32_t defer_cap,
-                                                          int32_t *__restrict__ deep_stacks)
+                                                          int32_t *__restrict__ deep_stacks, uint32_t vbase)
 {
     if (sort_failed(src)) return;
     __shared__ int32_t lds_stack[DEEP ? 1 : WQ_STACK][TRAV_THREADS];
@@ -256,6 +260,39 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
     uint32_t qcount = 0;                                // wave-uniform: candidates waiting in the queue
     uint32_t tested = 0, visits = 0, steps = 0;
     int32_t node = -1; int sptr = 0; uint32_t qi = 0, self_leaf = 0xffffffffu;
+    // Hand the last `count` (<= 64) queued candidates over to k_exact, one per lane.  A candidate the descent has
+    // decided exactly (CAND_CERTAIN) is a tested pair whatever follows, and all that stands between it and the SAT are
+    // two cheap filters on 16-byte records -- so they run here, with full lanes, and only the ~2 % that survive (plus
+    // everything that still needs the FP64 box test) travel through memory to k_exact.
+    auto flush = [&](uint32_t count) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        Candidates cd0 = Candidates{0, 0};
+        bool keep = lane < count;
+        if (keep) cd0 = queue[w][qcount - count + lane];
+        if (keep && (cd0.leaf & CAND_CERTAIN)) {
+            ++tested;                                                          // collision.cuh:31-32 decided (exactly) by the descent
+            const LeafTri lt = src.leaf[cd0.leaf & CAND_LEAF_MASK];
+            uint32_t q_id, qa, qb, qc;
+            if (EXTERNAL) {
+                const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + cd0.q;
+                q_id = q->id; qa = q->vidx[0]; qb = q->vidx[1]; qc = q->vidx[2];
+            } else {
+                const LeafTri ql = src.leaf[cd0.q];
+                q_id = ql.id; qa = ql.v0; qb = ql.v1; qc = ql.v2;
+            }
+            keep = neighbor_count(qa, qb, qc, lt.v0 + vbase, lt.v1 + vbase, lt.v2 + vbase) < 1 && q_id < lt.id;   // collision.cuh:38, tri_contact.cuh:81
+            cd0.leaf |= CAND_FILTERED;
+        }
+        qcount -= count;
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(keep);
+        if (mk != 0ull) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&sh->n_candidates, (unsigned long long)__popcll(mk));
+            base = __shfl(base, 0) + __popcll(mk & lt_mask);
+            if (keep && base < shard_cap) my_cand[base] = cd0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
     float qlo0 = 0, qlo1 = 0, qlo2 = 0, qhi0 = 0, qhi1 = 0, qhi2 = 0;
     uint32_t qcertain = 0;                              // CAND_CERTAIN if the query box is exact in fp32
     int32_t *gstack = DEEP ? deep_stacks + ((size_t)wave_id * 64 + lane) * DEEP_STACK : nullptr;
@@ -341,16 +378,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                 }
                 const unsigned long long mC = __builtin_amdgcn_ballot_w64(cnd);
                 if (mC) { if (cnd) queue[w][qcount + __popcll(mC & lt_mask)] = Candidates{qi, cleaf | ((r3.z & (go_left ? 2 : 1)) ? qcertain : 0u)}; qcount += __popcll(mC); }
-                while (qcount >= 64) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    const Candidates cd0 = queue[w][qcount - 64 + lane];
-                    qcount -= 64;
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(&sh->n_candidates, 64ull);
-                    base = __shfl(base, 0);
-                    if (base + lane < shard_cap) my_cand[base + lane] = cd0;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                }
+                while (qcount >= 64) flush(64);
                 if (onp < 0) break;
                 pn = __builtin_amdgcn_readfirstlane(onp);
             }
@@ -423,24 +451,9 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
             if (candR) queue[w][qcount + nL + __popcll(mR & lt_mask)] = Candidates{qi, leafR | ((ch.z & 2) ? qcertain : 0u)};
             qcount += nL + __popcll(mR);
         }
-        while (qcount >= 64) {                                   // full batch -> global buffer, 512 B coalesced
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const Candidates cnd = queue[w][qcount - 64 + lane];
-            qcount -= 64;
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(&sh->n_candidates, 64ull);
-            base = __shfl(base, 0);
-            if (base + lane < shard_cap) my_cand[base + lane] = cnd;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
+        while (qcount >= 64) flush(64);                          // full batch: one candidate per lane
     }
-    if (qcount > 0) {                                            // final partial batch
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&sh->n_candidates, (unsigned long long)qcount);
-        base = __shfl(base, 0);
-        if (lane < qcount && base + lane < shard_cap) my_cand[base + lane] = queue[w][lane];
-    }
+    if (qcount > 0) flush(qcount);                               // final partial batch
     const unsigned long long t64 = wave_sum_u64(tested), v64 = wave_sum_u64(visits);
     if (lane == 0) {
         if (t64) atomicAdd(&sh->pairs_tested, t64);
@@ -655,12 +668,14 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
                 c[j] = cand[(size_t)lo * shard_cap + (k - pre[lo])];
             }
         }
-        LeafTri lt[EXACT_ITEMS]; Box lb[EXACT_ITEMS], qbox[EXACT_ITEMS]; bool certain[EXACT_ITEMS]; uint32_t q_id[EXACT_ITEMS], qa[EXACT_ITEMS], qb[EXACT_ITEMS], qc[EXACT_ITEMS];
+        LeafTri lt[EXACT_ITEMS]; Box lb[EXACT_ITEMS], qbox[EXACT_ITEMS]; bool certain[EXACT_ITEMS], filtered[EXACT_ITEMS]; uint32_t q_id[EXACT_ITEMS], qa[EXACT_ITEMS], qb[EXACT_ITEMS], qc[EXACT_ITEMS];
 #pragma unroll
         for (int j = 0; j < EXACT_ITEMS; ++j) {
-            const uint32_t qi = c[j].q, lj = c[j].leaf & ~CAND_CERTAIN;   // (0, 0) for lanes past the end: harmless in-bounds loads
+            const uint32_t qi = c[j].q, lj = c[j].leaf & CAND_LEAF_MASK;  // (0, 0) for lanes past the end: harmless in-bounds loads
             certain[j] = (c[j].leaf & CAND_CERTAIN) != 0;
+            filtered[j] = (c[j].leaf & CAND_FILTERED) != 0;                 // counted and filtered by the descent: nothing to fetch here
             c[j].leaf = lj;
+            if (filtered[j]) { lt[j] = LeafTri{0, 0, 0, 0}; lb[j] = qbox[j] = Box{0, 0, 0, 0, 0, 0}; q_id[j] = qa[j] = qb[j] = qc[j] = 0; continue; }
             lt[j] = leaf[lj];
             lb[j] = qbox[j] = Box{0, 0, 0, 0, 0, 0};
             if (!certain[j]) lb[j] = load_box(boxes, (n - 1) + (int)lj);
@@ -676,6 +691,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
         }
 #pragma unroll
         for (int j = 0; j < EXACT_ITEMS; ++j) {
+            if (ok[j] && filtered[j]) { sq[atomicAdd(&sqcount, 1u)] = SatItem{c[j].q, c[j].leaf}; continue; }
             if (ok[j] && (certain[j] || box_overlap(qbox[j], lb[j]))) {        // collision.cuh:31-32, exact (certain: already decided exactly by the descent)
                 ++tested;
                 const bool survive = neighbor_count(qa[j], qb[j], qc[j], lt[j].v0 + vbase, lt[j].v1 + vbase, lt[j].v2 + vbase) < 1   // collision.cuh:38

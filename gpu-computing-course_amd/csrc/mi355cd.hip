@@ -242,10 +242,10 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
         uint2 *dl = DEEP ? nullptr : c->d_defer; const uint32_t dcap = DEEP ? 0u : c->defer_cap; int32_t *deep = DEEP ? c->d_deep : nullptr;
         if (qpw == 64)
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, false>), grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
-                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, deep);
+                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb);
         else
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, true>), grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
-                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, deep);
+                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb);
         if (!DEEP && !ride) evrec(c, EV_DESC1);
         hipExtLaunchKernelGGL((k_exact<EXTERNAL>), dim3(c->exact_blocks), dim3(EXACT_THREADS), 0u, s, nullptr, e2, 0u,
                               src, n, (const LeafTri *)c->d_leaf, (const double *)c->d_boxes, (const double *)c->d_verts, vb, (const Candidates *)c->d_cand,
