@@ -217,7 +217,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
 // between tiles; a pass that stays inside a workgroup has no hand-off.  So only the TOP 16 key bits are sorted
 // globally (2 onesweep passes); that leaves runs of equal top-16 bits (tens to thousands of keys: ~2^16 cells over
 // the Morton frame), contiguous and in input order, and k_local_sort finishes bits 32..63 inside LDS:
-//   * workgroup b takes the window [s_b, s_{b+1}), where s_b is the last run start at or before b * LOCAL_W -- no run
+//   * workgroup b takes the window [s_b, s_{b+1}), where s_b is the run start nearest to b * LOCAL_W -- no run
 //     straddles two windows, so sorting the windows independently sorts the array;
 //   * inside the window: stable LSD passes over digits 4..7 with the same __ballot ranking as k_os_pass, {high key
 //     half, position} held in registers and permuted through LDS; a pass whose digit is the same for the whole
@@ -242,26 +242,27 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     __shared__ uint2 sitem[LOCAL_CAP];                   // 80 KB: {high 32 key bits, position inside the window}
     __shared__ uint32_t wcnt[LOCAL_WAVES][RADIX];        // 16 KB
     __shared__ uint32_t s_wsum[RADIX / 64];
-    __shared__ int s_lo, s_hi;
+    __shared__ uint32_t s_enc[2];
     __shared__ uint32_t s_and, s_or;
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const uint32_t p0 = blockIdx.x * LOCAL_W, p1 = min(p0 + (uint32_t)LOCAL_W, n);
-    if (tid == 0) { s_lo = p0 == 0 ? 0 : -1; s_hi = p1 >= n ? (int)n : -1; }
+    if (tid == 0) { s_enc[0] = s_enc[1] = 0xffffffffu; }
     __syncthreads();
-    // window ends: the last run start at or before p0 and p1 (a run starts where the top 16 bits change).  All the
-    // probes of a thread (LOCAL_LIMIT / LOCAL_THREADS positions per end, two keys each) are issued before any is used.
+    // Window ends: the run start NEAREST to p0 and to p1 (a run starts where the top 16 bits change; equal distance:
+    // the lower one), searched LOCAL_LIMIT / 2 positions to either side -- the windows then differ from their nominal
+    // size by at most half a run to either side, instead of a whole run to one.  The function p -> nearest start is
+    // monotone, so windows never overlap.  All the probes of a thread (two keys each) are issued before any is used.
     {
-        constexpr int PROBES = LOCAL_LIMIT / LOCAL_THREADS;
+        constexpr int PROBES = LOCAL_LIMIT / LOCAL_THREADS, HALF = LOCAL_LIMIT / 2;
         uint32_t top[2][PROBES][2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const uint32_t p = e ? p1 : p0;
 #pragma unroll
             for (int u = 0; u < PROBES; ++u) {
-                const uint32_t t = u * LOCAL_THREADS + tid;
-                const bool live = p != 0 && p < n && t <= p;
-                const uint32_t q = live ? p - t : 0u;
+                const long long q = (long long)p - HALF + (u * LOCAL_THREADS + (int)tid);
+                const bool live = p != 0 && p < n && q >= 0 && q < (long long)n;
                 top[e][u][0] = (live && q > 0) ? (uint32_t)(keys_in[q - 1] >> 48) : 0x10000u;    // 0x10000: "differs" (q == 0 is a start)
                 top[e][u][1] = live ? (uint32_t)(keys_in[q] >> 48) : 0x10000u;
             }
@@ -271,19 +272,25 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
             const uint32_t p = e ? p1 : p0;
 #pragma unroll
             for (int u = 0; u < PROBES; ++u) {
-                const uint32_t t = u * LOCAL_THREADS + tid;
-                const bool live = p != 0 && p < n && t <= p;
-                if (live && top[e][u][0] != top[e][u][1]) atomicMax(e ? &s_hi : &s_lo, (int)(p - t));
+                const long long q = (long long)p - HALF + (u * LOCAL_THREADS + (int)tid);
+                const bool live = p != 0 && p < n && q >= 0 && q < (long long)n;
+                if (live && top[e][u][0] != top[e][u][1]) {
+                    const uint32_t dist = (uint32_t)(q > (long long)p ? q - p : p - q);
+                    atomicMin(&s_enc[e], (dist << 1) | (q > (long long)p ? 1u : 0u));
+                }
             }
         }
     }
     __syncthreads();
-    const int lo = s_lo, hi = s_hi;
-    if (lo < 0 || hi < 0) {                              // a run longer than LOCAL_LIMIT: flag it, pass the nominal range through
+    const uint32_t e0 = s_enc[0], e1 = s_enc[1];
+    const bool found0 = p0 == 0 || e0 != 0xffffffffu, found1 = p1 >= n || e1 != 0xffffffffu;
+    if (!found0 || !found1) {                            // a run longer than LOCAL_LIMIT: flag it, pass the nominal range through
         if (tid == 0) atomicExch(overflow, 1u);
         for (uint32_t i = p0 + tid; i < p1; i += LOCAL_THREADS) { keys_out[i] = keys_in[i]; vals_out[i] = vals_in[i]; }
         return;
     }
+    const int lo = p0 == 0 ? 0 : (int)((e0 & 1u) ? p0 + (e0 >> 1) : p0 - (e0 >> 1));
+    const int hi = p1 >= n ? (int)n : (int)((e1 & 1u) ? p1 + (e1 >> 1) : p1 - (e1 >> 1));
     const uint32_t cnt = (uint32_t)(hi - lo);            // <= LOCAL_W + LOCAL_LIMIT - 1
     // Only {high key half, position} travels through the passes (3 registers per key with its rank; whole keys and
     // values spilled); keys and values are gathered from the window once, at the end.
