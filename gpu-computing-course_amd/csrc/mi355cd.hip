@@ -37,7 +37,7 @@ struct cd_ctx {
     uint32_t vbase = 0;
     int trav_variant = 1;                   // CD_OPT_TRAVERSAL: 0 = lane-private FP64 (A), 1 = split fp32 descent + exact kernel (B)
     uint32_t queries_per_wave = 64; 
-    uint32_t dbg_halfload = 0;              // debug key 102: 1 = k_descend without the shared root path (A/B)
+    uint32_t dbg_no_shared_path = 0;              // debug key 102: 1 = k_descend without the shared root path (A/B)
     uint32_t dbg_lds_pad = 0;               // CD_OPT_DEBUG_LDS_PAD: extra dynamic LDS bytes per traversal workgroup (occupancy experiments)        // CD_OPT_QUERIES_PER_WAVE (variant B chunk size)                     // global id of local vertex 0 (cross-rank neighbour filter)
     double frame_host[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};   // morton.h:45,51,57
     hipStream_t stream = nullptr;
@@ -238,7 +238,7 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
         // (hipExtLaunchKernelGGL start / stop events): same timestamps, no gaps.
         const bool ride = !DEEP && !c->stage_events;
         hipEvent_t e0 = ride ? c->ev[EV_TRAV0] : nullptr, e1 = ride ? c->ev[EV_DESC1] : nullptr, e2 = ride ? c->ev[EV_TRAV1] : nullptr;
-        const uint32_t qarg = qpw | (c->dbg_halfload ? 0x40000000u : 0u);
+        const uint32_t qarg = qpw | (c->dbg_no_shared_path ? 0x40000000u : 0u);
         uint2 *dl = DEEP ? nullptr : c->d_defer; const uint32_t dcap = DEEP ? 0u : c->defer_cap; int32_t *deep = DEEP ? c->d_deep : nullptr;
         if (qpw == 64)
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, false>), grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
@@ -773,7 +773,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (key == CD_OPT_SORT_FULL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->sort_mode = value == 0 ? 0 : (value == 1 ? 2 : 1); return CD_OK; }
     if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }
     if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
-    if (key == 102) { c->dbg_halfload = (uint32_t)value; return CD_OK; }
+    if (key == 102) { c->dbg_no_shared_path = (uint32_t)value; return CD_OK; }
     if (key == 101) { if (value < 1 || value > 65535) return CD_ERR_ARG; c->exact_blocks = (int)value; return CD_OK; }
     return CD_ERR_ARG;
 }

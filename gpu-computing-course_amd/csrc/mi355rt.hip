@@ -143,9 +143,9 @@ __global__ __launch_bounds__(256) void k_prepare(const RtSphere *__restrict__ s,
 // BINNED == false: anime_ray.cu:70-82 verbatim -- every pixel loops over all spheres.  The sphere index
 // is wave-uniform, so the geometry comes through the scalar cache (s_load), not LDS.
 // BINNED == true: first the workgroup culls spheres that cannot touch the tile, with a bound built from
-// the same float operations as the hit test (below), keeping survivors in index order; pixels then loop
-// over the survivors only.  Identical pixels, ~S/(survivors) times fewer hit() evaluations.  The cull itself is
-// two-level: k_bin_super reduces the S spheres to a few dozen per 256x256 super-tile, the tile culls only those.
+// the same float operations as the hit test (below); pixels then loop over the survivors only (any order: the
+// tie rule is explicit in shade_one).  Identical pixels, ~S/(survivors) times fewer hit() evaluations.  The cull itself is
+// two-level: k_prepare bins every sphere into the 256x256 super-tiles it may touch, the tile culls only its super-tile's list.
 template <bool BINNED>
 __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ geom, const SphShade *__restrict__ shade, int n,
                                                     int dim, int c_shift_x, int c_shift_y, int tile_y0,
