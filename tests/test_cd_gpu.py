@@ -555,3 +555,26 @@ def test_exact_leaf_test_with_and_without_fp32_representable_boxes(kind):
             assert rc == 0 and n == r["stats"].n_pairs
             assert cd.stats().pairs_tested == r["stats"].pairs_tested
             assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """bench.py's N > 1 path end to end on the device: two processes (torch.distributed.run) share this GPU, the
+    collectives run on gloo with host staging (MI355_DIST_BACKEND=gloo -- RCCL refuses two ranks on one device), every
+    other line is the shipped multi-GPU step: local trees, root all-gather, query exchange, cross traversal.  The pair
+    total must equal the oracle's on the merged two-object mesh."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    quads = 60
+    env = dict(os.environ, MI355_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--quads", str(quads)],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    parts = [synth.cloth_shard(r, quads) for r in range(2)]
+    v = np.concatenate([p[0] for p in parts]); ids = np.concatenate([p[2] for p in parts])
+    t = np.concatenate([p[1] + (0 if r == 0 else parts[0][0].shape[0]) for r, p in enumerate(parts)]).astype(np.uint32)
+    ref = oracle.pipeline(v, t, ids)
+    assert line["config"]["colliding_pairs"] == ref["stats"].n_pairs
+    assert line["config"]["last_step_rank0"]["peers"] == [1] and line["config"]["last_step_rank0"]["sent_queries"] > 0
