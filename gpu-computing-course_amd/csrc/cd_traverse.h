@@ -324,7 +324,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                         self_leaf = qi;
                         // the query meets its own leaf in every traversal: decide that hit here, exactly, once
                         // (not in the deep pass, which only continues a traversal that already did)
-                        if (!DEEP && box_overlap(qb, qb)) ++tested;
+                        if (!DEEP && n > 1 && box_overlap(qb, qb)) ++tested;       // (a single triangle has no tree to walk: nothing is tested)
                     }
                     qlo0 = __double2float_rd(qb.x1); qhi0 = __double2float_ru(qb.x2);
                     qlo1 = __double2float_rd(qb.y1); qhi1 = __double2float_ru(qb.y2);

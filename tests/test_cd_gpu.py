@@ -578,3 +578,44 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     ref = oracle.pipeline(v, t, ids)
     assert line["config"]["colliding_pairs"] == ref["stats"].n_pairs
     assert line["config"]["last_step_rank0"]["peers"] == [1] and line["config"]["last_step_rank0"]["sent_queries"] > 0
+
+
+def test_random_meshes_property():
+    """Seeded random inputs of many shapes (sizes 1..3000, soups of very different density, shared-vertex meshes, exact
+    duplicates, zero-area triangles, coordinates that are / are not fp32 values, custom IDs in random order): every
+    traversal variant must reproduce the oracle's pair set and pairs-tested count, and the default pipeline its keys,
+    permutation and tree."""
+    rng = np.random.default_rng(20261003)
+    for case in range(120):
+        n = int(rng.choice([1, 2, 3, 5, 17, 64, 65, 130, 511, 513, 1200, 3000]))
+        kind = case % 4
+        if kind == 0:                                                       # soup, density from sparse to very dense
+            verts, vidx = synth.soup(n, float(rng.choice([0.01, 0.1, 0.5, 1.5])), int(rng.integers(1 << 30)))
+        elif kind == 1:                                                     # mesh with shared vertices (+ a few soup triangles)
+            q = max(1, int(np.sqrt(n / 4)))
+            verts, vidx = synth.cloth_pair(q)
+        elif kind == 2:                                                     # duplicates and degenerate triangles
+            verts, vidx = synth.soup(max(1, n // 2), 0.3, int(rng.integers(1 << 30)))
+            vidx = np.concatenate([vidx, vidx[: max(1, n // 4)]]).astype(np.uint32)          # exact duplicates (shared vertices -> filtered)
+            deg = vidx[:3].copy(); deg[:, 2] = deg[:, 1]                                        # zero-area triangles
+            vidx = np.concatenate([vidx, deg]).astype(np.uint32)
+        else:                                                               # full-precision doubles
+            verts, vidx = synth.soup(n, 0.2, int(rng.integers(1 << 30)))
+            verts = verts + (rng.random(verts.shape) - 0.5) * 1e-7
+        ids = None
+        if case % 3 == 0:
+            ids = rng.permutation(vidx.shape[0]).astype(np.uint32) + 7
+        r = oracle.pipeline(verts, vidx, ids)
+        for variant in VARIANTS:
+            with mi355cd.CollisionDetector(verts, vidx, ids) as cd:
+                cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
+                pairs, npairs, rc = cd.self_collide(cap=1 << 22)
+                assert rc == 0 and npairs == r["stats"].n_pairs, (case, variant)
+                assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])), (case, variant)
+                assert cd.stats().pairs_tested == r["stats"].pairs_tested, (case, variant)
+                if variant == 1:
+                    keys, perm = cd.export_keys()
+                    assert np.array_equal(keys, r["keys"]) and np.array_equal(perm, r["perm"]), case
+                    parent, left, right, boxes, bounded = cd.export_tree()
+                    assert np.array_equal(left, r["left"]) and np.array_equal(right, r["right"]) and np.array_equal(parent, r["parent"]), case
+                    assert np.array_equal(boxes.view(np.uint64), r["boxes"].view(np.uint64)), case
