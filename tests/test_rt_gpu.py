@@ -156,3 +156,30 @@ def test_rt_main_harness_animates(tmp_path):
     data = ppm.read_bytes()
     assert data.startswith(b"P6\n256 256\n255\n") and len(data) == len(b"P6\n256 256\n255\n") + 256 * 256 * 3
     assert any(data[15:])                                                  # not a black frame
+
+
+def test_random_scenes_property():
+    """Seeded random scenes: image sizes 64..512, 1..700 spheres with radii from sub-pixel to larger than the image,
+    positions on and far off the screen, duplicate spheres (ties in t), random sphere shifts (also through shuffled
+    idx), camera offsets and row slabs -- both modes must reproduce the oracle's pixels."""
+    rng = np.random.default_rng(77)
+    for case in range(30):
+        dim = int(rng.choice([64, 128, 192, 256, 512]))
+        n = int(rng.choice([1, 2, 7, 64, 65, 300, 700]))
+        spheres, shifts = synth.sphere_scene(n, dim, int(rng.integers(1 << 30)))
+        spheres["radius"] = (rng.random(n) ** 3 * float(rng.choice([4.0, 40.0, 2.0 * dim])) + 0.25).astype(np.float32)
+        spheres["x"] = (spheres["x"] * float(rng.choice([1.0, 3.0]))).astype(np.float32)      # some far off the screen
+        if n > 2:
+            spheres[n // 2] = spheres[0]; spheres["idx"][n // 2] = n // 2                        # an exact duplicate: tie in t
+        spheres["idx"] = rng.permutation(n).astype(np.int32)                                     # shifts looked up through idx
+        shifts[:, :2] = rng.integers(-40, 40, size=(n, 2))
+        csx, csy = int(rng.integers(-30, 30)), int(rng.integers(-30, 30))
+        want = oracle.rt_render(spheres, shifts, dim, csx, csy)
+        with mi355rt.RayTracer(spheres, dim) as rt:
+            for mode in MODES:
+                rt.set_mode(mode)
+                assert np.array_equal(rt.render(shifts, csx, csy), want), (case, mode)
+            if dim >= 128:
+                rt.set_mode(mi355rt.RT_MODE_BINNED)
+                y0 = 64 * int(rng.integers(0, dim // 64 - 1)); y1 = y0 + 64
+                assert np.array_equal(rt.render(shifts, csx, csy, rows=(y0, y1)), want[y0:y1]), case
