@@ -225,14 +225,16 @@ def main():
             desc_bytes = TRAVERSAL_BYTES_PER_TRI * nt
             achieved = desc_bytes / (kern["descend"] * 1e-3) / 1e9
             traffic = None
+            l2_hit = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if tj.get("triangles") == nt:
                     traffic = tj.get("traverse_hbm_bytes_per_launch")
+                    l2_hit = tj.get("l2_hit_rate")                     # TCC_HIT / (TCC_HIT + TCC_MISS) of k_descend, same rocprofv3 run set
             line["kernel_ms"] = kern
             line["roofline"] = {"bound": "hbm", "kernel": "k_descend (fp32 BVH descent; its candidates go to k_exact)", "achieved": achieved,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "l2_hit_rate": l2_hit,
                                 "algorithmic_bytes_per_launch": desc_bytes, "avg_launch_ms": kern["descend"],
                                 "dominant_stage": dominant,
                                 "whole_path": {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9,

@@ -12,6 +12,8 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3
 echo "FETCH_SIZE pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_write.json 2> $O/pmc_write.err
 echo "WRITE_SIZE pass done"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -o run -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_l2.json 2> $O/pmc_l2.err
+echo "L2 hit / miss pass done"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -o run -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_sq.json 2> $O/pmc_sq.err
 echo "SQ pass done"
 rm -f $O/trace/run_kernel_trace.csv        # tens of MB; the stats file is the summary

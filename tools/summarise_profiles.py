@@ -20,15 +20,19 @@ def per_kernel(path):
     return acc
 
 hbm = collections.defaultdict(dict)
-for sub in ("pmc_fetch", "pmc_write"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_l2"):
+    if not os.path.exists(os.path.join(src, sub, "run_counter_collection.csv")):
+        continue
     for k, cs in per_kernel(os.path.join(src, sub, "run_counter_collection.csv")).items():
         for c, v in cs.items():
             hbm[k][c] = sum(v) / len(v); hbm[k]["launches_" + c] = len(v)
 with open(os.path.join(dst, "pmc_hbm_per_kernel.csv"), "w") as f:
-    f.write("kernel,FETCH_SIZE_raw_per_launch,FETCH_SIZE_x2_per_launch,WRITE_SIZE_per_launch,launches\n")
+    f.write("kernel,FETCH_SIZE_raw_per_launch,FETCH_SIZE_x2_per_launch,WRITE_SIZE_per_launch,TCC_HIT_per_launch,TCC_MISS_per_launch,L2_hit_rate,launches\n")
     for k in sorted(hbm):
         fr = hbm[k].get("FETCH_SIZE", 0.0); wr = hbm[k].get("WRITE_SIZE", 0.0)
-        f.write(f"{k},{fr * 1024:.0f},{2 * fr * 1024:.0f},{wr * 1024:.0f},{hbm[k].get('launches_FETCH_SIZE', 0)}\n")
+        hit = hbm[k].get("TCC_HIT_sum", 0.0); miss = hbm[k].get("TCC_MISS_sum", 0.0)
+        rate = f"{hit / (hit + miss):.3f}" if hit + miss > 0 else ""
+        f.write(f"{k},{fr * 1024:.0f},{2 * fr * 1024:.0f},{wr * 1024:.0f},{hit:.0f},{miss:.0f},{rate},{hbm[k].get('launches_FETCH_SIZE', 0)}\n")
 sq = per_kernel(os.path.join(src, "pmc_sq", "run_counter_collection.csv"))
 names = sorted({c for cs in sq.values() for c in cs})
 with open(os.path.join(dst, "pmc_sq_per_kernel.csv"), "w") as f:
@@ -41,6 +45,7 @@ fetch = hbm[kd]["FETCH_SIZE"] * 1024; write = hbm[kd]["WRITE_SIZE"] * 1024      
 json.dump({"workload": "cloth-vs-cloth 1M (bench.py default)", "triangles": line["config"]["triangles_per_gpu"], "kernel": kd,
            "fetch_size_bytes_raw": fetch, "fetch_size_bytes_corrected": 2 * fetch, "write_size_bytes": write,
            "traverse_hbm_bytes_per_launch": 2 * fetch + write,
+           "l2_hit_rate": (hbm[kd]["TCC_HIT_sum"] / (hbm[kd]["TCC_HIT_sum"] + hbm[kd]["TCC_MISS_sum"])) if hbm[kd].get("TCC_HIT_sum", 0) + hbm[kd].get("TCC_MISS_sum", 0) > 0 else None,
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s/pmc_hbm_per_kernel.csv); FETCH_SIZE "
                    "doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B for 16-B/lane loads); WRITE_SIZE taken as read" % rnd},
           open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
