@@ -198,18 +198,24 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(QuerySrc src, uint32_
 
 // ====================================================================================================
 // Variant B ("split", default): the traversal the north star describes, as two kernels.
-//   k_descend : pure fp32 + integer descent over 64-byte NodeRec32 lines (conservative boxes, ~44 VGPRs).
+//   k_descend : pure fp32 + integer descent over 64-byte NodeRec32 lines (conservative boxes, ~48 VGPRs).
+//       * the wave first walks the root path of its first leaf through the scalar cache and every lane only tests
+//         the siblings hanging off it (self-collision queries are leaves of the tree they query); the private
+//         descent starts from the siblings a lane overlaps;
 //       * per-lane stack in LDS ([depth][thread], bank-conflict free); overflow hands the subtree to the deep pass;
+//       * busy lanes hand pending subtrees, with their query, to idle lanes of the wave (work sharing);
 //       * every leaf the fp32 test cannot rule out becomes a CANDIDATE (query, leaf) on a wavefront-shared LDS
 //         queue, compacted over the active lanes with __ballot / popcount prefixes;
-//       * a full batch of 64 candidates leaves the queue as ONE coalesced 512-byte store into the workgroup's
-//         shard of a global candidate buffer, reserved by ONE lane with a single atomicAdd;
-//       * lanes whose query has finished take the next query of the wave's chunk (dynamic refill), so a wave
-//         stays full until its chunk is exhausted.
-//   k_exact   : one candidate per lane: exact FP64 leaf-AABB test (box.cuh:40-43 -- this is what "pairs tested"
-//       counts), neighbour filter (collision.cuh:38), ID rule (tri_contact.cuh:81), 17-axis SAT
-//       (tri_contact.cuh:19-78), all lanes busy, no descent state kept alive.  Pairs are staged in LDS and
-//       appended with one global atomic per workgroup.
+//       * a full batch of 64 candidates is handed over one per lane: candidates the descent decided exactly (boxes
+//         that are fp32 values) are counted as tested and pass the neighbour filter and the ID rule right there;
+//         the survivors, and everything that still needs the FP64 box test, go to the workgroup's shard of a
+//         global candidate buffer, reserved by ONE lane with a single atomicAdd;
+//       * with CD_OPT_QUERIES_PER_WAVE > 64, lanes whose query has finished take the next query of the wave's
+//         chunk (dynamic refill) instead.
+//   k_exact   : exact FP64 leaf-AABB test for the candidates that need it (box.cuh:40-43 -- this is what "pairs
+//       tested" counts), neighbour filter (collision.cuh:38), ID rule (tri_contact.cuh:81), then the 17-axis SAT
+//       (tri_contact.cuh:19-78) on full batches of survivors, no descent state kept alive.  Pairs are staged in
+//       LDS and appended with one global atomic per workgroup.
 // Candidate-shard overflow is detected from the reserved counts (nothing is written past a shard's capacity)
 // and handled by the host: grow, redo.
 // ====================================================================================================
