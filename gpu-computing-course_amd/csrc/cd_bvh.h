@@ -14,15 +14,32 @@ namespace cd {
 typedef int4 NodeMeta;
 
 // fp32 traversal record, one 64-byte line: both child boxes rounded OUTWARD to float (lo down, hi up) +
-// both child ids.  Internal-node boxes only cull; a conservative (superset) box can never lose a pair, and
+// both child links.  Internal-node boxes only cull; a conservative (superset) box can never lose a pair, and
 // every leaf hit is re-decided with the exact FP64 product-form test of box.cuh:40-43 before it counts.
+//
+// Records are NAMED BY SPLIT: recs[s] is the internal node whose left child covers [first, s] and whose right
+// child covers [s + 1, last] (every s in [0, n-2] is the split of exactly one Karras node, so this is a
+// permutation of the Karras numbering that meta[] / parent[] / the exported tree keep).  A child link is the
+// child's own split for an internal child and ~j for leaf j.  With that naming the right siblings hanging off
+// the root path of leaf j -- the subtrees that partition the leaves (j, n-1] -- are reached bottom-up with no
+// parent pointers: s = j; { right child of recs[s]; s = recs[s].last; } until last == n-1 (cd_traverse.h).
+// The two 32-byte halves are laid out so that such a hop reads only the second one.
+constexpr uint32_t REC_LAST_MASK = 0x3fffffffu;     // n <= 2^30 (the candidate encoding has the same limit)
+constexpr uint32_t REC_L_EXACT = 0x40000000u;       // in `last`: the left / right child box is exactly representable
+constexpr uint32_t REC_R_EXACT = 0x80000000u;       //   in fp32 (box_is_fp32)
 struct alignas(64) NodeRec32 {
-    float l_lo[3], l_hi[3];
-    float r_lo[3], r_hi[3];
-    int32_t cl, cr;
-    int32_t pad[2];
+    float l_lo[3], l_hi[3]; int32_t cl; uint32_t first;     // quad 0, quad 1: left child (first: range start, informational)
+    float r_lo[3], r_hi[3]; int32_t cr; uint32_t last;      // quad 2, quad 3: right child, range end | REC_*_EXACT
 };
 static_assert(sizeof(NodeRec32) == 64, "NodeRec32 must be one 64-byte line");
+
+// fp32 query box of leaf j, rounded outward like the records', written by the refit: the descent reads 32 coalesced
+// bytes per query instead of the 48-byte FP64 box.  flags bit 0: the box is exact in fp32; bit 1: the FP64 box strictly
+// overlaps itself (box.cuh:40-43 with a == b -- false for a box that is flat along an axis): the query's hit on its
+// own leaf, which every traversal of the reference meets once (collision.cuh:31-32), is decided here, exactly.
+struct alignas(32) LeafBox32 { float lo[3], hi[3]; uint32_t flags, pad; };
+static_assert(sizeof(LeafBox32) == 32, "LeafBox32 layout");
+constexpr uint32_t LB_EXACT = 1u, LB_SELF = 2u;
 
 // Sorted-order leaf payload: {ID, vIdx[0..2]} (triangle.cuh:6,9) -- 16 B instead of the 56-byte Triangle.
 struct alignas(16) LeafTri { uint32_t id, v0, v1, v2; };
@@ -221,14 +238,23 @@ __device__ __forceinline__ bool box_is_fp32(const Box &b)
            (double)(float)b.y2 == b.y2 && (double)(float)b.z1 == b.z1 && (double)(float)b.z2 == b.z2;
 }
 
-__device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ r, const Box &bl, const Box &br, int2 ch)
+__device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ r, const Box &bl, const Box &br, int2 ch, uint32_t first, uint32_t last)
 {
     float4 *p = reinterpret_cast<float4 *>(r);
     p[0] = make_float4(__double2float_rd(bl.x1), __double2float_rd(bl.y1), __double2float_rd(bl.z1), __double2float_ru(bl.x2));
-    p[1] = make_float4(__double2float_ru(bl.y2), __double2float_ru(bl.z2), __double2float_rd(br.x1), __double2float_rd(br.y1));
-    p[2] = make_float4(__double2float_rd(br.z1), __double2float_ru(br.x2), __double2float_ru(br.y2), __double2float_ru(br.z2));
-    // word 2 of the last quad: bit 0 / bit 1 = the left / right child box is exactly representable (box_is_fp32)
-    reinterpret_cast<int4 *>(r)[3] = make_int4(ch.x, ch.y, (box_is_fp32(bl) ? 1 : 0) | (box_is_fp32(br) ? 2 : 0), 0);
+    p[1] = make_float4(__double2float_ru(bl.y2), __double2float_ru(bl.z2), __int_as_float(ch.x), __uint_as_float(first));
+    p[2] = make_float4(__double2float_rd(br.x1), __double2float_rd(br.y1), __double2float_rd(br.z1), __double2float_ru(br.x2));
+    p[3] = make_float4(__double2float_ru(br.y2), __double2float_ru(br.z2), __int_as_float(ch.y),
+                       __uint_as_float(last | (box_is_fp32(bl) ? REC_L_EXACT : 0u) | (box_is_fp32(br) ? REC_R_EXACT : 0u)));
+}
+
+// Link stored in a record for child `c` (unified Karras id): ~j for leaf j, the child's own split for an internal
+// child -- the decoded left-child id of meta[c] (Karras: the left child's index IS the split position).
+__device__ __forceinline__ int32_t child_link(const NodeMeta *__restrict__ meta, int c, int nleaf_base)
+{
+    if (c >= nleaf_base) return ~(c - nleaf_base);
+    const int mx = meta[c].x;
+    return mx >= nleaf_base ? mx - nleaf_base : mx;
 }
 
 // ---------------------------------------------------------------- calBoundingBox as RANGE QUERIES
@@ -256,11 +282,12 @@ __device__ __forceinline__ Box box_identity()
     return Box{inf, -inf, inf, -inf, inf, -inf};
 }
 
-// Given the exact boxes of both children, write the parent's 64-byte fp32 traversal record and return the
-// parent's exact box (bvh.cuh:277 merge(childA, childB)).  Child ids in the record: internal i >= 0, leaf j -> ~j.
-__device__ __forceinline__ Box emit_node(const Box &bl, const Box &br, int cl, int cr, NodeRec32 *__restrict__ rec32, int nleaf_base)
+// Given the exact boxes of both children, write the node's 64-byte fp32 traversal record -- at its SPLIT -- and return
+// the node's exact box (bvh.cuh:277 merge(childA, childB)).
+__device__ __forceinline__ Box emit_node(const Box &bl, const Box &br, const NodeMeta *__restrict__ meta, int cl, int cr, int split, int first, int last,
+                                         NodeRec32 *__restrict__ recs32, int nleaf_base)
 {
-    store_rec32(rec32, bl, br, make_int2(cl >= nleaf_base ? ~(cl - nleaf_base) : cl, cr >= nleaf_base ? ~(cr - nleaf_base) : cr));
+    store_rec32(recs32 + split, bl, br, make_int2(child_link(meta, cl, nleaf_base), child_link(meta, cr, nleaf_base)), (uint32_t)first, (uint32_t)last);
     return box_merge(bl, br);
 }
 
@@ -284,7 +311,8 @@ __device__ __forceinline__ Box seg_query_lds(const double (*t)[6], int l, int r)
 __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n,
                                                                const NodeMeta *__restrict__ meta,
                                                                double *__restrict__ boxes, uint32_t *__restrict__ bounded,
-                                                               NodeRec32 *__restrict__ recs32,
+                                                               NodeRec32 *__restrict__ recs32, LeafBox32 *__restrict__ qbox32,
+                                                               int32_t *__restrict__ root_name, int write_internal /* 0: FP64 boxes of the root and the leaves only */,
                                                                double *__restrict__ seg /* P x 6, heap order, node 0 unused */, int nbp2,
                                                                int32_t *__restrict__ cross_list /* 64 shards x cross_cap */, uint32_t *__restrict__ cross_count /* [64] */,
                                                                uint32_t cross_cap)
@@ -300,6 +328,10 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
         const LeafTri lt = leaf[j];
         mine = box_set(load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2));   // box.cuh:13-22
         store_box(boxes, (n - 1) + j, mine);
+        float4 *qp = reinterpret_cast<float4 *>(qbox32 + j);
+        qp[0] = make_float4(__double2float_rd(mine.x1), __double2float_rd(mine.y1), __double2float_rd(mine.z1), __double2float_ru(mine.x2));
+        qp[1] = make_float4(__double2float_ru(mine.y2), __double2float_ru(mine.z2),
+                            __uint_as_float((box_is_fp32(mine) ? LB_EXACT : 0u) | (box_overlap(mine, mine) ? LB_SELF : 0u)), 0.f);
     }
     {
         double *d = t[REFIT_BLK + tid];
@@ -328,7 +360,11 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
             const int split = (m.x >= n - 1) ? m.x - (n - 1) : m.x;    // childA covers [first, split], childB [split+1, last]
             const Box bl = seg_query_lds(t, first - b0, split - b0);
             const Box br = seg_query_lds(t, split + 1 - b0, last - b0);
-            store_box(boxes, i, emit_node(bl, br, m.x, m.y, recs32 + i, n - 1));
+            const Box whole = emit_node(bl, br, meta, m.x, m.y, split, first, last, recs32, n - 1);
+            // The FP64 boxes of internal nodes are the OUTPUT of calBoundingBox (bvh.cuh:277), not something the fused
+            // path reads (its traversal works on the records, the exact kernel on leaf boxes): written on request only
+            if (write_internal || i == 0) store_box(boxes, i, whole);
+            if (i == 0) *root_name = split;
             bounded[i] = 2;                                            // Node::bounded (bvh.cuh:270): both children merged
         }
     }
@@ -491,6 +527,7 @@ __device__ __forceinline__ Box seg_query_halves(const double *__restrict__ seg, 
 // Queries read only leaf boxes and segment-tree nodes, never another cross node's output: no ordering needed.
 __global__ __launch_bounds__(256) void k_refit_seg_cross(int n, const NodeMeta *__restrict__ meta, const double *__restrict__ seg, int nbp2,
                                                          double *boxes, uint32_t *__restrict__ bounded, NodeRec32 *__restrict__ recs32,
+                                                         int32_t *__restrict__ root_name, int write_internal,
                                                          const int32_t *__restrict__ cross_list, const uint32_t *__restrict__ cross_count, uint32_t cross_cap)
 {
     __shared__ uint32_t pre[65];
@@ -525,7 +562,9 @@ __global__ __launch_bounds__(256) void k_refit_seg_cross(int n, const NodeMeta *
             br = seg_query_wave(seg, boxes, n, P, split + 1, last, lane);
         }
         if (lane == 0) {
-            store_box(boxes, i, emit_node(bl, br, m.x, m.y, recs32 + i, n - 1));
+            const Box whole = emit_node(bl, br, meta, m.x, m.y, split, first, last, recs32, n - 1);
+            if (write_internal || i == 0) store_box(boxes, i, whole);
+            if (i == 0) *root_name = split;
             bounded[i] = 2;
         }
     }

@@ -82,6 +82,8 @@ __device__ __forceinline__ bool bor(bool a, bool b) { return a ? true : b; }
 struct QuerySrc {
     const LeafTri *leaf;          // local: sorted leaves
     const double  *boxes;         // local: node boxes (query box = boxes[(n-1)+j])
+    const LeafBox32 *qbox;        // local: fp32 query boxes + flags (cd_bvh.h), what the fp32 descents read
+    const int32_t *root;          // name (split) of the root record, written by the refit
     const void    *ext;           // external: cd_query records (88 B)
     const uint2   *list;          // deep pass: deferred (query index, subtree root) work items
     const uint32_t *sort_flags;   // 9 words, non-zero = the sort of this pipeline run failed (look-back time-out, or a half-key
@@ -240,12 +242,13 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                                                           TravState *__restrict__ st,
                                                           Candidates *__restrict__ cand, unsigned long long shard_cap,
                                                           uint2 *__restrict__ defer_list, uint32_t defer_cap,
-                                                          int32_t *__restrict__ deep_stacks, uint32_t vbase)
+                                                          int32_t *__restrict__ deep_stacks, uint32_t vbase, uint32_t half /* see k_descend_half: deep pass of a half traversal */)
 {
     if (sort_failed(src)) return;
     __shared__ int32_t lds_stack[DEEP ? 1 : WQ_STACK][TRAV_THREADS];
     __shared__ Candidates queue[WQ_WAVES][WQ_QCAP];
     __shared__ uint8_t share_map[WQ_WAVES][64];        // work sharing: lane id of the k-th donor
+    const int32_t root = (n > 1) ? *src.root : -1;     // records are named by split (cd_bvh.h): the root's name comes from the refit
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD and
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
         bool keep = lane < count;
         if (keep) cd0 = queue[w][qcount - count + lane];
         if (keep && (cd0.leaf & CAND_CERTAIN)) {
-            ++tested;                                                          // collision.cuh:31-32 decided (exactly) by the descent
+            tested += half ? 2u : 1u;                                          // collision.cuh:31-32 decided (exactly) by the descent (half: both directions)
             const LeafTri lt = src.leaf[cd0.leaf & CAND_LEAF_MASK];
             uint32_t q_id, qa, qb, qc;
             if (EXTERNAL) {
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                 const LeafTri ql = src.leaf[cd0.q];
                 q_id = ql.id; qa = ql.v0; qb = ql.v1; qc = ql.v2;
             }
-            keep = neighbor_count(qa, qb, qc, lt.v0 + vbase, lt.v1 + vbase, lt.v2 + vbase) < 1 && q_id < lt.id;   // collision.cuh:38, tri_contact.cuh:81
+            keep = neighbor_count(qa, qb, qc, lt.v0 + vbase, lt.v1 + vbase, lt.v2 + vbase) < 1 && (half ? q_id != lt.id : q_id < lt.id);   // collision.cuh:38, tri_contact.cuh:81
             cd0.leaf |= CAND_FILTERED;
         }
         qcount -= count;
@@ -318,24 +321,27 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                 const uint32_t rank = __popcll(mi & lt_mask);
                 if (idle && rank < remaining) {
                     const uint32_t item = next + rank;
-                    Box qb;
                     if (DEEP) { qi = src.list[item].x; node = (int32_t)src.list[item].y; }
-                    else { qi = item; node = (n > 1) ? 0 : -1; }
+                    else { qi = item; node = root; }
                     if (EXTERNAL) {
                         const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + qi;
-                        qb = box_set(d3{q->v[0], q->v[1], q->v[2]}, d3{q->v[3], q->v[4], q->v[5]}, d3{q->v[6], q->v[7], q->v[8]});
+                        const Box qb = box_set(d3{q->v[0], q->v[1], q->v[2]}, d3{q->v[3], q->v[4], q->v[5]}, d3{q->v[6], q->v[7], q->v[8]});
                         self_leaf = 0xffffffffu;
+                        qlo0 = __double2float_rd(qb.x1); qhi0 = __double2float_ru(qb.x2);
+                        qlo1 = __double2float_rd(qb.y1); qhi1 = __double2float_ru(qb.y2);
+                        qlo2 = __double2float_rd(qb.z1); qhi2 = __double2float_ru(qb.z2);
+                        qcertain = box_is_fp32(qb) ? CAND_CERTAIN : 0u;
                     } else {
-                        qb = load_box(boxes, (n - 1) + (int)qi);
+                        const float4 *qp = reinterpret_cast<const float4 *>(src.qbox + qi);
+                        const float4 q0 = qp[0], q1 = qp[1];
+                        const uint32_t qfl = __float_as_uint(q1.z);
+                        qlo0 = q0.x; qlo1 = q0.y; qlo2 = q0.z; qhi0 = q0.w; qhi1 = q1.x; qhi2 = q1.y;
+                        qcertain = (qfl & LB_EXACT) ? CAND_CERTAIN : 0u;
                         self_leaf = qi;
-                        // the query meets its own leaf in every traversal: decide that hit here, exactly, once
-                        // (not in the deep pass, which only continues a traversal that already did)
-                        if (!DEEP && n > 1 && box_overlap(qb, qb)) ++tested;       // (a single triangle has no tree to walk: nothing is tested)
+                        // the query meets its own leaf in every traversal: that hit was decided by the refit, exactly, once
+                        // (not counted in the deep pass, which only continues a traversal that already did)
+                        if (!DEEP && n > 1 && (qfl & LB_SELF)) ++tested;           // (a single triangle has no tree to walk: nothing is tested)
                     }
-                    qlo0 = __double2float_rd(qb.x1); qhi0 = __double2float_ru(qb.x2);
-                    qlo1 = __double2float_rd(qb.y1); qhi1 = __double2float_ru(qb.y2);
-                    qlo2 = __double2float_rd(qb.z1); qhi2 = __double2float_ru(qb.z2);
-                    qcertain = box_is_fp32(qb) ? CAND_CERTAIN : 0u;
                     sptr = 0;
                 }
                 const uint32_t taken = __popcll(mi);
@@ -353,19 +359,20 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
             const bool valid = (node != -1);
             // (readfirstlane: the compiler cannot see that chunk_begin is wave-uniform, and would select per lane)
             const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk_begin);
-            int32_t pn = 0;                                                  // wave-uniform path node
+            int32_t pn = __builtin_amdgcn_readfirstlane(root);              // wave-uniform path node
             node = -1;
-            while (true) {
+            for (int lev = 0; lev < 128; ++lev) {                            // (tree height <= 96: the bound only matters for a corrupt tree)
                 const int4 *rq = reinterpret_cast<const int4 *>(recs + pn);
                 const int4 r0 = rq[0], r1 = rq[1], r2 = rq[2], r3 = rq[3];
-                const int32_t chl = r3.x, chr = r3.y;
-                const uint32_t split = (uint32_t)(chl >= 0 ? chl : ~chl);      // the left child's id IS the split position
+                const int32_t chl = r1.z, chr = r3.z;
+                const uint32_t split = (uint32_t)pn;                           // a record's name IS its split position
                 const bool go_left = g0 <= split;                             // uniform
                 const int32_t sib = go_left ? chr : chl, onp = go_left ? chl : chr;
-                // record layout: left = lo(r0.x,r0.y,r0.z) hi(r0.w,r1.x,r1.y), right = lo(r1.z,r1.w,r2.x) hi(r2.y,r2.z,r2.w).
+                const uint32_t sib_exact = (uint32_t)r3.w & (go_left ? REC_R_EXACT : REC_L_EXACT), onp_exact = (uint32_t)r3.w & (go_left ? REC_L_EXACT : REC_R_EXACT);
+                // record layout: left = lo(r0.x,r0.y,r0.z) hi(r0.w,r1.x,r1.y), right = lo(r2.x,r2.y,r2.z) hi(r2.w,r3.x,r3.y).
                 // The selects are done on the raw words, so that they stay scalar (s_cselect) like their condition.
-                const float slo0 = __int_as_float(go_left ? r1.z : r0.x), slo1 = __int_as_float(go_left ? r1.w : r0.y), slo2 = __int_as_float(go_left ? r2.x : r0.z);
-                const float shi0 = __int_as_float(go_left ? r2.y : r0.w), shi1 = __int_as_float(go_left ? r2.z : r1.x), shi2 = __int_as_float(go_left ? r2.w : r1.y);
+                const float slo0 = __int_as_float(go_left ? r2.x : r0.x), slo1 = __int_as_float(go_left ? r2.y : r0.y), slo2 = __int_as_float(go_left ? r2.z : r0.z);
+                const float shi0 = __int_as_float(go_left ? r2.w : r0.w), shi1 = __int_as_float(go_left ? r3.x : r1.x), shi2 = __int_as_float(go_left ? r3.y : r1.y);
                 const bool hit = valid & (qlo0 < shi0) & (slo0 < qhi0) & (qlo1 < shi1) & (slo1 < qhi1) & (qlo2 < shi2) & (slo2 < qhi2);
                 visits += valid ? 1u : 0u;
                 bool cnd = false; uint32_t cleaf = 0;
@@ -376,14 +383,14 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                     }
                 } else { cleaf = (uint32_t)~sib; cnd = hit & (cleaf != self_leaf); }
                 if (onp < 0) {                                                // the path ends at leaf g0 (uniform): its box is the on-path child's
-                    const float plo0 = __int_as_float(go_left ? r0.x : r1.z), plo1 = __int_as_float(go_left ? r0.y : r1.w), plo2 = __int_as_float(go_left ? r0.z : r2.x);
-                    const float phi0 = __int_as_float(go_left ? r0.w : r2.y), phi1 = __int_as_float(go_left ? r1.x : r2.z), phi2 = __int_as_float(go_left ? r1.y : r2.w);
+                    const float plo0 = __int_as_float(go_left ? r0.x : r2.x), plo1 = __int_as_float(go_left ? r0.y : r2.y), plo2 = __int_as_float(go_left ? r0.z : r2.z);
+                    const float phi0 = __int_as_float(go_left ? r0.w : r2.w), phi1 = __int_as_float(go_left ? r1.x : r3.x), phi2 = __int_as_float(go_left ? r1.y : r3.y);
                     const bool ph = valid & (qi != g0) & (qlo0 < phi0) & (plo0 < qhi0) & (qlo1 < phi1) & (plo1 < qhi1) & (qlo2 < phi2) & (plo2 < qhi2);
                     const unsigned long long mP = __builtin_amdgcn_ballot_w64(ph);
-                    if (mP) { if (ph) queue[w][qcount + __popcll(mP & lt_mask)] = Candidates{qi, g0 | ((r3.z & (go_left ? 1 : 2)) ? qcertain : 0u)}; qcount += __popcll(mP); }
+                    if (mP) { if (ph) queue[w][qcount + __popcll(mP & lt_mask)] = Candidates{qi, g0 | (onp_exact ? qcertain : 0u)}; qcount += __popcll(mP); }
                 }
                 const unsigned long long mC = __builtin_amdgcn_ballot_w64(cnd);
-                if (mC) { if (cnd) queue[w][qcount + __popcll(mC & lt_mask)] = Candidates{qi, cleaf | ((r3.z & (go_left ? 2 : 1)) ? qcertain : 0u)}; qcount += __popcll(mC); }
+                if (mC) { if (cnd) queue[w][qcount + __popcll(mC & lt_mask)] = Candidates{qi, cleaf | (sib_exact ? qcertain : 0u)}; qcount += __popcll(mC); }
                 while (qcount >= 64) flush(64);
                 if (onp < 0) break;
                 pn = __builtin_amdgcn_readfirstlane(onp);
@@ -423,12 +430,13 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
         // kernel is instruction-issue bound (SQ_ACTIVE_INST_ANY ~ 70 % of its duration), so every exec-mask
         // save/restore the compiler does not have to emit is time.  Idle lanes fetch the root record and ignore it.
         const float4 *rp = reinterpret_cast<const float4 *>(recs + (active ? node : 0));
-        const float4 a = rp[0], b = rp[1], c = rp[2];
-        const int4 ch = reinterpret_cast<const int4 *>(rp)[3];         // child ids: internal i >= 0, leaf j -> ~j
-        // left: lo = (a.x, a.y, a.z) hi = (a.w, b.x, b.y); right: lo = (b.z, b.w, c.x) hi = (c.y, c.z, c.w)
+        const float4 a = rp[0], b = rp[1], c = rp[2], d = rp[3];
+        // child links: internal -> its split (>= 0), leaf j -> ~j; ch.z: REC_L_EXACT / REC_R_EXACT
+        const int4 ch = make_int4(__float_as_int(b.z), __float_as_int(d.z), (int)(__float_as_uint(d.w) >> 30), 0);
+        // left: lo = (a.x, a.y, a.z) hi = (a.w, b.x, b.y); right: lo = (c.x, c.y, c.z) hi = (c.w, d.x, d.y)
         // (bitwise & on purpose: && would be lowered to short-circuit branches with exec-mask juggling)
         const bool ol  = active & (qlo0 < a.w) & (a.x < qhi0) & (qlo1 < b.x) & (a.y < qhi1) & (qlo2 < b.y) & (a.z < qhi2);
-        const bool orr = active & (qlo0 < c.y) & (b.z < qhi0) & (qlo1 < c.z) & (b.w < qhi1) & (qlo2 < c.w) & (c.x < qhi2);
+        const bool orr = active & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
         visits += active ? 1u : 0u;
         // (selects on i1, not integer & of promoted bools: the masks then stay in SGPR pairs instead of being
         // materialised as 0 / 1 in VGPRs and compared again)
@@ -465,6 +473,226 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
         if (t64) atomicAdd(&sh->pairs_tested, t64);
         if (v64) atomicAdd(&sh->node_visits, v64);
         if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
+    }
+}
+
+// ====================================================================================================
+// Variant D ("half", default for self-collision): the same split as variant B, but a query only looks to its RIGHT.
+//   Self-collision queries are the leaves of the tree they query, and every step of the reference's decision for a
+//   (query a, leaf b) hit is symmetric in a and b up to the ID rule: the strict product-form box test
+//   (box.cuh:40-43: the two factors swap, IEEE multiplication commutes), neighborCount (triangle.cuh:18-30), and
+//   tri_contact.cuh:81, which lets exactly the direction with the smaller ID in front through.  So the reference's
+//   traversal meets every overlapping pair of leaf boxes twice, once from each side, and reports it at most once.
+//   Here the query at Morton position i meets only leaves at positions > i; each such hit counts as two tested
+//   pairs, and k_exact runs the SAT with the smaller-ID triangle in front, exactly as the reference would.
+//   * No walk from the root.  The leaves (i, n-1] are exactly the subtrees hanging off the root path of leaf i to
+//     the right, and with records named by split (cd_bvh.h) that chain is reached bottom-up from the leaf itself:
+//     s = i; { test the right child of recs[s]; s = recs[s].last; } until last == n-1 -- one 32-byte read and one
+//     box test per hop, about half the tree height of hops, the lowest (the ones that hit) first.
+//   * The workgroup owns the HALF_BLK consecutive leaves [B0, B_last].  A hop whose cursor s is below B_last reads
+//     recs[s] with s inside that range: the workgroup stages recs[B0 .. B0 + HALF_BLK) in LDS with coalesced loads
+//     first, so these hops -- and every descent step at a node whose split lies in the range -- never touch the
+//     vector memory path (a divergent 16-byte load costs the texture addresser one cache line per lane and clock;
+//     that, not HBM, is what bounds a per-lane descent).
+//   * A lane whose cursor reaches B_last or beyond is on the chain of leaf B_last (the `last` values along a root
+//     path are exactly that chain's cursors), which all lanes of the workgroup share from their joining point
+//     upwards: each wave walks it once with SCALAR loads and every lane that has joined tests the wave-uniform box.
+//   * Phase 1 (both chain parts) only records what it hits (internal sibling -> per-lane LDS stack, leaf ->
+//     candidate queue); phase 2 is variant B's private descent of those subtrees, with work sharing inside the
+//     wave.  Nothing in a sibling subtree is to the left of the query, so phase 2 needs no position test.
+// ====================================================================================================
+constexpr int HALF_STACK = 8;                // LDS stack entries per lane
+constexpr int HALF_QCAP = 192;               // candidate queue slots per wave
+constexpr uint32_t HALF_FLUSH_AT = HALF_QCAP - 64;   // an enqueue adds at most 64 candidates: drain before it when more than this are waiting
+
+__global__ __launch_bounds__(TRAV_THREADS, 8) void k_descend_half(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
+                                                                  TravState *__restrict__ st,
+                                                                  Candidates *__restrict__ cand, unsigned long long shard_cap,
+                                                                  uint2 *__restrict__ defer_list, uint32_t defer_cap, uint32_t diag)
+{
+    if (sort_failed(src)) return;
+    __shared__ int32_t lds_stack[HALF_STACK][TRAV_THREADS];
+    __shared__ Candidates queue[WQ_WAVES][HALF_QCAP];
+    __shared__ uint8_t share_map[WQ_WAVES][64];        // work sharing: lane id of the k-th donor
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t dg_p1a = 0, dg_p1 = 0, dg_hops_in = 0, dg_hops_out = 0, dg_vis = 0;   // diagnostics (diag != 0)
+    const uint32_t nb = gridDim.x, per = nb >> 3;       // XCD-aware mapping, see k_descend
+    const uint32_t vblock = (blockIdx.x < (per << 3)) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
+    Candidates *my_cand = cand + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_cap;
+    const uint32_t nq = (uint32_t)n, last_leaf = nq - 1u;
+    constexpr uint32_t END = 0xffffffffu;
+    // the wave owns the 64 consecutive leaves [g0, g_last]  (wave-uniform; readfirstlane tells the compiler)
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((vblock * WQ_WAVES + w) * 64u));
+    const uint32_t g_last = (g0 + 63u < last_leaf) ? g0 + 63u : last_leaf;
+    uint32_t qi = g0 + lane;
+    const bool valid = qi < nq && n > 1;
+    unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0, tm4 = 0;           // diagnostics: s_memtime stamps at the phase boundaries
+    if (diag) tm0 = __builtin_amdgcn_s_memtime();
+    uint32_t qcount = 0;                                // wave-uniform: candidates waiting in the queue
+    uint32_t tested = 0, visits = 0, steps = 0;
+    int sptr = 0;
+    // Hand-over of queued candidates to k_exact, as in k_descend, with the half traversal's counting (both directions)
+    // and ID rule (either order; k_exact puts the smaller ID in front).  The queue is drained only when it might not
+    // hold the next enqueue, and once at the end: a wave usually hands everything over in one go.
+    auto flush = [&](uint32_t count) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        Candidates cd0 = Candidates{0, 0};
+        bool keep = lane < count;
+        if (keep) cd0 = queue[w][qcount - count + lane];
+        if (keep && (cd0.leaf & CAND_CERTAIN)) {
+            tested += 2u;                                                      // collision.cuh:31-32, decided exactly by the descent, both directions
+            const LeafTri lt = src.leaf[cd0.leaf & CAND_LEAF_MASK];
+            const LeafTri ql = src.leaf[cd0.q];
+            keep = neighbor_count(ql.v0, ql.v1, ql.v2, lt.v0, lt.v1, lt.v2) < 1 && ql.id != lt.id;   // collision.cuh:38, tri_contact.cuh:81
+            cd0.leaf |= CAND_FILTERED;
+        }
+        qcount -= count;
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(keep);
+        if (mk != 0ull) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&sh->n_candidates, (unsigned long long)__popcll(mk));
+            base = __shfl(base, 0) + __popcll(mk & lt_mask);
+            if (keep && base < shard_cap) my_cand[base] = cd0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    // one candidate per lane where `c` holds (compacted over the wave with ballot / popcount prefixes)
+    auto enqueue = [&](bool c, uint32_t q, uint32_t leafword) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
+        if (m == 0ull) return;
+        while (qcount > HALF_FLUSH_AT) flush(64);
+        if (c) queue[w][qcount + __popcll(m & lt_mask)] = Candidates{q, leafword};
+        qcount += __popcll(m);
+    };
+    auto push_subtree = [&](int32_t link) {                                   // an internal sibling / child that was hit: descended in phase 2
+        if (sptr < HALF_STACK) { lds_stack[sptr][tid] = link; ++sptr; }
+        else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)link); }
+    };
+    // ---- the query: 32 coalesced bytes per lane (fp32 box rounded outward + flags, written by the refit)
+    float qlo0, qlo1, qlo2, qhi0, qhi1, qhi2; uint32_t qcertain;
+    {
+        const float4 *qp = reinterpret_cast<const float4 *>(src.qbox + (valid ? qi : 0u));
+        const float4 q0 = qp[0], q1 = qp[1];
+        const uint32_t qfl = __float_as_uint(q1.z);
+        qlo0 = q0.x; qlo1 = q0.y; qlo2 = q0.z; qhi0 = q0.w; qhi1 = q1.x; qhi2 = q1.y;
+        qcertain = (qfl & LB_EXACT) ? CAND_CERTAIN : 0u;
+        if (valid && (qfl & LB_SELF)) ++tested;                               // the query's own leaf (see LeafBox32)
+    }
+    // ---- the right-child half of the lane's own record recs[qi] (the last leaf has none), one coalesced fetch per wave:
+    // phase 1a reads these 8 words of OTHER lanes through the LDS crossbar (ds_bpermute) -- the hops below g_last have
+    // their cursor, a split, inside the wave's own 64 leaves, so they touch neither memory nor LDS storage
+    float4 rc = make_float4(0.f, 0.f, 0.f, 0.f), rd = rc;
+    if (valid && qi < last_leaf) { const float4 *rp = reinterpret_cast<const float4 *>(recs + qi) + 2; rc = rp[0]; rd = rp[1]; }
+    if (diag) tm1 = __builtin_amdgcn_s_memtime();
+    // ---- phase 1a: hops below g_last
+    uint32_t s = valid ? qi : END;                                            // cursor; >= g_last: joined the shared chain (or has none: g_last == n-1)
+    for (int hop = 0; hop < 128; ++hop) {                                     // tree height <= 96: the bound only matters for a corrupt tree
+        const bool act = s < g_last;
+        if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+        ++steps;
+        const int from = (int)((act ? (s - g0) : lane) << 2);
+        float4 c, d;
+        c.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.x))); c.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.y)));
+        c.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.z))); c.w = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.w)));
+        d.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.x))); d.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.y)));
+        d.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.z))); d.w = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.w)));
+        const bool hit = act & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
+        const int32_t link = __float_as_int(d.z);
+        const uint32_t lw = __float_as_uint(d.w);
+        visits += act ? 1u : 0u;
+        if (diag) dg_hops_in += act ? 1u : 0u;
+        if (band(hit, link >= 0)) push_subtree(link);
+        s = act ? (lw & REC_LAST_MASK) : s;
+        enqueue(band(hit, link < 0), qi, (uint32_t)~link | ((lw & REC_R_EXACT) ? qcertain : 0u));
+    }
+    dg_p1a = steps;
+    if (diag) tm2 = __builtin_amdgcn_s_memtime();
+    // ---- phase 1b: a lane whose cursor has reached g_last or beyond is on the chain of leaf g_last (the `last` values
+    // along a root path are exactly that chain's cursors), which all lanes share from their joining point upwards: the
+    // wave walks it once with SCALAR loads, and every lane that has joined tests the wave-uniform box.
+    {
+        uint32_t t = g_last;
+        for (int hop = 0; hop < 128 && t < last_leaf; ++hop) {
+            ++steps;
+            const int4 *rq = reinterpret_cast<const int4 *>(recs + t) + 2;    // wave-uniform address: scalar loads
+            const int4 c = rq[0], d = rq[1];
+            const bool act = s <= t;                                          // (s == END for lanes without a query: never)
+            const bool hit = act & (qlo0 < __int_as_float(c.w)) & (__int_as_float(c.x) < qhi0) & (qlo1 < __int_as_float(d.x)) &
+                             (__int_as_float(c.y) < qhi1) & (qlo2 < __int_as_float(d.y)) & (__int_as_float(c.z) < qhi2);
+            const int32_t link = d.z;                                         // wave-uniform
+            const uint32_t lw = (uint32_t)d.w;
+            visits += act ? 1u : 0u;
+            if (diag) dg_hops_out += act ? 1u : 0u;
+            if (link >= 0) { if (hit) push_subtree(link); }
+            else enqueue(hit, qi, (uint32_t)~link | ((lw & REC_R_EXACT) ? qcertain : 0u));
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lw & REC_LAST_MASK));
+        }
+    }
+    dg_p1 = steps;
+    if (diag) tm3 = __builtin_amdgcn_s_memtime();
+    // ---- phase 2: descend the sibling subtrees that were hit
+    int32_t node = -1;
+    if (sptr > 0) { --sptr; node = lds_stack[sptr][tid]; }
+    while (true) {
+        // work sharing inside the wave (see k_descend): a busy lane hands the top of its stack, with its query, to an idle lane
+        if (SHARE_MIN_IDLE <= 64) {
+            const bool idle = (node == -1), donor = (node != -1) & (sptr > 0);
+            const unsigned long long m_idle = __builtin_amdgcn_ballot_w64(idle), m_don = __builtin_amdgcn_ballot_w64(donor);
+            if (m_don != 0ull && __popcll(m_idle) >= SHARE_MIN_IDLE) {        // (wave-uniform)
+                const uint32_t nx = min((uint32_t)__popcll(m_don), (uint32_t)__popcll(m_idle));
+                const uint32_t rank_d = __popcll(m_don & lt_mask), rank_r = __popcll(m_idle & lt_mask);
+                const bool give = donor & (rank_d < nx), take = idle & (rank_r < nx);
+                int32_t top = -1;
+                if (give) { share_map[w][rank_d] = (uint8_t)lane; --sptr; top = lds_stack[sptr][tid]; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int from = take ? (int)share_map[w][rank_r] : (int)lane;
+                const int32_t e = __shfl(top, from);
+                const uint32_t s_qi = __shfl(qi, from), s_cert = __shfl(qcertain, from);
+                const float f0 = __shfl(qlo0, from), f1 = __shfl(qlo1, from), f2 = __shfl(qlo2, from);
+                const float f3 = __shfl(qhi0, from), f4 = __shfl(qhi1, from), f5 = __shfl(qhi2, from);
+                if (take) { node = e; qi = s_qi; qcertain = s_cert; qlo0 = f0; qlo1 = f1; qlo2 = f2; qhi0 = f3; qhi1 = f4; qhi2 = f5; sptr = 0; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+        const bool active = (node != -1);
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+        ++steps;
+        // one descent step per active lane, straight-line selects (see k_descend)
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, d = a;
+        if (active) { const float4 *rp = reinterpret_cast<const float4 *>(recs + node); a = rp[0]; b = rp[1]; c = rp[2]; d = rp[3]; }
+        const int32_t cl = __float_as_int(b.z), cr = __float_as_int(d.z);
+        const uint32_t lw = __float_as_uint(d.w);
+        const bool ol  = active & (qlo0 < a.w) & (a.x < qhi0) & (qlo1 < b.x) & (a.y < qhi1) & (qlo2 < b.y) & (a.z < qhi2);
+        const bool orr = active & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
+        visits += active ? 1u : 0u;
+        if (diag) dg_vis += active ? 1u : 0u;
+        const bool intL = band(ol, cl >= 0), intR = band(orr, cr >= 0);
+        int32_t nxt = intL ? cl : (intR ? cr : -1);
+        if (band(intL, intR)) push_subtree(cr);                            // both internal: descend left, push right
+        if (band(band(active, !bor(intL, intR)), sptr > 0)) { --sptr; nxt = lds_stack[sptr][tid]; }
+        node = active ? nxt : -1;
+        enqueue(band(ol, cl < 0), qi, (uint32_t)~cl | ((lw & REC_L_EXACT) ? qcertain : 0u));
+        enqueue(band(orr, cr < 0), qi, (uint32_t)~cr | ((lw & REC_R_EXACT) ? qcertain : 0u));
+    }
+    if (diag) tm4 = __builtin_amdgcn_s_memtime();
+    while (qcount > 0) flush(qcount < 64u ? qcount : 64u);
+    const unsigned long long t64 = wave_sum_u64(tested), v64 = wave_sum_u64(visits);
+    if (lane == 0) {
+        if (t64) atomicAdd(&sh->pairs_tested, t64);
+        if (v64) atomicAdd(&sh->node_visits, v64);
+        if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
+    }
+    if (diag) {
+        const unsigned long long hi = wave_sum_u64(dg_hops_in), ho = wave_sum_u64(dg_hops_out), vi = wave_sum_u64(dg_vis);
+        const unsigned long long tm5 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            atomicAdd(&sh->pad[0], (unsigned long long)(dg_p1 - dg_p1a)); atomicAdd(&sh->pad[1], hi); atomicAdd(&sh->pad[2], ho);
+            atomicAdd(&sh->pad[3], vi); atomicAdd(&sh->pad[5], (unsigned long long)dg_p1a);
+            atomicAdd(&sh->pad[6], tm1 - tm0); atomicAdd(&sh->pad[7], tm2 - tm1); atomicAdd(&sh->pad[8], tm3 - tm2);
+            atomicAdd(&sh->pad[9], tm4 - tm3); atomicAdd(&sh->pad[10], tm5 - tm4);
+        }
     }
 }
 
@@ -512,18 +740,19 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend_packet(QuerySrc src, u
         if (EXTERNAL) {
             const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + qi;
             qb = box_set(d3{q->v[0], q->v[1], q->v[2]}, d3{q->v[3], q->v[4], q->v[5]}, d3{q->v[6], q->v[7], q->v[8]});
+            qlo0 = __double2float_rd(qb.x1); qhi0 = __double2float_ru(qb.x2);
+            qlo1 = __double2float_rd(qb.y1); qhi1 = __double2float_ru(qb.y2);
+            qlo2 = __double2float_rd(qb.z1); qhi2 = __double2float_ru(qb.z2);
         } else {
-            qb = load_box(boxes, (n - 1) + (int)qi);
+            const LeafBox32 lb = src.qbox[qi];
+            qlo0 = lb.lo[0]; qlo1 = lb.lo[1]; qlo2 = lb.lo[2]; qhi0 = lb.hi[0]; qhi1 = lb.hi[1]; qhi2 = lb.hi[2];
             self_leaf = qi;
-            if (box_overlap(qb, qb)) ++tested;                             // the query's own leaf: decided here, exactly, once
+            if (lb.flags & LB_SELF) ++tested;                              // the query's own leaf: decided by the refit, exactly, once
         }
-        qlo0 = __double2float_rd(qb.x1); qhi0 = __double2float_ru(qb.x2);
-        qlo1 = __double2float_rd(qb.y1); qhi1 = __double2float_ru(qb.y2);
-        qlo2 = __double2float_rd(qb.z1); qhi2 = __double2float_ru(qb.z2);
         ++visits;                                                          // the root
     }
     int sptr = 0;
-    int node = 0;                                                          // wave-uniform
+    int node = *src.root;                                                  // wave-uniform (records are named by split, cd_bvh.h)
     while (true) {
         ++steps;
         // Fetch the wave-uniform 64-byte record through the VECTOR path: lanes 0..15 load one dword each (one
@@ -535,10 +764,10 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend_packet(QuerySrc src, u
         r.l_lo[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 0));  r.l_lo[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 1));
         r.l_lo[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 2));  r.l_hi[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 3));
         r.l_hi[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 4));  r.l_hi[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 5));
-        r.r_lo[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 6));  r.r_lo[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 7));
-        r.r_lo[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 8));  r.r_hi[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 9));
-        r.r_hi[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 10)); r.r_hi[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 11));
-        r.cl = __builtin_amdgcn_readlane(rv, 12); r.cr = __builtin_amdgcn_readlane(rv, 13);
+        r.r_lo[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 8));  r.r_lo[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 9));
+        r.r_lo[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 10)); r.r_hi[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 11));
+        r.r_hi[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 12)); r.r_hi[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 13));
+        r.cl = __builtin_amdgcn_readlane(rv, 6); r.cr = __builtin_amdgcn_readlane(rv, 14);
         const bool ol  = qlo0 < r.l_hi[0] && r.l_lo[0] < qhi0 && qlo1 < r.l_hi[1] && r.l_lo[1] < qhi1 && qlo2 < r.l_hi[2] && r.l_lo[2] < qhi2;
         const bool orr = qlo0 < r.r_hi[0] && r.r_lo[0] < qhi0 && qlo1 < r.r_hi[1] && r.r_lo[1] < qhi1 && qlo2 < r.r_hi[2] && r.r_lo[2] < qhi2;
         const unsigned long long mL = __ballot(ol), mR = __ballot(orr);
@@ -611,7 +840,8 @@ template <bool EXTERNAL>
 __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, const LeafTri *__restrict__ leaf, const double *__restrict__ boxes,
                                                          const double *__restrict__ verts, uint32_t vbase,
                                                          const Candidates *__restrict__ cand, unsigned long long shard_cap,
-                                                         uint32_t *__restrict__ pairs, unsigned long long cap, TravState *__restrict__ st)
+                                                         uint32_t *__restrict__ pairs, unsigned long long cap, TravState *__restrict__ st,
+                                                         uint32_t half /* candidates of a half traversal (k_descend_half): q and leaf are an unordered pair */)
 {
     __shared__ unsigned long long pre[NSHARD + 1];      // exclusive prefix of the shard counts
     __shared__ uint2 pbuf[EXACT_PB];
@@ -638,14 +868,17 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
 
     // SAT of one queued survivor; hit -> LDS pair staging (or direct append when the staging area is full)
     auto run_sat = [&](const SatItem it) {
-        const LeafTri lt = leaf[it.leaf];
+        LeafTri lt = leaf[it.leaf];
         uint32_t q_id; d3 P1, P2, P3;
         if (EXTERNAL) {
             const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + it.q;
             P1 = d3{q->v[0], q->v[1], q->v[2]}; P2 = d3{q->v[3], q->v[4], q->v[5]}; P3 = d3{q->v[6], q->v[7], q->v[8]};
             q_id = q->id;
         } else {
-            const LeafTri ql = leaf[it.q];
+            LeafTri ql = leaf[it.q];
+            // half traversal: the pair is unordered; the reference tests it with the smaller ID as the query
+            // (tri_contact.cuh:81 lets only that direction through), so that triangle goes in front
+            if (half && ql.id > lt.id) { const LeafTri t = ql; ql = lt; lt = t; }
             q_id = ql.id;
             P1 = load_vertex(verts, ql.v0); P2 = load_vertex(verts, ql.v1); P3 = load_vertex(verts, ql.v2);
         }
@@ -699,21 +932,24 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
         for (int j = 0; j < EXACT_ITEMS; ++j) {
             if (ok[j] && filtered[j]) { sq[atomicAdd(&sqcount, 1u)] = SatItem{c[j].q, c[j].leaf}; continue; }
             if (ok[j] && (certain[j] || box_overlap(qbox[j], lb[j]))) {        // collision.cuh:31-32, exact (certain: already decided exactly by the descent)
-                ++tested;
+                tested += half ? 2u : 1u;                                      // (half traversal: the reference meets the pair from both sides)
                 const bool survive = neighbor_count(qa[j], qb[j], qc[j], lt[j].v0 + vbase, lt[j].v1 + vbase, lt[j].v2 + vbase) < 1   // collision.cuh:38
-                                     && q_id[j] < lt[j].id;                    // tri_contact.cuh:81
+                                     && (half ? q_id[j] != lt[j].id : q_id[j] < lt[j].id);   // tri_contact.cuh:81
                 if (survive) sq[atomicAdd(&sqcount, 1u)] = SatItem{c[j].q, c[j].leaf};   // < 256 left over + <= 256*ITEMS new: fits EXACT_SQ
             }
         }
         __syncthreads();
-        while (sqcount >= EXACT_THREADS) {                                     // workgroup-uniform: full batch, every lane runs one SAT
-            const uint32_t base = sqcount - EXACT_THREADS;
-            const SatItem it = sq[base + tid];
-            __syncthreads();
-            if (tid == 0) sqcount = base;
+        // The count is read ONCE, between two barriers with no push in between, so that every wave sees the same value
+        // and the trip count below is workgroup-uniform whatever the skew between the waves (the loop holds barriers).
+        uint32_t cnt = sqcount;
+        while (cnt >= EXACT_THREADS) {                                         // full batch, every lane runs one SAT
+            cnt -= EXACT_THREADS;
+            const SatItem it = sq[cnt + tid];
             run_sat(it);
-            __syncthreads();
         }
+        __syncthreads();                                                       // every wave has read the count and its items ...
+        if (tid == 0) sqcount = cnt;                                           // ... before the count moves and the next round pushes
+        __syncthreads();
     }
     __syncthreads();
     if (tid < sqcount) run_sat(sq[tid]);                                       // final partial batch (< 256)

@@ -35,9 +35,10 @@ struct cd_ctx {
     int stage = ST_CREATED;
     int frame_mode = CD_FRAME_REFERENCE;
     uint32_t vbase = 0;
-    int trav_variant = 1;                   // CD_OPT_TRAVERSAL: 0 = lane-private FP64 (A), 1 = split fp32 descent + exact kernel (B)
+    int trav_variant = 3;                   // CD_OPT_TRAVERSAL: 0 = lane-private FP64 (A), 1 = split fp32 descent + exact kernel (B), 2 = packet (C), 3 = half traversal (D)
     uint32_t queries_per_wave = 64; 
     uint32_t dbg_no_shared_path = 0;              // debug key 102: 1 = k_descend without the shared root path (A/B)
+    uint32_t dbg_diag = 0;                  // debug key 103: the descent kernels also fill the diagnostic counters (cd_debug_counters)
     uint32_t dbg_lds_pad = 0;               // CD_OPT_DEBUG_LDS_PAD: extra dynamic LDS bytes per traversal workgroup (occupancy experiments)        // CD_OPT_QUERIES_PER_WAVE (variant B chunk size)                     // global id of local vertex 0 (cross-rank neighbour filter)
     double frame_host[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};   // morton.h:45,51,57
     hipStream_t stream = nullptr;
@@ -52,7 +53,9 @@ struct cd_ctx {
     double *d_frame = nullptr, *d_partial = nullptr;
     // tree
     LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; double *d_seg = nullptr; uint32_t nbp2 = 1; int32_t *d_cross = nullptr; uint32_t cross_cap = 0;   // segment tree over leaf boxes: nbp2*512 heap nodes
-    double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec32 *d_recs32 = nullptr;
+    double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec32 *d_recs32 = nullptr; LeafBox32 *d_qbox = nullptr;
+    int32_t *d_root = nullptr;              // name (split) of the root record, one word inside d_small
+    bool internal_boxes_valid = false;      // the FP64 boxes of the internal nodes were written by the last refit (fused calls skip them)
     uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
     // traversal
     TravState *d_state = nullptr;
@@ -87,7 +90,7 @@ void free_all(cd_ctx *c)
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_cross); hipFree(c->d_boxes);
-    hipFree(c->d_bounded); hipFree(c->d_recs32); 
+    hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox);
     if (c->d_pairs) hipFree(reinterpret_cast<char *>(c->d_pairs) - sizeof(Report));
     if (c->h_report) hipHostFree(c->h_report);
     hipFree(c->d_defer); hipFree(c->d_deep); hipFree(c->d_cand);
@@ -190,7 +193,7 @@ int enqueue_hierarchy(cd_ctx *c, bool poison_boxes)
     return 0;
 }
 
-int enqueue_refit(cd_ctx *c)
+int enqueue_refit(cd_ctx *c, bool write_internal)
 {
     const uint32_t n = c->nt;
     hipStream_t s = c->stream;
@@ -201,13 +204,15 @@ int enqueue_refit(cd_ctx *c)
     int32_t *cross_list = c->d_cross;
     uint32_t *cross_count = c->d_small + 16;
     if (!c->prezeroed) HIPCHK(hipMemsetAsync(cross_count, 0, 64 * sizeof(uint32_t), s));
-    k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded, c->d_recs32, c->d_seg, (int)c->nbp2,
+    k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded, c->d_recs32, c->d_qbox,
+                                                   c->d_root, write_internal ? 1 : 0, c->d_seg, (int)c->nbp2,
                                                    cross_list, cross_count, c->cross_cap);
     k_refit_seg_top<<<1, 1024, 0, s>>>(c->d_seg, (int)c->nbp2, nblocks);
     // about 13 cross nodes per 512-leaf block: ~one node per wave, every load chain in flight at once
     const uint32_t xblocks = nblocks * 4 < 256u ? 256u : (nblocks * 4 > 16384u ? 16384u : nblocks * 4);
     if (n > 1) k_refit_seg_cross<<<xblocks, 256, 0, s>>>((int)n, c->d_meta, c->d_seg, (int)c->nbp2, c->d_boxes, c->d_bounded, c->d_recs32,
-                                                      c->d_cross, cross_count, c->cross_cap);
+                                                      c->d_root, write_internal ? 1 : 0, c->d_cross, cross_count, c->cross_cap);
+    c->internal_boxes_valid = write_internal;
     HIPCHK(evrec(c, EV_REFIT1));
     HIPCHK(hipGetLastError());
     return 0;
@@ -224,12 +229,16 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
         const uint64_t shard_cap = c->cand_cap / NSHARD;
         k_descend_packet<EXTERNAL><<<cdiv(items, 64 * WQ_WAVES), TRAV_THREADS, c->dbg_lds_pad, s>>>(src, items, n, c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap);
         evrec(c, EV_DESC1);
-        k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, c->d_cand, shard_cap, c->d_pairs, cap_pairs, c->d_state);
+        k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, c->d_cand, shard_cap, c->d_pairs, cap_pairs, c->d_state, 0u);
     } else if (c->trav_variant == 0) {
         k_traverse<EXTERNAL, DEEP><<<cdiv(items, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, items, n, c->d_meta, c->d_boxes, c->d_leaf, c->d_verts, c->d_pairs, cap_pairs, c->d_state,
                                                                                        DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr, vb);
     } else {
-        const uint32_t qpw = DEEP ? 64u : c->queries_per_wave;
+        // variant 3 (half traversal) applies to self-collision queries; external queries are not leaves of this tree
+        // and take the full descent of variant 1.  The deep pass of a half traversal continues (query, subtree) items
+        // with the full descent, but its candidates keep the half traversal's meaning (`half`).
+        const bool half_mode = c->trav_variant == 3 && !EXTERNAL;
+        const uint32_t qpw = (DEEP || c->trav_variant == 3) ? 64u : c->queries_per_wave;
         const uint64_t shard_cap = c->cand_cap / NSHARD;
         const dim3 grid(cdiv(items, qpw * WQ_WAVES));
         const size_t pad = DEEP ? 0 : c->dbg_lds_pad;
@@ -240,16 +249,20 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
         hipEvent_t e0 = ride ? c->ev[EV_TRAV0] : nullptr, e1 = ride ? c->ev[EV_DESC1] : nullptr, e2 = ride ? c->ev[EV_TRAV1] : nullptr;
         const uint32_t qarg = qpw | (c->dbg_no_shared_path ? 0x40000000u : 0u);
         uint2 *dl = DEEP ? nullptr : c->d_defer; const uint32_t dcap = DEEP ? 0u : c->defer_cap; int32_t *deep = DEEP ? c->d_deep : nullptr;
-        if (qpw == 64)
+        const uint32_t half = half_mode ? 1u : 0u;
+        if (half_mode && !DEEP)
+            hipExtLaunchKernelGGL(k_descend_half, grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
+                                  src, n, (const NodeRec32 *)c->d_recs32, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
+        else if (qpw == 64)
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, false>), grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
-                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb);
+                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
         else
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, true>), grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
-                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb);
+                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
         if (!DEEP && !ride) evrec(c, EV_DESC1);
         hipExtLaunchKernelGGL((k_exact<EXTERNAL>), dim3(c->exact_blocks), dim3(EXACT_THREADS), 0u, s, nullptr, e2, 0u,
                               src, n, (const LeafTri *)c->d_leaf, (const double *)c->d_boxes, (const double *)c->d_verts, vb, (const Candidates *)c->d_cand,
-                              (unsigned long long)shard_cap, c->d_pairs, (unsigned long long)cap_pairs, c->d_state);
+                              (unsigned long long)shard_cap, c->d_pairs, (unsigned long long)cap_pairs, c->d_state, half);
         c->events_ride = ride;
     }
 }
@@ -298,6 +311,9 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     int rc = ensure_pairs(c, cap_pairs > 0 ? cap_pairs : 1);
     if (rc) return rc;
     const int per_pass = c->trav_variant == 0 ? 1 : 2;
+    if (c->trav_variant == 0 && !c->internal_boxes_valid) {                // variant 0 walks the FP64 boxes of the internal nodes
+        if ((rc = enqueue_refit(c, true))) return rc;
+    }
     uint32_t launches = 0;
     float deep_ms = 0.f;
     HostCounters h = {};
@@ -306,8 +322,8 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     c->stats.stack_overflows = 0;
     for (int attempt = 0; attempt < 8 && !done; ++attempt) {
         launches = 0; deep_ms = 0.f;
-        QuerySrc src{c->d_leaf, c->d_boxes, d_ext, nullptr, c->d_os_ticket + 8};
-        const bool will_ride = !c->stage_events && c->trav_variant == 1 && nq > 0;   // see launch_pass: events on the dispatch packets
+        QuerySrc src{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, d_ext, nullptr, c->d_os_ticket + 8};
+        const bool will_ride = !c->stage_events && (c->trav_variant == 1 || c->trav_variant == 3) && nq > 0;   // see launch_pass: events on the dispatch packets
         c->events_ride = false;
         if (!will_ride) HIPCHK(evrec(c, EV_TRAV0));
         if (!(c->prezeroed && attempt == 0)) HIPCHK(hipMemsetAsync(c->d_state, 0, sizeof(TravState), s));
@@ -444,6 +460,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_os, c->zero_bytes);
     c->d_small = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(c->d_os) + small_off);
     c->d_state = reinterpret_cast<TravState *>(reinterpret_cast<char *>(c->d_os) + state_off);
+    c->d_root = reinterpret_cast<int32_t *>(c->d_small + 96);
     c->d_os_hist = reinterpret_cast<uint32_t *>(c->d_os);
     c->d_os_ticket = c->d_os_hist + 8 * RADIX;
     c->d_os_look = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_os) + sizeof(uint32_t) * 8 * RADIX + 128);
@@ -460,6 +477,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_boxes, sizeof(double) * 6 * 2 * n);
     ALLOC(c->d_bounded, sizeof(uint32_t) * n);
     ALLOC(c->d_recs32, sizeof(NodeRec32) * n);
+    ALLOC(c->d_qbox, sizeof(LeafBox32) * n);
     c->cand_cap = ((4 * n > (1u << 20) ? 4 * n : (1u << 20)) + NSHARD - 1) / NSHARD * NSHARD;
     ALLOC(c->d_cand, sizeof(Candidates) * c->cand_cap);
     c->defer_cap = 1u << 16;
@@ -557,7 +575,7 @@ int cd_refit_boxes(cd_ctx *c)
     if (!c) return CD_ERR_ARG;
     c->root_box_valid = false;
     if (c->stage < ST_BUILT) return CD_ERR_ORDER;
-    int rc = enqueue_refit(c);
+    int rc = enqueue_refit(c, true);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     c->stats.ms_refit = elapsed(c, EV_REFIT0, EV_REFIT1);
@@ -565,10 +583,22 @@ int cd_refit_boxes(cd_ctx *c)
     return CD_OK;
 }
 
+// Fused calls do not write the FP64 boxes of the internal nodes (nothing on their path reads them); whoever asks for
+// them afterwards -- the exported tree, checkInternalNodes' uninitialised-box counter -- gets them from a full refit.
+static int materialise_internal_boxes(cd_ctx *c)
+{
+    if (c->stage < ST_REFIT || c->internal_boxes_valid || c->nt < 2) return CD_OK;
+    const int rc = enqueue_refit(c, true);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CD_OK;
+}
+
 static int run_check(cd_ctx *c, int which, uint32_t maxv, uint32_t *out, int nout)
 {
     if (!c || !out) return CD_ERR_ARG;
     if (c->stage < ST_BUILT) return CD_ERR_ORDER;
+    if (which == 0) { const int rm = materialise_internal_boxes(c); if (rm) return rm; }
     const int n = (int)c->nt;
     hipStream_t s = c->stream;
     HIPCHK(hipEventRecord(c->ev[EV_CHK0], s));
@@ -601,7 +631,7 @@ int cd_build_tree(cd_ctx *c)
     Prezeroed fused(c);                                                    // one memset for every counter of the pipeline
     rc = enqueue_morton_sort(c);
     if (!rc) rc = enqueue_hierarchy(c, false);
-    if (!rc) rc = enqueue_refit(c);
+    if (!rc) rc = enqueue_refit(c, c->trav_variant == 0);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));   // words 8..16
     HIPCHK(hipMemcpyAsync(c->root_box_host, c->d_boxes, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
@@ -627,7 +657,7 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     Prezeroed fused(c);                                                    // one memset for every counter of the pipeline
     rc = enqueue_morton_sort(c);
     if (!rc) rc = enqueue_hierarchy(c, false);
-    if (!rc) rc = enqueue_refit(c);
+    if (!rc) rc = enqueue_refit(c, c->trav_variant == 0);
     if (!rc) rc = run_traversal(c, nullptr, 0, pairs, cap_pairs, n_pairs);     // synchronises
     fused.done();
     if (rc < 0) return rc;
@@ -757,8 +787,19 @@ int cd_export_tree(cd_ctx *c, int32_t *parent, int32_t *left, int32_t *right, do
         for (size_t i = 0; i < n - 1; ++i) { if (left) left[i] = m[i].x; if (right) right[i] = m[i].y; }
     }
     if (boxes || bounded) { if (c->stage < ST_REFIT) return CD_ERR_ORDER; }
+    if (boxes) { const int rm = materialise_internal_boxes(c); if (rm) return rm; }
     if (boxes) HIPCHK(hipMemcpy(boxes, c->d_boxes, sizeof(double) * 6 * (2 * n - 1), hipMemcpyDeviceToHost));
     if (bounded && n > 1) HIPCHK(hipMemcpy(bounded, c->d_bounded, sizeof(uint32_t) * (n - 1), hipMemcpyDeviceToHost));
+    return CD_OK;
+}
+
+/* Debug only (not in the public header): sums of the 12 spare words of the 64 counter shards of the last traversal. */
+int cd_debug_counters(cd_ctx *c, unsigned long long out[12])
+{
+    if (!c || !out) return CD_ERR_ARG;
+    std::vector<TravState> h(1);
+    HIPCHK(hipMemcpy(h.data(), c->d_state, sizeof(TravState), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 12; ++k) { out[k] = 0; for (int i = 0; i < NSHARD; ++i) out[k] += h[0].shard[i].pad[k]; }
     return CD_OK;
 }
 
@@ -768,12 +809,13 @@ int cd_num_triangles(cd_ctx *c, uint32_t *nt) { if (!c || !nt) return CD_ERR_ARG
 int cd_set_option(cd_ctx *c, int key, int64_t value)
 {
     if (!c) return CD_ERR_ARG;
-    if (key == CD_OPT_TRAVERSAL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
+    if (key == CD_OPT_TRAVERSAL) { if (value < 0 || value > 3) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
     if (key == CD_OPT_QUERIES_PER_WAVE) { if (value < 64 || value > (1 << 20) || value % 64) return CD_ERR_ARG; c->queries_per_wave = (uint32_t)value; return CD_OK; }
     if (key == CD_OPT_SORT_FULL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->sort_mode = value == 0 ? 0 : (value == 1 ? 2 : 1); return CD_OK; }
     if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }
     if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
     if (key == 102) { c->dbg_no_shared_path = (uint32_t)value; return CD_OK; }
+    if (key == 103) { c->dbg_diag = (uint32_t)value; return CD_OK; }
     if (key == 101) { if (value < 1 || value > 65535) return CD_ERR_ARG; c->exact_blocks = (int)value; return CD_OK; }
     return CD_ERR_ARG;
 }

@@ -77,6 +77,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_export_keys.argtypes = [vp, vp, vp]
     lib.cd_export_tree.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.cd_get_stats.argtypes = [vp, C.POINTER(CdStats)]
+    lib.cd_debug_counters.argtypes = [vp, vp]
     lib.cd_num_triangles.argtypes = [vp, u32p]
     lib.cd_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.cd_set_vertex_id_base.argtypes = [vp, C.c_uint32]
@@ -244,6 +245,11 @@ class CollisionDetector:
         s = CdStats()
         self._chk("cd_get_stats", self.lib.cd_get_stats(self._ctx, C.byref(s)))
         return s
+
+    def debug_counters(self) -> np.ndarray:
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk("cd_debug_counters", self.lib.cd_debug_counters(self._ctx, out.ctypes.data))
+        return out
 
     # ---- cross-rank pass
     def set_vertex_id_base(self, base: int):

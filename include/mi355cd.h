@@ -164,6 +164,10 @@ enum {
 int cd_set_option(cd_ctx *ctx, int key, int64_t value);
 
 int cd_get_stats(cd_ctx *ctx, cd_stats *out);
+/* Diagnostics of the last traversal, filled only after cd_set_option(ctx, 103, 1): sums over the descent's waves of
+ * {chain steps, chain hops inside / outside the query's 256-leaf block, descent visits inside / outside it, longest
+ * chain of each wave, 6 spare}.  Not part of any result. */
+int cd_debug_counters(cd_ctx *ctx, unsigned long long out[12]);
 int cd_num_triangles(cd_ctx *ctx, uint32_t *nt);
 
 /* ---- multi-GPU cross-rank pass (new work defined by the north star; no reference call site) ----

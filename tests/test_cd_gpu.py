@@ -17,17 +17,21 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-VARIANTS = [0, 1, 2]     # CD_OPT_TRAVERSAL: lane-private FP64 descent / per-lane fp32 descent + exact kernel / packet descent + exact kernel
+VARIANTS = [0, 1, 2, 3]  # CD_OPT_TRAVERSAL: lane-private FP64 descent / per-lane fp32 descent + exact kernel / packet descent + exact kernel /
+                         # half traversal (default): bottom-up chain of right siblings + per-lane fp32 descent + exact kernel
 
 
 def _check_visits(st, ref_stats, variant):
     """Variant 0 walks exactly the oracle's nodes; variant 2 descends with conservative fp32 boxes, so it may visit a
     few more internal nodes (never fewer); variant 1 also walks the root-to-first-leaf path once per wave and counts
-    those (cheap, scalar-fetched) steps per lane, so its count is of the same order only -- a diagnostic, not a result."""
+    those (cheap, scalar-fetched) steps per lane, so its count is of the same order only -- a diagnostic, not a result.
+    Variant 3 visits only what lies to the right of each query (about half of it) plus one record per chain hop."""
     if variant == 0:
         assert st.node_visits == ref_stats.node_visits
     elif variant == 1:
         assert 0.5 * ref_stats.node_visits <= st.node_visits <= ref_stats.node_visits * 2 + 64
+    elif variant == 3:
+        assert 0 < st.node_visits <= ref_stats.node_visits * 2 + 64
     else:
         assert ref_stats.node_visits <= st.node_visits <= ref_stats.node_visits * 1.02 + 16
 
@@ -210,9 +214,9 @@ def test_capacity_overflow_and_stage_order():
     assert e.value.rc == mi355cd.CD_ERR_INDEX
 
 
-def _comb(codes):
+def _comb(codes, big_first=False):
     """Two tiny triangles per Morton code (decoded to grid cells of a unit-cell frame) + one triangle
-    spanning everything."""
+    spanning everything (big_first: with a centroid below the frame, so that it sorts FIRST -- key 0)."""
     tris = []
     for code in codes:
         c = np.zeros(3)
@@ -222,7 +226,7 @@ def _comb(codes):
         c += 0.5
         for s in (0.0, 0.02):
             tris.append([c + [s, 0, 0], c + [s + 0.2, 0.1, 0], c + [s, 0.1, 0.2]])
-    tris.append([[-1.0, -1.0, -1.0], [4.0e6, -1.0, -1.0], [-1.0, 4.0e6, 4.0e6]])
+    tris.append([[-9.0e6 if big_first else -1.0] * 3, [4.0e6, -1.0, -1.0], [-1.0, 4.0e6, 4.0e6]])
     verts = np.asarray(tris, dtype=np.float64).reshape(-1, 3)
     vidx = np.arange(verts.shape[0], dtype=np.uint32).reshape(-1, 3)
     return verts, vidx
@@ -252,12 +256,34 @@ def test_deep_tree_uses_the_deferred_stack_path(mirrored, variant):
         assert r["stats"].max_stack > 32
     elif variant == 2:
         assert st.stack_overflows == 0 and st.traverse_launches == 2     # wave-uniform stack holds the whole height
+    elif variant == 3:
+        pass                                                             # (the half traversal's overflow case: next test)
     else:
         assert st.stack_overflows > 0 and st.traverse_launches == (4 if variant == 1 else 2)
     assert n == r["stats"].n_pairs > 0
     assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
     assert st.pairs_tested == r["stats"].pairs_tested
     _check_visits(st, r["stats"], variant)
+
+
+def test_half_traversal_chain_overflows_into_the_deep_pass():
+    """Variant 3: the all-overlapping triangle sorts first, so the chain of right siblings of ITS leaf holds all 60
+    clusters of the left-hanging comb -- more than a lane's 12 LDS stack entries -> deferred (query, subtree) items that
+    the deep pass continues with the half traversal's counting."""
+    off = np.zeros(3); span = np.full(3, 1048576.0)
+    verts, vidx = _comb([1 << (59 - k) for k in range(60)], big_first=True)
+    r = oracle.pipeline(verts, vidx, off=off, span=span)
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, off, span)
+        pairs, n, rc = cd.self_collide()
+        st = cd.stats()
+        assert st.stack_overflows > 0 and st.traverse_launches == 4
+        assert n == r["stats"].n_pairs > 0 and st.pairs_tested == r["stats"].pairs_tested
+        assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+        for variant in (0, 1, 2):
+            cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
+            p2, n2, _ = cd.find_collisions()
+            assert np.array_equal(oracle.pair_set(p2), oracle.pair_set(pairs)) and cd.stats().pairs_tested == st.pairs_tested
 
 
 def test_exact_test_kernel_one_million_pairs():
@@ -613,7 +639,7 @@ def test_random_meshes_property():
                 assert rc == 0 and npairs == r["stats"].n_pairs, (case, variant)
                 assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])), (case, variant)
                 assert cd.stats().pairs_tested == r["stats"].pairs_tested, (case, variant)
-                if variant == 1:
+                if variant == 3:
                     keys, perm = cd.export_keys()
                     assert np.array_equal(keys, r["keys"]) and np.array_equal(perm, r["perm"]), case
                     parent, left, right, boxes, bounded = cd.export_tree()
