@@ -37,7 +37,7 @@ EXPORTS = [
     "cd_load_obj", "cd_free_obj", "cd_create", "cd_destroy", "cd_update_vertices", "cd_set_morton_frame", "cd_morton_sort",
     "cd_build_hierarchy", "cd_refit_boxes", "cd_check_internal", "cd_check_leaves",
     "cd_check_triangle_idx", "cd_find_collisions", "cd_build_tree", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
-    "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_num_triangles",
+    "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_debug_counters", "cd_num_triangles",
     "cd_set_option", "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
 ]
 
