@@ -1,0 +1,380 @@
+// cd_multi.h -- the multi-GPU step behind the C ABI (include/mi355cd.h, cd_multi_*): one process per GPU, triangles
+// sharded by object, RCCL over xGMI for the one exchange the path has.  Included at the end of mi355cd.hip (it uses
+// the stage enqueuers and the traversal passes of that file).
+//
+// The reference is single-GPU (main.cu:47-174 is the harness this slots into); SURVEY.md 8(e) defines the step:
+//   1. local LBVH (Morton keys, sort, hierarchy, refit)                       -- no communication
+//   2. all-gather of the per-rank root AABB (6 doubles)                       -- ncclAllGather, 48 B per rank
+//   3. ONE launch compacts, for every peer whose root strictly overlaps this rank's (box.cuh:40-43), the local leaves
+//      that overlap that root into cd_query records; the per-peer counts are all-gathered as a world x world matrix,
+//      so every rank knows what it sends, what it receives and whether ANY rank ran out of room -- decisions taken
+//      from that matrix (grow the slabs, redo a failed sort) are the same on every rank: no rank leaves a collective
+//      the others are still in
+//   4. grouped ncclSend / ncclRecv of the records, each peer's slice on its own xGMI link (no ring), on a second
+//      stream so that the local traversal runs while the records travel
+//   5. local traversal, then the received queries against the local tree; a cross pair {a, b}, a.ID < b.ID, is
+//      reported exactly once, by the owner of b (tri_contact.cuh:81 applied to external queries too)
+// Host synchronisations per step: two (after the count matrix; after both traversal passes).
+//
+// RCCL is loaded at run time (dlopen) by the first cd_multi_* call, so single-GPU users of the library do not pay for
+// it; there is no fallback transport: without librccl the calls return CD_ERR_RCCL.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+};
+
+RcclApi *rccl()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+            api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+            api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+            api.CommCount = (decltype(api.CommCount))dlsym(h, "ncclCommCount");
+            api.CommUserRank = (decltype(api.CommUserRank))dlsym(h, "ncclCommUserRank");
+            api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+            api.Send = (decltype(api.Send))dlsym(h, "ncclSend");
+            api.Recv = (decltype(api.Recv))dlsym(h, "ncclRecv");
+            api.GroupStart = (decltype(api.GroupStart))dlsym(h, "ncclGroupStart");
+            api.GroupEnd = (decltype(api.GroupEnd))dlsym(h, "ncclGroupEnd");
+            if (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.CommCount && api.CommUserRank && api.AllGather && api.Send && api.Recv &&
+                api.GroupStart && api.GroupEnd)
+                api.handle = h;
+        }
+    }
+    return api.handle ? &api : nullptr;
+}
+
+#define NCCLCHK(expr)                                                  \
+    do {                                                               \
+        ncclResult_t r_ = (expr);                                      \
+        if (r_ != ncclSuccess) return CD_ERR_RCCL;                     \
+    } while (0)
+
+enum MEv { ME_START, ME_TREE, ME_GATHER, ME_PACK, ME_COUNTS, ME_XCH0, ME_XCH1, ME_LOCAL, ME_CROSS, ME_COUNT };
+
+}  // namespace
+
+struct cd_multi {
+    cd_ctx *c = nullptr;
+    ncclComm_t comm = nullptr; bool own_comm = false;
+    int rank = 0, world = 1, flags = 0;
+    uint64_t qcap = 0;                           // records per peer slab -- the SAME on every rank (grown from the shared count matrix)
+    hipStream_t xstream = nullptr;               // payload exchange, beside the context's stream
+    hipEvent_t ev_payload = nullptr, ev[ME_COUNT] = {};
+    double *d_roots = nullptr;                   // world x 6
+    unsigned long long *d_row = nullptr;         // world + 1: records packed for each peer, then this rank's "redo" word
+    unsigned long long *d_matrix = nullptr;      // world x (world + 1), all-gathered rows
+    unsigned long long *h_matrix = nullptr;      // pinned copy
+    double *h_roots = nullptr;                   // pinned, world x 6
+    ExtQuery *d_send = nullptr;                  // world slabs of qcap records
+    ExtQuery *d_recv = nullptr; uint64_t recv_cap = 0;
+    std::vector<uint32_t> scratch_pairs;
+};
+
+namespace {
+
+void multi_free(cd_multi *m)
+{
+    if (!m) return;
+    if (m->c) hipStreamSynchronize(m->c->stream);
+    if (m->xstream) { hipStreamSynchronize(m->xstream); hipStreamDestroy(m->xstream); }
+    if (m->ev_payload) hipEventDestroy(m->ev_payload);
+    for (int i = 0; i < ME_COUNT; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
+    hipFree(m->d_roots); hipFree(m->d_row); hipFree(m->d_matrix); hipFree(m->d_send); hipFree(m->d_recv);
+    if (m->h_matrix) hipHostFree(m->h_matrix);
+    if (m->h_roots) hipHostFree(m->h_roots);
+    if (m->own_comm && m->comm && rccl()) rccl()->CommDestroy(m->comm);
+    delete m;
+}
+
+int multi_alloc(cd_multi *m)
+{
+    const size_t W = (size_t)m->world;
+    HIPCHK(hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_payload, hipEventDisableTiming));
+    for (int i = 0; i < ME_COUNT; ++i) HIPCHK(hipEventCreate(&m->ev[i]));
+    HIPCHK(hipMalloc(&m->d_roots, sizeof(double) * 6 * W));
+    HIPCHK(hipMalloc(&m->d_row, sizeof(unsigned long long) * (W + 1)));
+    HIPCHK(hipMalloc(&m->d_matrix, sizeof(unsigned long long) * W * (W + 1)));
+    HIPCHK(hipHostMalloc(&m->h_matrix, sizeof(unsigned long long) * W * (W + 1), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&m->h_roots, sizeof(double) * 6 * W, hipHostMallocDefault));
+    HIPCHK(hipMalloc(&m->d_send, sizeof(ExtQuery) * W * m->qcap));
+    // the external pass has its own counters, candidates, pairs and deferred list (TravBuf [1])
+    TravBuf &tb = m->c->tb[1];
+    if (!tb.d_state) { HIPCHK(hipMalloc(&tb.d_state, sizeof(TravState))); tb.state_owned = true; }
+    if (!tb.d_cand) { tb.cand_cap = (uint64_t)(1u << 20); HIPCHK(hipMalloc(&tb.d_cand, sizeof(Candidates) * tb.cand_cap)); }
+    if (!tb.d_defer) { tb.defer_cap = 1u << 14; HIPCHK(hipMalloc(&tb.d_defer, sizeof(uint2) * tb.defer_cap)); }
+    return CD_OK;
+}
+
+bool host_boxes_overlap(const double *a, const double *b)      // box.cuh:40-43
+{
+    return (a[0] - b[1]) * (b[0] - a[1]) > 0 && (a[2] - b[3]) * (b[2] - a[3]) > 0 && (a[4] - b[5]) * (b[4] - a[5]) > 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cd_multi_unique_id(void *id128)
+{
+    if (!id128) return CD_ERR_ARG;
+    RcclApi *r = rccl();
+    if (!r) return CD_ERR_RCCL;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    NCCLCHK(r->GetUniqueId(reinterpret_cast<ncclUniqueId *>(id128)));
+    return CD_OK;
+}
+
+static int multi_create_common(cd_multi **out, cd_ctx *ctx, ncclComm_t comm, bool own, int rank, int world, uint64_t query_cap_per_peer, int flags)
+{
+    cd_multi *m = new (std::nothrow) cd_multi();
+    if (!m) return CD_ERR_ARG;
+    m->c = ctx; m->comm = comm; m->own_comm = own; m->rank = rank; m->world = world; m->flags = flags;
+    m->qcap = query_cap_per_peer ? query_cap_per_peer : (uint64_t)(ctx->nt / 8 + 1024);
+    const int rc = multi_alloc(m);
+    if (rc) { multi_free(m); return rc; }
+    *out = m;
+    return CD_OK;
+}
+
+int cd_multi_create(cd_multi **out, cd_ctx *ctx, const void *id128, int rank, int world, uint64_t query_cap_per_peer, int flags)
+{
+    if (!out || !ctx || !id128 || world < 1 || rank < 0 || rank >= world) return CD_ERR_ARG;
+    *out = nullptr;
+    RcclApi *r = rccl();
+    if (!r) return CD_ERR_RCCL;
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    ncclComm_t comm = nullptr;
+    NCCLCHK(r->CommInitRank(&comm, world, id, rank));
+    const int rc = multi_create_common(out, ctx, comm, true, rank, world, query_cap_per_peer, flags);
+    if (rc) r->CommDestroy(comm);
+    return rc;
+}
+
+int cd_multi_create_from_comm(cd_multi **out, cd_ctx *ctx, void *nccl_comm, uint64_t query_cap_per_peer, int flags)
+{
+    if (!out || !ctx || !nccl_comm) return CD_ERR_ARG;
+    *out = nullptr;
+    RcclApi *r = rccl();
+    if (!r) return CD_ERR_RCCL;
+    int world = 0, rank = 0;
+    NCCLCHK(r->CommCount(static_cast<ncclComm_t>(nccl_comm), &world));
+    NCCLCHK(r->CommUserRank(static_cast<ncclComm_t>(nccl_comm), &rank));
+    return multi_create_common(out, ctx, static_cast<ncclComm_t>(nccl_comm), false, rank, world, query_cap_per_peer, flags);
+}
+
+void cd_multi_destroy(cd_multi *m) { multi_free(m); }
+
+int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs, cd_multi_info *info)
+{
+    if (!m || (cap_pairs && !pairs)) return CD_ERR_ARG;
+    RcclApi *r = rccl();
+    if (!r) return CD_ERR_RCCL;
+    cd_ctx *c = m->c;
+    hipStream_t s = c->stream;
+    const int W = m->world, me = m->rank;
+    const bool self_peer = (m->flags & CD_MULTI_SELF_PEER) != 0, timing = (m->flags & CD_MULTI_TIMING) != 0;
+    const size_t RW = (size_t)W + 1;
+    uint32_t syncs = 0, attempts = 0;
+    auto mark = [&](int e, hipStream_t st) { if (timing) hipEventRecord(m->ev[e], st); };
+
+    // ---- 1-3: tree, root all-gather, pack for all peers, count matrix; redone by EVERY rank if any rank asks for it
+    for (;; ++attempts) {
+        if (attempts >= 6) return CD_ERR_ARG;
+        mark(ME_START, s);
+        int rc;
+        {
+            Prezeroed fused(c);
+            rc = enqueue_morton_sort(c);
+            if (!rc) rc = enqueue_hierarchy(c, false);
+            if (!rc) rc = enqueue_refit(c, c->trav_variant == 0);
+        }
+        if (rc) return rc;                        // (an enqueue failure is a HIP error on this rank: nothing collective has started in this attempt)
+        mark(ME_TREE, s);
+        NCCLCHK(r->AllGather(c->d_boxes, m->d_roots, 6, ncclDouble, m->comm, s));          // node 0 = root (n == 1: leaf 0 is node 0 too)
+        mark(ME_GATHER, s);
+        HIPCHK(hipMemsetAsync(m->d_row, 0, sizeof(unsigned long long) * RW, s));
+        k_pack_queries<<<cdiv(c->nt, PACK_THREADS), PACK_THREADS, 0, s>>>(c->d_verts, c->d_leaf, c->d_boxes, c->d_qbox, (int)c->nt, m->d_roots, W,
+                                                                           self_peer ? -1 : me, m->d_roots + 6 * (size_t)me,
+                                                                           m->d_send, (unsigned long long)m->qcap, m->d_row, c->vbase);
+        // the "redo" word of the row: non-zero when this rank's sort has to be repeated in another form (cd_sort.h)
+        k_sort_flags_word<<<1, 64, 0, s>>>(c->d_os_ticket + 8, c->sort_mode, m->d_row + W);
+        mark(ME_PACK, s);
+        NCCLCHK(r->AllGather(m->d_row, m->d_matrix, RW, ncclUint64, m->comm, s));
+        HIPCHK(hipMemcpyAsync(m->h_matrix, m->d_matrix, sizeof(unsigned long long) * W * RW, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(m->h_roots, m->d_roots, sizeof(double) * 6 * W, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, s));
+        mark(ME_COUNTS, s);
+        HIPCHK(hipStreamSynchronize(s)); ++syncs;                                          // host synchronisation 1 of 2
+        HIPCHK(hipGetLastError());
+        // decisions from the matrix: identical on every rank
+        unsigned long long mx = 0; bool any_redo = false, any_fail = false;
+        for (int a = 0; a < W; ++a) {
+            for (int b = 0; b < W; ++b) mx = std::max(mx, m->h_matrix[a * RW + b]);
+            const unsigned long long f = m->h_matrix[a * RW + W];
+            any_redo |= f == 1; any_fail |= f > 1;
+        }
+        if (any_fail) return CD_ERR_SORT;                                                  // some rank's look-back timed out: every rank returns
+        bool again = false;
+        if (any_redo) { const int js = judge_sort_flags(c); if (js != CD_OK && js != SORT_REDO) return js; again = true; }   // this rank escalates its own sort mode if it was the one
+        if (mx > m->qcap) {
+            m->qcap = mx + mx / 4 + 1024;                                                  // same rule, same input -> same capacity on every rank
+            hipFree(m->d_send); m->d_send = nullptr;
+            HIPCHK(hipMalloc(&m->d_send, sizeof(ExtQuery) * (size_t)W * m->qcap));
+            again = true;
+        }
+        if (!again) break;
+    }
+    c->stage = ST_REFIT; c->root_box_valid = false;
+
+    // ---- 4: payload exchange on the second stream (everything it reads was complete at the synchronisation above)
+    uint64_t sent = 0, recvd = 0; uint32_t n_peers = 0;
+    std::vector<uint64_t> roff((size_t)W + 1, 0);
+    for (int p = 0; p < W; ++p) {
+        const uint64_t from_p = m->h_matrix[(size_t)p * RW + me];
+        roff[p + 1] = roff[p] + from_p;
+        const uint64_t to_p = m->h_matrix[(size_t)me * RW + p];
+        sent += to_p; recvd += from_p;
+        if (to_p || from_p) ++n_peers;
+    }
+    if (recvd > m->recv_cap) {
+        hipFree(m->d_recv); m->d_recv = nullptr; m->recv_cap = 0;
+        const uint64_t want = recvd + recvd / 4 + 1024;
+        HIPCHK(hipMalloc(&m->d_recv, sizeof(ExtQuery) * want));
+        m->recv_cap = want;
+    }
+    mark(ME_XCH0, m->xstream);
+    if (sent || recvd) {
+        NCCLCHK(r->GroupStart());
+        for (int p = 0; p < W; ++p) {
+            const uint64_t to_p = m->h_matrix[(size_t)me * RW + p], from_p = m->h_matrix[(size_t)p * RW + me];
+            if (to_p) NCCLCHK(r->Send(m->d_send + (size_t)p * m->qcap, to_p * sizeof(ExtQuery), ncclChar, p, m->comm, m->xstream));
+            if (from_p) NCCLCHK(r->Recv(m->d_recv + roff[p], from_p * sizeof(ExtQuery), ncclChar, p, m->comm, m->xstream));
+        }
+        NCCLCHK(r->GroupEnd());
+    }
+    mark(ME_XCH1, m->xstream);
+    HIPCHK(hipEventRecord(m->ev_payload, m->xstream));
+
+    // ---- 5: both traversal passes queued back to back, ONE synchronisation
+    TravBuf &t0 = c->tb[0], &t1 = c->tb[1];
+    const bool fast_path = c->trav_variant != 0;                              // (variant 0 has no candidate stage: take the general path)
+    const uint64_t cap = cap_pairs;
+    uint64_t n_local = 0, n_cross = 0, tested = 0;
+    int rc_l = CD_OK, rc_x = CD_OK;
+    bool need_general_l = !fast_path, need_general_x = !fast_path;
+    if (fast_path) {
+        int rc = ensure_pairs(c, t0, cap > 0 ? cap : 1);
+        if (!rc) rc = ensure_pairs(c, t1, cap > 0 ? cap : 1);
+        if (rc) return rc;
+        // (stage events off: the kernels' time stamps ride on their dispatch packets, no barrier packets between the passes)
+        const bool se = c->stage_events; c->stage_events = false;
+        QuerySrc src{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, nullptr, nullptr, c->d_os_ticket + 8};
+        HIPCHK(hipMemsetAsync(t0.d_state, 0, sizeof(TravState), s));
+        launch_pass<false, false>(c, t0, src, c->nt, cap);
+        uint64_t spec0 = cap < SPEC_PAIRS ? cap : SPEC_PAIRS, spec1 = spec0;
+        rc = enqueue_report(c, t0, pairs != nullptr, spec0);
+        if (rc) { c->stage_events = se; return rc; }
+        mark(ME_LOCAL, s);
+        HIPCHK(hipStreamWaitEvent(s, m->ev_payload, 0));
+        if (recvd) {
+            QuerySrc srcx{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, m->d_recv, nullptr, c->d_os_ticket + 8};
+            HIPCHK(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), s));
+            launch_pass<true, false>(c, t1, srcx, (uint32_t)recvd, cap);
+            m->scratch_pairs.resize(2 * (size_t)spec1 + 2);
+            rc = enqueue_report(c, t1, pairs != nullptr, spec1);
+            if (rc) { c->stage_events = se; return rc; }
+        }
+        mark(ME_CROSS, s);
+        c->stage_events = se;
+        HIPCHK(hipStreamSynchronize(s)); ++syncs;                                          // host synchronisation 2 of 2
+        HIPCHK(hipGetLastError());
+        HostCounters h0 = {}, h1 = {};
+        parse_report(c, t0, h0, pairs, spec0);
+        need_general_l = h0.max_shard_candidates > t0.cand_cap / NSHARD || h0.n_deferred > 0;
+        if (!need_general_l) {
+            n_local = h0.n_pairs; tested += h0.pairs_tested;
+            const uint64_t ncopy = std::min<uint64_t>(n_local, cap);
+            if (pairs && ncopy > spec0) { HIPCHK(hipMemcpy(pairs + 2 * spec0, t0.d_pairs + 2 * spec0, sizeof(uint32_t) * 2 * (ncopy - spec0), hipMemcpyDeviceToHost)); ++syncs; }
+            rc_l = n_local > cap ? CD_OVERFLOW : CD_OK;
+        }
+        if (recvd) {
+            parse_report(c, t1, h1, m->scratch_pairs.data(), spec1);
+            need_general_x = h1.max_shard_candidates > t1.cand_cap / NSHARD || h1.n_deferred > 0;
+        } else need_general_x = false;
+        if (recvd && !need_general_x && !need_general_l) {
+            n_cross = h1.n_pairs; tested += h1.pairs_tested;
+            const uint64_t room = cap > std::min<uint64_t>(n_local, cap) ? cap - std::min<uint64_t>(n_local, cap) : 0;
+            const uint64_t ncopy = std::min<uint64_t>(n_cross, room);
+            const uint64_t from_spec = std::min<uint64_t>(ncopy, spec1);
+            if (pairs && from_spec) std::memcpy(pairs + 2 * n_local, m->scratch_pairs.data(), sizeof(uint32_t) * 2 * from_spec);
+            if (pairs && ncopy > from_spec) { HIPCHK(hipMemcpy(pairs + 2 * (n_local + from_spec), t1.d_pairs + 2 * from_spec, sizeof(uint32_t) * 2 * (ncopy - from_spec), hipMemcpyDeviceToHost)); ++syncs; }
+            rc_x = n_cross > room ? CD_OVERFLOW : CD_OK;
+        } else if (recvd && !need_general_x) need_general_x = true;     // the local pass is redone below: append the cross pairs after its final count
+    }
+    // general path (rare: a candidate shard overflowed, or a stack overflowed into the deep pass): the pass that needs it
+    // runs again on its own, with the retries and the deep pass of run_traversal
+    if (need_general_l) {
+        uint64_t nl = 0;
+        rc_l = run_traversal(c, t0, nullptr, 0, pairs, cap, &nl);
+        if (rc_l < 0) return rc_l;
+        n_local = nl; tested += c->stats.pairs_tested; syncs += 1;
+    }
+    if (need_general_x && recvd) {
+        HIPCHK(hipStreamWaitEvent(s, m->ev_payload, 0));
+        const uint64_t used = std::min<uint64_t>(n_local, cap);
+        uint64_t nx = 0;
+        rc_x = run_traversal(c, t1, m->d_recv, recvd, pairs ? pairs + 2 * used : nullptr, cap - used, &nx);
+        if (rc_x < 0) return rc_x;
+        n_cross = nx; tested += c->stats.pairs_tested; syncs += 1;
+    }
+    // the payload exchange must have drained before the next step reuses the slabs (it has: the cross pass waited for it,
+    // or nothing was received; a rank that only SENT waits here)
+    if (!recvd && sent) { HIPCHK(hipStreamSynchronize(m->xstream)); }
+    c->stats.n_pairs = n_local + n_cross; c->stats.pairs_tested = tested;
+    c->last_pairs_on_device = 0;                                              // two lists: cd_sorted_pairs does not apply to a multi step
+    if (n_pairs) *n_pairs = n_local + n_cross;
+    if (info) {
+        std::memset(info, 0, sizeof *info);
+        info->world = (uint32_t)W; info->rank = (uint32_t)me; info->n_peers = n_peers; info->host_syncs = syncs; info->attempts = attempts + 1;
+        info->sent_queries = sent; info->recv_queries = recvd; info->local_pairs = n_local; info->cross_pairs = n_cross; info->pairs_tested = tested;
+        info->query_cap = m->qcap;
+        if (timing) {
+            auto el = [&](int a, int b) { float ms = 0.f; return hipEventElapsedTime(&ms, m->ev[a], m->ev[b]) == hipSuccess ? ms : -1.f; };
+            info->ms_tree = el(ME_START, ME_TREE); info->ms_allgather = el(ME_TREE, ME_GATHER); info->ms_pack = el(ME_GATHER, ME_PACK);
+            info->ms_counts = el(ME_PACK, ME_COUNTS);
+            hipEventSynchronize(m->ev[ME_XCH1]);
+            info->ms_exchange = el(ME_XCH0, ME_XCH1);
+            if (fast_path && !need_general_l && !need_general_x) { info->ms_local = el(ME_COUNTS, ME_LOCAL); info->ms_cross = el(ME_LOCAL, ME_CROSS); }
+            else { info->ms_local = -1.f; info->ms_cross = -1.f; }
+        }
+    }
+    (void)host_boxes_overlap;
+    return (rc_l == CD_OVERFLOW || rc_x == CD_OVERFLOW) ? CD_OVERFLOW : CD_OK;
+}
+
+}  // extern "C"

@@ -72,6 +72,17 @@ __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__re
     for (unsigned long long i = (unsigned long long)blockIdx.x * REPORT_THREADS + threadIdx.x; i < quads; i += (unsigned long long)gridDim.x * REPORT_THREADS) dst[i] = src[i];
 }
 
+// One word that says what the multi-GPU step has to do about this rank's sort (cd_multi.h): 0 = fine, 1 = redo it in
+// the next form (a run was too long for this one), 2 = it cannot be repaired (a bounded wait timed out, or the last
+// form overflowed).  The word travels with the all-gathered count matrix, so every rank takes the same decision.
+__global__ void k_sort_flags_word(const uint32_t *__restrict__ sort_flags /* 9 words */, int sort_mode, unsigned long long *__restrict__ out)
+{
+    if (threadIdx.x != 0) return;
+    uint32_t timeout = 0;
+    for (int i = 0; i < 8; ++i) timeout |= sort_flags[i];
+    *out = timeout ? 2ull : (sort_flags[8] ? (sort_mode >= 2 ? 2ull : 1ull) : 0ull);
+}
+
 constexpr int TRAV_THREADS = 256;
 constexpr int TRAV_STACK   = 32;       // variant A: LDS entries per lane (the reference's private stack is 32, collision.cuh:21)
 constexpr int DEEP_STACK   = 192;      // global-memory entries per item in the overflow pass (tree height <= 96)
@@ -1036,24 +1047,62 @@ __global__ __launch_bounds__(256) void k_test_pairs(const double *__restrict__ v
     out[k] = r ? 1 : 0;
 }
 
-// Leaves whose AABB strictly overlaps `box` -> cd_query records (cross-rank pass).
-__global__ __launch_bounds__(256) void k_pack_queries(const double *__restrict__ verts, const LeafTri *__restrict__ leaf,
-                                                      const double *__restrict__ boxes, int n, Box box,
-                                                      ExtQuery *__restrict__ out, unsigned long long cap, unsigned long long *__restrict__ count,
-                                                      uint32_t vbase)
+// Leaves whose AABB strictly overlaps a peer's root box -> cd_query records (cross-rank pass), for ALL peers in one
+// launch.  roots: n_boxes x 6 doubles in device memory (the all-gathered root AABBs, or one caller-supplied box);
+// box p is skipped when p == skip or when it does not strictly overlap my_root (box.cuh:40-43) -- a peer whose root
+// misses this rank's root cannot overlap any of its leaves.  Records for box p go to out + p * cap, their number to
+// counts[p] (may exceed cap: nothing is written past it).  A returning atomic on one word retires at ~88 per
+// microsecond on this chip, so hits are compacted with __ballot per wave and an LDS prefix over the 16 waves of the
+// workgroup, and reserved with ONE global atomic per workgroup and box.
+constexpr int PACK_THREADS = 1024;
+__global__ __launch_bounds__(PACK_THREADS) void k_pack_queries(const double *__restrict__ verts, const LeafTri *__restrict__ leaf,
+                                                              const double *__restrict__ boxes, const LeafBox32 *__restrict__ qbox32, int n,
+                                                              const double *__restrict__ roots, int n_boxes, int skip, const double *__restrict__ my_root,
+                                                              ExtQuery *__restrict__ out, unsigned long long cap, unsigned long long *__restrict__ counts,
+                                                              uint32_t vbase)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const Box lb = load_box(boxes, (n - 1) + j);
-    if (!box_overlap(lb, box)) return;
-    const unsigned long long k = atomicAdd(count, 1ull);
-    if (k >= cap) return;
-    const LeafTri lt = leaf[j];
-    const d3 A = load_vertex(verts, lt.v0), B = load_vertex(verts, lt.v1), C = load_vertex(verts, lt.v2);
-    ExtQuery q;
-    q.v[0] = A.x; q.v[1] = A.y; q.v[2] = A.z; q.v[3] = B.x; q.v[4] = B.y; q.v[5] = B.z; q.v[6] = C.x; q.v[7] = C.y; q.v[8] = C.z;
-    q.id = lt.id; q.vidx[0] = lt.v0 + vbase; q.vidx[1] = lt.v1 + vbase; q.vidx[2] = lt.v2 + vbase;
-    out[k] = q;
+    __shared__ uint32_t wcount[PACK_THREADS / 64];
+    __shared__ unsigned long long wg_base;
+    const int j = blockIdx.x * PACK_THREADS + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool live = j < n;
+    // the leaf's fp32 box (rounded outward) rules most leaves out without touching the 48-byte FP64 box
+    float lo0 = 0, lo1 = 0, lo2 = 0, hi0 = 0, hi1 = 0, hi2 = 0;
+    if (live) { const LeafBox32 lb = qbox32[j]; lo0 = lb.lo[0]; lo1 = lb.lo[1]; lo2 = lb.lo[2]; hi0 = lb.hi[0]; hi1 = lb.hi[1]; hi2 = lb.hi[2]; }
+    Box mine{0, 0, 0, 0, 0, 0}; bool have_box = false;
+    const Box me = my_root ? load_box(my_root, 0) : Box{0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < n_boxes; ++p) {                                       // (wave-uniform loop and skips)
+        if (p == skip) continue;
+        const Box rb = load_box(roots, p);
+        if (my_root && !box_overlap(me, rb)) continue;
+        // conservative: the exact strict overlap implies this one (monotone rounding, see DESIGN.md "fp32 boxes")
+        bool hit = live && lo0 < __double2float_ru(rb.x2) && __double2float_rd(rb.x1) < hi0 && lo1 < __double2float_ru(rb.y2) &&
+                   __double2float_rd(rb.y1) < hi1 && lo2 < __double2float_ru(rb.z2) && __double2float_rd(rb.z1) < hi2;
+        if (hit) {
+            if (!have_box) { mine = load_box(boxes, (n - 1) + j); have_box = true; }
+            hit = box_overlap(mine, rb);                                      // box.cuh:40-43, exact
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (lane == 0) wcount[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < PACK_THREADS / 64; ++k) { const uint32_t v = wcount[k]; before += (k < (int)w) ? v : 0u; total += v; }
+        if (total != 0u) {                                                    // (workgroup-uniform)
+            if (threadIdx.x == 0) wg_base = atomicAdd(&counts[p], (unsigned long long)total);
+            __syncthreads();
+            const unsigned long long k = wg_base + before + __popcll(m & ((1ull << lane) - 1ull));
+            if (hit && k < cap) {
+                const LeafTri lt = leaf[j];
+                const d3 A = load_vertex(verts, lt.v0), B = load_vertex(verts, lt.v1), C = load_vertex(verts, lt.v2);
+                ExtQuery q;
+                q.v[0] = A.x; q.v[1] = A.y; q.v[2] = A.z; q.v[3] = B.x; q.v[4] = B.y; q.v[5] = B.z; q.v[6] = C.x; q.v[7] = C.y; q.v[8] = C.z;
+                q.id = lt.id; q.vidx[0] = lt.v0 + vbase; q.vidx[1] = lt.v1 + vbase; q.vidx[2] = lt.v2 + vbase;
+                out[(size_t)p * cap + k] = q;
+            }
+        }
+        __syncthreads();                                                      // wcount / wg_base are reused by the next box
+    }
 }
 
 }  // namespace cd

@@ -30,6 +30,19 @@ enum Ev { EV_MORTON0, EV_MORTON1, EV_SORT1, EV_HIER0, EV_HIER1, EV_REFIT0, EV_RE
 
 }  // namespace
 
+// Everything one traversal pass writes: counters, candidates, pairs (+ the Report in front of them), deferred items.
+// The context has two sets: [0] for its own leaves as queries (and for every single-pass entry point), [1] for the
+// external queries of the multi-GPU step, so that both passes can be enqueued back to back and read with ONE host
+// synchronisation (cd_multi.h).
+struct TravBuf {
+    TravState *d_state = nullptr; bool state_owned = false;                // [0]: inside the context's scratch block (zeroed by the fused memset)
+    uint32_t *d_pairs = nullptr; uint64_t pairs_cap = 0;                   // d_pairs points sizeof(Report) bytes into its allocation: [Report][pairs]
+    char *h_report = nullptr;                                              // pinned: Report + SPEC_PAIRS pairs, target of the read-back
+    uint2 *d_defer = nullptr; uint32_t defer_cap = 0;
+    Candidates *d_cand = nullptr; uint64_t cand_cap = 0;
+    int32_t *d_deep = nullptr; uint64_t deep_items = 0;
+};
+
 struct cd_ctx {
     uint32_t nv = 0, nt = 0;
     int stage = ST_CREATED;
@@ -58,13 +71,8 @@ struct cd_ctx {
     bool internal_boxes_valid = false;      // the FP64 boxes of the internal nodes were written by the last refit (fused calls skip them)
     uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
     // traversal
-    TravState *d_state = nullptr;
+    TravBuf tb[2];
     int exact_blocks = 1024;
-    uint32_t *d_pairs = nullptr; uint64_t pairs_cap = 0;   // d_pairs points sizeof(Report) bytes into its allocation: [Report][pairs]
-    char *h_report = nullptr;               // pinned: Report + SPEC_PAIRS pairs, target of the single read-back copy
-    uint2 *d_defer = nullptr; uint32_t defer_cap = 0;
-    Candidates *d_cand = nullptr; uint64_t cand_cap = 0;    // variant C candidate buffer
-    int32_t *d_deep = nullptr; uint64_t deep_items = 0;
     // pair-list post-processing (cd_sorted_pairs / cd_collision_triangles): sort buffers sized on demand
     uint64_t *pp_keys[2] = {nullptr, nullptr}; uint32_t *pp_vals[2] = {nullptr, nullptr}; uint32_t *pp_flags = nullptr;
     void *pp_os = nullptr; size_t pp_os_bytes = 0; uint32_t pp_cap = 0;
@@ -91,9 +99,12 @@ void free_all(cd_ctx *c)
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_cross); hipFree(c->d_boxes);
     hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox);
-    if (c->d_pairs) hipFree(reinterpret_cast<char *>(c->d_pairs) - sizeof(Report));
-    if (c->h_report) hipHostFree(c->h_report);
-    hipFree(c->d_defer); hipFree(c->d_deep); hipFree(c->d_cand);
+    for (TravBuf &tb : c->tb) {
+        if (tb.d_pairs) hipFree(reinterpret_cast<char *>(tb.d_pairs) - sizeof(Report));
+        if (tb.h_report) hipHostFree(tb.h_report);
+        hipFree(tb.d_defer); hipFree(tb.d_deep); hipFree(tb.d_cand);
+        if (tb.state_owned) hipFree(tb.d_state);
+    }
     for (int i = 0; i < 2; ++i) { hipFree(c->pp_keys[i]); hipFree(c->pp_vals[i]); }
     hipFree(c->pp_flags); hipFree(c->pp_os);
     for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -104,15 +115,15 @@ inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b
 
 constexpr int BOUNDS_BLOCKS = 1024;
 
-int ensure_pairs(cd_ctx *c, uint64_t cap)
+int ensure_pairs(cd_ctx *c, TravBuf &tb, uint64_t cap)
 {
-    if (cap <= c->pairs_cap) return 0;
-    if (c->d_pairs) hipFree(reinterpret_cast<char *>(c->d_pairs) - sizeof(Report));
-    c->d_pairs = nullptr; c->pairs_cap = 0;
+    if (cap <= tb.pairs_cap) return 0;
+    if (tb.d_pairs) hipFree(reinterpret_cast<char *>(tb.d_pairs) - sizeof(Report));
+    tb.d_pairs = nullptr; tb.pairs_cap = 0;
     char *block = nullptr;
     HIPCHK(hipMalloc(&block, sizeof(Report) + sizeof(uint32_t) * 2 * cap + 16));      // +16: k_report moves pairs as 16-byte quads
-    c->d_pairs = reinterpret_cast<uint32_t *>(block + sizeof(Report));
-    c->pairs_cap = cap;
+    tb.d_pairs = reinterpret_cast<uint32_t *>(block + sizeof(Report));
+    tb.pairs_cap = cap;
     return 0;
 }
 
@@ -122,7 +133,7 @@ float elapsed(cd_ctx *c, int a, int b) { float ms = 0.f; hipEventElapsedTime(&ms
 // only the events the roofline needs are recorded: pipeline start, descent start / end, pipeline end.
 inline hipError_t evrec(cd_ctx *c, int idx)
 {
-    if (!c->stage_events && !(idx == EV_MORTON0 || idx == EV_TRAV0 || idx == EV_DESC1 || idx == EV_TRAV1)) return hipSuccess;
+    if (!c->stage_events && !(idx == EV_MORTON0 || idx == EV_TRAV0 || idx == EV_DESC1 || idx == EV_TRAV1 || idx == EV_DEEP0 || idx == EV_DEEP1)) return hipSuccess;
     return hipEventRecord(c->ev[idx], c->stream);
 }
 
@@ -220,26 +231,26 @@ int enqueue_refit(cd_ctx *c, bool write_internal)
 
 // Launch one traversal pass (shallow: all queries from the root; deep: the deferred (query, subtree) items).
 template <bool EXTERNAL, bool DEEP>
-void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pairs)
+void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, uint64_t cap_pairs)
 {
     const int n = (int)c->nt;
     hipStream_t s = c->stream;
     const uint32_t vb = EXTERNAL ? c->vbase : 0u;
     if (c->trav_variant == 2 && !DEEP) {
-        const uint64_t shard_cap = c->cand_cap / NSHARD;
-        k_descend_packet<EXTERNAL><<<cdiv(items, 64 * WQ_WAVES), TRAV_THREADS, c->dbg_lds_pad, s>>>(src, items, n, c->d_recs32, c->d_boxes, c->d_state, c->d_cand, shard_cap);
+        const uint64_t shard_cap = tb.cand_cap / NSHARD;
+        k_descend_packet<EXTERNAL><<<cdiv(items, 64 * WQ_WAVES), TRAV_THREADS, c->dbg_lds_pad, s>>>(src, items, n, c->d_recs32, c->d_boxes, tb.d_state, tb.d_cand, shard_cap);
         evrec(c, EV_DESC1);
-        k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, c->d_cand, shard_cap, c->d_pairs, cap_pairs, c->d_state, 0u);
+        k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, tb.d_cand, shard_cap, tb.d_pairs, cap_pairs, tb.d_state, 0u);
     } else if (c->trav_variant == 0) {
-        k_traverse<EXTERNAL, DEEP><<<cdiv(items, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, items, n, c->d_meta, c->d_boxes, c->d_leaf, c->d_verts, c->d_pairs, cap_pairs, c->d_state,
-                                                                                       DEEP ? nullptr : c->d_defer, DEEP ? 0u : c->defer_cap, DEEP ? c->d_deep : nullptr, vb);
+        k_traverse<EXTERNAL, DEEP><<<cdiv(items, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, items, n, c->d_meta, c->d_boxes, c->d_leaf, c->d_verts, tb.d_pairs, cap_pairs, tb.d_state,
+                                                                                       DEEP ? nullptr : tb.d_defer, DEEP ? 0u : tb.defer_cap, DEEP ? tb.d_deep : nullptr, vb);
     } else {
         // variant 3 (half traversal) applies to self-collision queries; external queries are not leaves of this tree
         // and take the full descent of variant 1.  The deep pass of a half traversal continues (query, subtree) items
         // with the full descent, but its candidates keep the half traversal's meaning (`half`).
         const bool half_mode = c->trav_variant == 3 && !EXTERNAL;
         const uint32_t qpw = (DEEP || c->trav_variant == 3) ? 64u : c->queries_per_wave;
-        const uint64_t shard_cap = c->cand_cap / NSHARD;
+        const uint64_t shard_cap = tb.cand_cap / NSHARD;
         const dim3 grid(cdiv(items, qpw * WQ_WAVES));
         const size_t pad = DEEP ? 0 : c->dbg_lds_pad;
         // Timing of the two kernels: with stage events on, hipEventRecord before / between / after (each record is a
@@ -248,21 +259,21 @@ void launch_pass(cd_ctx *c, const QuerySrc &src, uint32_t items, uint64_t cap_pa
         const bool ride = !DEEP && !c->stage_events;
         hipEvent_t e0 = ride ? c->ev[EV_TRAV0] : nullptr, e1 = ride ? c->ev[EV_DESC1] : nullptr, e2 = ride ? c->ev[EV_TRAV1] : nullptr;
         const uint32_t qarg = qpw | (c->dbg_no_shared_path ? 0x40000000u : 0u);
-        uint2 *dl = DEEP ? nullptr : c->d_defer; const uint32_t dcap = DEEP ? 0u : c->defer_cap; int32_t *deep = DEEP ? c->d_deep : nullptr;
+        uint2 *dl = DEEP ? nullptr : tb.d_defer; const uint32_t dcap = DEEP ? 0u : tb.defer_cap; int32_t *deep = DEEP ? tb.d_deep : nullptr;
         const uint32_t half = half_mode ? 1u : 0u;
         if (half_mode && !DEEP)
             hipExtLaunchKernelGGL(k_descend_half, grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
-                                  src, n, (const NodeRec32 *)c->d_recs32, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
+                                  src, n, (const NodeRec32 *)c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
         else if (qpw == 64)
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, false>), grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
-                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
+                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
         else
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, true>), grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
-                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, c->d_state, c->d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
+                                  src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
         if (!DEEP && !ride) evrec(c, EV_DESC1);
         hipExtLaunchKernelGGL((k_exact<EXTERNAL>), dim3(c->exact_blocks), dim3(EXACT_THREADS), 0u, s, nullptr, e2, 0u,
-                              src, n, (const LeafTri *)c->d_leaf, (const double *)c->d_boxes, (const double *)c->d_verts, vb, (const Candidates *)c->d_cand,
-                              (unsigned long long)shard_cap, c->d_pairs, (unsigned long long)cap_pairs, c->d_state, half);
+                              src, n, (const LeafTri *)c->d_leaf, (const double *)c->d_boxes, (const double *)c->d_verts, vb, (const Candidates *)tb.d_cand,
+                              (unsigned long long)shard_cap, tb.d_pairs, (unsigned long long)cap_pairs, tb.d_state, half);
         c->events_ride = ride;
     }
 }
@@ -272,43 +283,54 @@ struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_can
 constexpr uint64_t SPEC_PAIRS = 1u << 15;     // pairs copied back speculatively together with the counters (256 KB)
 
 // One host round trip and NO copy: k_report writes counters, the sort's time-out flags, the root box and the first
-// spec_n pairs straight into pinned host memory.
-int read_state(cd_ctx *c, HostCounters &h, uint32_t *spec_pairs = nullptr, uint64_t spec_n = 0)
+// spec_n pairs straight into pinned host memory.  enqueue_report queues the kernel; parse_report reads the record
+// after the caller has synchronised the stream (the multi-GPU step queues two passes and synchronises once).
+int enqueue_report(cd_ctx *c, TravBuf &tb, bool want_pairs, uint64_t &spec_n)
 {
-    if (!c->h_report) HIPCHK(hipHostMalloc(&c->h_report, sizeof(Report) + sizeof(uint32_t) * 2 * SPEC_PAIRS, hipHostMallocDefault));
-    if (!spec_pairs || spec_n > SPEC_PAIRS) spec_n = spec_pairs ? SPEC_PAIRS : 0;
+    if (!tb.h_report) HIPCHK(hipHostMalloc(&tb.h_report, sizeof(Report) + sizeof(uint32_t) * 2 * SPEC_PAIRS, hipHostMallocDefault));
+    if (!want_pairs) spec_n = 0; else if (spec_n > SPEC_PAIRS) spec_n = SPEC_PAIRS;
     // (the pair list is allocated with an even capacity + slack, so the quad copy may read one pair past `take`)
-    k_report<<<spec_n ? 32 : 1, REPORT_THREADS, 0, c->stream>>>(c->d_state, c->d_os_ticket + 8, c->d_boxes, reinterpret_cast<Report *>(c->h_report),
-                                                              c->d_pairs, reinterpret_cast<uint32_t *>(c->h_report + sizeof(Report)), (unsigned long long)spec_n);
-    HIPCHK(hipStreamSynchronize(c->stream));
-    const Report &r = *reinterpret_cast<const Report *>(c->h_report);
+    k_report<<<spec_n ? 32 : 1, REPORT_THREADS, 0, c->stream>>>(tb.d_state, c->d_os_ticket + 8, c->d_boxes, reinterpret_cast<Report *>(tb.h_report),
+                                                              tb.d_pairs, reinterpret_cast<uint32_t *>(tb.h_report + sizeof(Report)), (unsigned long long)spec_n);
+    return 0;
+}
+void parse_report(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs, uint64_t spec_n)
+{
+    const Report &r = *reinterpret_cast<const Report *>(tb.h_report);
     h = HostCounters{r.n_pairs, r.pairs_tested, r.node_visits, r.max_shard_candidates, r.n_deferred, r.wave_steps, r.candidates};
     std::memcpy(c->sort_flags, r.sort_flags, sizeof c->sort_flags);
     std::memcpy(c->root_box_host, r.root_box, sizeof(double) * 6);
-    if (spec_n) {
+    if (spec_n && spec_pairs) {
         const uint64_t take = r.n_pairs < spec_n ? r.n_pairs : spec_n;
-        std::memcpy(spec_pairs, c->h_report + sizeof(Report), sizeof(uint32_t) * 2 * take);
+        std::memcpy(spec_pairs, tb.h_report + sizeof(Report), sizeof(uint32_t) * 2 * take);
     }
+}
+int read_state(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs = nullptr, uint64_t spec_n = 0)
+{
+    int rc = enqueue_report(c, tb, spec_pairs != nullptr, spec_n);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    parse_report(c, tb, h, spec_pairs, spec_n);
     return 0;
 }
 
-int grow_candidates(cd_ctx *c, uint64_t max_shard)
+int grow_candidates(cd_ctx *c, TravBuf &tb, uint64_t max_shard)
 {
-    hipFree(c->d_cand); c->d_cand = nullptr; c->cand_cap = 0;
+    hipFree(tb.d_cand); tb.d_cand = nullptr; tb.cand_cap = 0;
     const uint64_t want = (max_shard + max_shard / 4 + 1024) * NSHARD;
-    HIPCHK(hipMalloc(&c->d_cand, sizeof(Candidates) * want));
-    c->cand_cap = want;
+    HIPCHK(hipMalloc(&tb.d_cand, sizeof(Candidates) * want));
+    tb.cand_cap = want;
     return 0;
 }
 
 // Traversal (local leaves or external queries).  Blocks: reads the counters, runs the deep pass when needed.
-int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs)
+int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs)
 {
     const uint32_t n = c->nt;
     hipStream_t s = c->stream;
     const bool external = d_ext != nullptr;
     const uint32_t nq = external ? (uint32_t)nq_ext : n;
-    int rc = ensure_pairs(c, cap_pairs > 0 ? cap_pairs : 1);
+    int rc = ensure_pairs(c, tb, cap_pairs > 0 ? cap_pairs : 1);
     if (rc) return rc;
     const int per_pass = c->trav_variant == 0 ? 1 : 2;
     if (c->trav_variant == 0 && !c->internal_boxes_valid) {                // variant 0 walks the FP64 boxes of the internal nodes
@@ -326,44 +348,44 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
         const bool will_ride = !c->stage_events && (c->trav_variant == 1 || c->trav_variant == 3) && nq > 0;   // see launch_pass: events on the dispatch packets
         c->events_ride = false;
         if (!will_ride) HIPCHK(evrec(c, EV_TRAV0));
-        if (!(c->prezeroed && attempt == 0)) HIPCHK(hipMemsetAsync(c->d_state, 0, sizeof(TravState), s));
+        if (!(c->prezeroed && attempt == 0 && &tb == &c->tb[0])) HIPCHK(hipMemsetAsync(tb.d_state, 0, sizeof(TravState), s));
         if (nq > 0) {
-            if (external) launch_pass<true, false>(c, src, nq, cap_pairs); else launch_pass<false, false>(c, src, nq, cap_pairs);
+            if (external) launch_pass<true, false>(c, tb, src, nq, cap_pairs); else launch_pass<false, false>(c, tb, src, nq, cap_pairs);
             launches += per_pass;
         }
         if (!c->events_ride) HIPCHK(evrec(c, EV_TRAV1));      // device time of the kernels only: recorded before the read-back
         const uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
-        if ((rc = read_state(c, h, pairs, spec_n))) return rc;
+        if ((rc = read_state(c, tb, h, pairs, spec_n))) return rc;
         spec_valid = spec_n;
-        if (h.max_shard_candidates > c->cand_cap / NSHARD) { if ((rc = grow_candidates(c, h.max_shard_candidates))) return rc; continue; }
-        if (h.n_deferred > c->defer_cap) {               // the deferred list was too small: grow it and redo (pairs restart at 0)
-            hipFree(c->d_defer); c->d_defer = nullptr; c->defer_cap = 0;
-            HIPCHK(hipMalloc(&c->d_defer, sizeof(uint2) * (size_t)h.n_deferred));
-            c->defer_cap = h.n_deferred;
+        if (h.max_shard_candidates > tb.cand_cap / NSHARD) { if ((rc = grow_candidates(c, tb, h.max_shard_candidates))) return rc; continue; }
+        if (h.n_deferred > tb.defer_cap) {               // the deferred list was too small: grow it and redo (pairs restart at 0)
+            hipFree(tb.d_defer); tb.d_defer = nullptr; tb.defer_cap = 0;
+            HIPCHK(hipMalloc(&tb.d_defer, sizeof(uint2) * (size_t)h.n_deferred));
+            tb.defer_cap = h.n_deferred;
             continue;
         }
         if (h.n_deferred > 0) {                          // deep pass over the deferred (query, subtree) items
             const uint32_t nd = h.n_deferred;
             const uint64_t deep_lanes = (uint64_t)cdiv(nd, 64) * 64 + 256;
-            if (deep_lanes > c->deep_items) {
-                hipFree(c->d_deep); c->d_deep = nullptr; c->deep_items = 0;
-                HIPCHK(hipMalloc(&c->d_deep, sizeof(int32_t) * (size_t)DEEP_STACK * deep_lanes));
-                c->deep_items = deep_lanes;
+            if (deep_lanes > tb.deep_items) {
+                hipFree(tb.d_deep); tb.d_deep = nullptr; tb.deep_items = 0;
+                HIPCHK(hipMalloc(&tb.d_deep, sizeof(int32_t) * (size_t)DEEP_STACK * deep_lanes));
+                tb.deep_items = deep_lanes;
             }
             HIPCHK(evrec(c, EV_DEEP0));
-            HIPCHK(hipMemsetAsync(&c->d_state->n_deferred, 0, sizeof(uint32_t), s));
+            HIPCHK(hipMemsetAsync(&tb.d_state->n_deferred, 0, sizeof(uint32_t), s));
             // candidate shards restart from 0: the shallow pass's candidates have all been consumed by k_exact
             for (int i = 0; i < NSHARD; ++i) { /* one memset per shard would be 64 calls: clear them with a 2-D memset */ }
-            HIPCHK(hipMemset2DAsync(&c->d_state->shard[0].n_candidates, sizeof(CtrShard), 0, sizeof(unsigned long long), NSHARD, s));
-            src.list = c->d_defer;
-            if (external) launch_pass<true, true>(c, src, nd, cap_pairs); else launch_pass<false, true>(c, src, nd, cap_pairs);
+            HIPCHK(hipMemset2DAsync(&tb.d_state->shard[0].n_candidates, sizeof(CtrShard), 0, sizeof(unsigned long long), NSHARD, s));
+            src.list = tb.d_defer;
+            if (external) launch_pass<true, true>(c, tb, src, nd, cap_pairs); else launch_pass<false, true>(c, tb, src, nd, cap_pairs);
             launches += per_pass;
             HIPCHK(evrec(c, EV_DEEP1));
-            if ((rc = read_state(c, h))) return rc;
+            if ((rc = read_state(c, tb, h))) return rc;
             if (h.n_deferred != 0) return CD_ERR_ARG;    // tree deeper than DEEP_STACK: cannot happen (height <= 96)
-            if (h.max_shard_candidates > c->cand_cap / NSHARD) { if ((rc = grow_candidates(c, h.max_shard_candidates))) return rc; continue; }
+            if (h.max_shard_candidates > tb.cand_cap / NSHARD) { if ((rc = grow_candidates(c, tb, h.max_shard_candidates))) return rc; continue; }
             c->stats.stack_overflows = nd;
-            if (c->stage_events) deep_ms = elapsed(c, EV_DEEP0, EV_DEEP1);
+            deep_ms = elapsed(c, EV_DEEP0, EV_DEEP1);            // (always recorded: a deep pass is device time of this traversal)
         }
         done = true;
     }
@@ -374,10 +396,10 @@ int run_traversal(cd_ctx *c, const void *d_ext, uint64_t nq_ext, uint32_t *pairs
     // the first spec_valid pairs came back with the counters -- unless a deep pass appended more afterwards
     const uint64_t have = (c->stats.stack_overflows == 0) ? spec_valid : 0;
     if (pairs && ncopy > have) {
-        HIPCHK(hipMemcpyAsync(pairs + 2 * have, c->d_pairs + 2 * have, sizeof(uint32_t) * 2 * (ncopy - have), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(pairs + 2 * have, tb.d_pairs + 2 * have, sizeof(uint32_t) * 2 * (ncopy - have), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     }
-    c->stats.ms_traverse = elapsed(c, EV_TRAV0, EV_TRAV1) + (c->stage_events ? deep_ms : 0.f);
+    c->stats.ms_traverse = elapsed(c, EV_TRAV0, EV_TRAV1) + deep_ms;
     c->stats.ms_descend = (c->trav_variant != 0 && nq > 0) ? elapsed(c, EV_TRAV0, EV_DESC1) : 0.f;
     c->stats.ms_exact = (c->trav_variant != 0 && nq > 0) ? elapsed(c, EV_DESC1, EV_TRAV1) : 0.f;
     c->stats.traverse_launches = launches;
@@ -459,7 +481,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     c->zero_bytes = state_off + sizeof(TravState);
     ALLOC(c->d_os, c->zero_bytes);
     c->d_small = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(c->d_os) + small_off);
-    c->d_state = reinterpret_cast<TravState *>(reinterpret_cast<char *>(c->d_os) + state_off);
+    c->tb[0].d_state = reinterpret_cast<TravState *>(reinterpret_cast<char *>(c->d_os) + state_off);
     c->d_root = reinterpret_cast<int32_t *>(c->d_small + 96);
     c->d_os_hist = reinterpret_cast<uint32_t *>(c->d_os);
     c->d_os_ticket = c->d_os_hist + 8 * RADIX;
@@ -478,10 +500,10 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_bounded, sizeof(uint32_t) * n);
     ALLOC(c->d_recs32, sizeof(NodeRec32) * n);
     ALLOC(c->d_qbox, sizeof(LeafBox32) * n);
-    c->cand_cap = ((4 * n > (1u << 20) ? 4 * n : (1u << 20)) + NSHARD - 1) / NSHARD * NSHARD;
-    ALLOC(c->d_cand, sizeof(Candidates) * c->cand_cap);
-    c->defer_cap = 1u << 16;
-    ALLOC(c->d_defer, sizeof(uint2) * c->defer_cap);
+    c->tb[0].cand_cap = ((4 * n > (1u << 20) ? 4 * n : (1u << 20)) + NSHARD - 1) / NSHARD * NSHARD;
+    ALLOC(c->tb[0].d_cand, sizeof(Candidates) * c->tb[0].cand_cap);
+    c->tb[0].defer_cap = 1u << 16;
+    ALLOC(c->tb[0].d_defer, sizeof(uint2) * c->tb[0].defer_cap);
 #undef ALLOC
     // main.cu:86-88 H2D
     bool ok = hipMemcpy(c->d_verts, verts_xyz, sizeof(double) * 3 * (size_t)nv, hipMemcpyHostToDevice) == hipSuccess &&
@@ -621,7 +643,7 @@ int cd_find_collisions(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t 
 {
     if (!c || (cap_pairs && !pairs)) return CD_ERR_ARG;
     if (c->stage < ST_REFIT) return CD_ERR_ORDER;
-    return run_traversal(c, nullptr, 0, pairs, cap_pairs, n_pairs);
+    return run_traversal(c, c->tb[0], nullptr, 0, pairs, cap_pairs, n_pairs);
 }
 
 int cd_build_tree(cd_ctx *c)
@@ -658,7 +680,7 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     rc = enqueue_morton_sort(c);
     if (!rc) rc = enqueue_hierarchy(c, false);
     if (!rc) rc = enqueue_refit(c, c->trav_variant == 0);
-    if (!rc) rc = run_traversal(c, nullptr, 0, pairs, cap_pairs, n_pairs);     // synchronises
+    if (!rc) rc = run_traversal(c, c->tb[0], nullptr, 0, pairs, cap_pairs, n_pairs);     // synchronises
     fused.done();
     if (rc < 0) return rc;
     { const int rs = judge_sort_flags(c);                                   // flags came back with the traversal counters
@@ -679,16 +701,16 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
 int cd_brute_force(cd_ctx *c, int box_filter, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs)
 {
     if (!c || (cap_pairs && !pairs)) return CD_ERR_ARG;
-    int rc = ensure_pairs(c, cap_pairs > 0 ? cap_pairs : 1);
+    int rc = ensure_pairs(c, c->tb[0], cap_pairs > 0 ? cap_pairs : 1);
     if (rc) return rc;
     hipStream_t s = c->stream;
-    HIPCHK(hipMemsetAsync(c->d_state, 0, sizeof(TravState), s));
-    k_brute_force<<<cdiv(c->nt, 256), 256, 0, s>>>(c->d_verts, c->d_vidx, c->d_ids, c->nt, box_filter, c->d_pairs, cap_pairs, c->d_state);
+    HIPCHK(hipMemsetAsync(c->tb[0].d_state, 0, sizeof(TravState), s));
+    k_brute_force<<<cdiv(c->nt, 256), 256, 0, s>>>(c->d_verts, c->d_vidx, c->d_ids, c->nt, box_filter, c->tb[0].d_pairs, cap_pairs, c->tb[0].d_state);
     HostCounters h;
-    { int r = read_state(c, h); if (r) return r; }
+    { int r = read_state(c, c->tb[0], h); if (r) return r; }
     HIPCHK(hipGetLastError());
     const uint64_t ncopy = h.n_pairs < cap_pairs ? h.n_pairs : cap_pairs;
-    if (pairs && ncopy) HIPCHK(hipMemcpy(pairs, c->d_pairs, sizeof(uint32_t) * 2 * ncopy, hipMemcpyDeviceToHost));
+    if (pairs && ncopy) HIPCHK(hipMemcpy(pairs, c->tb[0].d_pairs, sizeof(uint32_t) * 2 * ncopy, hipMemcpyDeviceToHost));
     if (n_pairs) *n_pairs = h.n_pairs;
     return h.n_pairs > cap_pairs ? CD_OVERFLOW : CD_OK;
 }
@@ -722,7 +744,7 @@ int cd_sorted_pairs(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     int rc = pp_reserve(c, m);
     if (rc) return rc;
     hipStream_t s = c->stream;
-    k_pairs_to_keys<<<cdiv(m, 256), 256, 0, s>>>(c->d_pairs, m, c->pp_keys[0]);
+    k_pairs_to_keys<<<cdiv(m, 256), 256, 0, s>>>(c->tb[0].d_pairs, m, c->pp_keys[0]);
     if ((rc = pp_sort(c, m))) return rc;
     k_keys_to_pairs<<<cdiv(m, 256), 256, 0, s>>>(c->pp_keys[0], m, reinterpret_cast<uint32_t *>(c->pp_keys[1]));
     const uint64_t ncopy = m < cap_pairs ? m : cap_pairs;
@@ -748,7 +770,7 @@ int cd_collision_triangles(cd_ctx *c, uint32_t *ids, uint64_t cap, uint64_t *n)
     int rc = pp_reserve(c, m2);
     if (rc) return rc;
     hipStream_t s = c->stream;
-    k_ids_to_keys<<<cdiv(m2, 256), 256, 0, s>>>(c->d_pairs, m2, c->pp_keys[0]);
+    k_ids_to_keys<<<cdiv(m2, 256), 256, 0, s>>>(c->tb[0].d_pairs, m2, c->pp_keys[0]);
     if ((rc = pp_sort(c, m2))) return rc;
     k_unique_flags<<<cdiv(m2, 256), 256, 0, s>>>(c->pp_keys[0], m2, c->pp_flags);
     k_scan_exclusive<<<1, 1024, 0, s>>>(c->pp_flags, m2);
@@ -798,7 +820,7 @@ int cd_debug_counters(cd_ctx *c, unsigned long long out[12])
 {
     if (!c || !out) return CD_ERR_ARG;
     std::vector<TravState> h(1);
-    HIPCHK(hipMemcpy(h.data(), c->d_state, sizeof(TravState), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h.data(), c->tb[0].d_state, sizeof(TravState), hipMemcpyDeviceToHost));
     for (int k = 0; k < 12; ++k) { out[k] = 0; for (int i = 0; i < NSHARD; ++i) out[k] += h[0].shard[i].pad[k]; }
     return CD_OK;
 }
@@ -837,11 +859,14 @@ int cd_pack_queries(cd_ctx *c, const double box[6], void *d_out, uint64_t cap, u
     if (!c || !box || !n || (cap && !d_out)) return CD_ERR_ARG;
     if (c->stage < ST_REFIT) return CD_ERR_ORDER;
     hipStream_t s = c->stream;
-    unsigned long long *d_cnt = &c->d_state->n_pairs;
-    HIPCHK(hipMemsetAsync(c->d_state, 0, sizeof(TravState), s));
-    Box b{box[0], box[1], box[2], box[3], box[4], box[5]};
-    k_pack_queries<<<cdiv(c->nt, 256), 256, 0, s>>>(c->d_verts, c->d_leaf, c->d_boxes, (int)c->nt, b,
-                                                     reinterpret_cast<ExtQuery *>(d_out), cap, d_cnt, c->vbase);
+    // the box and the counter live in the context's small scratch words (d_small[104..117]), not in the traversal state:
+    // packing does not disturb the statistics of the traversal before it
+    double *d_box = reinterpret_cast<double *>(c->d_small + 104);
+    unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(c->d_small + 116);
+    HIPCHK(hipMemcpyAsync(d_box, box, sizeof(double) * 6, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
+    k_pack_queries<<<cdiv(c->nt, PACK_THREADS), PACK_THREADS, 0, s>>>(c->d_verts, c->d_leaf, c->d_boxes, c->d_qbox, (int)c->nt, d_box, 1, -1, nullptr,
+                                                                       reinterpret_cast<ExtQuery *>(d_out), cap, d_cnt, c->vbase);
     unsigned long long h = 0;
     HIPCHK(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -855,7 +880,9 @@ int cd_find_collisions_queries(cd_ctx *c, const void *d_queries, uint64_t nq, ui
     if (!c || (cap_pairs && !pairs) || (nq && !d_queries) || nq > 0xffffffffull) return CD_ERR_ARG;
     if (c->stage < ST_REFIT) return CD_ERR_ORDER;
     if (nq == 0) { if (n_pairs) *n_pairs = 0; return CD_OK; }
-    return run_traversal(c, d_queries, nq, pairs, cap_pairs, n_pairs);
+    return run_traversal(c, c->tb[0], d_queries, nq, pairs, cap_pairs, n_pairs);
 }
 
 }  // extern "C"
+
+#include "cd_multi.h"

@@ -33,12 +33,25 @@ class CdStats(C.Structure):
 
 
 # every symbol include/mi355cd.h declares (tests check the library exports exactly these)
+CD_MULTI_SELF_PEER, CD_MULTI_TIMING = 1, 2
+CD_ERR_RCCL = -1008
+
+
+class CdMultiInfo(C.Structure):
+    _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("n_peers", C.c_uint32), ("host_syncs", C.c_uint32), ("attempts", C.c_uint32),
+                ("pad0", C.c_uint32), ("sent_queries", C.c_uint64), ("recv_queries", C.c_uint64), ("local_pairs", C.c_uint64),
+                ("cross_pairs", C.c_uint64), ("pairs_tested", C.c_uint64), ("query_cap", C.c_uint64),
+                ("ms_tree", C.c_float), ("ms_allgather", C.c_float), ("ms_pack", C.c_float), ("ms_counts", C.c_float),
+                ("ms_exchange", C.c_float), ("ms_local", C.c_float), ("ms_cross", C.c_float), ("pad1", C.c_float)]
+
+
 EXPORTS = [
     "cd_load_obj", "cd_free_obj", "cd_create", "cd_destroy", "cd_update_vertices", "cd_set_morton_frame", "cd_morton_sort",
     "cd_build_hierarchy", "cd_refit_boxes", "cd_check_internal", "cd_check_leaves",
     "cd_check_triangle_idx", "cd_find_collisions", "cd_build_tree", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
     "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_debug_counters", "cd_num_triangles",
     "cd_set_option", "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
+    "cd_multi_unique_id", "cd_multi_create", "cd_multi_create_from_comm", "cd_multi_destroy", "cd_multi_step",
 ]
 
 _lib = None
@@ -46,6 +59,14 @@ _lib = None
 
 def load_library(path: str = LIB_PATH) -> C.CDLL:
     global _lib
+    if _lib is None:
+        # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 (same sonames as /opt/rocm's).  Two HIP
+        # runtimes in one process do not work -- the second one finds no GPU -- so when torch is installed its copy is
+        # loaded first and serves this library too.  (Plumbing only: nothing here computes with torch.)
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if _lib is not None:
         return _lib
     path = os.environ.get("MI355CD_LIB", path)          # A/B runs of two builds (tools/)
@@ -85,8 +106,14 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_pack_queries.argtypes = [vp, vp, vp, C.c_uint64, u64p]
     lib.cd_find_collisions_queries.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]
     lib.cd_version.restype = C.c_char_p
+    lib.cd_multi_unique_id.argtypes = [vp]
+    lib.cd_multi_create.argtypes = [C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_uint64, C.c_int]
+    lib.cd_multi_create_from_comm.argtypes = [C.POINTER(vp), vp, vp, C.c_uint64, C.c_int]
+    lib.cd_multi_destroy.argtypes = [vp]
+    lib.cd_multi_destroy.restype = None
+    lib.cd_multi_step.argtypes = [vp, vp, C.c_uint64, u64p, C.POINTER(CdMultiInfo)]
     for name in EXPORTS:
-        if name not in ("cd_destroy", "cd_version", "cd_free_obj"):
+        if name not in ("cd_destroy", "cd_version", "cd_free_obj", "cd_multi_destroy"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -291,3 +318,47 @@ def load_obj(path: str, threads: int = 0):
 
 def version() -> str:
     return load_library().cd_version().decode()
+
+
+def multi_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (128 bytes): made on one rank, handed to all."""
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    rc = lib.cd_multi_unique_id(buf)
+    if rc != CD_OK:
+        raise CdError("cd_multi_unique_id", rc)
+    return buf.raw
+
+
+class MultiStep:
+    """The multi-GPU step of libmi355cd.so (cd_multi_*): RCCL collectives issued by the C++ side, one process per GPU."""
+
+    def __init__(self, cd: "CollisionDetector", unique_id: bytes, rank: int, world: int, query_cap_per_peer: int = 0, flags: int = 0):
+        self.lib = cd.lib
+        self.cd = cd
+        self._m = C.c_void_p()
+        rc = self.lib.cd_multi_create(C.byref(self._m), cd._ctx, C.c_char_p(unique_id), rank, world, query_cap_per_peer, flags)
+        if rc != CD_OK:
+            raise CdError("cd_multi_create", rc)
+        self._pairs = None
+
+    def step(self, cap: int = 1 << 22):
+        if self._pairs is None or self._pairs.shape[0] < cap:
+            self._pairs = np.empty((cap, 2), dtype=np.uint32)
+        n = C.c_uint64(0)
+        info = CdMultiInfo()
+        rc = self.lib.cd_multi_step(self._m, self._pairs.ctypes.data, cap, C.byref(n), C.byref(info))
+        if rc < 0:
+            raise CdError("cd_multi_step", rc)
+        return self._pairs[: min(n.value, cap)], int(n.value), rc, info
+
+    def close(self):
+        if self._m:
+            self.lib.cd_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

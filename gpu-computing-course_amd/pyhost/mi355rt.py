@@ -32,6 +32,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    try:                                                 # one HIP runtime per process: torch's bundled copy first (see mi355cd.load_library)
+        import torch  # noqa: F401
+    except Exception:
+        pass
     path = os.environ.get("MI355RT_LIB", path)          # A/B runs of two builds (tools/)
     if not os.path.exists(path):
         raise RuntimeError(f"{path} not built: run __graft_entry__.build() (there is no CPU fallback)")

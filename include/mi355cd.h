@@ -37,7 +37,8 @@ enum {
     CD_ERR_INDEX     = -1004,  /* a vertex index >= nv (checked at cd_create)                       */
     CD_ERR_SORT      = -1005,  /* a bounded device-side wait in the sort timed out (results invalid) */
     CD_ERR_IO        = -1006,  /* file cannot be opened / read                                      */
-    CD_ERR_FORMAT    = -1007   /* a `v` / `f` line is not in the reference's dialect, or no geometry */
+    CD_ERR_FORMAT    = -1007,  /* a `v` / `f` line is not in the reference's dialect, or no geometry */
+    CD_ERR_RCCL      = -1008   /* librccl could not be loaded, or an RCCL call failed (cd_multi_*)   */
 };
 
 /* Morton normalisation frame (morton.h:43-58 hard-codes one data set's bounds). */
@@ -194,6 +195,41 @@ int cd_pack_queries(cd_ctx *ctx, const double box[6], void *d_out, uint64_t cap,
  * the exact test passes.  Output as cd_find_collisions. */
 int cd_find_collisions_queries(cd_ctx *ctx, const void *d_queries, uint64_t nq,
                                uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs);
+
+/* ---- the multi-GPU step in C/C++ behind the ABI (the harness it slots into is main.cu:47-174) ----
+ * One process per GPU, one cd_ctx per process holding that rank's object(s) with GLOBAL triangle IDs and a vertex-id
+ * base (cd_set_vertex_id_base).  A step = local LBVH -> ncclAllGather of the root AABBs -> one pack launch for all
+ * overlapping peers -> ncclAllGather of the per-peer counts -> grouped ncclSend / ncclRecv of the records (beside the
+ * local traversal) -> local pairs + pairs of the received queries against the local tree.  Every decision that makes
+ * a rank repeat or leave the step (slab capacity, a sort that must be redone or has failed) is taken from data all
+ * ranks hold, so no rank is left waiting in a collective.  RCCL is loaded at run time (dlopen "librccl.so"). */
+typedef struct cd_multi cd_multi;
+enum {
+    CD_MULTI_SELF_PEER = 1,    /* test mode: a rank also exchanges with ITSELF (ncclSend / ncclRecv to its own rank), so a    */
+                               /* 1-rank communicator exercises every phase; the cross pass then reports the local pairs again */
+    CD_MULTI_TIMING    = 2     /* record HIP events at the phase boundaries (cd_multi_info.ms_*); costs a few idle us each     */
+};
+typedef struct cd_multi_info {
+    uint32_t world, rank;          /* as the communicator reports them                                        */
+    uint32_t n_peers;              /* ranks this rank sent to or received from                                */
+    uint32_t host_syncs;           /* host synchronisations of the step (2 unless a pass had to be redone)    */
+    uint32_t attempts;             /* 1 + collective repeats (slabs grown, sort redone)                       */
+    uint32_t pad0;
+    uint64_t sent_queries, recv_queries, local_pairs, cross_pairs, pairs_tested, query_cap;
+    float ms_tree, ms_allgather, ms_pack, ms_counts, ms_exchange, ms_local, ms_cross;   /* CD_MULTI_TIMING; -1 = not measured */
+    float pad1;
+} cd_multi_info;
+/* ncclGetUniqueId: 128 bytes, produced on one rank and handed to all (by whatever the launcher has: MPI, a file, ...). */
+int cd_multi_unique_id(void *id128);
+/* ncclCommInitRank(world, id, rank) on the current HIP device + the step's buffers.  query_cap_per_peer: records per
+ * peer slab (0 = nt / 8 + 1024); it must be the SAME on every rank -- it grows collectively when a step needs more. */
+int cd_multi_create(cd_multi **out, cd_ctx *ctx, const void *id128, int rank, int world, uint64_t query_cap_per_peer, int flags);
+/* The same over a communicator the caller owns (an opaque ncclComm_t); it is not destroyed by cd_multi_destroy. */
+int cd_multi_create_from_comm(cd_multi **out, cd_ctx *ctx, void *nccl_comm, uint64_t query_cap_per_peer, int flags);
+void cd_multi_destroy(cd_multi *m);
+/* One step.  pairs: local pairs first, then the cross pairs this rank owns (output format of cd_find_collisions);
+ * returns CD_OVERFLOW when they do not fit cap_pairs (*n_pairs holds the true count).  info may be NULL. */
+int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs, cd_multi_info *info);
 
 /* Library / build identification: "mi355cd <version> gfx950". */
 const char *cd_version(void);

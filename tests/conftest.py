@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:                      # PyTorch-ROCm wheels bundle their own HIP runtime; a process must not end up with two of them (the
+    import torch  # noqa: F401   second one finds no GPU), so torch's is loaded before libmi355cd.so pulls in /opt/rocm's
+except Exception:         # (tests that need torch skip or fail on their own)
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "gpu-computing-course_amd")
 for p in (ROOT, os.path.join(PKG, "pyhost"), os.path.dirname(os.path.abspath(__file__))):

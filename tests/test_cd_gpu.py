@@ -315,6 +315,11 @@ def test_gpu_brute_force_agrees_with_traversal():
     assert tn == bn == ln > 0
     assert np.array_equal(oracle.pair_set(tp), oracle.pair_set(bp))
     assert np.array_equal(oracle.pair_set(tp), oracle.pair_set(lp))
+    # the GPU all-pairs pass against the oracle's own all-pairs loop (check.cuh:117-141 restated), not only via the tree
+    op, on, otested = oracle.brute_force(verts, vidx, box_filter=True)
+    assert on == bn and np.array_equal(oracle.pair_set(bp), oracle.pair_set(op))
+    op2, on2, _ = oracle.brute_force(verts, vidx, box_filter=False)
+    assert on2 == ln and np.array_equal(oracle.pair_set(lp), oracle.pair_set(op2))
 
 
 def test_golden_pair_sets():
@@ -398,6 +403,82 @@ def test_cross_rank_pass_two_contexts_one_gpu(variant):
     assert sent > 0 and len(gs) > 0
     for e in engines:
         e.close()
+
+
+def test_config4_topology_eight_shards_on_one_gpu():
+    """BASELINE config 4's topology on the one GPU there is: EIGHT object shards (40-quad cloth pairs, neighbours
+    overlapping by 10 % along x) in eight contexts -- the middle shards have TWO peers -- root boxes exchanged by hand
+    as the all-gather would, every shard packs for every overlapping peer, every peer traverses what it receives.
+    Union of local + cross pairs == the single-tree oracle on the merged mesh, no duplicates; every cross pair is
+    reported by exactly one side (tri_contact.cuh:81 on external queries)."""
+    import torch
+    import mi355_multi as multi
+    dev = torch.device("cuda", 0)
+    W = 8
+    shards = [synth.cloth_shard(r, 40, overlap=0.10) for r in range(W)]
+    engines = [multi.HipEngine(v, t, i, dev, vertex_id_base=vb) for (v, t, i, vb) in shards]
+    got, roots, tested = [], [], 0
+    for e in engines:
+        pairs, n, t = e.self_collide(1 << 20)
+        got.append(pairs); roots.append(e.root_box()); tested += t
+    peers = {r: [s for s in range(W) if s != r and multi.boxes_overlap(roots[r], roots[s])] for r in range(W)}
+    assert peers[0] == [1] and peers[7] == [6] and all(peers[r] == [r - 1, r + 1] for r in range(1, 7))
+    cross_total = 0
+    for me in range(W):
+        for peer in peers[me]:
+            q = engines[me].pack_queries(roots[peer])               # my leaves overlapping the peer's root
+            assert q.numel() > 0
+            cross, n, t = engines[peer].find_collisions_queries(q, 1 << 20)
+            got.append(cross); cross_total += n; tested += t
+    got = np.concatenate(got, axis=0)
+    verts = np.concatenate([s[0] for s in shards]); vidx = np.concatenate([s[1] + np.uint32(s[3]) for s in shards])
+    ids = np.concatenate([s[2] for s in shards])
+    cen = (verts[vidx[:, 0]] + verts[vidx[:, 1]] + verts[vidx[:, 2]]) / 3
+    ref = oracle.pipeline(verts, vidx, ids, off=cen.min(0), span=(cen.max(0) - cen.min(0)) * (1 + 2.0 ** -20))
+    gs = oracle.pair_set(got)
+    assert len(gs) == len(np.unique(gs))
+    assert np.array_equal(gs, oracle.pair_set(ref["pairs"]))
+    assert cross_total > 0
+    # a (query, leaf) AABB hit across ranks is met from both sides, like inside one tree: the sharded count is the single tree's
+    assert tested == ref["stats"].pairs_tested
+    for e in engines:
+        e.close()
+
+
+def test_multi_step_c_abi_one_rank_self_peer():
+    """cd_multi_* (the multi-GPU step in C++ over RCCL) on a ONE-rank communicator in CD_MULTI_SELF_PEER mode: the rank
+    all-gathers its root, packs its own leaves for itself, exchanges counts and records with itself through
+    ncclSend / ncclRecv and traverses them as external queries -- every phase of the step runs.  The cross pass must
+    report exactly the local pair set again (q.id < leaf.id, no shared vertex, same SAT) and meet exactly as many
+    overlapping (query, leaf) boxes as the local pass (each query meets its own leaf too)."""
+    verts, vidx = synth.cloth_pair(60)
+    ids = (np.arange(vidx.shape[0], dtype=np.uint32)[::-1] * 2 + 5).astype(np.uint32)
+    r = oracle.pipeline(verts, vidx, ids)
+    with mi355cd.CollisionDetector(verts, vidx, ids) as cd:
+        uid = mi355cd.multi_unique_id()
+        assert len(uid) == 128
+        with mi355cd.MultiStep(cd, uid, 0, 1, query_cap_per_peer=64, flags=mi355cd.CD_MULTI_SELF_PEER | mi355cd.CD_MULTI_TIMING) as ms:
+            for it in range(3):                                      # the first step grows the (deliberately tiny) slabs collectively
+                pairs, n, rc, info = ms.step(cap=1 << 20)
+                assert rc == 0
+                nl = r["stats"].n_pairs
+                assert info.world == 1 and info.rank == 0 and info.n_peers == 1
+                assert info.local_pairs == nl and info.cross_pairs == nl and n == 2 * nl
+                assert info.sent_queries == info.recv_queries == vidx.shape[0]
+                assert np.array_equal(oracle.pair_set(pairs[:nl]), oracle.pair_set(r["pairs"]))
+                assert np.array_equal(oracle.pair_set(pairs[nl:]), oracle.pair_set(r["pairs"]))
+                assert info.pairs_tested == 2 * r["stats"].pairs_tested
+                assert info.attempts == (2 if it == 0 else 1) and info.query_cap >= vidx.shape[0]
+                assert info.host_syncs == (3 if it == 0 else 2)
+                assert info.ms_tree > 0 and info.ms_pack > 0 and info.ms_exchange >= 0 and info.ms_local > 0 and info.ms_cross > 0
+        # without the self peer a one-rank step is the plain self-collision
+        with mi355cd.MultiStep(cd, mi355cd.multi_unique_id(), 0, 1) as ms:
+            pairs, n, rc, info = ms.step(cap=1 << 20)
+            assert rc == 0 and n == r["stats"].n_pairs and info.cross_pairs == 0 and info.n_peers == 0 and info.host_syncs == 2
+            assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])) and info.pairs_tested == r["stats"].pairs_tested
+        # the context is still usable through the single-GPU entry points
+        p2, n2, rc2 = cd.self_collide()
+        assert np.array_equal(oracle.pair_set(p2), oracle.pair_set(r["pairs"]))
 
 
 def test_device_pair_post_processing():
