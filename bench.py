@@ -9,8 +9,11 @@ pair whose AABBs strictly overlap and therefore reaches the neighbour filter / S
 
 N = 1 : BASELINE config 3, the 1 M-triangle synthetic cloth-vs-cloth.
 N > 1 : BASELINE config 4, one 1 M-triangle cloth object per rank, neighbours overlapping by 10 % along
-        x (weak scaling); per step each rank self-collides its object, all-gathers root AABBs over RCCL,
-        exchanges the overlapping leaves with its neighbours and traverses the received queries.
+        x (weak scaling); per step each rank builds its tree, all-gathers root AABBs over RCCL, exchanges the
+        overlapping leaves with its neighbours (grouped send / recv beside the local traversal) and traverses the
+        received queries.  The step is cd_multi_step of libmi355cd.so: the C++ side issues the RCCL calls;
+        torch.distributed only bootstraps (unique-id broadcast) and reduces the timings.  UNMEASURED ON >1 GPU so
+        far: the builder's box has one GPU (a 1-rank communicator in self-peer mode runs every phase there).
 
 Prints ONE JSON line on rank 0.  Launch for N > 1:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -123,14 +126,18 @@ def main():
     # MI355_DIST_BACKEND=gloo is a single-GPU REHEARSAL of the multi-process flow (ranks share cuda:0, payloads
     # staged through the host); the measured configuration is always nccl (= RCCL over xGMI), one rank per GPU.
     backend = os.environ.get("MI355_DIST_BACKEND", "nccl")
-    if world > 1:
+    # MI355_BENCH_SELF_PEER=1 (rehearsal on ONE GPU, launched with --nproc-per-node 1): the multi-GPU code path of this
+    # file and cd_multi_step run with a one-rank communicator that exchanges with itself -- never a measured configuration
+    self_peer = os.environ.get("MI355_BENCH_SELF_PEER", "0") == "1" and world == 1
+    multi_path = world > 1 or self_peer
+    if multi_path:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)        # nccl == RCCL on ROCm
         else:
             dist.init_process_group(backend)
 
     # ---- workload (synthetic, seeded), resident in HBM before the timed region
-    if world == 1:
+    if not multi_path:
         verts, vidx = synth.cloth_pair(args.quads)
         ids = None
         frame = mi355cd.CD_FRAME_REFERENCE                            # geometry lies in the reference's Morton frame
@@ -138,11 +145,11 @@ def main():
     else:
         verts, vidx, ids, vbase = synth.cloth_shard(rank, args.quads)
         frame = mi355cd.CD_FRAME_AUTO
-        workload = (f"{world} x cloth-vs-cloth objects of {vidx.shape[0]} triangles, 10% x-overlap between neighbours, "
+        workload = (("ONE-GPU REHEARSAL (self peer) of " if self_peer else "") + f"{world} x cloth-vs-cloth objects of {vidx.shape[0]} triangles, 10% x-overlap between neighbours, "
                     f"sharded by object (BASELINE config 4 shape)")
     nt = vidx.shape[0]
     # neighborCount compares vertex INDICES: a per-rank base makes them global for the cross-rank pass
-    engine = multi.HipEngine(verts, vidx, ids, device, frame, vertex_id_base=vbase if world > 1 else 0)
+    engine = multi.HipEngine(verts, vidx, ids, device, frame, vertex_id_base=vbase if multi_path else 0)
     if args.traversal is not None:
         engine.cd.set_option(mi355cd.CD_OPT_TRAVERSAL, args.traversal)
     if args.qpw is not None:
@@ -150,8 +157,26 @@ def main():
     cap = 1 << 22
 
     comm_device = None if backend == "nccl" else "cpu"
+    ms = None
+    if multi_path and backend == "nccl":
+        # the product path: cd_multi_step (C++ over RCCL).  Rank 0 makes the ncclUniqueId, torch.distributed hands it round.
+        uid = torch.zeros(128, dtype=torch.uint8, device=device)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(mi355cd.multi_unique_id()), dtype=torch.uint8).to(device)
+        dist.broadcast(uid, src=0)
+        ms = mi355cd.MultiStep(engine.cd, bytes(uid.cpu().numpy().tobytes()), rank, world, query_cap_per_peer=nt // 8 + 1024,
+                               flags=mi355cd.CD_MULTI_SELF_PEER if self_peer else 0)
+    last_info = {}
 
     def step():
+        if ms is not None:
+            pairs, n, rc, mi = ms.step(cap)
+            if rc != 0:
+                raise RuntimeError(f"pair capacity {cap} too small for {n} pairs")
+            last_info["mi"] = mi
+            return pairs, int(mi.pairs_tested), {"local_pairs": int(mi.local_pairs), "cross_pairs": int(mi.cross_pairs), "sent_queries": int(mi.sent_queries),
+                                                 "recv_queries": int(mi.recv_queries), "n_peers": int(mi.n_peers), "host_syncs": int(mi.host_syncs),
+                                                 "attempts": int(mi.attempts)}
         return multi.collide_step(engine, dist, rank, world, cap, comm_device)
 
     for _ in range(args.warmup):
@@ -166,22 +191,22 @@ def main():
     pairs_found = 0
     pipeline_ms = 0.0
     info = {}
-    if world > 1:
+    if multi_path:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pairs, tested, info = step()
         st = engine.cd.stats()                                        # HIP-event stage times on the library's stream
-        if world == 1:
+        if not multi_path:
             kern["descend"] += st.ms_descend; kern["exact"] += st.ms_exact; pipeline_ms += st.ms_pipeline
         tested_total += tested
         pairs_found = pairs.shape[0]
     torch.cuda.synchronize()
-    if world > 1:
+    if multi_path:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi_path:
         rdev = device if backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -199,9 +224,9 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "triangles_per_gpu": int(nt), "pairs_tested_per_step": tested_total // k,
-                       "colliding_pairs": int(pairs_found), "sharding": "by object" if world > 1 else "none"},
+                       "colliding_pairs": int(pairs_found), "sharding": "by object" if multi_path else "none"},
         }
-        if world == 1:
+        if not multi_path:
             engine.cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 1)  # untimed: the same step with events around every stage
             prof_steps = min(k, 20)
             for _ in range(prof_steps):
@@ -246,9 +271,37 @@ def main():
                 line["ray_tracer"] = ray_tracer_measurement()
         else:
             line["config"]["last_step_rank0"] = info
+    if multi_path:
+        # which transport ran, what the communicator saw, and where the time goes (max over ranks of each phase, from a
+        # few extra untimed steps with HIP events at the phase boundaries)
+        phase = None
+        if ms is not None:
+            ms.set_flags(mi355cd.CD_MULTI_TIMING)
+            acc = np.zeros(7)
+            reps = 5
+            for _ in range(reps):
+                step()
+                mi = last_info["mi"]
+                acc += np.array([mi.ms_tree, mi.ms_allgather, mi.ms_pack, mi.ms_counts, mi.ms_exchange, mi.ms_local, mi.ms_cross])
+            t = torch.tensor(acc / reps, dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            names = ["tree", "allgather", "pack", "counts", "exchange", "local", "cross"]
+            phase = {k: float(v) for k, v in zip(names, t.tolist())}
+            observed = int(last_info["mi"].world)
+        else:
+            observed = dist.get_world_size()
+        if rank == 0:
+            line["backend"] = ("rccl (C++: cd_multi_step of libmi355cd.so issues ncclAllGather / ncclSend / ncclRecv)" if ms is not None
+                               else f"{backend} (REHEARSAL: Python orchestration, payloads staged through the host)")
+            line["world_size_observed"] = observed
+            line["phase_ms"] = phase
+            line["phase_ms_note"] = "max over ranks; exchange runs beside local; from 5 extra untimed steps with events at the phase boundaries"
+    if rank == 0:
         print(json.dumps(line))
+    if ms is not None:
+        ms.close()
     engine.close()
-    if world > 1:
+    if multi_path:
         dist.destroy_process_group()
 
 

@@ -189,6 +189,8 @@ int cd_multi_create_from_comm(cd_multi **out, cd_ctx *ctx, void *nccl_comm, uint
 
 void cd_multi_destroy(cd_multi *m) { multi_free(m); }
 
+int cd_multi_set_flags(cd_multi *m, int flags) { if (!m) return CD_ERR_ARG; m->flags = flags; return CD_OK; }
+
 int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs, cd_multi_info *info)
 {
     if (!m || (cap_pairs && !pairs)) return CD_ERR_ARG;

@@ -152,7 +152,7 @@ int enqueue_morton_sort(cd_ctx *c)
     HIPCHK(evrec(c, EV_MORTON0));
     if (c->frame_mode == CD_FRAME_AUTO) {
         k_centroid_bounds<<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_partial);
-        k_frame_from_bounds<<<1, 64, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->d_frame);
+        k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->d_frame);
     }
     // fused pipeline: the sort scratch, the small counters and the traversal state are one block, zeroed once here
     HIPCHK(hipMemsetAsync(c->d_os, 0, c->prezeroed ? c->zero_bytes : c->os_bytes, s));

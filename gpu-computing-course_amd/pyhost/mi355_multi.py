@@ -86,12 +86,30 @@ class HipEngine:
 
 
 def collide_step(engine, dist, rank, world, cap=1 << 22, comm_device=None):
-    """One multi-GPU step.  Returns (pairs ndarray[k,2] found by THIS rank, pairs_tested by this rank,
-    info dict).  `dist` is torch.distributed (nccl == RCCL on GPUs, gloo in CPU tests).
-    comm_device: where the collectives' tensors live; default = the engine's device (RCCL moves device buffers
-    directly over xGMI).  A rehearsal with the gloo backend passes "cpu": payloads are staged through the host."""
+    """One multi-GPU step, orchestrated from Python over torch.distributed.  Returns (pairs ndarray[k,2] found by THIS
+    rank, pairs_tested by this rank, info dict).  `dist` is torch.distributed.
+
+    This is the REHEARSAL / test orchestration (gloo on CPU with a stand-in engine, or gloo with ranks sharing one GPU):
+    the measured multi-GPU path is cd_multi_step in libmi355cd.so, which issues the RCCL calls itself (bench.py uses it
+    whenever the backend is nccl).  comm_device: where the collectives' tensors live; a gloo rehearsal passes "cpu".
+
+    Failure is COLLECTIVE: a rank whose engine raises (capacity overflow, CdError ...) keeps taking part in every
+    collective of the step with empty payloads, and an all-reduce(MAX) of an error flag at the end makes every rank
+    raise together -- no rank is left blocked in a collective its peer has abandoned."""
     import torch
     info = {"local_pairs": 0, "cross_pairs": 0, "sent_queries": 0, "recv_queries": 0, "peers": []}
+    err = []
+
+    def guard(fn, default):
+        if err:
+            return default
+        try:
+            return fn()
+        except Exception as e:                              # noqa: BLE001 -- reported collectively below
+            err.append(e)
+            return default
+
+    empty_pairs = (np.zeros((0, 2), dtype=np.uint32), 0, 0)
     if world == 1:
         local_pairs, n_local, tested = engine.self_collide(cap)
         if n_local > cap:
@@ -100,12 +118,12 @@ def collide_step(engine, dist, rank, world, cap=1 << 22, comm_device=None):
         return local_pairs, int(tested), info
 
     # 1a. the local tree (no traversal yet: the exchange below overlaps with it)
-    engine.build_tree()
+    guard(engine.build_tree, None)
 
-    # 2. all-gather of root AABBs
+    # 2. all-gather of root AABBs (a failed rank contributes an empty box: it strictly overlaps nothing)
     edev = engine.empty_queries().device
     dev = edev if comm_device is None else torch.device(comm_device)
-    mine = torch.from_numpy(np.ascontiguousarray(engine.root_box())).to(dev)
+    mine = torch.from_numpy(np.ascontiguousarray(guard(engine.root_box, np.zeros(6)))).to(dev)
     roots = torch.empty(world * 6, dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(roots, mine)
     roots = roots.cpu().numpy().reshape(world, 6)
@@ -113,7 +131,9 @@ def collide_step(engine, dist, rank, world, cap=1 << 22, comm_device=None):
     info["peers"] = peers
 
     # 3. query exchange: counts first, then the records (variable-size all-to-all), started asynchronously
-    send = [engine.pack_queries(roots[s]) if s in peers else engine.empty_queries() for s in range(world)]
+    send = [guard(lambda s=s: engine.pack_queries(roots[s]), engine.empty_queries()) if s in peers else engine.empty_queries() for s in range(world)]
+    if err:
+        send = [engine.empty_queries() for _ in range(world)]
     send_counts = torch.tensor([t.numel() for t in send], dtype=torch.int64, device=dev)
     recv_counts = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(recv_counts, send_counts)
@@ -127,18 +147,25 @@ def collide_step(engine, dist, rank, world, cap=1 << 22, comm_device=None):
     info["sent_queries"] = int(sendbuf.numel() // QUERY_BYTES)
     info["recv_queries"] = int(recvbuf.numel() // QUERY_BYTES)
 
-    # 1b. local traversal while the records travel (RCCL runs on its own stream, the library on its own)
-    local_pairs, n_local, tested = engine.find_collisions(cap)
-    if n_local > cap:
-        raise RuntimeError(f"pair capacity {cap} too small for {n_local} local pairs")
+    # 1b. local traversal while the records travel
+    local_pairs, n_local, tested = guard(lambda: engine.find_collisions(cap), empty_pairs)
+    if n_local > cap and not err:
+        err.append(RuntimeError(f"pair capacity {cap} too small for {n_local} local pairs"))
     info["local_pairs"] = int(n_local)
     work.wait()
     recvbuf = recvbuf.to(edev)
 
     # 4. received queries against the local tree
-    cross_pairs, n_cross, tested_cross = engine.find_collisions_queries(recvbuf, cap)
-    if n_cross > cap:
-        raise RuntimeError(f"pair capacity {cap} too small for {n_cross} cross pairs")
+    cross_pairs, n_cross, tested_cross = guard(lambda: engine.find_collisions_queries(recvbuf, cap), empty_pairs)
+    if n_cross > cap and not err:
+        err.append(RuntimeError(f"pair capacity {cap} too small for {n_cross} cross pairs"))
     info["cross_pairs"] = int(n_cross)
+
+    # 5. every rank learns whether ANY rank failed, and all raise together
+    flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        raise RuntimeError(f"collide_step failed on at least one rank (this rank: {err[0]!r})" if err else
+                           "collide_step failed on another rank") from (err[0] if err else None)
     pairs = np.concatenate([local_pairs, cross_pairs], axis=0) if n_cross else local_pairs
     return pairs, int(tested) + int(tested_cross), info

@@ -51,7 +51,7 @@ EXPORTS = [
     "cd_check_triangle_idx", "cd_find_collisions", "cd_build_tree", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
     "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_debug_counters", "cd_num_triangles",
     "cd_set_option", "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
-    "cd_multi_unique_id", "cd_multi_create", "cd_multi_create_from_comm", "cd_multi_destroy", "cd_multi_step",
+    "cd_multi_unique_id", "cd_multi_create", "cd_multi_create_from_comm", "cd_multi_destroy", "cd_multi_set_flags", "cd_multi_step",
 ]
 
 _lib = None
@@ -111,6 +111,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_multi_create_from_comm.argtypes = [C.POINTER(vp), vp, vp, C.c_uint64, C.c_int]
     lib.cd_multi_destroy.argtypes = [vp]
     lib.cd_multi_destroy.restype = None
+    lib.cd_multi_set_flags.argtypes = [vp, C.c_int]
     lib.cd_multi_step.argtypes = [vp, vp, C.c_uint64, u64p, C.POINTER(CdMultiInfo)]
     for name in EXPORTS:
         if name not in ("cd_destroy", "cd_version", "cd_free_obj", "cd_multi_destroy"):
@@ -351,6 +352,11 @@ class MultiStep:
         if rc < 0:
             raise CdError("cd_multi_step", rc)
         return self._pairs[: min(n.value, cap)], int(n.value), rc, info
+
+    def set_flags(self, flags: int):
+        rc = self.lib.cd_multi_set_flags(self._m, flags)
+        if rc != CD_OK:
+            raise CdError("cd_multi_set_flags", rc)
 
     def close(self):
         if self._m:

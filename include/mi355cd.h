@@ -227,6 +227,8 @@ int cd_multi_create(cd_multi **out, cd_ctx *ctx, const void *id128, int rank, in
 /* The same over a communicator the caller owns (an opaque ncclComm_t); it is not destroyed by cd_multi_destroy. */
 int cd_multi_create_from_comm(cd_multi **out, cd_ctx *ctx, void *nccl_comm, uint64_t query_cap_per_peer, int flags);
 void cd_multi_destroy(cd_multi *m);
+/* Change CD_MULTI_* flags between steps (e.g. untimed steps first, then a few with CD_MULTI_TIMING). */
+int cd_multi_set_flags(cd_multi *m, int flags);
 /* One step.  pairs: local pairs first, then the cross pairs this rank owns (output format of cd_find_collisions);
  * returns CD_OVERFLOW when they do not fit cap_pairs (*n_pairs holds the true count).  info may be NULL. */
 int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs, cd_multi_info *info);

@@ -114,6 +114,51 @@ def test_sharded_step_equals_single_process(tmp_path, world, overlap):
     assert sum(int(r["sent"]) for r in res) == sum(int(r["recv"]) for r in res)
 
 
+class FailingEngine(OracleEngine):
+    """Raises where a real engine would on a capacity overflow / CdError -- on one rank only."""
+
+    def __init__(self, *a, fail_in):
+        super().__init__(*a)
+        self.fail_in = fail_in
+
+    def pack_queries(self, box):
+        if self.fail_in == "pack":
+            raise RuntimeError("injected pack failure")
+        return super().pack_queries(box)
+
+    def find_collisions(self, cap):
+        if self.fail_in == "local":
+            raise RuntimeError("injected traversal failure")
+        return super().find_collisions(cap)
+
+
+def _failing_worker(rank, world, port, fail_in, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    verts, vidx, ids, vbase = synth.cloth_shard(rank, QUADS, overlap=0.10)
+    eng = FailingEngine(verts, vidx, ids, vbase, fail_in=fail_in if rank == 1 else None)
+    try:
+        multi.collide_step(eng, dist, rank, world, cap=1 << 20)
+        msg = "no error"
+    except RuntimeError as e:
+        msg = str(e)
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write(msg)
+    dist.barrier()                                   # reachable only if NO rank is stuck in a collective of the step
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("fail_in", ["pack", "local"])
+def test_failure_on_one_rank_is_raised_on_every_rank(tmp_path, fail_in):
+    """A rank-local failure between collectives must not leave the peers blocked in the next collective: the failing
+    rank keeps taking part with empty payloads, and every rank raises after the error flag's all-reduce."""
+    port = _free_port()
+    mp.spawn(_failing_worker, args=(2, port, fail_in, str(tmp_path)), nprocs=2, join=True)
+    m0 = (tmp_path / "rank0.txt").read_text(); m1 = (tmp_path / "rank1.txt").read_text()
+    assert "failed on another rank" in m0
+    assert "injected" in m1 and "this rank" in m1
+
+
 def test_boxes_overlap_is_the_reference_predicate():
     a = np.array([0, 1, 0, 1, 0, 1.0])
     assert multi.boxes_overlap(a, np.array([0.5, 2, 0.5, 2, 0.5, 2.0]))
