@@ -57,13 +57,27 @@ def cpu_baseline(verts, vidx, reps=3):
            "sample": f"{reps} full passes of the same workload (best of {reps}; {t_all:.1f} s of CPU work), single thread, gcc -O2 -ffp-contract=off",
            "total_collision_ms": dt * 1e3, "pairs_tested": int(st.pairs_tested), "n_pairs": int(st.n_pairs),
            "stage_ms": {"morton": tm.ms_morton, "sort": tm.ms_sort, "hierarchy": tm.ms_hierarchy, "refit": tm.ms_refit, "traverse": tm.ms_traverse}}
-    # multi-core variant: traversal loop split over OpenMP threads (build stages stay sequential)
-    threads = min(16, os.cpu_count() or 1)
-    if threads > 1:
-        t0 = time.perf_counter()
-        _, st2, tm2 = oracle.self_collide(verts, vidx, want_pairs=False, threads=threads)
-        dt2 = time.perf_counter() - t0
-        out["omp"] = {"value": st2.pairs_tested / dt2, "cores": threads, "total_collision_ms": dt2 * 1e3, "traverse_ms": tm2.ms_traverse}
+    # all-core variant: every stage but the sort on OpenMP threads -- one iteration per CUDA thread of the
+    # reference's own kernels (oracle/cd_oracle.c build_parallel); the sort stays sequential like the reference's host sort
+    try:
+        nproc = len(os.sched_getaffinity(0))
+    except AttributeError:
+        nproc = os.cpu_count() or 1
+    out["nproc"] = nproc
+    if nproc > 1:
+        oracle.self_collide(verts[:30000], vidx[:10000], want_pairs=False, threads=nproc)       # start the thread pool
+        best2 = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            _, st2, tm2 = oracle.self_collide(verts, vidx, want_pairs=False, threads=nproc)
+            dt2 = time.perf_counter() - t0
+            if best2 is None or dt2 < best2[0]:
+                best2 = (dt2, st2, tm2)
+        dt2, st2, tm2 = best2
+        out["omp"] = {"value": st2.pairs_tested / dt2, "cores": nproc, "total_collision_ms": dt2 * 1e3,
+                      "stage_ms": {"morton": tm2.ms_morton, "sort (sequential)": tm2.ms_sort, "hierarchy": tm2.ms_hierarchy, "refit": tm2.ms_refit,
+                                   "traverse": tm2.ms_traverse},
+                      "sample": f"best of {reps} full passes, {nproc} OpenMP threads, sort on one thread"}
     return out
 
 
@@ -251,22 +265,29 @@ def main():
             achieved = desc_bytes / (kern["descend"] * 1e-3) / 1e9
             traffic = None
             l2_hit = None
+            whole_traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if tj.get("triangles") == nt:
                     traffic = tj.get("traverse_hbm_bytes_per_launch")
                     l2_hit = tj.get("l2_hit_rate")                     # TCC_HIT / (TCC_HIT + TCC_MISS) of k_descend, same rocprofv3 run set
+                    whole_traffic = tj.get("whole_path_hbm_bytes_per_step")
             line["kernel_ms"] = kern
-            line["roofline"] = {"bound": "hbm", "kernel": "k_descend (fp32 BVH descent; its candidates go to k_exact)", "achieved": achieved,
+            line["roofline"] = {"bound": "hbm", "kernel": "k_descend_half (fp32 BVH descent, half traversal; its candidates go to k_exact)",
+                                "kernel_symbol": "k_descend_half", "achieved": achieved,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "l2_hit_rate": l2_hit,
                                 "algorithmic_bytes_per_launch": desc_bytes, "avg_launch_ms": kern["descend"],
                                 "dominant_stage": dominant,
                                 "whole_path": {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9,
-                                               "frac": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                                               "frac": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": whole_traffic}}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(verts, vidx)
                 line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+                if "omp" in line["cpu_baseline"]:
+                    line["speedup_vs_cpu_allcores"] = line["value"] / line["cpu_baseline"]["omp"]["value"]
+                    line["speedup_note"] = (f"reported baselines, not targets: 1 core of the box, and all {line['cpu_baseline']['nproc']} cores "
+                                            "this process may use (sched_getaffinity)")
             if not args.no_ray:
                 line["ray_tracer"] = ray_tracer_measurement()
         else:

@@ -120,6 +120,7 @@ int ensure_pairs(cd_ctx *c, TravBuf &tb, uint64_t cap)
     if (cap <= tb.pairs_cap) return 0;
     if (tb.d_pairs) hipFree(reinterpret_cast<char *>(tb.d_pairs) - sizeof(Report));
     tb.d_pairs = nullptr; tb.pairs_cap = 0;
+    if (&tb == &c->tb[0]) c->last_pairs_on_device = 0;                 // the resident pair list went with the old buffer
     char *block = nullptr;
     HIPCHK(hipMalloc(&block, sizeof(Report) + sizeof(uint32_t) * 2 * cap + 16));      // +16: k_report moves pairs as 16-byte quads
     tb.d_pairs = reinterpret_cast<uint32_t *>(block + sizeof(Report));
@@ -489,7 +490,8 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_frame, sizeof(double) * 6);
     ALLOC(c->d_partial, sizeof(double) * 6 * BOUNDS_BLOCKS);
     ALLOC(c->d_leaf, sizeof(LeafTri) * n);
-    HIPCHK(hipMemset(c->d_leaf, 0, sizeof(LeafTri) * n));      // a failed sort may leave slots unwritten for one (discarded) run: keep their vertex ids in range
+    // a failed sort may leave slots unwritten for one (discarded) run: keep their vertex ids in range
+    { hipError_t e_ = hipMemset(c->d_leaf, 0, sizeof(LeafTri) * n); if (e_ != hipSuccess) { free_all(c); delete c; return -(int)e_; } }
     ALLOC(c->d_meta, sizeof(NodeMeta) * n);
     ALLOC(c->d_parent, sizeof(int32_t) * 2 * n);
     { uint32_t nb = cdiv(nt, REFIT_BLK); c->nbp2 = 1; while (c->nbp2 < nb) c->nbp2 <<= 1; }
@@ -711,6 +713,9 @@ int cd_brute_force(cd_ctx *c, int box_filter, uint32_t *pairs, uint64_t cap_pair
     HIPCHK(hipGetLastError());
     const uint64_t ncopy = h.n_pairs < cap_pairs ? h.n_pairs : cap_pairs;
     if (pairs && ncopy) HIPCHK(hipMemcpy(pairs, c->tb[0].d_pairs, sizeof(uint32_t) * 2 * ncopy, hipMemcpyDeviceToHost));
+    // the device list now holds THIS call's pairs: cd_sorted_pairs / cd_collision_triangles refer to it
+    c->stats.n_pairs = h.n_pairs; c->stats.pairs_tested = h.pairs_tested;
+    c->last_pairs_on_device = ncopy;
     if (n_pairs) *n_pairs = h.n_pairs;
     return h.n_pairs > cap_pairs ? CD_OVERFLOW : CD_OK;
 }

@@ -59,17 +59,20 @@ __device__ __forceinline__ void shade_one(Px &p, float ox, float oy, const SphGe
 
 __device__ __forceinline__ uint32_t pack_px(const Px &p, const SphShade *__restrict__ shade)
 {
-    float r = 0.f, g = 0.f, b = 0.f;                                                   // anime_ray.cu:68
+    // a pixel no sphere covers: r = g = b = 0 (anime_ray.cu:68) -> bytes 0, 0, 0, 255 -- nothing to compute, and most
+    // pixels of a frame are such (the compiler skips the block below for a whole wave when none of its lanes has a hit)
+    uint32_t out = 255u << 24;
     if (p.win >= 0) {
         const SphShade h = shade[p.win];
         const float n = p.dz / h.sr;                                                   // sphere.cuh:41
-        r = h.r * n; g = h.g * n; b = h.b * n;                                         // anime_ray.cu:77-79
+        const float r = h.r * n, g = h.g * n, b = h.b * n;                             // anime_ray.cu:77-79
+        // anime_ray.cu:84-87: (int)(c * 255) stored to unsigned char; alpha 255
+        const uint32_t ri = (uint32_t)(unsigned char)(int)(r * 255);
+        const uint32_t gi = (uint32_t)(unsigned char)(int)(g * 255);
+        const uint32_t bi = (uint32_t)(unsigned char)(int)(b * 255);
+        out = ri | (gi << 8) | (bi << 16) | (255u << 24);
     }
-    // anime_ray.cu:84-87: (int)(c * 255) stored to unsigned char; alpha 255
-    const uint32_t ri = (uint32_t)(unsigned char)(int)(r * 255);
-    const uint32_t gi = (uint32_t)(unsigned char)(int)(g * 255);
-    const uint32_t bi = (uint32_t)(unsigned char)(int)(b * 255);
-    return ri | (gi << 8) | (bi << 16) | (255u << 24);
+    return out;
 }
 
 // Exact conservative cull of one sphere against the pixel rectangle [X0,X1] x [Y0,Y1] (inclusive).  For a column x
@@ -87,35 +90,55 @@ __device__ __forceinline__ bool may_touch(const SphGeom g, float ox0, float ox1,
     return !(mx * mx + my * my >= g.rr);
 }
 
-constexpr int TEST_SHARDS = 64;         // sphere-test counter shards, 128 bytes apart
 constexpr int SUPER = 256;             // super-tile edge in pixels (4 x 4 tiles)
+#ifndef RT_QUADRANTS
+#define RT_QUADRANTS 0
+#endif
+constexpr int TILE_CAP = 48;           // entries a tile's own list holds; a tile that is touched by more spheres falls back to its super-tile's list
 
-// Level 1 of the binning (bin_sphere, called by k_prepare for the sphere it has just prepared): every SPHERE appends itself to the lists of
-// the 256x256 super-tiles it may touch -- a handful of candidates from a conservative bound, decided by the exact
-// may_touch -- with one atomic per (sphere, super-tile).  List order is arbitrary: the tie rule of anime_ray.cu:75
-// ("strict >, so the lowest index wins a tie in t") is applied explicitly in shade_one instead of through the
-// processing order.  Tiles then cull only their super-tile's few dozen survivors instead of all S spheres.
+// What a pixel loop needs from one sphere, 32 bytes: the hit geometry, the colour and the index (for the tie rule).
+// sqrtf(rr) is recomputed where needed: it is the very operation of prepare_one on the very same operand.
+struct alignas(16) TileEnt { float cx, cy, rr, z; float r, g, b; int idx; };
+
+// The binning (bin_sphere, called by k_prepare for the sphere it has just prepared) is sphere-centric: every SPHERE
+// appends itself to the lists of the 64x64 tiles it may touch (a handful: a conservative index range, then the exact
+// may_touch) as a complete TileEnt, so that a tile's pixel loop is ONE dependent fetch away from its survivors; and to
+// the index list of every 256x256 super-tile it may touch, which a tile with more than TILE_CAP survivors walks
+// instead.  One atomic per (sphere, list).  List order is arbitrary: the tie rule of anime_ray.cu:75 ("strict >, so the
+// lowest index wins a tie in t") is applied explicitly in shade_one instead of through the processing order.
 __device__ __forceinline__ void bin_sphere(const SphGeom g, const SphShade h, int i, int n, int dim,
-                                           int c_shift_x, int c_shift_y, int nsx, int sy0, int sy1,
-                                           int *__restrict__ super_list, int *__restrict__ super_count)
+                                           int c_shift_x, int c_shift_y, int nsx, int ty0, int ty1,
+                                           int *__restrict__ super_list, int *__restrict__ super_count,
+                                           TileEnt *__restrict__ tile_list, int *__restrict__ tile_count)
 {
     const double sr = (double)h.sr, cx = (double)g.cx, cy = (double)g.cy;
     // pixel x sees ox = x - dim/2 + c_shift_x; the sphere can only touch |ox - cx| < sr (+ float rounding: margin)
-    int bx0 = 0, bx1 = nsx - 1, by0 = sy0, by1 = sy1 - 1;
     const double mx = 2.0 + 1e-6 * (fabs(cx) + sr), my = 2.0 + 1e-6 * (fabs(cy) + sr);
-    const double xlo = cx - sr - mx + dim / 2 - c_shift_x, xhi = cx + sr + mx + dim / 2 - c_shift_x;
-    const double ylo = cy - sr - my + dim / 2 - c_shift_y, yhi = cy + sr + my + dim / 2 - c_shift_y;
-    if (xlo == xlo && xhi == xhi && ylo == ylo && yhi == yhi) {            // NaN anywhere: keep the full range (may_touch keeps NaN too)
-        if (xhi < 0.0 || yhi < 0.0 || xlo > (double)(dim - 1) || ylo > (double)(dim - 1)) return;
-        bx0 = max(bx0, (int)(fmax(xlo, 0.0) / SUPER)); bx1 = min(bx1, (int)(fmin(xhi, (double)(dim - 1)) / SUPER));
-        by0 = max(by0, (int)(fmax(ylo, 0.0) / SUPER)); by1 = min(by1, (int)(fmin(yhi, (double)(dim - 1)) / SUPER));
-    }
-    for (int sy = by0; sy <= by1; ++sy)
-        for (int sx = bx0; sx <= bx1; ++sx) {
-            const int X0 = sx * SUPER, Y0 = sy * SUPER;
-            const int X1 = min(X0 + SUPER, dim) - 1, Y1 = min(Y0 + SUPER, dim) - 1;
+    double xlo = cx - sr - mx + dim / 2 - c_shift_x, xhi = cx + sr + mx + dim / 2 - c_shift_x;
+    double ylo = cy - sr - my + dim / 2 - c_shift_y, yhi = cy + sr + my + dim / 2 - c_shift_y;
+    const int ntx = dim / TILE;
+    const double Y0 = (double)ty0 * TILE, Y1 = (double)ty1 * TILE - 1.0;     // the rows being rendered
+    if (!(xlo == xlo && xhi == xhi && ylo == ylo && yhi == yhi)) { xlo = 0.0; xhi = (double)(dim - 1); ylo = Y0; yhi = Y1; }   // NaN anywhere: keep the full range (may_touch keeps NaN too)
+    if (xhi < 0.0 || yhi < Y0 || xlo > (double)(dim - 1) || ylo > Y1) return;
+    const int px0 = (int)fmax(xlo, 0.0), px1 = (int)fmin(xhi, (double)(dim - 1)), py0 = (int)fmax(ylo, Y0), py1 = (int)fmin(yhi, Y1);
+    const TileEnt ent{g.cx, g.cy, g.rr, g.z, h.r, h.g, h.b, i};
+    for (int ty = py0 / TILE; ty <= py1 / TILE; ++ty)
+        for (int tx = px0 / TILE; tx <= px1 / TILE; ++tx) {
+            const int X0 = tx * TILE, Yt = ty * TILE;
+            const float ox0 = (float)(X0 - dim / 2 + c_shift_x), ox1 = (float)(X0 + TILE - 1 - dim / 2 + c_shift_x);
+            const float oy0 = (float)(Yt - dim / 2 + c_shift_y), oy1 = (float)(Yt + TILE - 1 - dim / 2 + c_shift_y);
+            if (may_touch(g, ox0, ox1, oy0, oy1)) {
+                const int t = ty * ntx + tx;
+                const int pos = atomicAdd(&tile_count[t], 1);
+                if (pos < TILE_CAP) tile_list[(size_t)t * TILE_CAP + pos] = ent;
+            }
+        }
+    for (int sy = py0 / SUPER; sy <= py1 / SUPER; ++sy)
+        for (int sx = px0 / SUPER; sx <= px1 / SUPER; ++sx) {
+            const int X0 = sx * SUPER, Ys = sy * SUPER;
+            const int X1 = min(X0 + SUPER, dim) - 1, Ye = min(Ys + SUPER, dim) - 1;
             const float ox0 = (float)(X0 - dim / 2 + c_shift_x), ox1 = (float)(X1 - dim / 2 + c_shift_x);
-            const float oy0 = (float)(Y0 - dim / 2 + c_shift_y), oy1 = (float)(Y1 - dim / 2 + c_shift_y);
+            const float oy0 = (float)(Ys - dim / 2 + c_shift_y), oy1 = (float)(Ye - dim / 2 + c_shift_y);
             if (may_touch(g, ox0, ox1, oy0, oy1)) {
                 const int st = sy * nsx + sx;
                 super_list[(size_t)st * n + atomicAdd(&super_count[st], 1)] = i;
@@ -123,18 +146,22 @@ __device__ __forceinline__ void bin_sphere(const SphGeom g, const SphShade h, in
         }
 }
 
-// The per-sphere prepass; in binned mode (super_list != nullptr) the same thread also bins its sphere.
+// The per-sphere prepass; in binned mode (tile_list != nullptr) the same thread also bins its sphere, and the launch
+// zeroes the list counters of the NEXT frame (two sets, used alternately: no memset between frames).
 __global__ __launch_bounds__(256) void k_prepare(const RtSphere *__restrict__ s, const int32_t *__restrict__ shifts, int n,
                                                  SphGeom *__restrict__ geom, SphShade *__restrict__ shade,
-                                                 int dim, int c_shift_x, int c_shift_y, int nsx, int sy0, int sy1,
-                                                 int *__restrict__ super_list, int *__restrict__ super_count)
+                                                 int dim, int c_shift_x, int c_shift_y, int nsx, int ty0, int ty1,
+                                                 int *__restrict__ super_list, int *__restrict__ super_count,
+                                                 TileEnt *__restrict__ tile_list, int *__restrict__ tile_count,
+                                                 int *__restrict__ next_counts, int n_counts)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (next_counts) for (int j = i; j < n_counts; j += gridDim.x * blockDim.x) next_counts[j] = 0;
     if (i >= n) return;
     SphGeom g; SphShade h;
     prepare_one(s, shifts, i, g, h);
     geom[i] = g; shade[i] = h;
-    if (super_list) bin_sphere(g, h, i, n, dim, c_shift_x, c_shift_y, nsx, sy0, sy1, super_list, super_count);
+    if (tile_list) bin_sphere(g, h, i, n, dim, c_shift_x, c_shift_y, nsx, ty0, ty1, super_list, super_count, tile_list, tile_count);
 }
 
 // Thread layout inside a 64x64 tile: tx = tid & 15 owns 4 consecutive columns, ty = tid >> 4 owns rows
@@ -142,29 +169,36 @@ __global__ __launch_bounds__(256) void k_prepare(const RtSphere *__restrict__ s,
 //
 // BINNED == false: anime_ray.cu:70-82 verbatim -- every pixel loops over all spheres.  The sphere index
 // is wave-uniform, so the geometry comes through the scalar cache (s_load), not LDS.
-// BINNED == true: first the workgroup culls spheres that cannot touch the tile, with a bound built from
-// the same float operations as the hit test (below); pixels then loop over the survivors only (any order: the
-// tie rule is explicit in shade_one).  Identical pixels, ~S/(survivors) times fewer hit() evaluations.  The cull itself is
-// two-level: k_prepare bins every sphere into the 256x256 super-tiles it may touch, the tile culls only its super-tile's list.
+// BINNED == true: pixels loop over the tile's own list (k_prepare, above) -- identical pixels, ~S / (survivors) times
+// fewer hit() evaluations.  The list is the same for the whole workgroup, so its entries come through the scalar
+// cache too: count -> entries -> pixels is the whole dependency chain, no LDS, no barrier.  A tile with more than
+// TILE_CAP survivors walks its super-tile's index list instead, culling with may_touch (workgroup-uniform) as it goes:
+// any number of spheres works, only slower.
 template <bool BINNED>
 __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ geom, const SphShade *__restrict__ shade, int n,
                                                     int dim, int c_shift_x, int c_shift_y, int tile_y0,
-                                                    uint32_t *__restrict__ rgba, unsigned long long *__restrict__ tests,
-                                                    const int *__restrict__ super_list, const int *__restrict__ super_count, int nsx)
+                                                    uint32_t *__restrict__ rgba, uint32_t *__restrict__ tile_tests,
+                                                    const int *__restrict__ super_list, const int *__restrict__ super_count, int nsx,
+                                                    const TileEnt *__restrict__ tile_list, const int *__restrict__ tile_count)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *list = reinterpret_cast<int *>(smem);              // BINNED: 4 sub-lists of cap = ceil(n/4) entries
-    __shared__ int wcount[4];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x;
     const int X0 = blockIdx.x * TILE, Y0 = (blockIdx.y + tile_y0) * TILE;
-    const int tx = tid & 15, ty = tid >> 4;
+    // BRUTE: tx = tid & 15 owns 4 consecutive columns, ty = tid >> 4 owns rows ty, ty+16, ty+32, ty+48.
+    // BINNED: a wave owns one 32x32 QUADRANT of the tile (lane = 4 columns x 4 consecutive rows in an 8 x 8 grid), so
+    // that a sphere which cannot touch the quadrant is skipped by the whole wave (wave-uniform may_touch): a quadrant
+    // sees about half the spheres its tile does.  A row of a quadrant is 8 lanes x 16 B = 128 contiguous bytes.
+    const int wv = tid >> 6, ln = tid & 63;
+    constexpr bool QUAD = BINNED && RT_QUADRANTS;
+    const int tx = QUAD ? ((wv & 1) * 8 + (ln & 7)) : (tid & 15);
+    const int ty = QUAD ? ((wv >> 1) * 32 + (ln >> 3) * 4) : (tid >> 4);
+    const int rstep = QUAD ? 1 : 16;
     const int x = X0 + 4 * tx;
     float ox[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) ox[k] = (float)(x + k - dim / 2 + c_shift_x);          // anime_ray.cu:65
     float oy[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) oy[k] = (float)(Y0 + ty + 16 * k - dim / 2 + c_shift_y); // anime_ray.cu:66
+    for (int k = 0; k < 4; ++k) oy[k] = (float)(Y0 + ty + rstep * k - dim / 2 + c_shift_y); // anime_ray.cu:66
     Px px[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -180,44 +214,48 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
                 for (int b = 0; b < 4; ++b) shade_one(px[a][b], ox[b], oy[a], g, i);
         }
     } else {
-        // ---- level 2 of the binning: cull this tile's super-tile survivors (may_touch above), keeping index order
-        const float ox0 = (float)(X0 - dim / 2 + c_shift_x), ox1 = (float)(X0 + TILE - 1 - dim / 2 + c_shift_x);
-        const float oy0 = (float)(Y0 - dim / 2 + c_shift_y), oy1 = (float)(Y0 + TILE - 1 - dim / 2 + c_shift_y);
-        const int st = (Y0 / SUPER) * nsx + (X0 / SUPER);
-        const int *slist = super_list + (size_t)st * n;
-        const int scount = super_count[st];
-        const int sub_cap = (scount + 3) >> 2;                   // wave w takes list positions [w*sub_cap, (w+1)*sub_cap)
-        int cnt = 0;                                           // wave-uniform running length of this wave's sub-list
-        const int s_begin = w * sub_cap, s_end = min(scount, s_begin + sub_cap);
-        for (int base = s_begin; base < s_end; base += 64) {
-            const int pos = base + lane;
-            bool keep = false; int i = 0;
-            if (pos < s_end) { i = slist[pos]; keep = may_touch(geom[i], ox0, ox1, oy0, oy1); }
-            const unsigned long long m = __ballot(keep);
-            if (keep) list[w * sub_cap + cnt + __popcll(m & ((1ull << lane) - 1ull))] = i;
-            cnt += __popcll(m);
-        }
-        if (lane == 0) wcount[w] = cnt;
-        __syncthreads();
-        unsigned long long mytests = 0;
-        for (int ww = 0; ww < 4; ++ww) {                       // sub-lists in wave order == ascending sphere index
-            const int c = wcount[ww];
-            for (int k = 0; k < c; ++k) {
-                const int i = list[ww * sub_cap + k];
+        const int t = (Y0 / TILE) * (dim / TILE) + (X0 / TILE);
+        const int cnt = tile_count[t];
+        uint32_t mytests = 0;
+        // this wave's quadrant, in ray coordinates
+        const int QX0 = X0 + (wv & 1) * 32, QY0 = Y0 + (wv >> 1) * 32;
+        const float qx0 = (float)(QX0 - dim / 2 + c_shift_x), qx1 = (float)(QX0 + 31 - dim / 2 + c_shift_x);
+        const float qy0 = (float)(QY0 - dim / 2 + c_shift_y), qy1 = (float)(QY0 + 31 - dim / 2 + c_shift_y);
+        if (cnt <= TILE_CAP) {
+            const TileEnt *ents = tile_list + (size_t)t * TILE_CAP;                  // workgroup-uniform: scalar loads
+            for (int k = 0; k < cnt; ++k) {
+                const TileEnt e = ents[k];
+                const SphGeom g{e.cx, e.cy, e.rr, e.z};
+                if (QUAD && !may_touch(g, qx0, qx1, qy0, qy1)) continue;             // (wave-uniform)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) shade_one(px[a][b], ox[b], oy[a], g, e.idx);
+            }
+            mytests = (uint32_t)cnt;
+        } else {
+            const float ox0 = (float)(X0 - dim / 2 + c_shift_x), ox1 = (float)(X0 + TILE - 1 - dim / 2 + c_shift_x);
+            const float oy0 = (float)(Y0 - dim / 2 + c_shift_y), oy1 = (float)(Y0 + TILE - 1 - dim / 2 + c_shift_y);
+            const int st = (Y0 / SUPER) * nsx + (X0 / SUPER);
+            const int *slist = super_list + (size_t)st * n;
+            const int scount = super_count[st];
+            for (int k = 0; k < scount; ++k) {
+                const int i = slist[k];
                 const SphGeom g = geom[i];
+                if (!may_touch(g, ox0, ox1, oy0, oy1)) continue;                     // (workgroup-uniform)
+                ++mytests;
+                if (QUAD && !may_touch(g, qx0, qx1, qy0, qy1)) continue;             // (wave-uniform)
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) shade_one(px[a][b], ox[b], oy[a], g, i);
             }
-            mytests += (unsigned long long)c;
         }
-        // 64 counter shards on separate 128-B lines: one word for all 4096 workgroups serialises them (~10 ns each)
-        if (tid == 0 && tests) atomicAdd(tests + 16 * ((blockIdx.y * gridDim.x + blockIdx.x) & (TEST_SHARDS - 1)), mytests * (unsigned long long)(TILE * TILE));
+        if (tid == 0 && tile_tests) tile_tests[t] = mytests;                         // sphere tests per pixel of this tile (summed by the host)
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const int y = Y0 + ty + 16 * a;
+        const int y = Y0 + ty + rstep * a;
         uint4 o;
         o.x = pack_px(px[a][0], shade); o.y = pack_px(px[a][1], shade); o.z = pack_px(px[a][2], shade); o.w = pack_px(px[a][3], shade);
         *reinterpret_cast<uint4 *>(rgba + (size_t)y * dim + x) = o;                       // offset = x + y*dim, anime_ray.cu:64
@@ -312,9 +350,12 @@ struct rt_ctx {
     RtSphere *d_spheres = nullptr; int32_t *d_shifts = nullptr;
     Xorwow *d_rng = nullptr; double *d_angles = nullptr; bool anim_ready = false;   // animation state, sphere.cuh:50-61
     SphGeom *d_geom = nullptr; SphShade *d_shade = nullptr;
-    uint32_t *d_rgba = nullptr; unsigned long long *d_tests = nullptr;
-    int *d_super_list = nullptr, *d_super_count = nullptr;      // [nsuper][n] survivor lists (unordered), [nsuper] counts (inside d_tests' allocation)
-    size_t zero_bytes = 0;
+    uint32_t *d_rgba = nullptr;
+    int *d_super_list = nullptr;                                // [nsuper][n] indices of the spheres that may touch a super-tile (unordered)
+    TileEnt *d_tile_list = nullptr;                             // [ntiles][TILE_CAP]
+    int *d_counts[2] = {nullptr, nullptr};                      // two sets of [ntiles tile counts | nsuper super-tile counts], used alternately by
+    int n_counts = 0, ntiles = 0; uint32_t frame = 0;           //   successive frames: a frame's k_prepare zeroes the set of the next one
+    uint32_t *d_tile_tests = nullptr, *h_tile_tests = nullptr;  // sphere tests per pixel of every tile; pinned copy
     rt_stats stats = {};
 };
 
@@ -322,7 +363,9 @@ namespace {
 void rt_free(rt_ctx *c)
 {
     hipFree(c->d_rng); hipFree(c->d_angles);
-    hipFree(c->d_spheres); hipFree(c->d_shifts); hipFree(c->d_geom); hipFree(c->d_shade); hipFree(c->d_rgba); hipFree(c->d_tests); hipFree(c->d_super_list);
+    hipFree(c->d_spheres); hipFree(c->d_shifts); hipFree(c->d_geom); hipFree(c->d_shade); hipFree(c->d_rgba); hipFree(c->d_super_list);
+    hipFree(c->d_tile_list); hipFree(c->d_counts[0]); hipFree(c->d_tile_tests);
+    if (c->h_tile_tests) hipHostFree(c->h_tile_tests);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -356,9 +399,13 @@ int rt_create(rt_ctx **out, const RtSphere *spheres, int32_t n_spheres, int32_t 
     ok(hipMalloc(&c->d_rgba, sizeof(uint32_t) * (size_t)dim * dim));
     
     { const size_t ns = (size_t)((dim + SUPER - 1) / SUPER) * ((dim + SUPER - 1) / SUPER);
-      c->zero_bytes = sizeof(unsigned long long) * 16 * TEST_SHARDS + sizeof(int) * ns;     // test counter shards + list lengths: one memset per frame
-      ok(hipMalloc(&c->d_tests, c->zero_bytes));
-      c->d_super_count = reinterpret_cast<int *>(c->d_tests + 16 * TEST_SHARDS);
+      c->ntiles = (dim / TILE) * (dim / TILE);
+      c->n_counts = c->ntiles + (int)ns;
+      ok(hipMalloc(&c->d_counts[0], sizeof(int) * 2 * (size_t)c->n_counts));
+      if (e == hipSuccess) { c->d_counts[1] = c->d_counts[0] + c->n_counts; ok(hipMemset(c->d_counts[0], 0, sizeof(int) * 2 * (size_t)c->n_counts)); }
+      ok(hipMalloc(&c->d_tile_list, sizeof(TileEnt) * (size_t)c->ntiles * TILE_CAP));
+      ok(hipMalloc(&c->d_tile_tests, sizeof(uint32_t) * (size_t)c->ntiles));
+      ok(hipHostMalloc(&c->h_tile_tests, sizeof(uint32_t) * (size_t)c->ntiles, hipHostMallocDefault));
       ok(hipMalloc(&c->d_super_list, sizeof(int) * ns * (size_t)n_spheres)); }
     if (e == hipSuccess) ok(hipMemcpy(c->d_spheres, spheres, sizeof(RtSphere) * (size_t)n_spheres, hipMemcpyHostToDevice));
     if (e != hipSuccess) { rt_free(c); delete c; return -(int)e; }
@@ -394,34 +441,39 @@ int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, 
     if (!c || (!shifts4 && !c->anim_ready) || y0 < 0 || y1 > c->dim || y0 >= y1 || y0 % TILE || y1 % TILE) return RT_ERR_ARG;
     hipStream_t s = c->stream;
     if (shifts4) HIPCHK(hipMemcpyAsync(c->d_shifts, shifts4, sizeof(int32_t) * 4 * (size_t)c->n, hipMemcpyHostToDevice, s));   // NULL: the device-resident animation state
-    HIPCHK(hipMemsetAsync(c->d_tests, 0, c->zero_bytes, s));
     HIPCHK(hipEventRecord(c->ev0, s));
     const dim3 grid(c->dim / TILE, (y1 - y0) / TILE);
+    const int ty0 = y0 / TILE, ty1 = y1 / TILE, ntx = c->dim / TILE;
     if (c->mode == RT_MODE_BINNED) {
-        const size_t lds = sizeof(int) * 4 * (size_t)((c->n + 3) / 4);
         const int nsx = (c->dim + SUPER - 1) / SUPER;
-        const int sy0 = y0 / SUPER, sy1 = (y1 + SUPER - 1) / SUPER;
-        k_prepare<<<(c->n + 255) / 256, 256, 0, s>>>(c->d_spheres, c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, csx, csy, nsx, sy0, sy1, c->d_super_list, c->d_super_count);
-        k_render<true><<<grid, THREADS, lds, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, y0 / TILE, c->d_rgba, c->d_tests,
-                                                  c->d_super_list, c->d_super_count, nsx);
+        int *cur = c->d_counts[c->frame & 1], *nxt = c->d_counts[(c->frame + 1) & 1];
+        ++c->frame;
+        k_prepare<<<(c->n + 255) / 256, 256, 0, s>>>(c->d_spheres, c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, csx, csy, nsx, ty0, ty1,
+                                                      c->d_super_list, cur + c->ntiles, c->d_tile_list, cur, nxt, c->n_counts);
+        k_render<true><<<grid, THREADS, 0, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, ty0, c->d_rgba, c->d_tile_tests,
+                                                c->d_super_list, cur + c->ntiles, nsx, c->d_tile_list, cur);
     } else {
-        k_prepare<<<(c->n + 255) / 256, 256, 0, s>>>(c->d_spheres, c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, csx, csy, 0, 0, 0, nullptr, nullptr);
-        k_render<false><<<grid, THREADS, 0, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, y0 / TILE, c->d_rgba, nullptr, nullptr, nullptr, 0);
+        k_prepare<<<(c->n + 255) / 256, 256, 0, s>>>(c->d_spheres, c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, csx, csy, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+        k_render<false><<<grid, THREADS, 0, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, ty0, c->d_rgba, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
     }
     HIPCHK(hipEventRecord(c->ev1, s));
-    HIPCHK(hipGetLastError());
-    unsigned long long shard[16 * TEST_SHARDS];
-    HIPCHK(hipMemcpyAsync(shard, c->d_tests, sizeof shard, hipMemcpyDeviceToHost, s));
-    if (rgba_out)                                                   // anime_ray.cu:128-131 D2H of the frame
-        HIPCHK(hipMemcpyAsync(rgba_out, c->d_rgba + (size_t)y0 * c->dim, sizeof(uint32_t) * (size_t)(y1 - y0) * c->dim, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    // from here on an early return must not leave a copy into caller / context memory in flight: synchronise first
+    hipError_t e = hipGetLastError();
+    const size_t t0 = (size_t)ty0 * ntx, nt = (size_t)(ty1 - ty0) * ntx;
+    if (e == hipSuccess && c->mode == RT_MODE_BINNED)
+        e = hipMemcpyAsync(c->h_tile_tests + t0, c->d_tile_tests + t0, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && rgba_out)                                // anime_ray.cu:128-131 D2H of the frame
+        e = hipMemcpyAsync(rgba_out, c->d_rgba + (size_t)y0 * c->dim, sizeof(uint32_t) * (size_t)(y1 - y0) * c->dim, hipMemcpyDeviceToHost, s);
+    const hipError_t es = hipStreamSynchronize(s);
+    if (e != hipSuccess) return -(int)e;
+    if (es != hipSuccess) return -(int)es;
     unsigned long long tests = 0;
-    for (int i = 0; i < TEST_SHARDS; ++i) tests += shard[16 * i];
+    if (c->mode == RT_MODE_BINNED) for (size_t i = 0; i < nt; ++i) tests += c->h_tile_tests[t0 + i];
     float ms = 0.f;
     hipEventElapsedTime(&ms, c->ev0, c->ev1);
     c->stats.ms_render = ms;
     c->stats.mode = (uint32_t)c->mode;
-    c->stats.sphere_tests = c->mode == RT_MODE_BINNED ? tests : (uint64_t)c->n * (uint64_t)c->dim * (uint64_t)(y1 - y0);
+    c->stats.sphere_tests = c->mode == RT_MODE_BINNED ? tests * (unsigned long long)(TILE * TILE) : (uint64_t)c->n * (uint64_t)c->dim * (uint64_t)(y1 - y0);
     return RT_OK;
 }
 

@@ -67,11 +67,12 @@ int cd_load_obj(const char *path, double **verts_xyz, uint32_t *nv, uint32_t **v
     const long sz = std::ftell(f);
     std::fseek(f, 0, SEEK_SET);
     if (sz <= 0) { std::fclose(f); return CD_ERR_FORMAT; }
-    std::vector<char> buf((size_t)sz + 1);
+    std::vector<char> buf((size_t)sz + 2);
     const size_t got = std::fread(buf.data(), 1, (size_t)sz, f);
     std::fclose(f);
     if (got != (size_t)sz) return CD_ERR_IO;
-    buf[(size_t)sz] = '\n';
+    buf[(size_t)sz] = '\n';                                // a last line without a newline still ends in one ...
+    buf[(size_t)sz + 1] = '\0';                            // ... and strtol / strtof, which skip newlines as white space, stop at the NUL
     const char *base = buf.data(), *end = base + sz;
 
     int nth = threads > 0 ? threads : (int)std::thread::hardware_concurrency();

@@ -523,15 +523,67 @@ uint32_t orc_check_triangle_idx(int n, const uint32_t *perm, const uint32_t *vid
 }
 
 /* ------------------------------------------------------------------ whole path, for the CPU baseline */
+#include <time.h>
+static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+
 typedef struct {
     double ms_morton, ms_sort, ms_hierarchy, ms_refit, ms_traverse;
 } orc_times;
 
-#include <time.h>
-static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+/* The build stages on `threads` OpenMP threads (liboracle_omp.so): each is the reference's own data-parallel
+ * formulation run with one OpenMP iteration per CUDA thread -- Morton keys per triangle (load_obj.h:89-101),
+ * generateHierarchyParallel per internal node (bvh.cuh:146-199; the parent links of a valid tree are written by
+ * exactly one node each, the double-parent counter uses an atomic exchange), calBoundingBox per leaf with the
+ * second arriver continuing (bvh.cuh:258-285; the arrival counter is an acquire-release RMW, which the reference
+ * lacks).  The sort stays the sequential LSD radix sort (the reference sorts on one host thread too, load_obj.h:107);
+ * its share is reported in ms_sort. */
+#ifdef _OPENMP
+static void build_parallel(const double *verts, const uint32_t *vidx, int n, const double off[3], const double span[3], int threads,
+                           uint64_t *keys, uint32_t *perm, int32_t *left, int32_t *right, int32_t *parent, double *boxes, uint32_t *bounded,
+                           double t[5])
+{
+    t[0] = now_ms();
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int tt = 0; tt < n; ++tt) {
+        const double *p1 = verts + 3 * (size_t)vidx[3 * (size_t)tt + 0], *p2 = verts + 3 * (size_t)vidx[3 * (size_t)tt + 1], *p3 = verts + 3 * (size_t)vidx[3 * (size_t)tt + 2];
+        keys[tt] = orc_morton3d((p1[0] + p2[0] + p3[0]) / 3, (p1[1] + p2[1] + p3[1]) / 3, (p1[2] + p2[2] + p3[2]) / 3, off, span);
+    }
+    t[1] = now_ms();
+    orc_sort_by_key(keys, perm, (uint32_t)n);
+    t[2] = now_ms();
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int i = 0; i < 2 * n - 1; ++i) parent[i] = -1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4096)
+    for (int idx = 0; idx < n - 1; ++idx) {
+        int first, last;
+        orc_determine_range(keys, n, idx, 1, &first, &last);
+        int split = orc_find_split(keys, n, first, last, 1);
+        int32_t a = (split == first) ? (n - 1) + split : split, b = (split + 1 == last) ? (n - 1) + (split + 1) : split + 1;
+        left[idx] = a; right[idx] = b;
+        (void)__atomic_exchange_n(&parent[a], idx, __ATOMIC_RELAXED);
+        (void)__atomic_exchange_n(&parent[b], idx, __ATOMIC_RELAXED);
+    }
+    t[3] = now_ms();
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int i = 0; i < n - 1; ++i) bounded[i] = 0;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4096)
+    for (int j = 0; j < n; ++j) {
+        uint32_t tt = perm[j];
+        int node = (n - 1) + j;
+        box_set(boxes + 6 * (size_t)node, verts + 3 * (size_t)vidx[3 * (size_t)tt], verts + 3 * (size_t)vidx[3 * (size_t)tt + 1], verts + 3 * (size_t)vidx[3 * (size_t)tt + 2]);
+        int cur = parent[node];
+        while (cur != -1) {
+            if (__atomic_fetch_add(&bounded[cur], 1u, __ATOMIC_ACQ_REL) == 0) break;      /* bvh.cuh:270: the first arriver stops */
+            box_merge(boxes + 6 * (size_t)cur, boxes + 6 * (size_t)left[cur], boxes + 6 * (size_t)right[cur]);
+            cur = parent[cur];
+        }
+    }
+    t[4] = now_ms();
+}
+#endif
 
 /* main.cu:64-146 minus I/O: morton -> sort -> hierarchy -> refit -> traversal, single thread
- * (threads == 1), or the traversal loop split over OpenMP threads (threads > 1; pair order then
+ * (threads == 1), or every stage but the sort on `threads` OpenMP threads (threads > 1; pair order then
  * differs, sets do not). Returns the pair count; pairs may be NULL (count only). */
 uint64_t orc_self_collide(const double *verts, const uint32_t *vidx, const uint32_t *ids, int n,
                           const double off[3], const double span[3], int threads,
@@ -543,16 +595,26 @@ uint64_t orc_self_collide(const double *verts, const uint32_t *vidx, const uint3
     int32_t *parent = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)n);
     double *boxes = (double *)malloc(sizeof(double) * 12 * (size_t)n);
     uint32_t *bounded = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n);
-    double t0 = now_ms();
-    orc_centroid_morton(verts, vidx, (uint32_t)n, off, span, keys, NULL);
-    double t1 = now_ms();
-    orc_sort_by_key(keys, perm, (uint32_t)n);
-    double t2 = now_ms();
-    uint32_t wrong;
-    orc_build_hierarchy(keys, n, 1, left, right, parent, NULL, NULL, &wrong);
-    double t3 = now_ms();
-    orc_refit(verts, vidx, perm, n, left, right, parent, boxes, bounded, NULL);
-    double t4 = now_ms();
+    double t0, t1, t2, t3, t4;
+#ifdef _OPENMP
+    if (threads > 1) {
+        double tt[5];
+        build_parallel(verts, vidx, n, off, span, threads, keys, perm, left, right, parent, boxes, bounded, tt);
+        t0 = tt[0]; t1 = tt[1]; t2 = tt[2]; t3 = tt[3]; t4 = tt[4];
+    } else
+#endif
+    {
+        t0 = now_ms();
+        orc_centroid_morton(verts, vidx, (uint32_t)n, off, span, keys, NULL);
+        t1 = now_ms();
+        orc_sort_by_key(keys, perm, (uint32_t)n);
+        t2 = now_ms();
+        uint32_t wrong;
+        orc_build_hierarchy(keys, n, 1, left, right, parent, NULL, NULL, &wrong);
+        t3 = now_ms();
+        orc_refit(verts, vidx, perm, n, left, right, parent, boxes, bounded, NULL);
+        t4 = now_ms();
+    }
     memset(st, 0, sizeof *st);
     if (threads <= 1) {
         orc_find_collisions(verts, vidx, ids, perm, n, left, right, boxes, pairs, pairs ? cap : 0, st);

@@ -16,5 +16,7 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -o run
 echo "L2 hit / miss pass done"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -o run -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_sq.json 2> $O/pmc_sq.err
 echo "SQ pass done"
+rocprofv3 --pmc SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_SALU --output-format csv -d $O/pmc_sq2 -o run -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_sq2.json 2> $O/pmc_sq2.err
+echo "SQ pass 2 (scalar side, issue / wait split) done"
 rm -f $O/trace/run_kernel_trace.csv        # tens of MB; the stats file is the summary
 ls -la $O $O/trace
