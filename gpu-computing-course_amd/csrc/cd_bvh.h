@@ -23,7 +23,9 @@ typedef int4 NodeMeta;
 // child's own split for an internal child and ~j for leaf j.  With that naming the right siblings hanging off
 // the root path of leaf j -- the subtrees that partition the leaves (j, n-1] -- are reached bottom-up with no
 // parent pointers: s = j; { right child of recs[s]; s = recs[s].last; } until last == n-1 (cd_traverse.h).
-// The two 32-byte halves are laid out so that such a hop reads only the second one.
+// The two 32-byte halves of a record live in two ARRAYS (right halves first, then the left halves, in one allocation
+// of n x 64 bytes): a hop of that chain reads only the right half, so the chain walks a dense 32-byte-per-node array
+// (rec_right); a descent step reads both (rec_left, rec_right).  NodeRec32 remains the logical record.
 constexpr uint32_t REC_LAST_MASK = 0x3fffffffu;     // n <= 2^30 (the candidate encoding has the same limit)
 constexpr uint32_t REC_L_EXACT = 0x40000000u;       // in `last`: the left / right child box is exactly representable
 constexpr uint32_t REC_R_EXACT = 0x80000000u;       //   in fp32 (box_is_fp32)
@@ -31,7 +33,10 @@ struct alignas(64) NodeRec32 {
     float l_lo[3], l_hi[3]; int32_t cl; uint32_t first;     // quad 0, quad 1: left child (first: range start, informational)
     float r_lo[3], r_hi[3]; int32_t cr; uint32_t last;      // quad 2, quad 3: right child, range end | REC_*_EXACT
 };
-static_assert(sizeof(NodeRec32) == 64, "NodeRec32 must be one 64-byte line");
+static_assert(sizeof(NodeRec32) == 64, "NodeRec32 is two 32-byte halves");
+// quads (16 bytes) of the two halves of record s; `recs` is the allocation's base, n the number of leaves (= record slots)
+__device__ __forceinline__ const float4 *rec_right(const NodeRec32 *recs, int n, uint32_t s) { return reinterpret_cast<const float4 *>(recs) + 2 * (size_t)s; }
+__device__ __forceinline__ const float4 *rec_left(const NodeRec32 *recs, int n, uint32_t s) { return reinterpret_cast<const float4 *>(recs) + 2 * (size_t)n + 2 * (size_t)s; }
 
 // fp32 query box of leaf j, rounded outward like the records', written by the refit: the descent reads 32 coalesced
 // bytes per query instead of the 48-byte FP64 box.  flags bit 0: the box is exact in fp32; bit 1: the FP64 box strictly
@@ -251,14 +256,14 @@ __device__ __forceinline__ bool box_is_fp32(const Box &b)
            (double)(float)b.y2 == b.y2 && (double)(float)b.z1 == b.z1 && (double)(float)b.z2 == b.z2;
 }
 
-__device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ r, const Box &bl, const Box &br, int2 ch, uint32_t first, uint32_t last)
+__device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ recs, int n, uint32_t split, const Box &bl, const Box &br, int2 ch, uint32_t first, uint32_t last)
 {
-    float4 *p = reinterpret_cast<float4 *>(r);
-    p[0] = make_float4(__double2float_rd(bl.x1), __double2float_rd(bl.y1), __double2float_rd(bl.z1), __double2float_ru(bl.x2));
-    p[1] = make_float4(__double2float_ru(bl.y2), __double2float_ru(bl.z2), __int_as_float(ch.x), __uint_as_float(first));
-    p[2] = make_float4(__double2float_rd(br.x1), __double2float_rd(br.y1), __double2float_rd(br.z1), __double2float_ru(br.x2));
-    p[3] = make_float4(__double2float_ru(br.y2), __double2float_ru(br.z2), __int_as_float(ch.y),
-                       __uint_as_float(last | (box_is_fp32(bl) ? REC_L_EXACT : 0u) | (box_is_fp32(br) ? REC_R_EXACT : 0u)));
+    float4 *pl = const_cast<float4 *>(rec_left(recs, n, split)), *pr = const_cast<float4 *>(rec_right(recs, n, split));
+    pl[0] = make_float4(__double2float_rd(bl.x1), __double2float_rd(bl.y1), __double2float_rd(bl.z1), __double2float_ru(bl.x2));
+    pl[1] = make_float4(__double2float_ru(bl.y2), __double2float_ru(bl.z2), __int_as_float(ch.x), __uint_as_float(first));
+    pr[0] = make_float4(__double2float_rd(br.x1), __double2float_rd(br.y1), __double2float_rd(br.z1), __double2float_ru(br.x2));
+    pr[1] = make_float4(__double2float_ru(br.y2), __double2float_ru(br.z2), __int_as_float(ch.y),
+                        __uint_as_float(last | (box_is_fp32(bl) ? REC_L_EXACT : 0u) | (box_is_fp32(br) ? REC_R_EXACT : 0u)));
 }
 
 // Link stored in a record for child `c` (unified Karras id): ~j for leaf j, the child's own split for an internal
@@ -300,7 +305,7 @@ __device__ __forceinline__ Box box_identity()
 __device__ __forceinline__ Box emit_node(const Box &bl, const Box &br, const NodeMeta *__restrict__ meta, int cl, int cr, int split, int first, int last,
                                          NodeRec32 *__restrict__ recs32, int nleaf_base)
 {
-    store_rec32(recs32 + split, bl, br, make_int2(child_link(meta, cl, nleaf_base), child_link(meta, cr, nleaf_base)), (uint32_t)first, (uint32_t)last);
+    store_rec32(recs32, nleaf_base + 1, (uint32_t)split, bl, br, make_int2(child_link(meta, cl, nleaf_base), child_link(meta, cr, nleaf_base)), (uint32_t)first, (uint32_t)last);
     return box_merge(bl, br);
 }
 

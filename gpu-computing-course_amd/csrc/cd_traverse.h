@@ -373,8 +373,8 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
             int32_t pn = __builtin_amdgcn_readfirstlane(root);              // wave-uniform path node
             node = -1;
             for (int lev = 0; lev < 128; ++lev) {                            // (tree height <= 96: the bound only matters for a corrupt tree)
-                const int4 *rq = reinterpret_cast<const int4 *>(recs + pn);
-                const int4 r0 = rq[0], r1 = rq[1], r2 = rq[2], r3 = rq[3];
+                const int4 *rql = reinterpret_cast<const int4 *>(rec_left(recs, n, (uint32_t)pn)), *rqr = reinterpret_cast<const int4 *>(rec_right(recs, n, (uint32_t)pn));
+                const int4 r0 = rql[0], r1 = rql[1], r2 = rqr[0], r3 = rqr[1];
                 const int32_t chl = r1.z, chr = r3.z;
                 const uint32_t split = (uint32_t)pn;                           // a record's name IS its split position
                 const bool go_left = g0 <= split;                             // uniform
@@ -440,8 +440,9 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
         // ---- one descent step per active lane (fp32, conservative).  Written as straight-line selects: the
         // kernel is instruction-issue bound (SQ_ACTIVE_INST_ANY ~ 70 % of its duration), so every exec-mask
         // save/restore the compiler does not have to emit is time.  Idle lanes fetch the root record and ignore it.
-        const float4 *rp = reinterpret_cast<const float4 *>(recs + (active ? node : 0));
-        const float4 a = rp[0], b = rp[1], c = rp[2], d = rp[3];
+        const uint32_t rn = active ? (uint32_t)node : 0u;
+        const float4 *rpl = rec_left(recs, n, rn), *rpr = rec_right(recs, n, rn);
+        const float4 a = rpl[0], b = rpl[1], c = rpr[0], d = rpr[1];
         // child links: internal -> its split (>= 0), leaf j -> ~j; ch.z: REC_L_EXACT / REC_R_EXACT
         const int4 ch = make_int4(__float_as_int(b.z), __float_as_int(d.z), (int)(__float_as_uint(d.w) >> 30), 0);
         // left: lo = (a.x, a.y, a.z) hi = (a.w, b.x, b.y); right: lo = (c.x, c.y, c.z) hi = (c.w, d.x, d.y)
@@ -500,17 +501,20 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
 //     the right, and with records named by split (cd_bvh.h) that chain is reached bottom-up from the leaf itself:
 //     s = i; { test the right child of recs[s]; s = recs[s].last; } until last == n-1 -- one 32-byte read and one
 //     box test per hop, about half the tree height of hops, the lowest (the ones that hit) first.
-//   * The workgroup owns the HALF_BLK consecutive leaves [B0, B_last].  A hop whose cursor s is below B_last reads
-//     recs[s] with s inside that range: the workgroup stages recs[B0 .. B0 + HALF_BLK) in LDS with coalesced loads
-//     first, so these hops -- and every descent step at a node whose split lies in the range -- never touch the
-//     vector memory path (a divergent 16-byte load costs the texture addresser one cache line per lane and clock;
-//     that, not HBM, is what bounds a per-lane descent).
-//   * A lane whose cursor reaches B_last or beyond is on the chain of leaf B_last (the `last` values along a root
-//     path are exactly that chain's cursors), which all lanes of the workgroup share from their joining point
-//     upwards: each wave walks it once with SCALAR loads and every lane that has joined tests the wave-uniform box.
-//   * Phase 1 (both chain parts) only records what it hits (internal sibling -> per-lane LDS stack, leaf ->
-//     candidate queue); phase 2 is variant B's private descent of those subtrees, with work sharing inside the
-//     wave.  Nothing in a sibling subtree is to the left of the query, so phase 2 needs no position test.
+//   * The wave owns the 64 consecutive leaves [g0, g_last].  A hop whose cursor s is below g_last reads the right half
+//     of recs[s] with s inside that range -- a record one of the wave's own lanes was given at the start (one coalesced
+//     fetch of rec_right[g0 .. g0 + 63]): phase 1a reads it out of that lane's registers through the LDS crossbar
+//     (ds_bpermute), touching neither memory nor LDS storage.
+//   * A lane whose cursor reaches g_last or beyond is on the chain of leaf g_last (the `last` values along a root
+//     path are exactly that chain's cursors), which all lanes of the wave share from their joining point upwards:
+//     phase 1b walks it once with SCALAR loads and every lane that has joined tests the wave-uniform box.
+//   * Phase 1 (both parts) only records what it hits (internal sibling -> per-lane LDS stack, leaf -> candidate
+//     queue); phase 2 is variant B's private descent of those subtrees, with work sharing inside the wave.  Nothing
+//     in a sibling subtree is to the left of the query, so phase 2 needs no position test.
+//   What was measured on the way (profiles/r02_experiments/): the kernel's time tracks the instructions it issues
+//   (SQ_ACTIVE_INST_ANY x 4 cycles / 1024 SIMDs ~ its duration in every version), then occupancy; staging a 256-leaf
+//   block of records in LDS made the hops cheap but cost 3 of 8 workgroups per CU (no gain); running the chain inside
+//   the descent loop to overlap the two latencies added more instructions than it hid (slower).
 // ====================================================================================================
 constexpr int HALF_STACK = 8;                // LDS stack entries per lane
 constexpr int HALF_QCAP = 192;               // candidate queue slots per wave
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(TRAV_THREADS, 8) void k_descend_half(QuerySrc src, 
     // phase 1a reads these 8 words of OTHER lanes through the LDS crossbar (ds_bpermute) -- the hops below g_last have
     // their cursor, a split, inside the wave's own 64 leaves, so they touch neither memory nor LDS storage
     float4 rc = make_float4(0.f, 0.f, 0.f, 0.f), rd = rc;
-    if (valid && qi < last_leaf) { const float4 *rp = reinterpret_cast<const float4 *>(recs + qi) + 2; rc = rp[0]; rd = rp[1]; }
+    if (valid && qi < last_leaf) { const float4 *rp = rec_right(recs, n, qi); rc = rp[0]; rd = rp[1]; }
     if (diag) tm1 = __builtin_amdgcn_s_memtime();
     // ---- phase 1a: hops below g_last
     uint32_t s = valid ? qi : END;                                            // cursor; >= g_last: joined the shared chain (or has none: g_last == n-1)
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(TRAV_THREADS, 8) void k_descend_half(QuerySrc src, 
         uint32_t t = g_last;
         for (int hop = 0; hop < 128 && t < last_leaf; ++hop) {
             ++steps;
-            const int4 *rq = reinterpret_cast<const int4 *>(recs + t) + 2;    // wave-uniform address: scalar loads
+            const int4 *rq = reinterpret_cast<const int4 *>(rec_right(recs, n, t));    // wave-uniform address: scalar loads
             const int4 c = rq[0], d = rq[1];
             const bool act = s <= t;                                          // (s == END for lanes without a query: never)
             const bool hit = act & (qlo0 < __int_as_float(c.w)) & (__int_as_float(c.x) < qhi0) & (qlo1 < __int_as_float(d.x)) &
@@ -671,8 +675,10 @@ __global__ __launch_bounds__(TRAV_THREADS, 8) void k_descend_half(QuerySrc src, 
         if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
         ++steps;
         // one descent step per active lane, straight-line selects (see k_descend)
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, d = a;
-        if (active) { const float4 *rp = reinterpret_cast<const float4 *>(recs + node); a = rp[0]; b = rp[1]; c = rp[2]; d = rp[3]; }
+        // (idle lanes fetch record 0 and ignore it: one select for the address instead of fifteen register clears)
+        const uint32_t rn = active ? (uint32_t)node : 0u;
+        const float4 *rpl = rec_left(recs, n, rn), *rpr = rec_right(recs, n, rn);
+        const float4 a = rpl[0], b = rpl[1], c = rpr[0], d = rpr[1];
         const int32_t cl = __float_as_int(b.z), cr = __float_as_int(d.z);
         const uint32_t lw = __float_as_uint(d.w);
         const bool ol  = active & (qlo0 < a.w) & (a.x < qhi0) & (qlo1 < b.x) & (a.y < qhi1) & (qlo2 < b.y) & (a.z < qhi2);
@@ -684,8 +690,11 @@ __global__ __launch_bounds__(TRAV_THREADS, 8) void k_descend_half(QuerySrc src, 
         if (band(intL, intR)) push_subtree(cr);                            // both internal: descend left, push right
         if (band(band(active, !bor(intL, intR)), sptr > 0)) { --sptr; nxt = lds_stack[sptr][tid]; }
         node = active ? nxt : -1;
-        enqueue(band(ol, cl < 0), qi, (uint32_t)~cl | ((lw & REC_L_EXACT) ? qcertain : 0u));
-        enqueue(band(orr, cr < 0), qi, (uint32_t)~cr | ((lw & REC_R_EXACT) ? qcertain : 0u));
+        const bool candL = band(ol, cl < 0), candR = band(orr, cr < 0);
+        if (__builtin_amdgcn_ballot_w64(bor(candL, candR)) != 0ull) {        // (most steps meet no leaf: one test instead of two)
+            enqueue(candL, qi, (uint32_t)~cl | ((lw & REC_L_EXACT) ? qcertain : 0u));
+            enqueue(candR, qi, (uint32_t)~cr | ((lw & REC_R_EXACT) ? qcertain : 0u));
+        }
     }
     if (diag) tm4 = __builtin_amdgcn_s_memtime();
     while (qcount > 0) flush(qcount < 64u ? qcount : 64u);
@@ -770,7 +779,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend_packet(QuerySrc src, u
         // coalesced 64-byte access), then v_readlane broadcasts the 16 dwords into scalar registers.  (A scalar
         // s_load of the record measured ~1.25 us per step here: scalar-cache misses on a 64 MB tree are slow.)
         const int un = __builtin_amdgcn_readfirstlane(node);
-        const int rv = reinterpret_cast<const int *>(recs + un)[lane & 15u];
+        const int rv = reinterpret_cast<const int *>((lane & 8u) ? rec_right(recs, n, (uint32_t)un) : rec_left(recs, n, (uint32_t)un))[lane & 7u];
         struct { float l_lo[3], l_hi[3], r_lo[3], r_hi[3]; int cl, cr; } r;
         r.l_lo[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 0));  r.l_lo[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 1));
         r.l_lo[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 2));  r.l_hi[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 3));
