@@ -268,9 +268,10 @@ __device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ recs, int n,
 
 // Link stored in a record for child `c` (unified Karras id): ~j for leaf j, the child's own split for an internal
 // child -- the decoded left-child id of meta[c] (Karras: the left child's index IS the split position).
-__device__ __forceinline__ int32_t child_link(const NodeMeta *__restrict__ meta, int c, int nleaf_base)
+__device__ __forceinline__ int32_t child_link(const NodeMeta *__restrict__ meta, const int32_t *__restrict__ split_of, int c, int nleaf_base)
 {
     if (c >= nleaf_base) return ~(c - nleaf_base);
+    if (split_of) return split_of[c];                                        // fused build: the splits are an array of their own
     const int mx = meta[c].x;
     return mx >= nleaf_base ? mx - nleaf_base : mx;
 }
@@ -302,10 +303,11 @@ __device__ __forceinline__ Box box_identity()
 
 // Given the exact boxes of both children, write the node's 64-byte fp32 traversal record -- at its SPLIT -- and return
 // the node's exact box (bvh.cuh:277 merge(childA, childB)).
-__device__ __forceinline__ Box emit_node(const Box &bl, const Box &br, const NodeMeta *__restrict__ meta, int cl, int cr, int split, int first, int last,
-                                         NodeRec32 *__restrict__ recs32, int nleaf_base)
+__device__ __forceinline__ Box emit_node(const Box &bl, const Box &br, const NodeMeta *__restrict__ meta, const int32_t *__restrict__ split_of,
+                                         int cl, int cr, int split, int first, int last, NodeRec32 *__restrict__ recs32, int nleaf_base)
 {
-    store_rec32(recs32, nleaf_base + 1, (uint32_t)split, bl, br, make_int2(child_link(meta, cl, nleaf_base), child_link(meta, cr, nleaf_base)), (uint32_t)first, (uint32_t)last);
+    store_rec32(recs32, nleaf_base + 1, (uint32_t)split, bl, br, make_int2(child_link(meta, split_of, cl, nleaf_base), child_link(meta, split_of, cr, nleaf_base)),
+                (uint32_t)first, (uint32_t)last);
     return box_merge(bl, br);
 }
 
@@ -326,21 +328,68 @@ __device__ __forceinline__ Box seg_query_lds(const double (*t)[6], int l, int r)
     return box_merge(accL, accR);
 }
 
+// FUSED (the fused entry points, cd_self_collide / cd_build_tree / cd_multi_step): the kernel also BUILDS the hierarchy of
+// the nodes whose range stays inside its 512 leaves (about 98 % of them) instead of reading it from k_hierarchy's meta[]:
+//   * dl[p] = delta(p, p+1) + 1 for the positions b0-1 .. b0+512 as BYTES in LDS (0 = the out-of-range -1 of bvh.cuh:48);
+//     delta(i, j) of any range is the minimum of the adjacent deltas inside it (sorted keys, index tie-break), and
+//     adjacent deltas that bound a node are pairwise distinct, so determineRange (bvh.cuh:100-123) is a nearest-smaller-
+//     value query and findSplit (bvh.cuh:57-98) the position of the range minimum;
+//   * both are answered from a min-sparse-table over dl (10 levels, 5 KB) with a fixed 10-step descent: every node costs
+//     the same ~22 byte reads, where k_hierarchy's galloping / binary searches over the 64-bit keys in memory make a wave
+//     wait for its widest node (5.7 x the useful probes);
+//   * a node whose search runs off the block goes on the cross list; k_cross_meta then finds its range with the global
+//     searches of k_hierarchy, and k_refit_seg_cross its boxes.  split_of[i] is written for every node (child links).
+// meta[] / parent[] (the reference's tree, what cd_export_tree and the verifier read) are then not written at all:
+// the host materialises them with k_hierarchy when somebody asks (mi355cd.hip).
+constexpr int DL_N = REFIT_BLK + 2;             // dl positions b0-1 .. b0+512
+constexpr int DL_LEVELS = 10;                   // 2^9 = 512 < DL_N <= 2^10
+constexpr int DL_STRIDE = 520;
+
+// first p >= s (p < DL_N) with dl[p] < thr, or DL_N; T = the sparse table, T[k][x] = min(dl[x .. x + 2^k - 1])
+__device__ __forceinline__ int nsv_right(const uint8_t (*T)[DL_STRIDE], int s, int thr)
+{
+    int p = s;
+#pragma unroll
+    for (int k = DL_LEVELS - 1; k >= 0; --k) { const int q = p + (1 << k); if (q <= DL_N && (int)T[k][p < DL_N ? p : 0] >= thr) p = q; }
+    return p;
+}
+// last p <= s (p >= 0) with dl[p] < thr, or -1
+__device__ __forceinline__ int psv_left(const uint8_t (*T)[DL_STRIDE], int s, int thr)
+{
+    int p = s;
+#pragma unroll
+    for (int k = DL_LEVELS - 1; k >= 0; --k) { const int q = p - (1 << k); if (q >= -1 && (int)T[k][q + 1 >= 0 ? q + 1 : 0] >= thr) p = q; }
+    return p;
+}
+
+template <bool FUSED>
 __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n,
+                                                               const uint64_t *__restrict__ keys /* FUSED */, int32_t *__restrict__ split_of /* FUSED */,
                                                                const NodeMeta *__restrict__ meta,
                                                                double *__restrict__ boxes, uint32_t *__restrict__ bounded,
                                                                NodeRec32 *__restrict__ recs32, LeafBox32 *__restrict__ qbox32,
                                                                int32_t *__restrict__ root_name, int write_internal /* 0: FP64 boxes of the root and the leaves only */,
                                                                double *__restrict__ seg /* P x 6, heap order, node 0 unused */, int nbp2,
-                                                               int32_t *__restrict__ cross_list /* 64 shards x cross_cap */, uint32_t *__restrict__ cross_count /* [64] */,
+                                                               int32_t *__restrict__ cross_list /* cross_cap entries */, uint32_t *__restrict__ cross_count /* its length */,
                                                                uint32_t cross_cap)
 {
     __shared__ double t[2 * REFIT_BLK][6];          // 48 KB
-    __shared__ int32_t lcross[REFIT_BLK];
+    __shared__ int32_t lcross[FUSED ? 64 : REFIT_BLK];   // (FUSED: a block has about 13 cross nodes; a full list spills straight to memory)
     __shared__ uint32_t lcount, lbase;
+    __shared__ uint8_t dt[FUSED ? DL_LEVELS : 1][DL_STRIDE];
+    __shared__ int16_t lsplit[FUSED ? REFIT_BLK : 1];
     if (threadIdx.x == 0) lcount = 0;
     const int b = blockIdx.x, b0 = b * REFIT_BLK, tid = threadIdx.x;
     const int j = b0 + tid;
+    if (FUSED) {
+        // adjacent deltas of the positions b0-1 .. b0+512 (thread t: position b0-1+t; threads 0 and 1 also take the last two)
+        for (int x = tid; x < DL_STRIDE; x += REFIT_BLK) {
+            uint8_t v = 0;
+            const int p = b0 - 1 + x;
+            if (x < DL_N && p >= 0 && p < n - 1) v = (uint8_t)(delta_k(keys, n, p, keys[p], p + 1) + 1);
+            dt[0][x] = x < DL_N ? v : (uint8_t)255;
+        }
+    }
     Box mine = box_identity();
     if (j < n) {
         const LeafTri lt = leaf[j];
@@ -356,8 +405,17 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
         d[0] = mine.x1; d[1] = mine.x2; d[2] = mine.y1; d[3] = mine.y2; d[4] = mine.z1; d[5] = mine.z2;
     }
     // build the 9 levels above the leaves; global index of local node k at depth dd: ((nbp2 + b) << dd) + (k - 2^dd)
+    // (FUSED: the same barriers build the sparse table of the deltas, one level each)
     for (int dd = REFIT_LOG - 1; dd >= 0; --dd) {
         __syncthreads();
+        if (FUSED) {
+            const int k = REFIT_LOG - dd;                                  // levels 1 .. 9 here, level 10 - 1 = 9 is the last: DL_LEVELS - 1
+            for (int x = tid; x < DL_STRIDE; x += REFIT_BLK) {
+                const int y = x + (1 << (k - 1));
+                const uint8_t u = dt[k - 1][x], w = y < DL_STRIDE ? dt[k - 1][y] : (uint8_t)255;
+                dt[k][x] = u < w ? u : w;
+            }
+        }
         const int cnt = 1 << dd;
         if (tid < cnt) {
             const int k = cnt + tid;
@@ -369,30 +427,80 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
     }
     __syncthreads();
     const int i = j;                                                   // internal node with the same index
-    if (i < n - 1) {
+    int first = 0, last = 0, split = 0; bool have = false, cross = false;
+    if (FUSED) {
+        if (i < n - 1) {
+            // determineRange, bvh.cuh:100-123, on the adjacent deltas: dl index of position p is p - (b0 - 1)
+            const int x = tid;                                             // dl index of position i - 1; position i is x + 1
+            const int dL = (int)dt[0][x], dR = (int)dt[0][x + 1];
+            const bool right = dR >= dL;                                   // d = sign(delta(i, i+1) - delta(i, i-1)); equal only when both are out of range
+            const int thr = right ? dL : dR;                               // delta_min + 1
+            if (right) {
+                // j = first position p > i with delta(p, p+1) < delta_min  (leaf p is the last of the range)
+                // (node 0 has delta_min = -1, nothing is below it: its range is everything)
+                const int p = (thr == 0) ? ((n - 1 <= b0 + REFIT_BLK - 1) ? (n - 1) - (b0 - 1) : DL_N) : nsv_right(dt, x + 2, thr);
+                first = i; last = b0 - 1 + p;
+                have = p <= REFIT_BLK;                                       // dl index 512 is position b0+511, the block's last leaf
+                cross = !have;
+            } else {
+                // j = 1 + last position p < i - 1 with delta(p, p+1) < delta_min
+                const int p = psv_left(dt, x - 1, thr);
+                if (p < 0) cross = true;                                    // ran off the block (dl index 0 is position b0-1: found there means the range starts at b0)
+                else { first = b0 - 1 + p + 1; last = i; have = true; }
+            }
+            if (have) {
+                // findSplit, bvh.cuh:57-98: the position of the (unique) minimum adjacent delta inside [first, last - 1]
+                const int a = first - (b0 - 1), e = last - 1 - (b0 - 1);   // dl indices
+                const int len = e - a + 1;
+                const int k = 31 - __clz(len);
+                const int m0 = (int)dt[k][a], m1 = (int)dt[k][e - (1 << k) + 1];
+                const int mn = m0 < m1 ? m0 : m1;
+                split = b0 - 1 + nsv_right(dt, a, mn + 1);
+            }
+            lsplit[tid] = have ? (int16_t)(split - b0) : (int16_t)-1;
+            if (have) split_of[i] = split;
+            if (cross) {
+                const uint32_t k = atomicAdd(&lcount, 1u);
+                if (k < 64u) lcross[k] = i;
+                else { const uint32_t g = atomicAdd(cross_count, 1u); if (g < cross_cap) cross_list[g] = i; }
+            }
+        }
+        __syncthreads();                                                    // lsplit of the whole block (child links)
+    } else if (i < n - 1) {
         const NodeMeta m = meta[i];
-        const int first = min(i, m.z), last = max(i, m.z);
+        first = min(i, m.z); last = max(i, m.z);
         if (first < b0 || last >= b0 + REFIT_BLK) {
             lcross[atomicAdd(&lcount, 1u)] = i;                        // leaves the block: k_refit_seg_cross
-        } else {
-            const int split = (m.x >= n - 1) ? m.x - (n - 1) : m.x;    // childA covers [first, split], childB [split+1, last]
+        } else { have = true; split = (m.x >= n - 1) ? m.x - (n - 1) : m.x; }    // childA covers [first, split], childB [split+1, last]
+    }
+    if (have) {
+        {
+            // children as unified Karras ids (bvh.cuh:174-195): the left child is leaf `split` or internal node `split`
+            const int ca = (split == first) ? (n - 1) + split : split, cb = (split + 1 == last) ? (n - 1) + split + 1 : split + 1;
             const Box bl = seg_query_lds(t, first - b0, split - b0);
             const Box br = seg_query_lds(t, split + 1 - b0, last - b0);
-            const Box whole = emit_node(bl, br, meta, m.x, m.y, split, first, last, recs32, n - 1);
+            Box whole;
+            if (FUSED) {
+                // both children are nodes of this block: their splits are in lsplit
+                const int32_t la = (ca >= n - 1) ? ~(ca - (n - 1)) : b0 + (int)lsplit[ca - b0], lb = (cb >= n - 1) ? ~(cb - (n - 1)) : b0 + (int)lsplit[cb - b0];
+                store_rec32(recs32, n, (uint32_t)split, bl, br, make_int2(la, lb), (uint32_t)first, (uint32_t)last);
+                whole = box_merge(bl, br);
+            } else whole = emit_node(bl, br, meta, nullptr, ca, cb, split, first, last, recs32, n - 1);
             // The FP64 boxes of internal nodes are the OUTPUT of calBoundingBox (bvh.cuh:277), not something the fused
             // path reads (its traversal works on the records, the exact kernel on leaf boxes): written on request only
             if (write_internal || i == 0) store_box(boxes, i, whole);
             if (i == 0) *root_name = split;
-            bounded[i] = 2;                                            // Node::bounded (bvh.cuh:270): both children merged
+            if (!FUSED || write_internal) bounded[i] = 2;              // Node::bounded (bvh.cuh:270): both children merged
         }
     }
     __syncthreads();
-    // hand the block's cross nodes over: one global atomic per workgroup, on its shard's counter
-    const uint32_t shard = b & 63u, cnt = lcount;
+    // hand the block's cross nodes over: ONE global atomic per workgroup on the list's length (about 2 000 workgroups
+    // finishing over the kernel's duration: ~30 returning atomics per microsecond on that word, a third of what it takes)
+    const uint32_t cnt = FUSED ? min(lcount, 64u) : lcount;
     if (cnt == 0) return;
-    if (tid == 0) lbase = atomicAdd(&cross_count[shard], cnt);
+    if (tid == 0) lbase = atomicAdd(cross_count, cnt);
     __syncthreads();
-    if ((uint32_t)tid < cnt && lbase + tid < cross_cap) cross_list[(size_t)shard * cross_cap + lbase + tid] = lcross[tid];
+    if ((uint32_t)tid < cnt && lbase + tid < cross_cap) cross_list[lbase + tid] = lcross[tid];
 }
 
 // Levels above the 512-leaf blocks: heap nodes [1, nbp2).  One workgroup; children at or beyond the last real
@@ -540,32 +648,78 @@ __device__ __forceinline__ Box seg_query_halves(const double *__restrict__ seg, 
     return x;
 }
 
+// Fused build: range and split of the cross nodes (the ~2 % whose range leaves their 512-leaf block), by the searches of
+// generateHierarchyParallel (bvh.cuh:146-199) -- each of which looks for the last position at which a monotone predicate
+// on delta still holds.  A few thousand nodes on a whole chip is pure latency, so ONE WAVE takes a node and every round
+// probes 64 positions at once (all doublings of the galloping phase in one round, then 64 cut points per round): the
+// same answers in 4-6 dependent round trips instead of 40-60.  Writes meta[i] (what k_refit_seg_cross reads) and
+// split_of[i] (child links).
+// largest x in [lo, hi) with pred(x), given pred(lo) and !pred(hi) (pred is wave-uniformly monotone: true ... true false ... false)
+template <class Pred>
+__device__ __forceinline__ int wave_last_true(int lo, int hi, int lane, Pred pred)
+{
+    while (hi - lo > 1) {                                                   // (wave-uniform)
+        const int w = hi - lo;
+        const int step = (w + 63) >> 6;
+        const long long x = (long long)lo + (long long)lane * step;
+        const bool ok = x < hi && (lane == 0 || pred((int)x));
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);       // a prefix of the lanes
+        const int top = 63 - __clzll((long long)m);                         // bit 0 is always set
+        const int nlo = lo + top * step;
+        hi = (nlo + step < hi) ? nlo + step : hi;
+        lo = nlo;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_cross_meta(const uint64_t *__restrict__ keys, int n, NodeMeta *__restrict__ meta, int32_t *__restrict__ split_of,
+                                                    const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t total = min(*dense_total, dense_cap);
+    for (uint32_t k = blockIdx.x * 4 + (tid >> 6); k < total; k += gridDim.x * 4) {   // one wave per node (k is wave-uniform)
+        const int i = __builtin_amdgcn_readfirstlane(dense[k]);
+        const uint64_t ki = keys[i];
+        const int d = (delta_k(keys, n, i, ki, i + 1) - delta_k(keys, n, i, ki, i - 1)) >= 0 ? 1 : -1;
+        const int delta_min = delta_k(keys, n, i, ki, i - d);
+        // galloping phase: lane L asks about 2^(L+1); the first "no" is mlen (a position outside the keys says no)
+        int mlen;
+        {
+            const long long o = (long long)i + (long long)d * (2ll << (lane < 31 ? lane : 31));
+            const bool yes = lane < 31 && o >= 0 && o < n && delta_k(keys, n, i, ki, (int)o) > delta_min;
+            const unsigned long long m = ~__builtin_amdgcn_ballot_w64(yes);   // lanes >= 31 always say no
+            mlen = 2 << (__ffsll((long long)m) - 1);
+        }
+        const int l = wave_last_true(mlen >> 1, mlen, lane, [&](int x) { return delta_k(keys, n, i, ki, i + x * d) > delta_min; });
+        const int j = i + l * d;
+        const int first = min(i, j), last = max(i, j);
+        const uint64_t kf = keys[first];
+        const int common = delta_k(keys, n, first, kf, last);
+        // findSplit: the last s in [first, last) with delta(first, s) > common (s == first counts as yes)
+        const int split = wave_last_true(first, last, lane, [&](int x) { return delta_k(keys, n, first, kf, x) > common; });
+        if (lane == 0) {
+            const int a = (split == first) ? (n - 1) + split : split;
+            const int b = (split + 1 == last) ? (n - 1) + split + 1 : split + 1;
+            meta[i] = make_int4(a, b, j, 0);
+            split_of[i] = split;
+        }
+    }
+}
+
 // Nodes whose range leaves their 512-leaf block: one WAVE per node, its two range queries side by side in the two
 // halves of the wave (seg_query_halves; ranges of 65536 leaves or more take two full-wave queries).
 // Queries read only leaf boxes and segment-tree nodes, never another cross node's output: no ordering needed.
 __global__ __launch_bounds__(256) void k_refit_seg_cross(int n, const NodeMeta *__restrict__ meta, const double *__restrict__ seg, int nbp2,
                                                          double *boxes, uint32_t *__restrict__ bounded, NodeRec32 *__restrict__ recs32,
+                                                         const int32_t *__restrict__ split_of /* fused build: child links come from here, not from meta */,
                                                          int32_t *__restrict__ root_name, int write_internal,
-                                                         const int32_t *__restrict__ cross_list, const uint32_t *__restrict__ cross_count, uint32_t cross_cap)
+                                                         const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap)
 {
-    __shared__ uint32_t pre[65];
     const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < 64) {
-        uint32_t c = cross_count[tid];
-        if (c > cross_cap) c = cross_cap;
-        uint32_t v = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(v, o); if (lane >= o) v += u; }
-        pre[tid + 1] = v;
-        if (tid == 0) pre[0] = 0;
-    }
-    __syncthreads();
-    const uint32_t total = pre[64];
+    const uint32_t total = min(*dense_total, dense_cap);
     const long long P = (long long)nbp2 * REFIT_BLK;
     for (uint32_t k = blockIdx.x * 4 + (tid >> 6); k < total; k += gridDim.x * 4) {   // one wave per node (k is wave-uniform)
-        int lo = 0, hi = 64;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= k) lo = mid; else hi = mid; }
-        const int i = cross_list[(size_t)lo * cross_cap + (k - pre[lo])];
+        const int i = __builtin_amdgcn_readfirstlane(dense[k]);
         const NodeMeta m = meta[i];
         const int first = min(i, m.z), last = max(i, m.z);
         const int split = (m.x >= n - 1) ? m.x - (n - 1) : m.x;
@@ -580,10 +734,10 @@ __global__ __launch_bounds__(256) void k_refit_seg_cross(int n, const NodeMeta *
             br = seg_query_wave(seg, boxes, n, P, split + 1, last, lane);
         }
         if (lane == 0) {
-            const Box whole = emit_node(bl, br, meta, m.x, m.y, split, first, last, recs32, n - 1);
+            const Box whole = emit_node(bl, br, meta, split_of, m.x, m.y, split, first, last, recs32, n - 1);
             if (write_internal || i == 0) store_box(boxes, i, whole);
             if (i == 0) *root_name = split;
-            bounded[i] = 2;
+            if (!split_of || write_internal) bounded[i] = 2;
         }
     }
 }

@@ -212,8 +212,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         {
             Prezeroed fused(c);
             rc = enqueue_morton_sort(c);
-            if (!rc) rc = enqueue_hierarchy(c, false);
-            if (!rc) rc = enqueue_refit(c, c->trav_variant == 0);
+            if (!rc) rc = enqueue_tree(c);
         }
         if (rc) return rc;                        // (an enqueue failure is a HIP error on this rank: nothing collective has started in this attempt)
         mark(ME_TREE, s);

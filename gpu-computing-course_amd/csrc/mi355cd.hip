@@ -69,6 +69,10 @@ struct cd_ctx {
     double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec32 *d_recs32 = nullptr; LeafBox32 *d_qbox = nullptr;
     int32_t *d_root = nullptr;              // name (split) of the root record, one word inside d_small
     bool internal_boxes_valid = false;      // the FP64 boxes of the internal nodes were written by the last refit (fused calls skip them)
+    int32_t *d_split_of = nullptr;          // fused build: split of every internal node (child links of the records)
+    bool hierarchy_valid = false;           // meta[] / parent[] hold the tree of the current keys (fused calls build the records without them)
+    bool last_tree_fused = false;           // the last fused call built hierarchy + refit in one pass (ms_hierarchy is then part of ms_refit)
+    uint32_t dbg_no_fused_build = 0;        // debug key 104: fused entry points run k_hierarchy + the meta-reading refit (A/B)
     uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
     // traversal
     TravBuf tb[2];
@@ -98,7 +102,7 @@ void free_all(cd_ctx *c)
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_cross); hipFree(c->d_boxes);
-    hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox);
+    hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox); hipFree(c->d_split_of);
     for (TravBuf &tb : c->tb) {
         if (tb.d_pairs) hipFree(reinterpret_cast<char *>(tb.d_pairs) - sizeof(Report));
         if (tb.h_report) hipHostFree(tb.h_report);
@@ -128,7 +132,14 @@ int ensure_pairs(cd_ctx *c, TravBuf &tb, uint64_t cap)
     return 0;
 }
 
-float elapsed(cd_ctx *c, int a, int b) { float ms = 0.f; hipEventElapsedTime(&ms, c->ev[a], c->ev[b]); return ms; }
+// (an event that was never recorded -- stage events off -- makes hipEventElapsedTime fail: that is "no measurement",
+//  not an error of the call in progress, so the sticky last-error is cleared)
+float elapsed(cd_ctx *c, int a, int b)
+{
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) != hipSuccess) { (void)hipGetLastError(); return 0.f; }
+    return ms;
+}
 
 // Per-stage events cost a few microseconds of idle GPU each (two per stage boundary).  With CD_OPT_STAGE_TIMING 0
 // only the events the roofline needs are recorded: pipeline start, descent start / end, pipeline end.
@@ -200,34 +211,62 @@ int enqueue_hierarchy(cd_ctx *c, bool poison_boxes)
     c->leaves_filled = false;
     if (n > 1)
         k_hierarchy<<<cdiv(n - 1, 256), 256, 0, s>>>(c->d_keys[0], (int)n, c->d_meta, c->d_parent, c->d_small);
+    c->hierarchy_valid = true;
     HIPCHK(evrec(c, EV_HIER1));
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-int enqueue_refit(cd_ctx *c, bool write_internal)
+// fused: the local kernel builds the hierarchy of its block itself (cd_bvh.h, k_refit_seg_local<true>) and k_cross_meta
+// that of the cross nodes: no k_hierarchy before it, meta[] / parent[] are not written.
+int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
 {
     const uint32_t n = c->nt;
     hipStream_t s = c->stream;
     HIPCHK(evrec(c, EV_REFIT0));
     const int nblocks = (int)cdiv(n, REFIT_BLK);
-    // cross-node lists: 64 shards x cross_cap entries (a shard takes the blocks b with b % 64 == shard, each
-    // contributing at most 512 nodes); their 64 counters in d_small[16..79]
+    // the cross-node list (nodes whose range leaves their 512-leaf block) and its length, d_small[16]
     int32_t *cross_list = c->d_cross;
     uint32_t *cross_count = c->d_small + 16;
     if (!c->prezeroed) HIPCHK(hipMemsetAsync(cross_count, 0, 64 * sizeof(uint32_t), s));
-    k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded, c->d_recs32, c->d_qbox,
-                                                   c->d_root, write_internal ? 1 : 0, c->d_seg, (int)c->nbp2,
-                                                   cross_list, cross_count, c->cross_cap);
+    if (fused) {
+        if (!c->leaves_filled)                       // (the 8-pass sort does not fill the leaves; enqueue_hierarchy would have)
+            k_fill_leaves<<<cdiv(n, 256), 256, 0, s>>>(c->d_perm[0], c->d_vidx, c->d_ids, n, c->d_leaf, c->d_parent, c->d_bounded, nullptr);
+        c->leaves_filled = false;
+        c->hierarchy_valid = false;
+        k_refit_seg_local<true><<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_keys[0], c->d_split_of, c->d_meta, c->d_boxes, c->d_bounded,
+                                                             c->d_recs32, c->d_qbox, c->d_root, write_internal ? 1 : 0, c->d_seg, (int)c->nbp2,
+                                                             cross_list, cross_count, c->cross_cap);
+    } else
+        k_refit_seg_local<false><<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, nullptr, nullptr, c->d_meta, c->d_boxes, c->d_bounded,
+                                                              c->d_recs32, c->d_qbox, c->d_root, write_internal ? 1 : 0, c->d_seg, (int)c->nbp2,
+                                                              cross_list, cross_count, c->cross_cap);
     k_refit_seg_top<<<1, 1024, 0, s>>>(c->d_seg, (int)c->nbp2, nblocks);
     // about 13 cross nodes per 512-leaf block: ~one node per wave, every load chain in flight at once
-    const uint32_t xblocks = nblocks * 4 < 256u ? 256u : (nblocks * 4 > 16384u ? 16384u : nblocks * 4);
+    // one wave per cross node, about 13 of them per 512-leaf block: two workgroups (8 waves) per block -> 1-2 nodes per wave
+    // (measured: 1024 / 2048 / 4096 / 8192 workgroups at 1 M triangles -> 120 / 113 / 111 / 112 us for the whole stage)
+    const uint32_t xblocks = 2u * nblocks < 256u ? 256u : (2u * nblocks > 16384u ? 16384u : 2u * (uint32_t)nblocks);
+    if (fused && n > 1) k_cross_meta<<<xblocks, 256, 0, s>>>(c->d_keys[0], (int)n, c->d_meta, c->d_split_of, c->d_cross, cross_count, c->cross_cap);
     if (n > 1) k_refit_seg_cross<<<xblocks, 256, 0, s>>>((int)n, c->d_meta, c->d_seg, (int)c->nbp2, c->d_boxes, c->d_bounded, c->d_recs32,
-                                                      c->d_root, write_internal ? 1 : 0, c->d_cross, cross_count, c->cross_cap);
+                                                      fused ? c->d_split_of : nullptr, c->d_root, write_internal ? 1 : 0, c->d_cross, cross_count, c->cross_cap);
     c->internal_boxes_valid = write_internal;
     HIPCHK(evrec(c, EV_REFIT1));
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+// Hierarchy + refit of a fused call: one pass that builds the records straight from the sorted keys (no k_hierarchy, no
+// meta[] / parent[]), unless the traversal in use walks the reference-shaped tree (variant 0) or the A/B switch says so.
+int enqueue_tree(cd_ctx *c)
+{
+    c->last_tree_fused = false;
+    if (c->trav_variant == 0 || c->dbg_no_fused_build) {
+        int rc = enqueue_hierarchy(c, false);
+        if (!rc) rc = enqueue_refit(c, c->trav_variant == 0, false);
+        return rc;
+    }
+    c->last_tree_fused = true;
+    return enqueue_refit(c, false, true);
 }
 
 // Launch one traversal pass (shallow: all queries from the root; deep: the deferred (query, subtree) items).
@@ -334,8 +373,9 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
     int rc = ensure_pairs(c, tb, cap_pairs > 0 ? cap_pairs : 1);
     if (rc) return rc;
     const int per_pass = c->trav_variant == 0 ? 1 : 2;
-    if (c->trav_variant == 0 && !c->internal_boxes_valid) {                // variant 0 walks the FP64 boxes of the internal nodes
-        if ((rc = enqueue_refit(c, true))) return rc;
+    if (c->trav_variant == 0 && !(c->internal_boxes_valid && c->hierarchy_valid)) {   // variant 0 walks meta[] and the FP64 boxes of the internal nodes
+        if (!c->hierarchy_valid && (rc = enqueue_hierarchy(c, false))) return rc;
+        if ((rc = enqueue_refit(c, true, false))) return rc;
     }
     uint32_t launches = 0;
     float deep_ms = 0.f;
@@ -496,12 +536,13 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_parent, sizeof(int32_t) * 2 * n);
     { uint32_t nb = cdiv(nt, REFIT_BLK); c->nbp2 = 1; while (c->nbp2 < nb) c->nbp2 <<= 1; }
     ALLOC(c->d_seg, sizeof(double) * 6 * (size_t)c->nbp2 * REFIT_BLK);
-    c->cross_cap = (cdiv(nt, REFIT_BLK) / 64 + 1) * REFIT_BLK;
-    ALLOC(c->d_cross, sizeof(int32_t) * 64 * (size_t)c->cross_cap);
+    c->cross_cap = nt;                                  // every internal node could be one (it never is: about 2 %)
+    ALLOC(c->d_cross, sizeof(int32_t) * (size_t)c->cross_cap);
     ALLOC(c->d_boxes, sizeof(double) * 6 * 2 * n);
     ALLOC(c->d_bounded, sizeof(uint32_t) * n);
     ALLOC(c->d_recs32, sizeof(NodeRec32) * n);
     ALLOC(c->d_qbox, sizeof(LeafBox32) * n);
+    ALLOC(c->d_split_of, sizeof(int32_t) * n);
     c->tb[0].cand_cap = ((4 * n > (1u << 20) ? 4 * n : (1u << 20)) + NSHARD - 1) / NSHARD * NSHARD;
     ALLOC(c->tb[0].d_cand, sizeof(Candidates) * c->tb[0].cand_cap);
     c->tb[0].defer_cap = 1u << 16;
@@ -611,8 +652,10 @@ int cd_refit_boxes(cd_ctx *c)
 // them afterwards -- the exported tree, checkInternalNodes' uninitialised-box counter -- gets them from a full refit.
 static int materialise_internal_boxes(cd_ctx *c)
 {
-    if (c->stage < ST_REFIT || c->internal_boxes_valid || c->nt < 2) return CD_OK;
-    const int rc = enqueue_refit(c, true);
+    if (c->stage < ST_REFIT || (c->internal_boxes_valid && c->hierarchy_valid)) return CD_OK;
+    int rc = CD_OK;
+    if (!c->hierarchy_valid) rc = enqueue_hierarchy(c, false);             // k_fill_leaves (parent links reset) + k_hierarchy on the current keys
+    if (!rc) rc = enqueue_refit(c, true, false);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     return CD_OK;
@@ -622,7 +665,7 @@ static int run_check(cd_ctx *c, int which, uint32_t maxv, uint32_t *out, int nou
 {
     if (!c || !out) return CD_ERR_ARG;
     if (c->stage < ST_BUILT) return CD_ERR_ORDER;
-    if (which == 0) { const int rm = materialise_internal_boxes(c); if (rm) return rm; }
+    if (which != 2) { const int rm = materialise_internal_boxes(c); if (rm) return rm; }    // meta / parent / boxes of the reference-shaped tree
     const int n = (int)c->nt;
     hipStream_t s = c->stream;
     HIPCHK(hipEventRecord(c->ev[EV_CHK0], s));
@@ -654,8 +697,7 @@ int cd_build_tree(cd_ctx *c)
     int rc;
     Prezeroed fused(c);                                                    // one memset for every counter of the pipeline
     rc = enqueue_morton_sort(c);
-    if (!rc) rc = enqueue_hierarchy(c, false);
-    if (!rc) rc = enqueue_refit(c, c->trav_variant == 0);
+    if (!rc) rc = enqueue_tree(c);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));   // words 8..16
     HIPCHK(hipMemcpyAsync(c->root_box_host, c->d_boxes, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
@@ -666,7 +708,7 @@ int cd_build_tree(cd_ctx *c)
     if (c->stage_events) {
         c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
         c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
-        c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);
+        c->stats.ms_hierarchy = c->last_tree_fused ? 0.f : elapsed(c, EV_HIER0, EV_HIER1);
         c->stats.ms_refit = elapsed(c, EV_REFIT0, EV_REFIT1);
     }
     c->root_box_valid = true;
@@ -680,8 +722,7 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     int rc;
     Prezeroed fused(c);                                                    // one memset for every counter of the pipeline
     rc = enqueue_morton_sort(c);
-    if (!rc) rc = enqueue_hierarchy(c, false);
-    if (!rc) rc = enqueue_refit(c, c->trav_variant == 0);
+    if (!rc) rc = enqueue_tree(c);
     if (!rc) rc = run_traversal(c, c->tb[0], nullptr, 0, pairs, cap_pairs, n_pairs);     // synchronises
     fused.done();
     if (rc < 0) return rc;
@@ -691,7 +732,7 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     if (c->stage_events) {
         c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
         c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
-        c->stats.ms_hierarchy = elapsed(c, EV_HIER0, EV_HIER1);
+        c->stats.ms_hierarchy = c->last_tree_fused ? 0.f : elapsed(c, EV_HIER0, EV_HIER1);
         c->stats.ms_refit = elapsed(c, EV_REFIT0, EV_REFIT1);
     } else c->stats.ms_morton = c->stats.ms_sort = c->stats.ms_hierarchy = c->stats.ms_refit = 0.f;
     c->stats.ms_pipeline = elapsed(c, EV_MORTON0, EV_TRAV1) + (c->stats.ms_traverse - elapsed(c, EV_TRAV0, EV_TRAV1));   // + deep pass, if any
@@ -807,6 +848,7 @@ int cd_export_tree(cd_ctx *c, int32_t *parent, int32_t *left, int32_t *right, do
     if (!c) return CD_ERR_ARG;
     if (c->stage < ST_BUILT) return CD_ERR_ORDER;
     const size_t n = c->nt;
+    { const int rm = materialise_internal_boxes(c); if (rm) return rm; }      // after a fused call: the reference-shaped tree is built on request
     if (parent) HIPCHK(hipMemcpy(parent, c->d_parent, sizeof(int32_t) * (2 * n - 1), hipMemcpyDeviceToHost));
     if ((left || right) && n > 1) {
         std::vector<int4> m(n - 1);
@@ -814,7 +856,7 @@ int cd_export_tree(cd_ctx *c, int32_t *parent, int32_t *left, int32_t *right, do
         for (size_t i = 0; i < n - 1; ++i) { if (left) left[i] = m[i].x; if (right) right[i] = m[i].y; }
     }
     if (boxes || bounded) { if (c->stage < ST_REFIT) return CD_ERR_ORDER; }
-    if (boxes) { const int rm = materialise_internal_boxes(c); if (rm) return rm; }
+
     if (boxes) HIPCHK(hipMemcpy(boxes, c->d_boxes, sizeof(double) * 6 * (2 * n - 1), hipMemcpyDeviceToHost));
     if (bounded && n > 1) HIPCHK(hipMemcpy(bounded, c->d_bounded, sizeof(uint32_t) * (n - 1), hipMemcpyDeviceToHost));
     return CD_OK;
@@ -843,6 +885,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
     if (key == 102) { c->dbg_no_shared_path = (uint32_t)value; return CD_OK; }
     if (key == 103) { c->dbg_diag = (uint32_t)value; return CD_OK; }
+    if (key == 104) { c->dbg_no_fused_build = (uint32_t)value; return CD_OK; }
     if (key == 101) { if (value < 1 || value > 65535) return CD_ERR_ARG; c->exact_blocks = (int)value; return CD_OK; }
     return CD_ERR_ARG;
 }
