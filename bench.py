@@ -33,6 +33,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TRAVERSAL_BYTES_PER_TRI = 40.0   # box 24 + links 8 + leaf payload ~8 amortised, read once
+BUILD_BYTES_PER_TRI = 100.0      # SURVEY.md 8d rows S3 + S4: hierarchy 24 + refit 76 -- what the fused block-build kernel does in one pass
 TOTAL_BYTES_PER_TRI = 460.0      # whole path, compact layouts
 
 
@@ -63,21 +64,39 @@ def cpu_baseline(verts, vidx, reps=3):
         nproc = len(os.sched_getaffinity(0))
     except AttributeError:
         nproc = os.cpu_count() or 1
+    # a container's CPU share is a cgroup quota, which the affinity mask does not show: more threads than the quota only
+    # fight each other (256 threads on a 16-CPU share ran 3x SLOWER than one core), so the thread count is swept and the
+    # best one reported, with the mask's size beside it
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max") and txt[0] != "max":
+                quota = max(1, int(round(int(txt[0]) / int(txt[1]))))
+            elif path.endswith("cfs_quota_us") and int(txt[0]) > 0:
+                quota = max(1, int(round(int(txt[0]) / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))))
+            if quota:
+                break
+        except Exception:
+            pass
     out["nproc"] = nproc
+    out["cgroup_cpu_quota"] = quota
     if nproc > 1:
-        oracle.self_collide(verts[:30000], vidx[:10000], want_pairs=False, threads=nproc)       # start the thread pool
+        tries = sorted({t for t in (8, 16, 32, 64, quota or 0, nproc) if 1 < t <= nproc and t <= 128})
         best2 = None
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            _, st2, tm2 = oracle.self_collide(verts, vidx, want_pairs=False, threads=nproc)
-            dt2 = time.perf_counter() - t0
-            if best2 is None or dt2 < best2[0]:
-                best2 = (dt2, st2, tm2)
-        dt2, st2, tm2 = best2
-        out["omp"] = {"value": st2.pairs_tested / dt2, "cores": nproc, "total_collision_ms": dt2 * 1e3,
+        for th in tries:
+            oracle.self_collide(verts[:30000], vidx[:10000], want_pairs=False, threads=th)        # (re)size the thread pool
+            for _ in range(2):
+                t0 = time.perf_counter()
+                _, st2, tm2 = oracle.self_collide(verts, vidx, want_pairs=False, threads=th)
+                dt2 = time.perf_counter() - t0
+                if best2 is None or dt2 < best2[0]:
+                    best2 = (dt2, st2, tm2, th)
+        dt2, st2, tm2, th = best2
+        out["omp"] = {"value": st2.pairs_tested / dt2, "cores": th, "total_collision_ms": dt2 * 1e3,
                       "stage_ms": {"morton": tm2.ms_morton, "sort (sequential)": tm2.ms_sort, "hierarchy": tm2.ms_hierarchy, "refit": tm2.ms_refit,
                                    "traverse": tm2.ms_traverse},
-                      "sample": f"best of {reps} full passes, {nproc} OpenMP threads, sort on one thread"}
+                      "sample": f"best thread count of {tries} (2 full passes each), sort on one thread; affinity mask {nproc} CPUs, cgroup quota {quota}"}
     return out
 
 
@@ -200,7 +219,7 @@ def main():
     engine.cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0)
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
     stage = {"morton": 0.0, "sort": 0.0, "hierarchy": 0.0, "refit": 0.0, "traverse": 0.0}
-    kern = {"descend": 0.0, "exact": 0.0}                                # the two kernels inside "traverse"
+    kern = {"descend": 0.0, "exact": 0.0, "build_block": 0.0}            # the two kernels inside "traverse" + the fused hierarchy / refit kernel
     tested_total = 0
     pairs_found = 0
     pipeline_ms = 0.0
@@ -213,7 +232,7 @@ def main():
         pairs, tested, info = step()
         st = engine.cd.stats()                                        # HIP-event stage times on the library's stream
         if not multi_path:
-            kern["descend"] += st.ms_descend; kern["exact"] += st.ms_exact; pipeline_ms += st.ms_pipeline
+            kern["descend"] += st.ms_descend; kern["exact"] += st.ms_exact; kern["build_block"] += st.ms_build_block; pipeline_ms += st.ms_pipeline
         tested_total += tested
         pairs_found = pairs.shape[0]
     torch.cuda.synchronize()
@@ -255,39 +274,52 @@ def main():
             line["stage_ms"] = stage                               # untimed profiling steps (stage events add idle gaps)
             line["stage_ms_note"] = f"from {prof_steps} extra untimed steps with per-stage events; their sum exceeds total_collision_ms_device by the event gaps"
             line["traversal_pairs_tested_per_s"] = (tested_total / k) / (stage["traverse"] * 1e-3)
-            # roofline of the dominant kernel = k_descend (largest single launch of the step): ALGORITHMIC bytes per
-            # launch = 40 B/triangle (the tree -- boxes, links, leaf payload -- read once) over its
-            # average launch duration from HIP events recorded on the library's stream around that kernel
+            # roofline of the DOMINANT kernel -- whichever single launch of the step is longest, decided from the live
+            # per-kernel times (HIP events riding on the kernels' own dispatch packets, on the library's stream):
+            #   k_refit_seg_local<fused>: hierarchy + refit of the 512-leaf blocks in one pass, ALGORITHMIC bytes 100 B/triangle
+            #                             (SURVEY.md 8d rows S3 + S4);
+            #   k_descend_half:           the fp32 descent, 40 B/triangle (row S5: the tree read once).
+            # The other one is reported beside it.  `traffic` = HBM bytes per launch from the rocprofv3 --pmc passes
+            # (profiles/traffic.json, produced by tools/refresh_profiles.sh + tools/summarise_profiles.py).
             for k_ in kern:
                 kern[k_] /= k
             dominant = max(stage, key=stage.get)
-            desc_bytes = TRAVERSAL_BYTES_PER_TRI * nt
-            achieved = desc_bytes / (kern["descend"] * 1e-3) / 1e9
-            traffic = None
-            l2_hit = None
+            traffic_of = {}
+            l2_of = {}
             whole_traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if tj.get("triangles") == nt:
-                    traffic = tj.get("traverse_hbm_bytes_per_launch")
-                    l2_hit = tj.get("l2_hit_rate")                     # TCC_HIT / (TCC_HIT + TCC_MISS) of k_descend, same rocprofv3 run set
                     whole_traffic = tj.get("whole_path_hbm_bytes_per_step")
+                    for name, v in tj.get("whole_path_per_kernel", {}).items():
+                        traffic_of[name] = v.get("hbm_bytes_per_step")
+                    l2_of["k_descend_half"] = tj.get("l2_hit_rate")
+
+            def roof(symbol, label, ms, bytes_per_tri):
+                ach = bytes_per_tri * nt / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                tr = next((v for kk, v in traffic_of.items() if symbol in kk), None)
+                return {"bound": "hbm", "kernel": label, "kernel_symbol": symbol, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": tr, "l2_hit_rate": l2_of.get(symbol),
+                        "algorithmic_bytes_per_launch": bytes_per_tri * nt, "avg_launch_ms": ms}
+
+            cands = [roof("k_descend_half", "k_descend_half (fp32 BVH descent, half traversal; its candidates go to k_exact)", kern["descend"], TRAVERSAL_BYTES_PER_TRI),
+                     roof("k_refit_seg_local", "k_refit_seg_local<fused> (Karras hierarchy + AABB refit + traversal records of the 512-leaf blocks)",
+                          kern["build_block"], BUILD_BYTES_PER_TRI)]
+            cands.sort(key=lambda r: -r["avg_launch_ms"])
             line["kernel_ms"] = kern
-            line["roofline"] = {"bound": "hbm", "kernel": "k_descend_half (fp32 BVH descent, half traversal; its candidates go to k_exact)",
-                                "kernel_symbol": "k_descend_half", "achieved": achieved,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "l2_hit_rate": l2_hit,
-                                "algorithmic_bytes_per_launch": desc_bytes, "avg_launch_ms": kern["descend"],
-                                "dominant_stage": dominant,
-                                "whole_path": {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9,
-                                               "frac": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": whole_traffic}}
+            line["roofline"] = dict(cands[0])
+            line["roofline"]["dominant_stage"] = dominant
+            line["roofline"]["other_kernels"] = cands[1:]
+            line["roofline"]["whole_path"] = {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9,
+                                              "frac": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": whole_traffic}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(verts, vidx)
                 line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
                 if "omp" in line["cpu_baseline"]:
                     line["speedup_vs_cpu_allcores"] = line["value"] / line["cpu_baseline"]["omp"]["value"]
-                    line["speedup_note"] = (f"reported baselines, not targets: 1 core of the box, and all {line['cpu_baseline']['nproc']} cores "
-                                            "this process may use (sched_getaffinity)")
+                    line["speedup_note"] = (f"reported baselines, not targets: 1 core of the box, and the best OpenMP thread count "
+                                            f"({line['cpu_baseline']['omp']['cores']}) this process' CPU share supports")
             if not args.no_ray:
                 line["ray_tracer"] = ray_tracer_measurement()
         else:

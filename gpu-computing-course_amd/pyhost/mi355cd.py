@@ -29,7 +29,8 @@ class CdStats(C.Structure):
                 ("traverse_launches", C.c_uint32), ("stack_overflows", C.c_uint32),
                 ("n_pairs", C.c_uint64), ("pairs_tested", C.c_uint64), ("node_visits", C.c_uint64),
                 ("wave_steps", C.c_uint64), ("candidates", C.c_uint64),
-                ("ms_descend", C.c_float), ("ms_exact", C.c_float), ("sort_passes", C.c_uint32), ("ms_pipeline", C.c_float)]
+                ("ms_descend", C.c_float), ("ms_exact", C.c_float), ("sort_passes", C.c_uint32), ("ms_pipeline", C.c_float),
+                ("ms_build_block", C.c_float)]
 
 
 # every symbol include/mi355cd.h declares (tests check the library exports exactly these)

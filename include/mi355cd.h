@@ -68,6 +68,8 @@ typedef struct cd_stats {
     float ms_exact;            /* shallow pass: exact-test kernel        (part of ms_traverse)          */
     uint32_t sort_passes;      /* global digit passes of the last sort: 2 (hybrid), 4 (half-key) or 8     */
     float ms_pipeline;         /* fused calls: pipeline start -> end of the traversal kernels, one event pair */
+    float ms_build_block;      /* fused calls: the kernel that builds hierarchy + boxes + records of the 512-leaf     */
+                               /* blocks (k_refit_seg_local<fused>), from its own dispatch packet; part of ms_refit  */
 } cd_stats;
 
 /* main.cu:64 loadObj (load_obj.h:24-103), host side, multi-threaded: parse `v x y z` (as float, widened to double)

@@ -46,7 +46,8 @@ def test_rt_header_and_library_agree():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(mi355cd.CdStats) == 6 * 4 + 2 * 4 + 5 * 8 + 2 * 4 + 2 * 4
+    assert C.sizeof(mi355cd.CdStats) == 6 * 4 + 2 * 4 + 5 * 8 + 2 * 4 + 2 * 4 + 4 + 4          # ... ms_pipeline, ms_build_block, tail padding to 8
+    assert C.sizeof(mi355cd.CdMultiInfo) == 6 * 4 + 6 * 8 + 8 * 4
     assert mi355cd.QUERY_DTYPE.itemsize == 88
     assert mi355rt.SPHERE_DTYPE.itemsize == 32
     assert [n for n in mi355rt.SPHERE_DTYPE.names][:3] == ["r", "b", "g"]     # sphere.cuh:29 field order

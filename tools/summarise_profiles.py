@@ -63,7 +63,7 @@ with open(os.path.join(dst, "pmc_sq_per_kernel.csv"), "w") as f:
         f.write("\"" + k + "\"," + ",".join(f"{sum(sq[k][c]) / len(sq[k][c]):.1f}" if c in sq[k] else "" for c in names) + "\n")
 
 line = json.load(open(os.path.join(dst, "bench_line.json")))
-dom = line.get("roofline", {}).get("kernel_symbol", "k_descend_half")
+dom = "k_descend_half"          # the top-level fields describe the descent; every kernel has its row in whole_path_per_kernel
 kd = next(k for k in hbm if dom in k)
 fetch = hbm[kd]["FETCH_SIZE"] * 1024; write = hbm[kd]["WRITE_SIZE"] * 1024
 # whole step: every collision kernel (namespace cd) launched once per step -- the ray tracer's kernels are another path
