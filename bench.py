@@ -329,7 +329,7 @@ def main():
         # few extra untimed steps with HIP events at the phase boundaries)
         phase = None
         if ms is not None:
-            ms.set_flags(mi355cd.CD_MULTI_TIMING)
+            ms.set_flags(mi355cd.CD_MULTI_TIMING | (mi355cd.CD_MULTI_SELF_PEER if self_peer else 0))
             acc = np.zeros(7)
             reps = 5
             for _ in range(reps):
