@@ -20,6 +20,7 @@
 // it; there is no fallback transport: without librccl the calls return CD_ERR_RCCL.
 #pragma once
 #include <dlfcn.h>
+#include <cstdlib>
 #include <rccl/rccl.h>
 
 namespace {
@@ -44,9 +45,16 @@ RcclApi *rccl()
     static bool tried = false;
     if (!tried) {
         tried = true;
-        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        // MI355CD_RCCL_LIBRARY: load THAT library and nothing else (a site's own RCCL build; the tests' in-process
+        // loopback, tests/loopback_rccl).  Otherwise the process' RCCL: the copy already loaded (PyTorch's) wins by soname.
+        const char *over = std::getenv("MI355CD_RCCL_LIBRARY");
+        void *h = nullptr;
+        if (over && *over) h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        else {
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        }
         if (h) {
             api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
             api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");

@@ -1,0 +1,107 @@
+"""cd_multi_step with world > 1 on ONE GPU: every rank is a host thread of this process with its own cd_ctx, and
+libmi355cd.so talks to tests/loopback_rccl (an in-process stand-in for librccl.so, selected through MI355CD_RCCL_LIBRARY)
+instead of RCCL, which refuses two ranks on one device.  Everything else -- the pack launch for all peers, the count
+matrix, the collective capacity growth, slab and receive offsets, both traversal passes -- is the product code path.
+Run as a child process by tests/test_cd_gpu.py (the library choice is per process).
+
+usage: multi_loopback_driver.py QUADS QCAP STEPS X0,X1,...     (rank r's object sits at x = Xr * 2.88)
+Checks, and exits non-zero on failure: union of all ranks' pairs == oracle on the merged mesh, no duplicates, summed
+pairs_tested == the single tree's, sent/received totals consistent across ranks, peers as the root boxes say."""
+import json
+import os
+import sys
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+os.environ["MI355CD_RCCL_LIBRARY"] = os.path.join(HERE, "loopback_rccl", "librccl_loopback.so")
+import torch  # noqa: F401,E402  (its HIP runtime first, see conftest.py)
+sys.path[:0] = [os.path.join(ROOT, "gpu-computing-course_amd", "pyhost"), HERE]
+import numpy as np  # noqa: E402
+import mi355cd  # noqa: E402
+import mi355_multi as multi  # noqa: E402
+import mi355_synth as synth  # noqa: E402
+import oracle  # noqa: E402
+
+
+def main():
+    quads, qcap, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    xs = [float(x) for x in sys.argv[4].split(",")]
+    W = len(xs)
+    width = 2.88
+    shards, vbase, tbase = [], 0, 0
+    for r in range(W):
+        v, t = synth.cloth_pair(quads, x_offset=xs[r] * width)
+        ids = (np.arange(t.shape[0], dtype=np.uint64) + tbase).astype(np.uint32)
+        if r % 2:                                   # odd ranks hold the larger IDs first: the ID rule must not depend on rank order
+            ids = ids[::-1].copy()
+        shards.append((v, t, ids, vbase))
+        vbase += v.shape[0]; tbase += t.shape[0]
+    cds = []
+    for v, t, ids, vb in shards:
+        cd = mi355cd.CollisionDetector(v, t, ids)
+        cd.set_morton_frame(mi355cd.CD_FRAME_AUTO)
+        cd.set_vertex_id_base(vb)
+        cds.append(cd)
+    uid = mi355cd.multi_unique_id()                 # also loads the loopback library once, before the threads start
+    assert uid[8:16] == b"loopback", "libmi355cd.so did not load the loopback library"
+    results, errors = [None] * W, [None] * W
+
+    def rank_main(r):
+        try:
+            with mi355cd.MultiStep(cds[r], uid, r, W, query_cap_per_peer=qcap, flags=mi355cd.CD_MULTI_TIMING) as ms:
+                out = []
+                for _ in range(steps):
+                    pairs, n, rc, info = ms.step(cap=1 << 21)
+                    out.append((pairs.copy(), n, rc, {k: getattr(info, k) for k, _ in info._fields_}))
+                results[r] = out
+        except BaseException as e:                  # noqa: BLE001
+            errors[r] = repr(e)
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(W)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(240)
+    hung = [r for r, t in enumerate(th) if t.is_alive()]
+    if hung or any(errors):
+        print(json.dumps({"ok": False, "hung": hung, "errors": errors}))
+        os._exit(2)
+
+    roots = [cd.root_box() for cd in cds]
+    want_peers = [sum(1 for s in range(W) if s != r and multi.boxes_overlap(roots[r], roots[s])) for r in range(W)]
+    verts = np.concatenate([s[0] for s in shards]); vidx = np.concatenate([s[1] + np.uint32(s[3]) for s in shards])
+    ids = np.concatenate([s[2] for s in shards])
+    cen = (verts[vidx[:, 0]] + verts[vidx[:, 1]] + verts[vidx[:, 2]]) / 3
+    ref = oracle.pipeline(verts, vidx, ids, off=cen.min(0), span=(cen.max(0) - cen.min(0)) * (1 + 2.0 ** -20))
+    want = oracle.pair_set(ref["pairs"])
+    summary = {"ok": True, "world": W, "want_pairs": int(len(want)), "want_peers": want_peers, "steps": []}
+    for it in range(steps):
+        got = np.concatenate([results[r][it][0] for r in range(W)], axis=0)
+        infos = [results[r][it][3] for r in range(W)]
+        gs = oracle.pair_set(got)
+        checks = {
+            "rc_ok": all(results[r][it][2] == 0 for r in range(W)),
+            "no_duplicates": len(gs) == len(np.unique(gs)),
+            "pair_set_equals_oracle": bool(np.array_equal(gs, want)),
+            "pairs_tested_equals_single_tree": sum(i["pairs_tested"] for i in infos) == ref["stats"].pairs_tested,
+            "sent_equals_received": sum(i["sent_queries"] for i in infos) == sum(i["recv_queries"] for i in infos),
+            "peers_as_root_boxes_say": [i["n_peers"] for i in infos] == want_peers,
+            "world_rank": all(i["world"] == W and i["rank"] == r for r, i in enumerate(infos)),
+            "same_attempts_everywhere": len({i["attempts"] for i in infos}) == 1,
+            "same_capacity_everywhere": len({i["query_cap"] for i in infos}) == 1,
+            "n_counts": all(results[r][it][1] == infos[r]["local_pairs"] + infos[r]["cross_pairs"] for r in range(W)),
+        }
+        summary["steps"].append({"checks": checks, "attempts": infos[0]["attempts"], "query_cap": infos[0]["query_cap"],
+                                 "host_syncs": [i["host_syncs"] for i in infos], "sent": [i["sent_queries"] for i in infos],
+                                 "recv": [i["recv_queries"] for i in infos], "local": [i["local_pairs"] for i in infos],
+                                 "cross": [i["cross_pairs"] for i in infos], "got_pairs": int(len(gs))})
+        summary["ok"] = summary["ok"] and all(checks.values())
+    for cd in cds:
+        cd.close()
+    print(json.dumps(summary))
+    sys.exit(0 if summary["ok"] else 1)
+
+
+if __name__ == "__main__":
+    main()

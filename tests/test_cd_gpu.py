@@ -481,6 +481,42 @@ def test_multi_step_c_abi_one_rank_self_peer():
         assert np.array_equal(oracle.pair_set(p2), oracle.pair_set(r["pairs"]))
 
 
+@pytest.mark.parametrize("quads,qcap,xs", [
+    (40, 0, "0,0.9"),                                # two ranks, 10 % overlap
+    (30, 64, "0,0.9,1.8"),                           # chain of three, slabs deliberately tiny: the capacity grows COLLECTIVELY in step 1
+    (30, 0, "0,0.9,5.0"),                            # rank 2 overlaps nobody: it skips the exchange, the others do not wait for it
+    (24, 0, "0,0.2,0.4,0.6"),                        # everybody overlaps everybody: every slab and every receive offset in use
+    (24, 0, "0,0.9,1.8,2.7,3.6,4.5,5.4,6.3"),        # BASELINE config 4's topology: eight ranks in a row
+], ids=["w2", "w3-grow", "w3-isolated", "w4-all-to-all", "w8-chain"])
+def test_multi_step_world_gt_1_over_the_loopback_transport(quads, qcap, xs):
+    """cd_multi_step with world 2 .. 8 on the one GPU there is: ranks are host threads with a context each, and the
+    library is pointed (MI355CD_RCCL_LIBRARY) at tests/loopback_rccl, an in-process stand-in for the ten RCCL calls it
+    uses -- RCCL itself refuses two ranks on one device.  The union of all ranks' pairs must be the single-tree oracle's
+    set without duplicates, the summed pairs_tested the single tree's, peers / counts / capacities consistent on all
+    ranks.  Runs in a child process: which RCCL a process uses is decided once."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "multi_loopback_driver.py"), str(quads), str(qcap), "3", xs],
+                       capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    res = json.loads(lines[-1])
+    assert res["ok"] and p.returncode == 0, res
+    W = len(xs.split(","))
+    assert res["world"] == W and res["want_pairs"] > 0
+    for it, st in enumerate(res["steps"]):
+        if it == 0 and qcap:
+            assert st["attempts"] == 2, st                       # 64 records per slab cannot hold a 10 % overlap
+        if it > 0:
+            assert st["attempts"] == 1, st                       # capacity is kept: no second growth
+        assert st["host_syncs"] == [st["attempts"] + 1] * W, st    # one per attempt of the first half + one for both traversal passes
+        if "5.0" in xs:
+            assert st["sent"][2] == st["recv"][2] == 0 and st["cross"][2] == 0
+        assert sum(st["cross"]) > 0
+
+
 def test_device_pair_post_processing():
     """SURVEY 8f row 2 (main.cu:33-45,149-154): sorted pair list and the set of colliding triangle IDs, on the device."""
     verts, vidx = synth.soup(30000, 0.05, 12)
