@@ -90,7 +90,7 @@ struct cd_multi {
     int rank = 0, world = 1, flags = 0;
     uint64_t qcap = 0;                           // records per peer slab -- the SAME on every rank (grown from the shared count matrix)
     hipStream_t xstream = nullptr;               // payload exchange, beside the context's stream
-    hipEvent_t ev_payload = nullptr, ev[ME_COUNT] = {};
+    hipEvent_t ev_payload = nullptr, ev_counts = nullptr, ev[ME_COUNT] = {};
     double *d_roots = nullptr;                   // world x 6
     unsigned long long *d_row = nullptr;         // world + 1: records packed for each peer, then this rank's "redo" word
     unsigned long long *d_matrix = nullptr;      // world x (world + 1), all-gathered rows
@@ -109,6 +109,7 @@ void multi_free(cd_multi *m)
     if (m->c) hipStreamSynchronize(m->c->stream);
     if (m->xstream) { hipStreamSynchronize(m->xstream); hipStreamDestroy(m->xstream); }
     if (m->ev_payload) hipEventDestroy(m->ev_payload);
+    if (m->ev_counts) hipEventDestroy(m->ev_counts);
     for (int i = 0; i < ME_COUNT; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
     hipFree(m->d_roots); hipFree(m->d_row); hipFree(m->d_matrix); hipFree(m->d_send); hipFree(m->d_recv);
     if (m->h_matrix) hipHostFree(m->h_matrix);
@@ -122,6 +123,7 @@ int multi_alloc(cd_multi *m)
     const size_t W = (size_t)m->world;
     HIPCHK(hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&m->ev_payload, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
     for (int i = 0; i < ME_COUNT; ++i) HIPCHK(hipEventCreate(&m->ev[i]));
     HIPCHK(hipMalloc(&m->d_roots, sizeof(double) * 6 * W));
     HIPCHK(hipMalloc(&m->d_row, sizeof(unsigned long long) * (W + 1)));
@@ -212,6 +214,18 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     uint32_t syncs = 0, attempts = 0;
     auto mark = [&](int e, hipStream_t st) { if (timing) hipEventRecord(m->ev[e], st); };
 
+    TravBuf &t0 = c->tb[0], &t1 = c->tb[1];
+    const bool fast_path = c->trav_variant != 0;                              // (variant 0 has no candidate stage: take the general path)
+    const uint64_t cap = cap_pairs;
+    uint64_t spec0 = !pairs ? 0 : cap < SPEC_PAIRS ? cap : SPEC_PAIRS, spec1 = spec0;     // (enqueue_report clamps them the same way)
+    if (fast_path) {
+        int rc = ensure_pairs(c, t0, cap > 0 ? cap : 1);
+        if (!rc) rc = ensure_pairs(c, t1, cap > 0 ? cap : 1);
+        if (rc) return rc;
+    }
+    const bool se = c->stage_events;
+    struct RestoreStageEvents { cd_ctx *c; bool v; ~RestoreStageEvents() { c->stage_events = v; } } restore{c, se};
+
     // ---- 1-3: tree, root all-gather, pack for all peers, count matrix; redone by EVERY rank if any rank asks for it
     for (;; ++attempts) {
         if (attempts >= 6) return CD_ERR_ARG;
@@ -238,7 +252,20 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         HIPCHK(hipMemcpyAsync(m->h_roots, m->d_roots, sizeof(double) * 6 * W, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, s));
         mark(ME_COUNTS, s);
-        HIPCHK(hipStreamSynchronize(s)); ++syncs;                                          // host synchronisation 1 of 2
+        HIPCHK(hipEventRecord(m->ev_counts, s));
+        // the local traversal needs nothing from the other ranks: it is queued BEHIND the copies above and runs while the
+        // host reads the matrix and issues the exchange (a collective redo below throws its result away: rare)
+        if (fast_path) {
+            // (stage events off: the kernels' time stamps ride on their dispatch packets, no barrier packets between the passes)
+            c->stage_events = false;
+            QuerySrc src{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, nullptr, nullptr, c->d_os_ticket + 8};
+            HIPCHK(hipMemsetAsync(t0.d_state, 0, sizeof(TravState), s));
+            launch_pass<false, false>(c, t0, src, c->nt, cap);
+            const int rcr = enqueue_report(c, t0, pairs != nullptr, spec0);
+            if (rcr) return rcr;
+            mark(ME_LOCAL, s);
+        }
+        HIPCHK(hipEventSynchronize(m->ev_counts)); ++syncs;                                // host synchronisation 1 of 2: the counts, not the stream
         HIPCHK(hipGetLastError());
         // decisions from the matrix: identical on every rank
         unsigned long long mx = 0; bool any_redo = false, any_fail = false;
@@ -289,26 +316,12 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     mark(ME_XCH1, m->xstream);
     HIPCHK(hipEventRecord(m->ev_payload, m->xstream));
 
-    // ---- 5: both traversal passes queued back to back, ONE synchronisation
-    TravBuf &t0 = c->tb[0], &t1 = c->tb[1];
-    const bool fast_path = c->trav_variant != 0;                              // (variant 0 has no candidate stage: take the general path)
-    const uint64_t cap = cap_pairs;
+    // ---- 5: the pass over the received queries behind the local one, ONE synchronisation for both
     uint64_t n_local = 0, n_cross = 0, tested = 0;
     int rc_l = CD_OK, rc_x = CD_OK;
     bool need_general_l = !fast_path, need_general_x = !fast_path;
     if (fast_path) {
-        int rc = ensure_pairs(c, t0, cap > 0 ? cap : 1);
-        if (!rc) rc = ensure_pairs(c, t1, cap > 0 ? cap : 1);
-        if (rc) return rc;
-        // (stage events off: the kernels' time stamps ride on their dispatch packets, no barrier packets between the passes)
-        const bool se = c->stage_events; c->stage_events = false;
-        QuerySrc src{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, nullptr, nullptr, c->d_os_ticket + 8};
-        HIPCHK(hipMemsetAsync(t0.d_state, 0, sizeof(TravState), s));
-        launch_pass<false, false>(c, t0, src, c->nt, cap);
-        uint64_t spec0 = cap < SPEC_PAIRS ? cap : SPEC_PAIRS, spec1 = spec0;
-        rc = enqueue_report(c, t0, pairs != nullptr, spec0);
-        if (rc) { c->stage_events = se; return rc; }
-        mark(ME_LOCAL, s);
+        int rc;
         HIPCHK(hipStreamWaitEvent(s, m->ev_payload, 0));
         if (recvd) {
             QuerySrc srcx{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, m->d_recv, nullptr, c->d_os_ticket + 8};
@@ -316,7 +329,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
             launch_pass<true, false>(c, t1, srcx, (uint32_t)recvd, cap);
             m->scratch_pairs.resize(2 * (size_t)spec1 + 2);
             rc = enqueue_report(c, t1, pairs != nullptr, spec1);
-            if (rc) { c->stage_events = se; return rc; }
+            if (rc) return rc;
         }
         mark(ME_CROSS, s);
         c->stage_events = se;

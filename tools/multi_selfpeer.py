@@ -16,3 +16,9 @@ with mi355cd.CollisionDetector(v, t, ids) as cd:
             dt = time.perf_counter() - t0
             print(f"step {it}: wall {dt*1e3:.3f} ms rc {rc} syncs {mi.host_syncs} attempts {mi.attempts} sent {mi.sent_queries} local {mi.local_pairs} cross {mi.cross_pairs} | tree {mi.ms_tree*1e3:.0f} ag {mi.ms_allgather*1e3:.0f} "
                   f"pack {mi.ms_pack*1e3:.0f} counts {mi.ms_counts*1e3:.0f} xch {mi.ms_exchange*1e3:.0f} local {mi.ms_local*1e3:.0f} cross {mi.ms_cross*1e3:.0f} us")
+        ms.set_flags(mi355cd.CD_MULTI_SELF_PEER)
+        K = 30
+        t0 = time.perf_counter()
+        for _ in range(K):
+            ms.step(1 << 22)
+        print(f"untimed (no phase events): {(time.perf_counter() - t0) / K * 1e3:.3f} ms per step")
