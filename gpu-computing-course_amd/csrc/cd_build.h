@@ -1,0 +1,341 @@
+// cd_build.h -- the FUSED build of the fused entry points (cd_self_collide / cd_build_tree / cd_multi_step): Karras
+// hierarchy (bvh.cuh:100-199) + AABB refit (bvh.cuh:258-285) + the fp32 traversal records, straight from the sorted keys.
+//
+// What the traversal reads of an internal node is its 64-byte record: both child boxes rounded OUTWARD to fp32.  Rounding
+// is monotone, so it commutes with min / max: the outward-rounded box of a leaf range is the min / max of the leaves'
+// outward-rounded boxes -- bit for bit what rounding the FP64 merge (bvh.cuh:277) gives.  The fused build therefore
+// keeps ONE fp32 segment tree of the leaf boxes per 512-leaf block (hardware v_min_f32 / v_max_f32, 6 instructions a
+// merge against 18 for the FP64 compare-selects of box.cuh:24-32) and never forms an internal FP64 box, except
+//   * the FP64 leaf boxes themselves (k_exact, cd_pack_queries and the brute-force checker read them), and
+//   * the FP64 box of ALL leaves (node 0: cd_root_box, the multi-GPU root exchange), reduced per block from the few leaves
+//     whose fp32 value equals the block's fp32 extreme (only they can hold the FP64 extreme), then by k_refit_seg_top.
+// "Exact in fp32" flags (REC_L_EXACT / REC_R_EXACT) only matter for LEAF children -- a candidate is a pair of leaves --
+// and a leaf child's box is the leaf's box, whose flag the leaf's thread knows.
+// The reference's tree (meta[] / parent[] / FP64 boxes of internal nodes) is materialised by k_hierarchy + the stage-wise
+// refit when somebody asks for it (cd_export_tree, the verifier, traversal variant 0): mi355cd.hip.
+#pragma once
+#include "cd_bvh.h"
+
+namespace cd {
+
+struct B32 { float lx, ly, lz, hx, hy, hz; };
+
+// (inline asm: fminf / fmaxf on loaded values cost an extra canonicalising v_max_f32 x, x each under IEEE mode)
+__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ B32 b32_identity()
+{
+    const float inf = __uint_as_float(0x7f800000u);
+    return B32{inf, inf, inf, -inf, -inf, -inf};
+}
+__device__ __forceinline__ B32 b32_merge(const B32 &a, const B32 &b)
+{
+    return B32{hw_min(a.lx, b.lx), hw_min(a.ly, b.ly), hw_min(a.lz, b.lz), hw_max(a.hx, b.hx), hw_max(a.hy, b.hy), hw_max(a.hz, b.hz)};
+}
+__device__ __forceinline__ B32 b32_of(const Box &b)                       // outward: lo down, hi up (what store_rec32 does)
+{
+    return B32{__double2float_rd(b.x1), __double2float_rd(b.y1), __double2float_rd(b.z1), __double2float_ru(b.x2), __double2float_ru(b.y2), __double2float_ru(b.z2)};
+}
+__device__ __forceinline__ B32 b32_load(const float *p)                    // 24-byte node, 8-byte aligned
+{
+    const float2 a = reinterpret_cast<const float2 *>(p)[0], b = reinterpret_cast<const float2 *>(p)[1], c = reinterpret_cast<const float2 *>(p)[2];
+    return B32{a.x, a.y, b.x, b.y, c.x, c.y};
+}
+__device__ __forceinline__ void b32_store(float *p, const B32 &v)
+{
+    reinterpret_cast<float2 *>(p)[0] = make_float2(v.lx, v.ly); reinterpret_cast<float2 *>(p)[1] = make_float2(v.lz, v.hx);
+    reinterpret_cast<float2 *>(p)[2] = make_float2(v.hy, v.hz);
+}
+__device__ __forceinline__ B32 b32_of_leaf(const LeafBox32 *__restrict__ qbox32, int j)
+{
+    const float4 a = reinterpret_cast<const float4 *>(qbox32 + j)[0];
+    const float2 b = reinterpret_cast<const float2 *>(qbox32 + j)[2];
+    return B32{a.x, a.y, a.z, a.w, b.x, b.y};
+}
+
+// Range query [l, r] (inclusive, local leaf indices) over the block's fp32 segment tree in LDS (1-based heap, leaves at
+// REFIT_BLK + j).  min / max commute, so one accumulator takes the left and the right pieces as they come.
+__device__ __forceinline__ B32 seg_query32(const float (*t)[6], int l, int r)
+{
+    B32 acc = b32_identity();
+    l += REFIT_BLK; r += REFIT_BLK + 1;
+    for (int lev = 0; lev <= REFIT_LOG && l < r; ++lev) {
+        if (l & 1) { acc = b32_merge(acc, b32_load(t[l])); ++l; }
+        if (r & 1) { --r; acc = b32_merge(acc, b32_load(t[r])); }
+        l >>= 1; r >>= 1;
+    }
+    return acc;
+}
+
+// Doubles as unsigned integers of the same order (-0 below +0), for the LDS min / max of the block's FP64 extremes.
+__device__ __forceinline__ unsigned long long f64_ordered(double d)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double f64_from_ordered(unsigned long long k)
+{
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+
+// One workgroup per 512 consecutive leaves.  Thread t: leaf b0+t (FP64 box from the vertices -> boxes[], fp32 query box ->
+// qbox32[], fp32 leaf of the LDS tree) and internal node b0+t:
+//   1. adjacent deltas of the block as bytes + their min-sparse-table, and the fp32 segment tree, on the same 9 barriers;
+//   2. determineRange / findSplit as nearest-smaller-value / range-minimum-position queries on the table (cd_bvh.h);
+//      a node whose search runs off the block goes on the cross list (k_cross_meta, k_cross_records);
+//   3. ONE range query per node: its own box -> nb[] in LDS; after a barrier its record takes the two child boxes from
+//      nb[] (internal child: children of an in-block node are in-block) or from the tree's leaf level.
+// Levels >= SEG_MIN_LEVEL of the block's tree go to seg32 (what the cross nodes query), the FP64 box of the block's
+// leaves to seg[nbp2 + b] (k_refit_seg_top folds those into the box of all leaves).
+__global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n,
+                                                           const uint64_t *__restrict__ keys, int32_t *__restrict__ split_of,
+                                                           double *__restrict__ boxes, NodeRec32 *__restrict__ recs32, LeafBox32 *__restrict__ qbox32,
+                                                           int32_t *__restrict__ root_name, double *__restrict__ seg, float *__restrict__ seg32, int nbp2,
+                                                           int32_t *__restrict__ cross_list, uint32_t *__restrict__ cross_count, uint32_t cross_cap)
+{
+    __shared__ float t[2 * REFIT_BLK][6];           // 24 KB
+    __shared__ float nb[REFIT_BLK][6];              // 12 KB
+    __shared__ uint8_t dt[DL_LEVELS][DL_STRIDE];    // 5 KB
+    __shared__ int16_t lsplit[REFIT_BLK];
+    __shared__ unsigned long long lexact[REFIT_BLK / 64];
+    __shared__ unsigned long long acc[6];
+    __shared__ int32_t lcross[64];
+    __shared__ uint32_t lcount, lbase;
+    const int b = blockIdx.x, b0 = b * REFIT_BLK, tid = threadIdx.x;
+    const int j = b0 + tid;
+    if (tid == 0) lcount = 0;
+    if (tid < 6) acc[tid] = (tid & 1) ? 0ull : ~0ull;                      // x1 x2 y1 y2 z1 z2: min, max, min, max, min, max
+    // adjacent deltas of the positions b0-1 .. b0+512 (thread t: position b0-1+t; threads 0 and 1 also take the last two)
+    for (int x = tid; x < DL_STRIDE; x += REFIT_BLK) {
+        uint8_t v = 0;
+        const int p = b0 - 1 + x;
+        if (x < DL_N && p >= 0 && p < n - 1) v = (uint8_t)(delta_k(keys, n, p, keys[p], p + 1) + 1);
+        dt[0][x] = x < DL_N ? v : (uint8_t)255;
+    }
+    Box mine = box_identity();
+    B32 m32 = b32_identity();
+    bool exact = false;
+    if (j < n) {
+        const LeafTri lt = leaf[j];
+        mine = box_set(load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2));   // box.cuh:13-22
+        store_box(boxes, (n - 1) + j, mine);
+        m32 = b32_of(mine);
+        exact = box_is_fp32(mine);
+        float4 *qp = reinterpret_cast<float4 *>(qbox32 + j);
+        qp[0] = make_float4(m32.lx, m32.ly, m32.lz, m32.hx);
+        qp[1] = make_float4(m32.hy, m32.hz, __uint_as_float((exact ? LB_EXACT : 0u) | (box_overlap(mine, mine) ? LB_SELF : 0u)), 0.f);
+    }
+    b32_store(t[REFIT_BLK + tid], m32);
+    {
+        const unsigned long long em = __builtin_amdgcn_ballot_w64(exact);
+        if ((tid & 63) == 0) lexact[tid >> 6] = em;
+    }
+    // the 9 levels above the leaves and the 9 upper levels of the sparse table, one of each per barrier;
+    // global index of local node k at depth dd: ((nbp2 + b) << dd) + (k - 2^dd)
+    for (int dd = REFIT_LOG - 1; dd >= 0; --dd) {
+        __syncthreads();
+        {
+            const int k = REFIT_LOG - dd;
+            for (int x = tid; x < DL_STRIDE; x += REFIT_BLK) {
+                const int y = x + (1 << (k - 1));
+                const uint8_t u = dt[k - 1][x], w = y < DL_STRIDE ? dt[k - 1][y] : (uint8_t)255;
+                dt[k][x] = u < w ? u : w;
+            }
+        }
+        const int cnt = 1 << dd;
+        if (tid < cnt) {
+            const int k = cnt + tid;
+            const B32 m = b32_merge(b32_load(t[2 * k]), b32_load(t[2 * k + 1]));
+            b32_store(t[k], m);
+            if (REFIT_LOG - dd >= SEG_MIN_LEVEL) b32_store(seg32 + 6 * ((((size_t)nbp2 + b) << dd) + tid), m);
+        }
+    }
+    __syncthreads();
+    // FP64 box of the block's leaves: rounding is monotone, so the leaf with the smallest FP64 x1 is among the leaves whose
+    // rounded x1 equals the block's rounded minimum -- only those (normally one) touch the accumulator
+    if (j < n) {
+        const B32 tot = b32_load(t[1]);
+        if (m32.lx == tot.lx) atomicMin(&acc[0], f64_ordered(mine.x1));
+        if (m32.hx == tot.hx) atomicMax(&acc[1], f64_ordered(mine.x2));
+        if (m32.ly == tot.ly) atomicMin(&acc[2], f64_ordered(mine.y1));
+        if (m32.hy == tot.hy) atomicMax(&acc[3], f64_ordered(mine.y2));
+        if (m32.lz == tot.lz) atomicMin(&acc[4], f64_ordered(mine.z1));
+        if (m32.hz == tot.hz) atomicMax(&acc[5], f64_ordered(mine.z2));
+    }
+    const int i = j;                                                       // internal node with the same index
+    int first = 0, last = 0, split = 0; bool have = false, cross = false;
+    if (i < n - 1) {
+        // determineRange, bvh.cuh:100-123, on the adjacent deltas: dl index of position p is p - (b0 - 1)
+        const int x = tid;                                                 // dl index of position i - 1; position i is x + 1
+        const int dL = (int)dt[0][x], dR = (int)dt[0][x + 1];
+        const bool right = dR >= dL;                                       // d = sign(delta(i, i+1) - delta(i, i-1)); equal only when both are out of range
+        const int thr = right ? dL : dR;                                   // delta_min + 1
+        if (right) {
+            // j = first position p > i with delta(p, p+1) < delta_min  (leaf p is the last of the range)
+            // (node 0 has delta_min = -1, nothing is below it: its range is everything)
+            const int p = (thr == 0) ? ((n - 1 <= b0 + REFIT_BLK - 1) ? (n - 1) - (b0 - 1) : DL_N) : nsv_right(dt, x + 2, thr);
+            first = i; last = b0 - 1 + p;
+            have = p <= REFIT_BLK;                                         // dl index 512 is position b0+511, the block's last leaf
+            cross = !have;
+        } else {
+            // j = 1 + last position p < i - 1 with delta(p, p+1) < delta_min
+            const int p = psv_left(dt, x - 1, thr);
+            if (p < 0) cross = true;                                       // ran off the block (dl index 0 is position b0-1: found there means the range starts at b0)
+            else { first = b0 - 1 + p + 1; last = i; have = true; }
+        }
+        if (have) {
+            // findSplit, bvh.cuh:57-98: the position of the (unique) minimum adjacent delta inside [first, last - 1]
+            const int a = first - (b0 - 1), e = last - 1 - (b0 - 1);       // dl indices
+            const int len = e - a + 1;
+            const int k = 31 - __clz(len);
+            const int m0 = (int)dt[k][a], m1 = (int)dt[k][e - (1 << k) + 1];
+            const int mn = m0 < m1 ? m0 : m1;
+            split = b0 - 1 + nsv_right(dt, a, mn + 1);
+            split_of[i] = split;
+            b32_store(nb[tid], seg_query32(t, first - b0, last - b0));     // the node's own box
+        }
+        lsplit[tid] = have ? (int16_t)(split - b0) : (int16_t)-1;
+        if (cross) {
+            const uint32_t k = atomicAdd(&lcount, 1u);
+            if (k < 64u) lcross[k] = i;
+            else { const uint32_t g = atomicAdd(cross_count, 1u); if (g < cross_cap) cross_list[g] = i; }
+        }
+    }
+    __syncthreads();                                                        // nb[], lsplit[], acc[], lcount of the whole block
+    if (have) {
+        // children (bvh.cuh:174-195): the left child is leaf `split` or internal node `split`, the right one leaf / node split + 1
+        const bool leafL = split == first, leafR = split + 1 == last;
+        const int sl = split - b0, sr = split + 1 - b0;
+        const B32 bl = b32_load(leafL ? t[REFIT_BLK + sl] : nb[sl]);
+        const B32 br = b32_load(leafR ? t[REFIT_BLK + sr] : nb[sr]);
+        const int32_t la = leafL ? ~split : b0 + (int)lsplit[sl], lb = leafR ? ~(split + 1) : b0 + (int)lsplit[sr];
+        const uint32_t fl = ((leafL && ((lexact[sl >> 6] >> (sl & 63)) & 1ull)) ? REC_L_EXACT : 0u) |
+                            ((leafR && ((lexact[sr >> 6] >> (sr & 63)) & 1ull)) ? REC_R_EXACT : 0u);
+        float4 *pl = const_cast<float4 *>(rec_left(recs32, n, (uint32_t)split)), *pr = const_cast<float4 *>(rec_right(recs32, n, (uint32_t)split));
+        pl[0] = make_float4(bl.lx, bl.ly, bl.lz, bl.hx); pl[1] = make_float4(bl.hy, bl.hz, __int_as_float(la), __uint_as_float((uint32_t)first));
+        pr[0] = make_float4(br.lx, br.ly, br.lz, br.hx); pr[1] = make_float4(br.hy, br.hz, __int_as_float(lb), __uint_as_float((uint32_t)last | fl));
+        if (i == 0) *root_name = split;                                    // (a tree of one block: the root is an in-block node)
+    }
+    if (tid == 0) {
+        const Box tot{f64_from_ordered(acc[0]), f64_from_ordered(acc[1]), f64_from_ordered(acc[2]), f64_from_ordered(acc[3]),
+                      f64_from_ordered(acc[4]), f64_from_ordered(acc[5])};
+        store_box(seg, nbp2 + b, tot);
+        if (nbp2 == 1) store_box(boxes, 0, tot);                           // one block: this IS the box of node 0 (k_cross_records never sees it)
+    }
+    // hand the block's cross nodes over: ONE global atomic per workgroup on the list's length (about 2 000 workgroups
+    // finishing over the kernel's duration: ~30 returning atomics per microsecond on that word, a third of what it takes)
+    const uint32_t cnt = min(lcount, 64u);
+    if (cnt == 0) return;
+    if (tid == 0) lbase = atomicAdd(cross_count, cnt);
+    __syncthreads();
+    if ((uint32_t)tid < cnt && lbase + tid < cross_cap) cross_list[lbase + tid] = lcross[tid];
+}
+
+// Box of heap node k at level p (2^p leaves) for the cross nodes' queries: the leaves' fp32 boxes (levels below
+// SEG_MIN_LEVEL are rebuilt from 1, 2 or 4 of them), the blocks' fp32 trees (seg32), above the blocks the FP64 boxes of
+// k_refit_seg_top rounded outward.
+__device__ __forceinline__ B32 seg_piece32(const double *__restrict__ seg, const float *__restrict__ seg32, const LeafBox32 *__restrict__ qbox32,
+                                           int n, long long P, long long k, int p)
+{
+    if (p > REFIT_LOG) return b32_of(load_box(seg, (int)k));
+    if (p >= SEG_MIN_LEVEL) return b32_load(seg32 + 6 * (size_t)k);
+    const long long j0 = (k << p) - P;
+    B32 x = b32_identity();
+    for (int u = 0; u < (1 << p); ++u) { const long long jj = j0 + u; if (jj < n) x = b32_merge(x, b32_of_leaf(qbox32, (int)jj)); }
+    return x;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_shl32(float v, float fill)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ B32 dpp_step32(const B32 &x)
+{
+    const float inf = __uint_as_float(0x7f800000u);
+    const B32 y{dpp_row_shl32<CTRL>(x.lx, inf), dpp_row_shl32<CTRL>(x.ly, inf), dpp_row_shl32<CTRL>(x.lz, inf),
+                dpp_row_shl32<CTRL>(x.hx, -inf), dpp_row_shl32<CTRL>(x.hy, -inf), dpp_row_shl32<CTRL>(x.hz, -inf)};
+    return b32_merge(x, y);
+}
+__device__ __forceinline__ B32 b32_shfl_down(const B32 &x, int s)
+{
+    return B32{__shfl_down(x.lx, s), __shfl_down(x.ly, s), __shfl_down(x.lz, s), __shfl_down(x.hx, s), __shfl_down(x.hy, s), __shfl_down(x.hz, s)};
+}
+
+// The records of the cross nodes (range and split from k_cross_meta): one WAVE per node, its two child ranges side by
+// side in the two halves of the wave -- lanes 0-31 answer [first, split], lanes 32-63 [split + 1, last]; inside a half,
+// lane h < 16 owns the left piece of level h of the iterative bottom-up query and lane 31 - q the right piece of level q
+// (16 levels cover every range shorter than 65536 leaves; longer ranges take the 32 + 32 levels of a whole wave, one
+// child after the other).  Every lane fetches its piece (all loads in flight together), a segmented reduction folds them.
+// Lane 0 stores the left half of the record, lane 32 the right half.  Queries read leaf boxes and segment-tree nodes,
+// never another cross node's output: no ordering between the waves.
+__global__ __launch_bounds__(256) void k_cross_records(int n, const NodeMeta *__restrict__ meta, const double *__restrict__ seg, const float *__restrict__ seg32,
+                                                       int nbp2, const LeafBox32 *__restrict__ qbox32, double *__restrict__ boxes, NodeRec32 *__restrict__ recs32,
+                                                       const int32_t *__restrict__ split_of, int32_t *__restrict__ root_name,
+                                                       const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t total = min(*dense_total, dense_cap);
+    const long long P = (long long)nbp2 * REFIT_BLK;
+    for (uint32_t kk = blockIdx.x * 4 + (tid >> 6); kk < total; kk += gridDim.x * 4) {   // one wave per node (kk is wave-uniform)
+        const int i = __builtin_amdgcn_readfirstlane(dense[kk]);
+        const NodeMeta m = meta[i];
+        const int first = min(i, m.z), last = max(i, m.z);
+        const int split = (m.x >= n - 1) ? m.x - (n - 1) : m.x;
+        const bool second = lane >= 32;
+        B32 x = b32_identity();
+        if (last - first < 65535) {                                         // (wave-uniform) nearly all of them
+            const int hl = lane & 31;
+            const bool is_left = hl < 16;
+            const int l0 = second ? split + 1 : first, r0 = second ? last : split;
+            const int p = is_left ? hl : 31 - hl;                           // level of this lane's piece
+            const long long lp = ((long long)l0 + P + ((1ll << p) - 1)) >> p;   // l at level p (ceil)
+            const long long rp = ((long long)r0 + P + 1) >> p;              // r at level p (floor), half-open
+            if (lp < rp) {
+                const long long k = is_left ? lp : rp - 1;
+                const bool take = is_left ? (lp & 1) : (rp & 1);
+                if (take) x = seg_piece32(seg, seg32, qbox32, n, P, k, p);
+            }
+            // steps 1, 2, 4, 8 stay inside a row of 16 lanes (DPP row_shl, a VALU move); a lane whose source would be
+            // outside its row keeps the identity -- only lanes whose result is never consumed are affected
+            x = dpp_step32<0x101>(x); x = dpp_step32<0x102>(x); x = dpp_step32<0x104>(x); x = dpp_step32<0x108>(x);
+            x = b32_merge(x, b32_shfl_down(x, 16));                         // consumed in lanes 0 and 32, whose source is their own half
+        } else {
+            B32 res[2];
+            for (int h = 0; h < 2; ++h) {
+                const int l0 = h ? split + 1 : first, r0 = h ? last : split;
+                const bool is_left = lane < 32;
+                const int p = is_left ? lane : 63 - lane;
+                const long long lp = ((long long)l0 + P + ((1ll << p) - 1)) >> p;
+                const long long rp = ((long long)r0 + P + 1) >> p;
+                B32 y = b32_identity();
+                if (lp < rp) {
+                    const long long k = is_left ? lp : rp - 1;
+                    const bool take = is_left ? (lp & 1) : (rp & 1);
+                    if (take) y = seg_piece32(seg, seg32, qbox32, n, P, k, p);
+                }
+                for (int s = 1; s < 64; s <<= 1) y = b32_merge(y, b32_shfl_down(y, s));
+                res[h] = B32{__shfl(y.lx, 0), __shfl(y.ly, 0), __shfl(y.lz, 0), __shfl(y.hx, 0), __shfl(y.hy, 0), __shfl(y.hz, 0)};
+            }
+            x = second ? res[1] : res[0];
+        }
+        const bool leafL = split == first, leafR = split + 1 == last;       // (wave-uniform)
+        uint32_t fl = 0;
+        if (leafL && (qbox32[first].flags & LB_EXACT)) fl |= REC_L_EXACT;
+        if (leafR && (qbox32[last].flags & LB_EXACT)) fl |= REC_R_EXACT;
+        if (lane == 0) {
+            const int32_t la = child_link(meta, split_of, m.x, n - 1);
+            float4 *pl = const_cast<float4 *>(rec_left(recs32, n, (uint32_t)split));
+            pl[0] = make_float4(x.lx, x.ly, x.lz, x.hx); pl[1] = make_float4(x.hy, x.hz, __int_as_float(la), __uint_as_float((uint32_t)first));
+            if (i == 0) { *root_name = split; store_box(boxes, 0, load_box(seg, 1)); }   // the box of all leaves, from k_refit_seg_top
+        }
+        if (lane == 32) {
+            const int32_t lb = child_link(meta, split_of, m.y, n - 1);
+            float4 *pr = const_cast<float4 *>(rec_right(recs32, n, (uint32_t)split));
+            pr[0] = make_float4(x.lx, x.ly, x.lz, x.hx); pr[1] = make_float4(x.hy, x.hz, __int_as_float(lb), __uint_as_float((uint32_t)last | fl));
+        }
+    }
+}
+
+}  // namespace cd

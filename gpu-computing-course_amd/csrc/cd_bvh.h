@@ -303,10 +303,10 @@ __device__ __forceinline__ Box box_identity()
 
 // Given the exact boxes of both children, write the node's 64-byte fp32 traversal record -- at its SPLIT -- and return
 // the node's exact box (bvh.cuh:277 merge(childA, childB)).
-__device__ __forceinline__ Box emit_node(const Box &bl, const Box &br, const NodeMeta *__restrict__ meta, const int32_t *__restrict__ split_of,
+__device__ __forceinline__ Box emit_node(const Box &bl, const Box &br, const NodeMeta *__restrict__ meta,
                                          int cl, int cr, int split, int first, int last, NodeRec32 *__restrict__ recs32, int nleaf_base)
 {
-    store_rec32(recs32, nleaf_base + 1, (uint32_t)split, bl, br, make_int2(child_link(meta, split_of, cl, nleaf_base), child_link(meta, split_of, cr, nleaf_base)),
+    store_rec32(recs32, nleaf_base + 1, (uint32_t)split, bl, br, make_int2(child_link(meta, nullptr, cl, nleaf_base), child_link(meta, nullptr, cr, nleaf_base)),
                 (uint32_t)first, (uint32_t)last);
     return box_merge(bl, br);
 }
@@ -362,9 +362,7 @@ __device__ __forceinline__ int psv_left(const uint8_t (*T)[DL_STRIDE], int s, in
     return p;
 }
 
-template <bool FUSED>
 __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n,
-                                                               const uint64_t *__restrict__ keys /* FUSED */, int32_t *__restrict__ split_of /* FUSED */,
                                                                const NodeMeta *__restrict__ meta,
                                                                double *__restrict__ boxes, uint32_t *__restrict__ bounded,
                                                                NodeRec32 *__restrict__ recs32, LeafBox32 *__restrict__ qbox32,
@@ -374,22 +372,11 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
                                                                uint32_t cross_cap)
 {
     __shared__ double t[2 * REFIT_BLK][6];          // 48 KB
-    __shared__ int32_t lcross[FUSED ? 64 : REFIT_BLK];   // (FUSED: a block has about 13 cross nodes; a full list spills straight to memory)
+    __shared__ int32_t lcross[REFIT_BLK];
     __shared__ uint32_t lcount, lbase;
-    __shared__ uint8_t dt[FUSED ? DL_LEVELS : 1][DL_STRIDE];
-    __shared__ int16_t lsplit[FUSED ? REFIT_BLK : 1];
     if (threadIdx.x == 0) lcount = 0;
     const int b = blockIdx.x, b0 = b * REFIT_BLK, tid = threadIdx.x;
     const int j = b0 + tid;
-    if (FUSED) {
-        // adjacent deltas of the positions b0-1 .. b0+512 (thread t: position b0-1+t; threads 0 and 1 also take the last two)
-        for (int x = tid; x < DL_STRIDE; x += REFIT_BLK) {
-            uint8_t v = 0;
-            const int p = b0 - 1 + x;
-            if (x < DL_N && p >= 0 && p < n - 1) v = (uint8_t)(delta_k(keys, n, p, keys[p], p + 1) + 1);
-            dt[0][x] = x < DL_N ? v : (uint8_t)255;
-        }
-    }
     Box mine = box_identity();
     if (j < n) {
         const LeafTri lt = leaf[j];
@@ -405,17 +392,8 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
         d[0] = mine.x1; d[1] = mine.x2; d[2] = mine.y1; d[3] = mine.y2; d[4] = mine.z1; d[5] = mine.z2;
     }
     // build the 9 levels above the leaves; global index of local node k at depth dd: ((nbp2 + b) << dd) + (k - 2^dd)
-    // (FUSED: the same barriers build the sparse table of the deltas, one level each)
     for (int dd = REFIT_LOG - 1; dd >= 0; --dd) {
         __syncthreads();
-        if (FUSED) {
-            const int k = REFIT_LOG - dd;                                  // levels 1 .. 9 here, level 10 - 1 = 9 is the last: DL_LEVELS - 1
-            for (int x = tid; x < DL_STRIDE; x += REFIT_BLK) {
-                const int y = x + (1 << (k - 1));
-                const uint8_t u = dt[k - 1][x], w = y < DL_STRIDE ? dt[k - 1][y] : (uint8_t)255;
-                dt[k][x] = u < w ? u : w;
-            }
-        }
         const int cnt = 1 << dd;
         if (tid < cnt) {
             const int k = cnt + tid;
@@ -427,46 +405,8 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
     }
     __syncthreads();
     const int i = j;                                                   // internal node with the same index
-    int first = 0, last = 0, split = 0; bool have = false, cross = false;
-    if (FUSED) {
-        if (i < n - 1) {
-            // determineRange, bvh.cuh:100-123, on the adjacent deltas: dl index of position p is p - (b0 - 1)
-            const int x = tid;                                             // dl index of position i - 1; position i is x + 1
-            const int dL = (int)dt[0][x], dR = (int)dt[0][x + 1];
-            const bool right = dR >= dL;                                   // d = sign(delta(i, i+1) - delta(i, i-1)); equal only when both are out of range
-            const int thr = right ? dL : dR;                               // delta_min + 1
-            if (right) {
-                // j = first position p > i with delta(p, p+1) < delta_min  (leaf p is the last of the range)
-                // (node 0 has delta_min = -1, nothing is below it: its range is everything)
-                const int p = (thr == 0) ? ((n - 1 <= b0 + REFIT_BLK - 1) ? (n - 1) - (b0 - 1) : DL_N) : nsv_right(dt, x + 2, thr);
-                first = i; last = b0 - 1 + p;
-                have = p <= REFIT_BLK;                                       // dl index 512 is position b0+511, the block's last leaf
-                cross = !have;
-            } else {
-                // j = 1 + last position p < i - 1 with delta(p, p+1) < delta_min
-                const int p = psv_left(dt, x - 1, thr);
-                if (p < 0) cross = true;                                    // ran off the block (dl index 0 is position b0-1: found there means the range starts at b0)
-                else { first = b0 - 1 + p + 1; last = i; have = true; }
-            }
-            if (have) {
-                // findSplit, bvh.cuh:57-98: the position of the (unique) minimum adjacent delta inside [first, last - 1]
-                const int a = first - (b0 - 1), e = last - 1 - (b0 - 1);   // dl indices
-                const int len = e - a + 1;
-                const int k = 31 - __clz(len);
-                const int m0 = (int)dt[k][a], m1 = (int)dt[k][e - (1 << k) + 1];
-                const int mn = m0 < m1 ? m0 : m1;
-                split = b0 - 1 + nsv_right(dt, a, mn + 1);
-            }
-            lsplit[tid] = have ? (int16_t)(split - b0) : (int16_t)-1;
-            if (have) split_of[i] = split;
-            if (cross) {
-                const uint32_t k = atomicAdd(&lcount, 1u);
-                if (k < 64u) lcross[k] = i;
-                else { const uint32_t g = atomicAdd(cross_count, 1u); if (g < cross_cap) cross_list[g] = i; }
-            }
-        }
-        __syncthreads();                                                    // lsplit of the whole block (child links)
-    } else if (i < n - 1) {
+    int first = 0, last = 0, split = 0; bool have = false;
+    if (i < n - 1) {
         const NodeMeta m = meta[i];
         first = min(i, m.z); last = max(i, m.z);
         if (first < b0 || last >= b0 + REFIT_BLK) {
@@ -474,29 +414,19 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
         } else { have = true; split = (m.x >= n - 1) ? m.x - (n - 1) : m.x; }    // childA covers [first, split], childB [split+1, last]
     }
     if (have) {
-        {
-            // children as unified Karras ids (bvh.cuh:174-195): the left child is leaf `split` or internal node `split`
-            const int ca = (split == first) ? (n - 1) + split : split, cb = (split + 1 == last) ? (n - 1) + split + 1 : split + 1;
-            const Box bl = seg_query_lds(t, first - b0, split - b0);
-            const Box br = seg_query_lds(t, split + 1 - b0, last - b0);
-            Box whole;
-            if (FUSED) {
-                // both children are nodes of this block: their splits are in lsplit
-                const int32_t la = (ca >= n - 1) ? ~(ca - (n - 1)) : b0 + (int)lsplit[ca - b0], lb = (cb >= n - 1) ? ~(cb - (n - 1)) : b0 + (int)lsplit[cb - b0];
-                store_rec32(recs32, n, (uint32_t)split, bl, br, make_int2(la, lb), (uint32_t)first, (uint32_t)last);
-                whole = box_merge(bl, br);
-            } else whole = emit_node(bl, br, meta, nullptr, ca, cb, split, first, last, recs32, n - 1);
-            // The FP64 boxes of internal nodes are the OUTPUT of calBoundingBox (bvh.cuh:277), not something the fused
-            // path reads (its traversal works on the records, the exact kernel on leaf boxes): written on request only
-            if (write_internal || i == 0) store_box(boxes, i, whole);
-            if (i == 0) *root_name = split;
-            if (!FUSED || write_internal) bounded[i] = 2;              // Node::bounded (bvh.cuh:270): both children merged
-        }
+        // children as unified Karras ids (bvh.cuh:174-195): the left child is leaf `split` or internal node `split`
+        const int ca = (split == first) ? (n - 1) + split : split, cb = (split + 1 == last) ? (n - 1) + split + 1 : split + 1;
+        const Box bl = seg_query_lds(t, first - b0, split - b0);
+        const Box br = seg_query_lds(t, split + 1 - b0, last - b0);
+        const Box whole = emit_node(bl, br, meta, ca, cb, split, first, last, recs32, n - 1);
+        // The FP64 boxes of internal nodes are the OUTPUT of calBoundingBox (bvh.cuh:277): written on request
+        if (write_internal || i == 0) store_box(boxes, i, whole);
+        if (i == 0) *root_name = split;
+        bounded[i] = 2;                                                // Node::bounded (bvh.cuh:270): both children merged
     }
     __syncthreads();
-    // hand the block's cross nodes over: ONE global atomic per workgroup on the list's length (about 2 000 workgroups
-    // finishing over the kernel's duration: ~30 returning atomics per microsecond on that word, a third of what it takes)
-    const uint32_t cnt = FUSED ? min(lcount, 64u) : lcount;
+    // hand the block's cross nodes over: ONE global atomic per workgroup on the list's length
+    const uint32_t cnt = lcount;
     if (cnt == 0) return;
     if (tid == 0) lbase = atomicAdd(cross_count, cnt);
     __syncthreads();
@@ -711,7 +641,6 @@ __global__ __launch_bounds__(256) void k_cross_meta(const uint64_t *__restrict__
 // Queries read only leaf boxes and segment-tree nodes, never another cross node's output: no ordering needed.
 __global__ __launch_bounds__(256) void k_refit_seg_cross(int n, const NodeMeta *__restrict__ meta, const double *__restrict__ seg, int nbp2,
                                                          double *boxes, uint32_t *__restrict__ bounded, NodeRec32 *__restrict__ recs32,
-                                                         const int32_t *__restrict__ split_of /* fused build: child links come from here, not from meta */,
                                                          int32_t *__restrict__ root_name, int write_internal,
                                                          const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap)
 {
@@ -734,10 +663,10 @@ __global__ __launch_bounds__(256) void k_refit_seg_cross(int n, const NodeMeta *
             br = seg_query_wave(seg, boxes, n, P, split + 1, last, lane);
         }
         if (lane == 0) {
-            const Box whole = emit_node(bl, br, meta, split_of, m.x, m.y, split, first, last, recs32, n - 1);
+            const Box whole = emit_node(bl, br, meta, m.x, m.y, split, first, last, recs32, n - 1);
             if (write_internal || i == 0) store_box(boxes, i, whole);
             if (i == 0) *root_name = split;
-            if (!split_of || write_internal) bounded[i] = 2;
+            bounded[i] = 2;
         }
     }
 }

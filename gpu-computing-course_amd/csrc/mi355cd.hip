@@ -4,6 +4,7 @@
 #include "cd_math.h"
 #include "cd_sort.h"
 #include "cd_bvh.h"
+#include "cd_build.h"
 #include "cd_traverse.h"
 #include "cd_post.h"
 
@@ -65,7 +66,7 @@ struct cd_ctx {
     void *d_os = nullptr; size_t os_bytes = 0, zero_bytes = 0; uint32_t *d_os_hist = nullptr; uint32_t *d_os_ticket = nullptr; unsigned long long *d_os_look = nullptr;
     double *d_frame = nullptr, *d_partial = nullptr;
     // tree
-    LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; double *d_seg = nullptr; uint32_t nbp2 = 1; int32_t *d_cross = nullptr; uint32_t cross_cap = 0;   // segment tree over leaf boxes: nbp2*512 heap nodes
+    LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; double *d_seg = nullptr; float *d_seg32 = nullptr; uint32_t nbp2 = 1; int32_t *d_cross = nullptr; uint32_t cross_cap = 0;   // segment tree over leaf boxes: nbp2*512 heap nodes
     double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec32 *d_recs32 = nullptr; LeafBox32 *d_qbox = nullptr;
     int32_t *d_root = nullptr;              // name (split) of the root record, one word inside d_small
     bool internal_boxes_valid = false;      // the FP64 boxes of the internal nodes were written by the last refit (fused calls skip them)
@@ -101,7 +102,7 @@ void free_all(cd_ctx *c)
     hipFree(c->d_verts); hipFree(c->d_vidx); hipFree(c->d_ids);
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
-    hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_cross); hipFree(c->d_boxes);
+    hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_seg32); hipFree(c->d_cross); hipFree(c->d_boxes);
     hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox); hipFree(c->d_split_of);
     for (TravBuf &tb : c->tb) {
         if (tb.d_pairs) hipFree(reinterpret_cast<char *>(tb.d_pairs) - sizeof(Report));
@@ -217,8 +218,8 @@ int enqueue_hierarchy(cd_ctx *c, bool poison_boxes)
     return 0;
 }
 
-// fused: the local kernel builds the hierarchy of its block itself (cd_bvh.h, k_refit_seg_local<true>) and k_cross_meta
-// that of the cross nodes: no k_hierarchy before it, meta[] / parent[] are not written.
+// fused: k_build_block (cd_build.h) builds hierarchy, fp32 boxes and records of its 512-leaf block itself, k_cross_meta /
+// k_cross_records those of the cross nodes: no k_hierarchy before it, meta[] / parent[] / internal FP64 boxes are not written.
 int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
 {
     const uint32_t n = c->nt;
@@ -235,22 +236,26 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         c->leaves_filled = false;
         c->hierarchy_valid = false;
         // (its time stamps ride on its own dispatch packet: this is the largest kernel of the step, bench.py prices it)
-        hipExtLaunchKernelGGL((k_refit_seg_local<true>), dim3(nblocks), dim3(REFIT_BLK), 0u, s, c->ev[EV_BLK0], c->ev[EV_BLK1], 0u,
-                              (const double *)c->d_verts, (const LeafTri *)c->d_leaf, (int)n, (const uint64_t *)c->d_keys[0], c->d_split_of, (const NodeMeta *)c->d_meta,
-                              c->d_boxes, c->d_bounded, c->d_recs32, c->d_qbox, c->d_root, write_internal ? 1 : 0, c->d_seg, (int)c->nbp2,
+        hipExtLaunchKernelGGL(k_build_block, dim3(nblocks), dim3(REFIT_BLK), 0u, s, c->ev[EV_BLK0], c->ev[EV_BLK1], 0u,
+                              (const double *)c->d_verts, (const LeafTri *)c->d_leaf, (int)n, (const uint64_t *)c->d_keys[0], c->d_split_of,
+                              c->d_boxes, c->d_recs32, c->d_qbox, c->d_root, c->d_seg, c->d_seg32, (int)c->nbp2,
                               cross_list, cross_count, c->cross_cap);
     } else
-        k_refit_seg_local<false><<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, nullptr, nullptr, c->d_meta, c->d_boxes, c->d_bounded,
-                                                              c->d_recs32, c->d_qbox, c->d_root, write_internal ? 1 : 0, c->d_seg, (int)c->nbp2,
-                                                              cross_list, cross_count, c->cross_cap);
+        k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded,
+                                                       c->d_recs32, c->d_qbox, c->d_root, write_internal ? 1 : 0, c->d_seg, (int)c->nbp2,
+                                                       cross_list, cross_count, c->cross_cap);
     k_refit_seg_top<<<1, 1024, 0, s>>>(c->d_seg, (int)c->nbp2, nblocks);
     // about 13 cross nodes per 512-leaf block: ~one node per wave, every load chain in flight at once
     // one wave per cross node, about 13 of them per 512-leaf block: two workgroups (8 waves) per block -> 1-2 nodes per wave
     // (measured: 1024 / 2048 / 4096 / 8192 workgroups at 1 M triangles -> 120 / 113 / 111 / 112 us for the whole stage)
     const uint32_t xblocks = 2u * nblocks < 256u ? 256u : (2u * nblocks > 16384u ? 16384u : 2u * (uint32_t)nblocks);
-    if (fused && n > 1) k_cross_meta<<<xblocks, 256, 0, s>>>(c->d_keys[0], (int)n, c->d_meta, c->d_split_of, c->d_cross, cross_count, c->cross_cap);
-    if (n > 1) k_refit_seg_cross<<<xblocks, 256, 0, s>>>((int)n, c->d_meta, c->d_seg, (int)c->nbp2, c->d_boxes, c->d_bounded, c->d_recs32,
-                                                      fused ? c->d_split_of : nullptr, c->d_root, write_internal ? 1 : 0, c->d_cross, cross_count, c->cross_cap);
+    if (fused && n > 1) {
+        k_cross_meta<<<xblocks, 256, 0, s>>>(c->d_keys[0], (int)n, c->d_meta, c->d_split_of, c->d_cross, cross_count, c->cross_cap);
+        k_cross_records<<<xblocks, 256, 0, s>>>((int)n, c->d_meta, c->d_seg, c->d_seg32, (int)c->nbp2, c->d_qbox, c->d_boxes, c->d_recs32,
+                                                c->d_split_of, c->d_root, c->d_cross, cross_count, c->cross_cap);
+    } else if (n > 1)
+        k_refit_seg_cross<<<xblocks, 256, 0, s>>>((int)n, c->d_meta, c->d_seg, (int)c->nbp2, c->d_boxes, c->d_bounded, c->d_recs32,
+                                                  c->d_root, write_internal ? 1 : 0, c->d_cross, cross_count, c->cross_cap);
     c->internal_boxes_valid = write_internal;
     HIPCHK(evrec(c, EV_REFIT1));
     HIPCHK(hipGetLastError());
@@ -538,6 +543,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_parent, sizeof(int32_t) * 2 * n);
     { uint32_t nb = cdiv(nt, REFIT_BLK); c->nbp2 = 1; while (c->nbp2 < nb) c->nbp2 <<= 1; }
     ALLOC(c->d_seg, sizeof(double) * 6 * (size_t)c->nbp2 * REFIT_BLK);
+    ALLOC(c->d_seg32, sizeof(float) * 6 * ((size_t)c->nbp2 << (REFIT_LOG - SEG_MIN_LEVEL + 1)));   // fused build: levels SEG_MIN_LEVEL .. 9 of the blocks' fp32 trees
     c->cross_cap = nt;                                  // every internal node could be one (it never is: about 2 %)
     ALLOC(c->d_cross, sizeof(int32_t) * (size_t)c->cross_cap);
     ALLOC(c->d_boxes, sizeof(double) * 6 * 2 * n);
@@ -872,6 +878,17 @@ int cd_debug_counters(cd_ctx *c, unsigned long long out[12])
     std::vector<TravState> h(1);
     HIPCHK(hipMemcpy(h.data(), c->tb[0].d_state, sizeof(TravState), hipMemcpyDeviceToHost));
     for (int k = 0; k < 12; ++k) { out[k] = 0; for (int i = 0; i < NSHARD; ++i) out[k] += h[0].shard[i].pad[k]; }
+    return CD_OK;
+}
+
+int cd_debug_records(cd_ctx *c, void *recs, void *qboxes, int32_t *root)
+{
+    if (!c) return CD_ERR_ARG;
+    if (c->stage < ST_REFIT) return CD_ERR_ORDER;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (recs) HIPCHK(hipMemcpy(recs, c->d_recs32, sizeof(NodeRec32) * (size_t)c->nt, hipMemcpyDeviceToHost));
+    if (qboxes) HIPCHK(hipMemcpy(qboxes, c->d_qbox, sizeof(LeafBox32) * (size_t)c->nt, hipMemcpyDeviceToHost));
+    if (root) HIPCHK(hipMemcpy(root, c->d_root, sizeof(int32_t), hipMemcpyDeviceToHost));
     return CD_OK;
 }
 

@@ -50,7 +50,7 @@ EXPORTS = [
     "cd_load_obj", "cd_free_obj", "cd_create", "cd_destroy", "cd_update_vertices", "cd_set_morton_frame", "cd_morton_sort",
     "cd_build_hierarchy", "cd_refit_boxes", "cd_check_internal", "cd_check_leaves",
     "cd_check_triangle_idx", "cd_find_collisions", "cd_build_tree", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
-    "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_debug_counters", "cd_num_triangles",
+    "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_debug_counters", "cd_debug_records", "cd_num_triangles",
     "cd_set_option", "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
     "cd_multi_unique_id", "cd_multi_create", "cd_multi_create_from_comm", "cd_multi_destroy", "cd_multi_set_flags", "cd_multi_step",
 ]
@@ -100,6 +100,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_export_tree.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.cd_get_stats.argtypes = [vp, C.POINTER(CdStats)]
     lib.cd_debug_counters.argtypes = [vp, vp]
+    lib.cd_debug_records.argtypes = [vp, vp, vp, vp]
     lib.cd_num_triangles.argtypes = [vp, u32p]
     lib.cd_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.cd_set_vertex_id_base.argtypes = [vp, C.c_uint32]
@@ -279,6 +280,15 @@ class CollisionDetector:
         out = np.zeros(12, dtype=np.uint64)
         self._chk("cd_debug_counters", self.lib.cd_debug_counters(self._ctx, out.ctypes.data))
         return out
+
+    def debug_records(self):
+        """(right halves u32[n, 8], left halves u32[n, 8], query boxes u32[n, 8], root split) of the current tree."""
+        n = self.nt
+        recs = np.zeros((2 * n, 8), dtype=np.uint32)
+        qb = np.zeros((n, 8), dtype=np.uint32)
+        root = C.c_int32(0)
+        self._chk("cd_debug_records", self.lib.cd_debug_records(self._ctx, recs.ctypes.data, qb.ctypes.data, C.byref(root)))
+        return recs[:n], recs[n:], qb, int(root.value)
 
     # ---- cross-rank pass
     def set_vertex_id_base(self, base: int):

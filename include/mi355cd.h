@@ -171,6 +171,10 @@ int cd_get_stats(cd_ctx *ctx, cd_stats *out);
  * {chain steps, chain hops inside / outside the query's 256-leaf block, descent visits inside / outside it, longest
  * chain of each wave, 6 spare}.  Not part of any result. */
 int cd_debug_counters(cd_ctx *ctx, unsigned long long out[12]);
+/* Diagnostics: the fp32 traversal records of the current tree as the descent reads them -- recs: n x 64 bytes (n x 32 bytes
+ * of right halves {lo[3], hi[3], link, last | flags}, then n x 32 bytes of left halves {lo[3], hi[3], link, first}, both
+ * indexed by split), qboxes: n x 32 bytes {lo[3], hi[3], flags, 0}, root: the root record's split.  Either may be NULL. */
+int cd_debug_records(cd_ctx *ctx, void *recs, void *qboxes, int32_t *root);
 int cd_num_triangles(cd_ctx *ctx, uint32_t *nt);
 
 /* ---- multi-GPU cross-rank pass (new work defined by the north star; no reference call site) ----

@@ -517,6 +517,54 @@ def test_multi_step_world_gt_1_over_the_loopback_transport(quads, qcap, xs):
         assert sum(st["cross"]) > 0
 
 
+@pytest.mark.parametrize("kind", ["cloth-float", "soup-double", "mixed", "tiny", "one-block", "ragged"])
+def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
+    """The fused build (cd_build.h: hierarchy from adjacent deltas, fp32 segment trees, cross nodes by wave) against the
+    stage-wise one (k_hierarchy + the FP64 refit, key 104): the traversal records must be the same bytes -- child boxes
+    rounded outward, child links, range ends, the root's name, and the exact-in-fp32 bits of LEAF children (those of
+    internal children are not read by any kernel and not compared) -- and so must the fp32 query boxes."""
+    if kind == "cloth-float":
+        verts, vidx = synth.cloth_pair(90)
+        verts = verts.astype(np.float32).astype(np.float64)
+    elif kind == "soup-double":
+        verts, vidx = synth.soup(40000, 0.03, 77)
+    elif kind == "mixed":
+        verts, vidx = synth.soup(30000, 0.04, 78)
+        verts[: len(verts) // 2] = verts[: len(verts) // 2].astype(np.float32).astype(np.float64)
+    elif kind == "tiny":
+        verts, vidx = synth.soup(3, 0.5, 5)
+    elif kind == "one-block":
+        verts, vidx = synth.soup(512, 0.2, 6)
+    else:
+        verts, vidx = synth.soup(512 * 7 + 1, 0.05, 9)
+    got = {}
+    for fused in (1, 0):
+        with mi355cd.CollisionDetector(verts, vidx) as cd:
+            cd.set_option(104, 0 if fused else 1)
+            cd.build_tree()
+            got[fused] = cd.debug_records() + (cd.root_box(),)
+    (rr, rl, qb, root, rbox), (rr0, rl0, qb0, root0, rbox0) = got[1], got[0]
+    n = vidx.shape[0]
+    assert root == root0 and np.array_equal(qb, qb0) and np.array_equal(rbox, rbox0)
+    used = np.zeros(n, dtype=bool)                          # records are named by split: n - 1 of the n slots are in use
+    if n > 1:                                               # (unused slots hold whatever the allocation held: walk from the root)
+        frontier = np.array([root0])
+        while frontier.size:
+            used[frontier] = True
+            ch = np.concatenate([rr0[frontier, 6], rl0[frontier, 6]]).view(np.int32)
+            frontier = ch[ch >= 0]
+    assert used.sum() == max(n - 1, 0)
+    for a, b in ((rr, rr0), (rl, rl0)):
+        assert np.array_equal(a[used][:, :7], b[used][:, :7])
+    # last | flags: the low 30 bits always; bit 30 / 31 only where the left / right child is a leaf
+    assert np.array_equal(rr[used][:, 7] & 0x3fffffff, rr0[used][:, 7] & 0x3fffffff)
+    assert np.array_equal(rl[used][:, 7], rl0[used][:, 7])
+    leafL = rl0[used][:, 6].view(np.int32) < 0
+    leafR = rr0[used][:, 6].view(np.int32) < 0
+    assert np.array_equal((rr[used][:, 7] >> 30 & 1)[leafL], (rr0[used][:, 7] >> 30 & 1)[leafL])
+    assert np.array_equal((rr[used][:, 7] >> 31 & 1)[leafR], (rr0[used][:, 7] >> 31 & 1)[leafR])
+
+
 def test_device_pair_post_processing():
     """SURVEY 8f row 2 (main.cu:33-45,149-154): sorted pair list and the set of colliding triangle IDs, on the device."""
     verts, vidx = synth.soup(30000, 0.05, 12)
