@@ -276,8 +276,8 @@ def main():
             line["traversal_pairs_tested_per_s"] = (tested_total / k) / (stage["traverse"] * 1e-3)
             # roofline of the DOMINANT kernel -- whichever single launch of the step is longest, decided from the live
             # per-kernel times (HIP events riding on the kernels' own dispatch packets, on the library's stream):
-            #   k_refit_seg_local<fused>: hierarchy + refit of the 512-leaf blocks in one pass, ALGORITHMIC bytes 100 B/triangle
-            #                             (SURVEY.md 8d rows S3 + S4);
+            #   k_build_block:            hierarchy + refit + records of the 512-leaf blocks in one pass (cd_build.h), ALGORITHMIC
+            #                             bytes 100 B/triangle (SURVEY.md 8d rows S3 + S4);
             #   k_descend_half:           the fp32 descent, 40 B/triangle (row S5: the tree read once).
             # The other one is reported beside it.  `traffic` = HBM bytes per launch from the rocprofv3 --pmc passes
             # (profiles/traffic.json, produced by tools/refresh_profiles.sh + tools/summarise_profiles.py).
@@ -304,7 +304,7 @@ def main():
                         "algorithmic_bytes_per_launch": bytes_per_tri * nt, "avg_launch_ms": ms}
 
             cands = [roof("k_descend_half", "k_descend_half (fp32 BVH descent, half traversal; its candidates go to k_exact)", kern["descend"], TRAVERSAL_BYTES_PER_TRI),
-                     roof("k_refit_seg_local", "k_refit_seg_local<fused> (Karras hierarchy + AABB refit + traversal records of the 512-leaf blocks)",
+                     roof("k_build_block", "k_build_block (Karras hierarchy + AABB refit + traversal records of the 512-leaf blocks, fused)",
                           kern["build_block"], BUILD_BYTES_PER_TRI)]
             cands.sort(key=lambda r: -r["avg_launch_ms"])
             line["kernel_ms"] = kern

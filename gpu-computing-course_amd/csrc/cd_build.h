@@ -6,7 +6,8 @@
 // outward-rounded boxes -- bit for bit what rounding the FP64 merge (bvh.cuh:277) gives.  The fused build therefore
 // keeps ONE fp32 segment tree of the leaf boxes per 512-leaf block (hardware v_min_f32 / v_max_f32, 6 instructions a
 // merge against 18 for the FP64 compare-selects of box.cuh:24-32) and never forms an internal FP64 box, except
-//   * the FP64 leaf boxes themselves (k_exact, cd_pack_queries and the brute-force checker read them), and
+//   * the FP64 boxes of the leaves that are NOT exact in fp32 (k_exact and cd_pack_queries decide their candidates in
+//     FP64; an exact leaf's fp32 box is its FP64 box: leaf_box64, cd_bvh.h), and
 //   * the FP64 box of ALL leaves (node 0: cd_root_box, the multi-GPU root exchange), reduced per block from the few leaves
 //     whose fp32 value equals the block's fp32 extreme (only they can hold the FP64 extreme), then by k_refit_seg_top.
 // "Exact in fp32" flags (REC_L_EXACT / REC_R_EXACT) only matter for LEAF children -- a candidate is a pair of leaves --
@@ -53,18 +54,48 @@ __device__ __forceinline__ B32 b32_of_leaf(const LeafBox32 *__restrict__ qbox32,
     return B32{a.x, a.y, a.z, a.w, b.x, b.y};
 }
 
-// Range query [l, r] (inclusive, local leaf indices) over the block's fp32 segment tree in LDS (1-based heap, leaves at
-// REFIT_BLK + j).  min / max commute, so one accumulator takes the left and the right pieces as they come.
+// Range query [l, r] (inclusive, local leaf indices; l > r: nothing) over the block's fp32 segment tree in LDS (1-based
+// heap, leaves at REFIT_BLK + j; slot 0 holds the identity).  min / max commute, so one accumulator takes the left and
+// the right pieces as they come.  Written without branches: a level that contributes no piece reads slot 0, and the
+// loop ends when the widest range of the WAVE is done.
 __device__ __forceinline__ B32 seg_query32(const float (*t)[6], int l, int r)
 {
     B32 acc = b32_identity();
     l += REFIT_BLK; r += REFIT_BLK + 1;
-    for (int lev = 0; lev <= REFIT_LOG && l < r; ++lev) {
-        if (l & 1) { acc = b32_merge(acc, b32_load(t[l])); ++l; }
-        if (r & 1) { --r; acc = b32_merge(acc, b32_load(t[r])); }
-        l >>= 1; r >>= 1;
+    for (int lev = 0; lev <= REFIT_LOG; ++lev) {
+        const bool on = l < r;
+        if (!__builtin_amdgcn_ballot_w64(on)) break;
+        const int il = (on & ((l & 1) != 0)) ? l : 0, ir = (on & ((r & 1) != 0)) ? r - 1 : 0;
+        acc = b32_merge(acc, b32_load(t[il]));
+        acc = b32_merge(acc, b32_load(t[ir]));
+        l = (l + 1) >> 1; r >>= 1;
     }
     return acc;
+}
+
+// The adjacent deltas of a block and their min-sparse-table as 16-bit keys: T[k][x] = (m + 1) << 9 | o, where m is the
+// minimum of delta over the positions [x, x + 2^k - 1] and x + o the leftmost position that has it (o < 2^k <= 512;
+// delta + 1 <= 96: bvh.cuh:48 with the index tie-break of equal keys) -- the minimum of a range AND where it is, in
+// one value whose order is the order of the minima.
+constexpr int DK_SHIFT = 9;
+typedef uint16_t DKey;
+constexpr DKey DK_PAD = 0xffffu;
+static_assert(DL_LEVELS - 1 <= DK_SHIFT && ((64 + 32 + 1) << DK_SHIFT) < 0xffff, "key layout");
+// Nearest position with a delta below thr, walking right from s (first p >= s, or DL_N) or left from s (last p <= s,
+// or -1): a 10-step descent over the table, the same instructions for both directions.
+__device__ __forceinline__ int nsv_dir(const DKey (*T)[DL_STRIDE], bool right, int s, int thr)
+{
+    const int tk = thr << DK_SHIFT;
+    int p = s;
+#pragma unroll
+    for (int k = DL_LEVELS - 1; k >= 0; --k) {
+        const int q = right ? p + (1 << k) : p - (1 << k);
+        const int idx = right ? p : q + 1;                                 // the 2^k positions between p and q
+        const bool inside = right ? (q <= DL_N) : (q >= -1);
+        const DKey v = T[k][(idx >= 0 && idx < DL_N) ? idx : 0];
+        p = (inside & (v >= (DKey)tk)) ? q : p;
+    }
+    return p;
 }
 
 // Doubles as unsigned integers of the same order (-0 below +0), for the LDS min / max of the block's FP64 extremes.
@@ -94,8 +125,12 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
                                                            int32_t *__restrict__ cross_list, uint32_t *__restrict__ cross_count, uint32_t cross_cap)
 {
     __shared__ float t[2 * REFIT_BLK][6];           // 24 KB
-    __shared__ float nb[REFIT_BLK][6];              // 12 KB
-    __shared__ uint8_t dt[DL_LEVELS][DL_STRIDE];    // 5 KB
+    // the sparse table of the deltas (10 KB) is dead once every node knows its range and split; the nodes' own boxes
+    // (12 KB) then take its place
+    constexpr size_t TABLE_BYTES = sizeof(DKey) * DL_LEVELS * DL_STRIDE, NB_BYTES = sizeof(float) * 6 * REFIT_BLK;
+    __shared__ __align__(16) unsigned char scratch[TABLE_BYTES > NB_BYTES ? TABLE_BYTES : NB_BYTES];
+    DKey (*dt)[DL_STRIDE] = reinterpret_cast<DKey (*)[DL_STRIDE]>(scratch);
+    float (*nb)[6] = reinterpret_cast<float (*)[6]>(scratch);
     __shared__ int16_t lsplit[REFIT_BLK];
     __shared__ unsigned long long lexact[REFIT_BLK / 64];
     __shared__ unsigned long long acc[6];
@@ -103,14 +138,14 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
     __shared__ uint32_t lcount, lbase;
     const int b = blockIdx.x, b0 = b * REFIT_BLK, tid = threadIdx.x;
     const int j = b0 + tid;
-    if (tid == 0) lcount = 0;
+    if (tid == 0) { lcount = 0; b32_store(t[0], b32_identity()); }
     if (tid < 6) acc[tid] = (tid & 1) ? 0ull : ~0ull;                      // x1 x2 y1 y2 z1 z2: min, max, min, max, min, max
     // adjacent deltas of the positions b0-1 .. b0+512 (thread t: position b0-1+t; threads 0 and 1 also take the last two)
     for (int x = tid; x < DL_STRIDE; x += REFIT_BLK) {
-        uint8_t v = 0;
+        int v = 0;
         const int p = b0 - 1 + x;
-        if (x < DL_N && p >= 0 && p < n - 1) v = (uint8_t)(delta_k(keys, n, p, keys[p], p + 1) + 1);
-        dt[0][x] = x < DL_N ? v : (uint8_t)255;
+        if (x < DL_N && p >= 0 && p < n - 1) v = delta_k(keys, n, p, keys[p], p + 1) + 1;      // 0 = the out-of-range -1 of bvh.cuh:48
+        dt[0][x] = x < DL_N ? (DKey)(v << DK_SHIFT) : DK_PAD;
     }
     Box mine = box_identity();
     B32 m32 = b32_identity();
@@ -118,9 +153,9 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
     if (j < n) {
         const LeafTri lt = leaf[j];
         mine = box_set(load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2));   // box.cuh:13-22
-        store_box(boxes, (n - 1) + j, mine);
         m32 = b32_of(mine);
         exact = box_is_fp32(mine);
+        if (!exact || n == 1) store_box(boxes, (n - 1) + j, mine);        // an exact box is its fp32 copy (leaf_box64, cd_bvh.h); n == 1: the leaf is node 0
         float4 *qp = reinterpret_cast<float4 *>(qbox32 + j);
         qp[0] = make_float4(m32.lx, m32.ly, m32.lz, m32.hx);
         qp[1] = make_float4(m32.hy, m32.hz, __uint_as_float((exact ? LB_EXACT : 0u) | (box_overlap(mine, mine) ? LB_SELF : 0u)), 0.f);
@@ -138,8 +173,8 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
             const int k = REFIT_LOG - dd;
             for (int x = tid; x < DL_STRIDE; x += REFIT_BLK) {
                 const int y = x + (1 << (k - 1));
-                const uint8_t u = dt[k - 1][x], w = y < DL_STRIDE ? dt[k - 1][y] : (uint8_t)255;
-                dt[k][x] = u < w ? u : w;
+                const DKey u = dt[k - 1][x], w = y < DL_STRIDE ? dt[k - 1][y] : DK_PAD;
+                dt[k][x] = (w >> DK_SHIFT) < (u >> DK_SHIFT) ? (DKey)(w + (1 << (k - 1))) : u;     // a tie keeps the left one
             }
         }
         const int cnt = 1 << dd;
@@ -167,32 +202,26 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
     if (i < n - 1) {
         // determineRange, bvh.cuh:100-123, on the adjacent deltas: dl index of position p is p - (b0 - 1)
         const int x = tid;                                                 // dl index of position i - 1; position i is x + 1
-        const int dL = (int)dt[0][x], dR = (int)dt[0][x + 1];
+        const int dL = (int)(dt[0][x] >> DK_SHIFT), dR = (int)(dt[0][x + 1] >> DK_SHIFT);
         const bool right = dR >= dL;                                       // d = sign(delta(i, i+1) - delta(i, i-1)); equal only when both are out of range
         const int thr = right ? dL : dR;                                   // delta_min + 1
-        if (right) {
-            // j = first position p > i with delta(p, p+1) < delta_min  (leaf p is the last of the range)
-            // (node 0 has delta_min = -1, nothing is below it: its range is everything)
-            const int p = (thr == 0) ? ((n - 1 <= b0 + REFIT_BLK - 1) ? (n - 1) - (b0 - 1) : DL_N) : nsv_right(dt, x + 2, thr);
-            first = i; last = b0 - 1 + p;
-            have = p <= REFIT_BLK;                                         // dl index 512 is position b0+511, the block's last leaf
-            cross = !have;
-        } else {
-            // j = 1 + last position p < i - 1 with delta(p, p+1) < delta_min
-            const int p = psv_left(dt, x - 1, thr);
-            if (p < 0) cross = true;                                       // ran off the block (dl index 0 is position b0-1: found there means the range starts at b0)
-            else { first = b0 - 1 + p + 1; last = i; have = true; }
-        }
+        // right: the first position p > i with delta(p, p+1) < delta_min (leaf p is the last of the range);
+        // left: the last position p < i - 1 with delta(p, p+1) < delta_min (leaf p + 1 is the first of the range)
+        int p = nsv_dir(dt, right, right ? x + 2 : x - 1, thr);
+        // (node 0 has delta_min = -1, nothing is below it: its range is everything)
+        if (right && thr == 0) p = (n - 1 <= b0 + REFIT_BLK - 1) ? (n - 1) - (b0 - 1) : DL_N;
+        if (right) { first = i; last = b0 - 1 + p; have = p <= REFIT_BLK; }   // dl index 512 is position b0+511, the block's last leaf
+        else { first = b0 + p; last = i; have = p >= 0; }                   // dl index 0 is position b0-1: found there, the range starts at b0
+        cross = !have;                                                      // ran off the block
         if (have) {
             // findSplit, bvh.cuh:57-98: the position of the (unique) minimum adjacent delta inside [first, last - 1]
             const int a = first - (b0 - 1), e = last - 1 - (b0 - 1);       // dl indices
-            const int len = e - a + 1;
-            const int k = 31 - __clz(len);
-            const int m0 = (int)dt[k][a], m1 = (int)dt[k][e - (1 << k) + 1];
-            const int mn = m0 < m1 ? m0 : m1;
-            split = b0 - 1 + nsv_right(dt, a, mn + 1);
+            const int k = 31 - __clz(e - a + 1);
+            const int a1 = e - (1 << k) + 1;
+            const DKey m0 = dt[k][a], m1 = dt[k][a1];                      // (equal minima of the two windows are the same position: the minimum is unique)
+            const int omask = (1 << DK_SHIFT) - 1;
+            split = b0 - 1 + (((m1 >> DK_SHIFT) < (m0 >> DK_SHIFT)) ? a1 + ((int)m1 & omask) : a + ((int)m0 & omask));
             split_of[i] = split;
-            b32_store(nb[tid], seg_query32(t, first - b0, last - b0));     // the node's own box
         }
         lsplit[tid] = have ? (int16_t)(split - b0) : (int16_t)-1;
         if (cross) {
@@ -201,6 +230,8 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
             else { const uint32_t g = atomicAdd(cross_count, 1u); if (g < cross_cap) cross_list[g] = i; }
         }
     }
+    __syncthreads();                                                        // every node has its range and split: the table is dead
+    b32_store(nb[tid], seg_query32(t, have ? first - b0 : 1, have ? last - b0 : 0));   // the node's own box (an empty query for the others)
     __syncthreads();                                                        // nb[], lsplit[], acc[], lcount of the whole block
     if (have) {
         // children (bvh.cuh:174-195): the left child is leaf `split` or internal node `split`, the right one leaf / node split + 1

@@ -46,6 +46,17 @@ struct alignas(32) LeafBox32 { float lo[3], hi[3]; uint32_t flags, pad; };
 static_assert(sizeof(LeafBox32) == 32, "LeafBox32 layout");
 constexpr uint32_t LB_EXACT = 1u, LB_SELF = 2u;
 
+// FP64 box of leaf j.  A box that is exact in fp32 IS its query box (widening is exact, signed zeros included), and the
+// fused build (cd_build.h) does not store the FP64 copy of such a leaf at all: every reader of leaf boxes on the
+// traversal side comes through here.  (The stage-wise refit writes all of boxes[]: that is what cd_export_tree shows.)
+__device__ __forceinline__ Box load_box(const double *boxes, int node);
+__device__ __forceinline__ Box leaf_box64(const double *__restrict__ boxes, const LeafBox32 *__restrict__ qbox32, int n, int j)
+{
+    const float4 a = reinterpret_cast<const float4 *>(qbox32 + j)[0], b = reinterpret_cast<const float4 *>(qbox32 + j)[1];
+    if (__float_as_uint(b.z) & LB_EXACT) return Box{(double)a.x, (double)a.w, (double)a.y, (double)b.x, (double)a.z, (double)b.y};
+    return load_box(boxes, (n - 1) + j);
+}
+
 // Sorted-order leaf payload: {ID, vIdx[0..2]} (triangle.cuh:6,9) -- 16 B instead of the 56-byte Triangle.
 struct alignas(16) LeafTri { uint32_t id, v0, v1, v2; };
 

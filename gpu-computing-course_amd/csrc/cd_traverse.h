@@ -937,7 +937,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
             if (filtered[j]) { lt[j] = LeafTri{0, 0, 0, 0}; lb[j] = qbox[j] = Box{0, 0, 0, 0, 0, 0}; q_id[j] = qa[j] = qb[j] = qc[j] = 0; continue; }
             lt[j] = leaf[lj];
             lb[j] = qbox[j] = Box{0, 0, 0, 0, 0, 0};
-            if (!certain[j]) lb[j] = load_box(boxes, (n - 1) + (int)lj);
+            if (!certain[j]) lb[j] = leaf_box64(boxes, src.qbox, n, (int)lj);
             if (EXTERNAL) {
                 const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + qi;
                 q_id[j] = q->id; qa[j] = q->vidx[0]; qb[j] = q->vidx[1]; qc[j] = q->vidx[2];
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
             } else {
                 const LeafTri ql = leaf[qi];
                 q_id[j] = ql.id; qa[j] = ql.v0; qb[j] = ql.v1; qc[j] = ql.v2;
-                if (!certain[j]) qbox[j] = load_box(boxes, (n - 1) + (int)qi);
+                if (!certain[j]) qbox[j] = leaf_box64(boxes, src.qbox, n, (int)qi);
             }
         }
 #pragma unroll
@@ -1076,8 +1076,8 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_queries(const double *__r
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool live = j < n;
     // the leaf's fp32 box (rounded outward) rules most leaves out without touching the 48-byte FP64 box
-    float lo0 = 0, lo1 = 0, lo2 = 0, hi0 = 0, hi1 = 0, hi2 = 0;
-    if (live) { const LeafBox32 lb = qbox32[j]; lo0 = lb.lo[0]; lo1 = lb.lo[1]; lo2 = lb.lo[2]; hi0 = lb.hi[0]; hi1 = lb.hi[1]; hi2 = lb.hi[2]; }
+    float lo0 = 0, lo1 = 0, lo2 = 0, hi0 = 0, hi1 = 0, hi2 = 0; bool exact32 = false;
+    if (live) { const LeafBox32 lb = qbox32[j]; lo0 = lb.lo[0]; lo1 = lb.lo[1]; lo2 = lb.lo[2]; hi0 = lb.hi[0]; hi1 = lb.hi[1]; hi2 = lb.hi[2]; exact32 = (lb.flags & LB_EXACT) != 0; }
     Box mine{0, 0, 0, 0, 0, 0}; bool have_box = false;
     const Box me = my_root ? load_box(my_root, 0) : Box{0, 0, 0, 0, 0, 0};
     for (int p = 0; p < n_boxes; ++p) {                                       // (wave-uniform loop and skips)
@@ -1088,7 +1088,10 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_queries(const double *__r
         bool hit = live && lo0 < __double2float_ru(rb.x2) && __double2float_rd(rb.x1) < hi0 && lo1 < __double2float_ru(rb.y2) &&
                    __double2float_rd(rb.y1) < hi1 && lo2 < __double2float_ru(rb.z2) && __double2float_rd(rb.z1) < hi2;
         if (hit) {
-            if (!have_box) { mine = load_box(boxes, (n - 1) + j); have_box = true; }
+            if (!have_box) {                                                  // (an exact-in-fp32 box is its query box: leaf_box64, cd_bvh.h)
+                mine = exact32 ? Box{(double)lo0, (double)hi0, (double)lo1, (double)hi1, (double)lo2, (double)hi2} : load_box(boxes, (n - 1) + j);
+                have_box = true;
+            }
             hit = box_overlap(mine, rb);                                      // box.cuh:40-43, exact
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
