@@ -5,6 +5,7 @@
 #include "../../include/mi355rt.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstring>
 #include <new>
 
@@ -31,7 +32,11 @@ struct alignas(16) SphShade { float r, g, b, sr; };
 __device__ __forceinline__ void prepare_one(const RtSphere *__restrict__ s, const int32_t *__restrict__ shifts, int i, SphGeom &g, SphShade &h)
 {
     const RtSphere sp = s[i];
-    const int xs = shifts[4 * sp.idx], ys = shifts[4 * sp.idx + 1];        // sphere.cuh:35
+    // sphere.cuh:35: the shift row is the sphere's idx field; spheres normally carry idx == their position, so that row is
+    // fetched beside the sphere instead of after it (one memory round trip less) and only fetched again when idx differs
+    int2 sh = reinterpret_cast<const int2 *>(shifts)[2 * i];
+    if (sp.idx != i) sh = reinterpret_cast<const int2 *>(shifts)[2 * sp.idx];
+    const int xs = sh.x, ys = sh.y;
     g.cx = sp.x + (float)xs; g.cy = sp.y + (float)ys; g.rr = sp.radius * sp.radius; g.z = sp.z;
     h.r = sp.r; h.g = sp.g; h.b = sp.b; h.sr = sqrtf(sp.radius * sp.radius);
 }
@@ -91,9 +96,6 @@ __device__ __forceinline__ bool may_touch(const SphGeom g, float ox0, float ox1,
 }
 
 constexpr int SUPER = 256;             // super-tile edge in pixels (4 x 4 tiles)
-#ifndef RT_QUADRANTS
-#define RT_QUADRANTS 0
-#endif
 constexpr int TILE_CAP = 48;           // entries a tile's own list holds; a tile that is touched by more spheres falls back to its super-tile's list
 
 // What a pixel loop needs from one sphere, 32 bytes: the hit geometry, the colour and the index (for the tie rule).
@@ -122,33 +124,50 @@ __device__ __forceinline__ void bin_sphere(const SphGeom g, const SphShade h, in
     if (xhi < 0.0 || yhi < Y0 || xlo > (double)(dim - 1) || ylo > Y1) return;
     const int px0 = (int)fmax(xlo, 0.0), px1 = (int)fmin(xhi, (double)(dim - 1)), py0 = (int)fmax(ylo, Y0), py1 = (int)fmin(yhi, Y1);
     const TileEnt ent{g.cx, g.cy, g.rr, g.z, h.r, h.g, h.b, i};
-    for (int ty = py0 / TILE; ty <= py1 / TILE; ++ty)
-        for (int tx = px0 / TILE; tx <= px1 / TILE; ++tx) {
+    // The list positions come from returning atomics, a microsecond each: the tiles' and the super-tiles' are issued
+    // together, eight at a time (a sphere of the reference's sizes touches at most 2 x 2 tiles and 2 x 2 super-tiles), and
+    // waited for once.  Entries 0-3 of a batch are tiles, 4-7 super-tiles.
+    int pend[8], npt = 0, nps = 0;
+    auto flush = [&]() {
+        int pos[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pos[k] = k < npt ? atomicAdd(&tile_count[pend[k]], 1) : TILE_CAP;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pos[4 + k] = k < nps ? atomicAdd(&super_count[pend[4 + k]], 1) : -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (pos[k] < TILE_CAP) tile_list[(size_t)pend[k] * TILE_CAP + pos[k]] = ent;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (pos[4 + k] >= 0) super_list[(size_t)pend[4 + k] * n + pos[4 + k]] = i;
+        npt = nps = 0;
+    };
+    const int tx0 = px0 / TILE, tx1 = px1 / TILE, tyA = py0 / TILE, tyB = py1 / TILE;
+    const int sx0 = px0 / SUPER, sx1 = px1 / SUPER, syA = py0 / SUPER, syB = py1 / SUPER;
+    int tx = tx0, ty = tyA, sx = sx0, sy = syA;
+    bool more_t = true, more_s = true;
+    while (more_t || more_s) {
+        while (more_t && npt < 4) {
             const int X0 = tx * TILE, Yt = ty * TILE;
             const float ox0 = (float)(X0 - dim / 2 + c_shift_x), ox1 = (float)(X0 + TILE - 1 - dim / 2 + c_shift_x);
             const float oy0 = (float)(Yt - dim / 2 + c_shift_y), oy1 = (float)(Yt + TILE - 1 - dim / 2 + c_shift_y);
-            if (may_touch(g, ox0, ox1, oy0, oy1)) {
-                const int t = ty * ntx + tx;
-                const int pos = atomicAdd(&tile_count[t], 1);
-                if (pos < TILE_CAP) tile_list[(size_t)t * TILE_CAP + pos] = ent;
-            }
+            if (may_touch(g, ox0, ox1, oy0, oy1)) pend[npt++] = ty * ntx + tx;
+            if (++tx > tx1) { tx = tx0; if (++ty > tyB) more_t = false; }
         }
-    for (int sy = py0 / SUPER; sy <= py1 / SUPER; ++sy)
-        for (int sx = px0 / SUPER; sx <= px1 / SUPER; ++sx) {
+        while (more_s && nps < 4) {
             const int X0 = sx * SUPER, Ys = sy * SUPER;
             const int X1 = min(X0 + SUPER, dim) - 1, Ye = min(Ys + SUPER, dim) - 1;
             const float ox0 = (float)(X0 - dim / 2 + c_shift_x), ox1 = (float)(X1 - dim / 2 + c_shift_x);
             const float oy0 = (float)(Ys - dim / 2 + c_shift_y), oy1 = (float)(Ye - dim / 2 + c_shift_y);
-            if (may_touch(g, ox0, ox1, oy0, oy1)) {
-                const int st = sy * nsx + sx;
-                super_list[(size_t)st * n + atomicAdd(&super_count[st], 1)] = i;
-            }
+            if (may_touch(g, ox0, ox1, oy0, oy1)) pend[4 + nps++] = sy * nsx + sx;
+            if (++sx > sx1) { sx = sx0; if (++sy > syB) more_s = false; }
         }
+        flush();
+    }
 }
 
 // The per-sphere prepass; in binned mode (tile_list != nullptr) the same thread also bins its sphere, and the launch
 // zeroes the list counters of the NEXT frame (two sets, used alternately: no memset between frames).
-__global__ __launch_bounds__(256) void k_prepare(const RtSphere *__restrict__ s, const int32_t *__restrict__ shifts, int n,
+constexpr int PREP_THREADS = 64;       // one wave per workgroup: 4096 spheres spread over 64 CUs instead of 16
+__global__ __launch_bounds__(PREP_THREADS) void k_prepare(const RtSphere *__restrict__ s, const int32_t *__restrict__ shifts, int n,
                                                  SphGeom *__restrict__ geom, SphShade *__restrict__ shade,
                                                  int dim, int c_shift_x, int c_shift_y, int nsx, int ty0, int ty1,
                                                  int *__restrict__ super_list, int *__restrict__ super_count,
@@ -183,22 +202,25 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
 {
     const int tid = threadIdx.x;
     const int X0 = blockIdx.x * TILE, Y0 = (blockIdx.y + tile_y0) * TILE;
-    // BRUTE: tx = tid & 15 owns 4 consecutive columns, ty = tid >> 4 owns rows ty, ty+16, ty+32, ty+48.
-    // BINNED: a wave owns one 32x32 QUADRANT of the tile (lane = 4 columns x 4 consecutive rows in an 8 x 8 grid), so
-    // that a sphere which cannot touch the quadrant is skipped by the whole wave (wave-uniform may_touch): a quadrant
-    // sees about half the spheres its tile does.  A row of a quadrant is 8 lanes x 16 B = 128 contiguous bytes.
+    // BRUTE: tx = tid & 15 owns 4 consecutive columns, ty = tid >> 4 owns rows ty, ty+16, ty+32, ty+48 (every sphere
+    // is tested against every pixel: the mapping only has to store well).
+    // BINNED: what a wave pays for a sphere is decided by its pixels that are processed TOGETHER -- the sqrt / depth
+    // branch of shade_one runs for all 64 lanes as soon as one of them is inside the disc.  So a wave owns one 32x32
+    // QUADRANT of the tile, and its 16 pixel slots are the quadrant's sixteen 8x8 BLOCKS (lane = one pixel of the
+    // block): a sphere costs the blocks its disc touches (~area + perimeter) instead of every 64-pixel row segment it
+    // crosses, a sphere that cannot touch the quadrant is skipped by the whole wave (wave-uniform may_touch), and a block
+    // no sphere covers skips the shading epilogue.  The quadrant goes through LDS once at the end so that it is stored
+    // as rows of 128 contiguous bytes.
     const int wv = tid >> 6, ln = tid & 63;
-    constexpr bool QUAD = BINNED && RT_QUADRANTS;
-    const int tx = QUAD ? ((wv & 1) * 8 + (ln & 7)) : (tid & 15);
-    const int ty = QUAD ? ((wv >> 1) * 32 + (ln >> 3) * 4) : (tid >> 4);
-    const int rstep = QUAD ? 1 : 16;
+    const int qx = (wv & 1) * 32, qy = (wv >> 1) * 32;
+    const int tx = tid & 15, ty = tid >> 4;
     const int x = X0 + 4 * tx;
     float ox[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ox[k] = (float)(x + k - dim / 2 + c_shift_x);          // anime_ray.cu:65
+    for (int k = 0; k < 4; ++k) ox[k] = (float)((BINNED ? X0 + qx + 8 * k + (ln & 7) : x + k) - dim / 2 + c_shift_x);          // anime_ray.cu:65
     float oy[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) oy[k] = (float)(Y0 + ty + rstep * k - dim / 2 + c_shift_y); // anime_ray.cu:66
+    for (int k = 0; k < 4; ++k) oy[k] = (float)((BINNED ? Y0 + qy + 8 * k + (ln >> 3) : Y0 + ty + 16 * k) - dim / 2 + c_shift_y); // anime_ray.cu:66
     Px px[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -218,15 +240,16 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
         const int cnt = tile_count[t];
         uint32_t mytests = 0;
         // this wave's quadrant, in ray coordinates
-        const int QX0 = X0 + (wv & 1) * 32, QY0 = Y0 + (wv >> 1) * 32;
+        const int QX0 = X0 + qx, QY0 = Y0 + qy;
         const float qx0 = (float)(QX0 - dim / 2 + c_shift_x), qx1 = (float)(QX0 + 31 - dim / 2 + c_shift_x);
         const float qy0 = (float)(QY0 - dim / 2 + c_shift_y), qy1 = (float)(QY0 + 31 - dim / 2 + c_shift_y);
         if (cnt <= TILE_CAP) {
             const TileEnt *ents = tile_list + (size_t)t * TILE_CAP;                  // workgroup-uniform: scalar loads
+            // (fetching the entries four at a time, the first four before the count is known: no change, 35.0 us)
             for (int k = 0; k < cnt; ++k) {
                 const TileEnt e = ents[k];
                 const SphGeom g{e.cx, e.cy, e.rr, e.z};
-                if (QUAD && !may_touch(g, qx0, qx1, qy0, qy1)) continue;             // (wave-uniform)
+                if (!may_touch(g, qx0, qx1, qy0, qy1)) continue;             // (wave-uniform)
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -244,7 +267,7 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
                 const SphGeom g = geom[i];
                 if (!may_touch(g, ox0, ox1, oy0, oy1)) continue;                     // (workgroup-uniform)
                 ++mytests;
-                if (QUAD && !may_touch(g, qx0, qx1, qy0, qy1)) continue;             // (wave-uniform)
+                if (!may_touch(g, qx0, qx1, qy0, qy1)) continue;             // (wave-uniform)
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -253,12 +276,29 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
         }
         if (tid == 0 && tile_tests) tile_tests[t] = mytests;                         // sphere tests per pixel of this tile (summed by the host)
     }
+    if (BINNED) {
+        // pixel (8b + lx, 8a + ly) of the quadrant -> LDS (row stride 36 words: the eight rows of a block land in different
+        // banks), then every lane stores 4 consecutive pixels of rows ly, ly + 8, ly + 16, ly + 24.  Wave-private: no barrier.
+        __shared__ uint32_t quad[THREADS / 64][32][36];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int y = Y0 + ty + rstep * a;
-        uint4 o;
-        o.x = pack_px(px[a][0], shade); o.y = pack_px(px[a][1], shade); o.z = pack_px(px[a][2], shade); o.w = pack_px(px[a][3], shade);
-        *reinterpret_cast<uint4 *>(rgba + (size_t)y * dim + x) = o;                       // offset = x + y*dim, anime_ray.cu:64
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) quad[wv][8 * a + (ln >> 3)][8 * b + (ln & 7)] = pack_px(px[a][b], shade);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 8 * k + (ln >> 3), cx = 4 * (ln & 7);
+            const uint4 o = *reinterpret_cast<const uint4 *>(&quad[wv][r][cx]);
+            *reinterpret_cast<uint4 *>(rgba + (size_t)(Y0 + qy + r) * dim + (X0 + qx + cx)) = o;   // offset = x + y*dim, anime_ray.cu:64
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int y = Y0 + ty + 16 * a;
+            uint4 o;
+            o.x = pack_px(px[a][0], shade); o.y = pack_px(px[a][1], shade); o.z = pack_px(px[a][2], shade); o.w = pack_px(px[a][3], shade);
+            *reinterpret_cast<uint4 *>(rgba + (size_t)y * dim + x) = o;                   // offset = x + y*dim, anime_ray.cu:64
+        }
     }
 }
 
@@ -441,22 +481,28 @@ int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, 
     if (!c || (!shifts4 && !c->anim_ready) || y0 < 0 || y1 > c->dim || y0 >= y1 || y0 % TILE || y1 % TILE) return RT_ERR_ARG;
     hipStream_t s = c->stream;
     if (shifts4) HIPCHK(hipMemcpyAsync(c->d_shifts, shifts4, sizeof(int32_t) * 4 * (size_t)c->n, hipMemcpyHostToDevice, s));   // NULL: the device-resident animation state
-    HIPCHK(hipEventRecord(c->ev0, s));
+    // (the frame's time stamps ride on the dispatch packets of its first and last kernel: an event record of its own is a
+    //  barrier packet, a few idle microseconds each)
     const dim3 grid(c->dim / TILE, (y1 - y0) / TILE);
     const int ty0 = y0 / TILE, ty1 = y1 / TILE, ntx = c->dim / TILE;
     if (c->mode == RT_MODE_BINNED) {
         const int nsx = (c->dim + SUPER - 1) / SUPER;
         int *cur = c->d_counts[c->frame & 1], *nxt = c->d_counts[(c->frame + 1) & 1];
         ++c->frame;
-        k_prepare<<<(c->n + 255) / 256, 256, 0, s>>>(c->d_spheres, c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, csx, csy, nsx, ty0, ty1,
-                                                      c->d_super_list, cur + c->ntiles, c->d_tile_list, cur, nxt, c->n_counts);
-        k_render<true><<<grid, THREADS, 0, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, ty0, c->d_rgba, c->d_tile_tests,
-                                                c->d_super_list, cur + c->ntiles, nsx, c->d_tile_list, cur);
+        hipExtLaunchKernelGGL(k_prepare, dim3((c->n + PREP_THREADS - 1) / PREP_THREADS), dim3(PREP_THREADS), 0u, s, c->ev0, nullptr, 0u,
+                              (const RtSphere *)c->d_spheres, (const int32_t *)c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, (int)csx, (int)csy, nsx, ty0, ty1,
+                              c->d_super_list, cur + c->ntiles, c->d_tile_list, cur, nxt, c->n_counts);
+        hipExtLaunchKernelGGL(k_render<true>, grid, dim3(THREADS), 0u, s, nullptr, c->ev1, 0u,
+                              (const SphGeom *)c->d_geom, (const SphShade *)c->d_shade, c->n, c->dim, (int)csx, (int)csy, ty0, c->d_rgba, c->d_tile_tests,
+                              (const int *)c->d_super_list, (const int *)(cur + c->ntiles), nsx, (const TileEnt *)c->d_tile_list, (const int *)cur);
     } else {
-        k_prepare<<<(c->n + 255) / 256, 256, 0, s>>>(c->d_spheres, c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, csx, csy, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
-        k_render<false><<<grid, THREADS, 0, s>>>(c->d_geom, c->d_shade, c->n, c->dim, csx, csy, ty0, c->d_rgba, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
+        hipExtLaunchKernelGGL(k_prepare, dim3((c->n + PREP_THREADS - 1) / PREP_THREADS), dim3(PREP_THREADS), 0u, s, c->ev0, nullptr, 0u,
+                              (const RtSphere *)c->d_spheres, (const int32_t *)c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, (int)csx, (int)csy, 0, 0, 0,
+                              (int *)nullptr, (int *)nullptr, (TileEnt *)nullptr, (int *)nullptr, (int *)nullptr, 0);
+        hipExtLaunchKernelGGL(k_render<false>, grid, dim3(THREADS), 0u, s, nullptr, c->ev1, 0u,
+                              (const SphGeom *)c->d_geom, (const SphShade *)c->d_shade, c->n, c->dim, (int)csx, (int)csy, ty0, c->d_rgba, (uint32_t *)nullptr,
+                              (const int *)nullptr, (const int *)nullptr, 0, (const TileEnt *)nullptr, (const int *)nullptr);
     }
-    HIPCHK(hipEventRecord(c->ev1, s));
     // from here on an early return must not leave a copy into caller / context memory in flight: synchronise first
     hipError_t e = hipGetLastError();
     const size_t t0 = (size_t)ty0 * ntx, nt = (size_t)(ty1 - ty0) * ntx;
