@@ -128,17 +128,23 @@ __global__ __launch_bounds__(256) void k_frame_from_bounds(const double *__restr
 constexpr int MORTON_THREADS = 512;
 __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restrict__ verts, const uint32_t *__restrict__ vidx, uint32_t n,
                                                            const double *__restrict__ frame /* off[3], span[3] */,
-                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ ghist /* [8][256] */, int first_digit)
+                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ ghist /* [8][256] */, int first_digit,
+                                                           int down /* shifted hybrid sort: digits taken `down` bits lower */, uint32_t *__restrict__ overflow)
 {
     __shared__ uint32_t h[8][RADIX];
     for (int i = threadIdx.x; i < 8 * RADIX; i += MORTON_THREADS) (&h[0][0])[i] = 0;
     __syncthreads();
+    uint64_t above = 0;
     for (uint32_t t = blockIdx.x * MORTON_THREADS + threadIdx.x; t < n; t += gridDim.x * MORTON_THREADS) {
         const d3 c = centroid_of(verts, vidx, t);
         const uint64_t k = morton3d(c.x, c.y, c.z, frame, frame + 3);
         keys[t] = k;
-        hist_add(h, k, first_digit);
+        hist_add(h, k, first_digit, down);
+        above |= k;
     }
+    // a centroid outside the Morton frame sets key bits the shifted digits do not cover (bits 64 - down .. 63): the
+    // shifted hybrid sort then does not apply -- same flag, same repair (the next form) as a run too long to window
+    if (down && (above >> (64 - down))) atomicExch(overflow, 1u);
     __syncthreads();
     for (int i = threadIdx.x + first_digit * RADIX; i < 8 * RADIX; i += MORTON_THREADS) {
         const uint32_t v = (&h[0][0])[i];

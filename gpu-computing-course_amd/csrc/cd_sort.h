@@ -74,11 +74,12 @@ constexpr unsigned long long OS_VALUE_MASK = (1ull << 62) - 1;
 // Digit histograms: ghist[p][d] = number of keys whose digit p equals d, accumulated by k_morton (cd_bvh.h) while it
 // writes the keys -- workgroup-local LDS histograms flushed with one global atomic per non-empty bin.  hist_add() is
 // the per-key part.
-__device__ __forceinline__ void hist_add(uint32_t (*h)[RADIX], uint64_t k, int first_digit)
+// `down`: the digits are taken `down` bits lower (the shifted hybrid sort: digits 6 and 7 are key bits 44..51 and 52..59).
+__device__ __forceinline__ void hist_add(uint32_t (*h)[RADIX], uint64_t k, int first_digit, int down = 0)
 {
 #pragma unroll
     for (int p = 0; p < 8; ++p)
-        if (p >= first_digit) atomicAdd(&h[p][(k >> (8 * p)) & 255], 1u);      // (first_digit is workgroup-uniform)
+        if (p >= first_digit) atomicAdd(&h[p][(k >> (8 * p - down)) & 255], 1u);      // (first_digit, down are workgroup-uniform; down <= 8 * first_digit)
 }
 
 // Stand-alone histogram kernel for keys that do not come from k_morton (the pair post-processing sort).
@@ -237,6 +238,7 @@ constexpr int LOCAL_CAP     = LOCAL_ITEMS * LOCAL_THREADS;               // 1024
 
 __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                               uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n,
+                                                              int run_shift /* a run = equal key bits [run_shift, 64): what the global passes sorted by */,
                                                               uint32_t *__restrict__ overflow)
 {
     __shared__ uint2 sitem[LOCAL_CAP];                   // 80 KB: {high 32 key bits, position inside the window}
@@ -263,8 +265,8 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
             for (int u = 0; u < PROBES; ++u) {
                 const long long q = (long long)p - HALF + (u * LOCAL_THREADS + (int)tid);
                 const bool live = p != 0 && p < n && q >= 0 && q < (long long)n;
-                top[e][u][0] = (live && q > 0) ? (uint32_t)(keys_in[q - 1] >> 48) : 0x10000u;    // 0x10000: "differs" (q == 0 is a start)
-                top[e][u][1] = live ? (uint32_t)(keys_in[q] >> 48) : 0x10000u;
+                top[e][u][0] = (live && q > 0) ? (uint32_t)(keys_in[q - 1] >> run_shift) : 0xffffffffu;    // 0xffffffff: "differs" (q == 0 is a start); run_shift >= 44
+                top[e][u][1] = live ? (uint32_t)(keys_in[q] >> run_shift) : 0xffffffffu;
             }
         }
 #pragma unroll

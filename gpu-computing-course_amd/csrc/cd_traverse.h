@@ -80,7 +80,7 @@ __global__ void k_sort_flags_word(const uint32_t *__restrict__ sort_flags /* 9 w
     if (threadIdx.x != 0) return;
     uint32_t timeout = 0;
     for (int i = 0; i < 8; ++i) timeout |= sort_flags[i];
-    *out = timeout ? 2ull : (sort_flags[8] ? (sort_mode >= 2 ? 2ull : 1ull) : 0ull);
+    *out = timeout ? 2ull : (sort_flags[8] ? (sort_mode >= 3 ? 2ull : 1ull) : 0ull);
 }
 
 constexpr int TRAV_THREADS = 256;

@@ -89,7 +89,7 @@ struct cd_ctx {
     bool leaves_filled = false;             // the sort's fix-up hop already wrote leaf[], parent = -1, bounded = 0
     bool events_ride = false;               // the last pass recorded EV_TRAV0 / EV_DESC1 / EV_TRAV1 through its kernels' dispatch packets
     bool prezeroed = false;                 // fused path: the scratch block was zeroed by one memset at pipeline start
-    int sort_mode = 0;                      // 0 hybrid (2 global passes + in-LDS sort of the windows + fix-up), 1 half-key (4 passes + fix-up),
+    int sort_mode = 0;                      // 0 hybrid on key bits 44..59 (every in-frame Morton key is below 2^60), 1 hybrid on bits 48..63 (2 global passes + in-LDS sort of the windows + fix-up), 2 half-key (4 passes + fix-up),
                                             // 2 full (8 passes); forced by CD_OPT_SORT_FULL, or escalated after an overflow on this context
     double root_box_host[6] = {};           // AABB of the whole tree, fetched together with other read-backs
     bool root_box_valid = false;
@@ -173,28 +173,31 @@ int enqueue_morton_sort(cd_ctx *c)
     // sort of run-aligned windows + the fix-up hop; half-key = 4 global passes on the high 32 bits + the fix-up hop;
     // full = 8 global passes.  The keys start in the buffer that leaves the sorted data in buffer 0.
     const int mode = c->sort_mode;
-    const int first_digit = mode == 0 ? 6 : (mode == 1 ? 4 : 0);
-    int cur = mode == 1 ? 1 : 0;
+    const bool hybrid = mode <= 1;
+    const int down = mode == 0 ? 4 : 0;         // mode 0: the two global digits are key bits 44..51 and 52..59 -- 16 bits that all vary,
+                                                // where bits 48..63 of a 60-bit Morton key hold 12: runs 16 x shorter, windows of even size
+    const int first_digit = hybrid ? 6 : (mode == 2 ? 4 : 0);
+    int cur = mode == 2 ? 1 : 0;
     const uint32_t mblocks = cdiv(n, MORTON_THREADS * 4) < 1024u ? cdiv(n, MORTON_THREADS * 4) : 1024u;
-    k_morton<<<mblocks, MORTON_THREADS, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_frame, c->d_keys[cur], c->d_os_hist, first_digit);
+    k_morton<<<mblocks, MORTON_THREADS, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_frame, c->d_keys[cur], c->d_os_hist, first_digit, down, c->d_os_ticket + 16);
     HIPCHK(evrec(c, EV_MORTON1));
     // onesweep: one pass over the data per digit; the digit histograms came with the keys
     for (int pass = first_digit; pass < 8; ++pass) {
-        k_os_pass<<<c->ntiles, OS_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1], n, pass * RADIX_BITS,
+        k_os_pass<<<c->ntiles, OS_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1], n, pass * RADIX_BITS - down,
                                                     c->d_os_hist + pass * RADIX, c->d_os_look + (size_t)pass * c->ntiles * RADIX,
                                                     c->d_os_ticket + pass, pass == first_digit);
         cur ^= 1;
     }
-    if (mode == 0) {                            // data is in buffer 0 again; windows go 0 -> 1, the fix-up hop 1 -> 0
-        k_local_sort<<<cdiv(n, LOCAL_W), LOCAL_THREADS, 0, s>>>(c->d_keys[0], c->d_perm[0], c->d_keys[1], c->d_perm[1], n, c->d_os_ticket + 16);
+    if (hybrid) {                               // data is in buffer 0 again; windows go 0 -> 1, the fix-up hop 1 -> 0
+        k_local_sort<<<cdiv(n, LOCAL_W), LOCAL_THREADS, 0, s>>>(c->d_keys[0], c->d_perm[0], c->d_keys[1], c->d_perm[1], n, 48 - down, c->d_os_ticket + 16);
     }
     c->leaves_filled = false;
-    if (mode != 2) {
+    if (mode != 3) {
         k_sort_fixup_fill<<<cdiv(n, 256), 256, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, c->d_os_ticket + 16,
                                                        c->d_vidx, c->d_ids, c->d_leaf, c->d_parent, c->d_bounded);
         c->leaves_filled = true;                // by the fix-up hop; enqueue_hierarchy runs k_fill_leaves otherwise
     }
-    c->stats.sort_passes = mode == 0 ? 2 : (mode == 1 ? 4 : 8);
+    c->stats.sort_passes = hybrid ? 2 : (mode == 2 ? 4 : 8);
     HIPCHK(evrec(c, EV_SORT1));
     HIPCHK(hipGetLastError());
     return 0;
@@ -604,7 +607,7 @@ constexpr int SORT_REDO = 77;                   // internal: a run was too long 
 static int judge_sort_flags(cd_ctx *c)
 {
     for (int i = 0; i < 8; ++i) if (c->sort_flags[i]) return CD_ERR_SORT;
-    if (c->sort_flags[8]) { if (c->sort_mode >= 2) return CD_ERR_SORT; ++c->sort_mode; return SORT_REDO; }
+    if (c->sort_flags[8]) { if (c->sort_mode >= 3) return CD_ERR_SORT; ++c->sort_mode; return SORT_REDO; }
     return CD_OK;
 }
 static int check_sort_flags(cd_ctx *c)
@@ -711,7 +714,7 @@ int cd_build_tree(cd_ctx *c)
     HIPCHK(hipMemcpyAsync(c->root_box_host, c->d_boxes, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     rc = judge_sort_flags(c);
-    if (rc == SORT_REDO) return cd_build_tree(c);                    // at most twice: sort_mode has been escalated
+    if (rc == SORT_REDO) return cd_build_tree(c);                    // at most three times: sort_mode has been escalated
     if (rc) return rc;
     if (c->stage_events) {
         c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
@@ -735,7 +738,7 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     fused.done();
     if (rc < 0) return rc;
     { const int rs = judge_sort_flags(c);                                   // flags came back with the traversal counters
-      if (rs == SORT_REDO) return cd_self_collide(c, pairs, cap_pairs, n_pairs);   // at most twice: sort_mode has been escalated
+      if (rs == SORT_REDO) return cd_self_collide(c, pairs, cap_pairs, n_pairs);   // at most three times: sort_mode has been escalated
       if (rs) return rs; }
     if (c->stage_events) {
         c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
@@ -900,7 +903,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (!c) return CD_ERR_ARG;
     if (key == CD_OPT_TRAVERSAL) { if (value < 0 || value > 3) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
     if (key == CD_OPT_QUERIES_PER_WAVE) { if (value < 64 || value > (1 << 20) || value % 64) return CD_ERR_ARG; c->queries_per_wave = (uint32_t)value; return CD_OK; }
-    if (key == CD_OPT_SORT_FULL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->sort_mode = value == 0 ? 0 : (value == 1 ? 2 : 1); return CD_OK; }
+    if (key == CD_OPT_SORT_FULL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->sort_mode = value == 0 ? 0 : (value == 1 ? 3 : 2); return CD_OK; }
     if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }
     if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
     if (key == 102) { c->dbg_no_shared_path = (uint32_t)value; return CD_OK; }

@@ -643,6 +643,16 @@ def test_half_key_sort_equals_full_sort_and_falls_back():
             keys, perm = cd.export_keys()
             assert cd.stats().sort_passes == passes
             assert np.array_equal(keys, r_keys) and np.array_equal(perm, r_perm)
+    # centroids OUTSIDE the reference's Morton frame set key bits 60..62 (morton.h:7 keeps 21 bits per axis), which the default
+    # hybrid form (global digits = key bits 44..59) does not sort by: it must notice and redo with the digits at bits 48..63
+    ov, ot = synth.soup(50_000, 0.02, 32)
+    ov = ov + np.array([2.5, 0.0, 0.0])                         # frame: x in [0.0045, 3.0845)
+    ok_, op_ = oracle.sort_by_key(oracle.centroid_morton(ov, ot))
+    assert (ok_ >> np.uint64(60)).max() > 0 and (ok_ >> np.uint64(60)).min() == 0
+    with mi355cd.CollisionDetector(ov, ot) as cd:
+        cd.morton_sort()
+        keys, perm = cd.export_keys()
+        assert cd.stats().sort_passes == 2 and np.array_equal(keys, ok_) and np.array_equal(perm, op_)
     # the cloth's keys form long runs of equal top-16 bits (hundreds of keys): the window logic of the hybrid form
     cv, ct = synth.cloth_pair(150)
     ck, cp = oracle.sort_by_key(oracle.centroid_morton(cv, ct))
@@ -650,16 +660,17 @@ def test_half_key_sort_equals_full_sort_and_falls_back():
         cd.morton_sort()
         keys, perm = cd.export_keys()
         assert cd.stats().sort_passes == 2 and np.array_equal(keys, ck) and np.array_equal(perm, cp)
-    # 60 000 triangles in a few cells of the top-16-bit grid (a run longer than any window) but spread over the high half:
-    # hybrid -> half-key
+    # 12 000 triangles inside ONE cell of the grid of key bits 44..59 (x: 6 bits, y and z: 5 bits of the frame) -- a run longer than
+    # any window for both hybrid forms -- but spread over the 4096 cells of the high key half inside it: hybrid -> hybrid -> half-key
     rng0 = np.random.default_rng(8)
-    c1 = np.array([1.0, 0.0, 0.5]) + (rng0.random((60000, 1, 3)) - 0.5) * 0.1
-    v1 = (c1 + (rng0.random((60000, 3, 3)) - 0.5) * 1e-4).reshape(-1, 3)
-    t1 = np.arange(180000, dtype=np.uint32).reshape(60000, 3)
+    f_off, f_span = np.array([0.004501, -0.476622, -0.381965]), np.array([3.08, 0.76, 2.36])       # morton.h:45,51,57
+    cell = f_span / np.array([64.0, 32.0, 32.0])
+    c1 = f_off + (np.array([20, 16, 10]) + 0.5) * cell + (rng0.random((12000, 1, 3)) - 0.5) * 0.9 * cell
+    v1 = (c1 + (rng0.random((12000, 3, 3)) - 0.5) * 1e-5).reshape(-1, 3)
+    t1 = np.arange(36000, dtype=np.uint32).reshape(12000, 3)
     k1 = oracle.centroid_morton(v1, t1)
-    top16, cnt16 = np.unique(k1 >> np.uint64(48), return_counts=True)
     _, cnt32 = np.unique(k1 >> np.uint64(32), return_counts=True)
-    assert cnt16.max() > 10240 and cnt32.max() <= 16                                  # a run too long to window, short equal-high-half runs
+    assert len(np.unique(k1 >> np.uint64(44))) == 1 and cnt32.max() <= 16              # one run too long to window, short equal-high-half runs
     with mi355cd.CollisionDetector(v1, t1) as cd:
         cd.morton_sort()
         keys, perm = cd.export_keys()
