@@ -215,9 +215,11 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
 
 // ====================================================================================================
 // Hybrid sort (default).  The onesweep passes cost ~20 us each at 1 M keys, nearly all of it the cross-XCD hand-off
-// between tiles; a pass that stays inside a workgroup has no hand-off.  So only the TOP 16 key bits are sorted
-// globally (2 onesweep passes); that leaves runs of equal top-16 bits (tens to thousands of keys: ~2^16 cells over
-// the Morton frame), contiguous and in input order, and k_local_sort finishes bits 32..63 inside LDS:
+// between tiles; a pass that stays inside a workgroup has no hand-off.  So only 16 key bits are sorted globally (2
+// onesweep passes) -- bits 44..59: a Morton key of a centroid inside the frame is below 2^60 (morton.h:70-89), so these
+// are its top 16 bits, 2^16 cells over the frame; k_morton notices a key at or above 2^60 and the sort is redone on bits
+// 48..63 -- which leaves runs of equal top bits (tens to hundreds of keys), contiguous and in input order, and
+// k_local_sort finishes bits 32..63 inside LDS:
 //   * workgroup b takes the window [s_b, s_{b+1}), where s_b is the run start nearest to b * LOCAL_W -- no run
 //     straddles two windows, so sorting the windows independently sorts the array;
 //   * inside the window: stable LSD passes over digits 4..7 with the same __ballot ranking as k_os_pass, {high key
@@ -231,8 +233,9 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
 constexpr int LOCAL_THREADS = 1024;
 constexpr int LOCAL_WAVES   = LOCAL_THREADS / 64;
 constexpr int LOCAL_W       = 4096;                     // nominal keys per workgroup
-constexpr int LOCAL_LIMIT   = 6144;                     // longest run of equal top-16 bits that can be windowed (a planar 1 M cloth in the
-                                                        // reference's frame: 441 runs, the longest 4590)
+constexpr int LOCAL_LIMIT   = 6144;                     // longest run that can be windowed (a planar 1 M cloth in the reference's frame: runs of
+                                                        // ~500 on key bits 44..59; 441 runs, the longest 4590, on bits 48..63).  Windows of
+                                                        // 2048 keys (two workgroups per CU) were slower: sort 85 -> 94 us
 constexpr int LOCAL_ITEMS   = (LOCAL_W + LOCAL_LIMIT) / LOCAL_THREADS;   // 10 keys per lane
 constexpr int LOCAL_CAP     = LOCAL_ITEMS * LOCAL_THREADS;               // 10240 keys: 80 KB of LDS + 16 KB of counters
 

@@ -155,7 +155,7 @@ enum {
     CD_OPT_TRAVERSAL        = 0,   /* 0: lane-private FP64 descent, exact test inline (the reference's shape,        */
                                    /*    collision.cuh:19-71); 1 (default): fp32 conservative descent with a          */
                                    /*    wavefront-shared LDS candidate queue + a second kernel for the exact tests   */
-    CD_OPT_SORT_FULL        = 2,   /* 0 (default): hybrid -- 2 global passes on the top 16 key bits, the rest of the high half     */
+    CD_OPT_SORT_FULL        = 2,   /* 0 (default): hybrid -- 2 global passes on 16 key bits (44..59, or 48..63 when a key reaches 2^60), the rest of the high half */
                                    /*    sorted inside LDS windows, stable fix-up of equal-high-half runs; falls back to 2, then  */
                                    /*    to 1, by itself when a run is too long.  2: half-key -- 4 global passes + the fix-up.   */
                                    /*    1: all 8 digit passes.  All give the identical stable order by the full 64-bit key.     */
