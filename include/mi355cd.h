@@ -153,8 +153,11 @@ int cd_export_tree(cd_ctx *ctx, int32_t *parent, int32_t *left, int32_t *right, 
 /* Tuning knobs; none of them changes results (pair sets, pairs_tested are identical for every setting). */
 enum {
     CD_OPT_TRAVERSAL        = 0,   /* 0: lane-private FP64 descent, exact test inline (the reference's shape,        */
-                                   /*    collision.cuh:19-71); 1 (default): fp32 conservative descent with a          */
-                                   /*    wavefront-shared LDS candidate queue + a second kernel for the exact tests   */
+                                   /*    collision.cuh:19-71); 1: fp32 conservative descent of every query from the   */
+                                   /*    root with a wavefront-shared LDS candidate queue + a second kernel for the   */
+                                   /*    exact tests; 2: one wave walks the tree for its 64 queries; 3 (default): half */
+                                   /*    traversal -- a query meets only the leaves to its right in Morton order and   */
+                                   /*    every hit counts as the two ordered pairs the reference tests   */
     CD_OPT_SORT_FULL        = 2,   /* 0 (default): hybrid -- 2 global passes on 16 key bits (44..59, or 48..63 when a key reaches 2^60), the rest of the high half */
                                    /*    sorted inside LDS windows, stable fix-up of equal-high-half runs; falls back to 2, then  */
                                    /*    to 1, by itself when a run is too long.  2: half-key -- 4 global passes + the fix-up.   */
