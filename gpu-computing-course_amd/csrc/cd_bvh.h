@@ -162,6 +162,7 @@ __device__ __forceinline__ void fill_leaf(uint32_t j, uint32_t t, const uint32_t
     lt.id = ids ? ids[t] : t;
     lt.v0 = vidx[3 * (size_t)t]; lt.v1 = vidx[3 * (size_t)t + 1]; lt.v2 = vidx[3 * (size_t)t + 2];
     leaf[j] = lt;
+    if (!parent) return;                                   // the fused build follows: it reads leaf[] only (12 bytes per leaf less to write)
     parent[(n - 1) + j] = -1;
     // boxes are "uninitialised" until the refit writes them (Box::init, box.cuh:10,21,31): poison x1
     if (boxes) reinterpret_cast<uint64_t *>(boxes)[6 * (size_t)((n - 1) + j)] = 0xFFFFFFFFFFFFFFFFull;
@@ -597,24 +598,34 @@ __device__ __forceinline__ Box seg_query_halves(const double *__restrict__ seg, 
 
 // Fused build: range and split of the cross nodes (the ~2 % whose range leaves their 512-leaf block), by the searches of
 // generateHierarchyParallel (bvh.cuh:146-199) -- each of which looks for the last position at which a monotone predicate
-// on delta still holds.  A few thousand nodes on a whole chip is pure latency, so ONE WAVE takes a node and every round
-// probes 64 positions at once (all doublings of the galloping phase in one round, then 64 cut points per round): the
-// same answers in 4-6 dependent round trips instead of 40-60.  Writes meta[i] (what k_refit_seg_cross reads) and
-// split_of[i] (child links).
-// largest x in [lo, hi) with pred(x), given pred(lo) and !pred(hi) (pred is wave-uniformly monotone: true ... true false ... false)
+// on delta still holds.  A few ten thousand nodes on a whole chip is pure latency: what counts is how many of these
+// dependent chains are in flight and how many round trips each takes.  So a GROUP of 16 lanes takes a node -- four nodes
+// per wave, every node of a 1 M-triangle tree in flight at once -- and every round probes 16 positions (all doublings of
+// the galloping phase in one round, then 16 cut points per round): the same answers in 5-7 dependent round trips
+// instead of 40-60.  (One wave per node, 64 probes per round: 13.3 us; one thread per node: 23 us.)
+// Writes meta[i] (what the cross-record kernels read) and split_of[i] (child links).
+constexpr int XG = 16;                                                      // lanes per cross node
+// this lane's group's 16 bits of a wave-wide ballot
+__device__ __forceinline__ uint32_t group_ballot(bool c, int g) { return (uint32_t)(__builtin_amdgcn_ballot_w64(c) >> (g * XG)) & ((1u << XG) - 1u); }
+// largest x in [lo, hi) with pred(x), given pred(lo) and !pred(hi); lo, hi are uniform inside a group (pred is monotone:
+// true ... true false ... false); groups of a wave run their rounds together until the last one is done
 template <class Pred>
-__device__ __forceinline__ int wave_last_true(int lo, int hi, int lane, Pred pred)
+__device__ __forceinline__ int group_last_true(bool live, int lo, int hi, int g, int gl, Pred pred)
 {
-    while (hi - lo > 1) {                                                   // (wave-uniform)
+    for (;;) {
+        const bool more = live && hi - lo > 1;
+        if (!__builtin_amdgcn_ballot_w64(more)) break;                      // (wave-uniform)
         const int w = hi - lo;
-        const int step = (w + 63) >> 6;
-        const long long x = (long long)lo + (long long)lane * step;
-        const bool ok = x < hi && (lane == 0 || pred((int)x));
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);       // a prefix of the lanes
-        const int top = 63 - __clzll((long long)m);                         // bit 0 is always set
-        const int nlo = lo + top * step;
-        hi = (nlo + step < hi) ? nlo + step : hi;
-        lo = nlo;
+        const int step = (w + XG - 1) / XG;
+        const long long x = (long long)lo + (long long)gl * step;
+        const bool ok = more && x < hi && (gl == 0 || pred((int)x));
+        const uint32_t m = group_ballot(ok, g);                             // a prefix of the group's lanes (bit 0 set while `more`)
+        if (more) {
+            const int top = 31 - __clz((int)m);
+            const int nlo = lo + top * step;
+            hi = (nlo + step < hi) ? nlo + step : hi;
+            lo = nlo;
+        }
     }
     return lo;
 }
@@ -622,29 +633,36 @@ __device__ __forceinline__ int wave_last_true(int lo, int hi, int lane, Pred pre
 __global__ __launch_bounds__(256) void k_cross_meta(const uint64_t *__restrict__ keys, int n, NodeMeta *__restrict__ meta, int32_t *__restrict__ split_of,
                                                     const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap)
 {
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane / XG, gl = lane % XG;
+    constexpr int PER_WAVE = 64 / XG, PER_BLOCK = 256 / XG;
     const uint32_t total = min(*dense_total, dense_cap);
-    for (uint32_t k = blockIdx.x * 4 + (tid >> 6); k < total; k += gridDim.x * 4) {   // one wave per node (k is wave-uniform)
-        const int i = __builtin_amdgcn_readfirstlane(dense[k]);
+    for (uint32_t wbase = blockIdx.x * PER_BLOCK + (tid >> 6) * PER_WAVE; wbase < total; wbase += gridDim.x * PER_BLOCK) {   // (wbase is wave-uniform)
+        const uint32_t k = wbase + g;
+        const bool live = k < total;
+        const int i = live ? dense[k] : 0;
         const uint64_t ki = keys[i];
         const int d = (delta_k(keys, n, i, ki, i + 1) - delta_k(keys, n, i, ki, i - 1)) >= 0 ? 1 : -1;
         const int delta_min = delta_k(keys, n, i, ki, i - d);
-        // galloping phase: lane L asks about 2^(L+1); the first "no" is mlen (a position outside the keys says no)
-        int mlen;
-        {
-            const long long o = (long long)i + (long long)d * (2ll << (lane < 31 ? lane : 31));
-            const bool yes = lane < 31 && o >= 0 && o < n && delta_k(keys, n, i, ki, (int)o) > delta_min;
-            const unsigned long long m = ~__builtin_amdgcn_ballot_w64(yes);   // lanes >= 31 always say no
-            mlen = 2 << (__ffsll((long long)m) - 1);
+        // galloping phase: lane L of the group asks about 2^(L+1), in a second round about 2^(L+17); the first "no" is mlen
+        // (a position outside the keys says no)
+        int mlen = 0;
+        for (int r = 0; r < 2; ++r) {
+            const bool todo = live && mlen == 0;
+            if (!__builtin_amdgcn_ballot_w64(todo)) break;                  // (wave-uniform)
+            const int e = r * XG + gl;                                      // exponent - 1
+            const long long o = (long long)i + (long long)d * (2ll << (e < 31 ? e : 31));
+            const bool yes = todo && e < 31 && o >= 0 && o < n && delta_k(keys, n, i, ki, (int)o) > delta_min;
+            const uint32_t no = ~group_ballot(yes, g) & ((1u << XG) - 1u);
+            if (todo && no) mlen = 2 << (r * XG + __ffs((int)no) - 1);
         }
-        const int l = wave_last_true(mlen >> 1, mlen, lane, [&](int x) { return delta_k(keys, n, i, ki, i + x * d) > delta_min; });
+        const int l = group_last_true(live, mlen >> 1, mlen, g, gl, [&](int x) { return delta_k(keys, n, i, ki, i + x * d) > delta_min; });
         const int j = i + l * d;
         const int first = min(i, j), last = max(i, j);
         const uint64_t kf = keys[first];
         const int common = delta_k(keys, n, first, kf, last);
         // findSplit: the last s in [first, last) with delta(first, s) > common (s == first counts as yes)
-        const int split = wave_last_true(first, last, lane, [&](int x) { return delta_k(keys, n, first, kf, x) > common; });
-        if (lane == 0) {
+        const int split = group_last_true(live, first, last, g, gl, [&](int x) { return delta_k(keys, n, first, kf, x) > common; });
+        if (live && gl == 0) {
             const int a = (split == first) ? (n - 1) + split : split;
             const int b = (split + 1 == last) ? (n - 1) + split + 1 : split + 1;
             meta[i] = make_int4(a, b, j, 0);

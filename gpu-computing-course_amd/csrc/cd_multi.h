@@ -233,7 +233,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         int rc;
         {
             Prezeroed fused(c);
-            rc = enqueue_morton_sort(c);
+            rc = enqueue_morton_sort(c, !fused_build_next(c));
             if (!rc) rc = enqueue_tree(c);
         }
         if (rc) return rc;                        // (an enqueue failure is a HIP error on this rank: nothing collective has started in this attempt)

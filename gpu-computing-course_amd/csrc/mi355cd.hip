@@ -69,6 +69,7 @@ struct cd_ctx {
     LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; double *d_seg = nullptr; float *d_seg32 = nullptr; uint32_t nbp2 = 1; int32_t *d_cross = nullptr; uint32_t cross_cap = 0;   // segment tree over leaf boxes: nbp2*512 heap nodes
     double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec32 *d_recs32 = nullptr; LeafBox32 *d_qbox = nullptr;
     int32_t *d_root = nullptr;              // name (split) of the root record, one word inside d_small
+    bool leaf_records_filled = false;       // leaf[] holds the sorted triangles (leaves_filled: and parent[] / bounded[] are reset)
     bool internal_boxes_valid = false;      // the FP64 boxes of the internal nodes were written by the last refit (fused calls skip them)
     int32_t *d_split_of = nullptr;          // fused build: split of every internal node (child links of the records)
     bool hierarchy_valid = false;           // meta[] / parent[] hold the tree of the current keys (fused calls build the records without them)
@@ -158,7 +159,10 @@ struct Prezeroed {                          // scope of a fused call: stage mems
 };
 
 // ---- stage enqueuers (no host synchronisation inside) -------------------------------------------
-int enqueue_morton_sort(cd_ctx *c)
+static bool fused_build_next(const cd_ctx *c);
+// links_too: the fix-up hop also resets the parent links / arrival counters (k_hierarchy and the stage-wise refit need them;
+// the fused build does not)
+int enqueue_morton_sort(cd_ctx *c, bool links_too = true)
 {
     const uint32_t n = c->nt;
     hipStream_t s = c->stream;
@@ -191,11 +195,12 @@ int enqueue_morton_sort(cd_ctx *c)
     if (hybrid) {                               // data is in buffer 0 again; windows go 0 -> 1, the fix-up hop 1 -> 0
         k_local_sort<<<cdiv(n, LOCAL_W), LOCAL_THREADS, 0, s>>>(c->d_keys[0], c->d_perm[0], c->d_keys[1], c->d_perm[1], n, 48 - down, c->d_os_ticket + 16);
     }
-    c->leaves_filled = false;
+    c->leaves_filled = false; c->leaf_records_filled = false;
     if (mode != 3) {
         k_sort_fixup_fill<<<cdiv(n, 256), 256, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, c->d_os_ticket + 16,
-                                                       c->d_vidx, c->d_ids, c->d_leaf, c->d_parent, c->d_bounded);
-        c->leaves_filled = true;                // by the fix-up hop; enqueue_hierarchy runs k_fill_leaves otherwise
+                                                       c->d_vidx, c->d_ids, c->d_leaf, links_too ? c->d_parent : nullptr, links_too ? c->d_bounded : nullptr);
+        c->leaves_filled = links_too;           // by the fix-up hop; enqueue_hierarchy runs k_fill_leaves otherwise
+        c->leaf_records_filled = true;
     }
     c->stats.sort_passes = hybrid ? 2 : (mode == 2 ? 4 : 8);
     HIPCHK(evrec(c, EV_SORT1));
@@ -234,9 +239,9 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
     uint32_t *cross_count = c->d_small + 16;
     if (!c->prezeroed) HIPCHK(hipMemsetAsync(cross_count, 0, 64 * sizeof(uint32_t), s));
     if (fused) {
-        if (!c->leaves_filled)                       // (the 8-pass sort does not fill the leaves; enqueue_hierarchy would have)
+        if (!c->leaf_records_filled)                 // (the 8-pass sort does not fill the leaves; enqueue_hierarchy would have)
             k_fill_leaves<<<cdiv(n, 256), 256, 0, s>>>(c->d_perm[0], c->d_vidx, c->d_ids, n, c->d_leaf, c->d_parent, c->d_bounded, nullptr);
-        c->leaves_filled = false;
+        c->leaves_filled = false; c->leaf_records_filled = true;
         c->hierarchy_valid = false;
         // (its time stamps ride on its own dispatch packet: this is the largest kernel of the step, bench.py prices it)
         hipExtLaunchKernelGGL(k_build_block, dim3(nblocks), dim3(REFIT_BLK), 0u, s, c->ev[EV_BLK0], c->ev[EV_BLK1], 0u,
@@ -267,10 +272,11 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
 
 // Hierarchy + refit of a fused call: one pass that builds the records straight from the sorted keys (no k_hierarchy, no
 // meta[] / parent[]), unless the traversal in use walks the reference-shaped tree (variant 0) or the A/B switch says so.
+static bool fused_build_next(const cd_ctx *c) { return !(c->trav_variant == 0 || c->dbg_no_fused_build); }
 int enqueue_tree(cd_ctx *c)
 {
     c->last_tree_fused = false;
-    if (c->trav_variant == 0 || c->dbg_no_fused_build) {
+    if (!fused_build_next(c)) {
         int rc = enqueue_hierarchy(c, false);
         if (!rc) rc = enqueue_refit(c, c->trav_variant == 0, false);
         return rc;
@@ -623,7 +629,7 @@ int cd_morton_sort(cd_ctx *c)
     int rc = enqueue_morton_sort(c);
     if (rc) return rc;
     rc = check_sort_flags(c);
-    for (int redo = 0; rc == SORT_REDO && redo < 2; ++redo) { if ((rc = enqueue_morton_sort(c))) return rc; rc = check_sort_flags(c); }
+    for (int redo = 0; rc == SORT_REDO && redo < 3; ++redo) { if ((rc = enqueue_morton_sort(c))) return rc; rc = check_sort_flags(c); }
     if (rc) return rc;
     c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
     c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
@@ -707,7 +713,7 @@ int cd_build_tree(cd_ctx *c)
     if (!c) return CD_ERR_ARG;
     int rc;
     Prezeroed fused(c);                                                    // one memset for every counter of the pipeline
-    rc = enqueue_morton_sort(c);
+    rc = enqueue_morton_sort(c, !fused_build_next(c));
     if (!rc) rc = enqueue_tree(c);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));   // words 8..16
@@ -732,7 +738,7 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     if (!c || (cap_pairs && !pairs)) return CD_ERR_ARG;
     int rc;
     Prezeroed fused(c);                                                    // one memset for every counter of the pipeline
-    rc = enqueue_morton_sort(c);
+    rc = enqueue_morton_sort(c, !fused_build_next(c));
     if (!rc) rc = enqueue_tree(c);
     if (!rc) rc = run_traversal(c, c->tb[0], nullptr, 0, pairs, cap_pairs, n_pairs);     // synchronises
     fused.done();
