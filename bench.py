@@ -210,6 +210,12 @@ def main():
             return pairs, int(mi.pairs_tested), {"local_pairs": int(mi.local_pairs), "cross_pairs": int(mi.cross_pairs), "sent_queries": int(mi.sent_queries),
                                                  "recv_queries": int(mi.recv_queries), "n_peers": int(mi.n_peers), "host_syncs": int(mi.host_syncs),
                                                  "attempts": int(mi.attempts)}
+        if world == 1 and not multi_path:
+            # one GPU: the C ABI's call and nothing else -- pairs stay in the buffer the library wrote them into
+            pairs, n, rc = engine.cd.self_collide(cap, copy=False)
+            if rc != 0:
+                raise RuntimeError(f"pair capacity {cap} too small for {n} pairs")
+            return pairs, None, {}
         return multi.collide_step(engine, dist, rank, world, cap, comm_device)
 
     for _ in range(args.warmup):
@@ -231,6 +237,8 @@ def main():
     for _ in range(args.steps):
         pairs, tested, info = step()
         st = engine.cd.stats()                                        # HIP-event stage times on the library's stream
+        if tested is None:
+            tested = st.pairs_tested
         if not multi_path:
             kern["descend"] += st.ms_descend; kern["exact"] += st.ms_exact; kern["build_block"] += st.ms_build_block; pipeline_ms += st.ms_pipeline
         tested_total += tested

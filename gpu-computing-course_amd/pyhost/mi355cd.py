@@ -213,25 +213,29 @@ class CollisionDetector:
         self._chk("cd_check_triangle_idx", self.lib.cd_check_triangle_idx(self._ctx, maxv, C.byref(out)))
         return out.value
 
-    def _pairs_call(self, fn, name, cap, *pre):
+    def _pairs_call(self, fn, name, cap, *pre, copy=True):
         n = C.c_uint64(0)
         # the output buffer is kept between calls (a 4 M-pair buffer is 32 MB; allocating it per step costs more
-        # than the step); callers get a copy of the filled prefix
+        # than the step); callers get a copy of the filled prefix -- or, with copy=False, a VIEW of the buffer the C
+        # call wrote into, valid until the next call on this object (what a C caller has; a per-frame loop needs no more)
         buf = None
         if cap:
             if getattr(self, "_pairbuf", None) is None or self._pairbuf.shape[0] != cap:
                 self._pairbuf = np.empty((cap, 2), dtype=np.uint32)
+                self._pairptr = _ptr(self._pairbuf)
             buf = self._pairbuf
-        rc = fn(self._ctx, *pre, _ptr(buf), cap, C.byref(n))
+        rc = fn(self._ctx, *pre, self._pairptr if cap else None, cap, C.byref(n))
         self._chk(name, rc, allow=(CD_OK, CD_OVERFLOW))
         got = min(n.value, cap)
-        return (buf[:got].copy() if buf is not None else np.zeros((0, 2), dtype=np.uint32)), n.value, rc
+        if buf is None:
+            return np.zeros((0, 2), dtype=np.uint32), n.value, rc
+        return (buf[:got].copy() if copy else buf[:got]), n.value, rc
 
     def find_collisions(self, cap: int = 1 << 20):
         return self._pairs_call(self.lib.cd_find_collisions, "cd_find_collisions", cap)
 
-    def self_collide(self, cap: int = 1 << 20):
-        return self._pairs_call(self.lib.cd_self_collide, "cd_self_collide", cap)
+    def self_collide(self, cap: int = 1 << 20, copy: bool = True):
+        return self._pairs_call(self.lib.cd_self_collide, "cd_self_collide", cap, copy=copy)
 
     def sorted_pairs(self, cap: int = 1 << 20):
         """Pair list of the last traversal, sorted by (a, b) on the device."""
