@@ -39,38 +39,40 @@ struct RcclApi {
     ncclResult_t (*GroupEnd)() = nullptr;
 };
 
+RcclApi load_rccl()
+{
+    RcclApi api;
+    // MI355CD_RCCL_LIBRARY: load THAT library and nothing else (a site's own RCCL build; the tests' in-process
+    // loopback, tests/loopback_rccl).  Otherwise the process' RCCL: the copy already loaded (PyTorch's) wins by soname.
+    const char *over = std::getenv("MI355CD_RCCL_LIBRARY");
+    void *h = nullptr;
+    if (over && *over) h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+    else {
+        h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (h) {
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+        api.CommCount = (decltype(api.CommCount))dlsym(h, "ncclCommCount");
+        api.CommUserRank = (decltype(api.CommUserRank))dlsym(h, "ncclCommUserRank");
+        api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+        api.Send = (decltype(api.Send))dlsym(h, "ncclSend");
+        api.Recv = (decltype(api.Recv))dlsym(h, "ncclRecv");
+        api.GroupStart = (decltype(api.GroupStart))dlsym(h, "ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))dlsym(h, "ncclGroupEnd");
+        if (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.CommCount && api.CommUserRank && api.AllGather && api.Send && api.Recv &&
+            api.GroupStart && api.GroupEnd)
+            api.handle = h;
+    }
+    return api;
+}
+
 RcclApi *rccl()
 {
-    static RcclApi api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
-        // MI355CD_RCCL_LIBRARY: load THAT library and nothing else (a site's own RCCL build; the tests' in-process
-        // loopback, tests/loopback_rccl).  Otherwise the process' RCCL: the copy already loaded (PyTorch's) wins by soname.
-        const char *over = std::getenv("MI355CD_RCCL_LIBRARY");
-        void *h = nullptr;
-        if (over && *over) h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
-        else {
-            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-            if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        }
-        if (h) {
-            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
-            api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
-            api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
-            api.CommCount = (decltype(api.CommCount))dlsym(h, "ncclCommCount");
-            api.CommUserRank = (decltype(api.CommUserRank))dlsym(h, "ncclCommUserRank");
-            api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
-            api.Send = (decltype(api.Send))dlsym(h, "ncclSend");
-            api.Recv = (decltype(api.Recv))dlsym(h, "ncclRecv");
-            api.GroupStart = (decltype(api.GroupStart))dlsym(h, "ncclGroupStart");
-            api.GroupEnd = (decltype(api.GroupEnd))dlsym(h, "ncclGroupEnd");
-            if (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.CommCount && api.CommUserRank && api.AllGather && api.Send && api.Recv &&
-                api.GroupStart && api.GroupEnd)
-                api.handle = h;
-        }
-    }
+    static RcclApi api = load_rccl();                   // (initialised once, thread-safe: ranks may be threads of one process)
     return api.handle ? &api : nullptr;
 }
 

@@ -517,7 +517,7 @@ def test_multi_step_world_gt_1_over_the_loopback_transport(quads, qcap, xs):
         assert sum(st["cross"]) > 0
 
 
-@pytest.mark.parametrize("kind", ["cloth-float", "soup-double", "mixed", "tiny", "one-block", "ragged"])
+@pytest.mark.parametrize("kind", ["cloth-float", "soup-double", "mixed", "tiny", "one-block", "ragged", "duplicates", "long-ranges"])
 def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
     """The fused build (cd_build.h: hierarchy from adjacent deltas, fp32 segment trees, cross nodes by wave) against the
     stage-wise one (k_hierarchy + the FP64 refit, key 104): the traversal records must be the same bytes -- child boxes
@@ -535,6 +535,11 @@ def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
         verts, vidx = synth.soup(3, 0.5, 5)
     elif kind == "one-block":
         verts, vidx = synth.soup(512, 0.2, 6)
+    elif kind == "duplicates":                      # equal keys: delta falls through to the index tie-break (64 + clz), runs of equal deltas
+        v0, t0 = synth.soup(3000, 0.05, 10)
+        verts, vidx = v0, np.concatenate([t0, t0, t0[:1500]], axis=0)
+    elif kind == "long-ranges":                     # > 65535 leaves under the top nodes: the whole-wave form of the cross queries
+        verts, vidx = synth.soup(200_000, 0.01, 11)
     else:
         verts, vidx = synth.soup(512 * 7 + 1, 0.05, 9)
     got = {}
