@@ -74,52 +74,78 @@ __device__ __forceinline__ d3 centroid_of(const double *__restrict__ verts, cons
 __device__ __forceinline__ double wave_min(double v) { for (int o = 32; o; o >>= 1) { double t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
 __device__ __forceinline__ double wave_max(double v) { for (int o = 32; o; o >>= 1) { double t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
 
+// BOX: also the min / max over the triangles' VERTICES -- the box of all leaves (what node 0 of the tree will hold),
+// known before there is a tree: the multi-GPU step exchanges it first (cd_multi.h).  partial: gridDim.x x 12.
+constexpr int BOUNDS_STRIDE = 12;
+template <bool BOX>
 __global__ __launch_bounds__(256) void k_centroid_bounds(const double *__restrict__ verts, const uint32_t *__restrict__ vidx, uint32_t n,
-                                                         double *__restrict__ partial /* gridDim.x x 6 */)
+                                                         double *__restrict__ partial /* gridDim.x x BOUNDS_STRIDE: centroid lo[3] hi[3], vertex lo[3] hi[3] */)
 {
-    __shared__ double sm[4][6];
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    __shared__ double sm[4][BOUNDS_STRIDE];
+    constexpr int SETS = BOX ? 2 : 1;
+    double lo[SETS][3], hi[SETS][3];
+    for (int q = 0; q < SETS; ++q) for (int a = 0; a < 3; ++a) { lo[q][a] = 1e300; hi[q][a] = -1e300; }
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-        const d3 c = centroid_of(verts, vidx, t);
-        lo[0] = c.x < lo[0] ? c.x : lo[0]; hi[0] = c.x > hi[0] ? c.x : hi[0];
-        lo[1] = c.y < lo[1] ? c.y : lo[1]; hi[1] = c.y > hi[1] ? c.y : hi[1];
-        lo[2] = c.z < lo[2] ? c.z : lo[2]; hi[2] = c.z > hi[2] ? c.z : hi[2];
+        const uint32_t ia = vidx[3 * (size_t)t], ib = vidx[3 * (size_t)t + 1], ic = vidx[3 * (size_t)t + 2];
+        const d3 p1 = load_vertex(verts, ia), p2 = load_vertex(verts, ib), p3 = load_vertex(verts, ic);
+        const double c[3] = {(p1.x + p2.x + p3.x) / 3, (p1.y + p2.y + p3.y) / 3, (p1.z + p2.z + p3.z) / 3};      // load_obj.h:90
+        for (int a = 0; a < 3; ++a) { lo[0][a] = c[a] < lo[0][a] ? c[a] : lo[0][a]; hi[0][a] = c[a] > hi[0][a] ? c[a] : hi[0][a]; }
+        if (BOX) {
+            const Box b = box_set(p1, p2, p3);
+            const double bl[3] = {b.x1, b.y1, b.z1}, bh[3] = {b.x2, b.y2, b.z2};
+            for (int a = 0; a < 3; ++a) { lo[SETS - 1][a] = bl[a] < lo[SETS - 1][a] ? bl[a] : lo[SETS - 1][a]; hi[SETS - 1][a] = bh[a] > hi[SETS - 1][a] ? bh[a] : hi[SETS - 1][a]; }
+        }
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int a = 0; a < 3; ++a) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); }
-    if (lane == 0) for (int a = 0; a < 3; ++a) { sm[w][a] = lo[a]; sm[w][3 + a] = hi[a]; }
+    for (int q = 0; q < SETS; ++q)
+        for (int a = 0; a < 3; ++a) {
+            const double l = wave_min(lo[q][a]), h = wave_max(hi[q][a]);
+            if (lane == 0) { sm[w][6 * q + a] = l; sm[w][6 * q + 3 + a] = h; }
+        }
     __syncthreads();
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < 6 * SETS) {
+        const bool is_lo = (threadIdx.x % 6) < 3;
         double v = sm[0][threadIdx.x];
-        for (int ww = 1; ww < 4; ++ww) { const double t = sm[ww][threadIdx.x]; v = (threadIdx.x < 3) ? (t < v ? t : v) : (t > v ? t : v); }
-        partial[blockIdx.x * 6 + threadIdx.x] = v;
+        for (int ww = 1; ww < 4; ++ww) { const double t = sm[ww][threadIdx.x]; v = is_lo ? (t < v ? t : v) : (t > v ? t : v); }
+        partial[blockIdx.x * BOUNDS_STRIDE + threadIdx.x] = v;
     }
 }
 // One workgroup of 256 folds the per-block partials (it used to be three threads walking all of them one dependent
 // load after the other: 180 us for 1024 blocks).  min / max are exact and order-independent, so any order gives the
 // same frame.
-__global__ __launch_bounds__(256) void k_frame_from_bounds(const double *__restrict__ partial, uint32_t nblocks, double *__restrict__ frame)
+// frame (may be NULL): off[3], span[3] from the centroid bounds.  box (may be NULL): {x1,x2,y1,y2,z1,z2} from the vertex bounds
+// (partials written by k_centroid_bounds<true>).
+__global__ __launch_bounds__(256) void k_frame_from_bounds(const double *__restrict__ partial, uint32_t nblocks, double *__restrict__ frame,
+                                                           double *__restrict__ box)
 {
-    __shared__ double sm[4][6];
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (uint32_t b = threadIdx.x; b < nblocks; b += 256) {
+    __shared__ double sm[4][BOUNDS_STRIDE];
+    const int sets = box ? 2 : 1;
+    for (int q = 0; q < sets; ++q) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (uint32_t b = threadIdx.x; b < nblocks; b += 256) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double l = partial[b * 6 + a], h = partial[b * 6 + 3 + a];
-            lo[a] = l < lo[a] ? l : lo[a]; hi[a] = h > hi[a] ? h : hi[a];
+            for (int a = 0; a < 3; ++a) {
+                const double l = partial[b * BOUNDS_STRIDE + 6 * q + a], h = partial[b * BOUNDS_STRIDE + 6 * q + 3 + a];
+                lo[a] = l < lo[a] ? l : lo[a]; hi[a] = h > hi[a] ? h : hi[a];
+            }
         }
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (int a = 0; a < 3; ++a) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); }
+        if (lane == 0) for (int a = 0; a < 3; ++a) { sm[w][6 * q + a] = lo[a]; sm[w][6 * q + 3 + a] = hi[a]; }
     }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int a = 0; a < 3; ++a) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); }
-    if (lane == 0) for (int a = 0; a < 3; ++a) { sm[w][a] = lo[a]; sm[w][3 + a] = hi[a]; }
     __syncthreads();
-    if (threadIdx.x < 3) {
-        double l = sm[0][threadIdx.x], h = sm[0][3 + threadIdx.x];
-        for (int ww = 1; ww < 4; ++ww) { const double l2 = sm[ww][threadIdx.x], h2 = sm[ww][3 + threadIdx.x]; l = l2 < l ? l2 : l; h = h2 > h ? h2 : h; }
-        double span = (h - l) * (1.0 + 1.0 / 1048576.0);
-        if (!(span > 0.0)) span = 1.0;
-        frame[threadIdx.x] = l;
-        frame[3 + threadIdx.x] = span;
+    if (threadIdx.x < 3 * sets) {
+        const int q = threadIdx.x / 3, a = threadIdx.x % 3;
+        double l = sm[0][6 * q + a], h = sm[0][6 * q + 3 + a];
+        for (int ww = 1; ww < 4; ++ww) { const double l2 = sm[ww][6 * q + a], h2 = sm[ww][6 * q + 3 + a]; l = l2 < l ? l2 : l; h = h2 > h ? h2 : h; }
+        if (q == 0) {
+            if (frame) {
+                double span = (h - l) * (1.0 + 1.0 / 1048576.0);
+                if (!(span > 0.0)) span = 1.0;
+                frame[a] = l;
+                frame[3 + a] = span;
+            }
+        } else { box[2 * a] = l; box[2 * a + 1] = h; }
     }
 }
 

@@ -2,19 +2,23 @@
 // sharded by object, RCCL over xGMI for the one exchange the path has.  Included at the end of mi355cd.hip (it uses
 // the stage enqueuers and the traversal passes of that file).
 //
-// The reference is single-GPU (main.cu:47-174 is the harness this slots into); SURVEY.md 8(e) defines the step:
-//   1. local LBVH (Morton keys, sort, hierarchy, refit)                       -- no communication
-//   2. all-gather of the per-rank root AABB (6 doubles)                       -- ncclAllGather, 48 B per rank
-//   3. ONE launch compacts, for every peer whose root strictly overlaps this rank's (box.cuh:40-43), the local leaves
-//      that overlap that root into cd_query records; the per-peer counts are all-gathered as a world x world matrix,
-//      so every rank knows what it sends, what it receives and whether ANY rank ran out of room -- decisions taken
-//      from that matrix (grow the slabs, redo a failed sort) are the same on every rank: no rank leaves a collective
-//      the others are still in
-//   4. grouped ncclSend / ncclRecv of the records, each peer's slice on its own xGMI link (no ring), on a second
-//      stream so that the local traversal runs while the records travel
-//   5. local traversal, then the received queries against the local tree; a cross pair {a, b}, a.ID < b.ID, is
-//      reported exactly once, by the owner of b (tri_contact.cuh:81 applied to external queries too)
-// Host synchronisations per step: two (after the count matrix; after both traversal passes).
+// The reference is single-GPU (main.cu:47-174 is the harness this slots into); SURVEY.md 8(e) defines what a step has to
+// deliver (local pairs + each cross pair {a, b}, a.ID < b.ID, exactly once, from the owner of b: tri_contact.cuh:81
+// applied to external queries too).  The order of work is chosen so that everything the ranks exchange is on its way
+// before a rank starts on its own tree:
+//   1. the box of all the rank's triangles, a reduction over their vertices (= the value node 0 of its tree will hold),
+//      and its all-gather (ncclAllGather, 48 B per rank)
+//   2. ONE launch compacts, for every peer whose box strictly overlaps this rank's (box.cuh:40-43), the triangles that
+//      overlap that peer's box into cd_query records -- straight from the triangles in their original order: a query
+//      is a triangle, whatever tree it will sit in; the per-peer counts are all-gathered as a world x world matrix, so
+//      every rank knows what it sends, what it receives and whether ANY rank ran out of room -- the one decision taken
+//      from that matrix (grow the slabs) is the same on every rank: no rank leaves a collective the others are still in
+//   3. queued right behind, without waiting for the host: the rank's OWN pipeline (Morton keys, sort, fused build, half
+//      traversal of its own tree, report) -- it runs while the host reads the matrix and while
+//   4. the records travel: grouped ncclSend / ncclRecv, each peer's slice on its own xGMI link (no ring), second stream
+//   5. the received queries against the local tree, behind the local pass; both reports are read with one wait.
+// Host synchronisations per step: two (the count matrix -- with the GPU busy on 3; both traversal passes).  A sort that
+// must be redone in another form is local: the rank repeats 3 and 5 alone, after the step's collectives.
 //
 // RCCL is loaded at run time (dlopen) by the first cd_multi_* call, so single-GPU users of the library do not pay for
 // it; there is no fallback transport: without librccl the calls return CD_ERR_RCCL.
@@ -82,7 +86,7 @@ RcclApi *rccl()
         if (r_ != ncclSuccess) return CD_ERR_RCCL;                     \
     } while (0)
 
-enum MEv { ME_START, ME_TREE, ME_GATHER, ME_PACK, ME_COUNTS, ME_XCH0, ME_XCH1, ME_LOCAL, ME_CROSS, ME_COUNT };
+enum MEv { ME_START, ME_LOC0, ME_TREE, ME_GATHER, ME_PACK, ME_COUNTS, ME_XCH0, ME_XCH1, ME_LOCAL, ME_CROSS, ME_COUNT };
 
 }  // namespace
 
@@ -93,9 +97,10 @@ struct cd_multi {
     uint64_t qcap = 0;                           // records per peer slab -- the SAME on every rank (grown from the shared count matrix)
     hipStream_t xstream = nullptr;               // payload exchange, beside the context's stream
     hipEvent_t ev_payload = nullptr, ev_counts = nullptr, ev[ME_COUNT] = {};
+    double *d_myroot = nullptr;                  // 6: the box of all this rank's triangles, from their vertices
     double *d_roots = nullptr;                   // world x 6
-    unsigned long long *d_row = nullptr;         // world + 1: records packed for each peer, then this rank's "redo" word
-    unsigned long long *d_matrix = nullptr;      // world x (world + 1), all-gathered rows
+    unsigned long long *d_row = nullptr;         // world: records packed for each peer
+    unsigned long long *d_matrix = nullptr;      // world x world, all-gathered rows
     unsigned long long *h_matrix = nullptr;      // pinned copy
     double *h_roots = nullptr;                   // pinned, world x 6
     ExtQuery *d_send = nullptr;                  // world slabs of qcap records
@@ -113,7 +118,7 @@ void multi_free(cd_multi *m)
     if (m->ev_payload) hipEventDestroy(m->ev_payload);
     if (m->ev_counts) hipEventDestroy(m->ev_counts);
     for (int i = 0; i < ME_COUNT; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
-    hipFree(m->d_roots); hipFree(m->d_row); hipFree(m->d_matrix); hipFree(m->d_send); hipFree(m->d_recv);
+    hipFree(m->d_myroot); hipFree(m->d_roots); hipFree(m->d_row); hipFree(m->d_matrix); hipFree(m->d_send); hipFree(m->d_recv);
     if (m->h_matrix) hipHostFree(m->h_matrix);
     if (m->h_roots) hipHostFree(m->h_roots);
     if (m->own_comm && m->comm && rccl()) rccl()->CommDestroy(m->comm);
@@ -127,6 +132,7 @@ int multi_alloc(cd_multi *m)
     HIPCHK(hipEventCreateWithFlags(&m->ev_payload, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
     for (int i = 0; i < ME_COUNT; ++i) HIPCHK(hipEventCreate(&m->ev[i]));
+    HIPCHK(hipMalloc(&m->d_myroot, sizeof(double) * 6));
     HIPCHK(hipMalloc(&m->d_roots, sizeof(double) * 6 * W));
     HIPCHK(hipMalloc(&m->d_row, sizeof(unsigned long long) * (W + 1)));
     HIPCHK(hipMalloc(&m->d_matrix, sizeof(unsigned long long) * W * (W + 1)));
@@ -212,7 +218,6 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     hipStream_t s = c->stream;
     const int W = m->world, me = m->rank;
     const bool self_peer = (m->flags & CD_MULTI_SELF_PEER) != 0, timing = (m->flags & CD_MULTI_TIMING) != 0;
-    const size_t RW = (size_t)W + 1;
     uint32_t syncs = 0, attempts = 0;
     auto mark = [&](int e, hipStream_t st) { if (timing) hipEventRecord(m->ev[e], st); };
 
@@ -228,74 +233,76 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     const bool se = c->stage_events;
     struct RestoreStageEvents { cd_ctx *c; bool v; ~RestoreStageEvents() { c->stage_events = v; } } restore{c, se};
 
-    // ---- 1-3: tree, root all-gather, pack for all peers, count matrix; redone by EVERY rank if any rank asks for it
-    for (;; ++attempts) {
-        if (attempts >= 6) return CD_ERR_ARG;
-        mark(ME_START, s);
+    // The rank's OWN pipeline -- Morton keys, sort, fused build, the half traversal of its own tree, the report -- needs
+    // nothing from the other ranks.  It is queued right behind the packing below and runs while the counts and the records
+    // travel.  A sort that has to be redone in another form (cd_sort.h) is this rank's own business: it repeats this
+    // part alone, after the step's collectives.
+    auto enqueue_local = [&]() -> int {
         int rc;
+        mark(ME_LOC0, s);
         {
             Prezeroed fused(c);
-            rc = enqueue_morton_sort(c, !fused_build_next(c));
+            rc = enqueue_morton_sort(c, !fused_build_next(c), /*frame_ready=*/true);
             if (!rc) rc = enqueue_tree(c);
         }
-        if (rc) return rc;                        // (an enqueue failure is a HIP error on this rank: nothing collective has started in this attempt)
-        mark(ME_TREE, s);
-        NCCLCHK(r->AllGather(c->d_boxes, m->d_roots, 6, ncclDouble, m->comm, s));          // node 0 = root (n == 1: leaf 0 is node 0 too)
-        mark(ME_GATHER, s);
-        HIPCHK(hipMemsetAsync(m->d_row, 0, sizeof(unsigned long long) * RW, s));
-        k_pack_queries<<<cdiv(c->nt, PACK_THREADS), PACK_THREADS, 0, s>>>(c->d_verts, c->d_leaf, c->d_boxes, c->d_qbox, (int)c->nt, m->d_roots, W,
-                                                                           self_peer ? -1 : me, m->d_roots + 6 * (size_t)me,
-                                                                           m->d_send, (unsigned long long)m->qcap, m->d_row, c->vbase);
-        // the "redo" word of the row: non-zero when this rank's sort has to be repeated in another form (cd_sort.h)
-        k_sort_flags_word<<<1, 64, 0, s>>>(c->d_os_ticket + 8, c->sort_mode, m->d_row + W);
-        mark(ME_PACK, s);
-        NCCLCHK(r->AllGather(m->d_row, m->d_matrix, RW, ncclUint64, m->comm, s));
-        HIPCHK(hipMemcpyAsync(m->h_matrix, m->d_matrix, sizeof(unsigned long long) * W * RW, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(m->h_roots, m->d_roots, sizeof(double) * 6 * W, hipMemcpyDeviceToHost, s));
+        if (rc) return rc;
         HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, s));
-        mark(ME_COUNTS, s);
-        HIPCHK(hipEventRecord(m->ev_counts, s));
-        // the local traversal needs nothing from the other ranks: it is queued BEHIND the copies above and runs while the
-        // host reads the matrix and issues the exchange (a collective redo below throws its result away: rare)
+        mark(ME_TREE, s);
         if (fast_path) {
             // (stage events off: the kernels' time stamps ride on their dispatch packets, no barrier packets between the passes)
             c->stage_events = false;
             QuerySrc src{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, nullptr, nullptr, c->d_os_ticket + 8};
             HIPCHK(hipMemsetAsync(t0.d_state, 0, sizeof(TravState), s));
             launch_pass<false, false>(c, t0, src, c->nt, cap);
-            const int rcr = enqueue_report(c, t0, pairs != nullptr, spec0);
-            if (rcr) return rcr;
-            mark(ME_LOCAL, s);
+            rc = enqueue_report(c, t0, pairs != nullptr, spec0);
+            if (rc) return rc;
         }
+        mark(ME_LOCAL, s);
+        return CD_OK;
+    };
+
+    // ---- 1: what the OTHER ranks need from this one comes first: the box of all its triangles (a reduction over their
+    // vertices: the value node 0 of the tree will hold, known before there is a tree) and, once the boxes of all ranks are
+    // here, the triangles that overlap each peer's box, packed from the triangles in their ORIGINAL order.  The count matrix
+    // is all-gathered, and while the host waits for it the rank's own pipeline is already running.
+    for (;; ++attempts) {
+        if (attempts >= 6) return CD_ERR_ARG;
+        mark(ME_START, s);
+        k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, c->nt, c->d_partial);
+        k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->frame_mode == CD_FRAME_AUTO ? c->d_frame : nullptr, m->d_myroot);
+        NCCLCHK(r->AllGather(m->d_myroot, m->d_roots, 6, ncclDouble, m->comm, s));
+        mark(ME_GATHER, s);
+        HIPCHK(hipMemsetAsync(m->d_row, 0, sizeof(unsigned long long) * (size_t)W, s));
+        k_pack_triangles<<<cdiv(c->nt, PACK_THREADS), PACK_THREADS, 0, s>>>(c->d_verts, c->d_vidx, c->d_ids, (int)c->nt, m->d_roots, W,
+                                                                             self_peer ? -1 : me, m->d_roots + 6 * (size_t)me,
+                                                                             m->d_send, (unsigned long long)m->qcap, m->d_row, c->vbase);
+        mark(ME_PACK, s);
+        NCCLCHK(r->AllGather(m->d_row, m->d_matrix, (size_t)W, ncclUint64, m->comm, s));
+        HIPCHK(hipMemcpyAsync(m->h_matrix, m->d_matrix, sizeof(unsigned long long) * W * W, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(m->h_roots, m->d_roots, sizeof(double) * 6 * W, hipMemcpyDeviceToHost, s));
+        mark(ME_COUNTS, s);
+        HIPCHK(hipEventRecord(m->ev_counts, s));
+        if (attempts == 0) { const int rc = enqueue_local(); if (rc) return rc; }          // (a repeat only grows the slabs: the pipeline in flight stays valid)
         HIPCHK(hipEventSynchronize(m->ev_counts)); ++syncs;                                // host synchronisation 1 of 2: the counts, not the stream
         HIPCHK(hipGetLastError());
-        // decisions from the matrix: identical on every rank
-        unsigned long long mx = 0; bool any_redo = false, any_fail = false;
-        for (int a = 0; a < W; ++a) {
-            for (int b = 0; b < W; ++b) mx = std::max(mx, m->h_matrix[a * RW + b]);
-            const unsigned long long f = m->h_matrix[a * RW + W];
-            any_redo |= f == 1; any_fail |= f > 1;
-        }
-        if (any_fail) return CD_ERR_SORT;                                                  // some rank's look-back timed out: every rank returns
-        bool again = false;
-        if (any_redo) { const int js = judge_sort_flags(c); if (js != CD_OK && js != SORT_REDO) return js; again = true; }   // this rank escalates its own sort mode if it was the one
-        if (mx > m->qcap) {
-            m->qcap = mx + mx / 4 + 1024;                                                  // same rule, same input -> same capacity on every rank
-            hipFree(m->d_send); m->d_send = nullptr;
-            HIPCHK(hipMalloc(&m->d_send, sizeof(ExtQuery) * (size_t)W * m->qcap));
-            again = true;
-        }
-        if (!again) break;
+        // the one decision taken from the matrix is a function of the WHOLE matrix: identical on every rank
+        unsigned long long mx = 0;
+        for (int a = 0; a < W * W; ++a) mx = std::max(mx, m->h_matrix[a]);
+        if (mx <= m->qcap) break;
+        m->qcap = mx + mx / 4 + 1024;                                                      // same rule, same input -> same capacity on every rank
+        hipFree(m->d_send); m->d_send = nullptr;
+        HIPCHK(hipMalloc(&m->d_send, sizeof(ExtQuery) * (size_t)W * m->qcap));
     }
-    c->stage = ST_REFIT; c->root_box_valid = false;
+    c->stage = ST_REFIT;
+    std::memcpy(c->root_box_host, m->h_roots + 6 * (size_t)me, sizeof(double) * 6); c->root_box_valid = true;
 
-    // ---- 4: payload exchange on the second stream (everything it reads was complete at the synchronisation above)
+    // ---- 2: payload exchange on the second stream (everything it reads was complete at the synchronisation above)
     uint64_t sent = 0, recvd = 0; uint32_t n_peers = 0;
     std::vector<uint64_t> roff((size_t)W + 1, 0);
     for (int p = 0; p < W; ++p) {
-        const uint64_t from_p = m->h_matrix[(size_t)p * RW + me];
+        const uint64_t from_p = m->h_matrix[(size_t)p * W + me];
         roff[p + 1] = roff[p] + from_p;
-        const uint64_t to_p = m->h_matrix[(size_t)me * RW + p];
+        const uint64_t to_p = m->h_matrix[(size_t)me * W + p];
         sent += to_p; recvd += from_p;
         if (to_p || from_p) ++n_peers;
     }
@@ -309,7 +316,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     if (sent || recvd) {
         NCCLCHK(r->GroupStart());
         for (int p = 0; p < W; ++p) {
-            const uint64_t to_p = m->h_matrix[(size_t)me * RW + p], from_p = m->h_matrix[(size_t)p * RW + me];
+            const uint64_t to_p = m->h_matrix[(size_t)me * W + p], from_p = m->h_matrix[(size_t)p * W + me];
             if (to_p) NCCLCHK(r->Send(m->d_send + (size_t)p * m->qcap, to_p * sizeof(ExtQuery), ncclChar, p, m->comm, m->xstream));
             if (from_p) NCCLCHK(r->Recv(m->d_recv + roff[p], from_p * sizeof(ExtQuery), ncclChar, p, m->comm, m->xstream));
         }
@@ -318,25 +325,33 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     mark(ME_XCH1, m->xstream);
     HIPCHK(hipEventRecord(m->ev_payload, m->xstream));
 
-    // ---- 5: the pass over the received queries behind the local one, ONE synchronisation for both
+    // ---- 3: the pass over the received queries behind the local one, ONE synchronisation for both
     uint64_t n_local = 0, n_cross = 0, tested = 0;
     int rc_l = CD_OK, rc_x = CD_OK;
     bool need_general_l = !fast_path, need_general_x = !fast_path;
-    if (fast_path) {
-        int rc;
-        HIPCHK(hipStreamWaitEvent(s, m->ev_payload, 0));
-        if (recvd) {
-            QuerySrc srcx{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, m->d_recv, nullptr, c->d_os_ticket + 8};
-            HIPCHK(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), s));
-            launch_pass<true, false>(c, t1, srcx, (uint32_t)recvd, cap);
-            m->scratch_pairs.resize(2 * (size_t)spec1 + 2);
-            rc = enqueue_report(c, t1, pairs != nullptr, spec1);
-            if (rc) return rc;
+    for (int redo = 0;; ++redo) {
+        if (redo) { const int rc = enqueue_local(); if (rc) return rc; }                   // this rank's sort in its next form, then everything that follows it
+        if (fast_path) {
+            HIPCHK(hipStreamWaitEvent(s, m->ev_payload, 0));
+            if (recvd) {
+                QuerySrc srcx{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, m->d_recv, nullptr, c->d_os_ticket + 8};
+                HIPCHK(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), s));
+                launch_pass<true, false>(c, t1, srcx, (uint32_t)recvd, cap);
+                m->scratch_pairs.resize(2 * (size_t)spec1 + 2);
+                const int rc = enqueue_report(c, t1, pairs != nullptr, spec1);
+                if (rc) return rc;
+            }
         }
         mark(ME_CROSS, s);
-        c->stage_events = se;
         HIPCHK(hipStreamSynchronize(s)); ++syncs;                                          // host synchronisation 2 of 2
         HIPCHK(hipGetLastError());
+        const int js = judge_sort_flags(c);                                                // (escalates c->sort_mode when a run was too long for this form)
+        if (js == SORT_REDO && redo < 3) continue;
+        if (js != CD_OK) return js == SORT_REDO ? CD_ERR_SORT : js;
+        break;
+    }
+    c->stage_events = se;
+    if (fast_path) {
         HostCounters h0 = {}, h1 = {};
         parse_report(c, t0, h0, pairs, spec0);
         need_general_l = h0.max_shard_candidates > t0.cand_cap / NSHARD || h0.n_deferred > 0;
@@ -389,11 +404,11 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         info->query_cap = m->qcap;
         if (timing) {
             auto el = [&](int a, int b) { float ms = 0.f; return hipEventElapsedTime(&ms, m->ev[a], m->ev[b]) == hipSuccess ? ms : -1.f; };
-            info->ms_tree = el(ME_START, ME_TREE); info->ms_allgather = el(ME_TREE, ME_GATHER); info->ms_pack = el(ME_GATHER, ME_PACK);
-            info->ms_counts = el(ME_PACK, ME_COUNTS);
+            info->ms_allgather = el(ME_START, ME_GATHER); info->ms_pack = el(ME_GATHER, ME_PACK); info->ms_counts = el(ME_PACK, ME_COUNTS);
+            info->ms_tree = el(ME_LOC0, ME_TREE);
             hipEventSynchronize(m->ev[ME_XCH1]);
             info->ms_exchange = el(ME_XCH0, ME_XCH1);
-            if (fast_path && !need_general_l && !need_general_x) { info->ms_local = el(ME_COUNTS, ME_LOCAL); info->ms_cross = el(ME_LOCAL, ME_CROSS); }
+            if (fast_path && !need_general_l && !need_general_x) { info->ms_local = el(ME_TREE, ME_LOCAL); info->ms_cross = el(ME_LOCAL, ME_CROSS); }
             else { info->ms_local = -1.f; info->ms_cross = -1.f; }
         }
     }

@@ -72,17 +72,6 @@ __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__re
     for (unsigned long long i = (unsigned long long)blockIdx.x * REPORT_THREADS + threadIdx.x; i < quads; i += (unsigned long long)gridDim.x * REPORT_THREADS) dst[i] = src[i];
 }
 
-// One word that says what the multi-GPU step has to do about this rank's sort (cd_multi.h): 0 = fine, 1 = redo it in
-// the next form (a run was too long for this one), 2 = it cannot be repaired (a bounded wait timed out, or the last
-// form overflowed).  The word travels with the all-gathered count matrix, so every rank takes the same decision.
-__global__ void k_sort_flags_word(const uint32_t *__restrict__ sort_flags /* 9 words */, int sort_mode, unsigned long long *__restrict__ out)
-{
-    if (threadIdx.x != 0) return;
-    uint32_t timeout = 0;
-    for (int i = 0; i < 8; ++i) timeout |= sort_flags[i];
-    *out = timeout ? 2ull : (sort_flags[8] ? (sort_mode >= 3 ? 2ull : 1ull) : 0ull);
-}
-
 constexpr int TRAV_THREADS = 256;
 constexpr int TRAV_STACK   = 32;       // variant A: LDS entries per lane (the reference's private stack is 32, collision.cuh:21)
 constexpr int DEEP_STACK   = 192;      // global-memory entries per item in the overflow pass (tree height <= 96)
@@ -1110,6 +1099,56 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_queries(const double *__r
                 ExtQuery q;
                 q.v[0] = A.x; q.v[1] = A.y; q.v[2] = A.z; q.v[3] = B.x; q.v[4] = B.y; q.v[5] = B.z; q.v[6] = C.x; q.v[7] = C.y; q.v[8] = C.z;
                 q.id = lt.id; q.vidx[0] = lt.v0 + vbase; q.vidx[1] = lt.v1 + vbase; q.vidx[2] = lt.v2 + vbase;
+                out[(size_t)p * cap + k] = q;
+            }
+        }
+        __syncthreads();                                                      // wcount / wg_base are reused by the next box
+    }
+}
+
+// The same selection straight from the TRIANGLES, in their original order, before there is a tree: a query is a triangle
+// (vertices, ID, global vertex indices) whatever leaf order its owner's tree will have, and which triangles overlap a
+// peer's box does not depend on that order either.  The multi-GPU step packs with this kernel first thing, so that the
+// counts and the records travel while the rank sorts and builds (cd_multi.h).  The box test is the exact one
+// (box.cuh:13-22 + box.cuh:40-43) on the FP64 box of the triangle's vertices.
+__global__ __launch_bounds__(PACK_THREADS) void k_pack_triangles(const double *__restrict__ verts, const uint32_t *__restrict__ vidx, const uint32_t *__restrict__ ids,
+                                                                int n, const double *__restrict__ roots, int n_boxes, int skip, const double *__restrict__ my_root,
+                                                                ExtQuery *__restrict__ out, unsigned long long cap, unsigned long long *__restrict__ counts,
+                                                                uint32_t vbase)
+{
+    __shared__ uint32_t wcount[PACK_THREADS / 64];
+    __shared__ unsigned long long wg_base;
+    const int t = blockIdx.x * PACK_THREADS + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool live = t < n;
+    uint32_t ia = 0, ib = 0, ic = 0;
+    d3 A{0, 0, 0}, Bv{0, 0, 0}, Cv{0, 0, 0};
+    Box mine{0, 0, 0, 0, 0, 0};
+    if (live) {
+        ia = vidx[3 * (size_t)t]; ib = vidx[3 * (size_t)t + 1]; ic = vidx[3 * (size_t)t + 2];
+        A = load_vertex(verts, ia); Bv = load_vertex(verts, ib); Cv = load_vertex(verts, ic);
+        mine = box_set(A, Bv, Cv);
+    }
+    const Box me = load_box(my_root, 0);
+    for (int p = 0; p < n_boxes; ++p) {                                       // (wave-uniform loop and skips)
+        if (p == skip) continue;
+        const Box rb = load_box(roots, p);
+        if (!box_overlap(me, rb)) continue;                                   // a peer whose box misses this rank's box overlaps none of its triangles
+        const bool hit = live && box_overlap(mine, rb);                       // box.cuh:40-43, exact
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (lane == 0) wcount[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < PACK_THREADS / 64; ++k) { const uint32_t v = wcount[k]; before += (k < (int)w) ? v : 0u; total += v; }
+        if (total != 0u) {                                                    // (workgroup-uniform)
+            if (threadIdx.x == 0) wg_base = atomicAdd(&counts[p], (unsigned long long)total);
+            __syncthreads();
+            const unsigned long long k = wg_base + before + __popcll(m & ((1ull << lane) - 1ull));
+            if (hit && k < cap) {
+                ExtQuery q;
+                q.v[0] = A.x; q.v[1] = A.y; q.v[2] = A.z; q.v[3] = Bv.x; q.v[4] = Bv.y; q.v[5] = Bv.z; q.v[6] = Cv.x; q.v[7] = Cv.y; q.v[8] = Cv.z;
+                q.id = ids ? ids[t] : (uint32_t)t; q.vidx[0] = ia + vbase; q.vidx[1] = ib + vbase; q.vidx[2] = ic + vbase;
                 out[(size_t)p * cap + k] = q;
             }
         }

@@ -162,14 +162,15 @@ struct Prezeroed {                          // scope of a fused call: stage mems
 static bool fused_build_next(const cd_ctx *c);
 // links_too: the fix-up hop also resets the parent links / arrival counters (k_hierarchy and the stage-wise refit need them;
 // the fused build does not)
-int enqueue_morton_sort(cd_ctx *c, bool links_too = true)
+// frame_ready: the caller has already run the bounds kernels of this step (the multi-GPU step needs the box of all triangles first)
+int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = false)
 {
     const uint32_t n = c->nt;
     hipStream_t s = c->stream;
     HIPCHK(evrec(c, EV_MORTON0));
-    if (c->frame_mode == CD_FRAME_AUTO) {
-        k_centroid_bounds<<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_partial);
-        k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->d_frame);
+    if (c->frame_mode == CD_FRAME_AUTO && !frame_ready) {
+        k_centroid_bounds<false><<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_partial);
+        k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->d_frame, nullptr);
     }
     // fused pipeline: the sort scratch, the small counters and the traversal state are one block, zeroed once here
     HIPCHK(hipMemsetAsync(c->d_os, 0, c->prezeroed ? c->zero_bytes : c->os_bytes, s));
@@ -544,7 +545,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     c->d_os_ticket = c->d_os_hist + 8 * RADIX;
     c->d_os_look = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_os) + sizeof(uint32_t) * 8 * RADIX + 128);
     ALLOC(c->d_frame, sizeof(double) * 6);
-    ALLOC(c->d_partial, sizeof(double) * 6 * BOUNDS_BLOCKS);
+    ALLOC(c->d_partial, sizeof(double) * BOUNDS_STRIDE * BOUNDS_BLOCKS);
     ALLOC(c->d_leaf, sizeof(LeafTri) * n);
     // a failed sort may leave slots unwritten for one (discarded) run: keep their vertex ids in range
     { hipError_t e_ = hipMemset(c->d_leaf, 0, sizeof(LeafTri) * n); if (e_ != hipSuccess) { free_all(c); delete c; return -(int)e_; } }

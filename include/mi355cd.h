@@ -207,11 +207,12 @@ int cd_find_collisions_queries(cd_ctx *ctx, const void *d_queries, uint64_t nq,
 
 /* ---- the multi-GPU step in C/C++ behind the ABI (the harness it slots into is main.cu:47-174) ----
  * One process per GPU, one cd_ctx per process holding that rank's object(s) with GLOBAL triangle IDs and a vertex-id
- * base (cd_set_vertex_id_base).  A step = local LBVH -> ncclAllGather of the root AABBs -> one pack launch for all
- * overlapping peers -> ncclAllGather of the per-peer counts -> grouped ncclSend / ncclRecv of the records (beside the
- * local traversal) -> local pairs + pairs of the received queries against the local tree.  Every decision that makes
- * a rank repeat or leave the step (slab capacity, a sort that must be redone or has failed) is taken from data all
- * ranks hold, so no rank is left waiting in a collective.  RCCL is loaded at run time (dlopen "librccl.so"). */
+ * base (cd_set_vertex_id_base).  A step = box of the rank's triangles -> ncclAllGather of the boxes -> one pack launch for
+ * all overlapping peers (straight from the triangles) -> ncclAllGather of the per-peer counts -> grouped ncclSend / ncclRecv
+ * of the records, WHILE the rank sorts, builds and traverses its own tree -> the received queries against that tree.
+ * The one decision that makes the ranks repeat part of the step together (slab capacity) is taken from data all ranks
+ * hold, so no rank is left waiting in a collective.  RCCL is loaded at run time (dlopen "librccl.so"; the environment
+ * variable MI355CD_RCCL_LIBRARY names another library that provides the same ten calls). */
 typedef struct cd_multi cd_multi;
 enum {
     CD_MULTI_SELF_PEER = 1,    /* test mode: a rank also exchanges with ITSELF (ncclSend / ncclRecv to its own rank), so a    */
@@ -222,10 +223,12 @@ typedef struct cd_multi_info {
     uint32_t world, rank;          /* as the communicator reports them                                        */
     uint32_t n_peers;              /* ranks this rank sent to or received from                                */
     uint32_t host_syncs;           /* host synchronisations of the step (2 unless a pass had to be redone)    */
-    uint32_t attempts;             /* 1 + collective repeats (slabs grown, sort redone)                       */
+    uint32_t attempts;             /* 1 + collective repeats (slabs grown)                                    */
     uint32_t pad0;
     uint64_t sent_queries, recv_queries, local_pairs, cross_pairs, pairs_tested, query_cap;
-    float ms_tree, ms_allgather, ms_pack, ms_counts, ms_exchange, ms_local, ms_cross;   /* CD_MULTI_TIMING; -1 = not measured */
+    float ms_tree, ms_allgather, ms_pack, ms_counts, ms_exchange, ms_local, ms_cross;   /* CD_MULTI_TIMING; -1 = not measured.  In stream order:        */
+                                   /* allgather (box of the triangles + its all-gather), pack, counts (all-gather + copy to the host), tree (Morton keys */
+                                   /* .. fused build), local (own traversal), cross (wait for the records + their pass); exchange runs beside tree/local */
     float pad1;
 } cd_multi_info;
 /* ncclGetUniqueId: 128 bytes, produced on one rank and handed to all (by whatever the launcher has: MPI, a file, ...). */
