@@ -201,18 +201,22 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
                                                     const TileEnt *__restrict__ tile_list, const int *__restrict__ tile_count)
 {
     const int tid = threadIdx.x;
-    const int X0 = blockIdx.x * TILE, Y0 = (blockIdx.y + tile_y0) * TILE;
+    // BINNED: a workgroup renders HALF a tile (64 x 32 pixels, blockIdx.y counts halves): 8 pixels per thread instead of 16
+    // keep the kernel under 64 VGPRs (8 waves per SIMD instead of 5) and make the work items small against the frame's tail
+    constexpr int NA = BINNED ? 2 : 4;                                   // rows of pixel slots per thread
+    const int X0 = blockIdx.x * TILE, Y0 = ((BINNED ? (int)(blockIdx.y >> 1) : (int)blockIdx.y) + tile_y0) * TILE;
+    const int HY = BINNED ? (int)(blockIdx.y & 1) * (TILE / 2) : 0;
     // BRUTE: tx = tid & 15 owns 4 consecutive columns, ty = tid >> 4 owns rows ty, ty+16, ty+32, ty+48 (every sphere
     // is tested against every pixel: the mapping only has to store well).
     // BINNED: what a wave pays for a sphere is decided by its pixels that are processed TOGETHER -- the sqrt / depth
-    // branch of shade_one runs for all 64 lanes as soon as one of them is inside the disc.  So a wave owns one 32x32
-    // QUADRANT of the tile, and its 16 pixel slots are the quadrant's sixteen 8x8 BLOCKS (lane = one pixel of the
+    // branch of shade_one runs for all 64 lanes as soon as one of them is inside the disc.  So a wave owns one 32 x 16
+    // REGION of the half tile, and its 8 pixel slots are the region's eight 8x8 BLOCKS (lane = one pixel of the
     // block): a sphere costs the blocks its disc touches (~area + perimeter) instead of every 64-pixel row segment it
-    // crosses, a sphere that cannot touch the quadrant is skipped by the whole wave (wave-uniform may_touch), and a block
-    // no sphere covers skips the shading epilogue.  The quadrant goes through LDS once at the end so that it is stored
+    // crosses, a sphere that cannot touch the region is skipped by the whole wave (wave-uniform may_touch), and a block
+    // no sphere covers skips the shading epilogue.  The region goes through LDS once at the end so that it is stored
     // as rows of 128 contiguous bytes.
     const int wv = tid >> 6, ln = tid & 63;
-    const int qx = (wv & 1) * 32, qy = (wv >> 1) * 32;
+    const int qx = (wv & 1) * 32, qy = HY + (wv >> 1) * 16;
     const int tx = tid & 15, ty = tid >> 4;
     const int x = X0 + 4 * tx;
     float ox[4];
@@ -221,9 +225,9 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
     float oy[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) oy[k] = (float)((BINNED ? Y0 + qy + 8 * k + (ln >> 3) : Y0 + ty + 16 * k) - dim / 2 + c_shift_y); // anime_ray.cu:66
-    Px px[4][4];
+    Px px[NA][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) px[a][b] = Px{-RT_INF, 0.f, -1};                // anime_ray.cu:68-69
 
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
         for (int i = 0; i < n; ++i) {
             const SphGeom g = geom[i];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) shade_one(px[a][b], ox[b], oy[a], g, i);
         }
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
         // this wave's quadrant, in ray coordinates
         const int QX0 = X0 + qx, QY0 = Y0 + qy;
         const float qx0 = (float)(QX0 - dim / 2 + c_shift_x), qx1 = (float)(QX0 + 31 - dim / 2 + c_shift_x);
-        const float qy0 = (float)(QY0 - dim / 2 + c_shift_y), qy1 = (float)(QY0 + 31 - dim / 2 + c_shift_y);
+        const float qy0 = (float)(QY0 - dim / 2 + c_shift_y), qy1 = (float)(QY0 + 15 - dim / 2 + c_shift_y);
         if (cnt <= TILE_CAP) {
             const TileEnt *ents = tile_list + (size_t)t * TILE_CAP;                  // workgroup-uniform: scalar loads
             // (fetching the entries four at a time, the first four before the count is known: no change, 35.0 us)
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
                 const SphGeom g{e.cx, e.cy, e.rr, e.z};
                 if (!may_touch(g, qx0, qx1, qy0, qy1)) continue;             // (wave-uniform)
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < NA; ++a)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) shade_one(px[a][b], ox[b], oy[a], g, e.idx);
             }
@@ -269,24 +273,24 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
                 ++mytests;
                 if (!may_touch(g, qx0, qx1, qy0, qy1)) continue;             // (wave-uniform)
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < NA; ++a)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) shade_one(px[a][b], ox[b], oy[a], g, i);
             }
         }
-        if (tid == 0 && tile_tests) tile_tests[t] = mytests;                         // sphere tests per pixel of this tile (summed by the host)
+        if (tid == 0 && HY == 0 && tile_tests) tile_tests[t] = mytests;                         // sphere tests per pixel of this tile (summed by the host)
     }
     if (BINNED) {
-        // pixel (8b + lx, 8a + ly) of the quadrant -> LDS (row stride 36 words: the eight rows of a block land in different
-        // banks), then every lane stores 4 consecutive pixels of rows ly, ly + 8, ly + 16, ly + 24.  Wave-private: no barrier.
-        __shared__ uint32_t quad[THREADS / 64][32][36];
+        // pixel (8b + lx, 8a + ly) of the region -> LDS (row stride 36 words: the eight rows of a block land in different
+        // banks), then every lane stores 4 consecutive pixels of rows ly and ly + 8.  Wave-private: no barrier.
+        __shared__ uint32_t quad[THREADS / 64][8 * NA][36];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) quad[wv][8 * a + (ln >> 3)][8 * b + (ln & 7)] = pack_px(px[a][b], shade);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NA; ++k) {
             const int r = 8 * k + (ln >> 3), cx = 4 * (ln & 7);
             const uint4 o = *reinterpret_cast<const uint4 *>(&quad[wv][r][cx]);
             *reinterpret_cast<uint4 *>(rgba + (size_t)(Y0 + qy + r) * dim + (X0 + qx + cx)) = o;   // offset = x + y*dim, anime_ray.cu:64
@@ -483,7 +487,7 @@ int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, 
     if (shifts4) HIPCHK(hipMemcpyAsync(c->d_shifts, shifts4, sizeof(int32_t) * 4 * (size_t)c->n, hipMemcpyHostToDevice, s));   // NULL: the device-resident animation state
     // (the frame's time stamps ride on the dispatch packets of its first and last kernel: an event record of its own is a
     //  barrier packet, a few idle microseconds each)
-    const dim3 grid(c->dim / TILE, (y1 - y0) / TILE);
+    const dim3 grid(c->dim / TILE, (y1 - y0) / TILE), grid_binned(c->dim / TILE, 2 * ((y1 - y0) / TILE));   // binned: a workgroup per half tile
     const int ty0 = y0 / TILE, ty1 = y1 / TILE, ntx = c->dim / TILE;
     if (c->mode == RT_MODE_BINNED) {
         const int nsx = (c->dim + SUPER - 1) / SUPER;
@@ -492,7 +496,7 @@ int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, 
         hipExtLaunchKernelGGL(k_prepare, dim3((c->n + PREP_THREADS - 1) / PREP_THREADS), dim3(PREP_THREADS), 0u, s, c->ev0, nullptr, 0u,
                               (const RtSphere *)c->d_spheres, (const int32_t *)c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, (int)csx, (int)csy, nsx, ty0, ty1,
                               c->d_super_list, cur + c->ntiles, c->d_tile_list, cur, nxt, c->n_counts);
-        hipExtLaunchKernelGGL(k_render<true>, grid, dim3(THREADS), 0u, s, nullptr, c->ev1, 0u,
+        hipExtLaunchKernelGGL(k_render<true>, grid_binned, dim3(THREADS), 0u, s, nullptr, c->ev1, 0u,
                               (const SphGeom *)c->d_geom, (const SphShade *)c->d_shade, c->n, c->dim, (int)csx, (int)csy, ty0, c->d_rgba, c->d_tile_tests,
                               (const int *)c->d_super_list, (const int *)(cur + c->ntiles), nsx, (const TileEnt *)c->d_tile_list, (const int *)cur);
     } else {
