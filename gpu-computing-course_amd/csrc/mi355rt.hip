@@ -58,6 +58,7 @@ __device__ __forceinline__ void shade_one(Px &p, float ox, float oy, const SphGe
         const float t = dz + g.z;
         // anime_ray.cu:75 is a strict > in ascending sphere order, i.e. the lowest index wins a tie; stated
         // explicitly so that the spheres may arrive in any order (binned lists are unordered)
+        // (a branch-free form of this -- bitwise | and &, three selects -- measured the same: 30.6 vs 30.8 us per frame)
         if (t > p.maxz || (t == p.maxz && i < p.win)) { p.maxz = t; p.dz = dz; p.win = i; }
     }
 }
@@ -96,6 +97,9 @@ __device__ __forceinline__ bool may_touch(const SphGeom g, float ox0, float ox1,
 }
 
 constexpr int SUPER = 256;             // super-tile edge in pixels (4 x 4 tiles)
+#ifndef RT_SPLIT
+#define RT_SPLIT 2                     // binned mode: workgroups per 64x64 tile (2: 64 x 32 pixels each)
+#endif
 constexpr int TILE_CAP = 48;           // entries a tile's own list holds; a tile that is touched by more spheres falls back to its super-tile's list
 
 // What a pixel loop needs from one sphere, 32 bytes: the hit geometry, the colour and the index (for the tie rule).
@@ -203,9 +207,10 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
     const int tid = threadIdx.x;
     // BINNED: a workgroup renders HALF a tile (64 x 32 pixels, blockIdx.y counts halves): 8 pixels per thread instead of 16
     // keep the kernel under 64 VGPRs (8 waves per SIMD instead of 5) and make the work items small against the frame's tail
-    constexpr int NA = BINNED ? 2 : 4;                                   // rows of pixel slots per thread
-    const int X0 = blockIdx.x * TILE, Y0 = ((BINNED ? (int)(blockIdx.y >> 1) : (int)blockIdx.y) + tile_y0) * TILE;
-    const int HY = BINNED ? (int)(blockIdx.y & 1) * (TILE / 2) : 0;
+    constexpr int SPLIT = BINNED ? RT_SPLIT : 1;                         // workgroups per tile
+    constexpr int NA = 4 / SPLIT;                                        // rows of pixel slots per thread
+    const int X0 = blockIdx.x * TILE, Y0 = ((int)(blockIdx.y / SPLIT) + tile_y0) * TILE;
+    const int HY = (int)(blockIdx.y % SPLIT) * (TILE / SPLIT);
     // BRUTE: tx = tid & 15 owns 4 consecutive columns, ty = tid >> 4 owns rows ty, ty+16, ty+32, ty+48 (every sphere
     // is tested against every pixel: the mapping only has to store well).
     // BINNED: what a wave pays for a sphere is decided by its pixels that are processed TOGETHER -- the sqrt / depth
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
     // no sphere covers skips the shading epilogue.  The region goes through LDS once at the end so that it is stored
     // as rows of 128 contiguous bytes.
     const int wv = tid >> 6, ln = tid & 63;
-    const int qx = (wv & 1) * 32, qy = HY + (wv >> 1) * 16;
+    const int qx = (wv & 1) * 32, qy = HY + (wv >> 1) * (8 * NA);
     const int tx = tid & 15, ty = tid >> 4;
     const int x = X0 + 4 * tx;
     float ox[4];
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
         // this wave's quadrant, in ray coordinates
         const int QX0 = X0 + qx, QY0 = Y0 + qy;
         const float qx0 = (float)(QX0 - dim / 2 + c_shift_x), qx1 = (float)(QX0 + 31 - dim / 2 + c_shift_x);
-        const float qy0 = (float)(QY0 - dim / 2 + c_shift_y), qy1 = (float)(QY0 + 15 - dim / 2 + c_shift_y);
+        const float qy0 = (float)(QY0 - dim / 2 + c_shift_y), qy1 = (float)(QY0 + 8 * NA - 1 - dim / 2 + c_shift_y);
         if (cnt <= TILE_CAP) {
             const TileEnt *ents = tile_list + (size_t)t * TILE_CAP;                  // workgroup-uniform: scalar loads
             // (fetching the entries four at a time, the first four before the count is known: no change, 35.0 us)
@@ -487,7 +492,7 @@ int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, 
     if (shifts4) HIPCHK(hipMemcpyAsync(c->d_shifts, shifts4, sizeof(int32_t) * 4 * (size_t)c->n, hipMemcpyHostToDevice, s));   // NULL: the device-resident animation state
     // (the frame's time stamps ride on the dispatch packets of its first and last kernel: an event record of its own is a
     //  barrier packet, a few idle microseconds each)
-    const dim3 grid(c->dim / TILE, (y1 - y0) / TILE), grid_binned(c->dim / TILE, 2 * ((y1 - y0) / TILE));   // binned: a workgroup per half tile
+    const dim3 grid(c->dim / TILE, (y1 - y0) / TILE), grid_binned(c->dim / TILE, RT_SPLIT * ((y1 - y0) / TILE));   // binned: a workgroup per half tile
     const int ty0 = y0 / TILE, ty1 = y1 / TILE, ntx = c->dim / TILE;
     if (c->mode == RT_MODE_BINNED) {
         const int nsx = (c->dim + SUPER - 1) / SUPER;
