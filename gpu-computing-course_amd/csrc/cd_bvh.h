@@ -656,9 +656,63 @@ __device__ __forceinline__ int group_last_true(bool live, int lo, int hi, int g,
     return lo;
 }
 
-__global__ __launch_bounds__(256) void k_cross_meta(const uint64_t *__restrict__ keys, int n, NodeMeta *__restrict__ meta, int32_t *__restrict__ split_of,
-                                                    const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap)
+// The levels above the 512-leaf blocks (heap nodes [1, nbp2)) for trees of up to TOP_IN_BLOCK blocks, by ONE workgroup
+// of 256 threads without an LDS tree: a thread folds its nbp2 / 256 consecutive block boxes in registers, the waves fold
+// across lanes with shuffles (lower lane = LEFT operand: the order of box.cuh:24-32's ties is kept), four values cross
+// the waves through LDS.  Every node is stored: the cross nodes' queries read them.  Called by block 0 of k_cross_meta,
+// which has nothing to do with it -- a kernel of its own costs ~6 us for this microsecond of work (k_refit_seg_top).
+constexpr int TOP_IN_BLOCK = 2048;
+__device__ __forceinline__ Box box_shfl_down(const Box &x, int s)
 {
+    return Box{__shfl_down(x.x1, s), __shfl_down(x.x2, s), __shfl_down(x.y1, s), __shfl_down(x.y2, s), __shfl_down(x.z1, s), __shfl_down(x.z2, s)};
+}
+__device__ __forceinline__ void top_tree_one_block(double *__restrict__ seg, int nbp2, int nblocks)
+{
+    __shared__ double wbox[4][6];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (nbp2 < 2) return;
+    const int T = nbp2 < 256 ? nbp2 : 256;                                  // threads that own block boxes
+    const int per = nbp2 / T;                                               // 1, 2, 4 or 8 consecutive blocks per thread
+    Box x = box_identity();
+    if (tid < T) {
+        Box v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int b = tid * per + u; v[u] = (u < per && b < nblocks) ? load_box(seg, nbp2 + b) : box_identity(); }
+        // in-thread levels: width 8 -> 4 -> 2 -> 1 of the thread's `per` boxes; the node over blocks [b, b + 2^l) is heap node (nbp2 + b) >> l
+        int width = per;
+#pragma unroll
+        for (int l = 1; l <= 3; ++l) {
+            if ((1 << l) > per) break;
+            width >>= 1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (u < width) { v[u] = box_merge(v[2 * u], v[2 * u + 1]); store_box(seg, ((nbp2 + tid * per) >> l) + u, v[u]); }
+        }
+        x = v[0];
+    }
+    // x = heap node T + tid.  Across lanes: after the step with stride s, lanes that are multiples of 2s hold node (T + tid) / (2s)
+    for (int s = 1; s < 64 && s < T; s <<= 1) {
+        const Box y = box_shfl_down(x, s);
+        x = box_merge(x, y);
+        if (tid < T && (lane & (2 * s - 1)) == 0) store_box(seg, (T + tid) / (2 * s), x);
+    }
+    if (T <= 64) return;
+    if (lane == 0) { double *d = wbox[w]; d[0] = x.x1; d[1] = x.x2; d[2] = x.y1; d[3] = x.y2; d[4] = x.z1; d[5] = x.z2; }
+    __syncthreads();
+    if (tid == 0) {                                                         // the T / 64 = 2 or 4 wave results are heap nodes T/64 .. 2 T/64 - 1
+        auto wb = [&](int k) { return Box{wbox[k][0], wbox[k][1], wbox[k][2], wbox[k][3], wbox[k][4], wbox[k][5]}; };
+        if (T == 128) store_box(seg, 1, box_merge(wb(0), wb(1)));
+        else {
+            const Box l = box_merge(wb(0), wb(1)), r = box_merge(wb(2), wb(3));
+            store_box(seg, 2, l); store_box(seg, 3, r); store_box(seg, 1, box_merge(l, r));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cross_meta(const uint64_t *__restrict__ keys, int n, NodeMeta *__restrict__ meta, int32_t *__restrict__ split_of,
+                                                    const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap,
+                                                    double *__restrict__ seg /* non-NULL: block 0 also builds the levels above the blocks */, int nbp2, int nblocks)
+{
+    if (seg && blockIdx.x == 0) top_tree_one_block(seg, nbp2, nblocks);     // (workgroup-uniform)
     const int tid = threadIdx.x, lane = tid & 63, g = lane / XG, gl = lane % XG;
     constexpr int PER_WAVE = 64 / XG, PER_BLOCK = 256 / XG;
     const uint32_t total = min(*dense_total, dense_cap);

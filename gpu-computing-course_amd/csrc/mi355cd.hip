@@ -253,13 +253,16 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded,
                                                        c->d_recs32, c->d_qbox, c->d_root, write_internal ? 1 : 0, c->d_seg, (int)c->nbp2,
                                                        cross_list, cross_count, c->cross_cap);
-    k_refit_seg_top<<<1, 1024, 0, s>>>(c->d_seg, (int)c->nbp2, nblocks);
+    // the levels above the blocks: a launch of their own -- unless the fused build's k_cross_meta can take them along (block 0)
+    const bool top_in_meta = fused && n > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK;
+    if (!top_in_meta) k_refit_seg_top<<<1, 1024, 0, s>>>(c->d_seg, (int)c->nbp2, nblocks);
     // about 13 cross nodes per 512-leaf block: ~one node per wave, every load chain in flight at once
     // one wave per cross node, about 13 of them per 512-leaf block: two workgroups (8 waves) per block -> 1-2 nodes per wave
     // (measured: 1024 / 2048 / 4096 / 8192 workgroups at 1 M triangles -> 120 / 113 / 111 / 112 us for the whole stage)
     const uint32_t xblocks = 2u * nblocks < 256u ? 256u : (2u * nblocks > 16384u ? 16384u : 2u * (uint32_t)nblocks);
     if (fused && n > 1) {
-        k_cross_meta<<<xblocks, 256, 0, s>>>(c->d_keys[0], (int)n, c->d_meta, c->d_split_of, c->d_cross, cross_count, c->cross_cap);
+        k_cross_meta<<<xblocks, 256, 0, s>>>(c->d_keys[0], (int)n, c->d_meta, c->d_split_of, c->d_cross, cross_count, c->cross_cap,
+                                             top_in_meta ? c->d_seg : nullptr, (int)c->nbp2, nblocks);
         k_cross_records<<<xblocks, 256, 0, s>>>((int)n, c->d_meta, c->d_seg, c->d_seg32, (int)c->nbp2, c->d_qbox, c->d_boxes, c->d_recs32,
                                                 c->d_split_of, c->d_root, c->d_cross, cross_count, c->cross_cap);
     } else if (n > 1)

@@ -517,7 +517,7 @@ def test_multi_step_world_gt_1_over_the_loopback_transport(quads, qcap, xs):
         assert sum(st["cross"]) > 0
 
 
-@pytest.mark.parametrize("kind", ["cloth-float", "soup-double", "mixed", "tiny", "one-block", "ragged", "duplicates", "long-ranges"])
+@pytest.mark.parametrize("kind", ["cloth-float", "soup-double", "mixed", "tiny", "one-block", "ragged", "duplicates", "long-ranges", "1024-blocks"])
 def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
     """The fused build (cd_build.h: hierarchy from adjacent deltas, fp32 segment trees, cross nodes by wave) against the
     stage-wise one (k_hierarchy + the FP64 refit, key 104): the traversal records must be the same bytes -- child boxes
@@ -540,6 +540,8 @@ def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
         verts, vidx = v0, np.concatenate([t0, t0, t0[:1500]], axis=0)
     elif kind == "long-ranges":                     # > 65535 leaves under the top nodes: the whole-wave form of the cross queries
         verts, vidx = synth.soup(200_000, 0.01, 11)
+    elif kind == "1024-blocks":                     # 586 blocks of 512 leaves: four block boxes per thread in the top levels
+        verts, vidx = synth.soup(300_000, 0.01, 12)
     else:
         verts, vidx = synth.soup(512 * 7 + 1, 0.05, 9)
     got = {}
