@@ -517,6 +517,35 @@ def test_multi_step_world_gt_1_over_the_loopback_transport(quads, qcap, xs):
         assert sum(st["cross"]) > 0
 
 
+def _assert_fused_records_equal_stagewise(verts, vidx, ids=None):
+    got = {}
+    for fused in (1, 0):
+        with mi355cd.CollisionDetector(verts, vidx, ids) as cd:
+            cd.set_option(104, 0 if fused else 1)
+            cd.build_tree()
+            got[fused] = cd.debug_records() + (cd.root_box(),)
+    (rr, rl, qb, root, rbox), (rr0, rl0, qb0, root0, rbox0) = got[1], got[0]
+    n = vidx.shape[0]
+    assert (n == 1 or root == root0) and np.array_equal(qb, qb0) and np.array_equal(rbox, rbox0)   # (one leaf: no record, no root name)
+    used = np.zeros(n, dtype=bool)                          # records are named by split: n - 1 of the n slots are in use
+    if n > 1:                                               # (unused slots hold whatever the allocation held: walk from the root)
+        frontier = np.array([root0])
+        while frontier.size:
+            used[frontier] = True
+            ch = np.concatenate([rr0[frontier, 6], rl0[frontier, 6]]).view(np.int32)
+            frontier = ch[ch >= 0]
+    assert used.sum() == max(n - 1, 0)
+    for a, b in ((rr, rr0), (rl, rl0)):
+        assert np.array_equal(a[used][:, :7], b[used][:, :7])
+    # last | flags: the low 30 bits always; bit 30 / 31 only where the left / right child is a leaf
+    assert np.array_equal(rr[used][:, 7] & 0x3fffffff, rr0[used][:, 7] & 0x3fffffff)
+    assert np.array_equal(rl[used][:, 7], rl0[used][:, 7])
+    leafL = rl0[used][:, 6].view(np.int32) < 0
+    leafR = rr0[used][:, 6].view(np.int32) < 0
+    assert np.array_equal((rr[used][:, 7] >> 30 & 1)[leafL], (rr0[used][:, 7] >> 30 & 1)[leafL])
+    assert np.array_equal((rr[used][:, 7] >> 31 & 1)[leafR], (rr0[used][:, 7] >> 31 & 1)[leafR])
+
+
 @pytest.mark.parametrize("kind", ["cloth-float", "soup-double", "mixed", "tiny", "one-block", "ragged", "duplicates", "long-ranges", "1024-blocks"])
 def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
     """The fused build (cd_build.h: hierarchy from adjacent deltas, fp32 segment trees, cross nodes by wave) against the
@@ -544,32 +573,7 @@ def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
         verts, vidx = synth.soup(300_000, 0.01, 12)
     else:
         verts, vidx = synth.soup(512 * 7 + 1, 0.05, 9)
-    got = {}
-    for fused in (1, 0):
-        with mi355cd.CollisionDetector(verts, vidx) as cd:
-            cd.set_option(104, 0 if fused else 1)
-            cd.build_tree()
-            got[fused] = cd.debug_records() + (cd.root_box(),)
-    (rr, rl, qb, root, rbox), (rr0, rl0, qb0, root0, rbox0) = got[1], got[0]
-    n = vidx.shape[0]
-    assert root == root0 and np.array_equal(qb, qb0) and np.array_equal(rbox, rbox0)
-    used = np.zeros(n, dtype=bool)                          # records are named by split: n - 1 of the n slots are in use
-    if n > 1:                                               # (unused slots hold whatever the allocation held: walk from the root)
-        frontier = np.array([root0])
-        while frontier.size:
-            used[frontier] = True
-            ch = np.concatenate([rr0[frontier, 6], rl0[frontier, 6]]).view(np.int32)
-            frontier = ch[ch >= 0]
-    assert used.sum() == max(n - 1, 0)
-    for a, b in ((rr, rr0), (rl, rl0)):
-        assert np.array_equal(a[used][:, :7], b[used][:, :7])
-    # last | flags: the low 30 bits always; bit 30 / 31 only where the left / right child is a leaf
-    assert np.array_equal(rr[used][:, 7] & 0x3fffffff, rr0[used][:, 7] & 0x3fffffff)
-    assert np.array_equal(rl[used][:, 7], rl0[used][:, 7])
-    leafL = rl0[used][:, 6].view(np.int32) < 0
-    leafR = rr0[used][:, 6].view(np.int32) < 0
-    assert np.array_equal((rr[used][:, 7] >> 30 & 1)[leafL], (rr0[used][:, 7] >> 30 & 1)[leafL])
-    assert np.array_equal((rr[used][:, 7] >> 31 & 1)[leafR], (rr0[used][:, 7] >> 31 & 1)[leafR])
+    _assert_fused_records_equal_stagewise(verts, vidx)
 
 
 def test_device_pair_post_processing():
@@ -815,6 +819,7 @@ def test_random_meshes_property():
         if case % 3 == 0:
             ids = rng.permutation(vidx.shape[0]).astype(np.uint32) + 7
         r = oracle.pipeline(verts, vidx, ids)
+        _assert_fused_records_equal_stagewise(verts, vidx, ids)            # the two builds write the same traversal records
         for variant in VARIANTS:
             with mi355cd.CollisionDetector(verts, vidx, ids) as cd:
                 cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
