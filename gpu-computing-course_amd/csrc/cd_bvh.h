@@ -666,53 +666,67 @@ __device__ __forceinline__ Box box_shfl_down(const Box &x, int s)
 {
     return Box{__shfl_down(x.x1, s), __shfl_down(x.x2, s), __shfl_down(x.y1, s), __shfl_down(x.y2, s), __shfl_down(x.z1, s), __shfl_down(x.z2, s)};
 }
-__device__ __forceinline__ void top_tree_one_block(double *__restrict__ seg, int nbp2, int nblocks)
+// b0, span: the workgroup folds the span (<= TOP_IN_BLOCK, a power of two) blocks that start at block b0, up to their common
+// ancestor.  Heap node over the blocks [b, b + 2^l) = (nbp2 + b) >> l: the whole tree for span == nbp2; for a larger tree one
+// workgroup per span of 2048 blocks, then the same function again on the heap's upper part (k_top_levels, below).
+__device__ __forceinline__ void top_tree_one_block(double *__restrict__ seg, int nbp2, int nblocks, int b0, int span)
 {
     __shared__ double wbox[4][6];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (nbp2 < 2) return;
-    const int T = nbp2 < 256 ? nbp2 : 256;                                  // threads that own block boxes
-    const int per = nbp2 / T;                                               // 1, 2, 4 or 8 consecutive blocks per thread
+    if (span < 2) return;
+    const int T = span < 256 ? span : 256;                                  // threads that own block boxes
+    const int per = span / T;                                               // 1, 2, 4 or 8 consecutive blocks per thread
+    const int kt = (nbp2 + b0) / per + tid;                                 // heap node of the thread's blocks
     Box x = box_identity();
     if (tid < T) {
         Box v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int b = tid * per + u; v[u] = (u < per && b < nblocks) ? load_box(seg, nbp2 + b) : box_identity(); }
-        // in-thread levels: width 8 -> 4 -> 2 -> 1 of the thread's `per` boxes; the node over blocks [b, b + 2^l) is heap node (nbp2 + b) >> l
+        for (int u = 0; u < 8; ++u) { const int b = b0 + tid * per + u; v[u] = (u < per && b < nblocks) ? load_box(seg, nbp2 + b) : box_identity(); }
+        // in-thread levels: width 8 -> 4 -> 2 -> 1 of the thread's `per` boxes
         int width = per;
 #pragma unroll
         for (int l = 1; l <= 3; ++l) {
             if ((1 << l) > per) break;
             width >>= 1;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (u < width) { v[u] = box_merge(v[2 * u], v[2 * u + 1]); store_box(seg, ((nbp2 + tid * per) >> l) + u, v[u]); }
+            for (int u = 0; u < 4; ++u) if (u < width) { v[u] = box_merge(v[2 * u], v[2 * u + 1]); store_box(seg, ((nbp2 + b0 + tid * per) >> l) + u, v[u]); }
         }
         x = v[0];
     }
-    // x = heap node T + tid.  Across lanes: after the step with stride s, lanes that are multiples of 2s hold node (T + tid) / (2s)
+    // across lanes: after the step with stride s, lanes that are multiples of 2s hold node kt / (2s)
     for (int s = 1; s < 64 && s < T; s <<= 1) {
         const Box y = box_shfl_down(x, s);
         x = box_merge(x, y);
-        if (tid < T && (lane & (2 * s - 1)) == 0) store_box(seg, (T + tid) / (2 * s), x);
+        if (tid < T && (lane & (2 * s - 1)) == 0) store_box(seg, kt / (2 * s), x);
     }
     if (T <= 64) return;
     if (lane == 0) { double *d = wbox[w]; d[0] = x.x1; d[1] = x.x2; d[2] = x.y1; d[3] = x.y2; d[4] = x.z1; d[5] = x.z2; }
     __syncthreads();
-    if (tid == 0) {                                                         // the T / 64 = 2 or 4 wave results are heap nodes T/64 .. 2 T/64 - 1
+    if (tid == 0) {                                                         // the T / 64 = 2 or 4 wave results are the heap nodes kt / 64 .. + T / 64 - 1
         auto wb = [&](int k) { return Box{wbox[k][0], wbox[k][1], wbox[k][2], wbox[k][3], wbox[k][4], wbox[k][5]}; };
-        if (T == 128) store_box(seg, 1, box_merge(wb(0), wb(1)));
+        const int kw = kt / 64;                                             // (tid == 0: the first of them)
+        if (T == 128) store_box(seg, kw / 2, box_merge(wb(0), wb(1)));
         else {
             const Box l = box_merge(wb(0), wb(1)), r = box_merge(wb(2), wb(3));
-            store_box(seg, 2, l); store_box(seg, 3, r); store_box(seg, 1, box_merge(l, r));
+            store_box(seg, kw / 2, l); store_box(seg, kw / 2 + 1, r); store_box(seg, kw / 4, box_merge(l, r));
         }
     }
+}
+
+// Trees of more than TOP_IN_BLOCK blocks: one workgroup per span of TOP_IN_BLOCK blocks; launched again with
+// (nbp2 / TOP_IN_BLOCK, ceil(nblocks / TOP_IN_BLOCK)) it folds the span roots -- they ARE the block level of the heap's
+// upper part (same array, same indices).  (k_refit_seg_top's single workgroup takes 65 us at 8 M triangles.)
+__global__ __launch_bounds__(256) void k_top_levels(double *__restrict__ seg, int nbp2, int nblocks)
+{
+    const int span = nbp2 < TOP_IN_BLOCK ? nbp2 : TOP_IN_BLOCK;
+    top_tree_one_block(seg, nbp2, nblocks, (int)blockIdx.x * span, span);
 }
 
 __global__ __launch_bounds__(256) void k_cross_meta(const uint64_t *__restrict__ keys, int n, NodeMeta *__restrict__ meta, int32_t *__restrict__ split_of,
                                                     const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap,
                                                     double *__restrict__ seg /* non-NULL: block 0 also builds the levels above the blocks */, int nbp2, int nblocks)
 {
-    if (seg && blockIdx.x == 0) top_tree_one_block(seg, nbp2, nblocks);     // (workgroup-uniform)
+    if (seg && blockIdx.x == 0) top_tree_one_block(seg, nbp2, nblocks, 0, nbp2);   // (workgroup-uniform)
     const int tid = threadIdx.x, lane = tid & 63, g = lane / XG, gl = lane % XG;
     constexpr int PER_WAVE = 64 / XG, PER_BLOCK = 256 / XG;
     const uint32_t total = min(*dense_total, dense_cap);

@@ -255,7 +255,16 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
                                                        cross_list, cross_count, c->cross_cap);
     // the levels above the blocks: a launch of their own -- unless the fused build's k_cross_meta can take them along (block 0)
     const bool top_in_meta = fused && n > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK;
-    if (!top_in_meta) k_refit_seg_top<<<1, 1024, 0, s>>>(c->d_seg, (int)c->nbp2, nblocks);
+    if (!top_in_meta) {
+        if (fused && n > 1) {                    // a large tree: a workgroup per 2048 blocks, then the heap's upper part the same way
+            int nb = (int)c->nbp2, live = nblocks;
+            while (nb > 1) {
+                const int span = nb < TOP_IN_BLOCK ? nb : TOP_IN_BLOCK;
+                k_top_levels<<<nb / span, 256, 0, s>>>(c->d_seg, nb, live);
+                nb /= span; live = (live + span - 1) / span;
+            }
+        } else k_refit_seg_top<<<1, 1024, 0, s>>>(c->d_seg, (int)c->nbp2, nblocks);
+    }
     // about 13 cross nodes per 512-leaf block: ~one node per wave, every load chain in flight at once
     // one wave per cross node, about 13 of them per 512-leaf block: two workgroups (8 waves) per block -> 1-2 nodes per wave
     // (measured: 1024 / 2048 / 4096 / 8192 workgroups at 1 M triangles -> 120 / 113 / 111 / 112 us for the whole stage)

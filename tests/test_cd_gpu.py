@@ -546,7 +546,7 @@ def _assert_fused_records_equal_stagewise(verts, vidx, ids=None):
     assert np.array_equal((rr[used][:, 7] >> 31 & 1)[leafR], (rr0[used][:, 7] >> 31 & 1)[leafR])
 
 
-@pytest.mark.parametrize("kind", ["cloth-float", "soup-double", "mixed", "tiny", "one-block", "ragged", "duplicates", "long-ranges", "1024-blocks"])
+@pytest.mark.parametrize("kind", ["cloth-float", "soup-double", "mixed", "tiny", "one-block", "ragged", "duplicates", "long-ranges", "1024-blocks", "4096-blocks"])
 def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
     """The fused build (cd_build.h: hierarchy from adjacent deltas, fp32 segment trees, cross nodes by wave) against the
     stage-wise one (k_hierarchy + the FP64 refit, key 104): the traversal records must be the same bytes -- child boxes
@@ -571,6 +571,8 @@ def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
         verts, vidx = synth.soup(200_000, 0.01, 11)
     elif kind == "1024-blocks":                     # 586 blocks of 512 leaves: four block boxes per thread in the top levels
         verts, vidx = synth.soup(300_000, 0.01, 12)
+    elif kind == "4096-blocks":                     # 2149 blocks: beyond what one workgroup folds -- spans of 2048 blocks, then their roots
+        verts, vidx = synth.soup(1_100_000, 0.005, 13)
     else:
         verts, vidx = synth.soup(512 * 7 + 1, 0.05, 9)
     _assert_fused_records_equal_stagewise(verts, vidx)
