@@ -235,7 +235,7 @@ constexpr int LOCAL_WAVES   = LOCAL_THREADS / 64;
 constexpr int LOCAL_W       = 4096;                     // nominal keys per workgroup
 constexpr int LOCAL_LIMIT   = 6144;                     // longest run that can be windowed (a planar 1 M cloth in the reference's frame: runs of
                                                         // ~500 on key bits 44..59; 441 runs, the longest 4590, on bits 48..63).  Windows of
-                                                        // 2048 keys (two workgroups per CU) were slower: sort 85 -> 94 us
+                                                        // 2048 keys were slower: sort 85 -> 94 us (73 KB of LDS, one workgroup per CU), 84 -> 88 us (56 KB, two per CU)
 constexpr int LOCAL_ITEMS   = (LOCAL_W + LOCAL_LIMIT) / LOCAL_THREADS;   // 10 keys per lane
 constexpr int LOCAL_CAP     = LOCAL_ITEMS * LOCAL_THREADS;               // 10240 keys: 80 KB of LDS + 16 KB of counters
 
