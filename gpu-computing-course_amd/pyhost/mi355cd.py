@@ -349,13 +349,21 @@ def multi_unique_id() -> bytes:
 class MultiStep:
     """The multi-GPU step of libmi355cd.so (cd_multi_*): RCCL collectives issued by the C++ side, one process per GPU."""
 
-    def __init__(self, cd: "CollisionDetector", unique_id: bytes, rank: int, world: int, query_cap_per_peer: int = 0, flags: int = 0):
+    def __init__(self, cd: "CollisionDetector", unique_id: bytes, rank: int, world: int, query_cap_per_peer: int = 0, flags: int = 0,
+                 nccl_comm: int | None = None):
+        """unique_id / rank / world: the library creates (and owns) the communicator.  nccl_comm: an existing ncclComm_t (as an
+        integer address) whose rank and size are used instead; it stays the caller's."""
         self.lib = cd.lib
         self.cd = cd
         self._m = C.c_void_p()
-        rc = self.lib.cd_multi_create(C.byref(self._m), cd._ctx, C.c_char_p(unique_id), rank, world, query_cap_per_peer, flags)
+        if nccl_comm is not None:
+            rc = self.lib.cd_multi_create_from_comm(C.byref(self._m), cd._ctx, C.c_void_p(nccl_comm), query_cap_per_peer, flags)
+            name = "cd_multi_create_from_comm"
+        else:
+            rc = self.lib.cd_multi_create(C.byref(self._m), cd._ctx, C.c_char_p(unique_id), rank, world, query_cap_per_peer, flags)
+            name = "cd_multi_create"
         if rc != CD_OK:
-            raise CdError("cd_multi_create", rc)
+            raise CdError(name, rc)
         self._pairs = None
 
     def step(self, cap: int = 1 << 22):

@@ -476,6 +476,25 @@ def test_multi_step_c_abi_one_rank_self_peer():
             pairs, n, rc, info = ms.step(cap=1 << 20)
             assert rc == 0 and n == r["stats"].n_pairs and info.cross_pairs == 0 and info.n_peers == 0 and info.host_syncs == 2
             assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])) and info.pairs_tested == r["stats"].pairs_tested
+        # over a communicator the CALLER owns (cd_multi_create_from_comm): made here with RCCL's own ncclCommInitRank
+        import ctypes as C
+        import torch
+        rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+        class NcclId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        uid2 = NcclId()
+        assert rccl.ncclGetUniqueId(C.byref(uid2)) == 0
+        comm = C.c_void_p()
+        rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclId, C.c_int]
+        assert rccl.ncclCommInitRank(C.byref(comm), 1, uid2, 0) == 0
+        with mi355cd.MultiStep(cd, b"", 0, 1, flags=mi355cd.CD_MULTI_SELF_PEER, nccl_comm=comm.value) as ms:
+            pairs, n, rc, info = ms.step(cap=1 << 20)
+            nl = r["stats"].n_pairs
+            assert rc == 0 and info.world == 1 and info.rank == 0 and info.local_pairs == nl and info.cross_pairs == nl
+            assert np.array_equal(oracle.pair_set(pairs[nl:]), oracle.pair_set(r["pairs"]))
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        assert rccl.ncclCommDestroy(comm) == 0                       # still the caller's to destroy
         # the context is still usable through the single-GPU entry points
         p2, n2, rc2 = cd.self_collide()
         assert np.array_equal(oracle.pair_set(p2), oracle.pair_set(r["pairs"]))
