@@ -86,6 +86,10 @@ RcclApi *rccl()
         if (r_ != ncclSuccess) return CD_ERR_RCCL;                     \
     } while (0)
 
+// rehearsal only (CD_MULTI_SELF_SLICE): the box the rank sees of ITSELF as a peer keeps the upper tenth of its x extent --
+// about the share of its triangles a config-4 neighbour's box covers
+__global__ void k_slice_box(double *box) { box[0] = box[1] - 0.1 * (box[1] - box[0]); }
+
 enum MEv { ME_START, ME_LOC0, ME_TREE, ME_GATHER, ME_PACK, ME_COUNTS, ME_XCH0, ME_XCH1, ME_LOCAL, ME_CROSS, ME_COUNT };
 
 }  // namespace
@@ -96,7 +100,7 @@ struct cd_multi {
     int rank = 0, world = 1, flags = 0;
     uint64_t qcap = 0;                           // records per peer slab -- the SAME on every rank (grown from the shared count matrix)
     hipStream_t xstream = nullptr;               // payload exchange, beside the context's stream
-    hipEvent_t ev_payload = nullptr, ev_counts = nullptr, ev[ME_COUNT] = {};
+    hipEvent_t ev_payload = nullptr, ev_counts = nullptr, ev_tree = nullptr, ev_cross = nullptr, ev[ME_COUNT] = {};
     double *d_myroot = nullptr;                  // 6: the box of all this rank's triangles, from their vertices
     double *d_roots = nullptr;                   // world x 6
     unsigned long long *d_row = nullptr;         // world: records packed for each peer
@@ -117,6 +121,8 @@ void multi_free(cd_multi *m)
     if (m->xstream) { hipStreamSynchronize(m->xstream); hipStreamDestroy(m->xstream); }
     if (m->ev_payload) hipEventDestroy(m->ev_payload);
     if (m->ev_counts) hipEventDestroy(m->ev_counts);
+    if (m->ev_tree) hipEventDestroy(m->ev_tree);
+    if (m->ev_cross) hipEventDestroy(m->ev_cross);
     for (int i = 0; i < ME_COUNT; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
     hipFree(m->d_myroot); hipFree(m->d_roots); hipFree(m->d_row); hipFree(m->d_matrix); hipFree(m->d_send); hipFree(m->d_recv);
     if (m->h_matrix) hipHostFree(m->h_matrix);
@@ -131,6 +137,8 @@ int multi_alloc(cd_multi *m)
     HIPCHK(hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&m->ev_payload, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_tree, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_cross, hipEventDisableTiming));
     for (int i = 0; i < ME_COUNT; ++i) HIPCHK(hipEventCreate(&m->ev[i]));
     HIPCHK(hipMalloc(&m->d_myroot, sizeof(double) * 6));
     HIPCHK(hipMalloc(&m->d_roots, sizeof(double) * 6 * W));
@@ -247,6 +255,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         }
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(m->ev_tree, s));                                             // the tree exists: the cross pass may start (second stream)
         mark(ME_TREE, s);
         if (fast_path) {
             // (stage events off: the kernels' time stamps ride on their dispatch packets, no barrier packets between the passes)
@@ -265,12 +274,15 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     // vertices: the value node 0 of the tree will hold, known before there is a tree) and, once the boxes of all ranks are
     // here, the triangles that overlap each peer's box, packed from the triangles in their ORIGINAL order.  The count matrix
     // is all-gathered, and while the host waits for it the rank's own pipeline is already running.
+    // (Forking here -- all-gathers and pack on the second stream, the own pipeline at once on the first -- was measured in the
+    //  one-rank rehearsal: the second stream's work did not start before the build had finished, 0.46 vs 0.45 ms per step.)
     for (;; ++attempts) {
         if (attempts >= 6) return CD_ERR_ARG;
         mark(ME_START, s);
         k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, c->nt, c->d_partial);
         k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->frame_mode == CD_FRAME_AUTO ? c->d_frame : nullptr, m->d_myroot);
         NCCLCHK(r->AllGather(m->d_myroot, m->d_roots, 6, ncclDouble, m->comm, s));
+        if (self_peer && (m->flags & CD_MULTI_SELF_SLICE)) k_slice_box<<<1, 1, 0, s>>>(m->d_roots + 6 * (size_t)me);   // rehearsal at config 4's scale
         mark(ME_GATHER, s);
         HIPCHK(hipMemsetAsync(m->d_row, 0, sizeof(unsigned long long) * (size_t)W, s));
         k_pack_triangles<<<cdiv(c->nt, PACK_THREADS), PACK_THREADS, 0, s>>>(c->d_verts, c->d_vidx, c->d_ids, (int)c->nt, m->d_roots, W,
@@ -325,25 +337,34 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     mark(ME_XCH1, m->xstream);
     HIPCHK(hipEventRecord(m->ev_payload, m->xstream));
 
-    // ---- 3: the pass over the received queries behind the local one, ONE synchronisation for both
+    // ---- 3: the pass over the received queries, on the SECOND stream behind the exchange: it needs the records and the
+    // tree, nothing of the local traversal -- the two descents share the chip and the latency-bound ends of the two passes
+    // (exact tests, reports) overlap.  ONE wait for both.
     uint64_t n_local = 0, n_cross = 0, tested = 0;
     int rc_l = CD_OK, rc_x = CD_OK;
     bool need_general_l = !fast_path, need_general_x = !fast_path;
     for (int redo = 0;; ++redo) {
         if (redo) { const int rc = enqueue_local(); if (rc) return rc; }                   // this rank's sort in its next form, then everything that follows it
-        if (fast_path) {
-            HIPCHK(hipStreamWaitEvent(s, m->ev_payload, 0));
-            if (recvd) {
-                QuerySrc srcx{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, m->d_recv, nullptr, c->d_os_ticket + 8};
-                HIPCHK(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), s));
+        const bool serial = (m->flags & CD_MULTI_CROSS_SERIAL) != 0;                        // A/B: the cross pass behind the local one, on its stream
+        hipStream_t cs = serial ? s : m->xstream;
+        if (fast_path && recvd) {
+            HIPCHK(hipStreamWaitEvent(cs, serial ? m->ev_payload : m->ev_tree, 0));
+            QuerySrc srcx{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, m->d_recv, nullptr, c->d_os_ticket + 8};
+            HIPCHK(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), cs));
+            m->scratch_pairs.resize(2 * (size_t)spec1 + 2);
+            int rc;
+            {
+                struct OnStream { cd_ctx *c; hipStream_t keep; OnStream(cd_ctx *c_, hipStream_t st) : c(c_), keep(c_->stream) { c->stream = st; c->quiet_pass = true; }
+                                  ~OnStream() { c->stream = keep; c->quiet_pass = false; } } on(c, cs);
                 launch_pass<true, false>(c, t1, srcx, (uint32_t)recvd, cap);
-                m->scratch_pairs.resize(2 * (size_t)spec1 + 2);
-                const int rc = enqueue_report(c, t1, pairs != nullptr, spec1);
-                if (rc) return rc;
+                rc = enqueue_report(c, t1, pairs != nullptr, spec1);
             }
+            if (rc) return rc;
         }
-        mark(ME_CROSS, s);
-        HIPCHK(hipStreamSynchronize(s)); ++syncs;                                          // host synchronisation 2 of 2
+        mark(ME_CROSS, cs);
+        HIPCHK(hipEventRecord(m->ev_cross, m->xstream));
+        HIPCHK(hipStreamWaitEvent(s, m->ev_cross, 0));
+        HIPCHK(hipStreamSynchronize(s)); ++syncs;                                          // host synchronisation 2 of 2 (both streams)
         HIPCHK(hipGetLastError());
         const int js = judge_sort_flags(c);                                                // (escalates c->sort_mode when a run was too long for this form)
         if (js == SORT_REDO && redo < 3) continue;
@@ -391,9 +412,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         if (rc_x < 0) return rc_x;
         n_cross = nx; tested += c->stats.pairs_tested; syncs += 1;
     }
-    // the payload exchange must have drained before the next step reuses the slabs (it has: the cross pass waited for it,
-    // or nothing was received; a rank that only SENT waits here)
-    if (!recvd && sent) { HIPCHK(hipStreamSynchronize(m->xstream)); }
+    // (the payload exchange has drained: the second stream was waited for above)
     c->stats.n_pairs = n_local + n_cross; c->stats.pairs_tested = tested;
     c->last_pairs_on_device = 0;                                              // two lists: cd_sorted_pairs does not apply to a multi step
     if (n_pairs) *n_pairs = n_local + n_cross;
@@ -408,7 +427,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
             info->ms_tree = el(ME_LOC0, ME_TREE);
             hipEventSynchronize(m->ev[ME_XCH1]);
             info->ms_exchange = el(ME_XCH0, ME_XCH1);
-            if (fast_path && !need_general_l && !need_general_x) { info->ms_local = el(ME_TREE, ME_LOCAL); info->ms_cross = el(ME_LOCAL, ME_CROSS); }
+            if (fast_path && !need_general_l && !need_general_x) { info->ms_local = el(ME_TREE, ME_LOCAL); info->ms_cross = el(ME_XCH1, ME_CROSS); }
             else { info->ms_local = -1.f; info->ms_cross = -1.f; }
         }
     }

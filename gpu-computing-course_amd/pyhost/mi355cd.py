@@ -34,7 +34,7 @@ class CdStats(C.Structure):
 
 
 # every symbol include/mi355cd.h declares (tests check the library exports exactly these)
-CD_MULTI_SELF_PEER, CD_MULTI_TIMING = 1, 2
+CD_MULTI_SELF_PEER, CD_MULTI_TIMING, CD_MULTI_SELF_SLICE = 1, 2, 4
 CD_ERR_RCCL = -1008
 
 

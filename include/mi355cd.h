@@ -217,7 +217,11 @@ typedef struct cd_multi cd_multi;
 enum {
     CD_MULTI_SELF_PEER = 1,    /* test mode: a rank also exchanges with ITSELF (ncclSend / ncclRecv to its own rank), so a    */
                                /* 1-rank communicator exercises every phase; the cross pass then reports the local pairs again */
-    CD_MULTI_TIMING    = 2     /* record HIP events at the phase boundaries (cd_multi_info.ms_*); costs a few idle us each     */
+    CD_MULTI_TIMING    = 2,    /* record HIP events at the phase boundaries (cd_multi_info.ms_*); costs a few idle us each     */
+    CD_MULTI_CROSS_SERIAL = 8, /* A/B switch: the pass over the received queries runs behind the local traversal on its stream  */
+                               /* instead of beside it on the second stream                                                     */
+    CD_MULTI_SELF_SLICE = 4    /* with CD_MULTI_SELF_PEER: the rank exchanges only the tenth of its triangles at its upper x end */
+                               /* with itself -- a one-GPU rehearsal at the scale of a 10 % neighbour overlap                  */
 };
 typedef struct cd_multi_info {
     uint32_t world, rank;          /* as the communicator reports them                                        */
