@@ -100,7 +100,7 @@ struct cd_multi {
     int rank = 0, world = 1, flags = 0;
     uint64_t qcap = 0;                           // records per peer slab -- the SAME on every rank (grown from the shared count matrix)
     hipStream_t xstream = nullptr;               // payload exchange, beside the context's stream
-    hipEvent_t ev_payload = nullptr, ev_counts = nullptr, ev_tree = nullptr, ev_cross = nullptr, ev[ME_COUNT] = {};
+    hipEvent_t ev_payload = nullptr, ev_counts = nullptr, ev_tree = nullptr, ev_cross = nullptr, ev_box = nullptr, ev[ME_COUNT] = {};
     double *d_myroot = nullptr;                  // 6: the box of all this rank's triangles, from their vertices
     double *d_roots = nullptr;                   // world x 6
     unsigned long long *d_row = nullptr;         // world: records packed for each peer
@@ -122,6 +122,7 @@ void multi_free(cd_multi *m)
     if (m->ev_payload) hipEventDestroy(m->ev_payload);
     if (m->ev_counts) hipEventDestroy(m->ev_counts);
     if (m->ev_tree) hipEventDestroy(m->ev_tree);
+    if (m->ev_box) hipEventDestroy(m->ev_box);
     if (m->ev_cross) hipEventDestroy(m->ev_cross);
     for (int i = 0; i < ME_COUNT; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
     hipFree(m->d_myroot); hipFree(m->d_roots); hipFree(m->d_row); hipFree(m->d_matrix); hipFree(m->d_send); hipFree(m->d_recv);
@@ -138,6 +139,7 @@ int multi_alloc(cd_multi *m)
     HIPCHK(hipEventCreateWithFlags(&m->ev_payload, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_tree, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_box, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_cross, hipEventDisableTiming));
     for (int i = 0; i < ME_COUNT; ++i) HIPCHK(hipEventCreate(&m->ev[i]));
     HIPCHK(hipMalloc(&m->d_myroot, sizeof(double) * 6));
@@ -254,7 +256,8 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
             if (!rc) rc = enqueue_tree(c);
         }
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, s));
+        // (the sort's flags come back with the local pass's report; a copy of their own into pageable memory stalls the stream for ~20 us)
+        if (!fast_path) HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, s));
         HIPCHK(hipEventRecord(m->ev_tree, s));                                             // the tree exists: the cross pass may start (second stream)
         mark(ME_TREE, s);
         if (fast_path) {
@@ -271,31 +274,34 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     };
 
     // ---- 1: what the OTHER ranks need from this one comes first: the box of all its triangles (a reduction over their
-    // vertices: the value node 0 of the tree will hold, known before there is a tree) and, once the boxes of all ranks are
-    // here, the triangles that overlap each peer's box, packed from the triangles in their ORIGINAL order.  The count matrix
-    // is all-gathered, and while the host waits for it the rank's own pipeline is already running.
-    // (Forking here -- all-gathers and pack on the second stream, the own pipeline at once on the first -- was measured in the
-    //  one-rank rehearsal: the second stream's work did not start before the build had finished, 0.46 vs 0.45 ms per step.)
+    // vertices: the value node 0 of the tree will hold, known before there is a tree).  Then the step forks.  SECOND stream:
+    // all-gather of the boxes, pack of the triangles that overlap each peer's box (from the triangles in their ORIGINAL
+    // order), all-gather of the count matrix -- queued FIRST, so that it is on the device before the fifteen launches of
+    // the rank's own pipeline have been issued on the first stream.  The pack streams the vertices while the sort's
+    // latency-bound passes leave the memory system idle.
+    mark(ME_START, s);
+    k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, c->nt, c->d_partial);
+    k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->frame_mode == CD_FRAME_AUTO ? c->d_frame : nullptr, m->d_myroot);
+    HIPCHK(hipEventRecord(m->ev_box, s));
+    hipStream_t xs = m->xstream;
+    HIPCHK(hipStreamWaitEvent(xs, m->ev_box, 0));
     for (;; ++attempts) {
         if (attempts >= 6) return CD_ERR_ARG;
-        mark(ME_START, s);
-        k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, c->nt, c->d_partial);
-        k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->frame_mode == CD_FRAME_AUTO ? c->d_frame : nullptr, m->d_myroot);
-        NCCLCHK(r->AllGather(m->d_myroot, m->d_roots, 6, ncclDouble, m->comm, s));
-        if (self_peer && (m->flags & CD_MULTI_SELF_SLICE)) k_slice_box<<<1, 1, 0, s>>>(m->d_roots + 6 * (size_t)me);   // rehearsal at config 4's scale
-        mark(ME_GATHER, s);
-        HIPCHK(hipMemsetAsync(m->d_row, 0, sizeof(unsigned long long) * (size_t)W, s));
-        k_pack_triangles<<<cdiv(c->nt, PACK_THREADS), PACK_THREADS, 0, s>>>(c->d_verts, c->d_vidx, c->d_ids, (int)c->nt, m->d_roots, W,
-                                                                             self_peer ? -1 : me, m->d_roots + 6 * (size_t)me,
-                                                                             m->d_send, (unsigned long long)m->qcap, m->d_row, c->vbase);
-        mark(ME_PACK, s);
-        NCCLCHK(r->AllGather(m->d_row, m->d_matrix, (size_t)W, ncclUint64, m->comm, s));
-        HIPCHK(hipMemcpyAsync(m->h_matrix, m->d_matrix, sizeof(unsigned long long) * W * W, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(m->h_roots, m->d_roots, sizeof(double) * 6 * W, hipMemcpyDeviceToHost, s));
-        mark(ME_COUNTS, s);
-        HIPCHK(hipEventRecord(m->ev_counts, s));
-        if (attempts == 0) { const int rc = enqueue_local(); if (rc) return rc; }          // (a repeat only grows the slabs: the pipeline in flight stays valid)
-        HIPCHK(hipEventSynchronize(m->ev_counts)); ++syncs;                                // host synchronisation 1 of 2: the counts, not the stream
+        NCCLCHK(r->AllGather(m->d_myroot, m->d_roots, 6, ncclDouble, m->comm, xs));
+        if (self_peer && (m->flags & CD_MULTI_SELF_SLICE)) k_slice_box<<<1, 1, 0, xs>>>(m->d_roots + 6 * (size_t)me);   // rehearsal at config 4's scale
+        mark(ME_GATHER, xs);
+        HIPCHK(hipMemsetAsync(m->d_row, 0, sizeof(unsigned long long) * (size_t)W, xs));
+        k_pack_triangles<<<cdiv(c->nt, PACK_THREADS), PACK_THREADS, 0, xs>>>(c->d_verts, c->d_vidx, c->d_ids, (int)c->nt, m->d_roots, W,
+                                                                              self_peer ? -1 : me, m->d_roots + 6 * (size_t)me,
+                                                                              m->d_send, (unsigned long long)m->qcap, m->d_row, c->vbase);
+        mark(ME_PACK, xs);
+        NCCLCHK(r->AllGather(m->d_row, m->d_matrix, (size_t)W, ncclUint64, m->comm, xs));
+        HIPCHK(hipMemcpyAsync(m->h_matrix, m->d_matrix, sizeof(unsigned long long) * W * W, hipMemcpyDeviceToHost, xs));
+        HIPCHK(hipMemcpyAsync(m->h_roots, m->d_roots, sizeof(double) * 6 * W, hipMemcpyDeviceToHost, xs));
+        mark(ME_COUNTS, xs);
+        HIPCHK(hipEventRecord(m->ev_counts, xs));
+        if (attempts == 0) { const int rc = enqueue_local(); if (rc) return rc; }          // (a repeat only grows the slabs and packs again: the pipeline in flight stays valid)
+        HIPCHK(hipEventSynchronize(m->ev_counts)); ++syncs;                                // host synchronisation 1 of 2: the counts (the first stream keeps working)
         HIPCHK(hipGetLastError());
         // the one decision taken from the matrix is a function of the WHOLE matrix: identical on every rank
         unsigned long long mx = 0;
@@ -366,6 +372,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         HIPCHK(hipStreamWaitEvent(s, m->ev_cross, 0));
         HIPCHK(hipStreamSynchronize(s)); ++syncs;                                          // host synchronisation 2 of 2 (both streams)
         HIPCHK(hipGetLastError());
+        if (fast_path) std::memcpy(c->sort_flags, reinterpret_cast<const Report *>(t0.h_report)->sort_flags, sizeof c->sort_flags);
         const int js = judge_sort_flags(c);                                                // (escalates c->sort_mode when a run was too long for this form)
         if (js == SORT_REDO && redo < 3) continue;
         if (js != CD_OK) return js == SORT_REDO ? CD_ERR_SORT : js;
