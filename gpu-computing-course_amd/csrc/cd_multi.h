@@ -6,19 +6,21 @@
 // deliver (local pairs + each cross pair {a, b}, a.ID < b.ID, exactly once, from the owner of b: tri_contact.cuh:81
 // applied to external queries too).  The order of work is chosen so that everything the ranks exchange is on its way
 // before a rank starts on its own tree:
-//   1. the box of all the rank's triangles, a reduction over their vertices (= the value node 0 of its tree will hold),
-//      and its all-gather (ncclAllGather, 48 B per rank)
-//   2. ONE launch compacts, for every peer whose box strictly overlaps this rank's (box.cuh:40-43), the triangles that
-//      overlap that peer's box into cd_query records -- straight from the triangles in their original order: a query
-//      is a triangle, whatever tree it will sit in; the per-peer counts are all-gathered as a world x world matrix, so
-//      every rank knows what it sends, what it receives and whether ANY rank ran out of room -- the one decision taken
-//      from that matrix (grow the slabs) is the same on every rank: no rank leaves a collective the others are still in
-//   3. queued right behind, without waiting for the host: the rank's OWN pipeline (Morton keys, sort, fused build, half
-//      traversal of its own tree, report) -- it runs while the host reads the matrix and while
-//   4. the records travel: grouped ncclSend / ncclRecv, each peer's slice on its own xGMI link (no ring), second stream
-//   5. the received queries against the local tree, behind the local pass; both reports are read with one wait.
-// Host synchronisations per step: two (the count matrix -- with the GPU busy on 3; both traversal passes).  A sort that
-// must be redone in another form is local: the rank repeats 3 and 5 alone, after the step's collectives.
+//   1. the box of all the rank's triangles, a reduction over their vertices (= the value node 0 of its tree will hold);
+//      from here on two streams:
+//   B. all-gather of the boxes (ncclAllGather, 48 B per rank); ONE launch compacts, for every peer whose box strictly
+//      overlaps this rank's (box.cuh:40-43), the triangles that overlap that peer's box into cd_query records --
+//      straight from the triangles in their original order: a query is a triangle, whatever tree it will sit in; the
+//      per-peer counts are all-gathered as a world x world matrix, so every rank knows what it sends, what it receives
+//      and whether ANY rank ran out of room -- the one decision taken from that matrix (grow the slabs) is the same on
+//      every rank: no rank leaves a collective the others are still in
+//   A. beside it, without waiting for anything: the rank's OWN pipeline (Morton keys, sort, fused build, half traversal
+//      of its own tree, report)
+//   B. once the host has read the matrix: the records travel (grouped ncclSend / ncclRecv, each peer's slice on its own
+//      xGMI link, no ring), then -- as soon as the tree exists -- the received queries are traversed against it, beside
+//      the local traversal; both reports are read with one wait.
+// Host synchronisations per step: two (the count matrix -- with the GPU busy on A; both traversal passes).  A sort that
+// must be redone in another form is local: the rank repeats its pipeline and the cross pass alone, after the collectives.
 //
 // RCCL is loaded at run time (dlopen) by the first cd_multi_* call, so single-GPU users of the library do not pay for
 // it; there is no fallback transport: without librccl the calls return CD_ERR_RCCL.
