@@ -243,7 +243,8 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         if (rc) return rc;
     }
     const bool se = c->stage_events;
-    struct RestoreStageEvents { cd_ctx *c; bool v; ~RestoreStageEvents() { c->stage_events = v; } } restore{c, se};
+    struct RestoreStageEvents { cd_ctx *c; bool v; uint32_t mask; ~RestoreStageEvents() { c->stage_events = v; c->stamp_mask = mask; } } restore{c, se, c->stamp_mask};
+    c->stamp_mask = 0;                            // no per-kernel time stamps inside a multi step (~5 us of idle GPU each; nobody reads them here)
 
     // The rank's OWN pipeline -- Morton keys, sort, fused build, the half traversal of its own tree, the report -- needs
     // nothing from the other ranks.  It is queued right behind the packing below and runs while the counts and the records

@@ -74,6 +74,7 @@ struct cd_ctx {
     int32_t *d_split_of = nullptr;          // fused build: split of every internal node (child links of the records)
     bool hierarchy_valid = false;           // meta[] / parent[] hold the tree of the current keys (fused calls build the records without them)
     bool last_tree_fused = false;           // the last fused call built hierarchy + refit in one pass (ms_hierarchy is then part of ms_refit)
+    uint32_t stamp_mask = 15;               // CD_OPT_KERNEL_STAMPS: with stage timing off, which time stamps a fused call still takes (1 block build, 2 descent, 4 exact, 8 pipeline start): ~5 us of idle GPU each
     uint32_t dbg_no_fused_build = 0;        // debug key 104: fused entry points run k_hierarchy + the meta-reading refit (A/B)
     uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
     // traversal
@@ -149,6 +150,7 @@ float elapsed(cd_ctx *c, int a, int b)
 inline hipError_t evrec(cd_ctx *c, int idx)
 {
     if (!c->stage_events && !(idx == EV_MORTON0 || idx == EV_TRAV0 || idx == EV_DESC1 || idx == EV_TRAV1 || idx == EV_DEEP0 || idx == EV_DEEP1)) return hipSuccess;
+    if (!c->stage_events && idx == EV_MORTON0 && !(c->stamp_mask & 8u)) return hipSuccess;
     return hipEventRecord(c->ev[idx], c->stream);
 }
 
@@ -246,7 +248,8 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         c->leaves_filled = false; c->leaf_records_filled = true;
         c->hierarchy_valid = false;
         // (its time stamps ride on its own dispatch packet: this is the largest kernel of the step, bench.py prices it)
-        hipExtLaunchKernelGGL(k_build_block, dim3(nblocks), dim3(REFIT_BLK), 0u, s, c->ev[EV_BLK0], c->ev[EV_BLK1], 0u,
+        const bool stamp = (c->stamp_mask & 1u) != 0;
+        hipExtLaunchKernelGGL(k_build_block, dim3(nblocks), dim3(REFIT_BLK), 0u, s, stamp ? c->ev[EV_BLK0] : nullptr, stamp ? c->ev[EV_BLK1] : nullptr, 0u,
                               (const double *)c->d_verts, (const LeafTri *)c->d_leaf, (int)n, (const uint64_t *)c->d_keys[0], c->d_split_of,
                               c->d_boxes, c->d_recs32, c->d_qbox, c->d_root, c->d_seg, c->d_seg32, (int)c->nbp2,
                               cross_list, cross_count, c->cross_cap);
@@ -327,7 +330,8 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         // barrier packet and ~6 us of idle GPU); off, the events ride on the kernels' own dispatch packets
         // (hipExtLaunchKernelGGL start / stop events): same timestamps, no gaps.
         const bool ride = !DEEP && !c->stage_events && !c->quiet_pass;
-        hipEvent_t e0 = ride ? c->ev[EV_TRAV0] : nullptr, e1 = ride ? c->ev[EV_DESC1] : nullptr, e2 = ride ? c->ev[EV_TRAV1] : nullptr;
+        hipEvent_t e0 = (ride && (c->stamp_mask & 2u)) ? c->ev[EV_TRAV0] : nullptr, e1 = (ride && (c->stamp_mask & 2u)) ? c->ev[EV_DESC1] : nullptr;
+        hipEvent_t e2 = (ride && (c->stamp_mask & 4u)) ? c->ev[EV_TRAV1] : nullptr;
         const uint32_t qarg = qpw | (c->dbg_no_shared_path ? 0x40000000u : 0u);
         uint2 *dl = DEEP ? nullptr : tb.d_defer; const uint32_t dcap = DEEP ? 0u : tb.defer_cap; int32_t *deep = DEEP ? tb.d_deep : nullptr;
         const uint32_t half = half_mode ? 1u : 0u;
@@ -470,9 +474,11 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
         HIPCHK(hipMemcpyAsync(pairs + 2 * have, tb.d_pairs + 2 * have, sizeof(uint32_t) * 2 * (ncopy - have), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     }
-    c->stats.ms_traverse = elapsed(c, EV_TRAV0, EV_TRAV1) + deep_ms;
-    c->stats.ms_descend = (c->trav_variant != 0 && nq > 0) ? elapsed(c, EV_TRAV0, EV_DESC1) : 0.f;
-    c->stats.ms_exact = (c->trav_variant != 0 && nq > 0) ? elapsed(c, EV_DESC1, EV_TRAV1) : 0.f;
+    // (a time stamp that was not taken in this call must not be read: the event holds an earlier call's)
+    const bool have_d = !c->events_ride || (c->stamp_mask & 2u), have_x = !c->events_ride || (c->stamp_mask & 4u);
+    c->stats.ms_traverse = (have_d && have_x) ? elapsed(c, EV_TRAV0, EV_TRAV1) + deep_ms : 0.f;
+    c->stats.ms_descend = (c->trav_variant != 0 && nq > 0 && have_d) ? elapsed(c, EV_TRAV0, EV_DESC1) : 0.f;
+    c->stats.ms_exact = (c->trav_variant != 0 && nq > 0 && have_d && have_x) ? elapsed(c, EV_DESC1, EV_TRAV1) : 0.f;
     c->stats.traverse_launches = launches;
     c->stats.n_pairs = found; c->stats.pairs_tested = h.pairs_tested; c->stats.node_visits = h.node_visits;
     c->stats.wave_steps = h.wave_steps; c->stats.candidates = h.candidates;
@@ -766,8 +772,9 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         c->stats.ms_hierarchy = c->last_tree_fused ? 0.f : elapsed(c, EV_HIER0, EV_HIER1);
         c->stats.ms_refit = elapsed(c, EV_REFIT0, EV_REFIT1);
     } else c->stats.ms_morton = c->stats.ms_sort = c->stats.ms_hierarchy = c->stats.ms_refit = 0.f;
-    c->stats.ms_pipeline = elapsed(c, EV_MORTON0, EV_TRAV1) + (c->stats.ms_traverse - elapsed(c, EV_TRAV0, EV_TRAV1));   // + deep pass, if any
-    c->stats.ms_build_block = c->last_tree_fused ? elapsed(c, EV_BLK0, EV_BLK1) : 0.f;
+    const bool all_stamps = c->stage_events || (c->stamp_mask & 14u) == 14u;
+    c->stats.ms_pipeline = all_stamps ? elapsed(c, EV_MORTON0, EV_TRAV1) + (c->stats.ms_traverse - elapsed(c, EV_TRAV0, EV_TRAV1)) : 0.f;   // + deep pass, if any
+    c->stats.ms_build_block = (c->last_tree_fused && (c->stamp_mask & 1u)) ? elapsed(c, EV_BLK0, EV_BLK1) : 0.f;
     c->stage = ST_REFIT;
     c->root_box_valid = true;
     return rc;
@@ -929,6 +936,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (key == 102) { c->dbg_no_shared_path = (uint32_t)value; return CD_OK; }
     if (key == 103) { c->dbg_diag = (uint32_t)value; return CD_OK; }
     if (key == 104) { c->dbg_no_fused_build = (uint32_t)value; return CD_OK; }
+    if (key == CD_OPT_KERNEL_STAMPS) { if (value < 0 || value > 15) return CD_ERR_ARG; c->stamp_mask = (uint32_t)value; return CD_OK; }
     if (key == 101) { if (value < 1 || value > 65535) return CD_ERR_ARG; c->exact_blocks = (int)value; return CD_OK; }
     return CD_ERR_ARG;
 }

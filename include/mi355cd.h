@@ -162,6 +162,10 @@ enum {
                                    /*    sorted inside LDS windows, stable fix-up of equal-high-half runs; falls back to 2, then  */
                                    /*    to 1, by itself when a run is too long.  2: half-key -- 4 global passes + the fix-up.   */
                                    /*    1: all 8 digit passes.  All give the identical stable order by the full 64-bit key.     */
+    CD_OPT_KERNEL_STAMPS    = 4,   /* with CD_OPT_STAGE_TIMING 0: which time stamps a fused call still takes, a bit mask -- 1: the block-build   */
+                                   /*    kernel (cd_stats.ms_build_block), 2: the descent kernel (ms_descend), 4: the exact kernel (with 2:      */
+                                   /*    ms_exact, ms_traverse), 8: pipeline start (with 2 and 4: ms_pipeline).  Default 15.  A stamp rides on   */
+                                   /*    its kernel's dispatch packet and still costs ~5 us of idle GPU; a field whose stamps are off reads 0    */
     CD_OPT_STAGE_TIMING     = 3,   /* 1 (default): HIP events around every stage (cd_stats.ms_morton ... ms_refit); 0: only the  */
                                    /*    events of the pipeline as a whole and of the descent kernel (ms_pipeline, ms_traverse,   */
                                    /*    ms_descend, ms_exact) -- each stage boundary costs a few idle microseconds                */
