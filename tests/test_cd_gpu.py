@@ -758,6 +758,14 @@ def test_stage_timing_switch_changes_only_the_timers():
                 assert (st.ms_sort > 0) == bool(timing)
                 if timing:
                     assert st.ms_morton + st.ms_sort + st.ms_hierarchy + st.ms_refit + st.ms_traverse <= st.ms_pipeline * 1.001
+        # CD_OPT_KERNEL_STAMPS: with stage timing off, a time that was not stamped in THIS call reads 0 (never an earlier call's)
+        cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0)
+        for mask, want in ((2, (0, 1, 0, 0)), (0, (0, 0, 0, 0)), (7, (1, 1, 1, 0)), (15, (1, 1, 1, 1)), (14, (0, 1, 1, 1))):
+            cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, mask)
+            pairs, n, rc = cd.self_collide()
+            st = cd.stats()
+            assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])) and st.pairs_tested == r["stats"].pairs_tested
+            assert (st.ms_build_block > 0, st.ms_descend > 0, st.ms_exact > 0, st.ms_pipeline > 0) == tuple(bool(w) for w in want), (mask, st.ms_build_block, st.ms_descend, st.ms_exact, st.ms_pipeline)
         # the stage-wise API after a fused call zeroes its own counters again
         cd.morton_sort(); cd.build_hierarchy(); cd.refit_boxes()
         assert cd.check_internal().tolist() == [1, 0, 0, 0, 0]
