@@ -243,21 +243,25 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         if (rc) return rc;
     }
     const bool se = c->stage_events;
-    struct RestoreStageEvents { cd_ctx *c; bool v; uint32_t mask; ~RestoreStageEvents() { c->stage_events = v; c->stamp_mask = mask; } } restore{c, se, c->stamp_mask};
+    struct RestoreStageEvents { cd_ctx *c; bool v; uint32_t mask; ~RestoreStageEvents() { c->stage_events = v; c->stamp_mask = mask; c->prezeroed = false; } } restore{c, se, c->stamp_mask};
     c->stamp_mask = 0;                            // no per-kernel time stamps inside a multi step (~5 us of idle GPU each; nobody reads them here)
 
     // The rank's OWN pipeline -- Morton keys, sort, fused build, the half traversal of its own tree, the report -- needs
     // nothing from the other ranks.  It is queued right behind the packing below and runs while the counts and the records
     // travel.  A sort that has to be redone in another form (cd_sort.h) is this rank's own business: it repeats this
     // part alone, after the step's collectives.
-    auto enqueue_local = [&]() -> int {
-        int rc;
+    // (in two parts: the sort goes to the device BEFORE the host spends its tens of microseconds on the second stream's RCCL
+    //  calls, the rest after them)
+    auto enqueue_sort = [&]() -> int {
         mark(ME_LOC0, s);
-        {
-            Prezeroed fused(c);
-            rc = enqueue_morton_sort(c, !fused_build_next(c), /*frame_ready=*/true);
-            if (!rc) rc = enqueue_tree(c);
-        }
+        c->prezeroed = true;                                                               // (one memset for every counter of the pipeline, as in cd_self_collide)
+        const int rc = enqueue_morton_sort(c, !fused_build_next(c), /*frame_ready=*/true);
+        if (rc) c->prezeroed = false;
+        return rc;
+    };
+    auto enqueue_rest = [&]() -> int {
+        int rc = enqueue_tree(c);
+        c->prezeroed = false;
         if (rc) return rc;
         // (the sort's flags come back with the local pass's report; a copy of their own into pageable memory stalls the stream for ~20 us)
         if (!fast_path) HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, s));
@@ -286,6 +290,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, c->nt, c->d_partial);
     k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->frame_mode == CD_FRAME_AUTO ? c->d_frame : nullptr, m->d_myroot);
     HIPCHK(hipEventRecord(m->ev_box, s));
+    { const int rc = enqueue_sort(); if (rc) return rc; }
     hipStream_t xs = m->xstream;
     HIPCHK(hipStreamWaitEvent(xs, m->ev_box, 0));
     for (;; ++attempts) {
@@ -303,7 +308,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         HIPCHK(hipMemcpyAsync(m->h_roots, m->d_roots, sizeof(double) * 6 * W, hipMemcpyDeviceToHost, xs));
         mark(ME_COUNTS, xs);
         HIPCHK(hipEventRecord(m->ev_counts, xs));
-        if (attempts == 0) { const int rc = enqueue_local(); if (rc) return rc; }          // (a repeat only grows the slabs and packs again: the pipeline in flight stays valid)
+        if (attempts == 0) { const int rc = enqueue_rest(); if (rc) return rc; }           // (a repeat only grows the slabs and packs again: the pipeline in flight stays valid)
         HIPCHK(hipEventSynchronize(m->ev_counts)); ++syncs;                                // host synchronisation 1 of 2: the counts (the first stream keeps working)
         HIPCHK(hipGetLastError());
         // the one decision taken from the matrix is a function of the WHOLE matrix: identical on every rank
@@ -353,7 +358,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     int rc_l = CD_OK, rc_x = CD_OK;
     bool need_general_l = !fast_path, need_general_x = !fast_path;
     for (int redo = 0;; ++redo) {
-        if (redo) { const int rc = enqueue_local(); if (rc) return rc; }                   // this rank's sort in its next form, then everything that follows it
+        if (redo) { int rc = enqueue_sort(); if (!rc) rc = enqueue_rest(); if (rc) return rc; }   // this rank's sort in its next form, then everything that follows it
         const bool serial = (m->flags & CD_MULTI_CROSS_SERIAL) != 0;                        // A/B: the cross pass behind the local one, on its stream
         hipStream_t cs = serial ? s : m->xstream;
         if (fast_path && recvd) {
