@@ -367,7 +367,9 @@ def main():
                                else f"{backend} (REHEARSAL: Python orchestration, payloads staged through the host)")
             line["world_size_observed"] = observed
             line["phase_ms"] = phase
-            line["phase_ms_note"] = "max over ranks; exchange runs beside local; from 5 extra untimed steps with events at the phase boundaries"
+            line["phase_ms_note"] = ("max over ranks, from 5 extra untimed steps with events at the phase boundaries.  The phases are NOT additive: allgather / "
+                                     "pack / counts / exchange / cross run on a second stream beside tree / local (allgather counts from the step's start, "
+                                     "cross from the end of the exchange to the end of the pass over the received queries)")
     if rank == 0:
         print(json.dumps(line))
     if ms is not None:
