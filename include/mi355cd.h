@@ -234,9 +234,10 @@ typedef struct cd_multi_info {
     uint32_t attempts;             /* 1 + collective repeats (slabs grown)                                    */
     uint32_t pad0;
     uint64_t sent_queries, recv_queries, local_pairs, cross_pairs, pairs_tested, query_cap;
-    float ms_tree, ms_allgather, ms_pack, ms_counts, ms_exchange, ms_local, ms_cross;   /* CD_MULTI_TIMING; -1 = not measured.  In stream order:        */
-                                   /* allgather (box of the triangles + its all-gather), pack, counts (all-gather + copy to the host), tree (Morton keys */
-                                   /* .. fused build), local (own traversal), cross (wait for the records + their pass); exchange runs beside tree/local */
+    float ms_tree, ms_allgather, ms_pack, ms_counts, ms_exchange, ms_local, ms_cross;   /* CD_MULTI_TIMING; -1 = not measured.  NOT additive: */
+                                   /* first stream: tree (Morton keys .. fused build), local (own traversal); second stream, beside them: allgather  */
+                                   /* (from the step's start: box of the triangles + its all-gather), pack, counts (all-gather + copy to the host),  */
+                                   /* exchange (send / receive), cross (end of the exchange -> end of the pass over the received queries)            */
     float pad1;
 } cd_multi_info;
 /* ncclGetUniqueId: 128 bytes, produced on one rank and handed to all (by whatever the launcher has: MPI, a file, ...). */
