@@ -247,9 +247,9 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     c->stamp_mask = 0;                            // no per-kernel time stamps inside a multi step (~5 us of idle GPU each; nobody reads them here)
 
     // The rank's OWN pipeline -- Morton keys, sort, fused build, the half traversal of its own tree, the report -- needs
-    // nothing from the other ranks.  It is queued right behind the packing below and runs while the counts and the records
-    // travel.  A sort that has to be redone in another form (cd_sort.h) is this rank's own business: it repeats this
-    // part alone, after the step's collectives.
+    // nothing from the other ranks: it runs on the first stream while the boxes, the counts and the records travel on the
+    // second.  A sort that has to be redone in another form (cd_sort.h) is this rank's own business: it repeats this part
+    // alone, after the step's collectives.
     // (in two parts: the sort goes to the device BEFORE the host spends its tens of microseconds on the second stream's RCCL
     //  calls, the rest after them)
     auto enqueue_sort = [&]() -> int {
@@ -283,9 +283,9 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     // ---- 1: what the OTHER ranks need from this one comes first: the box of all its triangles (a reduction over their
     // vertices: the value node 0 of the tree will hold, known before there is a tree).  Then the step forks.  SECOND stream:
     // all-gather of the boxes, pack of the triangles that overlap each peer's box (from the triangles in their ORIGINAL
-    // order), all-gather of the count matrix -- queued FIRST, so that it is on the device before the fifteen launches of
-    // the rank's own pipeline have been issued on the first stream.  The pack streams the vertices while the sort's
-    // latency-bound passes leave the memory system idle.
+    // order), all-gather of the count matrix.  Order of issue on the host: the sort's launches (first stream: ~85 us of
+    // work to chew on), then the second stream's calls (RCCL's cost the host tens of microseconds), then tree and traversal.
+    // The pack streams the vertices while the sort's latency-bound passes leave the memory system idle.
     mark(ME_START, s);
     k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, c->nt, c->d_partial);
     k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->frame_mode == CD_FRAME_AUTO ? c->d_frame : nullptr, m->d_myroot);
