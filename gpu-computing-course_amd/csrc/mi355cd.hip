@@ -62,8 +62,10 @@ struct cd_ctx {
     // sort
     uint64_t *d_keys[2] = {nullptr, nullptr}; uint32_t *d_perm[2] = {nullptr, nullptr};
     uint32_t *d_counts = nullptr; uint32_t ntiles = 0;
-    // onesweep state: one allocation = [8][256] u32 histograms | 8 u32 tickets (padded) | [8][ntiles][256] u64 granules
-    void *d_os = nullptr; size_t os_bytes = 0, zero_bytes = 0; uint32_t *d_os_hist = nullptr; uint32_t *d_os_ticket = nullptr; unsigned long long *d_os_look = nullptr;
+    // onesweep state, part of one scratch block (layout: cd_create): [8][256] u32 histograms | 8 u32 tickets (padded) | [8][ntiles][256] u64 granules
+    void *d_os = nullptr; size_t os_bytes = 0 /* whole block */, zero_bytes = 0 /* its front part: all a fused call with the hybrid sort needs zeroed */, sort_hi_bytes = 0 /* of that, the sort's own */;
+    unsigned long long *d_os_look_lo = nullptr;   // granules of the digit passes 0..5 (behind the front part); d_os_look: passes 6 and 7
+    uint32_t *d_os_hist = nullptr; uint32_t *d_os_ticket = nullptr; unsigned long long *d_os_look = nullptr;
     double *d_frame = nullptr, *d_partial = nullptr;
     // tree
     LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; double *d_seg = nullptr; float *d_seg32 = nullptr; uint32_t nbp2 = 1; int32_t *d_cross = nullptr; uint32_t cross_cap = 0;   // segment tree over leaf boxes: nbp2*512 heap nodes
@@ -176,7 +178,8 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
         k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->d_frame, nullptr);
     }
     // fused pipeline: the sort scratch, the small counters and the traversal state are one block, zeroed once here
-    HIPCHK(hipMemsetAsync(c->d_os, 0, c->prezeroed ? c->zero_bytes : c->os_bytes, s));
+    // (the hybrid forms use the digit passes 6 and 7 only: their granules sit in the front part of the block, with the counters)
+    HIPCHK(hipMemsetAsync(c->d_os, 0, c->sort_mode <= 1 ? (c->prezeroed ? c->zero_bytes : c->sort_hi_bytes) : c->os_bytes, s));
     // Three forms of the same stable 64-bit sort (cd_sort.h): hybrid = 2 global passes on the top 16 bits + an in-LDS
     // sort of run-aligned windows + the fix-up hop; half-key = 4 global passes on the high 32 bits + the fix-up hop;
     // full = 8 global passes.  The keys start in the buffer that leaves the sorted data in buffer 0.
@@ -192,7 +195,8 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
     // onesweep: one pass over the data per digit; the digit histograms came with the keys
     for (int pass = first_digit; pass < 8; ++pass) {
         k_os_pass<<<c->ntiles, OS_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1], n, pass * RADIX_BITS - down,
-                                                    c->d_os_hist + pass * RADIX, c->d_os_look + (size_t)pass * c->ntiles * RADIX,
+                                                    c->d_os_hist + pass * RADIX,
+                                                    (pass >= 6 ? c->d_os_look + (size_t)(pass - 6) * c->ntiles * RADIX : c->d_os_look_lo + (size_t)pass * c->ntiles * RADIX),
                                                     c->d_os_ticket + pass, pass == first_digit);
         cur ^= 1;
     }
@@ -550,19 +554,24 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     if (ids) ALLOC(c->d_ids, sizeof(uint32_t) * n);
     for (int i = 0; i < 2; ++i) { ALLOC(c->d_keys[i], sizeof(uint64_t) * n); ALLOC(c->d_perm[i], sizeof(uint32_t) * n); }
     ALLOC(c->d_counts, sizeof(uint32_t) * RADIX * c->ntiles);
-    c->os_bytes = sizeof(uint32_t) * 8 * RADIX + 128 + sizeof(unsigned long long) * 8 * (size_t)c->ntiles * RADIX;   // hist | 8 tickets, 8 time-out flags, fix-up flag, pad | granules
-    // one scratch block so that the fused pipeline zeroes everything with ONE memset:
-    //   [onesweep: histograms | tickets, flags | look-back granules] [small counters: 128 words] [TravState]
-    const size_t os_only = c->os_bytes;
-    const size_t small_off = (os_only + 127) & ~(size_t)127, state_off = small_off + 512;
+    // one scratch block so that the fused pipeline zeroes everything with ONE memset, and as little as the sort form needs:
+    //   [onesweep: histograms | tickets, flags | look-back granules of passes 6, 7] [small counters: 128 words] [TravState]   <- hybrid sort: this much
+    //   [look-back granules of passes 0..5]                                                                                  <- the other forms: all of it
+    const size_t gran = sizeof(unsigned long long) * (size_t)c->ntiles * RADIX;           // one pass
+    const size_t look_off = sizeof(uint32_t) * 8 * RADIX + 128;                            // hist | 8 tickets, 8 time-out flags, fix-up flag, pad
+    c->sort_hi_bytes = look_off + 2 * gran;
+    const size_t small_off = (c->sort_hi_bytes + 127) & ~(size_t)127, state_off = small_off + 512;
     c->zero_bytes = state_off + sizeof(TravState);
-    ALLOC(c->d_os, c->zero_bytes);
+    const size_t lo_off = (c->zero_bytes + 127) & ~(size_t)127;
+    c->os_bytes = lo_off + 6 * gran;
+    ALLOC(c->d_os, c->os_bytes);
     c->d_small = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(c->d_os) + small_off);
     c->tb[0].d_state = reinterpret_cast<TravState *>(reinterpret_cast<char *>(c->d_os) + state_off);
     c->d_root = reinterpret_cast<int32_t *>(c->d_small + 96);
     c->d_os_hist = reinterpret_cast<uint32_t *>(c->d_os);
     c->d_os_ticket = c->d_os_hist + 8 * RADIX;
-    c->d_os_look = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_os) + sizeof(uint32_t) * 8 * RADIX + 128);
+    c->d_os_look = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_os) + look_off);
+    c->d_os_look_lo = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_os) + lo_off);
     ALLOC(c->d_frame, sizeof(double) * 6);
     ALLOC(c->d_partial, sizeof(double) * BOUNDS_STRIDE * BOUNDS_BLOCKS);
     ALLOC(c->d_leaf, sizeof(LeafTri) * n);
