@@ -119,6 +119,14 @@ def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5):
             st = rt.stats()
             m = statistics.median(ms)
             out[name] = {"ms_per_frame": m, "sphere_tests_per_frame": int(st.sphere_tests), "sphere_tests_per_s": st.sphere_tests / (m * 1e-3)}
+            if mode == mi355rt.RT_MODE_BINNED:
+                # 16 frames queued back to back (time stamps on the first and the last kernel only): what a loop that does not come back
+                # to the host per frame sees -- a single frame's two stamps cost it ~5 us of idle GPU between its two kernels
+                rb = []
+                for _ in range(3):
+                    rt.render_repeat(shifts, 16, download=False)
+                    rb.append(rt.stats().ms_render)
+                out[name]["ms_per_frame_back_to_back"] = statistics.median(rb)
     frame_bytes = dim * dim * 4 + n_spheres * 32
     a = frame_bytes / (out["binned"]["ms_per_frame"] * 1e-3) / 1e9
     out["roofline"] = {"bound": "hbm", "kernel": "k_render<binned>", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,

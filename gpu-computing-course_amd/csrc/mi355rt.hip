@@ -485,32 +485,36 @@ int rt_set_mode(rt_ctx *c, int mode)
     return RT_OK;
 }
 
-int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, int32_t y0, int32_t y1, uint8_t *rgba_out)
+// `frames` > 1: the same frame that many times back to back (rt_render_repeat); time stamps on the first and the last kernel only
+static int render_frames(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, int32_t y0, int32_t y1, uint8_t *rgba_out, int frames)
 {
-    if (!c || (!shifts4 && !c->anim_ready) || y0 < 0 || y1 > c->dim || y0 >= y1 || y0 % TILE || y1 % TILE) return RT_ERR_ARG;
+    if (!c || (!shifts4 && !c->anim_ready) || y0 < 0 || y1 > c->dim || y0 >= y1 || y0 % TILE || y1 % TILE || frames < 1) return RT_ERR_ARG;
     hipStream_t s = c->stream;
     if (shifts4) HIPCHK(hipMemcpyAsync(c->d_shifts, shifts4, sizeof(int32_t) * 4 * (size_t)c->n, hipMemcpyHostToDevice, s));   // NULL: the device-resident animation state
     // (the frame's time stamps ride on the dispatch packets of its first and last kernel: an event record of its own is a
     //  barrier packet, a few idle microseconds each)
     const dim3 grid(c->dim / TILE, (y1 - y0) / TILE), grid_binned(c->dim / TILE, RT_SPLIT * ((y1 - y0) / TILE));   // binned: a workgroup per half tile
     const int ty0 = y0 / TILE, ty1 = y1 / TILE, ntx = c->dim / TILE;
+    for (int f = 0; f < frames; ++f) {
+    hipEvent_t e0 = f == 0 ? c->ev0 : nullptr, e1 = f == frames - 1 ? c->ev1 : nullptr;
     if (c->mode == RT_MODE_BINNED) {
         const int nsx = (c->dim + SUPER - 1) / SUPER;
         int *cur = c->d_counts[c->frame & 1], *nxt = c->d_counts[(c->frame + 1) & 1];
         ++c->frame;
-        hipExtLaunchKernelGGL(k_prepare, dim3((c->n + PREP_THREADS - 1) / PREP_THREADS), dim3(PREP_THREADS), 0u, s, c->ev0, nullptr, 0u,
+        hipExtLaunchKernelGGL(k_prepare, dim3((c->n + PREP_THREADS - 1) / PREP_THREADS), dim3(PREP_THREADS), 0u, s, e0, nullptr, 0u,
                               (const RtSphere *)c->d_spheres, (const int32_t *)c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, (int)csx, (int)csy, nsx, ty0, ty1,
                               c->d_super_list, cur + c->ntiles, c->d_tile_list, cur, nxt, c->n_counts);
-        hipExtLaunchKernelGGL(k_render<true>, grid_binned, dim3(THREADS), 0u, s, nullptr, c->ev1, 0u,
+        hipExtLaunchKernelGGL(k_render<true>, grid_binned, dim3(THREADS), 0u, s, nullptr, e1, 0u,
                               (const SphGeom *)c->d_geom, (const SphShade *)c->d_shade, c->n, c->dim, (int)csx, (int)csy, ty0, c->d_rgba, c->d_tile_tests,
                               (const int *)c->d_super_list, (const int *)(cur + c->ntiles), nsx, (const TileEnt *)c->d_tile_list, (const int *)cur);
     } else {
-        hipExtLaunchKernelGGL(k_prepare, dim3((c->n + PREP_THREADS - 1) / PREP_THREADS), dim3(PREP_THREADS), 0u, s, c->ev0, nullptr, 0u,
+        hipExtLaunchKernelGGL(k_prepare, dim3((c->n + PREP_THREADS - 1) / PREP_THREADS), dim3(PREP_THREADS), 0u, s, e0, nullptr, 0u,
                               (const RtSphere *)c->d_spheres, (const int32_t *)c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, (int)csx, (int)csy, 0, 0, 0,
                               (int *)nullptr, (int *)nullptr, (TileEnt *)nullptr, (int *)nullptr, (int *)nullptr, 0);
-        hipExtLaunchKernelGGL(k_render<false>, grid, dim3(THREADS), 0u, s, nullptr, c->ev1, 0u,
+        hipExtLaunchKernelGGL(k_render<false>, grid, dim3(THREADS), 0u, s, nullptr, e1, 0u,
                               (const SphGeom *)c->d_geom, (const SphShade *)c->d_shade, c->n, c->dim, (int)csx, (int)csy, ty0, c->d_rgba, (uint32_t *)nullptr,
                               (const int *)nullptr, (const int *)nullptr, 0, (const TileEnt *)nullptr, (const int *)nullptr);
+    }
     }
     // from here on an early return must not leave a copy into caller / context memory in flight: synchronise first
     hipError_t e = hipGetLastError();
@@ -526,10 +530,21 @@ int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, 
     if (c->mode == RT_MODE_BINNED) for (size_t i = 0; i < nt; ++i) tests += c->h_tile_tests[t0 + i];
     float ms = 0.f;
     hipEventElapsedTime(&ms, c->ev0, c->ev1);
-    c->stats.ms_render = ms;
+    c->stats.ms_render = ms / (float)frames;
     c->stats.mode = (uint32_t)c->mode;
     c->stats.sphere_tests = c->mode == RT_MODE_BINNED ? tests * (unsigned long long)(TILE * TILE) : (uint64_t)c->n * (uint64_t)c->dim * (uint64_t)(y1 - y0);
     return RT_OK;
+}
+
+int rt_render_rows(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, int32_t y0, int32_t y1, uint8_t *rgba_out)
+{
+    return render_frames(c, shifts4, csx, csy, y0, y1, rgba_out, 1);
+}
+
+int rt_render_repeat(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, int32_t frames, uint8_t *rgba_out)
+{
+    if (!c) return RT_ERR_ARG;
+    return render_frames(c, shifts4, csx, csy, 0, c->dim, rgba_out, frames);
 }
 
 int rt_render(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t csy, uint8_t *rgba_out)

@@ -21,7 +21,7 @@ class RtStats(C.Structure):
     _fields_ = [("ms_render", C.c_float), ("mode", C.c_uint32), ("sphere_tests", C.c_uint64)]
 
 
-EXPORTS = ["rt_create", "rt_destroy", "rt_set_spheres", "rt_set_mode", "rt_render", "rt_render_rows",
+EXPORTS = ["rt_create", "rt_destroy", "rt_set_spheres", "rt_set_mode", "rt_render", "rt_render_rows", "rt_render_repeat",
            "rt_init_shifts", "rt_anim_init", "rt_anim_axis_move", "rt_anim_curve_move", "rt_anim_update_speed_angle",
            "rt_anim_get_state", "rt_get_stats", "rt_version"]
 
@@ -47,6 +47,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.rt_set_mode.argtypes = [vp, C.c_int]
     lib.rt_render.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     lib.rt_render_rows.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
+    lib.rt_render_repeat.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.rt_init_shifts.argtypes = [C.c_int32, vp, vp]
     lib.rt_anim_init.argtypes = [vp]
     lib.rt_anim_axis_move.argtypes = [vp, C.c_int32]
@@ -126,6 +127,15 @@ class RayTracer:
         sh = np.zeros((self.n, 4), dtype=np.int32); ang = np.zeros(self.n, dtype=np.float64); rng = np.zeros((self.n, 6), dtype=np.uint32)
         self._chk("rt_anim_get_state", self.lib.rt_anim_get_state(self._ctx, _ptr(sh), _ptr(ang), _ptr(rng)))
         return sh, ang, rng
+
+    def render_repeat(self, shifts, frames, c_shift_x=0, c_shift_y=0, download=True):
+        """The same frame `frames` times back to back; stats().ms_render is then the device time per frame."""
+        sh = np.ascontiguousarray(shifts, dtype=np.int32).reshape(-1, 4)
+        img = np.zeros((self.dim, self.dim, 4), dtype=np.uint8) if download else None
+        rc = self.lib.rt_render_repeat(self._ctx, _ptr(sh), c_shift_x, c_shift_y, frames, _ptr(img))
+        if rc:
+            raise RtError("rt_render_repeat", rc)
+        return img
 
     def render(self, shifts, c_shift_x=0, c_shift_y=0, rows=None, download=True):
         """shifts=None: render from the device-resident animation state (after anim_init)."""

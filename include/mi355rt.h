@@ -65,6 +65,11 @@ int rt_render_rows(rt_ctx *ctx, const int32_t *shifts4, int32_t c_shift_x, int32
 /* sphere.cuh:50-61 initSpheres, the deterministic part: shifts = {0,0,(i%5+1)*5,(i%2)*2-1}, angles = 0. */
 int rt_init_shifts(int32_t n_spheres, int32_t *shifts4, double *angles);
 
+/* The same frame `frames` times back to back, as a loop that queues frames without a host round trip per frame submits
+ * them (measurement aid: a time stamp costs a few idle microseconds next to the kernel that carries it, and a single frame
+ * carries two).  rt_stats.ms_render = device time per frame, first kernel start to last kernel end / frames. */
+int rt_render_repeat(rt_ctx *ctx, const int32_t *shifts4, int32_t c_shift_x, int32_t c_shift_y, int32_t frames, uint8_t *rgba_out);
+
 /* Device-resident animation state.  After rt_anim_init, rt_render / rt_render_rows accept
  * shifts4 == NULL and read the state the kernels below maintain; generate_frame's frame counters
  * (anime_ray.cu:101-125: camera shake, SPHERE_FRAME_PER_SHAKE, SPHERE_SHAKE_TYPE) stay with the caller.

@@ -92,6 +92,23 @@ def test_row_slabs_compose_the_frame(mode):
     assert np.array_equal(full, oracle.rt_render(spheres, shifts, 512))
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_repeated_frames_equal_the_single_frame(mode):
+    """rt_render_repeat: the same frame several times back to back (time stamps on the first and last kernel only) leaves
+    the same pixels and the same test count as one rt_render; the per-frame time is reported."""
+    spheres, shifts = synth.sphere_scene(200, 512, seed=31)
+    with mi355rt.RayTracer(spheres, 512) as rt:
+        rt.set_mode(mode)
+        one = rt.render(shifts, 2, -1)
+        t1 = rt.stats().sphere_tests
+        many = rt.render_repeat(shifts, 5, 2, -1)
+        st = rt.stats()
+        assert np.array_equal(one, many) and st.sphere_tests == t1 and st.ms_render > 0
+        again = rt.render(shifts, 2, -1)                                     # (the list counters of the next frame were left clean)
+        assert np.array_equal(one, again)
+    assert np.array_equal(one, oracle.rt_render(spheres, shifts, 512, 2, -1))
+
+
 def test_config5_shape_binned_equals_brute_and_oracle_rows():
     """BASELINE config 5 (4096^2, 4096 spheres): binned == brute on the full frame (size-independent
     property), and both equal the oracle on a 64-row slab (the oracle needs ~1 s per 64 rows here)."""

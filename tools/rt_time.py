@@ -13,3 +13,7 @@ with mi355rt.RayTracer(spheres, 4096) as rt:
         for _ in range(20):
             rt.render(shifts, download=False); ms.append(rt.stats().ms_render)
         print(name, "median %.1f us  min %.1f us  tests/frame %d" % (statistics.median(ms) * 1e3, min(ms) * 1e3, rt.stats().sphere_tests))
+        rb = []
+        for _ in range(5):
+            rt.render_repeat(shifts, 16, download=False); rb.append(rt.stats().ms_render)
+        print(name, "16 frames back to back: median %.1f us per frame" % (statistics.median(rb) * 1e3))
