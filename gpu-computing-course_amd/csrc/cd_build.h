@@ -109,15 +109,17 @@ __device__ __forceinline__ double f64_from_ordered(unsigned long long k)
     return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
 }
 
-// One workgroup per 512 consecutive leaves.  Thread t: leaf b0+t (FP64 box from the vertices -> boxes[], fp32 query box ->
-// qbox32[], fp32 leaf of the LDS tree) and internal node b0+t:
-//   1. adjacent deltas of the block as bytes + their min-sparse-table, and the fp32 segment tree, on the same 9 barriers;
-//   2. determineRange / findSplit as nearest-smaller-value / range-minimum-position queries on the table (cd_bvh.h);
-//      a node whose search runs off the block goes on the cross list (k_cross_meta, k_cross_records);
-//   3. ONE range query per node: its own box -> nb[] in LDS; after a barrier its record takes the two child boxes from
-//      nb[] (internal child: children of an in-block node are in-block) or from the tree's leaf level.
+// One workgroup per 512 consecutive leaves.  Thread t: leaf b0+t (FP64 box from the vertices -> boxes[] when it is not
+// exact in fp32, fp32 query box -> qbox32[], fp32 leaf of the LDS tree) and internal node b0+t:
+//   1. adjacent deltas of the block as 16-bit (min, offset) keys + their min-sparse-table, and the fp32 segment tree, on
+//      the same 9 barriers;
+//   2. determineRange as a nearest-smaller-value search on the table (one 10-step descent, either direction), findSplit
+//      as the position of the range minimum (two table reads); a node whose search runs off the block goes on the cross
+//      list (k_cross_meta, k_cross_records);
+//   3. ONE range query per node: its own box -> nb[] in LDS (over the table, which is dead by then); after a barrier its
+//      record takes the two child boxes from nb[] (children of an in-block node are in-block) or from the tree's leaves.
 // Levels >= SEG_MIN_LEVEL of the block's tree go to seg32 (what the cross nodes query), the FP64 box of the block's
-// leaves to seg[nbp2 + b] (k_refit_seg_top folds those into the box of all leaves).
+// leaves to seg[nbp2 + b] (the levels above the blocks fold those into the box of all leaves: cd_bvh.h, top_tree_one_block).
 __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n,
                                                            const uint64_t *__restrict__ keys, int32_t *__restrict__ split_of,
                                                            double *__restrict__ boxes, NodeRec32 *__restrict__ recs32, LeafBox32 *__restrict__ qbox32,
