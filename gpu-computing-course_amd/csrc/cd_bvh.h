@@ -372,39 +372,17 @@ __device__ __forceinline__ Box seg_query_lds(const double (*t)[6], int l, int r)
     return box_merge(accL, accR);
 }
 
-// FUSED (the fused entry points, cd_self_collide / cd_build_tree / cd_multi_step): the kernel also BUILDS the hierarchy of
-// the nodes whose range stays inside its 512 leaves (about 98 % of them) instead of reading it from k_hierarchy's meta[]:
-//   * dl[p] = delta(p, p+1) + 1 for the positions b0-1 .. b0+512 as BYTES in LDS (0 = the out-of-range -1 of bvh.cuh:48);
-//     delta(i, j) of any range is the minimum of the adjacent deltas inside it (sorted keys, index tie-break), and
-//     adjacent deltas that bound a node are pairwise distinct, so determineRange (bvh.cuh:100-123) is a nearest-smaller-
-//     value query and findSplit (bvh.cuh:57-98) the position of the range minimum;
-//   * both are answered from a min-sparse-table over dl (10 levels, 5 KB) with a fixed 10-step descent: every node costs
-//     the same ~22 byte reads, where k_hierarchy's galloping / binary searches over the 64-bit keys in memory make a wave
-//     wait for its widest node (5.7 x the useful probes);
-//   * a node whose search runs off the block goes on the cross list; k_cross_meta then finds its range with the global
-//     searches of k_hierarchy, and k_refit_seg_cross its boxes.  split_of[i] is written for every node (child links).
-// meta[] / parent[] (the reference's tree, what cd_export_tree and the verifier read) are then not written at all:
-// the host materialises them with k_hierarchy when somebody asks (mi355cd.hip).
+// The fused build (cd_build.h) also BUILDS the hierarchy of the nodes whose range stays inside their 512 leaves (about 98 %
+// of them) instead of reading it from k_hierarchy's meta[]: delta(i, j) of any leaf range is the minimum of the adjacent
+// deltas dl[p] = delta(p, p+1) inside it (sorted keys, index tie-break), and adjacent deltas that bound a node are pairwise
+// distinct, so determineRange (bvh.cuh:100-123) is a nearest-smaller-value query on dl and findSplit (bvh.cuh:57-98) the
+// position of the range minimum -- both answered from a min-sparse-table over the block's deltas in LDS, where
+// k_hierarchy's galloping / binary searches over the 64-bit keys in memory make a wave wait for its widest node (5.7 x
+// the useful probes).  meta[] / parent[] (the reference's tree, what cd_export_tree and the verifier read) are then not
+// written at all: the host materialises them with k_hierarchy when somebody asks (mi355cd.hip).
 constexpr int DL_N = REFIT_BLK + 2;             // dl positions b0-1 .. b0+512
 constexpr int DL_LEVELS = 10;                   // 2^9 = 512 < DL_N <= 2^10
 constexpr int DL_STRIDE = 520;
-
-// first p >= s (p < DL_N) with dl[p] < thr, or DL_N; T = the sparse table, T[k][x] = min(dl[x .. x + 2^k - 1])
-__device__ __forceinline__ int nsv_right(const uint8_t (*T)[DL_STRIDE], int s, int thr)
-{
-    int p = s;
-#pragma unroll
-    for (int k = DL_LEVELS - 1; k >= 0; --k) { const int q = p + (1 << k); if (q <= DL_N && (int)T[k][p < DL_N ? p : 0] >= thr) p = q; }
-    return p;
-}
-// last p <= s (p >= 0) with dl[p] < thr, or -1
-__device__ __forceinline__ int psv_left(const uint8_t (*T)[DL_STRIDE], int s, int thr)
-{
-    int p = s;
-#pragma unroll
-    for (int k = DL_LEVELS - 1; k >= 0; --k) { const int q = p - (1 << k); if (q >= -1 && (int)T[k][q + 1 >= 0 ? q + 1 : 0] >= thr) p = q; }
-    return p;
-}
 
 __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n,
                                                                const NodeMeta *__restrict__ meta,
