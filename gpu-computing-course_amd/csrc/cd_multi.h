@@ -159,11 +159,6 @@ int multi_alloc(cd_multi *m)
     return CD_OK;
 }
 
-bool host_boxes_overlap(const double *a, const double *b)      // box.cuh:40-43
-{
-    return (a[0] - b[1]) * (b[0] - a[1]) > 0 && (a[2] - b[3]) * (b[2] - a[3]) > 0 && (a[4] - b[5]) * (b[4] - a[5]) > 0;
-}
-
 }  // namespace
 
 extern "C" {
@@ -446,7 +441,6 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
             else { info->ms_local = -1.f; info->ms_cross = -1.f; }
         }
     }
-    (void)host_boxes_overlap;
     return (rc_l == CD_OVERFLOW || rc_x == CD_OVERFLOW) ? CD_OVERFLOW : CD_OK;
 }
 
