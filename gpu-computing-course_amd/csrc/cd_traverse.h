@@ -872,7 +872,6 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
     }
     __syncthreads();
     const unsigned long long total = pre[NSHARD];
-    const unsigned long long stride = (unsigned long long)gridDim.x * EXACT_THREADS;
     uint32_t tested = 0;
 
     // SAT of one queued survivor; hit -> LDS pair staging (or direct append when the staging area is full)
@@ -901,13 +900,18 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
         }
     };
 
-    for (unsigned long long k0 = (unsigned long long)blockIdx.x * (EXACT_THREADS * EXACT_ITEMS); k0 < total; k0 += stride * EXACT_ITEMS) {   // uniform trip count per workgroup
+    // Chunks of 256 candidates are dealt round-robin over the workgroups, EXACT_ITEMS chunks per workgroup and round: a few
+    // thousand survivors (the usual case: the descent has filtered the rest) spread over as many workgroups as they fill, one
+    // SAT batch each, instead of queueing four batches deep in a few workgroups; a million candidates still give every lane
+    // EXACT_ITEMS independent loads.
+    const unsigned long long nchunks = (total + EXACT_THREADS - 1) / EXACT_THREADS;
+    for (unsigned long long c0 = blockIdx.x; c0 < nchunks; c0 += (unsigned long long)gridDim.x * EXACT_ITEMS) {   // uniform trip count per workgroup
         // stage 1 on EXACT_ITEMS candidates per lane at once: their loads are independent and in flight together
         // (the stage is a chain of two dependent round trips per candidate -- latency, not bandwidth)
         Candidates c[EXACT_ITEMS]; bool ok[EXACT_ITEMS];
 #pragma unroll
         for (int j = 0; j < EXACT_ITEMS; ++j) {
-            const unsigned long long k = k0 + (unsigned long long)j * EXACT_THREADS + tid;
+            const unsigned long long k = (c0 + (unsigned long long)j * gridDim.x) * EXACT_THREADS + tid;
             ok[j] = k < total;
             c[j] = Candidates{0, 0};
             if (ok[j]) {
