@@ -275,7 +275,8 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
     }
     // about 13 cross nodes per 512-leaf block: ~one node per wave, every load chain in flight at once
     // one wave per cross node, about 13 of them per 512-leaf block: two workgroups (8 waves) per block -> 1-2 nodes per wave
-    // (measured: 1024 / 2048 / 4096 / 8192 workgroups at 1 M triangles -> 120 / 113 / 111 / 112 us for the whole stage)
+    // (measured: 1024 / 2048 / 4096 / 8192 workgroups at 1 M triangles -> 120 / 113 / 111 / 112 us for the whole stage with the FP64
+    //  kernels; k_cross_records alone with 2 .. 16 workgroups per block: no difference, 76 us for the stage)
     const uint32_t xblocks = 2u * nblocks < 256u ? 256u : (2u * nblocks > 16384u ? 16384u : 2u * (uint32_t)nblocks);
     if (fused && n > 1) {
         k_cross_meta<<<xblocks, 256, 0, s>>>(c->d_keys[0], (int)n, c->d_meta, c->d_split_of, c->d_cross, cross_count, c->cross_cap,
