@@ -195,6 +195,27 @@ __device__ __forceinline__ void fill_leaf(uint32_t j, uint32_t t, const uint32_t
     if (j < n - 1) { parent[j] = -1; bounded[j] = 0; if (boxes) reinterpret_cast<uint64_t *>(boxes)[6 * (size_t)j] = 0xFFFFFFFFFFFFFFFFull; }
 }
 
+// what k_local_sort's epilogue (cd_sort.h) does with a key's final position: fill that leaf (fill_leaf in two halves:
+// the gather by triangle number does not wait for the position)
+struct LeafFill {
+    const uint32_t *vidx, *ids; uint32_t n; LeafTri *leaf; int32_t *parent; uint32_t *bounded;
+    typedef LeafTri Payload;
+    __device__ __forceinline__ LeafTri load(uint32_t t) const
+    {
+        LeafTri lt;
+        lt.id = ids ? ids[t] : t;
+        lt.v0 = vidx[3 * (size_t)t]; lt.v1 = vidx[3 * (size_t)t + 1]; lt.v2 = vidx[3 * (size_t)t + 2];
+        return lt;
+    }
+    __device__ __forceinline__ void store(uint32_t j, uint32_t, const LeafTri &lt) const
+    {
+        leaf[j] = lt;
+        if (!parent) return;
+        parent[(n - 1) + j] = -1;
+        if (j < n - 1) { parent[j] = -1; bounded[j] = 0; }
+    }
+};
+
 __global__ __launch_bounds__(256) void k_fill_leaves(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ vidx,
                                                      const uint32_t *__restrict__ ids, uint32_t n,
                                                      LeafTri *__restrict__ leaf, int32_t *__restrict__ parent, uint32_t *__restrict__ bounded,

@@ -225,8 +225,9 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
 //   * inside the window: stable LSD passes over digits 4..7 with the same __ballot ranking as k_os_pass, {high key
 //     half, position} held in registers and permuted through LDS; a pass whose digit is the same for the whole
 //     window is skipped; keys and values are gathered once at the end.
-// The result is the stable order by the high 32 bits, exactly what 4 global passes give; k_sort_fixup_fill then places
-// every key by its low half as before, so keys and permutation stay bit-identical to the full 8-pass sort.  A run
+// The result is the stable order by the high 32 bits, exactly what 4 global passes give; the kernel's epilogue then places
+// every key by its low half as k_sort_fixup_fill does after the half-key sort (a run of equal high halves lies inside one
+// window), so keys and permutation stay bit-identical to the full 8-pass sort.  A run
 // longer than LOCAL_LIMIT cannot be windowed: the kernel flags it (same word as the fix-up's overflow) and the host
 // falls back to the 4-pass half-key sort, then to 8 passes.
 // ====================================================================================================
@@ -239,10 +240,12 @@ constexpr int LOCAL_LIMIT   = 6144;                     // longest run that can 
 constexpr int LOCAL_ITEMS   = (LOCAL_W + LOCAL_LIMIT) / LOCAL_THREADS;   // 10 keys per lane
 constexpr int LOCAL_CAP     = LOCAL_ITEMS * LOCAL_THREADS;               // 10240 keys: 80 KB of LDS + 16 KB of counters
 
+__device__ __forceinline__ bool fixup_position_lds(const uint2 *item, uint32_t cnt, uint32_t j, uint32_t low, uint32_t high, uint32_t &pos);
+template <class Emit>
 __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                               uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n,
                                                               int run_shift /* a run = equal key bits [run_shift, 64): what the global passes sorted by */,
-                                                              uint32_t *__restrict__ overflow)
+                                                              uint32_t *__restrict__ overflow, Emit emit /* load(value) -> payload, store(final position, value, payload): what the fix-up hop does per key */)
 {
     __shared__ uint2 sitem[LOCAL_CAP];                   // 80 KB: {high 32 key bits, position inside the window}
     __shared__ uint32_t wcnt[LOCAL_WAVES][RADIX];        // 16 KB
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     const bool found0 = p0 == 0 || e0 != 0xffffffffu, found1 = p1 >= n || e1 != 0xffffffffu;
     if (!found0 || !found1) {                            // a run longer than LOCAL_LIMIT: flag it, pass the nominal range through
         if (tid == 0) atomicExch(overflow, 1u);
-        for (uint32_t i = p0 + tid; i < p1; i += LOCAL_THREADS) { keys_out[i] = keys_in[i]; vals_out[i] = vals_in[i]; }
+        for (uint32_t i = p0 + tid; i < p1; i += LOCAL_THREADS) { const uint32_t t = vals_in[i]; keys_out[i] = keys_in[i]; vals_out[i] = t; emit.store(i, t, emit.load(t)); }
         return;
     }
     const int lo = p0 == 0 ? 0 : (int)((e0 & 1u) ? p0 + (e0 >> 1) : p0 - (e0 >> 1));
@@ -388,10 +391,42 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
         }
         __syncthreads();                                                   // sitem / wcnt are rewritten by the next pass
     }
+    // The window is now in stable order by the high key half.  The fix-up hop (below: every key placed inside its run of
+    // equal high halves by its low half) needs only the run's other keys, and a run lies inside ONE window (equal high
+    // halves have equal top bits): whole keys go to LDS, every item finds its final position there, and the kernel
+    // writes keys, permutation and (emit) the leaf of that position -- no k_sort_fixup_fill launch after it.
+    uint32_t tv[LOCAL_ITEMS];
 #pragma unroll
     for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit) {
         const uint32_t j = base_w + it * 64 + lane;
-        if (j < cnt) { keys_out[lo + j] = keys_in[lo + ix[it]]; vals_out[lo + j] = vals_in[lo + ix[it]]; }
+        if (j < cnt) {
+            const uint64_t k = keys_in[lo + ix[it]];
+            tv[it] = vals_in[lo + ix[it]];
+            sitem[j] = make_uint2((uint32_t)k, kh[it]);
+        }
+    }
+    __syncthreads();
+    // (in chunks of 5 items -- a window of the nominal size has 4 per lane: what emit gathers for an item is requested
+    //  before the LDS search of the chunk, and lands while it runs)
+    constexpr int CH = LOCAL_ITEMS / 2;
+#pragma unroll
+    for (int c0 = 0; c0 < LOCAL_ITEMS; c0 += CH) if (c0 < nit) {
+        typename Emit::Payload pl[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) if (c0 + u < nit && base_w + (c0 + u) * 64 + lane < cnt) pl[u] = emit.load(tv[c0 + u]);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) if (c0 + u < nit) {
+            const int it = c0 + u;
+            const uint32_t j = base_w + it * 64 + lane;
+            if (j < cnt) {
+                const uint32_t low = sitem[j].x;
+                uint32_t pos;
+                // run too long: flag it (the host redoes the sort with 8 passes) but still emit a valid permutation and valid leaves
+                if (!fixup_position_lds(sitem, cnt, j, low, kh[it], pos)) { atomicExch(overflow, 1u); pos = j; }
+                keys_out[lo + pos] = ((uint64_t)kh[it] << 32) | low; vals_out[lo + pos] = tv[it];
+                emit.store(lo + pos, tv[it], pl[u]);
+            }
+        }
     }
 }
 
@@ -435,6 +470,26 @@ __device__ __forceinline__ bool fixup_position(const uint64_t *__restrict__ keys
         }
     }
     pos = i - back + before;
+    return back < (uint32_t)FIX_MAX && fwd < (uint32_t)FIX_MAX;
+}
+
+// The same count over a window held in LDS as {low half, high half} (k_local_sort's epilogue).
+__device__ __forceinline__ bool fixup_position_lds(const uint2 *item, uint32_t cnt, uint32_t j, uint32_t low, uint32_t high, uint32_t &pos)
+{
+    uint32_t back = 0, before = 0, fwd = 0;
+    while (back < (uint32_t)FIX_MAX && back < j) {
+        const uint2 b = item[j - 1 - back];
+        if (b.y != high) break;
+        before += b.x <= low;
+        ++back;
+    }
+    while (fwd < (uint32_t)FIX_MAX && j + 1 + fwd < cnt) {
+        const uint2 f = item[j + 1 + fwd];
+        if (f.y != high) break;
+        before += f.x < low;
+        ++fwd;
+    }
+    pos = j - back + before;
     return back < (uint32_t)FIX_MAX && fwd < (uint32_t)FIX_MAX;
 }
 

@@ -188,7 +188,7 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
     const int down = mode == 0 ? 4 : 0;         // mode 0: the two global digits are key bits 44..51 and 52..59 -- 16 bits that all vary,
                                                 // where bits 48..63 of a 60-bit Morton key hold 12: runs 16 x shorter, windows of even size
     const int first_digit = hybrid ? 6 : (mode == 2 ? 4 : 0);
-    int cur = mode == 2 ? 1 : 0;
+    int cur = mode == 3 ? 0 : 1;
     const uint32_t mblocks = cdiv(n, MORTON_THREADS * 4) < 1024u ? cdiv(n, MORTON_THREADS * 4) : 1024u;
     k_morton<<<mblocks, MORTON_THREADS, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_frame, c->d_keys[cur], c->d_os_hist, first_digit, down, c->d_os_ticket + 16);
     HIPCHK(evrec(c, EV_MORTON1));
@@ -200,11 +200,13 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
                                                     c->d_os_ticket + pass, pass == first_digit);
         cur ^= 1;
     }
-    if (hybrid) {                               // data is in buffer 0 again; windows go 0 -> 1, the fix-up hop 1 -> 0
-        k_local_sort<<<cdiv(n, LOCAL_W), LOCAL_THREADS, 0, s>>>(c->d_keys[0], c->d_perm[0], c->d_keys[1], c->d_perm[1], n, 48 - down, c->d_os_ticket + 16);
-    }
     c->leaves_filled = false; c->leaf_records_filled = false;
-    if (mode != 3) {
+    if (hybrid) {                               // data is in buffer 1 again; windows go 1 -> 0, fix-up hop and leaf fill in the kernel's epilogue
+        const LeafFill fill{c->d_vidx, c->d_ids, n, c->d_leaf, links_too ? c->d_parent : nullptr, links_too ? c->d_bounded : nullptr};
+        k_local_sort<<<cdiv(n, LOCAL_W), LOCAL_THREADS, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, 48 - down, c->d_os_ticket + 16, fill);
+        c->leaves_filled = links_too;
+        c->leaf_records_filled = true;
+    } else if (mode != 3) {
         k_sort_fixup_fill<<<cdiv(n, 256), 256, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, c->d_os_ticket + 16,
                                                        c->d_vidx, c->d_ids, c->d_leaf, links_too ? c->d_parent : nullptr, links_too ? c->d_bounded : nullptr);
         c->leaves_filled = links_too;           // by the fix-up hop; enqueue_hierarchy runs k_fill_leaves otherwise
