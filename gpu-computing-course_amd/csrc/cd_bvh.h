@@ -38,8 +38,9 @@ static_assert(sizeof(NodeRec32) == 64, "NodeRec32 is two 32-byte halves");
 __device__ __forceinline__ const float4 *rec_right(const NodeRec32 *recs, int n, uint32_t s) { return reinterpret_cast<const float4 *>(recs) + 2 * (size_t)s; }
 __device__ __forceinline__ const float4 *rec_left(const NodeRec32 *recs, int n, uint32_t s) { return reinterpret_cast<const float4 *>(recs) + 2 * (size_t)n + 2 * (size_t)s; }
 
-// fp32 query box of leaf j, rounded outward like the records', written by the refit: the descent reads 32 coalesced
-// bytes per query instead of the 48-byte FP64 box.  flags bit 0: the box is exact in fp32; bit 1: the FP64 box strictly
+// fp32 query box of leaf j, rounded outward like the records', written by the refit: 32 coalesced bytes per query
+// instead of the 48-byte FP64 box (k_descend and the packers read it; k_descend_half takes the same box and the same
+// exact bit out of the leaf's parent record, which it reads anyway -- cd_traverse.h).  flags bit 0: the box is exact in fp32; bit 1: the FP64 box strictly
 // overlaps itself (box.cuh:40-43 with a == b -- false for a box that is flat along an axis): the query's hit on its
 // own leaf, which every traversal of the reference meets once (collision.cuh:31-32), is decided here, exactly.
 struct alignas(32) LeafBox32 { float lo[3], hi[3]; uint32_t flags, pad; };

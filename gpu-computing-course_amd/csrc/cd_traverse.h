@@ -574,21 +574,38 @@ __global__ __launch_bounds__(TRAV_THREADS, 8) void k_descend_half(QuerySrc src, 
         if (sptr < HALF_STACK) { lds_stack[sptr][tid] = link; ++sptr; }
         else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)link); }
     };
-    // ---- the query: 32 coalesced bytes per lane (fp32 box rounded outward + flags, written by the refit)
+    // ---- the query box comes out of the RECORDS, not out of qbox[]: leaf j is the left child of recs[j] (then that
+    // record's left link is ~j) or else the right child of recs[j - 1] -- every s is the split of exactly one node
+    // (cd_bvh.h) -- and a leaf child's box in a record is the leaf's own fp32 box with its exact bit.  The lane needs the
+    // right half of recs[j] anyway (phase 1a), the right half of recs[j - 1] is in the neighbour lane, and the left
+    // halves are what phase 2 reads next: 32 bytes per leaf less from HBM than with a separate query array.
+    // The last leaf has no record of its own: it is the right child of recs[n - 2].
     float qlo0, qlo1, qlo2, qhi0, qhi1, qhi2; uint32_t qcertain;
-    {
-        const float4 *qp = reinterpret_cast<const float4 *>(src.qbox + (valid ? qi : 0u));
-        const float4 q0 = qp[0], q1 = qp[1];
-        const uint32_t qfl = __float_as_uint(q1.z);
-        qlo0 = q0.x; qlo1 = q0.y; qlo2 = q0.z; qhi0 = q0.w; qhi1 = q1.x; qhi2 = q1.y;
-        qcertain = (qfl & LB_EXACT) ? CAND_CERTAIN : 0u;
-        if (valid && (qfl & LB_SELF)) ++tested;                               // the query's own leaf (see LeafBox32)
-    }
-    // ---- the right-child half of the lane's own record recs[qi] (the last leaf has none), one coalesced fetch per wave:
-    // phase 1a reads these 8 words of OTHER lanes through the LDS crossbar (ds_bpermute) -- the hops below g_last have
-    // their cursor, a split, inside the wave's own 64 leaves, so they touch neither memory nor LDS storage
     float4 rc = make_float4(0.f, 0.f, 0.f, 0.f), rd = rc;
-    if (valid && qi < last_leaf) { const float4 *rp = rec_right(recs, n, qi); rc = rp[0]; rd = rp[1]; }
+    {
+        float4 la = rc, lb = rc, pc = rc, pd = rc;
+        const bool own = valid && qi < last_leaf;
+        if (own) { const float4 *rp = rec_right(recs, n, qi); rc = rp[0]; rd = rp[1]; const float4 *lp = rec_left(recs, n, qi); la = lp[0]; lb = lp[1]; }
+        {   // the right half of recs[qi - 1]: the neighbour lane's registers (DPP wave_shr:1, a VALU move); lane 0 gets the
+            // record before the wave's first one through the scalar cache (wave-uniform address)
+            int4 e0 = make_int4(0, 0, 0, 0), e1 = e0;
+            if (g0 > 0u && g0 <= last_leaf && n > 1) { const int4 *pp = reinterpret_cast<const int4 *>(rec_right(recs, n, g0 - 1u)); e0 = pp[0]; e1 = pp[1]; }
+            auto shr1 = [](float v, int edge) { return __int_as_float(__builtin_amdgcn_update_dpp(edge, __float_as_int(v), 0x138, 0xf, 0xf, false)); };
+            pc.x = shr1(rc.x, e0.x); pc.y = shr1(rc.y, e0.y); pc.z = shr1(rc.z, e0.z); pc.w = shr1(rc.w, e0.w);
+            pd.x = shr1(rd.x, e1.x); pd.y = shr1(rd.y, e1.y); pd.z = shr1(rd.z, e1.z); pd.w = shr1(rd.w, e1.w);
+        }
+        const bool is_left = own && __float_as_int(lb.z) == (int32_t)~qi;
+        qlo0 = is_left ? la.x : pc.x; qlo1 = is_left ? la.y : pc.y; qlo2 = is_left ? la.z : pc.z;
+        qhi0 = is_left ? la.w : pc.w; qhi1 = is_left ? lb.x : pd.x; qhi2 = is_left ? lb.y : pd.y;
+        const bool exact = is_left ? (__float_as_uint(rd.w) & REC_L_EXACT) != 0u : (__float_as_uint(pd.w) & REC_R_EXACT) != 0u;
+        qcertain = exact ? CAND_CERTAIN : 0u;
+        // the query's own leaf, which every traversal of the reference meets once (collision.cuh:31-32): box.cuh:40-43 with
+        // a == b is (x1 - x2)^2 > 0 per axis -- for a box that is exact in fp32 that is lo != hi (the difference of two
+        // floats squared does not underflow in FP64), otherwise the FP64 box decides (stored for exactly those leaves)
+        bool self = exact & (qlo0 < qhi0) & (qlo1 < qhi1) & (qlo2 < qhi2);
+        if (valid && !exact) { const Box b = load_box(src.boxes, (n - 1) + (int)qi); self = box_overlap(b, b); }
+        if (valid && self) ++tested;
+    }
     if (diag) tm1 = __builtin_amdgcn_s_memtime();
     // ---- phase 1a: hops below g_last
     uint32_t s = valid ? qi : END;                                            // cursor; >= g_last: joined the shared chain (or has none: g_last == n-1)
