@@ -120,12 +120,26 @@ __device__ __forceinline__ double f64_from_ordered(unsigned long long k)
 //      record takes the two child boxes from nb[] (children of an in-block node are in-block) or from the tree's leaves.
 // Levels >= SEG_MIN_LEVEL of the block's tree go to seg32 (what the cross nodes query), the FP64 box of the block's
 // leaves to seg[nbp2 + b] (the levels above the blocks fold those into the box of all leaves: cd_bvh.h, top_tree_one_block).
+// A fused step zeroes its scratch inside its own kernels instead of with a memset in front of the pipeline (a launch and
+// ~3 us of idle GPU per step): the sort's histograms, tickets and look-back granules are dead once the sort is done, so
+// k_build_block clears them for the NEXT step (the sort flags are not touched: a non-zero flag makes the host redo the
+// step, with a memset), and the traversal counters for THIS step.  All pointers null: nothing to do.
+struct ZeroPlan { uint32_t *w0; uint32_t nw0; uint4 *q; uint32_t nq; uint32_t *w1; uint32_t nw1; };
+
 __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n,
                                                            const uint64_t *__restrict__ keys, int32_t *__restrict__ split_of,
                                                            double *__restrict__ boxes, NodeRec32 *__restrict__ recs32, LeafBox32 *__restrict__ qbox32,
                                                            int32_t *__restrict__ root_name, double *__restrict__ seg, float *__restrict__ seg32, int nbp2,
-                                                           int32_t *__restrict__ cross_list, uint32_t *__restrict__ cross_count, uint32_t cross_cap)
+                                                           int32_t *__restrict__ cross_list, uint32_t *__restrict__ cross_count, uint32_t cross_cap, ZeroPlan zp)
 {
+    {
+        const uint32_t G = gridDim.x * REFIT_BLK;
+        for (uint32_t x = blockIdx.x * REFIT_BLK + threadIdx.x; x < zp.nq; x += G) zp.q[x] = make_uint4(0u, 0u, 0u, 0u);
+        if (blockIdx.x == gridDim.x - 1) {
+            for (uint32_t x = threadIdx.x; x < zp.nw0; x += REFIT_BLK) zp.w0[x] = 0u;
+            for (uint32_t x = threadIdx.x; x < zp.nw1; x += REFIT_BLK) zp.w1[x] = 0u;
+        }
+    }
     __shared__ float t[2 * REFIT_BLK][6];           // 24 KB
     // the sparse table of the deltas (10 KB) is dead once every node knows its range and split; the nodes' own boxes
     // (12 KB) then take its place

@@ -245,8 +245,10 @@ template <class Emit>
 __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                               uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n,
                                                               int run_shift /* a run = equal key bits [run_shift, 64): what the global passes sorted by */,
-                                                              uint32_t *__restrict__ overflow, Emit emit /* load(value) -> payload, store(final position, value, payload): what the fix-up hop does per key */)
+                                                              uint32_t *__restrict__ overflow, Emit emit /* load(value) -> payload, store(final position, value, payload): what the fix-up hop does per key */,
+                                                              uint32_t *__restrict__ zero_words /* fused step: counters of the kernels that follow, zeroed here instead of by a memset */, uint32_t n_zero)
 {
+    if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < n_zero; i += LOCAL_THREADS) zero_words[i] = 0u;
     __shared__ uint2 sitem[LOCAL_CAP];                   // 80 KB: {high 32 key bits, position inside the window}
     __shared__ uint32_t wcnt[LOCAL_WAVES][RADIX];        // 16 KB
     __shared__ uint32_t s_wsum[RADIX / 64];

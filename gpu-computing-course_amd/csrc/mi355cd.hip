@@ -93,6 +93,7 @@ struct cd_ctx {
     bool leaves_filled = false;             // the sort's fix-up hop already wrote leaf[], parent = -1, bounded = 0
     bool events_ride = false;               // the last pass recorded EV_TRAV0 / EV_DESC1 / EV_TRAV1 through its kernels' dispatch packets
     bool prezeroed = false;                 // fused path: the scratch block was zeroed by one memset at pipeline start
+    bool scratch_clean = false;             // ... or by the kernels of the previous fused step (ZeroPlan, cd_build.h): no memset at all
     bool quiet_pass = false;                // launch_pass records no events (a pass on another stream, beside the one whose times are reported)
     int sort_mode = 0;                      // 0 hybrid on key bits 44..59 (every in-frame Morton key is below 2^60), 1 hybrid on bits 48..63 (2 global passes + in-LDS sort of the windows + fix-up), 2 half-key (4 passes + fix-up),
                                             // 2 full (8 passes); forced by CD_OPT_SORT_FULL, or escalated after an overflow on this context
@@ -179,7 +180,12 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
     }
     // fused pipeline: the sort scratch, the small counters and the traversal state are one block, zeroed once here
     // (the hybrid forms use the digit passes 6 and 7 only: their granules sit in the front part of the block, with the counters)
-    HIPCHK(hipMemsetAsync(c->d_os, 0, c->sort_mode <= 1 ? (c->prezeroed ? c->zero_bytes : c->sort_hi_bytes) : c->os_bytes, s));
+    // ... unless the previous fused step's own kernels have left the sort scratch zeroed and this step's kernels zero
+    // the rest (k_local_sort: the small counters, k_build_block: the traversal counters; ZeroPlan, cd_build.h)
+    const bool self_cleaning = c->prezeroed && c->sort_mode <= 1 && fused_build_next(c);
+    const bool skip_memset = self_cleaning && c->scratch_clean;
+    c->scratch_clean = false;
+    if (!skip_memset) HIPCHK(hipMemsetAsync(c->d_os, 0, c->sort_mode <= 1 ? (c->prezeroed ? c->zero_bytes : c->sort_hi_bytes) : c->os_bytes, s));
     // Three forms of the same stable 64-bit sort (cd_sort.h): hybrid = 2 global passes on the top 16 bits + an in-LDS
     // sort of run-aligned windows + the fix-up hop; half-key = 4 global passes on the high 32 bits + the fix-up hop;
     // full = 8 global passes.  The keys start in the buffer that leaves the sorted data in buffer 0.
@@ -203,7 +209,8 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
     c->leaves_filled = false; c->leaf_records_filled = false;
     if (hybrid) {                               // data is in buffer 1 again; windows go 1 -> 0, fix-up hop and leaf fill in the kernel's epilogue
         const LeafFill fill{c->d_vidx, c->d_ids, n, c->d_leaf, links_too ? c->d_parent : nullptr, links_too ? c->d_bounded : nullptr};
-        k_local_sort<<<cdiv(n, LOCAL_W), LOCAL_THREADS, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, 48 - down, c->d_os_ticket + 16, fill);
+        k_local_sort<<<cdiv(n, LOCAL_W), LOCAL_THREADS, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, 48 - down, c->d_os_ticket + 16, fill,
+                                                                self_cleaning ? c->d_small : nullptr, self_cleaning ? 128u : 0u);
         c->leaves_filled = links_too;
         c->leaf_records_filled = true;
     } else if (mode != 3) {
@@ -255,10 +262,19 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         c->hierarchy_valid = false;
         // (its time stamps ride on its own dispatch packet: this is the largest kernel of the step, bench.py prices it)
         const bool stamp = (c->stamp_mask & 1u) != 0;
+        const bool self_cleaning = c->prezeroed && c->sort_mode <= 1;
+        ZeroPlan zp{nullptr, 0u, nullptr, 0u, nullptr, 0u};
+        if (self_cleaning) {
+            const size_t gran = sizeof(unsigned long long) * (size_t)c->ntiles * RADIX;
+            zp = ZeroPlan{c->d_os_hist, 8u * RADIX + 8u /* histograms + tickets; the flags behind them stay */,
+                          reinterpret_cast<uint4 *>(c->d_os_look), (uint32_t)(2 * gran / sizeof(uint4)),
+                          reinterpret_cast<uint32_t *>(c->tb[0].d_state), (uint32_t)(sizeof(TravState) / sizeof(uint32_t))};
+        }
         hipExtLaunchKernelGGL(k_build_block, dim3(nblocks), dim3(REFIT_BLK), 0u, s, stamp ? c->ev[EV_BLK0] : nullptr, stamp ? c->ev[EV_BLK1] : nullptr, 0u,
                               (const double *)c->d_verts, (const LeafTri *)c->d_leaf, (int)n, (const uint64_t *)c->d_keys[0], c->d_split_of,
                               c->d_boxes, c->d_recs32, c->d_qbox, c->d_root, c->d_seg, c->d_seg32, (int)c->nbp2,
-                              cross_list, cross_count, c->cross_cap);
+                              cross_list, cross_count, c->cross_cap, zp);
+        c->scratch_clean = self_cleaning;       // (judge_sort_flags takes it back when the sort has raised a flag)
     } else
         k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded,
                                                        c->d_recs32, c->d_qbox, c->d_root, write_internal ? 1 : 0, c->d_seg, (int)c->nbp2,
@@ -644,6 +660,7 @@ int cd_set_morton_frame(cd_ctx *c, int mode, const double offset[3], const doubl
 constexpr int SORT_REDO = 77;                   // internal: a run was too long for this form of the sort, redo with the next one
 static int judge_sort_flags(cd_ctx *c)
 {
+    for (int i = 0; i < 9; ++i) if (c->sort_flags[i]) c->scratch_clean = false;     // the flag words are cleared by the memset only
     for (int i = 0; i < 8; ++i) if (c->sort_flags[i]) return CD_ERR_SORT;
     if (c->sort_flags[8]) { if (c->sort_mode >= 3) return CD_ERR_SORT; ++c->sort_mode; return SORT_REDO; }
     return CD_OK;

@@ -347,6 +347,47 @@ def test_update_vertices_rebuilds():
         assert np.array_equal(oracle.pair_set(p2), oracle.pair_set(p0))
 
 
+def test_steady_state_steps_clean_their_own_scratch():
+    """From the second fused step on there is no memset in front of the pipeline: the sort scratch is left zeroed by the
+    previous step's k_build_block, the small counters / traversal counters are zeroed by this step's own kernels
+    (ZeroPlan, cd_build.h).  Whatever happens between two steps -- other vertices, stage-wise calls, the brute-force
+    checker, another traversal variant, a sort that raises a flag and is redone -- every step must give the oracle's
+    pairs and its pairs-tested count."""
+    va, ta = synth.soup(60_000, 0.03, 77)
+    vb = va + np.random.default_rng(3).normal(0.0, 0.004, va.shape)
+    ra, rb = oracle.pipeline(va, ta), oracle.pipeline(vb, ta)
+    vo = va + np.array([2.5, 0.0, 0.0])                                    # half of the centroids outside the reference's Morton frame
+    ro = oracle.pipeline(vo, ta)
+
+    def step(cd, r):
+        pairs, n, rc = cd.self_collide(cap=1 << 20)
+        assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+        assert cd.stats().pairs_tested == r["stats"].pairs_tested
+
+    with mi355cd.CollisionDetector(va, ta) as cd:
+        for _ in range(3): step(cd, ra)
+        cd.update_vertices(vb)
+        for _ in range(2): step(cd, rb)
+        cd.morton_sort(); cd.build_hierarchy(); cd.refit_boxes()           # stage-wise calls dirty the scratch their own way
+        pairs, n, rc = cd.find_collisions(cap=1 << 20)
+        assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(rb["pairs"]))
+        for _ in range(2): step(cd, rb)
+        bf, nbf, _ = cd.brute_force(True, cap=1 << 20)
+        assert np.array_equal(oracle.pair_set(bf), oracle.pair_set(rb["pairs"]))
+        step(cd, rb)
+        for variant in (0, 2, 1, 3):
+            cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
+            step(cd, rb); step(cd, rb)
+        cd.update_vertices(vo)                                             # k_morton raises the flag, the step is redone with the other digits
+        for _ in range(3): step(cd, ro)
+        cd.update_vertices(va)
+        for _ in range(2): step(cd, ra)
+        cd.build_tree()                                                    # the fused build alone, then a traversal of its own
+        pairs, n, rc = cd.find_collisions(cap=1 << 20)
+        assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(ra["pairs"]))
+        step(cd, ra)
+
+
 def test_cd_main_harness_on_generated_obj(tmp_path):
     """BASELINE config 1, plumbing: the C++ harness (main.cu twin) on a generated OBJ in the reference's dialect."""
     text = synth.grids_obj_text(32)
