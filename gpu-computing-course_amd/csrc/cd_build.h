@@ -118,7 +118,7 @@ __device__ __forceinline__ double f64_from_ordered(unsigned long long k)
 //      list (k_cross_meta, k_cross_records);
 //   3. ONE range query per node: its own box -> nb[] in LDS (over the table, which is dead by then); after a barrier its
 //      record takes the two child boxes from nb[] (children of an in-block node are in-block) or from the tree's leaves.
-// Levels >= SEG_MIN_LEVEL of the block's tree go to seg32 (what the cross nodes query), the FP64 box of the block's
+// Levels >= SEG32_MIN_LEVEL of the block's tree go to seg32 (what the cross nodes query), the FP64 box of the block's
 // leaves to seg[nbp2 + b] (the levels above the blocks fold those into the box of all leaves: cd_bvh.h, top_tree_one_block).
 // A fused step zeroes its scratch inside its own kernels instead of with a memset in front of the pipeline (a launch and
 // ~3 us of idle GPU per step): the sort's histograms, tickets and look-back granules are dead once the sort is done, so
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
             const int k = cnt + tid;
             const B32 m = b32_merge(b32_load(t[2 * k]), b32_load(t[2 * k + 1]));
             b32_store(t[k], m);
-            if (REFIT_LOG - dd >= SEG_MIN_LEVEL) b32_store(seg32 + 6 * ((((size_t)nbp2 + b) << dd) + tid), m);
+            if (REFIT_LOG - dd >= SEG32_MIN_LEVEL) b32_store(seg32 + 6 * ((((size_t)nbp2 + b) << dd) + tid), m);
         }
     }
     __syncthreads();
@@ -279,13 +279,13 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
 }
 
 // Box of heap node k at level p (2^p leaves) for the cross nodes' queries: the leaves' fp32 boxes (levels below
-// SEG_MIN_LEVEL are rebuilt from 1, 2 or 4 of them), the blocks' fp32 trees (seg32), above the blocks the FP64 boxes of
+// SEG32_MIN_LEVEL are rebuilt from them), the blocks' fp32 trees (seg32), above the blocks the FP64 boxes of
 // k_refit_seg_top rounded outward.
 __device__ __forceinline__ B32 seg_piece32(const double *__restrict__ seg, const float *__restrict__ seg32, const LeafBox32 *__restrict__ qbox32,
                                            int n, long long P, long long k, int p)
 {
     if (p > REFIT_LOG) return b32_of(load_box(seg, (int)k));
-    if (p >= SEG_MIN_LEVEL) return b32_load(seg32 + 6 * (size_t)k);
+    if (p >= SEG32_MIN_LEVEL) return b32_load(seg32 + 6 * (size_t)k);
     const long long j0 = (k << p) - P;
     B32 x = b32_identity();
     for (int u = 0; u < (1 << p); ++u) { const long long jj = j0 + u; if (jj < n) x = b32_merge(x, b32_of_leaf(qbox32, (int)jj)); }
@@ -381,6 +381,218 @@ __global__ __launch_bounds__(256) void k_cross_records(int n, const NodeMeta *__
             const int32_t lb = child_link(meta, split_of, m.y, n - 1);
             float4 *pr = const_cast<float4 *>(rec_right(recs32, n, (uint32_t)split));
             pr[0] = make_float4(x.lx, x.ly, x.lz, x.hx); pr[1] = make_float4(x.hy, x.hz, __int_as_float(lb), __uint_as_float((uint32_t)last | fl));
+        }
+    }
+}
+
+// ====================================================================================================
+// k_cross_meta + k_cross_records in ONE launch, for trees of up to TOP_IN_BLOCK blocks.  Two things tied those kernels to
+// separate launches, and both can be had without a kernel boundary:
+//   * the levels above the blocks, which the range queries read and which block 0 of k_cross_meta builds: every
+//     workgroup folds the (at most 2048) fp32 block boxes into its own copy of those levels in LDS -- 24 bytes per
+//     block, a microsecond, no waiting for anyone (rounding outward is monotone: the fold of the rounded block boxes
+//     is the rounded fold);
+//   * the link to a cross child, which is the CHILD's split (records are named by split, cd_bvh.h) and so was read
+//     from split_of[] after k_cross_meta had finished: here the child WRITES its name into its parent's record.  The
+//     parent needs no search -- a node covering [first, last] is the left child of the record named `last` when
+//     delta(last, last + 1) > delta(first - 1, first) and the right child of the record named first - 1 otherwise (the
+//     range grows towards the neighbour it shares more key bits with) -- and a cross node's parent is a cross node.
+//     The record's owner writes every other word of the two halves; in-block children and leaves are linked by the
+//     owner as before (split_of[] of k_build_block, ~leaf).
+// A group of 16 lanes finds range and split of a node as in k_cross_meta (four nodes per wave); the wave then answers
+// the two range queries of each of its four nodes as k_cross_records does, all their loads in flight together.
+// Workgroup 0 also folds the FP64 block boxes (in order) into the box of all leaves, boxes[0].
+// ====================================================================================================
+// The levels from two above the blocks upwards as a private copy in LDS (top[6 * k]: heap node k in [1, nbp2 / 2)), folded
+// from the blocks' fp32 boxes: a thread folds the four blocks under one or two nodes of the lowest stored level, the
+// lanes of a wave fold with shuffles, the four wave results meet in LDS -- two barriers instead of one per level.  (The
+// level directly above the blocks is not stored: a piece of it is two block boxes away, and LDS is what limits how many
+// workgroups, i.e. how many searches, a CU holds.)
+__device__ __forceinline__ B32 block_box32(const float *__restrict__ seg32, int nbp2, int nblocks, int b)
+{
+    return b < nblocks ? b32_load(seg32 + 6 * ((size_t)nbp2 + b)) : b32_identity();
+}
+__device__ __forceinline__ void top32_to_lds(float *top, const float *__restrict__ seg32, int nbp2, int nblocks)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int M = nbp2 >> 2;                                                // nodes of the lowest stored level, M .. 2 M - 1
+    if (M >= 1) {                                                           // (workgroup-uniform)
+        const int T = M < 256 ? M : 256;                                    // threads that own nodes
+        const int per = M / T;                                              // 1 or 2 (nbp2 <= 2048)
+        B32 x = b32_identity();
+        if (tid < T) {
+            for (int u = 0; u < per; ++u) {
+                const int node = M + tid * per + u, b = 4 * (tid * per + u);
+                // four consecutive block boxes are 96 contiguous bytes, 16-byte aligned (nbp2 is a multiple of 4 here): six quads
+                const float4 *q = reinterpret_cast<const float4 *>(seg32 + 6 * ((size_t)nbp2 + b));
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+                const B32 id = b32_identity();
+                const B32 b0 = b < nblocks ? B32{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y} : id, b1 = b + 1 < nblocks ? B32{q1.z, q1.w, q2.x, q2.y, q2.z, q2.w} : id;
+                const B32 b2 = b + 2 < nblocks ? B32{q3.x, q3.y, q3.z, q3.w, q4.x, q4.y} : id, b3 = b + 3 < nblocks ? B32{q4.z, q4.w, q5.x, q5.y, q5.z, q5.w} : id;
+                const B32 v = b32_merge(b32_merge(b0, b1), b32_merge(b2, b3));
+                b32_store(top + 6 * node, v);
+                x = b32_merge(x, v);
+            }
+            if (per == 2) b32_store(top + 6 * ((M >> 1) + tid), x);
+        }
+        const int kt = M / per + tid;                                       // the node x is the box of
+        // across lanes: after the step with stride s, lanes that are multiples of 2s hold node kt / (2s)
+        for (int s = 1; s < 64 && s < T; s <<= 1) {
+            x = b32_merge(x, b32_shfl_down(x, s));
+            if (tid < T && (lane & (2 * s - 1)) == 0) b32_store(top + 6 * (kt / (2 * s)), x);
+        }
+        __syncthreads();
+        if (T > 64 && tid == 0) {                                           // the T / 64 = 2 or 4 wave results are the heap nodes T / 64 .. 2 T / 64 - 1
+            const int kw = T / 64;
+            if (T == 128) b32_store(top + 6, b32_merge(b32_load(top + 6 * 2), b32_load(top + 6 * 3)));
+            else {
+                const B32 l = b32_merge(b32_load(top + 6 * kw), b32_load(top + 6 * (kw + 1))), r = b32_merge(b32_load(top + 6 * (kw + 2)), b32_load(top + 6 * (kw + 3)));
+                b32_store(top + 6 * 2, l); b32_store(top + 6 * 3, r); b32_store(top + 6, b32_merge(l, r));
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// The FP64 box of all leaves from the blocks' FP64 boxes, by one workgroup, ties in order (lower block = LEFT operand of
+// box.cuh:24-32's compare-select: a fold of any shape that keeps the operand order gives the same bits).
+__device__ __forceinline__ void root_box_fold(const double *__restrict__ seg, int nbp2, int nblocks, double *__restrict__ out)
+{
+    __shared__ double wbox[4][6];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int T = nbp2 < 256 ? nbp2 : 256, per = nbp2 / T;
+    Box x = box_identity();
+    if (tid < T)
+        for (int u = 0; u < per; ++u) { const int b = tid * per + u; if (b < nblocks) x = box_merge(x, load_box(seg, nbp2 + b)); }
+    for (int s = 1; s < 64 && s < T; s <<= 1) x = box_merge(x, box_shfl_down(x, s));
+    if (lane == 0) { double *d = wbox[w]; d[0] = x.x1; d[1] = x.x2; d[2] = x.y1; d[3] = x.y2; d[4] = x.z1; d[5] = x.z2; }
+    __syncthreads();
+    if (tid == 0) {
+        auto wb = [&](int k) { return Box{wbox[k][0], wbox[k][1], wbox[k][2], wbox[k][3], wbox[k][4], wbox[k][5]}; };
+        Box r = wb(0);
+        for (int k = 1; k < (T + 63) / 64; ++k) r = box_merge(r, wb(k));
+        store_box(out, 0, r);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restrict__ keys, int n, const double *__restrict__ seg, const float *__restrict__ seg32,
+                                                     int nbp2, int nblocks, const LeafBox32 *__restrict__ qbox32, double *__restrict__ boxes,
+                                                     NodeRec32 *__restrict__ recs32, const int32_t *__restrict__ split_of, int32_t *__restrict__ root_name,
+                                                     const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap)
+{
+    extern __shared__ float top[];                                          // [max(nbp2 / 2, 1)][6]: heap nodes [1, nbp2 / 2)
+    const int tid = threadIdx.x, lane = tid & 63, g = lane / XG, gl = lane % XG;
+    // (a workgroup of its own, the last one of the grid: the fold is a chain of dependent loads, short against what the
+    //  others do, long when it comes on top of it)
+    if (blockIdx.x == gridDim.x - 1) { root_box_fold(seg, nbp2, nblocks, boxes); return; }   // (workgroup-uniform)
+    constexpr int PER_WAVE = 64 / XG, PER_BLOCK = 256 / XG;
+    const uint32_t total = min(*dense_total, dense_cap);
+    const long long P = (long long)nbp2 * REFIT_BLK;
+    // (the upper levels first: while the waves of a workgroup are still in step, so that its two barriers cost nothing)
+    top32_to_lds(top, seg32, nbp2, nblocks);
+    for (uint32_t wbase = blockIdx.x * PER_BLOCK + (tid >> 6) * PER_WAVE; wbase < total; wbase += (gridDim.x - 1) * PER_BLOCK) {   // (wbase is wave-uniform)
+        // ---- range and split, as k_cross_meta
+        const uint32_t kq = wbase + g;
+        const bool live = kq < total;
+        int first = 0, last = 0, split = 0;
+        {
+            const int i = live ? dense[kq] : 0;
+            const uint64_t ki = keys[i];
+            const int d = (delta_k(keys, n, i, ki, i + 1) - delta_k(keys, n, i, ki, i - 1)) >= 0 ? 1 : -1;
+            const int delta_min = delta_k(keys, n, i, ki, i - d);
+            int mlen = 0;
+            for (int r = 0; r < 2; ++r) {
+                const bool todo = live && mlen == 0;
+                if (!__builtin_amdgcn_ballot_w64(todo)) break;              // (wave-uniform)
+                const int e = r * XG + gl;                                  // exponent - 1
+                const long long o = (long long)i + (long long)d * (2ll << (e < 31 ? e : 31));
+                const bool yes = todo && e < 31 && o >= 0 && o < n && delta_k(keys, n, i, ki, (int)o) > delta_min;
+                const uint32_t no = ~group_ballot(yes, g) & ((1u << XG) - 1u);
+                if (todo && no) mlen = 2 << (r * XG + __ffs((int)no) - 1);
+            }
+            const int l = group_last_true(live, mlen >> 1, mlen, g, gl, [&](int x) { return delta_k(keys, n, i, ki, i + x * d) > delta_min; });
+            const int j = i + l * d;
+            first = min(i, j); last = max(i, j);
+            const uint64_t kf = keys[first], kl = keys[last];
+            const int common = delta_k(keys, n, first, kf, last);
+            split = group_last_true(live, first, last, g, gl, [&](int x) { return delta_k(keys, n, first, kf, x) > common; });
+            // ---- the node's name goes into its parent's record (the root has none: its name is the tree's entry point)
+            if (live && gl == 0) {
+                if (first == 0 && last == n - 1) *root_name = split;
+                else {
+                    const int dl = delta_k(keys, n, first, kf, first - 1), dr = delta_k(keys, n, last, kl, last + 1);   // -1 past the ends
+                    uint32_t *half = reinterpret_cast<uint32_t *>(const_cast<float4 *>(dr > dl ? rec_left(recs32, n, (uint32_t)last) : rec_right(recs32, n, (uint32_t)(first - 1))));
+                    half[6] = (uint32_t)split;                              // the link word of that half
+                }
+            }
+        }
+        // (what the record's owner has to fetch besides the boxes: requested before the pieces, used after them)
+        const bool leafL = split == first, leafR = split + 1 == last;
+        // a child that is itself a cross node (its range leaves its 512-leaf block: exactly k_build_block's test) links itself
+        const bool crossL = !leafL && first / REFIT_BLK != split / REFIT_BLK, crossR = !leafR && (split + 1) / REFIT_BLK != last / REFIT_BLK;
+        uint32_t fl = 0; int32_t linkL = ~split, linkR = ~(split + 1);
+        if (live && gl == 0) {
+            if (leafL) { if (qbox32[first].flags & LB_EXACT) fl |= REC_L_EXACT; } else if (!crossL) linkL = split_of[split];
+            if (leafR) { if (qbox32[last].flags & LB_EXACT) fl |= REC_R_EXACT; } else if (!crossR) linkR = split_of[split + 1];
+        }
+        // ---- the records: each group answers the two range queries of its own node.  Lane gl takes the (at most two) pieces
+        // of level gl of either range -- 16 levels cover every range shorter than 65536 leaves, a longer one takes a second
+        // sweep over the levels 16..31 -- so a lane's pieces are all of ONE kind (leaves / a stored level of a block's tree /
+        // two block boxes / the LDS copy of the upper levels): its loads go out together, unconditionally (a piece that
+        // is not taken reads a valid dummy and is dropped), then the 16 lanes fold with DPP row shifts.
+        const int sweeps = __builtin_amdgcn_ballot_w64(live && last - first >= 65535) ? 2 : 1;   // (wave-uniform)
+        B32 accL = b32_identity(), accR = b32_identity();
+        for (int sw = 0; sw < sweeps; ++sw) {
+            const int p = gl + 16 * sw;
+            long long kk[4]; bool tk[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int l0 = h ? split + 1 : first, r0 = h ? last : split;
+                const long long lp = ((long long)l0 + P + ((1ll << p) - 1)) >> p;   // l at level p (ceil)
+                const long long rp = ((long long)r0 + P + 1) >> p;          // r at level p (floor), half-open
+                const bool any = live && lp < rp;
+                tk[2 * h] = any && (lp & 1); tk[2 * h + 1] = any && (rp & 1);
+                kk[2 * h] = lp; kk[2 * h + 1] = rp - 1;
+            }
+            B32 v[4];
+            if (p > REFIT_LOG + 1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = tk[u] ? b32_load(top + 6 * (int)kk[u]) : b32_identity();
+            } else if (p == REFIT_LOG + 1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int b = tk[u] ? (int)(2 * kk[u] - nbp2) : 0;
+                    v[u] = b32_merge(block_box32(seg32, nbp2, nblocks, b), block_box32(seg32, nbp2, nblocks, b + 1));
+                }
+            } else if (p >= SEG32_MIN_LEVEL) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = b32_load(seg32 + 6 * (size_t)(tk[u] ? kk[u] : (P >> p)));
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long j0 = tk[u] ? (kk[u] << p) - P : 0;
+                    v[u] = b32_identity();
+#pragma unroll
+                    for (int e = 0; e < (1 << (SEG32_MIN_LEVEL > 0 ? SEG32_MIN_LEVEL - 1 : 0)); ++e) {     // (all of a lane's leaf loads go out together)
+                        const long long jj = j0 + e;
+                        const B32 lf = b32_of_leaf(qbox32, (int)(jj < n ? jj : n - 1));
+                        if (e < (1 << p) && jj < n) v[u] = b32_merge(v[u], lf);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (tk[u]) { if (u < 2) accL = b32_merge(accL, v[u]); else accR = b32_merge(accR, v[u]); }
+        }
+        accL = dpp_step32<0x101>(accL); accL = dpp_step32<0x102>(accL); accL = dpp_step32<0x104>(accL); accL = dpp_step32<0x108>(accL);
+        accR = dpp_step32<0x101>(accR); accR = dpp_step32<0x102>(accR); accR = dpp_step32<0x104>(accR); accR = dpp_step32<0x108>(accR);
+        if (live && gl == 0) {
+            float4 *pl = const_cast<float4 *>(rec_left(recs32, n, (uint32_t)split)), *pr = const_cast<float4 *>(rec_right(recs32, n, (uint32_t)split));
+            pl[0] = make_float4(accL.lx, accL.ly, accL.lz, accL.hx);
+            pr[0] = make_float4(accR.lx, accR.ly, accR.lz, accR.hx);
+            if (crossL) { reinterpret_cast<float2 *>(pl + 1)[0] = make_float2(accL.hy, accL.hz); reinterpret_cast<uint32_t *>(pl + 1)[3] = (uint32_t)first; }
+            else pl[1] = make_float4(accL.hy, accL.hz, __int_as_float(linkL), __uint_as_float((uint32_t)first));
+            if (crossR) { reinterpret_cast<float2 *>(pr + 1)[0] = make_float2(accR.hy, accR.hz); reinterpret_cast<uint32_t *>(pr + 1)[3] = (uint32_t)last | fl; }
+            else pr[1] = make_float4(accR.hy, accR.hz, __int_as_float(linkR), __uint_as_float((uint32_t)last | fl));
         }
     }
 }

@@ -360,6 +360,11 @@ __device__ __forceinline__ int32_t child_link(const NodeMeta *__restrict__ meta,
 constexpr int REFIT_BLK = 512;     // leaves per workgroup
 constexpr int REFIT_LOG = 9;
 constexpr int SEG_MIN_LEVEL = 3;   // lowest level of the segment tree that is stored in memory (see seg_piece)
+#ifndef SEG32_MIN
+#define SEG32_MIN 1
+#endif
+constexpr int SEG32_MIN_LEVEL = SEG32_MIN;   // the same for the fp32 trees of the fused build (seg32): its lower levels are 24 bytes a node, and every level
+                                     // that is not stored is a dependent gather of 2^level leaf boxes on the cross nodes' critical path
 
 __device__ __forceinline__ Box box_identity()
 {

@@ -77,6 +77,7 @@ struct cd_ctx {
     bool hierarchy_valid = false;           // meta[] / parent[] hold the tree of the current keys (fused calls build the records without them)
     bool last_tree_fused = false;           // the last fused call built hierarchy + refit in one pass (ms_hierarchy is then part of ms_refit)
     uint32_t stamp_mask = 15;               // CD_OPT_KERNEL_STAMPS: with stage timing off, which time stamps a fused call still takes (1 block build, 2 descent, 4 exact, 8 pipeline start): ~5 us of idle GPU each
+    uint32_t dbg_split_cross = 0;           // debug key 105: the fused build runs k_cross_meta + k_cross_records instead of k_cross_fused (A/B, tests)
     uint32_t dbg_no_fused_build = 0;        // debug key 104: fused entry points run k_hierarchy + the meta-reading refit (A/B)
     uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
     // traversal
@@ -279,6 +280,16 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded,
                                                        c->d_recs32, c->d_qbox, c->d_root, write_internal ? 1 : 0, c->d_seg, (int)c->nbp2,
                                                        cross_list, cross_count, c->cross_cap);
+    // fused build, a tree of 2 .. 2048 blocks: the cross nodes' ranges, splits, links and records in ONE launch (k_cross_fused, cd_build.h)
+    if (fused && n > 1 && c->nbp2 > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK && !c->dbg_split_cross) {
+        const uint32_t xb = (uint32_t)nblocks < 8u ? 8u : ((uint32_t)nblocks > 1792u ? 1792u : (uint32_t)nblocks);   // 16 nodes per workgroup and round, ~13 per block; at most what the chip holds at once (7 workgroups per CU)
+        k_cross_fused<<<xb + 1u /* the last workgroup folds the FP64 box of all leaves */, 256, sizeof(float) * 6 * (c->nbp2 >= 2 ? c->nbp2 / 2 : 1), s>>>(c->d_keys[0], (int)n, c->d_seg, c->d_seg32, (int)c->nbp2, nblocks, c->d_qbox, c->d_boxes,
+                                                                    c->d_recs32, c->d_split_of, c->d_root, c->d_cross, cross_count, c->cross_cap);
+        c->internal_boxes_valid = write_internal;
+        HIPCHK(evrec(c, EV_REFIT1));
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     // the levels above the blocks: a launch of their own -- unless the fused build's k_cross_meta can take them along (block 0)
     const bool top_in_meta = fused && n > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK;
     if (!top_in_meta) {
@@ -600,7 +611,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_parent, sizeof(int32_t) * 2 * n);
     { uint32_t nb = cdiv(nt, REFIT_BLK); c->nbp2 = 1; while (c->nbp2 < nb) c->nbp2 <<= 1; }
     ALLOC(c->d_seg, sizeof(double) * 6 * (size_t)c->nbp2 * REFIT_BLK);
-    ALLOC(c->d_seg32, sizeof(float) * 6 * ((size_t)c->nbp2 << (REFIT_LOG - SEG_MIN_LEVEL + 1)));   // fused build: levels SEG_MIN_LEVEL .. 9 of the blocks' fp32 trees
+    ALLOC(c->d_seg32, sizeof(float) * 6 * ((size_t)c->nbp2 << (REFIT_LOG - SEG32_MIN_LEVEL + 1)));   // fused build: levels SEG32_MIN_LEVEL .. 9 of the blocks' fp32 trees
     c->cross_cap = nt;                                  // every internal node could be one (it never is: about 2 %)
     ALLOC(c->d_cross, sizeof(int32_t) * (size_t)c->cross_cap);
     ALLOC(c->d_boxes, sizeof(double) * 6 * 2 * n);
@@ -965,6 +976,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (key == 102) { c->dbg_no_shared_path = (uint32_t)value; return CD_OK; }
     if (key == 103) { c->dbg_diag = (uint32_t)value; return CD_OK; }
     if (key == 104) { c->dbg_no_fused_build = (uint32_t)value; return CD_OK; }
+    if (key == 105) { c->dbg_split_cross = (uint32_t)value; return CD_OK; }
     if (key == CD_OPT_KERNEL_STAMPS) { if (value < 0 || value > 15) return CD_ERR_ARG; c->stamp_mask = (uint32_t)value; return CD_OK; }
     if (key == 101) { if (value < 1 || value > 65535) return CD_ERR_ARG; c->exact_blocks = (int)value; return CD_OK; }
     return CD_ERR_ARG;
