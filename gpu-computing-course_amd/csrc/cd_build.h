@@ -410,7 +410,8 @@ __global__ __launch_bounds__(256) void k_cross_records(int n, const NodeMeta *__
 // workgroups, i.e. how many searches, a CU holds.)
 __device__ __forceinline__ B32 block_box32(const float *__restrict__ seg32, int nbp2, int nblocks, int b)
 {
-    return b < nblocks ? b32_load(seg32 + 6 * ((size_t)nbp2 + b)) : b32_identity();
+    const B32 v = b32_load(seg32 + 6 * ((size_t)nbp2 + (b < nblocks ? b : 0)));     // (an unconditional load: several of these go out together)
+    return b < nblocks ? v : b32_identity();
 }
 __device__ __forceinline__ void top32_to_lds(float *top, const float *__restrict__ seg32, int nbp2, int nblocks)
 {
