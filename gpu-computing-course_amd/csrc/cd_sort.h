@@ -254,6 +254,7 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     __shared__ uint32_t s_wsum[RADIX / 64];
     __shared__ uint32_t s_enc[2];
     __shared__ uint32_t s_and, s_or;
+    __shared__ uint32_t s_wruns[LOCAL_WAVES];
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const uint32_t p0 = blockIdx.x * LOCAL_W, p1 = min(p0 + (uint32_t)LOCAL_W, n);
@@ -312,11 +313,32 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     const uint32_t base_w = w * per;
     uint32_t kh[LOCAL_ITEMS], ix[LOCAL_ITEMS], rk[LOCAL_ITEMS];
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // What travels is not the high key half itself but {index of the key's run inside the window, key bits 32 .. run_shift - 1}:
+    // the runs are in order already (the global passes), so this composite sorts like the high half -- and it is SHORT: a
+    // window of a mesh holds a handful of long runs, 4 bits of run index + the 12 bits below the run bits are two
+    // 8-bit passes instead of three (a window of many short runs needs the third, as before).  The run index of an item
+    // is the number of run starts at or before it: a ballot per item round, a running count, the waves' totals through LDS.
+    {
+        const int low_bits = run_shift - 32;             // 12 or 16
+        const unsigned long long le_mask = lt_mask | (1ull << lane);
+        uint32_t before = 0, ridx[LOCAL_ITEMS];
 #pragma unroll
-    for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit) {
-        const uint32_t j = base_w + it * 64 + lane;
-        kh[it] = j < cnt ? (uint32_t)(keys_in[lo + j] >> 32) : ~0u;
-        ix[it] = j;
+        for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit) {
+            const uint32_t j = base_w + it * 64 + lane;
+            const uint64_t kj = j < cnt ? keys_in[lo + j] : 0ull, kp = (j < cnt && j > 0) ? keys_in[lo + j - 1] : kj;
+            const unsigned long long m = __ballot(j < cnt && (kj >> run_shift) != (kp >> run_shift));
+            ridx[it] = before + (uint32_t)__popcll(m & le_mask);
+            before += (uint32_t)__popcll(m);
+            kh[it] = (uint32_t)(kj >> 32) & ((1u << low_bits) - 1u);
+            ix[it] = j;
+        }
+        if (lane == 0) s_wruns[w] = before;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int ww = 0; ww < w; ++ww) woff += s_wruns[ww];
+#pragma unroll
+        for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit)
+            kh[it] = base_w + it * 64 + lane < cnt ? (((woff + ridx[it]) << low_bits) | kh[it]) : ~0u;
     }
     // which digits vary at all inside the window (typically not the top one): one AND / OR reduction for all four
     if (tid == 0) { s_and = 0xffffffffu; s_or = 0u; }
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     }
     __syncthreads();
     const uint32_t varying = s_and ^ s_or;
-    for (int digit = 0; digit < 4; ++digit) {            // digits 4..7 of the key = digits 0..3 of its high half
+    for (int digit = 0; digit < 4; ++digit) {            // digits of the composite (see above)
         const int shift = digit * RADIX_BITS;
         if (((varying >> shift) & (RADIX - 1)) == 0) continue;            // (workgroup-uniform) one value in this digit: already in order
         for (int i = tid; i < LOCAL_WAVES * RADIX; i += LOCAL_THREADS) (&wcnt[0][0])[i] = 0;
@@ -404,6 +426,7 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
         if (j < cnt) {
             const uint64_t k = keys_in[lo + ix[it]];
             tv[it] = vals_in[lo + ix[it]];
+            kh[it] = (uint32_t)(k >> 32);                // (from here on the true high half)
             sitem[j] = make_uint2((uint32_t)k, kh[it]);
         }
     }
