@@ -606,9 +606,11 @@ def _assert_fused_records_equal_stagewise(verts, vidx, ids=None):
     assert np.array_equal((rr[used][:, 7] >> 31 & 1)[leafR], (rr0[used][:, 7] >> 31 & 1)[leafR])
 
 
-@pytest.mark.parametrize("kind", ["cloth-float", "soup-double", "mixed", "tiny", "one-block", "ragged", "duplicates", "long-ranges", "1024-blocks", "4096-blocks"])
+@pytest.mark.parametrize("kind", ["cloth-float", "soup-double", "mixed", "tiny", "one-block", "two-blocks", "three-blocks", "ragged", "duplicates", "long-ranges",
+                                  "1024-blocks", "2048-blocks", "4096-blocks"])
 def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
-    """The fused build (cd_build.h: hierarchy from adjacent deltas, fp32 segment trees, cross nodes by wave) against the
+    """The fused build (cd_build.h: hierarchy from adjacent deltas, fp32 segment trees, cross nodes by k_cross_fused -- or, beyond
+    2048 blocks, by k_cross_meta + k_cross_records) against the
     stage-wise one (k_hierarchy + the FP64 refit, key 104): the traversal records must be the same bytes -- child boxes
     rounded outward, child links, range ends, the root's name, and the exact-in-fp32 bits of LEAF children (those of
     internal children are not read by any kernel and not compared) -- and so must the fp32 query boxes."""
@@ -624,6 +626,12 @@ def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
         verts, vidx = synth.soup(3, 0.5, 5)
     elif kind == "one-block":
         verts, vidx = synth.soup(512, 0.2, 6)
+    elif kind == "two-blocks":                      # the level above the blocks is the root: nothing above it to keep in LDS
+        verts, vidx = synth.soup(600, 0.2, 7)
+    elif kind == "three-blocks":                    # four block slots, the last one empty
+        verts, vidx = synth.soup(1300, 0.15, 8)
+    elif kind == "2048-blocks":                     # 1954 blocks: the largest tree k_cross_fused takes, two nodes of the lowest LDS level per thread
+        verts, vidx = synth.soup(1_000_000, 0.005, 14)
     elif kind == "duplicates":                      # equal keys: delta falls through to the index tie-break (64 + clz), runs of equal deltas
         v0, t0 = synth.soup(3000, 0.05, 10)
         verts, vidx = v0, np.concatenate([t0, t0, t0[:1500]], axis=0)
