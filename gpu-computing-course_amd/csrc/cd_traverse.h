@@ -522,7 +522,20 @@ __global__ __launch_bounds__(TRAV_THREADS, 8) void k_descend_half(QuerySrc src, 
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t dg_p1a = 0, dg_p1 = 0, dg_hops_in = 0, dg_hops_out = 0, dg_vis = 0;   // diagnostics (diag != 0)
     const uint32_t nb = gridDim.x, per = nb >> 3;       // XCD-aware mapping, see k_descend
-    const uint32_t vblock = (blockIdx.x < (per << 3)) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+#ifndef HALF_XSUB
+#define HALF_XSUB 4
+#endif
+    uint32_t vblock = (blockIdx.x < (per << 3)) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    // ... as HALF_XSUB chunks from different parts of the mesh rather than ONE contiguous eighth: the work per query is not
+    // even over a mesh (where the surfaces meet, a query has candidates; elsewhere none), and an XCD with a busy eighth
+    // was the kernel's tail.  1 M cloth: 1 / 2 / 4 / 8 / 16 chunks -> 57.8 / 57.9 / 54.1 / 54.4 / 54.6 us.
+    if (HALF_XSUB > 1) {
+        const uint32_t c = per / HALF_XSUB;
+        if (c > 0 && blockIdx.x < c * HALF_XSUB * 8u) {
+            const uint32_t x = blockIdx.x & 7u, l = blockIdx.x >> 3, sub = l / c, off = l % c;
+            vblock = (sub * 8u + x) * c + off;
+        } else if (c > 0) vblock = blockIdx.x;          // (the remainder keeps its own index: c * HALF_XSUB * 8 <= blockIdx.x < nb are not produced above)
+    }
     CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
     Candidates *my_cand = cand + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_cap;
     const uint32_t nq = (uint32_t)n, last_leaf = nq - 1u;
