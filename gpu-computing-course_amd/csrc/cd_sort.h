@@ -305,12 +305,14 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     const uint32_t cnt = (uint32_t)(hi - lo);            // <= LOCAL_W + LOCAL_LIMIT - 1
     // Only {high key half, position} travels through the passes (3 registers per key with its rank; whole keys and
     // values spilled); keys and values are gathered from the window once, at the end.
-    // Wave w owns the contiguous items [w * per, (w + 1) * per), per = the window spread evenly over the 16 waves
-    // (item order == position order, as stability needs); a window of 4096 keys costs 4 item rounds per pass, not
-    // the 10 its capacity allows: every sweep below stops at `nit` (workgroup-uniform).
-    const uint32_t per = (((cnt + LOCAL_WAVES - 1) / LOCAL_WAVES) + 63u) & ~63u;
-    const int nit = (int)(per >> 6);                     // <= LOCAL_ITEMS
-    const uint32_t base_w = w * per;
+    // Wave w owns contiguous items (item order == position order, as stability needs), whole rounds of 64: every wave
+    // cnt / 1024 rounds, the first waves one more until the window is covered -- a window of 4200 keys costs fourteen
+    // waves 4 item rounds per pass and two waves 5 (with equal shares rounded up to 64 it cost thirteen waves 5 rounds and
+    // left three idle; the windows end at run starts, so half of them are a little over their nominal 4096 keys).  Every
+    // sweep below stops at `nit` (wave-uniform; no barrier sits inside a sweep).
+    const uint32_t full = cnt >> 10, extra = ((cnt & 1023u) + 63u) >> 6;      // 1024 = 16 waves x 64 lanes
+    const int nit = (int)(full + ((uint32_t)w < extra ? 1u : 0u));            // <= LOCAL_ITEMS
+    const uint32_t base_w = ((uint32_t)w * full + min((uint32_t)w, extra)) * 64u;
     uint32_t kh[LOCAL_ITEMS], ix[LOCAL_ITEMS], rk[LOCAL_ITEMS];
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // What travels is not the high key half itself but {index of the key's run inside the window, key bits 32 .. run_shift - 1}:
