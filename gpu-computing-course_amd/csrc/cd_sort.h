@@ -264,7 +264,33 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     // the lower one), searched LOCAL_LIMIT / 2 positions to either side -- the windows then differ from their nominal
     // size by at most half a run to either side, instead of a whole run to one.  The function p -> nearest start is
     // monotone, so windows never overlap.  All the probes of a thread (two keys each) are issued before any is used.
+    // First the LOCAL_THREADS positions around p0 and p1 (one per thread: runs of a mesh are a few hundred keys, the nearest
+    // start is almost always there, and it is THE nearest if it is); the whole range only for an end that found nothing.
     {
+        constexpr int NEAR = LOCAL_THREADS / 2;
+        uint32_t top[2][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t p = e ? p1 : p0;
+            const long long q = (long long)p - NEAR + (int)tid;
+            const bool live = p != 0 && p < n && q >= 0 && q < (long long)n;
+            top[e][0] = (live && q > 0) ? (uint32_t)(keys_in[q - 1] >> run_shift) : 0xffffffffu;
+            top[e][1] = live ? (uint32_t)(keys_in[q] >> run_shift) : 0xffffffffu;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t p = e ? p1 : p0;
+            const long long q = (long long)p - NEAR + (int)tid;
+            const bool live = p != 0 && p < n && q >= 0 && q < (long long)n;
+            if (live && top[e][0] != top[e][1]) {
+                const uint32_t dist = (uint32_t)(q > (long long)p ? q - p : p - q);
+                atomicMin(&s_enc[e], (dist << 1) | (q > (long long)p ? 1u : 0u));
+            }
+        }
+    }
+    __syncthreads();
+    const bool far0 = p0 != 0 && s_enc[0] == 0xffffffffu, far1 = p1 < n && s_enc[1] == 0xffffffffu;    // (workgroup-uniform)
+    if (far0 || far1) {
         constexpr int PROBES = LOCAL_LIMIT / LOCAL_THREADS, HALF = LOCAL_LIMIT / 2;
         uint32_t top[2][PROBES][2];
 #pragma unroll
@@ -273,7 +299,7 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
 #pragma unroll
             for (int u = 0; u < PROBES; ++u) {
                 const long long q = (long long)p - HALF + (u * LOCAL_THREADS + (int)tid);
-                const bool live = p != 0 && p < n && q >= 0 && q < (long long)n;
+                const bool live = (e ? far1 : far0) && q >= 0 && q < (long long)n;
                 top[e][u][0] = (live && q > 0) ? (uint32_t)(keys_in[q - 1] >> run_shift) : 0xffffffffu;    // 0xffffffff: "differs" (q == 0 is a start); run_shift >= 44
                 top[e][u][1] = live ? (uint32_t)(keys_in[q] >> run_shift) : 0xffffffffu;
             }
@@ -284,7 +310,7 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
 #pragma unroll
             for (int u = 0; u < PROBES; ++u) {
                 const long long q = (long long)p - HALF + (u * LOCAL_THREADS + (int)tid);
-                const bool live = p != 0 && p < n && q >= 0 && q < (long long)n;
+                const bool live = (e ? far1 : far0) && q >= 0 && q < (long long)n;
                 if (live && top[e][u][0] != top[e][u][1]) {
                     const uint32_t dist = (uint32_t)(q > (long long)p ? q - p : p - q);
                     atomicMin(&s_enc[e], (dist << 1) | (q > (long long)p ? 1u : 0u));
