@@ -266,7 +266,9 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
             // (stage events off: the kernels' time stamps ride on their dispatch packets, no barrier packets between the passes)
             c->stage_events = false;
             QuerySrc src{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, nullptr, nullptr, c->d_os_ticket + 8};
-            HIPCHK(hipMemsetAsync(t0.d_state, 0, sizeof(TravState), s));
+            // (the fused build has just zeroed the traversal counters itself -- ZeroPlan, cd_build.h -- unless the sort took a form that
+            //  goes without; a memset here sits between the tree and the traversal: 12 us of the step)
+            if (!c->scratch_clean) HIPCHK(hipMemsetAsync(t0.d_state, 0, sizeof(TravState), s));
             launch_pass<false, false>(c, t0, src, c->nt, cap);
             rc = enqueue_report(c, t0, pairs != nullptr, spec0);
             if (rc) return rc;
@@ -282,12 +284,21 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     // work to chew on), then the second stream's calls (RCCL's cost the host tens of microseconds), then tree and traversal.
     // The pack streams the vertices while the sort's latency-bound passes leave the memory system idle.
     mark(ME_START, s);
-    k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, c->nt, c->d_partial);
-    k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->frame_mode == CD_FRAME_AUTO ? c->d_frame : nullptr, m->d_myroot);
-    HIPCHK(hipEventRecord(m->ev_box, s));
-    { const int rc = enqueue_sort(); if (rc) return rc; }
     hipStream_t xs = m->xstream;
-    HIPCHK(hipStreamWaitEvent(xs, m->ev_box, 0));
+    if (c->frame_mode == CD_FRAME_AUTO) {         // the Morton frame IS that box: the sort waits for it too
+        k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, c->nt, c->d_partial);
+        k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->d_frame, m->d_myroot);
+        HIPCHK(hipEventRecord(m->ev_box, s));
+        { const int rc = enqueue_sort(); if (rc) return rc; }
+        HIPCHK(hipStreamWaitEvent(xs, m->ev_box, 0));
+    } else {                                      // a given frame: the own pipeline starts at once, the box is the second stream's first job (~20 us off the step)
+        { const int rc = enqueue_sort(); if (rc) return rc; }
+        k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, xs>>>(c->d_verts, c->d_vidx, c->nt, c->d_partial);
+        k_frame_from_bounds<<<1, 256, 0, xs>>>(c->d_partial, BOUNDS_BLOCKS, nullptr, m->d_myroot);
+    }
+    // (the counters of the pass over the received queries: zeroed here, where the second stream has time -- behind the exchange the
+    //  memset would sit between the records' arrival and the pass, 8 us + a launch gap on the step's longest chain)
+    if (!(m->flags & CD_MULTI_CROSS_SERIAL)) HIPCHK(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), xs));
     for (;; ++attempts) {
         if (attempts >= 6) return CD_ERR_ARG;
         NCCLCHK(r->AllGather(m->d_myroot, m->d_roots, 6, ncclDouble, m->comm, xs));
@@ -357,9 +368,9 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         const bool serial = (m->flags & CD_MULTI_CROSS_SERIAL) != 0;                        // A/B: the cross pass behind the local one, on its stream
         hipStream_t cs = serial ? s : m->xstream;
         if (fast_path && recvd) {
+            if (redo || serial) HIPCHK(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), cs));   // (first time round: zeroed at the start of the step, see there)
             HIPCHK(hipStreamWaitEvent(cs, serial ? m->ev_payload : m->ev_tree, 0));
             QuerySrc srcx{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, m->d_recv, nullptr, c->d_os_ticket + 8};
-            HIPCHK(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), cs));
             m->scratch_pairs.resize(2 * (size_t)spec1 + 2);
             int rc;
             {
