@@ -3,6 +3,7 @@ the CPU oracle on the same seeded inputs.  Bar: bit-exact (integer keys / indice
 box bits, pair index SETS -- the reference's own output order is an atomicAdd race, collision.cuh:40)."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -869,6 +870,15 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     ref = oracle.pipeline(v, t, ids)
     assert line["config"]["colliding_pairs"] == ref["stats"].n_pairs
     assert line["config"]["last_step_rank0"]["peers"] == [1] and line["config"]["last_step_rank0"]["sent_queries"] > 0
+
+
+def test_medium_random_meshes_match_the_oracle():
+    """tools/soak_medium.py (seeded): meshes of 5 k .. 700 k triangles -- uniform and clustered soups, cloth pairs, float and
+    double coordinates -- two fused steps each against the oracle's pair set, pairs-tested count, keys and permutation.  The
+    sizes at which trees have hundreds of blocks, windows of the hybrid sort hold runs of every length and a step reuses the
+    scratch its predecessor cleaned."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_medium.py"), "20261004", "12"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_random_meshes_property():
