@@ -497,10 +497,13 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
         const bool live = kq < total;
         int first = 0, last = 0, split = 0;
         {
+            // (a dependent load costs a round trip even when it hits: values that are already in registers are not fetched again)
+            auto delta_v = [](uint64_t ka, int ia, uint64_t kb, int ib) { const uint64_t x = ka ^ kb; return x ? __clzll((long long)x) : 64 + __clz((int)((uint32_t)ia ^ (uint32_t)ib)); };
             const int i = live ? dense[kq] : 0;
             const uint64_t ki = keys[i];
-            const int d = (delta_k(keys, n, i, ki, i + 1) - delta_k(keys, n, i, ki, i - 1)) >= 0 ? 1 : -1;
-            const int delta_min = delta_k(keys, n, i, ki, i - d);
+            const int dnext = delta_k(keys, n, i, ki, i + 1), dprev = delta_k(keys, n, i, ki, i - 1);
+            const int d = (dnext - dprev) >= 0 ? 1 : -1;
+            const int delta_min = d > 0 ? dprev : dnext;                    // delta(i, i - d)
             int mlen = 0;
             for (int r = 0; r < 2; ++r) {
                 const bool todo = live && mlen == 0;
@@ -514,14 +517,17 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
             const int l = group_last_true(live, mlen >> 1, mlen, g, gl, [&](int x) { return delta_k(keys, n, i, ki, i + x * d) > delta_min; });
             const int j = i + l * d;
             first = min(i, j); last = max(i, j);
-            const uint64_t kf = keys[first], kl = keys[last];
-            const int common = delta_k(keys, n, first, kf, last);
+            const uint64_t kj = keys[j];
+            // (the keys next to the range's ends, for the parent rule below: requested together with the far end's key)
+            const uint64_t kbefore = first > 0 ? keys[first - 1] : 0ull, kafter = last < n - 1 ? keys[last + 1] : 0ull;
+            const uint64_t kf = first == i ? ki : kj, kl = last == i ? ki : kj;
+            const int common = delta_v(kf, first, kl, last);
             split = group_last_true(live, first, last, g, gl, [&](int x) { return delta_k(keys, n, first, kf, x) > common; });
             // ---- the node's name goes into its parent's record (the root has none: its name is the tree's entry point)
             if (live && gl == 0) {
                 if (first == 0 && last == n - 1) *root_name = split;
                 else {
-                    const int dl = delta_k(keys, n, first, kf, first - 1), dr = delta_k(keys, n, last, kl, last + 1);   // -1 past the ends
+                    const int dl = first > 0 ? delta_v(kf, first, kbefore, first - 1) : -1, dr = last < n - 1 ? delta_v(kl, last, kafter, last + 1) : -1;   // -1 past the ends
                     uint32_t *half = reinterpret_cast<uint32_t *>(const_cast<float4 *>(dr > dl ? rec_left(recs32, n, (uint32_t)last) : rec_right(recs32, n, (uint32_t)(first - 1))));
                     half[6] = (uint32_t)split;                              // the link word of that half
                 }
