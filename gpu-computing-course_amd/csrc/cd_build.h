@@ -130,7 +130,9 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
                                                            const uint64_t *__restrict__ keys, int32_t *__restrict__ split_of,
                                                            double *__restrict__ boxes, NodeRec32 *__restrict__ recs32, LeafBox32 *__restrict__ qbox32,
                                                            int32_t *__restrict__ root_name, double *__restrict__ seg, float *__restrict__ seg32, int nbp2,
-                                                           int32_t *__restrict__ cross_list, uint32_t *__restrict__ cross_count, uint32_t cross_cap, ZeroPlan zp)
+                                                           int32_t *__restrict__ cross_list, uint32_t *__restrict__ cross_count, uint32_t cross_cap, ZeroPlan zp,
+                                                           int seg_min /* lowest level of the block's tree that goes to seg32: SEG32_MIN_LEVEL for the trees k_cross_fused takes,
+                                                                          SEG_MIN_LEVEL beyond (there the kernel is bound by its writes, and levels 1 and 2 are 18 bytes a leaf) */)
 {
     {
         const uint32_t G = gridDim.x * REFIT_BLK;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
             const int k = cnt + tid;
             const B32 m = b32_merge(b32_load(t[2 * k]), b32_load(t[2 * k + 1]));
             b32_store(t[k], m);
-            if (REFIT_LOG - dd >= SEG32_MIN_LEVEL) b32_store(seg32 + 6 * ((((size_t)nbp2 + b) << dd) + tid), m);
+            if (REFIT_LOG - dd >= seg_min) b32_store(seg32 + 6 * ((((size_t)nbp2 + b) << dd) + tid), m);
         }
     }
     __syncthreads();
@@ -282,10 +284,10 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
 // SEG32_MIN_LEVEL are rebuilt from them), the blocks' fp32 trees (seg32), above the blocks the FP64 boxes of
 // k_refit_seg_top rounded outward.
 __device__ __forceinline__ B32 seg_piece32(const double *__restrict__ seg, const float *__restrict__ seg32, const LeafBox32 *__restrict__ qbox32,
-                                           int n, long long P, long long k, int p)
+                                           int n, long long P, long long k, int p, int seg_min = SEG_MIN_LEVEL)
 {
     if (p > REFIT_LOG) return b32_of(load_box(seg, (int)k));
-    if (p >= SEG32_MIN_LEVEL) return b32_load(seg32 + 6 * (size_t)k);
+    if (p >= seg_min) return b32_load(seg32 + 6 * (size_t)k);
     const long long j0 = (k << p) - P;
     B32 x = b32_identity();
     for (int u = 0; u < (1 << p); ++u) { const long long jj = j0 + u; if (jj < n) x = b32_merge(x, b32_of_leaf(qbox32, (int)jj)); }

@@ -274,7 +274,8 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         hipExtLaunchKernelGGL(k_build_block, dim3(nblocks), dim3(REFIT_BLK), 0u, s, stamp ? c->ev[EV_BLK0] : nullptr, stamp ? c->ev[EV_BLK1] : nullptr, 0u,
                               (const double *)c->d_verts, (const LeafTri *)c->d_leaf, (int)n, (const uint64_t *)c->d_keys[0], c->d_split_of,
                               c->d_boxes, c->d_recs32, c->d_qbox, c->d_root, c->d_seg, c->d_seg32, (int)c->nbp2,
-                              cross_list, cross_count, c->cross_cap, zp);
+                              cross_list, cross_count, c->cross_cap, zp,
+                              (c->nbp2 > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK && !c->dbg_split_cross) ? SEG32_MIN_LEVEL : SEG_MIN_LEVEL);
         c->scratch_clean = self_cleaning;       // (judge_sort_flags takes it back when the sort has raised a flag)
     } else
         k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded,
