@@ -76,11 +76,11 @@ __device__ __forceinline__ double wave_min(double v) { for (int o = 32; o; o >>=
 __device__ __forceinline__ double wave_max(double v) { for (int o = 32; o; o >>= 1) { double t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
 
 // BOX: also the min / max over the triangles' VERTICES -- the box of all leaves (what node 0 of the tree will hold),
-// known before there is a tree: the multi-GPU step exchanges it first (cd_multi.h).  partial: gridDim.x x 12.
+// known before there is a tree: the multi-GPU step exchanges it first (cd_multi.h).  partial: 12 x gridDim.x.
 constexpr int BOUNDS_STRIDE = 12;
 template <bool BOX>
 __global__ __launch_bounds__(256) void k_centroid_bounds(const double *__restrict__ verts, const uint32_t *__restrict__ vidx, uint32_t n,
-                                                         double *__restrict__ partial /* gridDim.x x BOUNDS_STRIDE: centroid lo[3] hi[3], vertex lo[3] hi[3] */)
+                                                         double *__restrict__ partial /* BOUNDS_STRIDE x gridDim.x: centroid lo[3] hi[3], vertex lo[3] hi[3], each for every block */)
 {
     __shared__ double sm[4][BOUNDS_STRIDE];
     constexpr int SETS = BOX ? 2 : 1;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_centroid_bounds(const double *__restric
         const bool is_lo = (threadIdx.x % 6) < 3;
         double v = sm[0][threadIdx.x];
         for (int ww = 1; ww < 4; ++ww) { const double t = sm[ww][threadIdx.x]; v = is_lo ? (t < v ? t : v) : (t > v ? t : v); }
-        partial[blockIdx.x * BOUNDS_STRIDE + threadIdx.x] = v;
+        partial[threadIdx.x * gridDim.x + blockIdx.x] = v;                   // value-major: the folds below read consecutive blocks
     }
 }
 // One workgroup of 256 folds the per-block partials (it used to be three threads walking all of them one dependent
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_frame_from_bounds(const double *__restr
         for (uint32_t b = threadIdx.x; b < nblocks; b += 256) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const double l = partial[b * BOUNDS_STRIDE + 6 * q + a], h = partial[b * BOUNDS_STRIDE + 6 * q + 3 + a];
+                const double l = partial[(6 * q + a) * nblocks + b], h = partial[(6 * q + 3 + a) * nblocks + b];
                 lo[a] = l < lo[a] ? l : lo[a]; hi[a] = h > hi[a] ? h : hi[a];
             }
         }
@@ -156,10 +156,47 @@ constexpr int MORTON_THREADS = 512;
 __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restrict__ verts, const uint32_t *__restrict__ vidx, uint32_t n,
                                                            const double *__restrict__ frame /* off[3], span[3] */,
                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ ghist /* [8][256] */, int first_digit,
-                                                           int down /* shifted hybrid sort: digits taken `down` bits lower */, uint32_t *__restrict__ overflow)
+                                                           int down /* shifted hybrid sort: digits taken `down` bits lower */, uint32_t *__restrict__ overflow,
+                                                           const double *__restrict__ partial /* auto frame: k_centroid_bounds' per-block bounds, else NULL */, uint32_t nparts,
+                                                           double *__restrict__ frame_out, double *__restrict__ box_out /* NULL, or the box of all vertices (partials of k_centroid_bounds<true>) */)
 {
     __shared__ uint32_t h[8][RADIX];
+    __shared__ double smw[MORTON_THREADS / 64][BOUNDS_STRIDE];
+    __shared__ double sframe[6];
     for (int i = threadIdx.x; i < 8 * RADIX; i += MORTON_THREADS) (&h[0][0])[i] = 0;
+    // Auto frame: EVERY workgroup folds the per-block bounds itself (min / max are exact and order-independent: the same
+    // frame in all of them) -- 48 KB of L2 reads and a microsecond, against a one-workgroup kernel of its own in front of
+    // this one (k_frame_from_bounds: ~6 us + a launch gap).  Workgroup 0 stores the frame (and the vertex box) for the others.
+    if (partial) {                                                              // (uniform)
+        const int sets = box_out ? 2 : 1;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (int q = 0; q < sets; ++q) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (uint32_t b = threadIdx.x; b < nparts; b += MORTON_THREADS) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double l = partial[(6 * q + a) * nparts + b], hh = partial[(6 * q + 3 + a) * nparts + b];
+                    lo[a] = l < lo[a] ? l : lo[a]; hi[a] = hh > hi[a] ? hh : hi[a];
+                }
+            }
+            for (int a = 0; a < 3; ++a) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); }
+            if (lane == 0) for (int a = 0; a < 3; ++a) { smw[w][6 * q + a] = lo[a]; smw[w][6 * q + 3 + a] = hi[a]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3 * sets) {
+            const int q = threadIdx.x / 3, a = threadIdx.x % 3;
+            double l = smw[0][6 * q + a], hh = smw[0][6 * q + 3 + a];
+            for (int ww = 1; ww < MORTON_THREADS / 64; ++ww) { const double l2 = smw[ww][6 * q + a], h2 = smw[ww][6 * q + 3 + a]; l = l2 < l ? l2 : l; hh = h2 > hh ? h2 : hh; }
+            if (q == 0) {
+                double span = (hh - l) * (1.0 + 1.0 / 1048576.0);                 // (as k_frame_from_bounds)
+                if (!(span > 0.0)) span = 1.0;
+                sframe[a] = l; sframe[3 + a] = span;
+                if (blockIdx.x == 0 && frame_out) { frame_out[a] = l; frame_out[3 + a] = span; }
+            } else if (blockIdx.x == 0) { box_out[2 * a] = l; box_out[2 * a + 1] = hh; }
+        }
+        __syncthreads();
+        frame = sframe;
+    }
     __syncthreads();
     uint64_t above = 0;
     for (uint32_t t = blockIdx.x * MORTON_THREADS + threadIdx.x; t < n; t += gridDim.x * MORTON_THREADS) {

@@ -104,6 +104,7 @@ struct cd_multi {
     hipStream_t xstream = nullptr;               // payload exchange, beside the context's stream
     hipEvent_t ev_payload = nullptr, ev_counts = nullptr, ev_tree = nullptr, ev_cross = nullptr, ev_box = nullptr, ev[ME_COUNT] = {};
     double *d_myroot = nullptr;                  // 6: the box of all this rank's triangles, from their vertices
+    double *d_partial = nullptr;                 // per-block bounds of that reduction (the context's own are the first stream's, for its Morton frame)
     double *d_roots = nullptr;                   // world x 6
     unsigned long long *d_row = nullptr;         // world: records packed for each peer
     unsigned long long *d_matrix = nullptr;      // world x world, all-gathered rows
@@ -127,7 +128,7 @@ void multi_free(cd_multi *m)
     if (m->ev_box) hipEventDestroy(m->ev_box);
     if (m->ev_cross) hipEventDestroy(m->ev_cross);
     for (int i = 0; i < ME_COUNT; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
-    hipFree(m->d_myroot); hipFree(m->d_roots); hipFree(m->d_row); hipFree(m->d_matrix); hipFree(m->d_send); hipFree(m->d_recv);
+    hipFree(m->d_myroot); hipFree(m->d_partial); hipFree(m->d_roots); hipFree(m->d_row); hipFree(m->d_matrix); hipFree(m->d_send); hipFree(m->d_recv);
     if (m->h_matrix) hipHostFree(m->h_matrix);
     if (m->h_roots) hipHostFree(m->h_roots);
     if (m->own_comm && m->comm && rccl()) rccl()->CommDestroy(m->comm);
@@ -140,11 +141,12 @@ int multi_alloc(cd_multi *m)
     HIPCHK(hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&m->ev_payload, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&m->ev_tree, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&m->ev_tree));                                                    // (a kernel's stop event: with time stamps)
     HIPCHK(hipEventCreateWithFlags(&m->ev_box, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_cross, hipEventDisableTiming));
     for (int i = 0; i < ME_COUNT; ++i) HIPCHK(hipEventCreate(&m->ev[i]));
     HIPCHK(hipMalloc(&m->d_myroot, sizeof(double) * 6));
+    HIPCHK(hipMalloc(&m->d_partial, sizeof(double) * BOUNDS_STRIDE * BOUNDS_BLOCKS));
     HIPCHK(hipMalloc(&m->d_roots, sizeof(double) * 6 * W));
     HIPCHK(hipMalloc(&m->d_row, sizeof(unsigned long long) * (W + 1)));
     HIPCHK(hipMalloc(&m->d_matrix, sizeof(unsigned long long) * W * (W + 1)));
@@ -247,20 +249,23 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     // alone, after the step's collectives.
     // (in two parts: the sort goes to the device BEFORE the host spends its tens of microseconds on the second stream's RCCL
     //  calls, the rest after them)
-    auto enqueue_sort = [&]() -> int {
+    auto enqueue_sort = [&](bool again) -> int {                                           // (again: the bounds of an auto frame are still there)
         mark(ME_LOC0, s);
         c->prezeroed = true;                                                               // (one memset for every counter of the pipeline, as in cd_self_collide)
-        const int rc = enqueue_morton_sort(c, !fused_build_next(c), /*frame_ready=*/true);
+        const int rc = enqueue_morton_sort(c, !fused_build_next(c), /*frame_ready=*/again);
         if (rc) c->prezeroed = false;
         return rc;
     };
     auto enqueue_rest = [&]() -> int {
+        c->tree_done_event = m->ev_tree;                                                   // (rides on the tree's last kernel when that launch can carry it)
         int rc = enqueue_tree(c);
+        const bool carried = c->tree_done_event == nullptr;
+        c->tree_done_event = nullptr;
         c->prezeroed = false;
         if (rc) return rc;
         // (the sort's flags come back with the local pass's report; a copy of their own into pageable memory stalls the stream for ~20 us)
         if (!fast_path) HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipEventRecord(m->ev_tree, s));                                             // the tree exists: the cross pass may start (second stream)
+        if (!carried) HIPCHK(hipEventRecord(m->ev_tree, s));                               // the tree exists: the cross pass may start (second stream)
         mark(ME_TREE, s);
         if (fast_path) {
             // (stage events off: the kernels' time stamps ride on their dispatch packets, no barrier packets between the passes)
@@ -285,17 +290,12 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     // The pack streams the vertices while the sort's latency-bound passes leave the memory system idle.
     mark(ME_START, s);
     hipStream_t xs = m->xstream;
-    if (c->frame_mode == CD_FRAME_AUTO) {         // the Morton frame IS that box: the sort waits for it too
-        k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, c->nt, c->d_partial);
-        k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->d_frame, m->d_myroot);
-        HIPCHK(hipEventRecord(m->ev_box, s));
-        { const int rc = enqueue_sort(); if (rc) return rc; }
-        HIPCHK(hipStreamWaitEvent(xs, m->ev_box, 0));
-    } else {                                      // a given frame: the own pipeline starts at once, the box is the second stream's first job (~20 us off the step)
-        { const int rc = enqueue_sort(); if (rc) return rc; }
-        k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, xs>>>(c->d_verts, c->d_vidx, c->nt, c->d_partial);
-        k_frame_from_bounds<<<1, 256, 0, xs>>>(c->d_partial, BOUNDS_BLOCKS, nullptr, m->d_myroot);
-    }
+    // The box of the triangles is the SECOND stream's first job (its own pass over the vertices, its own partials): the first
+    // stream starts the rank's pipeline at once and no event ties the two together before the tree is there (an event record
+    // between two kernels of a stream is a barrier packet: ~6 us of idle GPU).
+    { const int rc = enqueue_sort(false); if (rc) return rc; }
+    k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, xs>>>(c->d_verts, c->d_vidx, c->nt, m->d_partial);
+    k_frame_from_bounds<<<1, 256, 0, xs>>>(m->d_partial, BOUNDS_BLOCKS, nullptr, m->d_myroot);
     // (the counters of the pass over the received queries: zeroed here, where the second stream has time -- behind the exchange the
     //  memset would sit between the records' arrival and the pass, 8 us + a launch gap on the step's longest chain)
     if (!(m->flags & CD_MULTI_CROSS_SERIAL)) HIPCHK(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), xs));
@@ -364,7 +364,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     int rc_l = CD_OK, rc_x = CD_OK;
     bool need_general_l = !fast_path, need_general_x = !fast_path;
     for (int redo = 0;; ++redo) {
-        if (redo) { int rc = enqueue_sort(); if (!rc) rc = enqueue_rest(); if (rc) return rc; }   // this rank's sort in its next form, then everything that follows it
+        if (redo) { int rc = enqueue_sort(true); if (!rc) rc = enqueue_rest(); if (rc) return rc; }   // this rank's sort in its next form, then everything that follows it
         const bool serial = (m->flags & CD_MULTI_CROSS_SERIAL) != 0;                        // A/B: the cross pass behind the local one, on its stream
         hipStream_t cs = serial ? s : m->xstream;
         if (fast_path && recvd) {

@@ -94,6 +94,7 @@ struct cd_ctx {
     bool leaves_filled = false;             // the sort's fix-up hop already wrote leaf[], parent = -1, bounded = 0
     bool events_ride = false;               // the last pass recorded EV_TRAV0 / EV_DESC1 / EV_TRAV1 through its kernels' dispatch packets
     bool prezeroed = false;                 // fused path: the scratch block was zeroed by one memset at pipeline start
+    hipEvent_t tree_done_event = nullptr;   // set by the multi-GPU step: taken (and cleared) by the launch that completes the tree, if it can carry it
     bool scratch_clean = false;             // ... or by the kernels of the previous fused step (ZeroPlan, cd_build.h): no memset at all
     bool quiet_pass = false;                // launch_pass records no events (a pass on another stream, beside the one whose times are reported)
     int sort_mode = 0;                      // 0 hybrid on key bits 44..59 (every in-frame Morton key is below 2^60), 1 hybrid on bits 48..63 (2 global passes + in-LDS sort of the windows + fix-up), 2 half-key (4 passes + fix-up),
@@ -175,10 +176,10 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
     const uint32_t n = c->nt;
     hipStream_t s = c->stream;
     HIPCHK(evrec(c, EV_MORTON0));
-    if (c->frame_mode == CD_FRAME_AUTO && !frame_ready) {
-        k_centroid_bounds<false><<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_partial);
-        k_frame_from_bounds<<<1, 256, 0, s>>>(c->d_partial, BOUNDS_BLOCKS, c->d_frame, nullptr);
-    }
+    // auto frame: per-block centroid bounds here (frame_ready: they are still there from this step's first sort); k_morton
+    // folds them into the frame itself
+    const bool auto_frame = c->frame_mode == CD_FRAME_AUTO;
+    if (auto_frame && !frame_ready) k_centroid_bounds<false><<<BOUNDS_BLOCKS, 256, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_partial);
     // fused pipeline: the sort scratch, the small counters and the traversal state are one block, zeroed once here
     // (the hybrid forms use the digit passes 6 and 7 only: their granules sit in the front part of the block, with the counters)
     // ... unless the previous fused step's own kernels have left the sort scratch zeroed and this step's kernels zero
@@ -197,7 +198,8 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
     const int first_digit = hybrid ? 6 : (mode == 2 ? 4 : 0);
     int cur = mode == 3 ? 0 : 1;
     const uint32_t mblocks = cdiv(n, MORTON_THREADS * 4) < 1024u ? cdiv(n, MORTON_THREADS * 4) : 1024u;
-    k_morton<<<mblocks, MORTON_THREADS, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_frame, c->d_keys[cur], c->d_os_hist, first_digit, down, c->d_os_ticket + 16);
+    k_morton<<<mblocks, MORTON_THREADS, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_frame, c->d_keys[cur], c->d_os_hist, first_digit, down, c->d_os_ticket + 16,
+                                                auto_frame ? c->d_partial : nullptr, (uint32_t)BOUNDS_BLOCKS, c->d_frame, nullptr);
     HIPCHK(evrec(c, EV_MORTON1));
     // onesweep: one pass over the data per digit; the digit histograms came with the keys
     for (int pass = first_digit; pass < 8; ++pass) {
@@ -284,8 +286,13 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
     // fused build, a tree of 2 .. 2048 blocks: the cross nodes' ranges, splits, links and records in ONE launch (k_cross_fused, cd_build.h)
     if (fused && n > 1 && c->nbp2 > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK && !c->dbg_split_cross) {
         const uint32_t xb = (uint32_t)nblocks < 8u ? 8u : ((uint32_t)nblocks > 1792u ? 1792u : (uint32_t)nblocks);   // 16 nodes per workgroup and round, ~13 per block; at most what the chip holds at once (7 workgroups per CU)
-        k_cross_fused<<<xb + 1u /* the last workgroup folds the FP64 box of all leaves */, 256, sizeof(float) * 6 * (c->nbp2 >= 2 ? c->nbp2 / 2 : 1), s>>>(c->d_keys[0], (int)n, c->d_seg, c->d_seg32, (int)c->nbp2, nblocks, c->d_qbox, c->d_boxes,
-                                                                    c->d_recs32, c->d_split_of, c->d_root, c->d_cross, cross_count, c->cross_cap);
+        // (the multi-GPU step's "tree is there" event rides on this kernel's dispatch packet: recorded on its own it is a barrier
+        //  packet between the tree and the traversal, ~6 us of idle GPU)
+        hipEvent_t done = c->tree_done_event; c->tree_done_event = nullptr;
+        hipExtLaunchKernelGGL(k_cross_fused, dim3(xb + 1u /* the last workgroup folds the FP64 box of all leaves */), dim3(256),
+                              (uint32_t)(sizeof(float) * 6 * (c->nbp2 >= 2 ? c->nbp2 / 2 : 1)), s, nullptr, done, 0u,
+                              (const uint64_t *)c->d_keys[0], (int)n, (const double *)c->d_seg, (const float *)c->d_seg32, (int)c->nbp2, nblocks, (const LeafBox32 *)c->d_qbox, c->d_boxes,
+                              c->d_recs32, (const int32_t *)c->d_split_of, c->d_root, (const int32_t *)c->d_cross, (const uint32_t *)cross_count, c->cross_cap);
         c->internal_boxes_valid = write_internal;
         HIPCHK(evrec(c, EV_REFIT1));
         HIPCHK(hipGetLastError());
