@@ -872,6 +872,33 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert line["config"]["last_step_rank0"]["peers"] == [1] and line["config"]["last_step_rank0"]["sent_queries"] > 0
 
 
+def test_every_morton_key_equal():
+    """All centroids are EXACTLY one point (p1 = c + a, p2 = c + b, p3 = c - a - b with few-bit a, b): one Morton key, so the
+    order and the whole tree are the index tie-break's (delta = 64 + clz(i ^ j)), across six 512-leaf blocks -- the cross nodes'
+    ranges, splits and the parent rule of k_cross_fused all run on tie-break deltas -- and every triangle contains c: all
+    n (n - 1) / 2 pairs collide.  The sort falls back to its full form (one run of equal keys)."""
+    n = 2800
+    i = np.arange(n, dtype=np.float64)
+    c = np.array([1.0, 0.0, 0.5])
+    a = np.stack([(i % 97 + 1) * 2.0 ** -12, (i // 97 + 1) * 2.0 ** -13, np.zeros(n)], axis=1)
+    b = np.stack([np.zeros(n), (i % 89 + 1) * 2.0 ** -12, (i // 89 + 1) * 2.0 ** -13], axis=1)
+    verts = np.stack([c + a, c + b, c - a - b], axis=1).reshape(-1, 3)
+    vidx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    assert len(np.unique(oracle.centroid_morton(verts, vidx))) == 1
+    _assert_fused_records_equal_stagewise(verts, vidx)
+    r = oracle.pipeline(verts, vidx)
+    assert r["stats"].n_pairs == n * (n - 1) // 2
+    for variant in VARIANTS:
+        with mi355cd.CollisionDetector(verts, vidx) as cd:
+            cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
+            for _ in range(2):
+                pairs, npairs, rc = cd.self_collide(cap=1 << 22)
+                assert rc == 0 and npairs == r["stats"].n_pairs and cd.stats().pairs_tested == r["stats"].pairs_tested
+                assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+            keys, perm = cd.export_keys()
+            assert np.array_equal(keys, r["keys"]) and np.array_equal(perm, r["perm"]) and cd.stats().sort_passes == 8
+
+
 def test_medium_random_meshes_match_the_oracle():
     """tools/soak_medium.py (seeded): meshes of 5 k .. 700 k triangles -- uniform and clustered soups, cloth pairs, float and
     double coordinates -- two fused steps each against the oracle's pair set, pairs-tested count, keys and permutation.  The
