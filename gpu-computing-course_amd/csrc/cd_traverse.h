@@ -509,15 +509,22 @@ constexpr int HALF_STACK = 8;                // LDS stack entries per lane
 constexpr int HALF_QCAP = 192;               // candidate queue slots per wave
 constexpr uint32_t HALF_FLUSH_AT = HALF_QCAP - 64;   // an enqueue adds at most 64 candidates: drain before it when more than this are waiting
 
-__global__ __launch_bounds__(TRAV_THREADS, 8) void k_descend_half(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
+// (one wave per workgroup: the waves of this kernel never meet -- no barrier, wave-private LDS -- and a workgroup holds its
+//  slot until its SLOWEST wave is done; with the work per query as uneven as it is, single-wave workgroups give the slots
+//  back sooner: 53.8 -> 52.4 us at 1 M triangles.  Two waves: 53.2 us)
+#ifndef HALF_T
+#define HALF_T 64
+#endif
+constexpr int HALF_THREADS = HALF_T, HALF_WAVES = HALF_THREADS / 64;
+__global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
                                                                   TravState *__restrict__ st,
                                                                   Candidates *__restrict__ cand, unsigned long long shard_cap,
                                                                   uint2 *__restrict__ defer_list, uint32_t defer_cap, uint32_t diag)
 {
     if (sort_failed(src)) return;
-    __shared__ int32_t lds_stack[HALF_STACK][TRAV_THREADS];
-    __shared__ Candidates queue[WQ_WAVES][HALF_QCAP];
-    __shared__ uint8_t share_map[WQ_WAVES][64];        // work sharing: lane id of the k-th donor
+    __shared__ int32_t lds_stack[HALF_STACK][HALF_THREADS];
+    __shared__ Candidates queue[HALF_WAVES][HALF_QCAP];
+    __shared__ uint8_t share_map[HALF_WAVES][64];      // work sharing: lane id of the k-th donor
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t dg_p1a = 0, dg_p1 = 0, dg_hops_in = 0, dg_hops_out = 0, dg_vis = 0;   // diagnostics (diag != 0)
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(TRAV_THREADS, 8) void k_descend_half(QuerySrc src, 
     const uint32_t nq = (uint32_t)n, last_leaf = nq - 1u;
     constexpr uint32_t END = 0xffffffffu;
     // the wave owns the 64 consecutive leaves [g0, g_last]  (wave-uniform; readfirstlane tells the compiler)
-    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((vblock * WQ_WAVES + w) * 64u));
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((vblock * HALF_WAVES + w) * 64u));
     const uint32_t g_last = (g0 + 63u < last_leaf) ? g0 + 63u : last_leaf;
     uint32_t qi = g0 + lane;
     const bool valid = qi < nq && n > 1;

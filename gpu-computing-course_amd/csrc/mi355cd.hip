@@ -378,7 +378,7 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         uint2 *dl = DEEP ? nullptr : tb.d_defer; const uint32_t dcap = DEEP ? 0u : tb.defer_cap; int32_t *deep = DEEP ? tb.d_deep : nullptr;
         const uint32_t half = half_mode ? 1u : 0u;
         if (half_mode && !DEEP)
-            hipExtLaunchKernelGGL(k_descend_half, grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
+            hipExtLaunchKernelGGL(k_descend_half, dim3(cdiv(items, 64u * HALF_WAVES)), dim3(HALF_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, n, (const NodeRec32 *)c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
         else if (qpw == 64)
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, false>), grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
