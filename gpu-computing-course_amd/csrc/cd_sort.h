@@ -246,7 +246,8 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
                                                               uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n,
                                                               int run_shift /* a run = equal key bits [run_shift, 64): what the global passes sorted by */,
                                                               uint32_t *__restrict__ overflow, Emit emit /* load(value) -> payload, store(final position, value, payload): what the fix-up hop does per key */,
-                                                              uint32_t *__restrict__ zero_words /* fused step: counters of the kernels that follow, zeroed here instead of by a memset */, uint32_t n_zero)
+                                                              uint32_t *__restrict__ zero_words /* fused step: counters of the kernels that follow, zeroed here instead of by a memset */, uint32_t n_zero,
+                                                              uint32_t win /* nominal keys per workgroup, <= LOCAL_W: n spread over the chip's CUs when that is less */)
 {
     if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < n_zero; i += LOCAL_THREADS) zero_words[i] = 0u;
     __shared__ uint2 sitem[LOCAL_CAP];                   // 80 KB: {high 32 key bits, position inside the window}
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     __shared__ uint32_t s_wruns[LOCAL_WAVES];
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
-    const uint32_t p0 = blockIdx.x * LOCAL_W, p1 = min(p0 + (uint32_t)LOCAL_W, n);
+    const uint32_t p0 = blockIdx.x * win, p1 = min(p0 + win, n);
     if (tid == 0) { s_enc[0] = s_enc[1] = 0xffffffffu; }
     __syncthreads();
     // Window ends: the run start NEAREST to p0 and to p1 (a run starts where the top 16 bits change; equal distance:

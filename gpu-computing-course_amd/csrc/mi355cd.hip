@@ -212,8 +212,11 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
     c->leaves_filled = false; c->leaf_records_filled = false;
     if (hybrid) {                               // data is in buffer 1 again; windows go 1 -> 0, fix-up hop and leaf fill in the kernel's epilogue
         const LeafFill fill{c->d_vidx, c->d_ids, n, c->d_leaf, links_too ? c->d_parent : nullptr, links_too ? c->d_bounded : nullptr};
-        k_local_sort<<<cdiv(n, LOCAL_W), LOCAL_THREADS, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, 48 - down, c->d_os_ticket + 16, fill,
-                                                                self_cleaning ? c->d_small : nullptr, self_cleaning ? 128u : 0u);
+        // one workgroup per CU is all this kernel's LDS allows: the windows are n / 256 keys when that is less than their nominal
+        // 4096 (1 M keys: 256 windows of 3907 instead of 245 of 4096 -- every CU busy, fewer windows over 4096 keys), not below 1024
+        const uint32_t per_cu = cdiv(n, 256u), win = per_cu >= (uint32_t)LOCAL_W ? (uint32_t)LOCAL_W : (per_cu < 1024u ? 1024u : per_cu);
+        k_local_sort<<<cdiv(n, win), LOCAL_THREADS, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, 48 - down, c->d_os_ticket + 16, fill,
+                                                            self_cleaning ? c->d_small : nullptr, self_cleaning ? 128u : 0u, win);
         c->leaves_filled = links_too;
         c->leaf_records_filled = true;
     } else if (mode != 3) {
