@@ -578,15 +578,21 @@ def test_multi_step_world_gt_1_over_the_loopback_transport(quads, qcap, xs):
         assert sum(st["cross"]) > 0
 
 
-def _assert_fused_records_equal_stagewise(verts, vidx, ids=None):
+def _assert_fused_records_equal_stagewise(verts, vidx, ids=None, split_cross_too=True):
     got = {}
-    for fused in (1, 0):
+    for fused in (1, 0, 2):                                 # 2: the fused build with k_cross_meta + k_cross_records (what trees beyond 2048 blocks take)
         with mi355cd.CollisionDetector(verts, vidx, ids) as cd:
             cd.set_option(104, 0 if fused else 1)
+            cd.set_option(105, 1 if fused == 2 else 0)
             cd.build_tree()
             got[fused] = cd.debug_records() + (cd.root_box(),)
-    (rr, rl, qb, root, rbox), (rr0, rl0, qb0, root0, rbox0) = got[1], got[0]
-    n = vidx.shape[0]
+    if split_cross_too:
+        _compare_records(vidx.shape[0], got[2], got[0])
+    _compare_records(vidx.shape[0], got[1], got[0])
+
+
+def _compare_records(n, a, b):
+    (rr, rl, qb, root, rbox), (rr0, rl0, qb0, root0, rbox0) = a, b
     assert (n == 1 or root == root0) and np.array_equal(qb, qb0) and np.array_equal(rbox, rbox0)   # (one leaf: no record, no root name)
     used = np.zeros(n, dtype=bool)                          # records are named by split: n - 1 of the n slots are in use
     if n > 1:                                               # (unused slots hold whatever the allocation held: walk from the root)
