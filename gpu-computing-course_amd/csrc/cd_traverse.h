@@ -236,8 +236,10 @@ constexpr uint32_t CAND_FILTERED = 0x40000000u;
 constexpr uint32_t CAND_LEAF_MASK = 0x3fffffffu;
 
 // queries_per_wave: size of the contiguous chunk of queries one wave works through (multiple of 64).
+// (one wave per workgroup, as k_descend_half: the waves of this kernel never meet)
+constexpr int DESC_THREADS = 64, DESC_WAVES = DESC_THREADS / 64;
 template <bool EXTERNAL, bool DEEP, bool REFILL>
-__global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t nq, int n, uint32_t queries_per_wave,
+__global__ __launch_bounds__(DESC_THREADS) void k_descend(QuerySrc src, uint32_t nq, int n, uint32_t queries_per_wave,
                                                           const NodeRec32 *__restrict__ recs, const double *__restrict__ boxes,
                                                           TravState *__restrict__ st,
                                                           Candidates *__restrict__ cand, unsigned long long shard_cap,
@@ -245,9 +247,9 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
                                                           int32_t *__restrict__ deep_stacks, uint32_t vbase, uint32_t half /* see k_descend_half: deep pass of a half traversal */)
 {
     if (sort_failed(src)) return;
-    __shared__ int32_t lds_stack[DEEP ? 1 : WQ_STACK][TRAV_THREADS];
-    __shared__ Candidates queue[WQ_WAVES][WQ_QCAP];
-    __shared__ uint8_t share_map[WQ_WAVES][64];        // work sharing: lane id of the k-th donor
+    __shared__ int32_t lds_stack[DEEP ? 1 : WQ_STACK][DESC_THREADS];
+    __shared__ Candidates queue[DESC_WAVES][WQ_QCAP];
+    __shared__ uint8_t share_map[DESC_WAVES][64];      // work sharing: lane id of the k-th donor
     const int32_t root = (n > 1) ? *src.root : -1;     // records are named by split (cd_bvh.h): the root's name comes from the refit
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_descend(QuerySrc src, uint32_t
     // mapping that is a permutation of the workgroups gives the same results.
     const uint32_t nb = gridDim.x, per = nb >> 3;
     const uint32_t vblock = (blockIdx.x < (per << 3)) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
-    const uint32_t wave_id = vblock * WQ_WAVES + w;
+    const uint32_t wave_id = vblock * DESC_WAVES + w;
     CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
     Candidates *my_cand = cand + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_cap;
     // this wave's chunk of work items (queries, or deferred (query, subtree) items in the deep pass)

@@ -369,7 +369,7 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         const bool half_mode = c->trav_variant == 3 && !EXTERNAL;
         const uint32_t qpw = (DEEP || c->trav_variant == 3) ? 64u : c->queries_per_wave;
         const uint64_t shard_cap = tb.cand_cap / NSHARD;
-        const dim3 grid(cdiv(items, qpw * WQ_WAVES));
+        const dim3 grid(cdiv(items, qpw * DESC_WAVES));
         const size_t pad = DEEP ? 0 : c->dbg_lds_pad;
         // Timing of the two kernels: with stage events on, hipEventRecord before / between / after (each record is a
         // barrier packet and ~6 us of idle GPU); off, the events ride on the kernels' own dispatch packets
@@ -384,10 +384,10 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
             hipExtLaunchKernelGGL(k_descend_half, dim3(cdiv(items, 64u * HALF_WAVES)), dim3(HALF_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, n, (const NodeRec32 *)c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
         else if (qpw == 64)
-            hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, false>), grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
+            hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, false>), grid, dim3(DESC_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
         else
-            hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, true>), grid, dim3(TRAV_THREADS), (uint32_t)pad, s, e0, e1, 0u,
+            hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, true>), grid, dim3(DESC_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
         if (!DEEP && !ride && !c->quiet_pass) evrec(c, EV_DESC1);
         hipExtLaunchKernelGGL((k_exact<EXTERNAL>), dim3(c->exact_blocks), dim3(EXACT_THREADS), 0u, s, nullptr, e2, 0u,
