@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_frame_from_bounds(const double *__restr
 constexpr int MORTON_THREADS = 512;
 __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restrict__ verts, const uint32_t *__restrict__ vidx, uint32_t n,
                                                            const double *__restrict__ frame /* off[3], span[3] */,
-                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ ghist /* [8][256] */, int first_digit,
+                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ ghist /* [HIST_COPIES][8][256] */, int first_digit,
                                                            int down /* shifted hybrid sort: digits taken `down` bits lower */, uint32_t *__restrict__ overflow,
                                                            const double *__restrict__ partial /* auto frame: k_centroid_bounds' per-block bounds, else NULL */, uint32_t nparts,
                                                            double *__restrict__ frame_out, double *__restrict__ box_out /* NULL, or the box of all vertices (partials of k_centroid_bounds<true>) */)
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restr
     __syncthreads();
     for (int i = threadIdx.x + first_digit * RADIX; i < 8 * RADIX; i += MORTON_THREADS) {
         const uint32_t v = (&h[0][0])[i];
-        if (v) atomicAdd(&ghist[i], v);
+        if (v) atomicAdd(&ghist[(size_t)(blockIdx.x & (HIST_COPIES - 1)) * HIST_STRIDE + i], v);
     }
 }
 

@@ -64,6 +64,11 @@ __global__ __launch_bounds__(1024) void k_scan_exclusive(uint32_t *__restrict__ 
 // tile cannot scatter before every earlier tile has ranked), not the walk; forwarding each key into the NEXT
 // pass's per-tile histogram with global atomics while scattering (no look-back at all) cost 3x (1 M scattered
 // atomics per pass).
+// The histograms that come with the Morton keys are kept as HIST_COPIES partial tables (workgroup b of k_morton adds to table
+// b mod HIST_COPIES; k_os_pass adds the tables up): its ~500 workgroups all flush at the end of the kernel, and atomics on one
+// word retire one after the other.  1 / 2 / 4 / 8 / 16 tables: k_morton 17.0 / 12.9 / 12.4 / 12.6 / 12.5 us, k_os_pass 17.4 /
+// 17.5 / 17.7 / 18.2 / 19.6 us per pass (1 M keys).
+constexpr int HIST_COPIES = 2, HIST_STRIDE = 8 * RADIX;
 constexpr int OS_THREADS = 1024;                       // 16 waves x 4 keys per lane = the same 4096-key tile; the serial ranking chain per wave is what a pass waits for
 constexpr int OS_WAVES   = OS_THREADS / 64;
 constexpr int OS_ITEMS   = SORT_TILE / OS_THREADS;
@@ -98,8 +103,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_hist(const uint64_t *__rest
 
 __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                           uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-                                                          uint32_t n, int shift, const uint32_t *__restrict__ digit_hist /* [256] raw counts of this digit */,
-                                                          unsigned long long *lookback /* [ntiles][256] */, uint32_t *ticket /* [pass]; ticket[8 - pass] = timeout flag */, int first_pass)
+                                                          uint32_t n, int shift, const uint32_t *__restrict__ digit_hist /* [256] raw counts of this digit, hist_copies partial tables HIST_STRIDE words apart */,
+                                                          unsigned long long *lookback /* [ntiles][256] */, uint32_t *ticket /* [pass]; ticket[8 - pass] = timeout flag */, int first_pass, int hist_copies)
 {
     __shared__ uint32_t wcnt[OS_WAVES][RADIX];
     __shared__ uint32_t gbase[RADIX];
@@ -112,7 +117,8 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
     // digit bases = exclusive scan of the 256 raw counts; every tile does it for itself (no scan kernel)
     uint32_t dbase = 0;
     if (tid < RADIX) {
-        const uint32_t c = digit_hist[tid];
+        uint32_t c = 0;
+        for (int k = 0; k < hist_copies; ++k) c += digit_hist[(size_t)k * HIST_STRIDE + tid];
         uint32_t v = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(v, o); if (lane >= o) v += t; }

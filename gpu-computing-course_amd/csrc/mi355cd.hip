@@ -206,7 +206,7 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
         k_os_pass<<<c->ntiles, OS_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1], n, pass * RADIX_BITS - down,
                                                     c->d_os_hist + pass * RADIX,
                                                     (pass >= 6 ? c->d_os_look + (size_t)(pass - 6) * c->ntiles * RADIX : c->d_os_look_lo + (size_t)pass * c->ntiles * RADIX),
-                                                    c->d_os_ticket + pass, pass == first_digit);
+                                                    c->d_os_ticket + pass, pass == first_digit, HIST_COPIES);
         cur ^= 1;
     }
     c->leaves_filled = false; c->leaf_records_filled = false;
@@ -272,7 +272,7 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         ZeroPlan zp{nullptr, 0u, nullptr, 0u, nullptr, 0u};
         if (self_cleaning) {
             const size_t gran = sizeof(unsigned long long) * (size_t)c->ntiles * RADIX;
-            zp = ZeroPlan{c->d_os_hist, 8u * RADIX + 8u /* histograms + tickets; the flags behind them stay */,
+            zp = ZeroPlan{c->d_os_hist, (uint32_t)HIST_COPIES * 8u * RADIX + 8u /* histograms + tickets; the flags behind them stay */,
                           reinterpret_cast<uint4 *>(c->d_os_look), (uint32_t)(2 * gran / sizeof(uint4)),
                           reinterpret_cast<uint32_t *>(c->tb[0].d_state), (uint32_t)(sizeof(TravState) / sizeof(uint32_t))};
         }
@@ -562,7 +562,7 @@ int pp_sort(cd_ctx *c, uint32_t m)
     int cur = 0;
     for (int pass = 0; pass < 8; ++pass) {
         k_os_pass<<<ntiles, OS_THREADS, 0, s>>>(c->pp_keys[cur], c->pp_vals[cur], c->pp_keys[cur ^ 1], c->pp_vals[cur ^ 1], m, pass * RADIX_BITS,
-                                                hist + pass * RADIX, look + (size_t)pass * ntiles * RADIX, ticket + pass, pass == 0);
+                                                hist + pass * RADIX, look + (size_t)pass * ntiles * RADIX, ticket + pass, pass == 0, 1);
         cur ^= 1;
     }
     return 0;
@@ -599,7 +599,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     //   [onesweep: histograms | tickets, flags | look-back granules of passes 6, 7] [small counters: 128 words] [TravState]   <- hybrid sort: this much
     //   [look-back granules of passes 0..5]                                                                                  <- the other forms: all of it
     const size_t gran = sizeof(unsigned long long) * (size_t)c->ntiles * RADIX;           // one pass
-    const size_t look_off = sizeof(uint32_t) * 8 * RADIX + 128;                            // hist | 8 tickets, 8 time-out flags, fix-up flag, pad
+    const size_t look_off = sizeof(uint32_t) * HIST_COPIES * 8 * RADIX + 128;              // hist (HIST_COPIES partial tables) | 8 tickets, 8 time-out flags, fix-up flag, pad
     c->sort_hi_bytes = look_off + 2 * gran;
     const size_t small_off = (c->sort_hi_bytes + 127) & ~(size_t)127, state_off = small_off + 512;
     c->zero_bytes = state_off + sizeof(TravState);
@@ -610,7 +610,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     c->tb[0].d_state = reinterpret_cast<TravState *>(reinterpret_cast<char *>(c->d_os) + state_off);
     c->d_root = reinterpret_cast<int32_t *>(c->d_small + 96);
     c->d_os_hist = reinterpret_cast<uint32_t *>(c->d_os);
-    c->d_os_ticket = c->d_os_hist + 8 * RADIX;
+    c->d_os_ticket = c->d_os_hist + HIST_COPIES * 8 * RADIX;
     c->d_os_look = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_os) + look_off);
     c->d_os_look_lo = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_os) + lo_off);
     ALLOC(c->d_frame, sizeof(double) * 6);
