@@ -126,6 +126,17 @@ void free_all(cd_ctx *c)
 
 inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// morton.h:70-89 / :7-29 on explicit inputs (cd_morton3d_points, cd_expand64_values): the device functions k_morton uses
+__global__ void k_morton_points(const double *__restrict__ xyz, uint64_t n, const double *__restrict__ frame, uint64_t *__restrict__ keys)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        keys[i] = morton3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], frame, frame + 3);
+}
+__global__ void k_expand_values(const uint64_t *__restrict__ v, uint64_t n, uint64_t *__restrict__ out)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = expand64(v[i]);
+}
+
 constexpr int BOUNDS_BLOCKS = 1024;
 
 int ensure_pairs(cd_ctx *c, TravBuf &tb, uint64_t cap)
@@ -971,6 +982,44 @@ int cd_debug_records(cd_ctx *c, void *recs, void *qboxes, int32_t *root)
     if (qboxes) HIPCHK(hipMemcpy(qboxes, c->d_qbox, sizeof(LeafBox32) * (size_t)c->nt, hipMemcpyDeviceToHost));
     if (root) HIPCHK(hipMemcpy(root, c->d_root, sizeof(int32_t), hipMemcpyDeviceToHost));
     return CD_OK;
+}
+
+// morton3D / expand64Bits themselves, on caller-supplied inputs; no context (one-shot device buffers on the null stream)
+static int morton_batch(const void *in, size_t in_bytes, uint64_t n, const double frame[6], uint64_t *out)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return CD_ERR_NO_DEVICE;
+    void *d_in = nullptr; uint64_t *d_out = nullptr; double *d_frame = nullptr;
+    int rc = CD_OK;
+    hipError_t e = hipMalloc(&d_in, in_bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(uint64_t) * n);
+    if (e == hipSuccess && frame) e = hipMalloc(&d_frame, sizeof(double) * 6);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && frame) e = hipMemcpy(d_frame, frame, sizeof(double) * 6, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const uint32_t blocks = cdiv(n, 256) < 4096u ? cdiv(n, 256) : 4096u;
+        if (frame) k_morton_points<<<blocks, 256>>>(static_cast<const double *>(d_in), n, d_frame, d_out);
+        else k_expand_values<<<blocks, 256>>>(static_cast<const uint64_t *>(d_in), n, d_out);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(out, d_out, sizeof(uint64_t) * n, hipMemcpyDeviceToHost);
+    }
+    if (e != hipSuccess) rc = -(int)e;
+    hipFree(d_in); hipFree(d_out); hipFree(d_frame);
+    return rc;
+}
+int cd_morton3d_points(const double *xyz, uint64_t n, const double offset[3], const double span[3], uint64_t *keys)
+{
+    if (!xyz || !keys || (!offset) != (!span)) return CD_ERR_ARG;
+    if (n == 0) return CD_OK;
+    double frame[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};           // morton.h:45,51,57
+    if (offset) for (int a = 0; a < 3; ++a) { frame[a] = offset[a]; frame[3 + a] = span[a]; }
+    return morton_batch(xyz, sizeof(double) * 3 * n, n, frame, keys);
+}
+int cd_expand64_values(const uint64_t *v, uint64_t n, uint64_t *out)
+{
+    if (!v || !out) return CD_ERR_ARG;
+    if (n == 0) return CD_OK;
+    return morton_batch(v, sizeof(uint64_t) * n, n, nullptr, out);
 }
 
 int cd_get_stats(cd_ctx *c, cd_stats *out) { if (!c || !out) return CD_ERR_ARG; *out = c->stats; return CD_OK; }

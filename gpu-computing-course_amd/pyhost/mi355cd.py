@@ -52,6 +52,7 @@ EXPORTS = [
     "cd_check_triangle_idx", "cd_find_collisions", "cd_build_tree", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
     "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_debug_counters", "cd_debug_records", "cd_num_triangles",
     "cd_set_option", "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
+    "cd_morton3d_points", "cd_expand64_values",
     "cd_multi_unique_id", "cd_multi_create", "cd_multi_create_from_comm", "cd_multi_destroy", "cd_multi_set_flags", "cd_multi_step",
 ]
 
@@ -108,6 +109,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_pack_queries.argtypes = [vp, vp, vp, C.c_uint64, u64p]
     lib.cd_find_collisions_queries.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]
     lib.cd_version.restype = C.c_char_p
+    lib.cd_morton3d_points.argtypes = [vp, C.c_uint64, vp, vp, vp]
+    lib.cd_expand64_values.argtypes = [vp, C.c_uint64, vp]
     lib.cd_multi_unique_id.argtypes = [vp]
     lib.cd_multi_create.argtypes = [C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_uint64, C.c_int]
     lib.cd_multi_create_from_comm.argtypes = [C.POINTER(vp), vp, vp, C.c_uint64, C.c_int]
@@ -330,6 +333,28 @@ def load_obj(path: str, threads: int = 0):
     finally:
         lib.cd_free_obj(pv, pf)
     return verts, vidx
+
+
+def morton3d_points(xyz, offset=None, span=None) -> np.ndarray:
+    """morton.h:70-89 morton3D on explicit points, on the device (cd_morton3d_points)."""
+    p = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    off = None if offset is None else np.ascontiguousarray(offset, dtype=np.float64)
+    sp = None if span is None else np.ascontiguousarray(span, dtype=np.float64)
+    keys = np.zeros(p.shape[0], dtype=np.uint64)
+    rc = load_library().cd_morton3d_points(_ptr(p), p.shape[0], _ptr(off), _ptr(sp), _ptr(keys))
+    if rc != CD_OK:
+        raise CdError("cd_morton3d_points", rc)
+    return keys
+
+
+def expand64_values(v) -> np.ndarray:
+    """morton.h:7-29 expand64Bits on explicit values, on the device (cd_expand64_values)."""
+    a = np.ascontiguousarray(v, dtype=np.uint64).ravel()
+    out = np.zeros(a.shape[0], dtype=np.uint64)
+    rc = load_library().cd_expand64_values(_ptr(a), a.shape[0], _ptr(out))
+    if rc != CD_OK:
+        raise CdError("cd_expand64_values", rc)
+    return out
 
 
 def version() -> str:

@@ -93,6 +93,14 @@ int cd_update_vertices(cd_ctx *ctx, const double *verts_xyz);
  * read only for CD_FRAME_CUSTOM. */
 int cd_set_morton_frame(cd_ctx *ctx, int mode, const double offset[3], const double span[3]);
 
+/* morton.h:70-89 morton3D(x, y, z) and morton.h:7-29 expand64Bits(v) themselves, on n caller-supplied inputs (host
+ * pointers; no context): the device functions cd_morton_sort uses, exposed so that the reference's own functions can be
+ * compared value by value (tests/golden/morton_ref.npz holds outputs of the reference's morton.h compiled unmodified).
+ * offset / span: both NULL = the constants of morton.h:45,51,57, else a custom frame.  Defined where the reference is
+ * undefined: a negative or NaN normalised coordinate maps to cell 0 (morton.h:78's assert is compiled out in Release). */
+int cd_morton3d_points(const double *xyz, uint64_t n, const double offset[3], const double span[3], uint64_t *keys);
+int cd_expand64_values(const uint64_t *v, uint64_t n, uint64_t *out);
+
 /* load_obj.h:89-107: centroid + morton3D per face, then sort_by_key(mortons, triangles) -- on the GPU. */
 int cd_morton_sort(cd_ctx *ctx);
 

@@ -78,6 +78,16 @@ uint64_t orc_morton3d(double x, double y, double z, const double off[3], const d
     return (xx << 2) | (yy << 1) | zz;
 }
 
+/* morton3D / expand64Bits over arrays (the reference-compiled fixture tests/golden/morton_ref.npz is replayed through these) */
+void orc_morton3d_batch(const double *xyz, uint64_t n, const double off[3], const double span[3], uint64_t *keys)
+{
+    for (uint64_t i = 0; i < n; ++i) keys[i] = orc_morton3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], off, span);
+}
+void orc_expand64_batch(const uint64_t *v, uint64_t n, uint64_t *out)
+{
+    for (uint64_t i = 0; i < n; ++i) out[i] = orc_expand64(v[i]);
+}
+
 /* load_obj.h:89-101: centroid = (p1+p2+p3)/3 per axis, then morton3D.  centroids may be NULL. */
 void orc_centroid_morton(const double *verts, const uint32_t *vidx, uint32_t n,
                          const double off[3], const double span[3],

@@ -43,6 +43,8 @@ def lib(omp: bool = False) -> C.CDLL:
     vp = C.c_void_p
     L.orc_expand64.argtypes = [C.c_uint64]; L.orc_expand64.restype = C.c_uint64
     L.orc_morton3d.argtypes = [C.c_double, C.c_double, C.c_double, vp, vp]; L.orc_morton3d.restype = C.c_uint64
+    L.orc_morton3d_batch.argtypes = [vp, C.c_uint64, vp, vp, vp]; L.orc_morton3d_batch.restype = None
+    L.orc_expand64_batch.argtypes = [vp, C.c_uint64, vp]; L.orc_expand64_batch.restype = None
     L.orc_centroid_morton.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp]; L.orc_centroid_morton.restype = None
     L.orc_sort_by_key.argtypes = [vp, vp, C.c_uint32]; L.orc_sort_by_key.restype = None
     L.orc_clz64.argtypes = [C.c_uint64]; L.orc_clz64.restype = C.c_int
@@ -98,6 +100,21 @@ def expand64(v: int) -> int:
 def morton3d(x, y, z, off=REF_OFF, span=REF_SPAN) -> int:
     off = np.ascontiguousarray(off, dtype=np.float64); span = np.ascontiguousarray(span, dtype=np.float64)
     return lib().orc_morton3d(x, y, z, _p(off), _p(span))
+
+
+def morton3d_batch(xyz, off=REF_OFF, span=REF_SPAN):
+    p = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    off = np.ascontiguousarray(off, dtype=np.float64); span = np.ascontiguousarray(span, dtype=np.float64)
+    keys = np.zeros(p.shape[0], dtype=np.uint64)
+    lib().orc_morton3d_batch(_p(p), p.shape[0], _p(off), _p(span), _p(keys))
+    return keys
+
+
+def expand64_batch(v):
+    a = np.ascontiguousarray(v, dtype=np.uint64).ravel()
+    out = np.zeros(a.shape[0], dtype=np.uint64)
+    lib().orc_expand64_batch(_p(a), a.shape[0], _p(out))
+    return out
 
 
 def centroid_morton(verts, vidx, off=REF_OFF, span=REF_SPAN, want_centroids=False):

@@ -954,3 +954,89 @@ def test_random_meshes_property():
                     parent, left, right, boxes, bounded = cd.export_tree()
                     assert np.array_equal(left, r["left"]) and np.array_equal(right, r["right"]) and np.array_equal(parent, r["parent"]), case
                     assert np.array_equal(boxes.view(np.uint64), r["boxes"].view(np.uint64)), case
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The code path bench.py times, at the sizes BASELINE.json names, against the oracle: cd_self_collide
+# with DEFAULT options -- fused build (k_build_block + k_cross_fused), half traversal (k_descend_half + k_exact), hybrid
+# sort -- two consecutive steps on one context (the second one runs on the scratch the first one cleaned: no memset),
+# then the same with the options bench.py sets for its timed region (no stage events, only the descent's time stamps).
+_ORACLE_CACHE = {}
+
+
+def _baseline_config(name):
+    if name not in _ORACLE_CACHE:
+        verts, vidx = synth.soup(100_000, 0.02, 1234) if name == "config2-100k-soup" else synth.cloth_pair(500)
+        _ORACLE_CACHE[name] = (verts, vidx, oracle.pipeline(verts, vidx))
+    return _ORACLE_CACHE[name]
+
+
+@pytest.mark.parametrize("config", ["config2-100k-soup", "config3-1M-cloth"])
+def test_benched_path_default_options_matches_oracle_at_baseline_size(config):
+    verts, vidx, r = _baseline_config(config)
+    want_set = oracle.pair_set(r["pairs"])
+    assert r["stats"].n_pairs > 1000
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        for phase in ("default", "default-2nd-step", "bench-options", "bench-options-2nd-step"):
+            if phase == "bench-options":
+                cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0)
+                cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 2)
+            pairs, n, rc = cd.self_collide(cap=1 << 22)
+            st = cd.stats()
+            assert rc == 0 and n == r["stats"].n_pairs, (phase, n)
+            assert st.pairs_tested == r["stats"].pairs_tested, phase
+            assert np.array_equal(oracle.pair_set(pairs), want_set), phase
+            assert (pairs[:, 0] < pairs[:, 1]).all()
+            assert st.sort_passes == 2 and st.stack_overflows == 0, phase            # hybrid sort, no deep pass: the benched kernels
+            keys, perm = cd.export_keys()
+            assert np.array_equal(keys, r["keys"]) and np.array_equal(perm, r["perm"]), phase
+        # the tree the LAST fused step walked, as the descent reads it: byte-equal to the stage-wise build's records
+        fused_records = cd.debug_records() + (cd.root_box(),)
+        # ... and on request the reference-shaped tree (k_hierarchy + FP64 refit on the same sorted keys) equals the oracle's
+        parent, left, right, boxes, bounded = cd.export_tree()
+    assert np.array_equal(left, r["left"]) and np.array_equal(right, r["right"]) and np.array_equal(parent, r["parent"])
+    assert np.array_equal(boxes.view(np.uint64), r["boxes"].view(np.uint64)) and (bounded == 2).all()
+    with mi355cd.CollisionDetector(verts, vidx) as cd0:
+        cd0.set_option(104, 1)                                  # stage-wise build (proven against the oracle link by link above)
+        cd0.build_tree()
+        _compare_records(vidx.shape[0], fused_records, cd0.debug_records() + (cd0.root_box(),))
+
+
+# Reference-COMPILED Morton vectors (tests/golden/morton_ref.npz, made by the reference's morton.h in the build container;
+# see tests/test_oracle_pins.py) against the device functions and against the keys of BASELINE config 3.
+import morton_inputs as mi  # noqa: E402
+
+
+def test_device_morton_equals_reference_compiled_vectors():
+    ref = np.load(os.path.join(GOLD, "morton_ref.npz"))
+    v = mi.expand_inputs()
+    assert mi.sha(v) == str(ref["expand_in_sha"])
+    assert np.array_equal(mi355cd.expand64_values(v), ref["expand_out"])                      # morton.h:7-29, 131 072 values
+    pts = mi.frame_points()
+    assert mi.sha(pts) == str(ref["points_in_sha"])
+    keys = mi355cd.morton3d_points(pts)                                                        # morton.h:70-89, 1 048 576 points
+    assert np.array_equal(keys[:mi.N_FULL], ref["points_keys_head"])
+    assert np.array_equal(keys[::mi.SAMPLE_STRIDE], ref["points_keys_sample"])
+    assert mi.sha(keys) == str(ref["points_keys_sha"])
+    assert mi355cd.morton3d_points(ref["anchor_points"]).tolist() == [384255804010903211, 1008806316530991104]
+    # a custom frame equal to the reference's constants is the same function
+    assert np.array_equal(mi355cd.morton3d_points(pts[:4096], mi.REF_OFF, mi.REF_SPAN), keys[:4096])
+
+
+def test_config3_sorted_keys_equal_reference_compiled_keys():
+    """The keys cd_self_collide sorts for BASELINE config 3 are the reference's morton3D of the reference's centroids
+    (load_obj.h:89-101), all 1 000 000 of them, and the permutation is the stable order of those keys."""
+    ref = np.load(os.path.join(GOLD, "morton_ref.npz"))
+    cen, verts, vidx = mi.cloth_centroids(500)
+    assert mi.sha(verts) == str(ref["cloth_verts_sha"]) and mi.sha(cen) == str(ref["cloth_centroids_sha"])
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        pairs, n, rc = cd.self_collide(cap=1 << 22)
+        keys, perm = cd.export_keys()
+    assert rc == 0
+    assert np.array_equal(keys[::mi.SAMPLE_STRIDE], ref["cloth_sorted_sample"])
+    assert mi.sha(keys) == str(ref["cloth_sorted_sha"])
+    assert [int(keys[0]), int(keys[-1])] == ref["cloth_first_last"].tolist()
+    unsorted = mi355cd.morton3d_points(cen)
+    assert mi.sha(unsorted) == str(ref["cloth_keys_sha"])
+    assert np.array_equal(unsorted[perm], keys) and np.array_equal(np.sort(perm), np.arange(perm.size, dtype=np.uint32))
+    assert int(ref["cloth_distinct"]) == 1_000_000                  # all keys distinct: the permutation is unique

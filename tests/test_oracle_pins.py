@@ -242,3 +242,72 @@ def test_animation_oracle_basics():
     assert np.allclose(np.abs(an.angles), 3.1415926535898 / 12)
     an.axis_move(35)
     assert ((an.shifts[:, :2] >= 0) & (an.shifts[:, :2] < 35)).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Reference-COMPILED pin of rows a3 / a4 (and the key half of a5): tests/golden/morton_ref.npz holds outputs of the
+# reference's own morton.h (expand64Bits :7-29, normX/Y/Z :43-58, morton3D :70-89), compiled unmodified into
+# oracle/_ref/libref_morton.so in the build container (oracle/Makefile, tests/golden/make_morton_ref.py).  The inputs
+# are recipes (tests/morton_inputs.py) whose SHA-256 the fixture records.
+import morton_inputs as mi  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def morton_ref():
+    return np.load(os.path.join(GOLD, "morton_ref.npz"))
+
+
+def test_ref_compiled_expand64(morton_ref):
+    v = mi.expand_inputs()
+    assert mi.sha(v) == str(morton_ref["expand_in_sha"])
+    want = morton_ref["expand_out"]
+    assert v.size >= 100000 and want.shape == v.shape
+    assert np.array_equal(oracle.expand64_batch(v), want)
+    assert [oracle.expand64(int(x)) for x in v[:256]] == want[:256].tolist()          # the scalar entry point too
+
+
+def test_ref_compiled_anchors(morton_ref):
+    # the two anchors SURVEY.md recorded, as the reference's own object code computes them
+    assert morton_ref["anchor_keys"].tolist() == [384255804010903211, 1008806316530991104]
+    a = morton_ref["anchor_points"]
+    assert [oracle.morton3d(*a[0]), oracle.morton3d(*a[1])] == morton_ref["anchor_keys"].tolist()
+
+
+def test_ref_compiled_morton3d_points(morton_ref):
+    """All 2^20 in-frame points (float-valued, full doubles, cell boundaries +- 1 ulp, frame faces) through orc_morton3d:
+    the head in full, every 64th key, and the SHA-256 of all keys equal the reference-compiled ones."""
+    pts = mi.frame_points()
+    assert pts.shape[0] >= 1000000 and mi.sha(pts) == str(morton_ref["points_in_sha"])
+    keys = oracle.morton3d_batch(pts)
+    assert np.array_equal(keys[:mi.N_FULL], morton_ref["points_keys_head"])
+    assert np.array_equal(keys[::mi.SAMPLE_STRIDE], morton_ref["points_keys_sample"])
+    assert mi.sha(keys) == str(morton_ref["points_keys_sha"])
+    assert int(keys.max()) < (1 << 60) and np.unique(keys >> np.uint64(57)).size == 8      # in-frame keys: 60 bits, every top octant hit
+
+
+def test_ref_compiled_config3_keys(morton_ref):
+    """BASELINE config 3: centroids (load_obj.h:89-101 operand order) -> morton3D, all 1 000 000 keys, through the oracle's
+    own centroid + key loop (orc_centroid_morton), compared by SHA-256 with the reference-compiled keys; and sorted."""
+    cen, verts, vidx = mi.cloth_centroids(500)
+    assert mi.sha(verts) == str(morton_ref["cloth_verts_sha"]) and mi.sha(vidx) == str(morton_ref["cloth_vidx_sha"])
+    keys, ocen = oracle.centroid_morton(verts, vidx, want_centroids=True)
+    assert mi.sha(ocen) == str(morton_ref["cloth_centroids_sha"])          # the oracle's centroids == the ones the reference keys were made from
+    assert np.array_equal(keys[::mi.SAMPLE_STRIDE], morton_ref["cloth_keys_sample"])
+    assert mi.sha(keys) == str(morton_ref["cloth_keys_sha"])
+    sk, _ = oracle.sort_by_key(keys)
+    assert np.array_equal(sk[::mi.SAMPLE_STRIDE], morton_ref["cloth_sorted_sample"])
+    assert mi.sha(sk) == str(morton_ref["cloth_sorted_sha"])
+    assert [int(sk[0]), int(sk[-1])] == morton_ref["cloth_first_last"].tolist()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "libref_morton.so")),
+                    reason="oracle/_ref exists only in the build container (the reference does not travel)")
+def test_fixture_is_what_the_reference_build_produces_now(morton_ref, tmp_path):
+    """Build container only: the committed fixture equals a fresh run of the reference-compiled library."""
+    import ctypes as C
+    L = C.CDLL(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "libref_morton.so"))
+    pts = mi.frame_points()
+    k = np.zeros(pts.shape[0], dtype=np.uint64)
+    L.ref_morton3D.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]; L.ref_morton3D.restype = None
+    L.ref_morton3D(pts.ctypes.data_as(C.c_void_p), pts.shape[0], k.ctypes.data_as(C.c_void_p))
+    assert mi.sha(k) == str(morton_ref["points_keys_sha"])
