@@ -100,26 +100,55 @@ def cpu_baseline(verts, vidx, reps=3):
     return out
 
 
-def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5):
+def parity_check(pairs, tested, verts, vidx, ids=None, off=None, span=None, own_id_range=None):
+    """Checker leg (after the timed region, never inside it): the pair SET and the pairs-tested count of the LAST timed step
+    against the CPU oracle's on the same input (collision.cuh:19-88, tri_contact.cuh:80-87).  own_id_range (multi-GPU): the
+    oracle ran on this rank's mesh merged with its lower neighbour's; the rank owns the pairs whose LARGER id is its own."""
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    kw = {} if off is None else {"off": off, "span": span}
+    want, st, _ = oracle.self_collide(verts, vidx, ids, want_pairs=True, threads=1, **kw)
+    if own_id_range is not None:
+        lo, hi = own_id_range
+        want = want[(want[:, 1] >= lo) & (want[:, 1] < hi)]
+    got_set, want_set = oracle.pair_set(pairs), oracle.pair_set(want)
+    out = {"pairs_equal": bool(np.array_equal(got_set, want_set)), "n_pairs": int(got_set.size), "oracle_n_pairs": int(want_set.size),
+           "pair_set_sha256": hashlib.sha256(got_set.tobytes()).hexdigest()[:16], "oracle_pair_set_sha256": hashlib.sha256(want_set.tobytes()).hexdigest()[:16]}
+    if own_id_range is None:
+        out["pairs_tested_equal"] = bool(int(tested) == int(st.pairs_tested))
+        out["pairs_tested"] = int(tested); out["oracle_pairs_tested"] = int(st.pairs_tested)
+    out["ok"] = out["pairs_equal"] and out.get("pairs_tested_equal", True)
+    return out
+
+
+def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5, rank=0, world=1, dist=None, torch=None, device=None):
     """Secondary path (BASELINE config 5): 4096^2 image, 4096 spheres, frame kept on the device (the reference
-    copies every frame to the host for glDrawPixels, anime_ray.cu:128-131; that PCIe copy is not kernel time)."""
+    copies every frame to the host for glDrawPixels, anime_ray.cu:128-131; that PCIe copy is not kernel time).
+    world > 1: REPLICAS ONLY -- spheres replicated, rank r renders image rows [r, r+1) * dim / world (rt_render_rows), no
+    collective on the data path; frames/s = frames all ranks finished / max-over-ranks wall time.  The row slabs going to the
+    host (the reference's per-frame D2H) and their assembly on rank 0 (a host-side gather over a gloo group) are timed separately.
+    Every rank checks 64 rows of its slab against the oracle (the whole frame takes the CPU minutes)."""
     import statistics
     import mi355_synth as synth
     import mi355rt
     spheres, shifts = synth.sphere_scene(n_spheres, dim, seed=7)
-    out = {"workload": f"{dim}x{dim} RGBA8 frame, {n_spheres} spheres (BASELINE config 5), pixel-exact vs oracle in tests/test_rt_gpu.py"}
+    rows = (rank * dim // world, (rank + 1) * dim // world)
+    out = {"workload": f"{dim}x{dim} RGBA8 frame, {n_spheres} spheres (BASELINE config 5)" + (f", image rows sharded over {world} replicas (spheres replicated, no collective)" if world > 1 else "")}
     with mi355rt.RayTracer(spheres, dim) as rt:
         for name, mode in (("binned", mi355rt.RT_MODE_BINNED), ("brute", mi355rt.RT_MODE_BRUTE)):
+            if world > 1 and name == "brute":
+                continue
             rt.set_mode(mode)
-            rt.render(shifts, download=False)
+            rt.render(shifts, rows=rows, download=False)
             ms = []
             for _ in range(frames):
-                rt.render(shifts, download=False)
+                rt.render(shifts, rows=rows, download=False)
                 ms.append(rt.stats().ms_render)
             st = rt.stats()
             m = statistics.median(ms)
             out[name] = {"ms_per_frame": m, "sphere_tests_per_frame": int(st.sphere_tests), "sphere_tests_per_s": st.sphere_tests / (m * 1e-3)}
-            if mode == mi355rt.RT_MODE_BINNED:
+            if mode == mi355rt.RT_MODE_BINNED and world == 1:
                 # 16 frames queued back to back (time stamps on the first and the last kernel only): what a loop that does not come back
                 # to the host per frame sees -- a single frame's two stamps cost it ~5 us of idle GPU between its two kernels
                 rb = []
@@ -127,10 +156,47 @@ def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5):
                     rt.render_repeat(shifts, 16, download=False)
                     rb.append(rt.stats().ms_render)
                 out[name]["ms_per_frame_back_to_back"] = statistics.median(rb)
-    frame_bytes = dim * dim * 4 + n_spheres * 32
+        rt.set_mode(mi355rt.RT_MODE_BINNED)
+        if world > 1:
+            # whole-job frame rate: K frames per rank (its rows), barrier + synchronize both sides, max over ranks
+            kf = 50
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(kf):
+                rt.render(shifts, rows=rows, download=False)
+            torch.cuda.synchronize(); dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out["frames_per_s_whole_job"] = kf / float(t.item())
+            out["ms_per_frame_wall_max_over_ranks"] = float(t.item()) * 1e3 / kf
+            t0 = time.perf_counter()
+            slab = rt.render(shifts, rows=rows, download=True)           # + D2H of the rank's slab (anime_ray.cu:128-131)
+            t_d2h = time.perf_counter() - t0
+            g = dist.new_group(backend="gloo")
+            slabs = [torch.empty((rows[1] - rows[0], dim, 4), dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+            t0 = time.perf_counter()
+            dist.gather(torch.from_numpy(slab), slabs, dst=0, group=g)
+            t_gather = time.perf_counter() - t0
+            out["row_slab_render_plus_d2h_ms"] = t_d2h * 1e3
+            out["row_slab_gather_on_host_ms"] = t_gather * 1e3
+        else:
+            slab = rt.render(shifts, rows=rows, download=True)
+        # checker: 64 rows of this rank's slab against the oracle (sphere.cuh:34-44, anime_ray.cu:61-87)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle
+        y0 = rows[0] + ((rows[1] - rows[0]) // 2 // 64) * 64
+        want = oracle.rt_render(spheres, shifts, dim, rows=(y0, y0 + 64))
+        ok = bool(np.array_equal(slab[y0 - rows[0]: y0 - rows[0] + 64], want[y0:y0 + 64] if want.shape[0] == dim else want))
+        if world > 1:
+            f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            ok = bool(int(f.item()))
+        out["parity_checked"] = ok
+        out["parity_note"] = f"rows [{y0}, {y0 + 64}) of every rank's slab pixel-equal to the CPU oracle" + (" (MIN over ranks)" if world > 1 else "") + "; whole frames in tests/test_rt_gpu.py"
+    frame_bytes = (rows[1] - rows[0]) * dim * 4 + n_spheres * 32
     a = frame_bytes / (out["binned"]["ms_per_frame"] * 1e-3) / 1e9
     out["roofline"] = {"bound": "hbm", "kernel": "k_render<binned>", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                       "algorithmic_bytes_per_launch": frame_bytes}
+                       "algorithmic_bytes_per_launch": frame_bytes, "note": "per GPU (its rows)"}
     return out
 
 
@@ -141,6 +207,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--quads", type=int, default=500, help="quads per sheet edge; 500 -> 1 000 000 triangles per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the last timed step's pair set")
     ap.add_argument("--no-ray", action="store_true", help="skip the secondary ray-tracer measurement (BASELINE config 5)")
     ap.add_argument("--traversal", type=int, default=None, help="CD_OPT_TRAVERSAL override (0 lane-private FP64, 1 wave-queued)")
     ap.add_argument("--qpw", type=int, default=None, help="CD_OPT_QUERIES_PER_WAVE override")
@@ -235,7 +302,7 @@ def main():
     if not multi_path:
         engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 2)
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
-    stage = {"morton": 0.0, "sort": 0.0, "hierarchy": 0.0, "refit": 0.0, "traverse": 0.0}
+    stage = {"morton": 0.0, "sort": 0.0, "build_fused(hierarchy+refit+records)": 0.0, "traverse": 0.0}
     kern = {"descend": 0.0, "exact": 0.0, "build_block": 0.0}            # the two kernels inside "traverse" + the fused hierarchy / refit kernel
     tested_total = 0
     pairs_found = 0
@@ -258,6 +325,8 @@ def main():
     if multi_path:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    last_pairs = np.array(pairs, copy=True)                           # the LAST TIMED step's output (the buffer is reused below): what parity_check sees
+    last_tested = tested
     if multi_path:
         rdev = device if backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
@@ -277,6 +346,12 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "triangles_per_gpu": int(nt), "pairs_tested_per_step": tested_total // k,
                        "colliding_pairs": int(pairs_found), "sharding": "by object" if multi_path else "none"},
+            # `value` counts what the reference counts: (query, leaf) pairs whose AABBs strictly overlap, every unordered leaf pair TWICE
+            # (collision.cuh:31-44 lets each leaf query the whole tree).  The default half traversal decides each unordered pair ONCE and
+            # credits 2 (box.cuh:40-43 and neighborCount are symmetric; equal to the oracle's counter in every test): the device executes
+            # half as many exact box decisions as `value` says
+            "pairs_tested_counting": "reference-equivalent: the half traversal decides each unordered leaf pair once and credits the 2 ordered tests the reference makes",
+            "box_decisions_executed_per_step": (tested_total // k) // (1 if args.traversal in (0, 1, 2) else 2),
         }
         if not multi_path:
             prof_steps = min(k, 20)
@@ -290,8 +365,9 @@ def main():
             for _ in range(prof_steps):
                 step()
                 st = engine.cd.stats()
-                stage["morton"] += st.ms_morton; stage["sort"] += st.ms_sort; stage["hierarchy"] += st.ms_hierarchy
-                stage["refit"] += st.ms_refit; stage["traverse"] += st.ms_traverse
+                stage["morton"] += st.ms_morton; stage["sort"] += st.ms_sort
+                stage["build_fused(hierarchy+refit+records)"] += st.ms_hierarchy + st.ms_refit      # one pass: k_build_block + k_cross_fused (ms_hierarchy is 0 on the fused path)
+                stage["traverse"] += st.ms_traverse
             for s in stage:
                 stage[s] /= prof_steps
             dev_total = pipeline_ms / k
@@ -308,7 +384,6 @@ def main():
             # (profiles/traffic.json, produced by tools/refresh_profiles.sh + tools/summarise_profiles.py).
             for k_ in kern:
                 kern[k_] /= k
-            dominant = max(stage, key=stage.get)
             traffic_of = {}
             l2_of = {}
             whole_traffic = None
@@ -318,14 +393,17 @@ def main():
                 if tj.get("triangles") == nt:
                     whole_traffic = tj.get("whole_path_hbm_bytes_per_step")
                     for name, v in tj.get("whole_path_per_kernel", {}).items():
-                        traffic_of[name] = v.get("hbm_bytes_per_step")
+                        traffic_of[name] = v
                     l2_of["k_descend_half"] = tj.get("l2_hit_rate")
 
             def roof(symbol, label, ms, bytes_per_tri):
                 ach = bytes_per_tri * nt / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-                tr = next((v for kk, v in traffic_of.items() if symbol in kk), None)
+                tr = next((v for kk, v in traffic_of.items() if symbol in kk), None) or {}
                 return {"bound": "hbm", "kernel": label, "kernel_symbol": symbol, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": tr, "l2_hit_rate": l2_of.get(symbol),
+                        "frac": ach / HBM_PEAK_GBS, "traffic": tr.get("hbm_bytes_per_step"), "traffic_raw": tr.get("hbm_bytes_per_step_raw"),
+                        "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of an earlier run of this command; NOT measured in this run): "
+                                          "traffic = FETCH_SIZE corrected as calibrated for this kernel's request mix + WRITE_SIZE, traffic_raw = FETCH_SIZE as reported + WRITE_SIZE",
+                        "l2_hit_rate": l2_of.get(symbol),
                         "algorithmic_bytes_per_launch": bytes_per_tri * nt, "avg_launch_ms": ms}
 
             cands = [roof("k_descend_half", "k_descend_half (fp32 BVH descent, half traversal; its candidates go to k_exact)", kern["descend"], TRAVERSAL_BYTES_PER_TRI),
@@ -336,10 +414,14 @@ def main():
             line["kernel_ms_note"] = (f"descend: live, over the {k} timed steps (time stamps on the kernel's dispatch packet); exact, build_block and "
                                       f"total_collision_ms_device: from {prof_steps} extra untimed steps with all stamps on (each stamp costs ~5 us of idle GPU)")
             line["roofline"] = dict(cands[0])
-            line["roofline"]["dominant_stage"] = dominant
             line["roofline"]["other_kernels"] = cands[1:]
             line["roofline"]["whole_path"] = {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9,
                                               "frac": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": whole_traffic}
+            if not args.no_parity:
+                # checker leg: the LAST TIMED step's pair set + pairs-tested count against the oracle (one more CPU pass, with pairs)
+                pc = parity_check(last_pairs, last_tested, verts, vidx)
+                line["parity_checked"] = pc["ok"]
+                line["parity"] = pc
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(verts, vidx)
                 line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
@@ -347,10 +429,32 @@ def main():
                     line["speedup_vs_cpu_allcores"] = line["value"] / line["cpu_baseline"]["omp"]["value"]
                     line["speedup_note"] = (f"reported baselines, not targets: 1 core of the box, and the best OpenMP thread count "
                                             f"({line['cpu_baseline']['omp']['cores']}) this process' CPU share supports")
-            if not args.no_ray:
-                line["ray_tracer"] = ray_tracer_measurement()
         else:
             line["config"]["last_step_rank0"] = info
+    if multi_path and not args.no_parity:
+        # checker leg on EVERY rank: the oracle on this rank's mesh merged with its lower neighbour's (the only rank whose triangles have
+        # smaller ids and overlap this one's); the rank owns exactly the oracle pairs whose larger id is its own (tri_contact.cuh:81)
+        if self_peer:
+            pc = parity_check(last_pairs[: len(last_pairs) // 2], None, verts, vidx, ids, own_id_range=(0, 1 << 32))
+        else:
+            mv, mt, mi_ = [verts], [vidx], [ids]
+            if rank > 0:
+                lv, lt, li, _ = synth.cloth_shard(rank - 1, args.quads)
+                mv, mt, mi_ = [lv, verts], [lt, vidx + np.uint32(lv.shape[0])], [li, ids]
+            allv = np.concatenate(mv); allt = np.concatenate(mt).astype(np.uint32); alli = np.concatenate(mi_).astype(np.uint32)
+            cen = (allv[allt[:, 0]] + allv[allt[:, 1]] + allv[allt[:, 2]]) / 3
+            off = cen.min(0); span = (cen.max(0) - off) * (1.0 + 1.0 / 1048576.0)
+            pc = parity_check(last_pairs, None, allv, allt, alli, off=off, span=span, own_id_range=(int(ids[0]), int(ids[-1]) + 1))
+        f = torch.tensor([1 if pc["ok"] else 0], dtype=torch.int32, device=device if backend == "nccl" else torch.device("cpu"))
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            line["parity_checked"] = bool(int(f.item()))
+            line["parity"] = dict(pc, note="rank 0's own check shown; parity_checked = MIN over ranks: every rank's pair list of the last timed step == "
+                                           "the oracle's pairs (on the rank's mesh merged with its lower neighbour's) whose larger id the rank owns")
+    if not args.no_ray and not self_peer and (backend == "nccl" or not multi_path):
+        rtm = ray_tracer_measurement(rank=rank, world=world if multi_path else 1, dist=dist if multi_path else None, torch=torch, device=device)
+        if rank == 0:
+            line["ray_tracer"] = rtm
     if multi_path:
         # which transport ran, what the communicator saw, and where the time goes (max over ranks of each phase, from a
         # few extra untimed steps with HIP events at the phase boundaries)

@@ -22,6 +22,16 @@
 // Host synchronisations per step: two (the count matrix -- with the GPU busy on A; both traversal passes).  A sort that
 // must be redone in another form is local: the rank repeats its pipeline and the cross pass alone, after the collectives.
 //
+// Failing TOGETHER.  A rank that fails locally must not leave its peers waiting in a collective it never joins.  Every row of the
+// count matrix therefore carries a STATUS word (slot W; 0 = fine): a rank whose own work has failed up to the point where the
+// rows are all-gathered -- allocation, launch, its own pipeline's enqueue, an error kept from the previous step -- still joins
+// both all-gathers, packs nothing and publishes its error; after the one read of the matrix EVERY rank sees it, nobody posts a
+// send or a receive, and all return in the same step: the failing rank its own error, the others CD_ERR_PEER.  Nothing is
+// allocated between the matrix and the exchange (the receive buffer is sized with the send slabs, the per-peer capacity is
+// COMMON to all ranks from creation on and grows by a rule of the whole matrix), so the decision taken from the matrix is the
+// last one that can differ; an error after it (an RCCL call, the final wait) closes the group it has opened, is returned, and is
+// KEPT: the rank's next cd_multi_step publishes it, so the peers of a caller that goes on learn of it one step later.
+//
 // RCCL is loaded at run time (dlopen) by the first cd_multi_* call, so single-GPU users of the library do not pay for
 // it; there is no fallback transport: without librccl the calls return CD_ERR_RCCL.
 #pragma once
@@ -91,6 +101,7 @@ RcclApi *rccl()
 // rehearsal only (CD_MULTI_SELF_SLICE): the box the rank sees of ITSELF as a peer keeps the upper tenth of its x extent --
 // about the share of its triangles a config-4 neighbour's box covers
 __global__ void k_slice_box(double *box) { box[0] = box[1] - 0.1 * (box[1] - box[0]); }
+__global__ void k_set_word(unsigned long long *w, unsigned long long v) { *w = v; }
 
 enum MEv { ME_START, ME_LOC0, ME_TREE, ME_GATHER, ME_PACK, ME_COUNTS, ME_XCH0, ME_XCH1, ME_LOCAL, ME_CROSS, ME_COUNT };
 
@@ -100,18 +111,20 @@ struct cd_multi {
     cd_ctx *c = nullptr;
     ncclComm_t comm = nullptr; bool own_comm = false;
     int rank = 0, world = 1, flags = 0;
-    uint64_t qcap = 0;                           // records per peer slab -- the SAME on every rank (grown from the shared count matrix)
-    hipStream_t xstream = nullptr;               // payload exchange, beside the context's stream
+    uint64_t qcap = 0;                           // records per peer slab -- the SAME on every rank (max of the ranks' requests at creation, grown from the shared count matrix)
+    int sticky_err = 0;                          // an error met AFTER the last collective decision of a step: published by the next step's status word
+    hipStream_t xstream = nullptr;               // payload exchange, beside the context's stream; HIGHEST priority: its kernels (RCCL's send / receive,
+                                                 // the pass over the received queries) are not queued behind a tree build that fills every CU
     hipEvent_t ev_payload = nullptr, ev_counts = nullptr, ev_tree = nullptr, ev_cross = nullptr, ev_box = nullptr, ev[ME_COUNT] = {};
     double *d_myroot = nullptr;                  // 6: the box of all this rank's triangles, from their vertices
     double *d_partial = nullptr;                 // per-block bounds of that reduction (the context's own are the first stream's, for its Morton frame)
     double *d_roots = nullptr;                   // world x 6
-    unsigned long long *d_row = nullptr;         // world: records packed for each peer
-    unsigned long long *d_matrix = nullptr;      // world x world, all-gathered rows
+    unsigned long long *d_row = nullptr;         // world + 1: records packed for each peer | this rank's status word
+    unsigned long long *d_matrix = nullptr;      // world x (world + 1), all-gathered rows
     unsigned long long *h_matrix = nullptr;      // pinned copy
     double *h_roots = nullptr;                   // pinned, world x 6
     ExtQuery *d_send = nullptr;                  // world slabs of qcap records
-    ExtQuery *d_recv = nullptr; uint64_t recv_cap = 0;
+    ExtQuery *d_recv = nullptr;                  // world x qcap as well: whatever the peers send fits (allocated WITH the slabs, never between matrix and exchange)
     std::vector<uint32_t> scratch_pairs;
 };
 
@@ -120,7 +133,7 @@ namespace {
 void multi_free(cd_multi *m)
 {
     if (!m) return;
-    if (m->c) hipStreamSynchronize(m->c->stream);
+    if (m->c) { hipStreamSynchronize(m->c->stream); if (m->c->attached_multi == m) m->c->attached_multi = nullptr; }
     if (m->xstream) { hipStreamSynchronize(m->xstream); hipStreamDestroy(m->xstream); }
     if (m->ev_payload) hipEventDestroy(m->ev_payload);
     if (m->ev_counts) hipEventDestroy(m->ev_counts);
@@ -138,7 +151,9 @@ void multi_free(cd_multi *m)
 int multi_alloc(cd_multi *m)
 {
     const size_t W = (size_t)m->world;
-    HIPCHK(hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking));
+    { int least = 0, greatest = 0;
+      HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      HIPCHK(hipStreamCreateWithPriority(&m->xstream, hipStreamNonBlocking, greatest)); }
     HIPCHK(hipEventCreateWithFlags(&m->ev_payload, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&m->ev_tree));                                                    // (a kernel's stop event: with time stamps)
@@ -152,7 +167,6 @@ int multi_alloc(cd_multi *m)
     HIPCHK(hipMalloc(&m->d_matrix, sizeof(unsigned long long) * W * (W + 1)));
     HIPCHK(hipHostMalloc(&m->h_matrix, sizeof(unsigned long long) * W * (W + 1), hipHostMallocDefault));
     HIPCHK(hipHostMalloc(&m->h_roots, sizeof(double) * 6 * W, hipHostMallocDefault));
-    HIPCHK(hipMalloc(&m->d_send, sizeof(ExtQuery) * W * m->qcap));
     // the external pass has its own counters, candidates, pairs and deferred list (TravBuf [1])
     TravBuf &tb = m->c->tb[1];
     if (!tb.d_state) { HIPCHK(hipMalloc(&tb.d_state, sizeof(TravState))); tb.state_owned = true; }
@@ -161,7 +175,29 @@ int multi_alloc(cd_multi *m)
     return CD_OK;
 }
 
+// the send slabs and the receive buffer, both world x qcap records: (re)allocated together, only where a failure can still be
+// published through the status word of the NEXT all-gather
+int multi_slabs(cd_multi *m)
+{
+    hipFree(m->d_send); hipFree(m->d_recv); m->d_send = nullptr; m->d_recv = nullptr;
+    HIPCHK(hipMalloc(&m->d_send, sizeof(ExtQuery) * (size_t)m->world * m->qcap));
+    HIPCHK(hipMalloc(&m->d_recv, sizeof(ExtQuery) * (size_t)m->world * m->qcap));
+    return CD_OK;
+}
+
 }  // namespace
+
+// cd_destroy with a cd_multi still attached: the multi step's state is released first (its streams wait for the context's), the
+// cd_multi object itself stays valid for cd_multi_destroy and refuses further steps (CD_ERR_ORDER)
+void multi_detach_from(cd_ctx *c)
+{
+    cd_multi *m = c->attached_multi;
+    if (!m) return;
+    hipStreamSynchronize(c->stream);
+    if (m->xstream) hipStreamSynchronize(m->xstream);
+    m->c = nullptr;
+    c->attached_multi = nullptr;
+}
 
 extern "C" {
 
@@ -181,8 +217,29 @@ static int multi_create_common(cd_multi **out, cd_ctx *ctx, ncclComm_t comm, boo
     if (!m) return CD_ERR_ARG;
     m->c = ctx; m->comm = comm; m->own_comm = own; m->rank = rank; m->world = world; m->flags = flags;
     m->qcap = query_cap_per_peer ? query_cap_per_peer : (uint64_t)(ctx->nt / 8 + 1024);
-    const int rc = multi_alloc(m);
-    if (rc) { multi_free(m); return rc; }
+    int rc = multi_alloc(m);
+    // The per-peer capacity must be the SAME on every rank (the decision to grow it is taken by all from the shared matrix):
+    // shards of unequal size -- or callers with different arguments -- would start with different values, so the ranks agree
+    // on the largest request here, once (creation is a collective already: ncclCommInitRank).  A rank whose allocations failed
+    // still joins (with 0), so nobody waits for it; it then returns its error.
+    RcclApi *r = rccl();
+    if (r && m->xstream && m->d_row && m->d_matrix && m->h_matrix) {
+        const unsigned long long mine = rc ? 0ull : (unsigned long long)m->qcap;
+        k_set_word<<<1, 1, 0, m->xstream>>>(m->d_row, mine);
+        const ncclResult_t ar = r->AllGather(m->d_row, m->d_matrix, 1, ncclUint64, m->comm, m->xstream);
+        hipError_t e = hipMemcpyAsync(m->h_matrix, m->d_matrix, sizeof(unsigned long long) * (size_t)world, hipMemcpyDeviceToHost, m->xstream);
+        if (e == hipSuccess) e = hipStreamSynchronize(m->xstream);
+        if (!rc && ar != ncclSuccess) rc = CD_ERR_RCCL;
+        if (!rc && e != hipSuccess) rc = -(int)e;
+        if (!rc) {
+            bool peer_failed = false;
+            for (int p = 0; p < world; ++p) { if (m->h_matrix[p] == 0) peer_failed = true; m->qcap = std::max<uint64_t>(m->qcap, m->h_matrix[p]); }
+            if (peer_failed) rc = CD_ERR_PEER;
+        }
+    } else if (!rc) rc = CD_ERR_RCCL;
+    if (!rc) rc = multi_slabs(m);
+    if (rc) { if (!own) m->comm = nullptr; multi_free(m); return rc; }     // (an owned communicator is destroyed by multi_free, ONCE)
+    ctx->attached_multi = m;
     *out = m;
     return CD_OK;
 }
@@ -191,21 +248,21 @@ int cd_multi_create(cd_multi **out, cd_ctx *ctx, const void *id128, int rank, in
 {
     if (!out || !ctx || !id128 || world < 1 || rank < 0 || rank >= world) return CD_ERR_ARG;
     *out = nullptr;
+    if (ctx->attached_multi) return CD_ERR_ORDER;                          // one cd_multi per context
     RcclApi *r = rccl();
     if (!r) return CD_ERR_RCCL;
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
     ncclComm_t comm = nullptr;
     NCCLCHK(r->CommInitRank(&comm, world, id, rank));
-    const int rc = multi_create_common(out, ctx, comm, true, rank, world, query_cap_per_peer, flags);
-    if (rc) r->CommDestroy(comm);
-    return rc;
+    return multi_create_common(out, ctx, comm, true, rank, world, query_cap_per_peer, flags);     // (on failure multi_free has destroyed the communicator)
 }
 
 int cd_multi_create_from_comm(cd_multi **out, cd_ctx *ctx, void *nccl_comm, uint64_t query_cap_per_peer, int flags)
 {
     if (!out || !ctx || !nccl_comm) return CD_ERR_ARG;
     *out = nullptr;
+    if (ctx->attached_multi) return CD_ERR_ORDER;
     RcclApi *r = rccl();
     if (!r) return CD_ERR_RCCL;
     int world = 0, rank = 0;
@@ -220,24 +277,39 @@ int cd_multi_set_flags(cd_multi *m, int flags) { if (!m) return CD_ERR_ARG; m->f
 
 int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs, cd_multi_info *info)
 {
-    if (!m || (cap_pairs && !pairs)) return CD_ERR_ARG;
+    if (!m) return CD_ERR_ARG;
+    if (!m->c) return CD_ERR_ORDER;                                           // the context was destroyed under this cd_multi
     RcclApi *r = rccl();
     if (!r) return CD_ERR_RCCL;
     cd_ctx *c = m->c;
     hipStream_t s = c->stream;
     const int W = m->world, me = m->rank;
+    const size_t RW = (size_t)W + 1;                                          // a row of the matrix: W counts | the rank's status word
     const bool self_peer = (m->flags & CD_MULTI_SELF_PEER) != 0, timing = (m->flags & CD_MULTI_TIMING) != 0;
     uint32_t syncs = 0, attempts = 0;
     auto mark = [&](int e, hipStream_t st) { if (timing) hipEventRecord(m->ev[e], st); };
+    if (info) std::memset(info, 0, sizeof *info);
+
+    // What has gone wrong on THIS rank so far.  From here to the read of the count matrix nothing returns: a rank with an error
+    // still joins both all-gathers (it packs nothing and publishes the error in its row), so that every rank leaves the step
+    // together -- see the header of this file.
+    int local_err = m->sticky_err;                                            // kept from the previous step: an error met after its last collective decision
+    m->sticky_err = 0;
+    if (!local_err && cap_pairs && !pairs) local_err = CD_ERR_ARG;
+    if (!local_err && (m->flags & CD_MULTI_INJECT_FAILURE)) local_err = CD_ERR_INJECTED;   // test hook: this rank's next step fails locally
+    m->flags &= ~CD_MULTI_INJECT_FAILURE;
+    auto late = [&](int rc) { m->sticky_err = rc; c->scratch_clean = false; hipStreamSynchronize(s); hipStreamSynchronize(m->xstream); return rc; };   // an error AFTER the decision: returned, and published by the next step
+#define LATE_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return late(-(int)e_); } while (0)
+#define SOFT_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess && !local_err) local_err = -(int)e_; } while (0)
 
     TravBuf &t0 = c->tb[0], &t1 = c->tb[1];
     const bool fast_path = c->trav_variant != 0;                              // (variant 0 has no candidate stage: take the general path)
     const uint64_t cap = cap_pairs;
     uint64_t spec0 = !pairs ? 0 : cap < SPEC_PAIRS ? cap : SPEC_PAIRS, spec1 = spec0;     // (enqueue_report clamps them the same way)
-    if (fast_path) {
+    if (fast_path && !local_err) {
         int rc = ensure_pairs(c, t0, cap > 0 ? cap : 1);
         if (!rc) rc = ensure_pairs(c, t1, cap > 0 ? cap : 1);
-        if (rc) return rc;
+        if (rc) local_err = rc;
     }
     const bool se = c->stage_events;
     struct RestoreStageEvents { cd_ctx *c; bool v; uint32_t mask; ~RestoreStageEvents() { c->stage_events = v; c->stamp_mask = mask; c->prezeroed = false; } } restore{c, se, c->stamp_mask};
@@ -286,76 +358,90 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     // vertices: the value node 0 of the tree will hold, known before there is a tree).  Then the step forks.  SECOND stream:
     // all-gather of the boxes, pack of the triangles that overlap each peer's box (from the triangles in their ORIGINAL
     // order), all-gather of the count matrix.  Order of issue on the host: the sort's launches (first stream: ~85 us of
-    // work to chew on), then the second stream's calls (RCCL's cost the host tens of microseconds), then tree and traversal.
+    // work to chew on), then the second stream's box / all-gather / pack (RCCL's calls cost the host tens of microseconds),
+    // then tree and traversal, then -- the rank's status being final only now -- the all-gather of the rows.
     // The pack streams the vertices while the sort's latency-bound passes leave the memory system idle.
     mark(ME_START, s);
     hipStream_t xs = m->xstream;
     // The box of the triangles is the SECOND stream's first job (its own pass over the vertices, its own partials): the first
     // stream starts the rank's pipeline at once and no event ties the two together before the tree is there (an event record
     // between two kernels of a stream is a barrier packet: ~6 us of idle GPU).
-    { const int rc = enqueue_sort(false); if (rc) return rc; }
+    if (!local_err) { const int rc = enqueue_sort(false); if (rc) local_err = rc; }
     k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, xs>>>(c->d_verts, c->d_vidx, c->nt, m->d_partial);
     k_frame_from_bounds<<<1, 256, 0, xs>>>(m->d_partial, BOUNDS_BLOCKS, nullptr, m->d_myroot);
     // (the counters of the pass over the received queries: zeroed here, where the second stream has time -- behind the exchange the
     //  memset would sit between the records' arrival and the pass, 8 us + a launch gap on the step's longest chain)
-    if (!(m->flags & CD_MULTI_CROSS_SERIAL)) HIPCHK(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), xs));
+    if (!(m->flags & CD_MULTI_CROSS_SERIAL)) SOFT_HIP(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), xs));
+    int failed_rank = -1;
+    unsigned long long failed_status = 0;
     for (;; ++attempts) {
-        if (attempts >= 6) return CD_ERR_ARG;
-        NCCLCHK(r->AllGather(m->d_myroot, m->d_roots, 6, ncclDouble, m->comm, xs));
+        if (r->AllGather(m->d_myroot, m->d_roots, 6, ncclDouble, m->comm, xs) != ncclSuccess && !local_err) local_err = CD_ERR_RCCL;
         if (self_peer && (m->flags & CD_MULTI_SELF_SLICE)) k_slice_box<<<1, 1, 0, xs>>>(m->d_roots + 6 * (size_t)me);   // rehearsal at config 4's scale
         mark(ME_GATHER, xs);
-        HIPCHK(hipMemsetAsync(m->d_row, 0, sizeof(unsigned long long) * (size_t)W, xs));
-        k_pack_triangles<<<cdiv(c->nt, PACK_THREADS), PACK_THREADS, 0, xs>>>(c->d_verts, c->d_vidx, c->d_ids, (int)c->nt, m->d_roots, W,
-                                                                              self_peer ? -1 : me, m->d_roots + 6 * (size_t)me,
-                                                                              m->d_send, (unsigned long long)m->qcap, m->d_row, c->vbase);
+        SOFT_HIP(hipMemsetAsync(m->d_row, 0, sizeof(unsigned long long) * RW, xs));
+        if (!local_err && m->d_send)
+            k_pack_triangles<<<cdiv(c->nt, PACK_THREADS), PACK_THREADS, 0, xs>>>(c->d_verts, c->d_vidx, c->d_ids, (int)c->nt, m->d_roots, W,
+                                                                                  self_peer ? -1 : me, m->d_roots + 6 * (size_t)me,
+                                                                                  m->d_send, (unsigned long long)m->qcap, m->d_row, c->vbase);
         mark(ME_PACK, xs);
-        NCCLCHK(r->AllGather(m->d_row, m->d_matrix, (size_t)W, ncclUint64, m->comm, xs));
-        HIPCHK(hipMemcpyAsync(m->h_matrix, m->d_matrix, sizeof(unsigned long long) * W * W, hipMemcpyDeviceToHost, xs));
-        HIPCHK(hipMemcpyAsync(m->h_roots, m->d_roots, sizeof(double) * 6 * W, hipMemcpyDeviceToHost, xs));
+        // the rank's own tree and traversal go to the first stream BEFORE its row is published: whatever their enqueue reports is in the status word
+        if (attempts == 0 && !local_err) { const int rc = enqueue_rest(); if (rc) local_err = rc; }   // (a repeat only grows the slabs and packs again: the pipeline in flight stays valid)
+        SOFT_HIP(hipGetLastError());
+        if (local_err) k_set_word<<<1, 1, 0, xs>>>(m->d_row + W, (unsigned long long)(uint32_t)(-local_err));
+        if (r->AllGather(m->d_row, m->d_matrix, RW, ncclUint64, m->comm, xs) != ncclSuccess && !local_err) local_err = CD_ERR_RCCL;
+        SOFT_HIP(hipMemcpyAsync(m->h_matrix, m->d_matrix, sizeof(unsigned long long) * W * RW, hipMemcpyDeviceToHost, xs));
+        SOFT_HIP(hipMemcpyAsync(m->h_roots, m->d_roots, sizeof(double) * 6 * W, hipMemcpyDeviceToHost, xs));
         mark(ME_COUNTS, xs);
-        HIPCHK(hipEventRecord(m->ev_counts, xs));
-        if (attempts == 0) { const int rc = enqueue_rest(); if (rc) return rc; }           // (a repeat only grows the slabs and packs again: the pipeline in flight stays valid)
-        HIPCHK(hipEventSynchronize(m->ev_counts)); ++syncs;                                // host synchronisation 1 of 2: the counts (the first stream keeps working)
-        HIPCHK(hipGetLastError());
-        // the one decision taken from the matrix is a function of the WHOLE matrix: identical on every rank
+        SOFT_HIP(hipEventRecord(m->ev_counts, xs));
+        SOFT_HIP(hipEventSynchronize(m->ev_counts)); ++syncs;                              // host synchronisation 1 of 2: the counts (the first stream keeps working)
+        // every decision taken from the matrix is a function of the WHOLE matrix: identical on every rank
+        for (int a = 0; a < W && failed_rank < 0; ++a) if (m->h_matrix[(size_t)a * RW + W]) { failed_rank = a; failed_status = m->h_matrix[(size_t)a * RW + W]; }
+        if (failed_rank >= 0 || local_err) break;                                          // (local_err without a published status: the all-gather itself failed here)
         unsigned long long mx = 0;
-        for (int a = 0; a < W * W; ++a) mx = std::max(mx, m->h_matrix[a]);
+        for (int a = 0; a < W; ++a) for (int p = 0; p < W; ++p) mx = std::max(mx, m->h_matrix[(size_t)a * RW + p]);
         if (mx <= m->qcap) break;
+        if (attempts >= 5) { failed_rank = W; break; }                                     // (the same count on every rank: they all give up here)
         m->qcap = mx + mx / 4 + 1024;                                                      // same rule, same input -> same capacity on every rank
-        hipFree(m->d_send); m->d_send = nullptr;
-        HIPCHK(hipMalloc(&m->d_send, sizeof(ExtQuery) * (size_t)W * m->qcap));
+        { const int rc = multi_slabs(m); if (rc) local_err = rc; }                         // (a failure here is published by the next round's status word)
     }
-    c->stage = ST_REFIT;
-    std::memcpy(c->root_box_host, m->h_roots + 6 * (size_t)me, sizeof(double) * 6); c->root_box_valid = true;
+    if (failed_rank >= 0 || local_err) {
+        // Some rank has failed (perhaps this one): NOBODY posts a send or a receive.  Whatever this rank has in flight drains; the next
+        // step starts from scratch.
+        hipStreamSynchronize(s); hipStreamSynchronize(xs);
+        (void)hipGetLastError();
+        c->scratch_clean = false; c->prezeroed = false;
+        if (info) { info->world = (uint32_t)W; info->rank = (uint32_t)me; info->host_syncs = syncs; info->attempts = attempts + 1; info->query_cap = m->qcap;
+                    info->failed_rank_plus1 = failed_rank >= 0 && failed_rank < W ? (uint32_t)failed_rank + 1u : 0u; }
+        if (n_pairs) *n_pairs = 0;
+        if (local_err) return local_err;
+        return failed_rank == W ? CD_ERR_ARG : CD_ERR_PEER;
+        (void)failed_status;
+    }
 
     // ---- 2: payload exchange on the second stream (everything it reads was complete at the synchronisation above)
     uint64_t sent = 0, recvd = 0; uint32_t n_peers = 0;
     std::vector<uint64_t> roff((size_t)W + 1, 0);
     for (int p = 0; p < W; ++p) {
-        const uint64_t from_p = m->h_matrix[(size_t)p * W + me];
+        const uint64_t from_p = m->h_matrix[(size_t)p * RW + me];
         roff[p + 1] = roff[p] + from_p;
-        const uint64_t to_p = m->h_matrix[(size_t)me * W + p];
+        const uint64_t to_p = m->h_matrix[(size_t)me * RW + p];
         sent += to_p; recvd += from_p;
         if (to_p || from_p) ++n_peers;
     }
-    if (recvd > m->recv_cap) {
-        hipFree(m->d_recv); m->d_recv = nullptr; m->recv_cap = 0;
-        const uint64_t want = recvd + recvd / 4 + 1024;
-        HIPCHK(hipMalloc(&m->d_recv, sizeof(ExtQuery) * want));
-        m->recv_cap = want;
-    }
+    // (recvd <= W x qcap: every count passed the capacity test above, and the receive buffer was allocated with the slabs)
     mark(ME_XCH0, m->xstream);
     if (sent || recvd) {
-        NCCLCHK(r->GroupStart());
+        bool bad = r->GroupStart() != ncclSuccess;
         for (int p = 0; p < W; ++p) {
-            const uint64_t to_p = m->h_matrix[(size_t)me * W + p], from_p = m->h_matrix[(size_t)p * W + me];
-            if (to_p) NCCLCHK(r->Send(m->d_send + (size_t)p * m->qcap, to_p * sizeof(ExtQuery), ncclChar, p, m->comm, m->xstream));
-            if (from_p) NCCLCHK(r->Recv(m->d_recv + roff[p], from_p * sizeof(ExtQuery), ncclChar, p, m->comm, m->xstream));
+            const uint64_t to_p = m->h_matrix[(size_t)me * RW + p], from_p = m->h_matrix[(size_t)p * RW + me];
+            if (to_p) bad |= r->Send(m->d_send + (size_t)p * m->qcap, to_p * sizeof(ExtQuery), ncclChar, p, m->comm, m->xstream) != ncclSuccess;
+            if (from_p) bad |= r->Recv(m->d_recv + roff[p], from_p * sizeof(ExtQuery), ncclChar, p, m->comm, m->xstream) != ncclSuccess;
         }
-        NCCLCHK(r->GroupEnd());
+        bad |= r->GroupEnd() != ncclSuccess;                                               // (a group that was opened is always closed)
+        if (bad) return late(CD_ERR_RCCL);
     }
     mark(ME_XCH1, m->xstream);
-    HIPCHK(hipEventRecord(m->ev_payload, m->xstream));
+    LATE_HIP(hipEventRecord(m->ev_payload, m->xstream));
 
     // ---- 3: the pass over the received queries, on the SECOND stream behind the exchange: it needs the records and the
     // tree, nothing of the local traversal -- the two descents share the chip and the latency-bound ends of the two passes
@@ -364,12 +450,12 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     int rc_l = CD_OK, rc_x = CD_OK;
     bool need_general_l = !fast_path, need_general_x = !fast_path;
     for (int redo = 0;; ++redo) {
-        if (redo) { int rc = enqueue_sort(true); if (!rc) rc = enqueue_rest(); if (rc) return rc; }   // this rank's sort in its next form, then everything that follows it
+        if (redo) { int rc = enqueue_sort(true); if (!rc) rc = enqueue_rest(); if (rc) return late(rc); }   // this rank's sort in its next form, then everything that follows it
         const bool serial = (m->flags & CD_MULTI_CROSS_SERIAL) != 0;                        // A/B: the cross pass behind the local one, on its stream
         hipStream_t cs = serial ? s : m->xstream;
         if (fast_path && recvd) {
-            if (redo || serial) HIPCHK(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), cs));   // (first time round: zeroed at the start of the step, see there)
-            HIPCHK(hipStreamWaitEvent(cs, serial ? m->ev_payload : m->ev_tree, 0));
+            if (redo || serial) LATE_HIP(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), cs));   // (first time round: zeroed at the start of the step, see there)
+            LATE_HIP(hipStreamWaitEvent(cs, serial ? m->ev_payload : m->ev_tree, 0));
             QuerySrc srcx{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, m->d_recv, nullptr, c->d_os_ticket + 8};
             m->scratch_pairs.resize(2 * (size_t)spec1 + 2);
             int rc;
@@ -379,20 +465,22 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
                 launch_pass<true, false>(c, t1, srcx, (uint32_t)recvd, cap);
                 rc = enqueue_report(c, t1, pairs != nullptr, spec1);
             }
-            if (rc) return rc;
+            if (rc) return late(rc);
         }
         mark(ME_CROSS, cs);
-        HIPCHK(hipEventRecord(m->ev_cross, m->xstream));
-        HIPCHK(hipStreamWaitEvent(s, m->ev_cross, 0));
-        HIPCHK(hipStreamSynchronize(s)); ++syncs;                                          // host synchronisation 2 of 2 (both streams)
-        HIPCHK(hipGetLastError());
+        LATE_HIP(hipEventRecord(m->ev_cross, m->xstream));
+        LATE_HIP(hipStreamWaitEvent(s, m->ev_cross, 0));
+        LATE_HIP(hipStreamSynchronize(s)); ++syncs;                                          // host synchronisation 2 of 2 (both streams)
+        LATE_HIP(hipGetLastError());
         if (fast_path) std::memcpy(c->sort_flags, reinterpret_cast<const Report *>(t0.h_report)->sort_flags, sizeof c->sort_flags);
         const int js = judge_sort_flags(c);                                                // (escalates c->sort_mode when a run was too long for this form)
         if (js == SORT_REDO && redo < 3) continue;
-        if (js != CD_OK) return js == SORT_REDO ? CD_ERR_SORT : js;
+        if (js != CD_OK) return late(js == SORT_REDO ? CD_ERR_SORT : js);
         break;
     }
     c->stage_events = se;
+    c->stage = ST_REFIT;                                                      // (only now: the sort's flags have been judged)
+    std::memcpy(c->root_box_host, m->h_roots + 6 * (size_t)me, sizeof(double) * 6); c->root_box_valid = true;
     if (fast_path) {
         HostCounters h0 = {}, h1 = {};
         parse_report(c, t0, h0, pairs, spec0);
@@ -400,7 +488,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         if (!need_general_l) {
             n_local = h0.n_pairs; tested += h0.pairs_tested;
             const uint64_t ncopy = std::min<uint64_t>(n_local, cap);
-            if (pairs && ncopy > spec0) { HIPCHK(hipMemcpy(pairs + 2 * spec0, t0.d_pairs + 2 * spec0, sizeof(uint32_t) * 2 * (ncopy - spec0), hipMemcpyDeviceToHost)); ++syncs; }
+            if (pairs && ncopy > spec0) { LATE_HIP(hipMemcpy(pairs + 2 * spec0, t0.d_pairs + 2 * spec0, sizeof(uint32_t) * 2 * (ncopy - spec0), hipMemcpyDeviceToHost)); ++syncs; }
             rc_l = n_local > cap ? CD_OVERFLOW : CD_OK;
         }
         if (recvd) {
@@ -413,7 +501,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
             const uint64_t ncopy = std::min<uint64_t>(n_cross, room);
             const uint64_t from_spec = std::min<uint64_t>(ncopy, spec1);
             if (pairs && from_spec) std::memcpy(pairs + 2 * n_local, m->scratch_pairs.data(), sizeof(uint32_t) * 2 * from_spec);
-            if (pairs && ncopy > from_spec) { HIPCHK(hipMemcpy(pairs + 2 * (n_local + from_spec), t1.d_pairs + 2 * from_spec, sizeof(uint32_t) * 2 * (ncopy - from_spec), hipMemcpyDeviceToHost)); ++syncs; }
+            if (pairs && ncopy > from_spec) { LATE_HIP(hipMemcpy(pairs + 2 * (n_local + from_spec), t1.d_pairs + 2 * from_spec, sizeof(uint32_t) * 2 * (ncopy - from_spec), hipMemcpyDeviceToHost)); ++syncs; }
             rc_x = n_cross > room ? CD_OVERFLOW : CD_OK;
         } else if (recvd && !need_general_x) need_general_x = true;     // the local pass is redone below: append the cross pairs after its final count
     }
@@ -422,15 +510,15 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     if (need_general_l) {
         uint64_t nl = 0;
         rc_l = run_traversal(c, t0, nullptr, 0, pairs, cap, &nl);
-        if (rc_l < 0) return rc_l;
+        if (rc_l < 0) return late(rc_l);
         n_local = nl; tested += c->stats.pairs_tested; syncs += 1;
     }
     if (need_general_x && recvd) {
-        HIPCHK(hipStreamWaitEvent(s, m->ev_payload, 0));
+        LATE_HIP(hipStreamWaitEvent(s, m->ev_payload, 0));
         const uint64_t used = std::min<uint64_t>(n_local, cap);
         uint64_t nx = 0;
         rc_x = run_traversal(c, t1, m->d_recv, recvd, pairs ? pairs + 2 * used : nullptr, cap - used, &nx);
-        if (rc_x < 0) return rc_x;
+        if (rc_x < 0) return late(rc_x);
         n_cross = nx; tested += c->stats.pairs_tested; syncs += 1;
     }
     // (the payload exchange has drained: the second stream was waited for above)
@@ -438,7 +526,6 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     c->last_pairs_on_device = 0;                                              // two lists: cd_sorted_pairs does not apply to a multi step
     if (n_pairs) *n_pairs = n_local + n_cross;
     if (info) {
-        std::memset(info, 0, sizeof *info);
         info->world = (uint32_t)W; info->rank = (uint32_t)me; info->n_peers = n_peers; info->host_syncs = syncs; info->attempts = attempts + 1;
         info->sent_queries = sent; info->recv_queries = recvd; info->local_pairs = n_local; info->cross_pairs = n_cross; info->pairs_tested = tested;
         info->query_cap = m->qcap;
@@ -453,6 +540,8 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         }
     }
     return (rc_l == CD_OVERFLOW || rc_x == CD_OVERFLOW) ? CD_OVERFLOW : CD_OK;
+#undef LATE_HIP
+#undef SOFT_HIP
 }
 
 }  // extern "C"

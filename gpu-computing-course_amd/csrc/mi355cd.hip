@@ -44,8 +44,10 @@ struct TravBuf {
     int32_t *d_deep = nullptr; uint64_t deep_items = 0;
 };
 
+struct cd_multi;
 struct cd_ctx {
     uint32_t nv = 0, nt = 0;
+    cd_multi *attached_multi = nullptr;     // the multi-GPU step object built on this context, if any (cd_multi.h): it holds a pointer to the context and buffers inside it
     int stage = ST_CREATED;
     int frame_mode = CD_FRAME_REFERENCE;
     uint32_t vbase = 0;
@@ -209,7 +211,7 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
     const int first_digit = hybrid ? 6 : (mode == 2 ? 4 : 0);
     int cur = mode == 3 ? 0 : 1;
     const uint32_t mblocks = cdiv(n, MORTON_THREADS * 4) < 1024u ? cdiv(n, MORTON_THREADS * 4) : 1024u;
-    k_morton<<<mblocks, MORTON_THREADS, 0, s>>>(c->d_verts, c->d_vidx, n, c->d_frame, c->d_keys[cur], c->d_os_hist, first_digit, down, c->d_os_ticket + 16,
+    k_morton<<<mblocks, MORTON_THREADS, 0, s>>>(c->d_verts, c->d_vidx, n, auto_frame ? nullptr : c->d_frame /* (auto: the kernel folds the partial bounds itself and WRITES d_frame) */, c->d_keys[cur], c->d_os_hist, first_digit, down, c->d_os_ticket + 16,
                                                 auto_frame ? c->d_partial : nullptr, (uint32_t)BOUNDS_BLOCKS, c->d_frame, nullptr);
     HIPCHK(evrec(c, EV_MORTON1));
     // onesweep: one pass over the data per digit; the digit histograms came with the keys
@@ -581,6 +583,8 @@ int pp_sort(cd_ctx *c, uint32_t m)
 
 }  // namespace
 
+void multi_detach_from(cd_ctx *c);          // cd_multi.h
+
 extern "C" {
 
 const char *cd_version(void) { return "mi355cd 0.1 gfx950"; }
@@ -659,6 +663,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
 void cd_destroy(cd_ctx *c)
 {
     if (!c) return;
+    multi_detach_from(c);                   // a cd_multi still attached keeps no pointer into a freed context (its next step returns CD_ERR_ORDER)
     hipStreamSynchronize(c->stream);
     free_all(c);
     delete c;

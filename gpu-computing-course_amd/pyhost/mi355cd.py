@@ -34,13 +34,13 @@ class CdStats(C.Structure):
 
 
 # every symbol include/mi355cd.h declares (tests check the library exports exactly these)
-CD_MULTI_SELF_PEER, CD_MULTI_TIMING, CD_MULTI_SELF_SLICE = 1, 2, 4
-CD_ERR_RCCL = -1008
+CD_MULTI_SELF_PEER, CD_MULTI_TIMING, CD_MULTI_SELF_SLICE, CD_MULTI_CROSS_SERIAL, CD_MULTI_INJECT_FAILURE = 1, 2, 4, 8, 16
+CD_ERR_RCCL, CD_ERR_PEER, CD_ERR_INJECTED = -1008, -1009, -1010
 
 
 class CdMultiInfo(C.Structure):
     _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("n_peers", C.c_uint32), ("host_syncs", C.c_uint32), ("attempts", C.c_uint32),
-                ("pad0", C.c_uint32), ("sent_queries", C.c_uint64), ("recv_queries", C.c_uint64), ("local_pairs", C.c_uint64),
+                ("failed_rank_plus1", C.c_uint32), ("sent_queries", C.c_uint64), ("recv_queries", C.c_uint64), ("local_pairs", C.c_uint64),
                 ("cross_pairs", C.c_uint64), ("pairs_tested", C.c_uint64), ("query_cap", C.c_uint64),
                 ("ms_tree", C.c_float), ("ms_allgather", C.c_float), ("ms_pack", C.c_float), ("ms_counts", C.c_float),
                 ("ms_exchange", C.c_float), ("ms_local", C.c_float), ("ms_cross", C.c_float), ("pad1", C.c_float)]

@@ -38,7 +38,9 @@ enum {
     CD_ERR_SORT      = -1005,  /* a bounded device-side wait in the sort timed out (results invalid) */
     CD_ERR_IO        = -1006,  /* file cannot be opened / read                                      */
     CD_ERR_FORMAT    = -1007,  /* a `v` / `f` line is not in the reference's dialect, or no geometry */
-    CD_ERR_RCCL      = -1008   /* librccl could not be loaded, or an RCCL call failed (cd_multi_*)   */
+    CD_ERR_RCCL      = -1008,  /* librccl could not be loaded, or an RCCL call failed (cd_multi_*)   */
+    CD_ERR_PEER      = -1009,  /* cd_multi_*: ANOTHER rank failed in this step; every rank returned in the same step (that rank its own error) */
+    CD_ERR_INJECTED  = -1010   /* cd_multi_step: the failure asked for with CD_MULTI_INJECT_FAILURE (tests)  */
 };
 
 /* Morton normalisation frame (morton.h:43-58 hard-codes one data set's bounds). */
@@ -232,15 +234,17 @@ enum {
     CD_MULTI_TIMING    = 2,    /* record HIP events at the phase boundaries (cd_multi_info.ms_*); costs a few idle us each     */
     CD_MULTI_CROSS_SERIAL = 8, /* A/B switch: the pass over the received queries runs behind the local traversal on its stream  */
                                /* instead of beside it on the second stream                                                     */
-    CD_MULTI_SELF_SLICE = 4    /* with CD_MULTI_SELF_PEER: the rank exchanges only the tenth of its triangles at its upper x end */
+    CD_MULTI_SELF_SLICE = 4,   /* with CD_MULTI_SELF_PEER: the rank exchanges only the tenth of its triangles at its upper x end */
                                /* with itself -- a one-GPU rehearsal at the scale of a 10 % neighbour overlap                  */
+    CD_MULTI_INJECT_FAILURE = 16 /* test hook: this rank's NEXT step fails locally (CD_ERR_INJECTED) before its pipeline starts; the flag */
+                               /* clears itself.  Every other rank must return CD_ERR_PEER from the same step, none may block      */
 };
 typedef struct cd_multi_info {
     uint32_t world, rank;          /* as the communicator reports them                                        */
     uint32_t n_peers;              /* ranks this rank sent to or received from                                */
     uint32_t host_syncs;           /* host synchronisations of the step (2 unless a pass had to be redone)    */
     uint32_t attempts;             /* 1 + collective repeats (slabs grown)                                    */
-    uint32_t pad0;
+    uint32_t failed_rank_plus1;    /* a step that returned CD_ERR_PEER / a local error: 1 + the lowest rank that published a failure, else 0 */
     uint64_t sent_queries, recv_queries, local_pairs, cross_pairs, pairs_tested, query_cap;
     float ms_tree, ms_allgather, ms_pack, ms_counts, ms_exchange, ms_local, ms_cross;   /* CD_MULTI_TIMING; -1 = not measured.  NOT additive: */
                                    /* first stream: tree (Morton keys .. fused build), local (own traversal); second stream, beside them: allgather  */
@@ -250,8 +254,14 @@ typedef struct cd_multi_info {
 } cd_multi_info;
 /* ncclGetUniqueId: 128 bytes, produced on one rank and handed to all (by whatever the launcher has: MPI, a file, ...). */
 int cd_multi_unique_id(void *id128);
-/* ncclCommInitRank(world, id, rank) on the current HIP device + the step's buffers.  query_cap_per_peer: records per
- * peer slab (0 = nt / 8 + 1024); it must be the SAME on every rank -- it grows collectively when a step needs more. */
+/* ncclCommInitRank(world, id, rank) on the current HIP device + the step's buffers.  COLLECTIVE: every rank of the communicator
+ * calls it.  query_cap_per_peer: records per peer slab (0 = nt / 8 + 1024); the ranks agree on the LARGEST request here (one
+ * 8-byte all-gather), so shards of unequal size start from a common capacity; it grows collectively when a step needs more.
+ * One cd_multi per context (CD_ERR_ORDER otherwise).  Lifetime: cd_multi_destroy before cd_destroy; a context destroyed first
+ * detaches the cd_multi, whose further steps return CD_ERR_ORDER.
+ * Failure semantics of cd_multi_step: a rank whose own work fails still joins the step's collectives and publishes its error in
+ * the count matrix; every rank then returns from the SAME step -- the failing rank its error, the others CD_ERR_PEER -- before
+ * any send / receive is posted.  An error met after that point is returned to its caller and published by that rank's next step. */
 int cd_multi_create(cd_multi **out, cd_ctx *ctx, const void *id128, int rank, int world, uint64_t query_cap_per_peer, int flags);
 /* The same over a communicator the caller owns (an opaque ncclComm_t); it is not destroyed by cd_multi_destroy. */
 int cd_multi_create_from_comm(cd_multi **out, cd_ctx *ctx, void *nccl_comm, uint64_t query_cap_per_peer, int flags);

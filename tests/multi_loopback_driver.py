@@ -4,7 +4,11 @@ instead of RCCL, which refuses two ranks on one device.  Everything else -- the 
 matrix, the collective capacity growth, slab and receive offsets, both traversal passes -- is the product code path.
 Run as a child process by tests/test_cd_gpu.py (the library choice is per process).
 
-usage: multi_loopback_driver.py QUADS QCAP STEPS X0,X1,...     (rank r's object sits at x = Xr * 2.88)
+usage: multi_loopback_driver.py QUADS QCAP STEPS X0,X1,... [INJECT_RANK:INJECT_STEP]    (rank r's object sits at x = Xr * 2.88)
+QUADS may be a comma list, one value per rank (shards of unequal size: the default capacity nt / 8 + 1024 then differs per rank
+and must be agreed at creation).  INJECT: that rank sets CD_MULTI_INJECT_FAILURE before that step -- EVERY rank must return an
+error from that step (the rank itself CD_ERR_INJECTED, the others CD_ERR_PEER), none may block, and the following steps must be
+right again.
 Checks, and exits non-zero on failure: union of all ranks' pairs == oracle on the merged mesh, no duplicates, summed
 pairs_tested == the single tree's, sent/received totals consistent across ranks, peers as the root boxes say."""
 import json
@@ -25,13 +29,16 @@ import oracle  # noqa: E402
 
 
 def main():
-    quads, qcap, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    qcap, steps = int(sys.argv[2]), int(sys.argv[3])
     xs = [float(x) for x in sys.argv[4].split(",")]
     W = len(xs)
+    quads_of = [int(q) for q in sys.argv[1].split(",")]
+    quads_of = quads_of * W if len(quads_of) == 1 else quads_of
+    inject = tuple(int(v) for v in sys.argv[5].split(":")) if len(sys.argv) > 5 else None
     width = 2.88
     shards, vbase, tbase = [], 0, 0
     for r in range(W):
-        v, t = synth.cloth_pair(quads, x_offset=xs[r] * width)
+        v, t = synth.cloth_pair(quads_of[r], x_offset=xs[r] * width)
         ids = (np.arange(t.shape[0], dtype=np.uint64) + tbase).astype(np.uint32)
         if r % 2:                                   # odd ranks hold the larger IDs first: the ID rule must not depend on rank order
             ids = ids[::-1].copy()
@@ -51,9 +58,14 @@ def main():
         try:
             with mi355cd.MultiStep(cds[r], uid, r, W, query_cap_per_peer=qcap, flags=mi355cd.CD_MULTI_TIMING) as ms:
                 out = []
-                for _ in range(steps):
-                    pairs, n, rc, info = ms.step(cap=1 << 21)
-                    out.append((pairs.copy(), n, rc, {k: getattr(info, k) for k, _ in info._fields_}))
+                for it in range(steps):
+                    if inject and inject == (r, it):
+                        ms.set_flags(mi355cd.CD_MULTI_TIMING | mi355cd.CD_MULTI_INJECT_FAILURE)
+                    try:
+                        pairs, n, rc, info = ms.step(cap=1 << 21)
+                        out.append((pairs.copy(), n, rc, {k: getattr(info, k) for k, _ in info._fields_}))
+                    except mi355cd.CdError as e:
+                        out.append((np.zeros((0, 2), dtype=np.uint32), 0, e.rc, {}))
                 results[r] = out
         except BaseException as e:                  # noqa: BLE001
             errors[r] = repr(e)
@@ -77,6 +89,12 @@ def main():
     want = oracle.pair_set(ref["pairs"])
     summary = {"ok": True, "world": W, "want_pairs": int(len(want)), "want_peers": want_peers, "steps": []}
     for it in range(steps):
+        if inject and it == inject[1]:
+            rcs = [results[r][it][2] for r in range(W)]
+            want_rcs = [mi355cd.CD_ERR_INJECTED if r == inject[0] else mi355cd.CD_ERR_PEER for r in range(W)]
+            summary["steps"].append({"injected": True, "rcs": rcs, "checks": {"all_ranks_failed_together": rcs == want_rcs}})
+            summary["ok"] = summary["ok"] and rcs == want_rcs
+            continue
         got = np.concatenate([results[r][it][0] for r in range(W)], axis=0)
         infos = [results[r][it][3] for r in range(W)]
         gs = oracle.pair_set(got)

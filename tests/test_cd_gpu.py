@@ -548,7 +548,9 @@ def test_multi_step_c_abi_one_rank_self_peer():
     (30, 0, "0,0.9,5.0"),                            # rank 2 overlaps nobody: it skips the exchange, the others do not wait for it
     (24, 0, "0,0.2,0.4,0.6"),                        # everybody overlaps everybody: every slab and every receive offset in use
     (24, 0, "0,0.9,1.8,2.7,3.6,4.5,5.4,6.3"),        # BASELINE config 4's topology: eight ranks in a row
-], ids=["w2", "w3-grow", "w3-isolated", "w4-all-to-all", "w8-chain"])
+    ("12,60,20", 0, "0,0.9,1.8"),                    # shards of UNEQUAL size with the default capacity (nt / 8 + 1024 differs per rank: 1 168 / 4 624 / 1 424):
+                                                     # agreed at creation, or ranks 0 and 2 would grow their slabs while rank 1 moves on to send / receive
+], ids=["w2", "w3-grow", "w3-isolated", "w4-all-to-all", "w8-chain", "w3-unequal-shards"])
 def test_multi_step_world_gt_1_over_the_loopback_transport(quads, qcap, xs):
     """cd_multi_step with world 2 .. 8 on the one GPU there is: ranks are host threads with a context each, and the
     library is pointed (MI355CD_RCCL_LIBRARY) at tests/loopback_rccl, an in-process stand-in for the ten RCCL calls it
@@ -576,6 +578,30 @@ def test_multi_step_world_gt_1_over_the_loopback_transport(quads, qcap, xs):
         if "5.0" in xs:
             assert st["sent"][2] == st["recv"][2] == 0 and st["cross"][2] == 0
         assert sum(st["cross"]) > 0
+        if quads == "12,60,20":
+            assert st["query_cap"] == 60 * 60 * 4 // 8 + 1024, st       # the largest rank's default, on every rank ("same_capacity_everywhere" is among the checks)
+
+
+@pytest.mark.parametrize("world_xs,inject", [("0,0.9", "1:1"), ("0,0.9,1.8,2.7", "2:0"), ("0,0.9,1.8", "0:2")], ids=["w2-rank1-step1", "w4-rank2-step0", "w3-rank0-step2"])
+def test_multi_step_fails_on_every_rank_together(world_xs, inject):
+    """A rank that fails locally (CD_MULTI_INJECT_FAILURE: before its own pipeline starts) still joins the step's collectives and
+    publishes its error in the count matrix: EVERY rank returns from that step -- the rank itself CD_ERR_INJECTED, the others
+    CD_ERR_PEER -- before any send / receive is posted, nobody blocks (the driver's threads are joined with a time-out), and the
+    steps before and after it give the oracle's pair set."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "multi_loopback_driver.py"), "30", "0", "4", world_xs, inject],
+                       capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    res = json.loads(lines[-1])
+    assert res["ok"] and p.returncode == 0, res
+    step = int(inject.split(":")[1])
+    assert res["steps"][step].get("injected") and res["steps"][step]["checks"]["all_ranks_failed_together"]
+    good = [st for st in res["steps"] if not st.get("injected")]
+    assert len(good) == 3 and all(all(st["checks"].values()) for st in good), res
 
 
 def _assert_fused_records_equal_stagewise(verts, vidx, ids=None, split_cross_too=True):
@@ -1040,3 +1066,25 @@ def test_config3_sorted_keys_equal_reference_compiled_keys():
     assert mi.sha(unsorted) == str(ref["cloth_keys_sha"])
     assert np.array_equal(unsorted[perm], keys) and np.array_equal(np.sort(perm), np.arange(perm.size, dtype=np.uint32))
     assert int(ref["cloth_distinct"]) == 1_000_000                  # all keys distinct: the permutation is unique
+
+
+def test_config4_neighbour_pair_at_full_shard_size_over_the_loopback_transport():
+    """BASELINE config 4 at its SHARD size on the one GPU there is: one neighbour pair of the row of eight -- two contexts of
+    1 000 000 triangles each (cloth_pair(500)), 10 % overlap along x -- stepped by cd_multi_step (world 2) over the loopback
+    transport: the union of the two ranks' pairs == the oracle's pair set on the merged 2 M-triangle mesh, no duplicates, and
+    the summed pairs_tested == the single tree's.  What config 4 then still lacks is real links between real GPUs."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "multi_loopback_driver.py"), "500", "0", "2", "0,0.9"],
+                       capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    res = json.loads(lines[-1])
+    assert res["ok"] and p.returncode == 0, res
+    assert res["world"] == 2 and res["want_pairs"] > 40_000
+    for st in res["steps"]:
+        assert all(st["checks"].values()), st
+        assert st["attempts"] == 1 and st["host_syncs"] == [2, 2], st
+        assert st["sent"][0] > 90_000 and st["sent"][1] > 90_000 and sum(st["cross"]) > 1000, st       # ~101 k overlapping triangles each way
