@@ -745,6 +745,215 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
 }
 
 // ====================================================================================================
+// Variant E (default since round 3): the half traversal with a WORKGROUP-shared frontier for the descent.
+//   Phases 0 / 1a / 1b are variant D's, wave by wave (query box out of the records; right-sibling chain walked bottom-up:
+//   in-wave hops over registers, then the shared chain over scalar loads).  What changes is phase 2.  In variant D a lane
+//   descends the sibling subtrees ITS query hit, depth first over a private LDS stack: 2.8 node visits per query, but a
+//   wave runs as many steps as its deepest lane needs -- 9.7 steps at 18 of 64 lanes busy (1 M cloth) -- and the kernel's time
+//   is the instructions it issues, busy lane or not.  Here every (query, subtree) item a chain hit produces goes onto ONE ring
+//   in LDS per workgroup of WGF_WAVES x 64 consecutive queries, compacted with __ballot / popcount prefixes (one LDS atomic per wave
+//   and push), and the workgroup works the frontier off LEVEL by level: wave w takes items [64 w, 64 w + 64) of the level, every
+//   lane one item -- the item's query box comes out of LDS, the node's record out of memory -- and the children that are hit go
+//   onto the ring as the next level.  A level of 150 items costs three full wave-steps instead of a step of every wave: the
+//   CPU model of this scheme (tools/sim/bfs_sim.py) gives 4.7 wave-steps per 64 queries at 256 queries per workgroup against
+//   9.9 for the private descent, 12.5 levels per workgroup.  One barrier per level: the level counters rotate through three
+//   words (level L is counted in cnt[L % 3], filled during level L - 1, cleared during level L + 1), so no wave can read a
+//   count another wave is already adding to.  A frontier that outgrows the ring (dense contact) overflows, item by item, into
+//   the deferred list of the deep pass, as a full private stack did.
+// ====================================================================================================
+#ifndef WGF_WAVES
+#define WGF_WAVES 4
+#endif
+constexpr int WGF_THREADS = 64 * WGF_WAVES;
+constexpr uint32_t WGF_RING = 256u * WGF_WAVES;          // items; a power of two
+constexpr int WGF_QCAP = 192;                           // candidate queue slots per wave
+constexpr uint32_t WGF_FLUSH_AT = WGF_QCAP - 128;       // a descent step enqueues at most 2 x 64 candidates
+struct WgItem { uint32_t q; int32_t node; };             // q: query index inside the workgroup
+
+__global__ __launch_bounds__(WGF_THREADS) void k_descend_wg(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
+                                                            TravState *__restrict__ st,
+                                                            Candidates *__restrict__ cand, unsigned long long shard_cap,
+                                                            uint2 *__restrict__ defer_list, uint32_t defer_cap, uint32_t diag)
+{
+    if (sort_failed(src)) return;
+    __shared__ WgItem ring[WGF_RING];
+    __shared__ float4 qbox_lds[WGF_THREADS][2];           // {lo.xyz, hi.x}, {hi.y, hi.z, certain, -}
+    __shared__ Candidates queue[WGF_WAVES][WGF_QCAP];
+    __shared__ uint32_t cnt[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    if (tid < 4) cnt[tid] = 0u;
+    const uint32_t nb = gridDim.x, per = nb >> 3;         // XCD-aware mapping, see k_descend_half
+    uint32_t vblock = (blockIdx.x < (per << 3)) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    {
+        const uint32_t c = per / 4u;
+        if (c > 0 && blockIdx.x < c * 4u * 8u) { const uint32_t x = blockIdx.x & 7u, l = blockIdx.x >> 3, sub = l / c, off = l % c; vblock = (sub * 8u + x) * c + off; }
+        else if (c > 0) vblock = blockIdx.x;
+    }
+    CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
+    Candidates *my_cand = cand + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_cap;
+    const uint32_t nq = (uint32_t)n, last_leaf = nq - 1u;
+    constexpr uint32_t END = 0xffffffffu;
+    const uint32_t wg0 = vblock * (uint32_t)WGF_THREADS;                      // first leaf of the workgroup
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + w * 64u));
+    const uint32_t g_last = (g0 + 63u < last_leaf) ? g0 + 63u : last_leaf;
+    const uint32_t qi = g0 + lane;
+    const bool valid = qi < nq && n > 1;
+    uint32_t qcount = 0;                                // wave-uniform: candidates waiting in this wave's queue
+    uint32_t tested = 0, visits = 0, steps = 0;
+    auto flush = [&](uint32_t count) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        Candidates cd0 = Candidates{0, 0};
+        bool keep = lane < count;
+        if (keep) cd0 = queue[w][qcount - count + lane];
+        if (keep && (cd0.leaf & CAND_CERTAIN)) {
+            tested += 2u;                                                      // collision.cuh:31-32, decided exactly by the descent, both directions
+            const LeafTri lt = src.leaf[cd0.leaf & CAND_LEAF_MASK];
+            const LeafTri ql = src.leaf[cd0.q];
+            keep = neighbor_count(ql.v0, ql.v1, ql.v2, lt.v0, lt.v1, lt.v2) < 1 && ql.id != lt.id;   // collision.cuh:38, tri_contact.cuh:81
+            cd0.leaf |= CAND_FILTERED;
+        }
+        qcount -= count;
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(keep);
+        if (mk != 0ull) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&sh->n_candidates, (unsigned long long)__popcll(mk));
+            base = __shfl(base, 0) + __popcll(mk & lt_mask);
+            if (keep && base < shard_cap) my_cand[base] = cd0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    auto enqueue = [&](bool c, uint32_t q, uint32_t leafword) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
+        if (m == 0ull) return;
+        while (qcount > WGF_QCAP - 64u) flush(64);
+        if (c) queue[w][qcount + __popcll(m & lt_mask)] = Candidates{q, leafword};
+        qcount += __popcll(m);
+    };
+    // an internal node some query's box overlaps -> one item of the frontier level counted in *counter (room for `room` items, the
+    // ring minus the level still being read); beyond that, the deep pass's list
+    auto push_items = [&](bool c, uint32_t qlocal, int32_t link, int counter, uint32_t base_pos, uint32_t room) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
+        if (m == 0ull) return;
+        uint32_t b = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) b = atomicAdd(&cnt[counter], (uint32_t)__popcll(m));     // (an LDS atomic: ds_add_rtn_u32)
+        b = (uint32_t)__builtin_amdgcn_readlane((int)b, __builtin_ctzll(m)) + (uint32_t)__popcll(m & lt_mask);
+        if (c) {
+            if (b < room) ring[(base_pos + b) & (WGF_RING - 1u)] = WgItem{qlocal, link};
+            else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(wg0 + qlocal, (uint32_t)link); }
+        }
+    };
+    // ---- phase 0: the query box out of the records (see k_descend_half)
+    float qlo0, qlo1, qlo2, qhi0, qhi1, qhi2; uint32_t qcertain;
+    float4 rc = make_float4(0.f, 0.f, 0.f, 0.f), rd = rc;
+    {
+        float4 la = rc, lb = rc, pc = rc, pd = rc;
+        const bool own = valid && qi < last_leaf;
+        if (own) { const float4 *rp = rec_right(recs, n, qi); rc = rp[0]; rd = rp[1]; const float4 *lp = rec_left(recs, n, qi); la = lp[0]; lb = lp[1]; }
+        {
+            int4 e0 = make_int4(0, 0, 0, 0), e1 = e0;
+            if (g0 > 0u && g0 <= last_leaf && n > 1) { const int4 *pp = reinterpret_cast<const int4 *>(rec_right(recs, n, g0 - 1u)); e0 = pp[0]; e1 = pp[1]; }
+            auto shr1 = [](float v, int edge) { return __int_as_float(__builtin_amdgcn_update_dpp(edge, __float_as_int(v), 0x138, 0xf, 0xf, false)); };
+            pc.x = shr1(rc.x, e0.x); pc.y = shr1(rc.y, e0.y); pc.z = shr1(rc.z, e0.z); pc.w = shr1(rc.w, e0.w);
+            pd.x = shr1(rd.x, e1.x); pd.y = shr1(rd.y, e1.y); pd.z = shr1(rd.z, e1.z); pd.w = shr1(rd.w, e1.w);
+        }
+        const bool is_left = own && __float_as_int(lb.z) == (int32_t)~qi;
+        qlo0 = is_left ? la.x : pc.x; qlo1 = is_left ? la.y : pc.y; qlo2 = is_left ? la.z : pc.z;
+        qhi0 = is_left ? la.w : pc.w; qhi1 = is_left ? lb.x : pd.x; qhi2 = is_left ? lb.y : pd.y;
+        const bool exact = is_left ? (__float_as_uint(rd.w) & REC_L_EXACT) != 0u : (__float_as_uint(pd.w) & REC_R_EXACT) != 0u;
+        qcertain = exact ? CAND_CERTAIN : 0u;
+        bool self = exact & (qlo0 < qhi0) & (qlo1 < qhi1) & (qlo2 < qhi2);
+        if (valid && !exact) { const Box b = load_box(src.boxes, (n - 1) + (int)qi); self = box_overlap(b, b); }
+        if (valid && self) ++tested;
+        qbox_lds[tid][0] = make_float4(qlo0, qlo1, qlo2, qhi0);
+        qbox_lds[tid][1] = make_float4(qhi1, qhi2, __uint_as_float(qcertain), 0.f);
+    }
+    __syncthreads();                                                          // cnt[] is zero before the first push
+    // ---- phase 1a: hops below g_last (registers of the wave)
+    uint32_t s = valid ? qi : END;
+    for (int hop = 0; hop < 128; ++hop) {
+        const bool act = s < g_last;
+        if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+        ++steps;
+        const int from = (int)((act ? (s - g0) : lane) << 2);
+        float4 c, d;
+        c.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.x))); c.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.y)));
+        c.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.z))); c.w = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.w)));
+        d.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.x))); d.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.y)));
+        d.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.z))); d.w = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.w)));
+        const bool hit = act & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
+        const int32_t link = __float_as_int(d.z);
+        const uint32_t lw = __float_as_uint(d.w);
+        visits += act ? 1u : 0u;
+        push_items(band(hit, link >= 0), tid, link, 0, 0u, WGF_RING);
+        s = act ? (lw & REC_LAST_MASK) : s;
+        enqueue(band(hit, link < 0), qi, (uint32_t)~link | ((lw & REC_R_EXACT) ? qcertain : 0u));
+    }
+    // ---- phase 1b: the shared chain above the wave (scalar loads)
+    {
+        uint32_t t = g_last;
+        for (int hop = 0; hop < 128 && t < last_leaf; ++hop) {
+            ++steps;
+            const int4 *rq = reinterpret_cast<const int4 *>(rec_right(recs, n, t));
+            const int4 c = rq[0], d = rq[1];
+            const bool act = s <= t;
+            const bool hit = act & (qlo0 < __int_as_float(c.w)) & (__int_as_float(c.x) < qhi0) & (qlo1 < __int_as_float(d.x)) &
+                             (__int_as_float(c.y) < qhi1) & (qlo2 < __int_as_float(d.y)) & (__int_as_float(c.z) < qhi2);
+            const int32_t link = d.z;                                         // wave-uniform
+            const uint32_t lw = (uint32_t)d.w;
+            visits += act ? 1u : 0u;
+            if (link >= 0) push_items(hit, tid, link, 0, 0u, WGF_RING);
+            else enqueue(hit, qi, (uint32_t)~link | ((lw & REC_R_EXACT) ? qcertain : 0u));
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lw & REC_LAST_MASK));
+        }
+    }
+    // ---- phase 2: the workgroup's frontier, level by level
+    uint32_t start = 0u, room = WGF_RING;
+    for (int level = 0; level < 4096; ++level) {
+        __syncthreads();
+        uint32_t c = cnt[level % 3];
+        c = c < room ? c : room;                                              // (what did not fit went to the deferred list)
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        if (c == 0u) break;
+        if (tid == 0) cnt[(level + 2) % 3] = 0u;                              // the word the NEXT level's pushes will count in
+        const int next = (level + 1) % 3;
+        const uint32_t next_room = WGF_RING - c, next_start = start + c;
+        for (uint32_t base = w * 64u; base < c; base += (uint32_t)WGF_THREADS) {
+            const uint32_t idx = base + lane;
+            const bool active = idx < c;
+            ++steps;
+            const WgItem it = ring[(start + (active ? idx : base)) & (WGF_RING - 1u)];
+            const float4 qa = qbox_lds[it.q][0], qb = qbox_lds[it.q][1];
+            const uint32_t rn = (uint32_t)it.node;
+            const float4 *rpl = rec_left(recs, n, rn), *rpr = rec_right(recs, n, rn);
+            const float4 a = rpl[0], b = rpl[1], cc = rpr[0], d = rpr[1];
+            const int32_t cl = __float_as_int(b.z), cr = __float_as_int(d.z);
+            const uint32_t lw = __float_as_uint(d.w), qc = __float_as_uint(qb.z);
+            const bool ol  = active & (qa.x < a.w) & (a.x < qa.w) & (qa.y < b.x) & (a.y < qb.x) & (qa.z < b.y) & (a.z < qb.y);
+            const bool orr = active & (qa.x < cc.w) & (cc.x < qa.w) & (qa.y < d.x) & (cc.y < qb.x) & (qa.z < d.y) & (cc.z < qb.y);
+            visits += active ? 1u : 0u;
+            push_items(band(ol, cl >= 0), it.q, cl, next, next_start, next_room);
+            push_items(band(orr, cr >= 0), it.q, cr, next, next_start, next_room);
+            const bool candL = band(ol, cl < 0), candR = band(orr, cr < 0);
+            if (__builtin_amdgcn_ballot_w64(bor(candL, candR)) != 0ull) {
+                const uint32_t gq = wg0 + it.q;
+                enqueue(candL, gq, (uint32_t)~cl | ((lw & REC_L_EXACT) ? qc : 0u));
+                enqueue(candR, gq, (uint32_t)~cr | ((lw & REC_R_EXACT) ? qc : 0u));
+            }
+        }
+        start = next_start; room = next_room;
+    }
+    while (qcount > 0) flush(qcount < 64u ? qcount : 64u);
+    const unsigned long long t64 = wave_sum_u64(tested), v64 = wave_sum_u64(visits);
+    if (lane == 0) {
+        if (t64) atomicAdd(&sh->pairs_tested, t64);
+        if (v64) atomicAdd(&sh->node_visits, v64);
+        if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
+    }
+    (void)diag; (void)WGF_FLUSH_AT;
+}
+
+// ====================================================================================================
 // Variant C ("packet"): wavefront-shared traversal.  A wave walks the tree ONCE for its 64 Morton-adjacent
 // queries: the current node is wave-uniform, so its 64-byte record comes through the SCALAR cache
 // (s_load, no per-lane address traffic at all -- the per-lane descents above are bound by the texture

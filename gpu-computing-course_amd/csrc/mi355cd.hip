@@ -379,8 +379,8 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         // variant 3 (half traversal) applies to self-collision queries; external queries are not leaves of this tree
         // and take the full descent of variant 1.  The deep pass of a half traversal continues (query, subtree) items
         // with the full descent, but its candidates keep the half traversal's meaning (`half`).
-        const bool half_mode = c->trav_variant == 3 && !EXTERNAL;
-        const uint32_t qpw = (DEEP || c->trav_variant == 3) ? 64u : c->queries_per_wave;
+        const bool half_mode = c->trav_variant >= 3 && !EXTERNAL;
+        const uint32_t qpw = (DEEP || c->trav_variant >= 3) ? 64u : c->queries_per_wave;
         const uint64_t shard_cap = tb.cand_cap / NSHARD;
         const dim3 grid(cdiv(items, qpw * DESC_WAVES));
         const size_t pad = DEEP ? 0 : c->dbg_lds_pad;
@@ -393,7 +393,10 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         const uint32_t qarg = qpw | (c->dbg_no_shared_path ? 0x40000000u : 0u);
         uint2 *dl = DEEP ? nullptr : tb.d_defer; const uint32_t dcap = DEEP ? 0u : tb.defer_cap; int32_t *deep = DEEP ? tb.d_deep : nullptr;
         const uint32_t half = half_mode ? 1u : 0u;
-        if (half_mode && !DEEP)
+        if (half_mode && !DEEP && c->trav_variant == 4)
+            hipExtLaunchKernelGGL(k_descend_wg, dim3(cdiv(items, (uint32_t)WGF_THREADS)), dim3(WGF_THREADS), (uint32_t)pad, s, e0, e1, 0u,
+                                  src, n, (const NodeRec32 *)c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
+        else if (half_mode && !DEEP)
             hipExtLaunchKernelGGL(k_descend_half, dim3(cdiv(items, 64u * HALF_WAVES)), dim3(HALF_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, n, (const NodeRec32 *)c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
         else if (qpw == 64)
@@ -478,7 +481,7 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
     for (int attempt = 0; attempt < 8 && !done; ++attempt) {
         launches = 0; deep_ms = 0.f;
         QuerySrc src{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, d_ext, nullptr, c->d_os_ticket + 8};
-        const bool will_ride = !c->stage_events && (c->trav_variant == 1 || c->trav_variant == 3) && nq > 0;   // see launch_pass: events on the dispatch packets
+        const bool will_ride = !c->stage_events && (c->trav_variant == 1 || c->trav_variant >= 3) && nq > 0;   // see launch_pass: events on the dispatch packets
         c->events_ride = false;
         if (!will_ride) HIPCHK(evrec(c, EV_TRAV0));
         if (!(c->prezeroed && attempt == 0 && &tb == &c->tb[0])) HIPCHK(hipMemsetAsync(tb.d_state, 0, sizeof(TravState), s));
@@ -1033,7 +1036,7 @@ int cd_num_triangles(cd_ctx *c, uint32_t *nt) { if (!c || !nt) return CD_ERR_ARG
 int cd_set_option(cd_ctx *c, int key, int64_t value)
 {
     if (!c) return CD_ERR_ARG;
-    if (key == CD_OPT_TRAVERSAL) { if (value < 0 || value > 3) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
+    if (key == CD_OPT_TRAVERSAL) { if (value < 0 || value > 4) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
     if (key == CD_OPT_QUERIES_PER_WAVE) { if (value < 64 || value > (1 << 20) || value % 64) return CD_ERR_ARG; c->queries_per_wave = (uint32_t)value; return CD_OK; }
     if (key == CD_OPT_SORT_FULL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->sort_mode = value == 0 ? 0 : (value == 1 ? 3 : 2); return CD_OK; }
     if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }
