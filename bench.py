@@ -263,6 +263,7 @@ def main():
     if args.qpw is not None:
         engine.cd.set_option(mi355cd.CD_OPT_QUERIES_PER_WAVE, args.qpw)
     cap = 1 << 22
+    pair_buf = np.empty((cap, 2), dtype=np.uint32)
 
     comm_device = None if backend == "nccl" else "cpu"
     ms = None
@@ -287,23 +288,27 @@ def main():
                                                  "attempts": int(mi.attempts)}
         if world == 1 and not multi_path:
             # one GPU: the C ABI's call and nothing else -- pairs stay in the buffer the library wrote them into
-            pairs, n, rc = engine.cd.self_collide(cap, copy=False)
+            n, rc = engine.cd.self_collide_into(pair_buf)
             if rc != 0:
                 raise RuntimeError(f"pair capacity {cap} too small for {n} pairs")
-            return pairs, None, {}
+            return pair_buf[:n], None, {}
         return multi.collide_step(engine, dist, rank, world, cap, comm_device)
 
     for _ in range(args.warmup):
         step()
-    # the timed steps take only the time stamps the roofline needs -- start / end of the DOMINANT kernel (the descent), riding on its
-    # own dispatch packet; every further stamp costs ~5 us of idle GPU per step (tools/event_cost.py).  The other kernels' times, the
-    # device time of the whole pipeline and the per-stage breakdown come from extra, untimed steps (see the end)
+    # The DOMINANT kernel (the descent) is timed over the timed region in two ways: (1) by ITSELF in every step -- first wave start ->
+    # last wave end on the device's constant wall clock (cd_stats.ms_descend_clock), free; (2) with HIP events riding on its dispatch
+    # packet (cd_stats.ms_descend) in every STAMP_EVERY-th timed step -- a stamped kernel costs the step ~7 us of idle GPU around it
+    # (tools/event_cost.py), so stamping all K steps would make the measurement 3 % of what it measures.  The other kernels' times,
+    # the device time of the whole pipeline and the per-stage breakdown come from extra, untimed steps (see the end)
+    STAMP_EVERY = 8
     engine.cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0)
     if not multi_path:
-        engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 2)
+        engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
     stage = {"morton": 0.0, "sort": 0.0, "build_fused(hierarchy+refit+records)": 0.0, "traverse": 0.0}
-    kern = {"descend": 0.0, "exact": 0.0, "build_block": 0.0}            # the two kernels inside "traverse" + the fused hierarchy / refit kernel
+    kern = {"descend": 0.0, "descend_device_clock": 0.0, "exact": 0.0, "build_block": 0.0}   # the two kernels inside "traverse" + the fused hierarchy / refit kernel
+    stamped_steps = 0
     tested_total = 0
     pairs_found = 0
     pipeline_ms = 0.0
@@ -312,13 +317,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i_step in range(args.steps):
+        stamped = (not multi_path) and i_step % STAMP_EVERY == 0
+        if stamped:
+            engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 2)     # HIP events on the descent's dispatch packet, this step only
         pairs, tested, info = step()
-        st = engine.cd.stats()                                        # HIP-event stage times on the library's stream
+        st = engine.cd.fast_stats if not multi_path else engine.cd.stats()   # (refreshed by the step's own call)
         if tested is None:
             tested = st.pairs_tested
         if not multi_path:
-            kern["descend"] += st.ms_descend
+            kern["descend_device_clock"] += st.ms_descend_clock
+            if stamped:
+                kern["descend"] += st.ms_descend; stamped_steps += 1
+                engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
         tested_total += tested
         pairs_found = pairs.shape[0]
     torch.cuda.synchronize()
@@ -382,6 +393,7 @@ def main():
             #   k_descend_half:           the fp32 descent, 40 B/triangle (row S5: the tree read once).
             # The other one is reported beside it.  `traffic` = HBM bytes per launch from the rocprofv3 --pmc passes
             # (profiles/traffic.json, produced by tools/refresh_profiles.sh + tools/summarise_profiles.py).
+            kern["descend"] *= k / max(1, stamped_steps)
             for k_ in kern:
                 kern[k_] /= k
             traffic_of = {}
@@ -411,8 +423,10 @@ def main():
                           kern["build_block"], BUILD_BYTES_PER_TRI)]
             cands.sort(key=lambda r: -r["avg_launch_ms"])
             line["kernel_ms"] = kern
-            line["kernel_ms_note"] = (f"descend: live, over the {k} timed steps (time stamps on the kernel's dispatch packet); exact, build_block and "
-                                      f"total_collision_ms_device: from {prof_steps} extra untimed steps with all stamps on (each stamp costs ~5 us of idle GPU)")
+            line["kernel_ms_note"] = (f"descend: live over the timed region, HIP events on the kernel's dispatch packet in {stamped_steps} of the {k} timed steps (every "
+                                      f"{STAMP_EVERY}th: a stamped kernel costs its step ~7 us of idle GPU); descend_device_clock: live, EVERY timed step, the kernel's own "
+                                      f"first-wave-start -> last-wave-end on the device wall clock; exact, build_block and total_collision_ms_device: from {prof_steps} "
+                                      f"extra untimed steps with all stamps on")
             line["roofline"] = dict(cands[0])
             line["roofline"]["other_kernels"] = cands[1:]
             line["roofline"]["whole_path"] = {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9,

@@ -39,6 +39,7 @@ struct alignas(256) Report {
     uint32_t n_deferred, pad0;
     uint32_t sort_flags[9]; uint32_t pad1;
     double root_box[6];
+    unsigned long long clk_start_inv, clk_end;   // descent kernel, device wall clock (s_memrealtime ticks): ~(earliest wave start), latest wave end; 0 = not taken
 };
 static_assert(sizeof(Report) == 256, "report layout");
 
@@ -56,11 +57,16 @@ __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__re
         const CtrShard sh = st->shard[lane];
         const unsigned long long tested = wave_sum_u64(sh.pairs_tested), visits = wave_sum_u64(sh.node_visits);
         const unsigned long long steps = wave_sum_u64(sh.wave_steps), cands = wave_sum_u64(sh.n_candidates);
-        unsigned long long mx = sh.n_candidates;
-        for (int o = 32; o; o >>= 1) { const unsigned long long u = __shfl_xor(mx, o); mx = u > mx ? u : mx; }
+        unsigned long long mx = sh.n_candidates, c0 = sh.pad[4], c1 = sh.pad[11];
+        for (int o = 32; o; o >>= 1) {
+            const unsigned long long u = __shfl_xor(mx, o); mx = u > mx ? u : mx;
+            const unsigned long long u0 = __shfl_xor(c0, o); c0 = u0 > c0 ? u0 : c0;
+            const unsigned long long u1 = __shfl_xor(c1, o); c1 = u1 > c1 ? u1 : c1;
+        }
         if (lane == 0) {
             out->n_pairs = np; out->pairs_tested = tested; out->node_visits = visits; out->max_shard_candidates = mx;
             out->wave_steps = steps; out->candidates = cands; out->n_deferred = st->n_deferred;
+            out->clk_start_inv = c0; out->clk_end = c1;
         }
         if (lane < 9) out->sort_flags[lane] = sort_flags[lane];
         if (lane < 6) out->root_box[lane] = root_box[lane];
@@ -524,6 +530,16 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
                                                                   uint2 *__restrict__ defer_list, uint32_t defer_cap, uint32_t diag)
 {
     if (sort_failed(src)) return;
+#ifdef CD_ABLATE       // TIMING EXPERIMENTS ONLY, never in the shipped build (tools/ab_build.sh abl -DCD_ABLATE; tools/exp_descent_ablation.py): parts of the
+    const uint32_t ablate = diag >> 8;   // kernel switched off by debug key 103, bits 8..: 1 no descent, 2 no shared chain, 4 no in-wave hops, 8 no candidate
+    diag &= 0xffu;                       // hand-over, 16 no record loads for the query box, 32 no counters.  Results are wrong by construction.
+#else
+    constexpr uint32_t ablate = 0u;
+#endif
+    // The kernel times ITSELF with the device's constant-rate wall clock (s_memrealtime): first wave start -> last wave end, two
+    // sharded atomicMax per wave (the start as its complement, so that the zeroed counters need no initial value).  A HIP time
+    // stamp on the dispatch packet costs the step ~7 us of idle GPU around the kernel; this costs it nothing measurable.
+    const unsigned long long clk0 = __builtin_amdgcn_s_memrealtime();
     __shared__ int32_t lds_stack[HALF_STACK][HALF_THREADS];
     __shared__ Candidates queue[HALF_WAVES][HALF_QCAP];
     __shared__ uint8_t share_map[HALF_WAVES][64];      // work sharing: lane id of the k-th donor
@@ -593,6 +609,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         qcount += __popcll(m);
     };
     auto push_subtree = [&](int32_t link) {                                   // an internal sibling / child that was hit: descended in phase 2
+        if (ablate & 1u) return;                                              // TIMING EXPERIMENT ONLY (wrong results): phase 1 alone
         if (sptr < HALF_STACK) { lds_stack[sptr][tid] = link; ++sptr; }
         else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)link); }
     };
@@ -606,7 +623,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     float4 rc = make_float4(0.f, 0.f, 0.f, 0.f), rd = rc;
     {
         float4 la = rc, lb = rc, pc = rc, pd = rc;
-        const bool own = valid && qi < last_leaf;
+        const bool own = valid && qi < last_leaf && !(ablate & 16u);
         if (own) { const float4 *rp = rec_right(recs, n, qi); rc = rp[0]; rd = rp[1]; const float4 *lp = rec_left(recs, n, qi); la = lp[0]; lb = lp[1]; }
         {   // the right half of recs[qi - 1]: the neighbour lane's registers (DPP wave_shr:1, a VALU move); lane 0 gets the
             // record before the wave's first one through the scalar cache (wave-uniform address)
@@ -631,6 +648,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     if (diag) tm1 = __builtin_amdgcn_s_memtime();
     // ---- phase 1a: hops below g_last
     uint32_t s = valid ? qi : END;                                            // cursor; >= g_last: joined the shared chain (or has none: g_last == n-1)
+    if (ablate & 4u) s = valid ? g_last : END;
     for (int hop = 0; hop < 128; ++hop) {                                     // tree height <= 96: the bound only matters for a corrupt tree
         const bool act = s < g_last;
         if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
@@ -656,7 +674,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     // along a root path are exactly that chain's cursors), which all lanes share from their joining point upwards: the
     // wave walks it once with SCALAR loads, and every lane that has joined tests the wave-uniform box.
     {
-        uint32_t t = g_last;
+        uint32_t t = (ablate & 2u) ? last_leaf : g_last;
         for (int hop = 0; hop < 128 && t < last_leaf; ++hop) {
             ++steps;
             const int4 *rq = reinterpret_cast<const int4 *>(rec_right(recs, n, t));    // wave-uniform address: scalar loads
@@ -725,12 +743,17 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         }
     }
     if (diag) tm4 = __builtin_amdgcn_s_memtime();
+    if (ablate & 8u) qcount = 0;
     while (qcount > 0) flush(qcount < 64u ? qcount : 64u);
     const unsigned long long t64 = wave_sum_u64(tested), v64 = wave_sum_u64(visits);
-    if (lane == 0) {
+    if (lane == 0 && !(ablate & 32u)) {
         if (t64) atomicAdd(&sh->pairs_tested, t64);
         if (v64) atomicAdd(&sh->node_visits, v64);
         if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
+    }
+    if (lane == 0) {
+        if (blockIdx.x < 256u) atomicMax(&sh->pad[4], ~clk0);                  // (the earliest start is among the first workgroups dispatched)
+        atomicMax(&sh->pad[11], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
     if (diag) {
         const unsigned long long hi = wave_sum_u64(dg_hops_in), ho = wave_sum_u64(dg_hops_out), vi = wave_sum_u64(dg_vis);
@@ -1227,7 +1250,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
     __syncthreads();
     for (uint32_t i = tid; i < staged; i += EXACT_THREADS) {
         const unsigned long long cur = pbase + i;
-        if (cur < cap) { pairs[2 * cur] = pbuf[i].x; pairs[2 * cur + 1] = pbuf[i].y; }
+        if (cur < cap) reinterpret_cast<uint2 *>(pairs)[cur] = pbuf[i];
     }
 }
 

@@ -101,6 +101,7 @@ struct cd_ctx {
     bool quiet_pass = false;                // launch_pass records no events (a pass on another stream, beside the one whose times are reported)
     int sort_mode = 0;                      // 0 hybrid on key bits 44..59 (every in-frame Morton key is below 2^60), 1 hybrid on bits 48..63 (2 global passes + in-LDS sort of the windows + fix-up), 2 half-key (4 passes + fix-up),
                                             // 2 full (8 passes); forced by CD_OPT_SORT_FULL, or escalated after an overflow on this context
+    int wall_clock_khz = 0;                 // hipDeviceAttributeWallClockRate: ticks of s_memrealtime per millisecond
     double root_box_host[6] = {};           // AABB of the whole tree, fetched together with other read-backs
     bool root_box_valid = false;
 };
@@ -127,6 +128,7 @@ void free_all(cd_ctx *c)
 }
 
 inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+constexpr uint64_t SPEC_PAIRS = 1u << 15;     // pairs that come back together with the counters, zero-copy (256 KB)
 
 // morton.h:70-89 / :7-29 on explicit inputs (cd_morton3d_points, cd_expand64_values): the device functions k_morton uses
 __global__ void k_morton_points(const double *__restrict__ xyz, uint64_t n, const double *__restrict__ frame, uint64_t *__restrict__ keys)
@@ -413,16 +415,19 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
     }
 }
 
-struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_candidates; uint32_t n_deferred; uint64_t wave_steps, candidates; };
-
-constexpr uint64_t SPEC_PAIRS = 1u << 15;     // pairs copied back speculatively together with the counters (256 KB)
+struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_candidates; uint32_t n_deferred; uint64_t wave_steps, candidates, clk_start_inv, clk_end; };
 
 // One host round trip and NO copy: k_report writes counters, the sort's time-out flags, the root box and the first
 // spec_n pairs straight into pinned host memory.  enqueue_report queues the kernel; parse_report reads the record
 // after the caller has synchronised the stream (the multi-GPU step queues two passes and synchronises once).
-int enqueue_report(cd_ctx *c, TravBuf &tb, bool want_pairs, uint64_t &spec_n)
+int ensure_report(TravBuf &tb)
 {
     if (!tb.h_report) HIPCHK(hipHostMalloc(&tb.h_report, sizeof(Report) + sizeof(uint32_t) * 2 * SPEC_PAIRS, hipHostMallocDefault));
+    return 0;
+}
+int enqueue_report(cd_ctx *c, TravBuf &tb, bool want_pairs, uint64_t &spec_n)
+{
+    { const int rc = ensure_report(tb); if (rc) return rc; }
     if (!want_pairs) spec_n = 0; else if (spec_n > SPEC_PAIRS) spec_n = SPEC_PAIRS;
     // (the pair list is allocated with an even capacity + slack, so the quad copy may read one pair past `take`)
     k_report<<<spec_n ? 32 : 1, REPORT_THREADS, 0, c->stream>>>(tb.d_state, c->d_os_ticket + 8, c->d_boxes, reinterpret_cast<Report *>(tb.h_report),
@@ -432,7 +437,7 @@ int enqueue_report(cd_ctx *c, TravBuf &tb, bool want_pairs, uint64_t &spec_n)
 void parse_report(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs, uint64_t spec_n)
 {
     const Report &r = *reinterpret_cast<const Report *>(tb.h_report);
-    h = HostCounters{r.n_pairs, r.pairs_tested, r.node_visits, r.max_shard_candidates, r.n_deferred, r.wave_steps, r.candidates};
+    h = HostCounters{r.n_pairs, r.pairs_tested, r.node_visits, r.max_shard_candidates, r.n_deferred, r.wave_steps, r.candidates, r.clk_start_inv, r.clk_end};
     std::memcpy(c->sort_flags, r.sort_flags, sizeof c->sort_flags);
     std::memcpy(c->root_box_host, r.root_box, sizeof(double) * 6);
     if (spec_n && spec_pairs) {
@@ -485,12 +490,12 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
         c->events_ride = false;
         if (!will_ride) HIPCHK(evrec(c, EV_TRAV0));
         if (!(c->prezeroed && attempt == 0 && &tb == &c->tb[0])) HIPCHK(hipMemsetAsync(tb.d_state, 0, sizeof(TravState), s));
+        const uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
         if (nq > 0) {
             if (external) launch_pass<true, false>(c, tb, src, nq, cap_pairs); else launch_pass<false, false>(c, tb, src, nq, cap_pairs);
             launches += per_pass;
         }
         if (!c->events_ride) HIPCHK(evrec(c, EV_TRAV1));      // device time of the kernels only: recorded before the read-back
-        const uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
         if ((rc = read_state(c, tb, h, pairs, spec_n))) return rc;
         spec_valid = spec_n;
         if (h.max_shard_candidates > tb.cand_cap / NSHARD) { if ((rc = grow_candidates(c, tb, h.max_shard_candidates))) return rc; continue; }
@@ -543,6 +548,9 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
     c->stats.traverse_launches = launches;
     c->stats.n_pairs = found; c->stats.pairs_tested = h.pairs_tested; c->stats.node_visits = h.node_visits;
     c->stats.wave_steps = h.wave_steps; c->stats.candidates = h.candidates;
+    // the descent kernel's own clock (k_descend_half): first wave start -> last wave end, in ticks of the device's constant wall clock
+    c->stats.ms_descend_clock = (h.clk_end && h.clk_start_inv && c->wall_clock_khz > 0 && c->stats.stack_overflows == 0)
+                                    ? (float)((double)(h.clk_end - ~h.clk_start_inv) / (double)c->wall_clock_khz) : 0.f;
     c->last_pairs_on_device = found <= cap_pairs ? found : cap_pairs;
     if (n_pairs) *n_pairs = found;
     return found > cap_pairs ? CD_OVERFLOW : CD_OK;
@@ -603,6 +611,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     if (!c) return CD_ERR_ARG;
     c->nv = nv; c->nt = nt;
     c->ntiles = cdiv(nt, SORT_TILE);
+    { int dev = 0, khz = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess) c->wall_clock_khz = khz; (void)hipGetLastError(); }
     const size_t n = nt;
 #define ALLOC(p, bytes) do { hipError_t e_ = hipMalloc((void **)&(p), (bytes)); if (e_ != hipSuccess) { free_all(c); delete c; return -(int)e_; } } while (0)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

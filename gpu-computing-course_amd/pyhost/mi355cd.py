@@ -30,7 +30,7 @@ class CdStats(C.Structure):
                 ("n_pairs", C.c_uint64), ("pairs_tested", C.c_uint64), ("node_visits", C.c_uint64),
                 ("wave_steps", C.c_uint64), ("candidates", C.c_uint64),
                 ("ms_descend", C.c_float), ("ms_exact", C.c_float), ("sort_passes", C.c_uint32), ("ms_pipeline", C.c_float),
-                ("ms_build_block", C.c_float)]
+                ("ms_build_block", C.c_float), ("ms_descend_clock", C.c_float)]
 
 
 # every symbol include/mi355cd.h declares (tests check the library exports exactly these)
@@ -239,6 +239,22 @@ class CollisionDetector:
 
     def self_collide(self, cap: int = 1 << 20, copy: bool = True):
         return self._pairs_call(self.lib.cd_self_collide, "cd_self_collide", cap, copy=copy)
+
+    def self_collide_into(self, buf: np.ndarray):
+        """cd_self_collide and cd_get_stats with every ctypes argument built ONCE (a per-frame loop: the marshalling of the
+        generic path costs several microseconds a step).  buf: caller-owned uint32[cap, 2], reused.  Returns (n_pairs, rc);
+        the pairs are buf[:min(n_pairs, cap)], the statistics self.fast_stats (a CdStats refreshed by every call)."""
+        fc = getattr(self, "_fast", None)
+        if fc is None or fc[0] is not buf:
+            n = C.c_uint64(0)
+            self.fast_stats = CdStats()
+            fc = self._fast = (buf, _ptr(buf), C.c_uint64(buf.shape[0]), n, C.byref(n), C.byref(self.fast_stats),
+                               self.lib.cd_self_collide, self.lib.cd_get_stats)
+        rc = fc[6](self._ctx, fc[1], fc[2], fc[4])
+        if rc != CD_OK and rc != CD_OVERFLOW:
+            raise CdError("cd_self_collide", rc)
+        fc[7](self._ctx, fc[5])
+        return fc[3].value, rc
 
     def sorted_pairs(self, cap: int = 1 << 20):
         """Pair list of the last traversal, sorted by (a, b) on the device."""

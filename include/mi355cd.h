@@ -72,6 +72,10 @@ typedef struct cd_stats {
     float ms_pipeline;         /* fused calls: pipeline start -> end of the traversal kernels, one event pair */
     float ms_build_block;      /* fused calls: the kernel that builds hierarchy + boxes + records of the 512-leaf     */
                                /* blocks (k_refit_seg_local<fused>), from its own dispatch packet; part of ms_refit  */
+    float ms_descend_clock;    /* the descent kernel (CD_OPT_TRAVERSAL 3) timed by ITSELF: first wave start -> last wave end on the    */
+                               /* device's constant-rate wall clock (s_memrealtime, hipDeviceAttributeWallClockRate).  Taken in every */
+                               /* call at no cost; slightly below ms_descend (the dispatch packet's stamps also cover launch and the  */
+                               /* end-of-kernel write-back).  0 when the traversal needed a deep pass or another variant ran           */
 } cd_stats;
 
 /* main.cu:64 loadObj (load_obj.h:24-103), host side, multi-threaded: parse `v x y z` (as float, widened to double)

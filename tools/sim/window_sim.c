@@ -94,3 +94,39 @@ void bfs_sim(int n, const int32_t *left, const int32_t *right, const int32_t *rl
     }
     free(node_of); free(fq); free(fn); free(gq); free(gn);
 }
+
+/* Phase-2 visits of the half traversal by size of the visited node (log2 of its leaf count), and how many DISTINCT (64-query group, node)
+ * pairs they are: out[2*k] visits at nodes with 2^k <= leaves < 2^(k+1), out[2*k+1] distinct (group, node) pairs among them. k < 24. */
+#include <stdio.h>
+static int cmp_u64(const void *a, const void *b) { uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b; return x < y ? -1 : x > y; }
+void p2_size_sim(int n, const int32_t *left, const int32_t *right, const int32_t *rf, const int32_t *rl, const double *boxes, uint64_t *out)
+{
+    int32_t *node_of = malloc(sizeof(int32_t) * n);
+    for (int i = 0; i < n - 1; ++i) { int l = left[i]; int sp = l >= n - 1 ? l - (n - 1) : rl[l]; node_of[sp] = i; }
+    memset(out, 0, sizeof(uint64_t) * 48);
+    size_t cap = 1 << 23, cnt = 0;
+    uint64_t *vis = malloc(sizeof(uint64_t) * cap);      /* (log2size << 56) | (group << 28) | node */
+    int32_t stack[256];
+    for (int j = 0; j < n; ++j) {
+        const double *qb = boxes + 6 * (size_t)((n - 1) + j);
+        int s = j;
+        while (s < n - 1) {
+            int i = node_of[s]; int c = right[i];
+            if (c < n - 1 && ov(qb, boxes + 6 * (size_t)c)) {
+                int sp = 0; stack[sp++] = c;
+                while (sp) {
+                    int nd = stack[--sp];
+                    int sz = rl[nd] - rf[nd] + 1, k = 0; while ((2 << k) <= sz) ++k;
+                    if (cnt < cap) vis[cnt++] = ((uint64_t)k << 56) | ((uint64_t)(j >> 6) << 28) | (uint64_t)nd;
+                    int cl = left[nd], cr = right[nd];
+                    if (cl < n - 1 && ov(qb, boxes + 6 * (size_t)cl)) stack[sp++] = cl;
+                    if (cr < n - 1 && ov(qb, boxes + 6 * (size_t)cr)) stack[sp++] = cr;
+                }
+            }
+            s = rl[i];
+        }
+    }
+    qsort(vis, cnt, sizeof(uint64_t), cmp_u64);
+    for (size_t i = 0; i < cnt; ++i) { int k = (int)(vis[i] >> 56); ++out[2 * k]; if (i == 0 || vis[i] != vis[i - 1]) ++out[2 * k + 1]; }
+    free(vis); free(node_of);
+}
