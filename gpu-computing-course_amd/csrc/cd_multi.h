@@ -113,8 +113,9 @@ struct cd_multi {
     int rank = 0, world = 1, flags = 0;
     uint64_t qcap = 0;                           // records per peer slab -- the SAME on every rank (max of the ranks' requests at creation, grown from the shared count matrix)
     int sticky_err = 0;                          // an error met AFTER the last collective decision of a step: published by the next step's status word
-    hipStream_t xstream = nullptr;               // payload exchange, beside the context's stream; HIGHEST priority: its kernels (RCCL's send / receive,
-                                                 // the pass over the received queries) are not queued behind a tree build that fills every CU
+    hipStream_t xstream = nullptr;               // payload exchange, beside the context's stream.  Default priority: with the device's HIGHEST priority
+                                                 // (CD_MULTI_PRIORITY_STREAM) the two streams' kernels slow each other down -- 0.65 against 0.32 ms per step in
+                                                 // the one-GPU rehearsal at config 4's scale (profiles/r03_experiments/multi_priority_stream.log)
     hipEvent_t ev_payload = nullptr, ev_counts = nullptr, ev_tree = nullptr, ev_cross = nullptr, ev_box = nullptr, ev[ME_COUNT] = {};
     double *d_myroot = nullptr;                  // 6: the box of all this rank's triangles, from their vertices
     double *d_partial = nullptr;                 // per-block bounds of that reduction (the context's own are the first stream's, for its Morton frame)
@@ -151,9 +152,11 @@ void multi_free(cd_multi *m)
 int multi_alloc(cd_multi *m)
 {
     const size_t W = (size_t)m->world;
-    { int least = 0, greatest = 0;
-      HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      HIPCHK(hipStreamCreateWithPriority(&m->xstream, hipStreamNonBlocking, greatest)); }
+    if (m->flags & CD_MULTI_PRIORITY_STREAM) {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&m->xstream, hipStreamNonBlocking, greatest));
+    } else HIPCHK(hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&m->ev_payload, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&m->ev_tree));                                                    // (a kernel's stop event: with time stamps)

@@ -240,6 +240,9 @@ enum {
                                /* instead of beside it on the second stream                                                     */
     CD_MULTI_SELF_SLICE = 4,   /* with CD_MULTI_SELF_PEER: the rank exchanges only the tenth of its triangles at its upper x end */
                                /* with itself -- a one-GPU rehearsal at the scale of a 10 % neighbour overlap                  */
+    CD_MULTI_PRIORITY_STREAM = 32, /* at creation only: the second stream (all-gathers, pack, send / receive, the pass over the received queries) gets the */
+                               /* device's highest stream priority.  Measured on one GPU (self-peer rehearsal, 1 M triangles): the two streams' kernels */
+                               /* then slow each other down -- 0.65 against 0.32 ms per step -- so it is off by default                                     */
     CD_MULTI_INJECT_FAILURE = 16 /* test hook: this rank's NEXT step fails locally (CD_ERR_INJECTED) before its pipeline starts; the flag */
                                /* clears itself.  Every other rank must return CD_ERR_PEER from the same step, none may block      */
 };

@@ -258,8 +258,8 @@ def test_deep_tree_uses_the_deferred_stack_path(mirrored, variant):
         assert r["stats"].max_stack > 32
     elif variant == 2:
         assert st.stack_overflows == 0 and st.traverse_launches == 2     # wave-uniform stack holds the whole height
-    elif variant == 3:
-        pass                                                             # (the half traversal's overflow case: next test)
+    elif variant >= 3:
+        pass                                                             # (the half traversals' overflow case: next test; variant 4's frontier is a ring, not a stack)
     else:
         assert st.stack_overflows > 0 and st.traverse_launches == (4 if variant == 1 else 2)
     assert n == r["stats"].n_pairs > 0

@@ -7,6 +7,8 @@ import mi355_synth as synth, mi355cd
 quads = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 SERIAL = 8 if "serial" in sys.argv[2:] else 0                                                     # CD_MULTI_CROSS_SERIAL
 SLICE = SERIAL | mi355cd.CD_MULTI_SELF_SLICE if "slice" in sys.argv[2:] else SERIAL      # exchange a tenth of the triangles (config 4's overlap)
+if "priority" in sys.argv[2:]:
+    SLICE |= mi355cd.CD_MULTI_PRIORITY_STREAM
 v, t, ids, vb = synth.cloth_shard(0, quads)
 with mi355cd.CollisionDetector(v, t, ids) as cd:
     cd.set_morton_frame(mi355cd.CD_FRAME_AUTO)

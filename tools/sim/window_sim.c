@@ -130,3 +130,40 @@ void p2_size_sim(int n, const int32_t *left, const int32_t *right, const int32_t
     for (size_t i = 0; i < cnt; ++i) { int k = (int)(vis[i] >> 56); ++out[2 * k]; if (i == 0 || vis[i] != vis[i - 1]) ++out[2 * k + 1]; }
     free(vis); free(node_of);
 }
+
+/* Half traversal where a hit subtree of at most F leaves is not descended but handed over as a RANGE (every leaf box in it tested
+ * directly).  Per F: out[0] tree visits in phase 2, [1] range items, [2] leaf tests in ranges, [3] sum over waves (64 queries) of the
+ * level-synchronous step count of the remaining descents (levels with any item), [4] leaf hits from ranges, [5] leaf hits from the tree,
+ * [6] sum over waves of ceil(range items / 8) (flat steps at 8 items per wave-step) */
+void flat_sim(int n, const int32_t *left, const int32_t *right, const int32_t *rf, const int32_t *rl, const double *boxes, int F, uint64_t *out)
+{
+    int32_t *node_of = malloc(sizeof(int32_t) * n);
+    for (int i = 0; i < n - 1; ++i) { int l = left[i]; int sp = l >= n - 1 ? l - (n - 1) : rl[l]; node_of[sp] = i; }
+    memset(out, 0, sizeof(uint64_t) * 8);
+    size_t cap = 1 << 20;
+    int32_t *fq = malloc(sizeof(int32_t) * cap), *fn = malloc(sizeof(int32_t) * cap), *gq = malloc(sizeof(int32_t) * cap), *gn = malloc(sizeof(int32_t) * cap);
+    for (int w0 = 0; w0 < n; w0 += 64) {
+        size_t cnt = 0; uint64_t items = 0;
+        #define HANDLE(c, qj, qb, Q, N, M) do { int c_ = (c); if (c_ >= n - 1) { ++out[5]; } else { int sz_ = rl[c_] - rf[c_] + 1; \
+            if (sz_ <= F) { ++out[1]; ++items; out[2] += sz_; for (int k_ = rf[c_]; k_ <= rl[c_]; ++k_) if (ov(qb, boxes + 6 * (size_t)((n - 1) + k_))) ++out[4]; } \
+            else { Q[M] = qj; N[M++] = c_; } } } while (0)
+        for (int j = w0; j < w0 + 64 && j < n; ++j) {
+            const double *qb = boxes + 6 * (size_t)((n - 1) + j);
+            int s = j;
+            while (s < n - 1) { int i = node_of[s]; int c = right[i]; if (ov(qb, boxes + 6 * (size_t)c)) HANDLE(c, j, qb, fq, fn, cnt); s = rl[i]; }
+        }
+        while (cnt) {
+            ++out[3]; out[0] += cnt;
+            size_t m = 0;
+            for (size_t k = 0; k < cnt; ++k) {
+                const double *qb = boxes + 6 * (size_t)((n - 1) + fq[k]);
+                int nd = fn[k], cl = left[nd], cr = right[nd];
+                if (ov(qb, boxes + 6 * (size_t)cl)) HANDLE(cl, fq[k], qb, gq, gn, m);
+                if (ov(qb, boxes + 6 * (size_t)cr)) HANDLE(cr, fq[k], qb, gq, gn, m);
+            }
+            int32_t *t; t = fq; fq = gq; gq = t; t = fn; fn = gn; gn = t; cnt = m;
+        }
+        out[6] += (items + 7) / 8;
+    }
+    free(node_of); free(fq); free(fn); free(gq); free(gn);
+}
