@@ -398,12 +398,12 @@ def main():
                 kern[k_] /= k
             traffic_of = {}
             l2_of = {}
-            whole_traffic = None
+            whole_traffic = whole_traffic_raw = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if tj.get("triangles") == nt:
-                    whole_traffic = tj.get("whole_path_hbm_bytes_per_step")
+                    whole_traffic = tj.get("whole_path_hbm_bytes_per_step"); whole_traffic_raw = tj.get("whole_path_hbm_bytes_per_step_raw")
                     for name, v in tj.get("whole_path_per_kernel", {}).items():
                         traffic_of[name] = v
                     l2_of["k_descend_half"] = tj.get("l2_hit_rate")
@@ -414,7 +414,8 @@ def main():
                 return {"bound": "hbm", "kernel": label, "kernel_symbol": symbol, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": tr.get("hbm_bytes_per_step"), "traffic_raw": tr.get("hbm_bytes_per_step_raw"),
                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of an earlier run of this command; NOT measured in this run): "
-                                          "traffic = FETCH_SIZE corrected as calibrated for this kernel's request mix + WRITE_SIZE, traffic_raw = FETCH_SIZE as reported + WRITE_SIZE",
+                                          "traffic = reads by request size (32 n32 + 64 n64 + 128 n128, TCC_EA0_RDREQ_*) + WRITE_SIZE; traffic_raw = FETCH_SIZE as reported "
+                                          "(every request tallied at 64 B) + WRITE_SIZE; calibration: profiles/r03_experiments/fetch_size_calibration.csv",
                         "l2_hit_rate": l2_of.get(symbol),
                         "algorithmic_bytes_per_launch": bytes_per_tri * nt, "avg_launch_ms": ms}
 
@@ -430,7 +431,7 @@ def main():
             line["roofline"] = dict(cands[0])
             line["roofline"]["other_kernels"] = cands[1:]
             line["roofline"]["whole_path"] = {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9,
-                                              "frac": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": whole_traffic}
+                                              "frac": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": whole_traffic, "traffic_raw": whole_traffic_raw}
             if not args.no_parity:
                 # checker leg: the LAST TIMED step's pair set + pairs-tested count against the oracle (one more CPU pass, with pairs)
                 pc = parity_check(last_pairs, last_tested, verts, vidx)

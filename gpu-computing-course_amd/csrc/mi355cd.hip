@@ -101,6 +101,12 @@ struct cd_ctx {
     bool quiet_pass = false;                // launch_pass records no events (a pass on another stream, beside the one whose times are reported)
     int sort_mode = 0;                      // 0 hybrid on key bits 44..59 (every in-frame Morton key is below 2^60), 1 hybrid on bits 48..63 (2 global passes + in-LDS sort of the windows + fix-up), 2 half-key (4 passes + fix-up),
                                             // 2 full (8 passes); forced by CD_OPT_SORT_FULL, or escalated after an overflow on this context
+    // CD_OPT_GRAPH: the steady-state fused step captured once as a hipGraph and replayed (graph_step); the key is everything a replay bakes in
+    bool graph_opt = false;
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+    struct GraphKey { uint64_t cap, spec_n; int sort_mode, variant, frame_mode; uint32_t nt, exact_blocks, dbg; const void *p_pairs, *p_cand, *p_defer, *p_report; uint64_t cand_cap; uint32_t defer_cap; } graph_key = {};
+    struct GraphPost { bool leaves_filled, leaf_records_filled, hierarchy_valid, internal_boxes_valid, last_tree_fused, events_ride, scratch_clean; uint32_t sort_passes; } graph_post = {};
+    uint64_t graph_replays = 0, graph_captures = 0;
     int wall_clock_khz = 0;                 // hipDeviceAttributeWallClockRate: ticks of s_memrealtime per millisecond
     double root_box_host[6] = {};           // AABB of the whole tree, fetched together with other read-backs
     bool root_box_valid = false;
@@ -123,6 +129,8 @@ void free_all(cd_ctx *c)
     }
     for (int i = 0; i < 2; ++i) { hipFree(c->pp_keys[i]); hipFree(c->pp_vals[i]); }
     hipFree(c->pp_flags); hipFree(c->pp_os);
+    if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) hipGraphDestroy(c->graph);
     for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);
 }
@@ -291,11 +299,15 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
                           reinterpret_cast<uint4 *>(c->d_os_look), (uint32_t)(2 * gran / sizeof(uint4)),
                           reinterpret_cast<uint32_t *>(c->tb[0].d_state), (uint32_t)(sizeof(TravState) / sizeof(uint32_t))};
         }
-        hipExtLaunchKernelGGL(k_build_block, dim3(nblocks), dim3(REFIT_BLK), 0u, s, stamp ? c->ev[EV_BLK0] : nullptr, stamp ? c->ev[EV_BLK1] : nullptr, 0u,
-                              (const double *)c->d_verts, (const LeafTri *)c->d_leaf, (int)n, (const uint64_t *)c->d_keys[0], c->d_split_of,
-                              c->d_boxes, c->d_recs32, c->d_qbox, c->d_root, c->d_seg, c->d_seg32, (int)c->nbp2,
-                              cross_list, cross_count, c->cross_cap, zp,
-                              (c->nbp2 > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK && !c->dbg_split_cross) ? SEG32_MIN_LEVEL : SEG_MIN_LEVEL);
+        const int seg_min = (c->nbp2 > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK && !c->dbg_split_cross) ? SEG32_MIN_LEVEL : SEG_MIN_LEVEL;
+        if (stamp)
+            hipExtLaunchKernelGGL(k_build_block, dim3(nblocks), dim3(REFIT_BLK), 0u, s, c->ev[EV_BLK0], c->ev[EV_BLK1], 0u,
+                                  (const double *)c->d_verts, (const LeafTri *)c->d_leaf, (int)n, (const uint64_t *)c->d_keys[0], c->d_split_of,
+                                  c->d_boxes, c->d_recs32, c->d_qbox, c->d_root, c->d_seg, c->d_seg32, (int)c->nbp2,
+                                  cross_list, cross_count, c->cross_cap, zp, seg_min);
+        else                                        // (no time stamps: a plain launch, which a stream capture can record -- graph_step)
+            k_build_block<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_keys[0], c->d_split_of, c->d_boxes, c->d_recs32, c->d_qbox, c->d_root,
+                                                        c->d_seg, c->d_seg32, (int)c->nbp2, cross_list, cross_count, c->cross_cap, zp, seg_min);
         c->scratch_clean = self_cleaning;       // (judge_sort_flags takes it back when the sort has raised a flag)
     } else
         k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded,
@@ -307,10 +319,14 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         // (the multi-GPU step's "tree is there" event rides on this kernel's dispatch packet: recorded on its own it is a barrier
         //  packet between the tree and the traversal, ~6 us of idle GPU)
         hipEvent_t done = c->tree_done_event; c->tree_done_event = nullptr;
-        hipExtLaunchKernelGGL(k_cross_fused, dim3(xb + 1u /* the last workgroup folds the FP64 box of all leaves */), dim3(256),
-                              (uint32_t)(sizeof(float) * 6 * (c->nbp2 >= 2 ? c->nbp2 / 2 : 1)), s, nullptr, done, 0u,
-                              (const uint64_t *)c->d_keys[0], (int)n, (const double *)c->d_seg, (const float *)c->d_seg32, (int)c->nbp2, nblocks, (const LeafBox32 *)c->d_qbox, c->d_boxes,
-                              c->d_recs32, (const int32_t *)c->d_split_of, c->d_root, (const int32_t *)c->d_cross, (const uint32_t *)cross_count, c->cross_cap);
+        const uint32_t xlds = (uint32_t)(sizeof(float) * 6 * (c->nbp2 >= 2 ? c->nbp2 / 2 : 1));
+        if (done)
+            hipExtLaunchKernelGGL(k_cross_fused, dim3(xb + 1u /* the last workgroup folds the FP64 box of all leaves */), dim3(256), xlds, s, nullptr, done, 0u,
+                                  (const uint64_t *)c->d_keys[0], (int)n, (const double *)c->d_seg, (const float *)c->d_seg32, (int)c->nbp2, nblocks, (const LeafBox32 *)c->d_qbox, c->d_boxes,
+                                  c->d_recs32, (const int32_t *)c->d_split_of, c->d_root, (const int32_t *)c->d_cross, (const uint32_t *)cross_count, c->cross_cap);
+        else
+            k_cross_fused<<<xb + 1u, 256, xlds, s>>>(c->d_keys[0], (int)n, c->d_seg, c->d_seg32, (int)c->nbp2, nblocks, c->d_qbox, c->d_boxes,
+                                                     c->d_recs32, c->d_split_of, c->d_root, c->d_cross, cross_count, c->cross_cap);
         c->internal_boxes_valid = write_internal;
         HIPCHK(evrec(c, EV_REFIT1));
         HIPCHK(hipGetLastError());
@@ -395,7 +411,10 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         const uint32_t qarg = qpw | (c->dbg_no_shared_path ? 0x40000000u : 0u);
         uint2 *dl = DEEP ? nullptr : tb.d_defer; const uint32_t dcap = DEEP ? 0u : tb.defer_cap; int32_t *deep = DEEP ? tb.d_deep : nullptr;
         const uint32_t half = half_mode ? 1u : 0u;
-        if (half_mode && !DEEP && c->trav_variant == 4)
+        const bool plain = !e0 && !e1 && !e2;          // no time stamp rides on these launches: plain launches (a stream capture can record them)
+        if (plain && half_mode && !DEEP && c->trav_variant == 3)
+            k_descend_half<<<cdiv(items, 64u * HALF_WAVES), HALF_THREADS, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
+        else if (half_mode && !DEEP && c->trav_variant == 4)
             hipExtLaunchKernelGGL(k_descend_wg, dim3(cdiv(items, (uint32_t)WGF_THREADS)), dim3(WGF_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, n, (const NodeRec32 *)c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
         else if (half_mode && !DEEP)
@@ -408,9 +427,13 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, true>), grid, dim3(DESC_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
         if (!DEEP && !ride && !c->quiet_pass) evrec(c, EV_DESC1);
-        hipExtLaunchKernelGGL((k_exact<EXTERNAL>), dim3(c->exact_blocks), dim3(EXACT_THREADS), 0u, s, nullptr, e2, 0u,
-                              src, n, (const LeafTri *)c->d_leaf, (const double *)c->d_boxes, (const double *)c->d_verts, vb, (const Candidates *)tb.d_cand,
-                              (unsigned long long)shard_cap, tb.d_pairs, (unsigned long long)cap_pairs, tb.d_state, half);
+        if (plain)
+            k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, tb.d_cand, (unsigned long long)shard_cap, tb.d_pairs,
+                                                                        (unsigned long long)cap_pairs, tb.d_state, half);
+        else
+            hipExtLaunchKernelGGL((k_exact<EXTERNAL>), dim3(c->exact_blocks), dim3(EXACT_THREADS), 0u, s, nullptr, e2, 0u,
+                                  src, n, (const LeafTri *)c->d_leaf, (const double *)c->d_boxes, (const double *)c->d_verts, vb, (const Candidates *)tb.d_cand,
+                                  (unsigned long long)shard_cap, tb.d_pairs, (unsigned long long)cap_pairs, tb.d_state, half);
         c->events_ride = ride;
     }
 }
@@ -592,6 +615,92 @@ int pp_sort(cd_ctx *c, uint32_t m)
     return 0;
 }
 
+int judge_sort_flags(cd_ctx *c);
+// ---- CD_OPT_GRAPH: the steady-state fused step as ONE hipGraph launch ------------------------------------------------
+// Eligible: no stage events, no time stamps, hybrid sort, fused build, half traversal, and a previous step has left the
+// scratch clean (so the captured sequence holds kernels only: no memset).  The capture records exactly what the stream path
+// enqueues -- k_morton, 2 x k_os_pass, k_local_sort, k_build_block, k_cross_fused, k_descend_half, k_exact, k_report -- with
+// the arguments of this call baked in; any change of those (capacity, buffers grown, options) captures again.  Whatever the
+// report says that the stream path would answer with a retry -- a sort flag, a candidate shard that overflowed, a deferred
+// subtree -- is handed to the stream path (handled = false, or run_traversal on the tree that is there).
+void graph_drop(cd_ctx *c)
+{
+    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+}
+bool graph_eligible(const cd_ctx *c)
+{
+    return c->graph_opt && !c->stage_events && c->stamp_mask == 0 && c->sort_mode <= 1 && fused_build_next(c) && c->trav_variant == 3 &&
+           c->scratch_clean && !c->dbg_diag && !c->dbg_lds_pad && c->nt > 1 && c->tree_done_event == nullptr;
+}
+int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs, bool &handled)
+{
+    handled = false;
+    TravBuf &tb = c->tb[0];
+    hipStream_t s = c->stream;
+    int rc = ensure_pairs(c, tb, cap_pairs > 0 ? cap_pairs : 1);
+    if (!rc) rc = ensure_report(tb);
+    if (rc) return rc;
+    uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
+    const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1),
+                               tb.d_pairs, tb.d_cand, tb.d_defer, tb.h_report, tb.cand_cap, tb.defer_cap};
+    if (!c->graph_exec || std::memcmp(&key, &c->graph_key, sizeof key) != 0) {
+        graph_drop(c);
+        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        c->prezeroed = true;
+        rc = enqueue_morton_sort(c, false);
+        if (!rc) rc = enqueue_tree(c);
+        if (!rc) {
+            QuerySrc src{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, nullptr, nullptr, c->d_os_ticket + 8};
+            launch_pass<false, false>(c, tb, src, c->nt, cap_pairs);
+            rc = enqueue_report(c, tb, pairs != nullptr, spec_n);
+        }
+        c->prezeroed = false;
+        hipGraph_t g = nullptr;
+        const hipError_t ee = hipStreamEndCapture(s, &g);
+        if (rc || ee != hipSuccess || !g) { if (g) hipGraphDestroy(g); (void)hipGetLastError(); c->scratch_clean = false; return CD_OK; }   // (not handled: the stream path runs, with its memset)
+        c->graph = g;
+        if (hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) { graph_drop(c); (void)hipGetLastError(); c->scratch_clean = false; return CD_OK; }
+        std::memset(&c->graph_key, 0, sizeof c->graph_key);
+        c->graph_key = key;
+        c->graph_post = cd_ctx::GraphPost{c->leaves_filled, c->leaf_records_filled, c->hierarchy_valid, c->internal_boxes_valid, c->last_tree_fused, c->events_ride, c->scratch_clean,
+                                          c->stats.sort_passes};
+        ++c->graph_captures;
+    }
+    // what the enqueue functions leave behind on the host side, as the capture left it
+    const cd_ctx::GraphPost &gp = c->graph_post;
+    c->leaves_filled = gp.leaves_filled; c->leaf_records_filled = gp.leaf_records_filled; c->hierarchy_valid = gp.hierarchy_valid;
+    c->internal_boxes_valid = gp.internal_boxes_valid; c->last_tree_fused = gp.last_tree_fused; c->events_ride = gp.events_ride; c->scratch_clean = gp.scratch_clean;
+    c->stats.sort_passes = gp.sort_passes;
+    HIPCHK(hipGraphLaunch(c->graph_exec, s));
+    HIPCHK(hipStreamSynchronize(s));
+    ++c->graph_replays;
+    HostCounters h = {};
+    parse_report(c, tb, h, pairs, spec_n);
+    c->stage = ST_REFIT; c->root_box_valid = true;
+    { const int js = judge_sort_flags(c); if (js != CD_OK) return CD_OK; }                 // (not handled: the stream path redoes the step in the sort's next form)
+    if (h.max_shard_candidates > tb.cand_cap / NSHARD || h.n_deferred > 0) {             // the tree is fine: the traversal again, with the stream path's retries / deep pass
+        handled = true;
+        c->scratch_clean = false;
+        return run_traversal(c, tb, nullptr, 0, pairs, cap_pairs, n_pairs);
+    }
+    handled = true;
+    const uint64_t found = h.n_pairs, ncopy = found < cap_pairs ? found : cap_pairs;
+    if (pairs && ncopy > spec_n) {
+        HIPCHK(hipMemcpyAsync(pairs + 2 * spec_n, tb.d_pairs + 2 * spec_n, sizeof(uint32_t) * 2 * (ncopy - spec_n), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    c->stats.ms_morton = c->stats.ms_sort = c->stats.ms_hierarchy = c->stats.ms_refit = c->stats.ms_traverse = c->stats.ms_descend = c->stats.ms_exact = 0.f;
+    c->stats.ms_pipeline = c->stats.ms_build_block = 0.f;
+    c->stats.traverse_launches = 0; c->stats.stack_overflows = 0;       // (0: this call launched no kernel of its own -- one graph launch)
+    c->stats.n_pairs = found; c->stats.pairs_tested = h.pairs_tested; c->stats.node_visits = h.node_visits;
+    c->stats.wave_steps = h.wave_steps; c->stats.candidates = h.candidates;
+    c->stats.ms_descend_clock = (h.clk_end && h.clk_start_inv && c->wall_clock_khz > 0) ? (float)((double)(h.clk_end - ~h.clk_start_inv) / (double)c->wall_clock_khz) : 0.f;
+    c->last_pairs_on_device = ncopy;
+    if (n_pairs) *n_pairs = found;
+    return found > cap_pairs ? CD_OVERFLOW : CD_OK;
+}
+
 }  // namespace
 
 void multi_detach_from(cd_ctx *c);          // cd_multi.h
@@ -708,13 +817,13 @@ int cd_set_morton_frame(cd_ctx *c, int mode, const double offset[3], const doubl
 
 // the onesweep look-back spins are bounded; a timeout sets one of the words d_os_ticket[8..15]
 constexpr int SORT_REDO = 77;                   // internal: a run was too long for this form of the sort, redo with the next one
-static int judge_sort_flags(cd_ctx *c)
+namespace { int judge_sort_flags(cd_ctx *c)
 {
     for (int i = 0; i < 9; ++i) if (c->sort_flags[i]) c->scratch_clean = false;     // the flag words are cleared by the memset only
     for (int i = 0; i < 8; ++i) if (c->sort_flags[i]) return CD_ERR_SORT;
     if (c->sort_flags[8]) { if (c->sort_mode >= 3) return CD_ERR_SORT; ++c->sort_mode; return SORT_REDO; }
     return CD_OK;
-}
+} }
 static int check_sort_flags(cd_ctx *c)
 {
     HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));
@@ -836,6 +945,11 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
 {
     if (!c || (cap_pairs && !pairs)) return CD_ERR_ARG;
     int rc;
+    if (graph_eligible(c)) {                                               // CD_OPT_GRAPH: the steady-state step as one graph launch
+        bool handled = false;
+        rc = graph_step(c, pairs, cap_pairs, n_pairs, handled);
+        if (rc < 0 || handled) return rc;
+    }
     Prezeroed fused(c);                                                    // one memset for every counter of the pipeline
     rc = enqueue_morton_sort(c, !fused_build_next(c));
     if (!rc) rc = enqueue_tree(c);
@@ -1049,6 +1163,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (key == CD_OPT_QUERIES_PER_WAVE) { if (value < 64 || value > (1 << 20) || value % 64) return CD_ERR_ARG; c->queries_per_wave = (uint32_t)value; return CD_OK; }
     if (key == CD_OPT_SORT_FULL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->sort_mode = value == 0 ? 0 : (value == 1 ? 3 : 2); return CD_OK; }
     if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }
+    if (key == CD_OPT_GRAPH) { c->graph_opt = value != 0; if (!c->graph_opt) graph_drop(c); return CD_OK; }
     if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
     if (key == 102) { c->dbg_no_shared_path = (uint32_t)value; return CD_OK; }
     if (key == 103) { c->dbg_diag = (uint32_t)value; return CD_OK; }

@@ -58,7 +58,7 @@ typedef struct cd_stats {
     float ms_refit;            /* bottom-up AABB refit                      (main.cu:107)            */
     float ms_traverse;         /* traversal + exact test                    (main.cu:142)            */
     float ms_check;            /* verifier kernels                          (main.cu:115,123,131)    */
-    uint32_t traverse_launches;/* kernel launches inside the last traversal                         */
+    uint32_t traverse_launches;/* kernel launches inside the last traversal (0: the step was a graph replay, CD_OPT_GRAPH) */
     uint32_t stack_overflows;  /* queries that needed the deep-stack fallback in the last traversal */
     uint64_t n_pairs;          /* contacts found by the last traversal      (main.cu:145 test_val)   */
     uint64_t pairs_tested;     /* (query, leaf) pairs with strictly overlapping AABBs                */
@@ -183,6 +183,10 @@ enum {
     CD_OPT_STAGE_TIMING     = 3,   /* 1 (default): HIP events around every stage (cd_stats.ms_morton ... ms_refit); 0: only the  */
                                    /*    events of the pipeline as a whole and of the descent kernel (ms_pipeline, ms_traverse,   */
                                    /*    ms_descend, ms_exact) -- each stage boundary costs a few idle microseconds                */
+    CD_OPT_GRAPH            = 5,   /* 1: cd_self_collide replays its steady-state step -- the nine kernel launches -- as ONE hipGraph launch, captured on   */
+                                   /*    the first eligible call (CD_OPT_STAGE_TIMING 0, CD_OPT_KERNEL_STAMPS 0, default sort / build / traversal, a previous */
+                                   /*    step done); anything a replay cannot answer (a sort flag, an overflow, a deep pass) falls back to the stream path.  */
+                                   /*    Default 0: measured equal to the stream path within noise -- the host is ahead of the GPU either way */
     CD_OPT_QUERIES_PER_WAVE = 1    /* variant 1: queries one wave works through with dynamic lane refill (x64)         */
 };
 int cd_set_option(cd_ctx *ctx, int key, int64_t value);

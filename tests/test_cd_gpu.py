@@ -1089,3 +1089,48 @@ def test_config4_neighbour_pair_at_full_shard_size_over_the_loopback_transport()
         assert all(st["checks"].values()), st
         assert st["attempts"] == 1 and st["host_syncs"] == [2, 2], st
         assert st["sent"][0] > 90_000 and st["sent"][1] > 90_000 and sum(st["cross"]) > 1000, st       # ~101 k overlapping triangles each way
+
+
+def test_graph_replay_of_the_steady_state_step_gives_the_same_results():
+    """CD_OPT_GRAPH: the fused step replayed as one hipGraph launch -- same pair set, same counters as the stream path and the oracle,
+    across new vertex positions (same graph), another capacity (captured again), an overflowing capacity, and a mesh whose
+    traversal needs the deep pass (handed to the stream path's traversal)."""
+    verts, vidx = synth.cloth_pair(120)
+    r = oracle.pipeline(verts, vidx)
+    want = oracle.pair_set(r["pairs"])
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+        cd.set_option(mi355cd.CD_OPT_GRAPH, 1)
+        for it in range(6):                                  # step 0 runs on the stream (nothing to replay yet), the rest are replays
+            pairs, n, rc = cd.self_collide(cap=1 << 20)
+            assert rc == 0 and n == r["stats"].n_pairs and np.array_equal(oracle.pair_set(pairs), want), it
+            assert cd.stats().pairs_tested == r["stats"].pairs_tested
+            assert cd.stats().traverse_launches == (2 if it == 0 else 0), it         # 0 = the step was one graph launch
+        keys, perm = cd.export_keys()
+        assert np.array_equal(keys, r["keys"]) and np.array_equal(perm, r["perm"])
+        v2 = verts.copy(); v2[:, 1] += 0.003 * np.sin(40.0 * v2[:, 0]); v2 = v2.astype(np.float32).astype(np.float64)
+        r2 = oracle.pipeline(v2, vidx)
+        cd.update_vertices(v2)
+        for it in range(3):
+            pairs, n, rc = cd.self_collide(cap=1 << 20)
+            assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r2["pairs"])) and cd.stats().pairs_tested == r2["stats"].pairs_tested
+        pairs, n, rc = cd.self_collide(cap=1 << 18)          # another capacity: another capture
+        assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r2["pairs"]))
+        pairs, n, rc = cd.self_collide(cap=16)               # too small: the true count comes back with CD_OVERFLOW
+        assert rc == mi355cd.CD_OVERFLOW and n == r2["stats"].n_pairs and len(pairs) == 16
+        pairs, n, rc = cd.self_collide(cap=1 << 18)
+        assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r2["pairs"]))
+        cd.set_option(mi355cd.CD_OPT_GRAPH, 0)
+        pairs, n, rc = cd.self_collide(cap=1 << 18)
+        assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r2["pairs"]))
+    # a comb tree whose chain overflows a lane's stack: the replayed step reports deferred subtrees, the stream path's traversal finishes them
+    off = np.zeros(3); span = np.full(3, 1048576.0)
+    cv, ct = _comb([1 << (59 - k) for k in range(60)], big_first=True)
+    rc_ = oracle.pipeline(cv, ct, off=off, span=span)
+    with mi355cd.CollisionDetector(cv, ct) as cd:
+        cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, off, span)
+        cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0); cd.set_option(mi355cd.CD_OPT_GRAPH, 1)
+        for it in range(4):
+            pairs, n, rc = cd.self_collide()
+            assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(rc_["pairs"])), it
+            assert cd.stats().pairs_tested == rc_["stats"].pairs_tested

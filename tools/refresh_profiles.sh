@@ -10,6 +10,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o run -- pytho
 echo "kernel trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 echo "FETCH_SIZE pass done"
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/pmc_rdreq -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-parity --steps 20 --warmup 5 > $O/pmc_rdreq.json 2> $O/pmc_rdreq.err
+echo "size-resolved read request pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_write.json 2> $O/pmc_write.err
 echo "WRITE_SIZE pass done"
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -o run -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_l2.json 2> $O/pmc_l2.err
