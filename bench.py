@@ -263,7 +263,8 @@ def main():
     if args.qpw is not None:
         engine.cd.set_option(mi355cd.CD_OPT_QUERIES_PER_WAVE, args.qpw)
     cap = 1 << 22
-    pair_buf = np.empty((cap, 2), dtype=np.uint32)
+    host_pairs = mi355cd.HostPairs(cap)                               # cd_alloc_host_pairs: pinned, the GPU writes the pairs straight into it
+    pair_buf = host_pairs.array
 
     comm_device = None if backend == "nccl" else "cpu"
     ms = None
@@ -502,6 +503,8 @@ def main():
     if ms is not None:
         ms.close()
     engine.close()
+    pair_buf = None
+    host_pairs.close()
     if multi_path:
         dist.destroy_process_group()
 

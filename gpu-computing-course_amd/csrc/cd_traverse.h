@@ -71,11 +71,12 @@ __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__re
         if (lane < 9) out->sort_flags[lane] = sort_flags[lane];
         if (lane < 6) out->root_box[lane] = root_box[lane];
     }
-    const unsigned long long take = np < spec_n ? np : spec_n;          // pairs are 8 bytes; move them as 16-byte quads
-    const unsigned long long quads = (take + 1) >> 1;
+    const unsigned long long take = np < spec_n ? np : spec_n;          // pairs are 8 bytes; move them as 16-byte quads, an odd last pair on its own
+    const unsigned long long quads = take >> 1;                         // (pairs_out may be the caller's buffer: nothing is written past the list)
     const uint4 *src = reinterpret_cast<const uint4 *>(pairs);
     uint4 *dst = reinterpret_cast<uint4 *>(pairs_out);
     for (unsigned long long i = (unsigned long long)blockIdx.x * REPORT_THREADS + threadIdx.x; i < quads; i += (unsigned long long)gridDim.x * REPORT_THREADS) dst[i] = src[i];
+    if ((take & 1ull) && blockIdx.x == 0 && threadIdx.x == 64) reinterpret_cast<uint2 *>(pairs_out)[take - 1] = reinterpret_cast<const uint2 *>(pairs)[take - 1];
 }
 
 constexpr int TRAV_THREADS = 256;

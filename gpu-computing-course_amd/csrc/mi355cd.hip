@@ -12,7 +12,9 @@
 #include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 using namespace cd;
@@ -136,6 +138,18 @@ void free_all(cd_ctx *c)
 }
 
 inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// pair buffers handed out by cd_alloc_host_pairs: pinned host memory the report kernel writes STRAIGHT into (no staging copy on the host)
+struct PinnedPairs { std::mutex mu; std::vector<std::pair<const uint32_t *, uint64_t>> v; };
+PinnedPairs &pinned_pairs() { static PinnedPairs p; return p; }
+bool is_pinned_pairs(const uint32_t *pairs, uint64_t cap)
+{
+    if (!pairs) return false;
+    PinnedPairs &pp = pinned_pairs();
+    std::lock_guard<std::mutex> lock(pp.mu);
+    for (const auto &e : pp.v) if (e.first == pairs && cap <= e.second) return true;
+    return false;
+}
 constexpr uint64_t SPEC_PAIRS = 1u << 15;     // pairs that come back together with the counters, zero-copy (256 KB)
 
 // morton.h:70-89 / :7-29 on explicit inputs (cd_morton3d_points, cd_expand64_values): the device functions k_morton uses
@@ -448,13 +462,15 @@ int ensure_report(TravBuf &tb)
     if (!tb.h_report) HIPCHK(hipHostMalloc(&tb.h_report, sizeof(Report) + sizeof(uint32_t) * 2 * SPEC_PAIRS, hipHostMallocDefault));
     return 0;
 }
-int enqueue_report(cd_ctx *c, TravBuf &tb, bool want_pairs, uint64_t &spec_n)
+// direct: the first spec_n pairs go straight into the CALLER's buffer (pinned host memory from cd_alloc_host_pairs) instead of the staging area behind the record
+int enqueue_report(cd_ctx *c, TravBuf &tb, bool want_pairs, uint64_t &spec_n, uint32_t *direct = nullptr)
 {
     { const int rc = ensure_report(tb); if (rc) return rc; }
     if (!want_pairs) spec_n = 0; else if (spec_n > SPEC_PAIRS) spec_n = SPEC_PAIRS;
-    // (the pair list is allocated with an even capacity + slack, so the quad copy may read one pair past `take`)
+    // (the pair list is allocated with an even capacity + slack, so the quad copy may read one pair past `take`; a pinned buffer of
+    //  cd_alloc_host_pairs has the same slack)
     k_report<<<spec_n ? 32 : 1, REPORT_THREADS, 0, c->stream>>>(tb.d_state, c->d_os_ticket + 8, c->d_boxes, reinterpret_cast<Report *>(tb.h_report),
-                                                              tb.d_pairs, reinterpret_cast<uint32_t *>(tb.h_report + sizeof(Report)), (unsigned long long)spec_n);
+                                                              tb.d_pairs, direct ? direct : reinterpret_cast<uint32_t *>(tb.h_report + sizeof(Report)), (unsigned long long)spec_n);
     return 0;
 }
 void parse_report(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs, uint64_t spec_n)
@@ -468,12 +484,12 @@ void parse_report(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs,
         std::memcpy(spec_pairs, tb.h_report + sizeof(Report), sizeof(uint32_t) * 2 * take);
     }
 }
-int read_state(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs = nullptr, uint64_t spec_n = 0)
+int read_state(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs = nullptr, uint64_t spec_n = 0, bool direct = false)
 {
-    int rc = enqueue_report(c, tb, spec_pairs != nullptr, spec_n);
+    int rc = enqueue_report(c, tb, spec_pairs != nullptr, spec_n, direct ? spec_pairs : nullptr);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    parse_report(c, tb, h, spec_pairs, spec_n);
+    parse_report(c, tb, h, direct ? nullptr : spec_pairs, spec_n);          // (direct: the pairs are already where the caller wants them)
     return 0;
 }
 
@@ -519,7 +535,7 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
             launches += per_pass;
         }
         if (!c->events_ride) HIPCHK(evrec(c, EV_TRAV1));      // device time of the kernels only: recorded before the read-back
-        if ((rc = read_state(c, tb, h, pairs, spec_n))) return rc;
+        if ((rc = read_state(c, tb, h, pairs, spec_n, is_pinned_pairs(pairs, cap_pairs)))) return rc;
         spec_valid = spec_n;
         if (h.max_shard_candidates > tb.cand_cap / NSHARD) { if ((rc = grow_candidates(c, tb, h.max_shard_candidates))) return rc; continue; }
         if (h.n_deferred > tb.defer_cap) {               // the deferred list was too small: grow it and redo (pairs restart at 0)
@@ -642,8 +658,9 @@ int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs
     if (!rc) rc = ensure_report(tb);
     if (rc) return rc;
     uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
+    const bool direct = is_pinned_pairs(pairs, cap_pairs);
     const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1),
-                               tb.d_pairs, tb.d_cand, tb.d_defer, tb.h_report, tb.cand_cap, tb.defer_cap};
+                               tb.d_pairs, tb.d_cand, tb.d_defer, direct ? (const void *)pairs : (const void *)tb.h_report, tb.cand_cap, tb.defer_cap};
     if (!c->graph_exec || std::memcmp(&key, &c->graph_key, sizeof key) != 0) {
         graph_drop(c);
         HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -653,7 +670,7 @@ int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs
         if (!rc) {
             QuerySrc src{c->d_leaf, c->d_boxes, c->d_qbox, c->d_root, nullptr, nullptr, c->d_os_ticket + 8};
             launch_pass<false, false>(c, tb, src, c->nt, cap_pairs);
-            rc = enqueue_report(c, tb, pairs != nullptr, spec_n);
+            rc = enqueue_report(c, tb, pairs != nullptr, spec_n, direct ? pairs : nullptr);
         }
         c->prezeroed = false;
         hipGraph_t g = nullptr;
@@ -676,7 +693,7 @@ int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs
     HIPCHK(hipStreamSynchronize(s));
     ++c->graph_replays;
     HostCounters h = {};
-    parse_report(c, tb, h, pairs, spec_n);
+    parse_report(c, tb, h, direct ? nullptr : pairs, spec_n);
     c->stage = ST_REFIT; c->root_box_valid = true;
     { const int js = judge_sort_flags(c); if (js != CD_OK) return CD_OK; }                 // (not handled: the stream path redoes the step in the sort's next form)
     if (h.max_shard_candidates > tb.cand_cap / NSHARD || h.n_deferred > 0) {             // the tree is fine: the traversal again, with the stream path's retries / deep pass
@@ -1151,6 +1168,28 @@ int cd_expand64_values(const uint64_t *v, uint64_t n, uint64_t *out)
     if (!v || !out) return CD_ERR_ARG;
     if (n == 0) return CD_OK;
     return morton_batch(v, sizeof(uint64_t) * n, n, nullptr, out);
+}
+
+int cd_alloc_host_pairs(uint64_t cap_pairs, uint32_t **pairs)
+{
+    if (!pairs || cap_pairs == 0) return CD_ERR_ARG;
+    *pairs = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return CD_ERR_NO_DEVICE;
+    void *p = nullptr;
+    HIPCHK(hipHostMalloc(&p, sizeof(uint32_t) * 2 * cap_pairs + 16, hipHostMallocDefault));      // +16: the report kernel moves pairs as 16-byte quads
+    PinnedPairs &pp = pinned_pairs();
+    { std::lock_guard<std::mutex> lock(pp.mu); pp.v.emplace_back(static_cast<const uint32_t *>(p), cap_pairs); }
+    *pairs = static_cast<uint32_t *>(p);
+    return CD_OK;
+}
+void cd_free_host_pairs(uint32_t *pairs)
+{
+    if (!pairs) return;
+    PinnedPairs &pp = pinned_pairs();
+    { std::lock_guard<std::mutex> lock(pp.mu);
+      for (size_t i = 0; i < pp.v.size(); ++i) if (pp.v[i].first == pairs) { pp.v.erase(pp.v.begin() + (long)i); break; } }
+    hipHostFree(pairs);
 }
 
 int cd_get_stats(cd_ctx *c, cd_stats *out) { if (!c || !out) return CD_ERR_ARG; *out = c->stats; return CD_OK; }

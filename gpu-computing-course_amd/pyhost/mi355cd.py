@@ -52,7 +52,7 @@ EXPORTS = [
     "cd_check_triangle_idx", "cd_find_collisions", "cd_build_tree", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
     "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_debug_counters", "cd_debug_records", "cd_num_triangles",
     "cd_set_option", "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
-    "cd_morton3d_points", "cd_expand64_values",
+    "cd_morton3d_points", "cd_expand64_values", "cd_alloc_host_pairs", "cd_free_host_pairs",
     "cd_multi_unique_id", "cd_multi_create", "cd_multi_create_from_comm", "cd_multi_destroy", "cd_multi_set_flags", "cd_multi_step",
 ]
 
@@ -109,6 +109,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_pack_queries.argtypes = [vp, vp, vp, C.c_uint64, u64p]
     lib.cd_find_collisions_queries.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]
     lib.cd_version.restype = C.c_char_p
+    lib.cd_alloc_host_pairs.argtypes = [C.c_uint64, C.POINTER(u32p)]
+    lib.cd_free_host_pairs.argtypes = [u32p]
+    lib.cd_free_host_pairs.restype = None
     lib.cd_morton3d_points.argtypes = [vp, C.c_uint64, vp, vp, vp]
     lib.cd_expand64_values.argtypes = [vp, C.c_uint64, vp]
     lib.cd_multi_unique_id.argtypes = [vp]
@@ -119,7 +122,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_multi_set_flags.argtypes = [vp, C.c_int]
     lib.cd_multi_step.argtypes = [vp, vp, C.c_uint64, u64p, C.POINTER(CdMultiInfo)]
     for name in EXPORTS:
-        if name not in ("cd_destroy", "cd_version", "cd_free_obj", "cd_multi_destroy"):
+        if name not in ("cd_destroy", "cd_version", "cd_free_obj", "cd_multi_destroy", "cd_free_host_pairs"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -349,6 +352,31 @@ def load_obj(path: str, threads: int = 0):
     finally:
         lib.cd_free_obj(pv, pf)
     return verts, vidx
+
+
+class HostPairs:
+    """cd_alloc_host_pairs: a uint32[cap, 2] array in pinned host memory the library lets the GPU write straight into
+    (.array; hand it to CollisionDetector.self_collide_into).  Freed by close() / the context manager."""
+
+    def __init__(self, cap: int):
+        self.lib = load_library()
+        self._p = C.POINTER(C.c_uint32)()
+        rc = self.lib.cd_alloc_host_pairs(cap, C.byref(self._p))
+        if rc != CD_OK:
+            raise CdError("cd_alloc_host_pairs", rc)
+        self.array = np.ctypeslib.as_array(self._p, shape=(cap, 2))
+
+    def close(self):
+        if self._p:
+            self.array = None
+            self.lib.cd_free_host_pairs(self._p)
+            self._p = C.POINTER(C.c_uint32)()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def morton3d_points(xyz, offset=None, span=None) -> np.ndarray:

@@ -132,6 +132,13 @@ int cd_check_triangle_idx(cd_ctx *ctx, uint32_t maxv, uint32_t *out);
  * (the reference writes past its 500-pair buffer instead, main.cu:81). */
 int cd_find_collisions(cd_ctx *ctx, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs);
 
+/* main.cu:74,81 (the reference's colTris host array + cudaMalloc'd copy): an output buffer for cap_pairs pairs in PINNED host memory.
+ * Optional: every entry point that returns pairs takes any host pointer; handed THIS buffer (the pointer as returned, cap_pairs up to
+ * its capacity), cd_find_collisions / cd_self_collide let the GPU write the pairs straight into it -- no staging copy on the host
+ * (~4 us of a 0.24 ms step at 20 k pairs).  Release with cd_free_host_pairs, after the last call that uses it. */
+int cd_alloc_host_pairs(uint64_t cap_pairs, uint32_t **pairs);
+void cd_free_host_pairs(uint32_t *pairs);
+
 /* cd_morton_sort -> cd_build_hierarchy -> cd_refit_boxes queued back to back, one host synchronisation: the tree
  * without the traversal (the multi-GPU step exchanges query leaves while the local traversal runs). */
 int cd_build_tree(cd_ctx *ctx);

@@ -1134,3 +1134,28 @@ def test_graph_replay_of_the_steady_state_step_gives_the_same_results():
             pairs, n, rc = cd.self_collide()
             assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(rc_["pairs"])), it
             assert cd.stats().pairs_tested == rc_["stats"].pairs_tested
+
+
+def test_pinned_host_pair_buffer_receives_the_pairs_directly():
+    """cd_alloc_host_pairs: with a pair buffer in pinned host memory from the library, the report kernel writes the pairs straight
+    into it (no staging copy); same pairs as through an ordinary buffer -- below and above the 32 768 pairs that travel with the
+    report, with the stream path and with the graph replay, and with a capacity below the buffer's."""
+    for verts, vidx in (synth.cloth_pair(120), synth.soup(60_000, 0.08, 21)):          # ~1 k pairs; ~90 k pairs (> 32 768)
+        r = oracle.pipeline(verts, vidx)
+        want = oracle.pair_set(r["pairs"])
+        with mi355cd.CollisionDetector(verts, vidx) as cd, mi355cd.HostPairs(1 << 18) as hp:
+            plain = np.empty((1 << 18, 2), dtype=np.uint32)
+            for graph in (0, 1):
+                cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0); cd.set_option(mi355cd.CD_OPT_GRAPH, graph)
+                for it in range(3):
+                    hp.array[:] = 0xffffffff
+                    n, rc = cd.self_collide_into(hp.array)
+                    assert rc == 0 and n == len(want) and np.array_equal(oracle.pair_set(hp.array[:n]), want), (graph, it)
+                    assert (hp.array[n:n + 8] == 0xffffffff).all()                      # nothing written past the list
+                    n2, rc2 = cd.self_collide_into(plain)
+                    assert rc2 == 0 and np.array_equal(oracle.pair_set(plain[:n2]), want)
+            sub = hp.array[:1 << 12]                                                     # same pointer, smaller capacity
+            n, rc = cd.self_collide_into(sub)
+            assert n == len(want) and rc == (mi355cd.CD_OVERFLOW if len(want) > (1 << 12) else 0)
+            got = oracle.pair_set(sub[:min(n, 1 << 12)])
+            assert np.isin(got, want).all() and len(np.unique(got)) == len(got)
