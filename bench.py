@@ -122,22 +122,22 @@ def parity_check(pairs, tested, verts, vidx, ids=None, off=None, span=None, own_
     return out
 
 
-def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5, rank=0, world=1, dist=None, torch=None, device=None):
+def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5, rank=0, world=1, dist=None, torch=None, device=None, multi=False):
     """Secondary path (BASELINE config 5): 4096^2 image, 4096 spheres, frame kept on the device (the reference
     copies every frame to the host for glDrawPixels, anime_ray.cu:128-131; that PCIe copy is not kernel time).
     world > 1: REPLICAS ONLY -- spheres replicated, rank r renders image rows [r, r+1) * dim / world (rt_render_rows), no
     collective on the data path; frames/s = frames all ranks finished / max-over-ranks wall time.  The row slabs going to the
-    host (the reference's per-frame D2H) and their assembly on rank 0 (a host-side gather over a gloo group) are timed separately.
+    host (the reference's per-frame D2H) and their assembly into one frame (an all-gather over RCCL) are timed separately.
     Every rank checks 64 rows of its slab against the oracle (the whole frame takes the CPU minutes)."""
     import statistics
     import mi355_synth as synth
     import mi355rt
     spheres, shifts = synth.sphere_scene(n_spheres, dim, seed=7)
     rows = (rank * dim // world, (rank + 1) * dim // world)
-    out = {"workload": f"{dim}x{dim} RGBA8 frame, {n_spheres} spheres (BASELINE config 5)" + (f", image rows sharded over {world} replicas (spheres replicated, no collective)" if world > 1 else "")}
+    out = {"workload": f"{dim}x{dim} RGBA8 frame, {n_spheres} spheres (BASELINE config 5)" + (f", image rows sharded over {world} replicas (spheres replicated, no collective)" if multi else "")}
     with mi355rt.RayTracer(spheres, dim) as rt:
         for name, mode in (("binned", mi355rt.RT_MODE_BINNED), ("brute", mi355rt.RT_MODE_BRUTE)):
-            if world > 1 and name == "brute":
+            if multi and name == "brute":
                 continue
             rt.set_mode(mode)
             rt.render(shifts, rows=rows, download=False)
@@ -148,7 +148,7 @@ def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5, rank=0, world=1, 
             st = rt.stats()
             m = statistics.median(ms)
             out[name] = {"ms_per_frame": m, "sphere_tests_per_frame": int(st.sphere_tests), "sphere_tests_per_s": st.sphere_tests / (m * 1e-3)}
-            if mode == mi355rt.RT_MODE_BINNED and world == 1:
+            if mode == mi355rt.RT_MODE_BINNED and not multi:
                 # 16 frames queued back to back (time stamps on the first and the last kernel only): what a loop that does not come back
                 # to the host per frame sees -- a single frame's two stamps cost it ~5 us of idle GPU between its two kernels
                 rb = []
@@ -157,7 +157,7 @@ def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5, rank=0, world=1, 
                     rb.append(rt.stats().ms_render)
                 out[name]["ms_per_frame_back_to_back"] = statistics.median(rb)
         rt.set_mode(mi355rt.RT_MODE_BINNED)
-        if world > 1:
+        if multi:
             # whole-job frame rate: K frames per rank (its rows), barrier + synchronize both sides, max over ranks
             kf = 50
             dist.barrier(); torch.cuda.synchronize()
@@ -172,13 +172,17 @@ def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5, rank=0, world=1, 
             t0 = time.perf_counter()
             slab = rt.render(shifts, rows=rows, download=True)           # + D2H of the rank's slab (anime_ray.cu:128-131)
             t_d2h = time.perf_counter() - t0
-            g = dist.new_group(backend="gloo")
-            slabs = [torch.empty((rows[1] - rows[0], dim, 4), dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+            # the slabs assembled into one frame in rank-order: an all-gather over RCCL (the library keeps its frame buffer to itself, so the
+            # slab goes back to the device first, untimed; a display process would rather read the ranks' host slabs where they are)
+            dslab = torch.from_numpy(slab).to(device)
+            frame = torch.empty((world,) + tuple(dslab.shape), dtype=torch.uint8, device=device)
+            torch.cuda.synchronize(); dist.barrier()
             t0 = time.perf_counter()
-            dist.gather(torch.from_numpy(slab), slabs, dst=0, group=g)
+            dist.all_gather_into_tensor(frame, dslab)
+            torch.cuda.synchronize()
             t_gather = time.perf_counter() - t0
             out["row_slab_render_plus_d2h_ms"] = t_d2h * 1e3
-            out["row_slab_gather_on_host_ms"] = t_gather * 1e3
+            out["row_slabs_all_gather_rccl_ms"] = t_gather * 1e3
         else:
             slab = rt.render(shifts, rows=rows, download=True)
         # checker: 64 rows of this rank's slab against the oracle (sphere.cuh:34-44, anime_ray.cu:61-87)
@@ -187,12 +191,12 @@ def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5, rank=0, world=1, 
         y0 = rows[0] + ((rows[1] - rows[0]) // 2 // 64) * 64
         want = oracle.rt_render(spheres, shifts, dim, rows=(y0, y0 + 64))
         ok = bool(np.array_equal(slab[y0 - rows[0]: y0 - rows[0] + 64], want[y0:y0 + 64] if want.shape[0] == dim else want))
-        if world > 1:
+        if multi:
             f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
             dist.all_reduce(f, op=dist.ReduceOp.MIN)
             ok = bool(int(f.item()))
         out["parity_checked"] = ok
-        out["parity_note"] = f"rows [{y0}, {y0 + 64}) of every rank's slab pixel-equal to the CPU oracle" + (" (MIN over ranks)" if world > 1 else "") + "; whole frames in tests/test_rt_gpu.py"
+        out["parity_note"] = f"rows [{y0}, {y0 + 64}) of every rank's slab pixel-equal to the CPU oracle" + (" (MIN over ranks)" if multi else "") + "; whole frames in tests/test_rt_gpu.py"
     frame_bytes = (rows[1] - rows[0]) * dim * 4 + n_spheres * 32
     a = frame_bytes / (out["binned"]["ms_per_frame"] * 1e-3) / 1e9
     out["roofline"] = {"bound": "hbm", "kernel": "k_render<binned>", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
@@ -467,8 +471,8 @@ def main():
             line["parity_checked"] = bool(int(f.item()))
             line["parity"] = dict(pc, note="rank 0's own check shown; parity_checked = MIN over ranks: every rank's pair list of the last timed step == "
                                            "the oracle's pairs (on the rank's mesh merged with its lower neighbour's) whose larger id the rank owns")
-    if not args.no_ray and not self_peer and (backend == "nccl" or not multi_path):
-        rtm = ray_tracer_measurement(rank=rank, world=world if multi_path else 1, dist=dist if multi_path else None, torch=torch, device=device)
+    if not args.no_ray and (backend == "nccl" or not multi_path):
+        rtm = ray_tracer_measurement(rank=rank, world=world if multi_path else 1, dist=dist if multi_path else None, torch=torch, device=device, multi=multi_path)
         if rank == 0:
             line["ray_tracer"] = rtm
     if multi_path:
