@@ -152,13 +152,15 @@ __global__ __launch_bounds__(256) void k_frame_from_bounds(const double *__restr
 
 // ---------------------------------------------------------------- Morton keys (load_obj.h:89-101, morton.h:70-89)
 // Grid-stride; the workgroup also accumulates the radix sort's digit histograms (cd_sort.h) of the keys it writes.
-constexpr int MORTON_THREADS = 512;
+constexpr int MORTON_THREADS = 1024;                  // one sort tile (SORT_TILE = 4096 keys) per workgroup pass: 4 keys per thread
 __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restrict__ verts, const uint32_t *__restrict__ vidx, uint32_t n,
                                                            const double *__restrict__ frame /* off[3], span[3] */,
                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ ghist /* [HIST_COPIES][8][256] */, int first_digit,
                                                            int down /* shifted hybrid sort: digits taken `down` bits lower */, uint32_t *__restrict__ overflow,
                                                            const double *__restrict__ partial /* auto frame: k_centroid_bounds' per-block bounds, else NULL */, uint32_t nparts,
-                                                           double *__restrict__ frame_out, double *__restrict__ box_out /* NULL, or the box of all vertices (partials of k_centroid_bounds<true>) */)
+                                                           double *__restrict__ frame_out, double *__restrict__ box_out /* NULL, or the box of all vertices (partials of k_centroid_bounds<true>) */,
+                                                           uint32_t *__restrict__ tile_hist /* [tiles][256]: per SORT_TILE keys, the counts of digit `first_digit` -- the first global pass of the sort
+                                                                                              takes its tile offsets from these (no look-back: k_os_pass) */)
 {
     __shared__ uint32_t h[8][RADIX];
     __shared__ double smw[MORTON_THREADS / 64][BOUNDS_STRIDE];
@@ -199,12 +201,25 @@ __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restr
     }
     __syncthreads();
     uint64_t above = 0;
-    for (uint32_t t = blockIdx.x * MORTON_THREADS + threadIdx.x; t < n; t += gridDim.x * MORTON_THREADS) {
-        const d3 c = centroid_of(verts, vidx, t);
-        const uint64_t k = morton3d(c.x, c.y, c.z, frame, frame + 3);
-        keys[t] = k;
-        hist_add(h, k, first_digit, down);
-        above |= k;
+    // a workgroup takes whole sort tiles (SORT_TILE consecutive keys): beside the digit histograms of ALL keys it leaves, per tile,
+    // the counts of the first global digit -- with those the sort's first pass needs no rendezvous between its tiles
+    const uint32_t ntile = (n + SORT_TILE - 1) / SORT_TILE;
+    uint32_t seen = 0;                                   // thread d < 256: what h[first_digit][d] held when this tile began (the tile's counts are the difference)
+    for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+#pragma unroll
+        for (int it = 0; it < SORT_TILE / MORTON_THREADS; ++it) {
+            const uint32_t t = tile * SORT_TILE + it * MORTON_THREADS + threadIdx.x;
+            if (t < n) {
+                const d3 c = centroid_of(verts, vidx, t);
+                const uint64_t k = morton3d(c.x, c.y, c.z, frame, frame + 3);
+                keys[t] = k;
+                hist_add(h, k, first_digit, down);
+                above |= k;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < RADIX) { const uint32_t now = h[first_digit][threadIdx.x]; tile_hist[(size_t)tile * RADIX + threadIdx.x] = now - seen; seen = now; }
+        if (tile + gridDim.x < ntile) __syncthreads();   // (more than 2048 tiles: the next tile's counts start on top of these)
     }
     // a centroid outside the Morton frame sets key bits the shifted digits do not cover (bits 64 - down .. 63): the
     // shifted hybrid sort then does not apply -- same flag, same repair (the next form) as a run too long to window

@@ -64,6 +64,10 @@ __global__ __launch_bounds__(1024) void k_scan_exclusive(uint32_t *__restrict__ 
 // tile cannot scatter before every earlier tile has ranked), not the walk; forwarding each key into the NEXT
 // pass's per-tile histogram with global atomics while scattering (no look-back at all) cost 3x (1 M scattered
 // atomics per pass).
+// Round 3: the FIRST global pass has no rendezvous at all.  k_morton takes whole tiles and leaves, per tile, the counts of the first
+// global digit (tile_hist[tile][256]); a tile of the first pass sums the rows of the earlier tiles (16-byte loads, 16 waves x 4 rows
+// in flight: ~1 us) instead of looking back: 17.4 -> 12.6 us for that pass at 1 M keys (k_morton 13.2 -> 14.0 us).  The later passes'
+// input order only exists once the pass before them has run, so they keep the look-back.
 // The histograms that come with the Morton keys are kept as HIST_COPIES partial tables (workgroup b of k_morton adds to table
 // b mod HIST_COPIES; k_os_pass adds the tables up): its ~500 workgroups all flush at the end of the kernel, and atomics on one
 // word retire one after the other.  1 / 2 / 4 / 8 / 16 tables: k_morton 17.0 / 12.9 / 12.4 / 12.6 / 12.5 us, k_os_pass 17.4 /
@@ -104,10 +108,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_hist(const uint64_t *__rest
 __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                           uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                           uint32_t n, int shift, const uint32_t *__restrict__ digit_hist /* [256] raw counts of this digit, hist_copies partial tables HIST_STRIDE words apart */,
-                                                          unsigned long long *lookback /* [ntiles][256] */, uint32_t *ticket /* [pass]; ticket[8 - pass] = timeout flag */, int first_pass, int hist_copies)
+                                                          unsigned long long *lookback /* [ntiles][256] */, uint32_t *ticket /* [pass]; ticket[8 - pass] = timeout flag */, int first_pass, int hist_copies,
+                                                          const uint32_t *__restrict__ tile_hist /* NULL, or [ntiles][256]: this digit's counts per INPUT tile, left by the kernel that wrote the keys
+                                                                                                    (k_morton): the tile offsets are their sums, no look-back */)
 {
     __shared__ uint32_t wcnt[OS_WAVES][RADIX];
     __shared__ uint32_t gbase[RADIX];
+    __shared__ uint32_t tpart[OS_THREADS / 64][RADIX];     // flat tile offsets: 16 partial sums per digit
     __shared__ uint32_t s_tile;
     __shared__ uint32_t s_wsum[RADIX / 64];
     const uint32_t tid = threadIdx.x;
@@ -128,6 +135,23 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
     __syncthreads();
     if (tid < RADIX) for (int ww = 0; ww < w; ++ww) dbase += s_wsum[ww];
     const uint32_t tile = s_tile;
+    // The first global pass of a sort whose keys come with per-tile digit counts (k_morton): how many keys of digit d the EARLIER
+    // tiles hold is a sum over rows that were complete before this kernel started -- plain loads, no dependence between the tiles of
+    // this pass at all, where the look-back below is a rendezvous of all of them (~9 us of a 17 us pass at 245 tiles).
+    if (tile_hist) {
+        // 64 lanes x 4 digits cover a row (16-byte loads), the 16 waves take every 16th earlier tile, four rows in flight per lane
+        const uint4 *rows = reinterpret_cast<const uint4 *>(tile_hist);
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, a2 = a0, a3 = a0;
+        uint32_t t2 = (uint32_t)w;
+        for (; t2 + 3u * OS_WAVES < tile; t2 += 4u * OS_WAVES) {
+            const uint4 r0 = rows[(size_t)t2 * (RADIX / 4) + lane], r1 = rows[(size_t)(t2 + OS_WAVES) * (RADIX / 4) + lane];
+            const uint4 r2 = rows[(size_t)(t2 + 2u * OS_WAVES) * (RADIX / 4) + lane], r3 = rows[(size_t)(t2 + 3u * OS_WAVES) * (RADIX / 4) + lane];
+            a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w; a1.x += r1.x; a1.y += r1.y; a1.z += r1.z; a1.w += r1.w;
+            a2.x += r2.x; a2.y += r2.y; a2.z += r2.z; a2.w += r2.w; a3.x += r3.x; a3.y += r3.y; a3.z += r3.z; a3.w += r3.w;
+        }
+        for (; t2 < tile; t2 += OS_WAVES) { const uint4 r0 = rows[(size_t)t2 * (RADIX / 4) + lane]; a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w; }
+        reinterpret_cast<uint4 *>(&tpart[w][0])[lane] = make_uint4(a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y, a0.z + a1.z + a2.z + a3.z, a0.w + a1.w + a2.w + a3.w);
+    }
 
     const uint32_t base_w = tile * SORT_TILE + w * (OS_ITEMS * 64);
     uint64_t k[OS_ITEMS];
@@ -170,7 +194,10 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
         const unsigned long long count = run;
         unsigned long long *mine = lookback + (size_t)tile * RADIX + tid;
         unsigned long long excl = 0;
-        if (tile == 0) {
+        if (tile_hist) {
+#pragma unroll
+            for (int q = 0; q < OS_THREADS / 64; ++q) excl += tpart[q][tid];
+        } else if (tile == 0) {
             __hip_atomic_store(mine, OS_PREFIX | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             __hip_atomic_store(mine, OS_AGG | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -234,16 +234,16 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
                                                 // where bits 48..63 of a 60-bit Morton key hold 12: runs 16 x shorter, windows of even size
     const int first_digit = hybrid ? 6 : (mode == 2 ? 4 : 0);
     int cur = mode == 3 ? 0 : 1;
-    const uint32_t mblocks = cdiv(n, MORTON_THREADS * 4) < 1024u ? cdiv(n, MORTON_THREADS * 4) : 1024u;
+    const uint32_t mblocks = c->ntiles < 2048u ? c->ntiles : 2048u;         // a workgroup per sort tile (4096 keys)
     k_morton<<<mblocks, MORTON_THREADS, 0, s>>>(c->d_verts, c->d_vidx, n, auto_frame ? nullptr : c->d_frame /* (auto: the kernel folds the partial bounds itself and WRITES d_frame) */, c->d_keys[cur], c->d_os_hist, first_digit, down, c->d_os_ticket + 16,
-                                                auto_frame ? c->d_partial : nullptr, (uint32_t)BOUNDS_BLOCKS, c->d_frame, nullptr);
+                                                auto_frame ? c->d_partial : nullptr, (uint32_t)BOUNDS_BLOCKS, c->d_frame, nullptr, c->d_counts);
     HIPCHK(evrec(c, EV_MORTON1));
     // onesweep: one pass over the data per digit; the digit histograms came with the keys
     for (int pass = first_digit; pass < 8; ++pass) {
         k_os_pass<<<c->ntiles, OS_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1], n, pass * RADIX_BITS - down,
                                                     c->d_os_hist + pass * RADIX,
                                                     (pass >= 6 ? c->d_os_look + (size_t)(pass - 6) * c->ntiles * RADIX : c->d_os_look_lo + (size_t)pass * c->ntiles * RADIX),
-                                                    c->d_os_ticket + pass, pass == first_digit, HIST_COPIES);
+                                                    c->d_os_ticket + pass, pass == first_digit, HIST_COPIES, pass == first_digit ? c->d_counts : nullptr);
         cur ^= 1;
     }
     c->leaves_filled = false; c->leaf_records_filled = false;
@@ -625,7 +625,7 @@ int pp_sort(cd_ctx *c, uint32_t m)
     int cur = 0;
     for (int pass = 0; pass < 8; ++pass) {
         k_os_pass<<<ntiles, OS_THREADS, 0, s>>>(c->pp_keys[cur], c->pp_vals[cur], c->pp_keys[cur ^ 1], c->pp_vals[cur ^ 1], m, pass * RADIX_BITS,
-                                                hist + pass * RADIX, look + (size_t)pass * ntiles * RADIX, ticket + pass, pass == 0, 1);
+                                                hist + pass * RADIX, look + (size_t)pass * ntiles * RADIX, ticket + pass, pass == 0, 1, nullptr);
         cur ^= 1;
     }
     return 0;
