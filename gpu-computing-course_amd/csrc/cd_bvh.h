@@ -35,17 +35,8 @@ struct alignas(64) NodeRec32 {
 };
 static_assert(sizeof(NodeRec32) == 64, "NodeRec32 is two 32-byte halves");
 // quads (16 bytes) of the two halves of record s; `recs` is the allocation's base, n the number of leaves (= record slots)
-#ifdef REC_INTERLEAVED      // both halves of a record in ONE 64-byte slot, the right half first: what the quad descent (k_descend_quad) fetches with one 16-byte load per lane
-constexpr bool REC_IS_INTERLEAVED = true;
-__device__ __forceinline__ const float4 *rec_right(const NodeRec32 *recs, int n, uint32_t s) { return reinterpret_cast<const float4 *>(recs) + 4 * (size_t)s; }
-__device__ __forceinline__ const float4 *rec_left(const NodeRec32 *recs, int n, uint32_t s) { return reinterpret_cast<const float4 *>(recs) + 4 * (size_t)s + 2; }
-#else
-constexpr bool REC_IS_INTERLEAVED = false;
 __device__ __forceinline__ const float4 *rec_right(const NodeRec32 *recs, int n, uint32_t s) { return reinterpret_cast<const float4 *>(recs) + 2 * (size_t)s; }
 __device__ __forceinline__ const float4 *rec_left(const NodeRec32 *recs, int n, uint32_t s) { return reinterpret_cast<const float4 *>(recs) + 2 * (size_t)n + 2 * (size_t)s; }
-#endif
-// quad r (0..3) of record s in the order {right quad 0, right quad 1, left quad 0, left quad 1}
-__device__ __forceinline__ const float4 *rec_quad(const NodeRec32 *recs, int n, uint32_t s, uint32_t r) { return (r < 2u ? rec_right(recs, n, s) : rec_left(recs, n, s)) + (r & 1u); }
 
 // fp32 query box of leaf j, rounded outward like the records', written by the refit: 32 coalesced bytes per query
 // instead of the 48-byte FP64 box (k_descend and the packers read it; k_descend_half takes the same box and the same

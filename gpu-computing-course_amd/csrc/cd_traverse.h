@@ -769,303 +769,6 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
 }
 
 // ====================================================================================================
-// Variant F (round 3): the half traversal with a QUAD-cooperative descent -- phases 0 / 1 as variant D, phase 2 as described at its
-// head below.  Needs the interleaved record layout (REC_INTERLEAVED) to pay: a worker's four 16-byte loads are then one 64-byte segment.
-// ====================================================================================================
-__global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_quad(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
-                                                                  TravState *__restrict__ st,
-                                                                  Candidates *__restrict__ cand, unsigned long long shard_cap,
-                                                                  uint2 *__restrict__ defer_list, uint32_t defer_cap, uint32_t diag)
-{
-    if (sort_failed(src)) return;
-#ifdef CD_ABLATE       // TIMING EXPERIMENTS ONLY, never in the shipped build (tools/ab_build.sh abl -DCD_ABLATE; tools/exp_descent_ablation.py): parts of the
-    const uint32_t ablate = diag >> 8;   // kernel switched off by debug key 103, bits 8..: 1 no descent, 2 no shared chain, 4 no in-wave hops, 8 no candidate
-    diag &= 0xffu;                       // hand-over, 16 no record loads for the query box, 32 no counters.  Results are wrong by construction.
-#else
-    constexpr uint32_t ablate = 0u;
-#endif
-    // The kernel times ITSELF with the device's constant-rate wall clock (s_memrealtime): first wave start -> last wave end, two
-    // sharded atomicMax per wave (the start as its complement, so that the zeroed counters need no initial value).  A HIP time
-    // stamp on the dispatch packet costs the step ~7 us of idle GPU around the kernel; this costs it nothing measurable.
-    const unsigned long long clk0 = __builtin_amdgcn_s_memrealtime();
-    __shared__ int32_t lds_stack[HALF_STACK][HALF_THREADS];
-    __shared__ Candidates queue[HALF_WAVES][HALF_QCAP];
-    __shared__ uint8_t share_map[HALF_WAVES][64];      // work sharing: lane id of the k-th donor
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t dg_p1a = 0, dg_p1 = 0, dg_hops_in = 0, dg_hops_out = 0, dg_vis = 0;   // diagnostics (diag != 0)
-    const uint32_t nb = gridDim.x, per = nb >> 3;       // XCD-aware mapping, see k_descend
-#ifndef HALF_XSUB
-#define HALF_XSUB 4
-#endif
-    uint32_t vblock = (blockIdx.x < (per << 3)) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
-    // ... as HALF_XSUB chunks from different parts of the mesh rather than ONE contiguous eighth: the work per query is not
-    // even over a mesh (where the surfaces meet, a query has candidates; elsewhere none), and an XCD with a busy eighth
-    // was the kernel's tail.  1 M cloth: 1 / 2 / 4 / 8 / 16 chunks -> 57.8 / 57.9 / 54.1 / 54.4 / 54.6 us.
-    if (HALF_XSUB > 1) {
-        const uint32_t c = per / HALF_XSUB;
-        if (c > 0 && blockIdx.x < c * HALF_XSUB * 8u) {
-            const uint32_t x = blockIdx.x & 7u, l = blockIdx.x >> 3, sub = l / c, off = l % c;
-            vblock = (sub * 8u + x) * c + off;
-        } else if (c > 0) vblock = blockIdx.x;          // (the remainder keeps its own index: c * HALF_XSUB * 8 <= blockIdx.x < nb are not produced above)
-    }
-    CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
-    Candidates *my_cand = cand + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_cap;
-    const uint32_t nq = (uint32_t)n, last_leaf = nq - 1u;
-    constexpr uint32_t END = 0xffffffffu;
-    // the wave owns the 64 consecutive leaves [g0, g_last]  (wave-uniform; readfirstlane tells the compiler)
-    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((vblock * HALF_WAVES + w) * 64u));
-    const uint32_t g_last = (g0 + 63u < last_leaf) ? g0 + 63u : last_leaf;
-    uint32_t qi = g0 + lane;
-    const bool valid = qi < nq && n > 1;
-    unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0, tm4 = 0;           // diagnostics: s_memtime stamps at the phase boundaries
-    if (diag) tm0 = __builtin_amdgcn_s_memtime();
-    uint32_t qcount = 0;                                // wave-uniform: candidates waiting in the queue
-    uint32_t tested = 0, visits = 0, steps = 0;
-    int sptr = 0;
-    // Hand-over of queued candidates to k_exact, as in k_descend, with the half traversal's counting (both directions)
-    // and ID rule (either order; k_exact puts the smaller ID in front).  The queue is drained only when it might not
-    // hold the next enqueue, and once at the end: a wave usually hands everything over in one go.
-    auto flush = [&](uint32_t count) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        Candidates cd0 = Candidates{0, 0};
-        bool keep = lane < count;
-        if (keep) cd0 = queue[w][qcount - count + lane];
-        if (keep && (cd0.leaf & CAND_CERTAIN)) {
-            tested += 2u;                                                      // collision.cuh:31-32, decided exactly by the descent, both directions
-            const LeafTri lt = src.leaf[cd0.leaf & CAND_LEAF_MASK];
-            const LeafTri ql = src.leaf[cd0.q];
-            keep = neighbor_count(ql.v0, ql.v1, ql.v2, lt.v0, lt.v1, lt.v2) < 1 && ql.id != lt.id;   // collision.cuh:38, tri_contact.cuh:81
-            cd0.leaf |= CAND_FILTERED;
-        }
-        qcount -= count;
-        const unsigned long long mk = __builtin_amdgcn_ballot_w64(keep);
-        if (mk != 0ull) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(&sh->n_candidates, (unsigned long long)__popcll(mk));
-            base = __shfl(base, 0) + __popcll(mk & lt_mask);
-            if (keep && base < shard_cap) my_cand[base] = cd0;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
-    // one candidate per lane where `c` holds (compacted over the wave with ballot / popcount prefixes)
-    auto enqueue = [&](bool c, uint32_t q, uint32_t leafword) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
-        if (m == 0ull) return;
-        while (qcount > HALF_FLUSH_AT) flush(64);
-        if (c) queue[w][qcount + __popcll(m & lt_mask)] = Candidates{q, leafword};
-        qcount += __popcll(m);
-    };
-    auto push_subtree = [&](int32_t link) {                                   // an internal sibling / child that was hit: descended in phase 2
-        if (ablate & 1u) return;                                              // TIMING EXPERIMENT ONLY (wrong results): phase 1 alone
-        if (sptr < HALF_STACK) { lds_stack[sptr][tid] = link; ++sptr; }
-        else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)link); }
-    };
-    // ---- the query box comes out of the RECORDS, not out of qbox[]: leaf j is the left child of recs[j] (then that
-    // record's left link is ~j) or else the right child of recs[j - 1] -- every s is the split of exactly one node
-    // (cd_bvh.h) -- and a leaf child's box in a record is the leaf's own fp32 box with its exact bit.  The lane needs the
-    // right half of recs[j] anyway (phase 1a), the right half of recs[j - 1] is in the neighbour lane, and the left
-    // halves are what phase 2 reads next: 32 bytes per leaf less from HBM than with a separate query array.
-    // The last leaf has no record of its own: it is the right child of recs[n - 2].
-    float qlo0, qlo1, qlo2, qhi0, qhi1, qhi2; uint32_t qcertain;
-    float4 rc = make_float4(0.f, 0.f, 0.f, 0.f), rd = rc;
-    {
-        float4 la = rc, lb = rc, pc = rc, pd = rc;
-        const bool own = valid && qi < last_leaf && !(ablate & 16u);
-        if (own) { const float4 *rp = rec_right(recs, n, qi); rc = rp[0]; rd = rp[1]; const float4 *lp = rec_left(recs, n, qi); la = lp[0]; lb = lp[1]; }
-        {   // the right half of recs[qi - 1]: the neighbour lane's registers (DPP wave_shr:1, a VALU move); lane 0 gets the
-            // record before the wave's first one through the scalar cache (wave-uniform address)
-            int4 e0 = make_int4(0, 0, 0, 0), e1 = e0;
-            if (g0 > 0u && g0 <= last_leaf && n > 1) { const int4 *pp = reinterpret_cast<const int4 *>(rec_right(recs, n, g0 - 1u)); e0 = pp[0]; e1 = pp[1]; }
-            auto shr1 = [](float v, int edge) { return __int_as_float(__builtin_amdgcn_update_dpp(edge, __float_as_int(v), 0x138, 0xf, 0xf, false)); };
-            pc.x = shr1(rc.x, e0.x); pc.y = shr1(rc.y, e0.y); pc.z = shr1(rc.z, e0.z); pc.w = shr1(rc.w, e0.w);
-            pd.x = shr1(rd.x, e1.x); pd.y = shr1(rd.y, e1.y); pd.z = shr1(rd.z, e1.z); pd.w = shr1(rd.w, e1.w);
-        }
-        const bool is_left = own && __float_as_int(lb.z) == (int32_t)~qi;
-        qlo0 = is_left ? la.x : pc.x; qlo1 = is_left ? la.y : pc.y; qlo2 = is_left ? la.z : pc.z;
-        qhi0 = is_left ? la.w : pc.w; qhi1 = is_left ? lb.x : pd.x; qhi2 = is_left ? lb.y : pd.y;
-        const bool exact = is_left ? (__float_as_uint(rd.w) & REC_L_EXACT) != 0u : (__float_as_uint(pd.w) & REC_R_EXACT) != 0u;
-        qcertain = exact ? CAND_CERTAIN : 0u;
-        // the query's own leaf, which every traversal of the reference meets once (collision.cuh:31-32): box.cuh:40-43 with
-        // a == b is (x1 - x2)^2 > 0 per axis -- for a box that is exact in fp32 that is lo != hi (the difference of two
-        // floats squared does not underflow in FP64), otherwise the FP64 box decides (stored for exactly those leaves)
-        bool self = exact & (qlo0 < qhi0) & (qlo1 < qhi1) & (qlo2 < qhi2);
-        if (valid && !exact) { const Box b = load_box(src.boxes, (n - 1) + (int)qi); self = box_overlap(b, b); }
-        if (valid && self) ++tested;
-    }
-    if (diag) tm1 = __builtin_amdgcn_s_memtime();
-    // ---- phase 1a: hops below g_last
-    uint32_t s = valid ? qi : END;                                            // cursor; >= g_last: joined the shared chain (or has none: g_last == n-1)
-    if (ablate & 4u) s = valid ? g_last : END;
-    for (int hop = 0; hop < 128; ++hop) {                                     // tree height <= 96: the bound only matters for a corrupt tree
-        const bool act = s < g_last;
-        if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
-        ++steps;
-        const int from = (int)((act ? (s - g0) : lane) << 2);
-        float4 c, d;
-        c.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.x))); c.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.y)));
-        c.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.z))); c.w = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.w)));
-        d.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.x))); d.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.y)));
-        d.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.z))); d.w = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.w)));
-        const bool hit = act & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
-        const int32_t link = __float_as_int(d.z);
-        const uint32_t lw = __float_as_uint(d.w);
-        visits += act ? 1u : 0u;
-        if (diag) dg_hops_in += act ? 1u : 0u;
-        if (band(hit, link >= 0)) push_subtree(link);
-        s = act ? (lw & REC_LAST_MASK) : s;
-        enqueue(band(hit, link < 0), qi, (uint32_t)~link | ((lw & REC_R_EXACT) ? qcertain : 0u));
-    }
-    dg_p1a = steps;
-    if (diag) tm2 = __builtin_amdgcn_s_memtime();
-    // ---- phase 1b: a lane whose cursor has reached g_last or beyond is on the chain of leaf g_last (the `last` values
-    // along a root path are exactly that chain's cursors), which all lanes share from their joining point upwards: the
-    // wave walks it once with SCALAR loads, and every lane that has joined tests the wave-uniform box.
-    {
-        uint32_t t = (ablate & 2u) ? last_leaf : g_last;
-        for (int hop = 0; hop < 128 && t < last_leaf; ++hop) {
-            ++steps;
-            const int4 *rq = reinterpret_cast<const int4 *>(rec_right(recs, n, t));    // wave-uniform address: scalar loads
-            const int4 c = rq[0], d = rq[1];
-            const bool act = s <= t;                                          // (s == END for lanes without a query: never)
-            const bool hit = act & (qlo0 < __int_as_float(c.w)) & (__int_as_float(c.x) < qhi0) & (qlo1 < __int_as_float(d.x)) &
-                             (__int_as_float(c.y) < qhi1) & (qlo2 < __int_as_float(d.y)) & (__int_as_float(c.z) < qhi2);
-            const int32_t link = d.z;                                         // wave-uniform
-            const uint32_t lw = (uint32_t)d.w;
-            visits += act ? 1u : 0u;
-            if (diag) dg_hops_out += act ? 1u : 0u;
-            if (link >= 0) { if (hit) push_subtree(link); }
-            else enqueue(hit, qi, (uint32_t)~link | ((lw & REC_R_EXACT) ? qcertain : 0u));
-            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lw & REC_LAST_MASK));
-        }
-    }
-    dg_p1 = steps;
-    if (diag) tm3 = __builtin_amdgcn_s_memtime();
-    // ---- phase 2, QUAD-cooperative: a WORKER is four neighbouring lanes; it descends one (query, subtree) item at a time, depth first
-    // over its own small LDS stack, and a visit is ONE 16-byte load per lane -- lane r of the worker fetches quad r of the node's record
-    // {right lo.xyz hi.x | right hi.yz link last | left lo.xyz hi.x | left hi.yz link first} -- instead of four divergent loads in one lane
-    // with three quarters of the wave idle.  The lanes compare what they hold (even lanes four planes, odd lanes two) against
-    // operands prepared once per item, the partial verdicts meet in scalar registers (ok & ok >> 1: a child box is two
-    // neighbouring lanes), links and flags reach the whole worker by DPP quad broadcasts, and all four lanes then take the same
-    // decisions on replicated state.  Idle workers take items off the per-lane stacks phase 1 filled (lane q's stack = the hit
-    // subtrees of query q), then off busy workers' stacks.
-    {
-        constexpr int QW = 16;                                               // workers per wave
-        constexpr int QSTACK = 8;
-        __shared__ int32_t wstack[QSTACK][QW * HALF_WAVES];
-        __shared__ uint2 mailbox[HALF_WAVES][QW];
-        const uint32_t qr = lane & 3u, worker = lane >> 2;
-        const bool leader = qr == 0u, oddl = (qr & 1u) != 0u;
-        const uint32_t sbit = oddl ? 0x80000000u : 0u;
-        constexpr unsigned long long LEADERS = 0x1111111111111111ull, ODDS = 0xaaaaaaaaaaaaaaaaull;
-        int32_t node = -1; int wsp = 0;                                      // replicated in the worker's four lanes
-        uint32_t wq = 0, wcert = 0;
-        float Px = 0.f, Py = 0.f, Pz = 0.f, Pw = 0.f;
-        const uint32_t wbase = w * QW + worker;
-        // hand items (query lane, subtree) from donor lanes to idle workers: donor k writes mailbox[k], receiver k reads it
-        auto hand_over = [&](bool donor, uint32_t dq, int32_t dnode, unsigned long long m_idle, unsigned long long m_don) {
-            const uint32_t nx = min((uint32_t)__popcll(m_idle), (uint32_t)__popcll(m_don));
-            const uint32_t rank_d = __popcll(m_don & lt_mask);
-            const bool give = donor & (rank_d < nx);
-            if (give) mailbox[w][rank_d] = make_uint2(dq, (uint32_t)dnode);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const uint32_t rank_r = __popcll(m_idle & ((1ull << (lane & ~3u)) - 1ull));   // rank of this lane's WORKER among the idle ones: the same in its four lanes
-            const bool idle_me = ((m_idle >> (lane & ~3u)) & 1ull) != 0ull;
-            const bool take = idle_me & (rank_r < nx);
-            const uint2 it = mailbox[w][take ? rank_r : 0u];
-            const int from = take ? (int)it.x : (int)lane;
-            const float f0 = __shfl(qlo0, from), f1 = __shfl(qlo1, from), f2 = __shfl(qlo2, from);
-            const float f3 = __shfl(qhi0, from), f4 = __shfl(qhi1, from), f5 = __shfl(qhi2, from);
-            const uint32_t fc = __shfl(qcertain, from);
-            if (take) {
-                node = (int32_t)it.y; wq = it.x; wcert = fc; wsp = 0;
-                Px = oddl ? -f1 : f3; Py = oddl ? -f2 : f4; Pz = f5; Pw = -f0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            return give;
-        };
-        while (true) {
-            // ---- idle workers take items: first off the per-lane stacks of phase 1, then (when at least four workers idle) off busy workers' stacks
-            {
-                const unsigned long long m_idle = __builtin_amdgcn_ballot_w64((node == -1) & leader);
-                if (m_idle != 0ull) {
-                    const unsigned long long m_d1 = __builtin_amdgcn_ballot_w64(sptr > 0);
-                    if (m_d1 != 0ull) {
-                        const bool donor = sptr > 0;
-                        const int32_t top = donor ? lds_stack[sptr - 1][tid] : -1;
-                        if (hand_over(donor, lane, top, m_idle, m_d1)) --sptr;
-                    } else {
-                        const bool donor = (node != -1) & (wsp > 0) & leader;
-                        const unsigned long long m_d2 = __builtin_amdgcn_ballot_w64(donor);
-                        if (m_d2 != 0ull && __popcll(m_idle) >= 4) {
-                            const int32_t top = (wsp > 0) ? wstack[wsp - 1][wbase] : -1;
-                            const bool gave = hand_over(donor, wq, top, m_idle, m_d2);
-                            // the donor's four lanes all drop the entry: the leader's verdict reaches them through a ballot
-                            const unsigned long long m_g = __builtin_amdgcn_ballot_w64(gave);
-                            if ((m_g >> (lane & ~3u)) & 1ull) --wsp;
-                        }
-                    }
-                }
-            }
-            const bool active = node != -1;
-            const unsigned long long m_act = __builtin_amdgcn_ballot_w64(active);
-            if (m_act == 0ull) { if (__builtin_amdgcn_ballot_w64(sptr > 0) == 0ull) break; else continue; }
-            ++steps;
-            const float4 v = *rec_quad(recs, n, active ? (uint32_t)node : 0u, qr);
-            const float tx = __uint_as_float(__float_as_uint(v.x) ^ sbit), ty = __uint_as_float(__float_as_uint(v.y) ^ sbit);
-            const unsigned long long c0 = __builtin_amdgcn_ballot_w64(tx < Px), c1 = __builtin_amdgcn_ballot_w64(ty < Py);
-            const unsigned long long c2 = __builtin_amdgcn_ballot_w64(v.z < Pz), c3 = __builtin_amdgcn_ballot_w64(-v.w < Pw);
-            const unsigned long long ok = c0 & c1 & ((c2 & c3) | ODDS) & m_act;
-            const unsigned long long pr = ok & (ok >> 1);                    // bit 4k: the right child's box is hit, bit 4k + 2: the left child's
-            unsigned long long hR = pr & LEADERS, hL = (pr >> 2) & LEADERS;
-            hR |= hR << 1; hR |= hR << 2; hL |= hL << 1; hL |= hL << 2;       // the verdicts in all four lanes of the worker
-            const bool hitR = (hR >> lane) & 1ull, hitL = (hL >> lane) & 1ull;
-            const int32_t cr = __builtin_amdgcn_update_dpp(0, __float_as_int(v.z), 0x55, 0xf, 0xf, false);      // quad broadcast of lane 1: right link
-            const uint32_t lw = (uint32_t)__builtin_amdgcn_update_dpp(0, __float_as_int(v.w), 0x55, 0xf, 0xf, false);   //   ... last | exact flags
-            const int32_t cl = __builtin_amdgcn_update_dpp(0, __float_as_int(v.z), 0xff, 0xf, 0xf, false);      // quad broadcast of lane 3: left link
-            visits += (active & leader) ? 1u : 0u;
-            const bool intL = hitL & (cl >= 0), intR = hitR & (cr >= 0);
-            int32_t nxt = intL ? cl : (intR ? cr : -1);
-            if (intL & intR) {                                               // both internal: descend left, keep right
-                if (wsp < QSTACK) { if (leader) wstack[wsp][wbase] = cr; ++wsp; }
-                else if (leader) { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(g0 + wq, (uint32_t)cr); }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (active & !intL & !intR & (wsp > 0)) { --wsp; nxt = wstack[wsp][wbase]; }
-            node = active ? nxt : -1;
-            const bool candL = hitL & (cl < 0) & leader, candR = hitR & (cr < 0) & leader;
-            if (__builtin_amdgcn_ballot_w64(candL | candR) != 0ull) {
-                enqueue(candL, g0 + wq, (uint32_t)~cl | ((lw & REC_L_EXACT) ? wcert : 0u));
-                enqueue(candR, g0 + wq, (uint32_t)~cr | ((lw & REC_R_EXACT) ? wcert : 0u));
-            }
-        }
-    }
-    if (diag) tm4 = __builtin_amdgcn_s_memtime();
-    if (ablate & 8u) qcount = 0;
-    while (qcount > 0) flush(qcount < 64u ? qcount : 64u);
-    const unsigned long long t64 = wave_sum_u64(tested), v64 = wave_sum_u64(visits);
-    if (lane == 0 && !(ablate & 32u)) {
-        if (t64) atomicAdd(&sh->pairs_tested, t64);
-        if (v64) atomicAdd(&sh->node_visits, v64);
-        if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
-    }
-    if (lane == 0) {
-        if (blockIdx.x < 256u) atomicMax(&sh->pad[4], ~clk0);                  // (the earliest start is among the first workgroups dispatched)
-        atomicMax(&sh->pad[11], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    }
-    if (diag) {
-        const unsigned long long hi = wave_sum_u64(dg_hops_in), ho = wave_sum_u64(dg_hops_out), vi = wave_sum_u64(dg_vis);
-        const unsigned long long tm5 = __builtin_amdgcn_s_memtime();
-        if (lane == 0) {
-            atomicAdd(&sh->pad[0], (unsigned long long)(dg_p1 - dg_p1a)); atomicAdd(&sh->pad[1], hi); atomicAdd(&sh->pad[2], ho);
-            atomicAdd(&sh->pad[3], vi); atomicAdd(&sh->pad[5], (unsigned long long)dg_p1a);
-            atomicAdd(&sh->pad[6], tm1 - tm0); atomicAdd(&sh->pad[7], tm2 - tm1); atomicAdd(&sh->pad[8], tm3 - tm2);
-            atomicAdd(&sh->pad[9], tm4 - tm3); atomicAdd(&sh->pad[10], tm5 - tm4);
-        }
-    }
-}
-
-// ====================================================================================================
 // Variant E (default since round 3): the half traversal with a WORKGROUP-shared frontier for the descent.
 //   Phases 0 / 1a / 1b are variant D's, wave by wave (query box out of the records; right-sibling chain walked bottom-up:
 //   in-wave hops over registers, then the shared chain over scalar loads).  What changes is phase 2.  In variant D a lane

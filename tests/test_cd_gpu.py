@@ -18,10 +18,9 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-VARIANTS = [0, 1, 2, 3, 4, 5]  # CD_OPT_TRAVERSAL: lane-private FP64 descent / per-lane fp32 descent + exact kernel / packet descent + exact kernel /
+VARIANTS = [0, 1, 2, 3, 4]  # CD_OPT_TRAVERSAL: lane-private FP64 descent / per-lane fp32 descent + exact kernel / packet descent + exact kernel /
                             # half traversal: bottom-up chain of right siblings + per-lane fp32 descent + exact kernel / the same with the
-                            # descent as a workgroup-shared frontier worked off level by level (round 3) / the same with a quad-cooperative descent
-                            # (four lanes per visit, one 16-byte load each; round 3)
+                            # descent as a workgroup-shared frontier worked off level by level (round 3)
 
 
 def _check_visits(st, ref_stats, variant):

@@ -11,7 +11,7 @@ def main():
     for name, (verts, vidx) in (("cloth1M", synth.cloth_pair(500)), ("soup1M", synth.soup(1_000_000, 0.01, 1234))):
         with mi355cd.CollisionDetector(verts, vidx) as cd:
             cd.self_collide()
-            settings = [(5, 64), (3, 64)]
+            settings = [(4, 64), (3, 64)]
             times = {s: [] for s in settings}; desc = {}; stats = {}
             for r in range(rounds):
                 for s in settings:
