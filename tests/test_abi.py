@@ -67,6 +67,10 @@ def test_argument_errors_do_not_need_a_device():
     assert lib.cd_create(C.byref(ctx), None, 0, None, None, 0) == mi355cd.CD_ERR_ARG
     assert lib.cd_morton_sort(None) == mi355cd.CD_ERR_ARG
     assert lib.cd_find_collisions(None, None, 0, None) == mi355cd.CD_ERR_ARG
+    assert lib.cd_morton3d_points(None, 4, None, None, None) == mi355cd.CD_ERR_ARG
+    assert lib.cd_expand64_values(None, 4, None) == mi355cd.CD_ERR_ARG
+    assert lib.cd_alloc_host_pairs(0, None) == mi355cd.CD_ERR_ARG
+    assert lib.cd_multi_step(None, None, 0, None, None) == mi355cd.CD_ERR_ARG
     rl = mi355rt.load_library()
     rctx = C.c_void_p()
     assert rl.rt_create(C.byref(rctx), None, 0, 0) == mi355rt.RT_ERR_ARG
@@ -87,6 +91,11 @@ def test_no_device_is_an_error_not_a_fallback():
     with pytest.raises(mi355rt.RtError) as e:
         mi355rt.RayTracer(s, 64)
     assert e.value.rc == mi355rt.RT_ERR_NO_DEVICE
+    # the context-free entry points too: morton3D / expand64Bits on the device, the pinned pair buffer
+    for fn, arg in ((mi355cd.morton3d_points, np.zeros((4, 3))), (mi355cd.expand64_values, np.arange(4, dtype=np.uint64)), (mi355cd.HostPairs, 16)):
+        with pytest.raises(mi355cd.CdError) as e:
+            fn(arg)
+        assert e.value.rc == mi355cd.CD_ERR_NO_DEVICE
 
 
 def test_product_never_references_the_oracle():
