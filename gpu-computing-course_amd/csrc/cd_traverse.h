@@ -574,7 +574,8 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0, tm4 = 0;           // diagnostics: s_memtime stamps at the phase boundaries
     if (diag) tm0 = __builtin_amdgcn_s_memtime();
     uint32_t qcount = 0;                                // wave-uniform: candidates waiting in the queue
-    uint32_t tested = 0, visits = 0, steps = 0;
+    uint32_t tested = 0, steps = 0;
+    uint32_t wvisits = 0;                               // wave-uniform: node visits of the whole wave (a popcount of the active mask per step: two scalar instructions, no per-lane add)
     int sptr = 0;
     // Hand-over of queued candidates to k_exact, as in k_descend, with the half traversal's counting (both directions)
     // and ID rule (either order; k_exact puts the smaller ID in front).  The queue is drained only when it might not
@@ -652,8 +653,9 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     if (ablate & 4u) s = valid ? g_last : END;
     for (int hop = 0; hop < 128; ++hop) {                                     // tree height <= 96: the bound only matters for a corrupt tree
         const bool act = s < g_last;
-        if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
-        ++steps;
+        const unsigned long long m_act1 = __builtin_amdgcn_ballot_w64(act);
+        if (m_act1 == 0ull) break;
+        ++steps; wvisits += (uint32_t)__popcll(m_act1);
         const int from = (int)((act ? (s - g0) : lane) << 2);
         float4 c, d;
         c.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.x))); c.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.y)));
@@ -663,7 +665,6 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         const bool hit = act & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
         const int32_t link = __float_as_int(d.z);
         const uint32_t lw = __float_as_uint(d.w);
-        visits += act ? 1u : 0u;
         if (diag) dg_hops_in += act ? 1u : 0u;
         if (band(hit, link >= 0)) push_subtree(link);
         s = act ? (lw & REC_LAST_MASK) : s;
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
                              (__int_as_float(c.y) < qhi1) & (qlo2 < __int_as_float(d.y)) & (__int_as_float(c.z) < qhi2);
             const int32_t link = d.z;                                         // wave-uniform
             const uint32_t lw = (uint32_t)d.w;
-            visits += act ? 1u : 0u;
+            wvisits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(act));
             if (diag) dg_hops_out += act ? 1u : 0u;
             if (link >= 0) { if (hit) push_subtree(link); }
             else enqueue(hit, qi, (uint32_t)~link | ((lw & REC_R_EXACT) ? qcertain : 0u));
@@ -719,8 +720,9 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
             }
         }
         const bool active = (node != -1);
-        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-        ++steps;
+        const unsigned long long m_act2 = __builtin_amdgcn_ballot_w64(active);
+        if (m_act2 == 0ull) break;
+        ++steps; wvisits += (uint32_t)__popcll(m_act2);
         // one descent step per active lane, straight-line selects (see k_descend)
         // (idle lanes fetch record 0 and ignore it: one select for the address instead of fifteen register clears)
         const uint32_t rn = active ? (uint32_t)node : 0u;
@@ -730,7 +732,6 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         const uint32_t lw = __float_as_uint(d.w);
         const bool ol  = active & (qlo0 < a.w) & (a.x < qhi0) & (qlo1 < b.x) & (a.y < qhi1) & (qlo2 < b.y) & (a.z < qhi2);
         const bool orr = active & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
-        visits += active ? 1u : 0u;
         if (diag) dg_vis += active ? 1u : 0u;
         const bool intL = band(ol, cl >= 0), intR = band(orr, cr >= 0);
         int32_t nxt = intL ? cl : (intR ? cr : -1);
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     if (diag) tm4 = __builtin_amdgcn_s_memtime();
     if (ablate & 8u) qcount = 0;
     while (qcount > 0) flush(qcount < 64u ? qcount : 64u);
-    const unsigned long long t64 = wave_sum_u64(tested), v64 = wave_sum_u64(visits);
+    const unsigned long long t64 = wave_sum_u64(tested), v64 = wvisits;
     if (lane == 0 && !(ablate & 32u)) {
         if (t64) atomicAdd(&sh->pairs_tested, t64);
         if (v64) atomicAdd(&sh->node_visits, v64);
