@@ -6,13 +6,17 @@
  * cpu_baseline leg of bench.py may load it.  The shipped product (libmi355cd.so) never links,
  * loads or calls anything in this directory.
  *
- * Pinning status: the reference itself is CUDA C++ (needs <cuda_runtime.h>, Thrust, nvcc) and is
- * unbuildable in this image without writing stand-in headers, which this project does not do.
- * The oracle is therefore pinned by (i) the reference's own known-answer inputs
- * (check.cuh:19-27 key set; morton.h masks), (ii) outputs of the reference recorded in SURVEY.md
- * when the survey ran the reference sources (range/split table, morton3D anchors, pair counts on
- * seeded soups), and (iii) an independent O(N^2) brute force (check.cuh:117-141 restated).
- * See tests/test_oracle_pins.py.
+ * Pinning status.  The reference is CUDA C++ (<cuda_runtime.h>, Thrust, nvcc) and is unbuildable in this image without
+ * stand-in headers, which this project does not write -- EXCEPT morton.h, which is plain host C++ and is compiled unmodified
+ * (oracle/Makefile -> oracle/_ref/libref_morton.so, wrapper oracle/ref_morton.cpp).  So:
+ *   - orc_expand64, orc_morton3d, orc_centroid_morton (and the keys orc_sort_by_key orders) are pinned to the REFERENCE'S OWN
+ *     OBJECT CODE through tests/golden/morton_ref.npz (2^17 expand inputs, 2^20 in-frame points, the 10^6 centroids of
+ *     BASELINE config 3; generator tests/golden/make_morton_ref.py) -- tests/test_oracle_pins.py;
+ *   - everything else (delta / determineRange / findSplit / hierarchy, refit, box overlap, neighbour count, the 17-axis contact
+ *     test, the traversal, the verifier counters) is PARITY UNPINNED by any replayable reference-held vector: it is pinned by
+ *     (i) the reference's own known-answer inputs (check.cuh:19-27 key set), (ii) outputs of the reference recorded in SURVEY.md
+ *     when the survey ran the reference sources (range / split table, pair counts on seeded soups), and (iii) an independent
+ *     O(N^2) brute force (check.cuh:117-141 restated).
  *
  * Build: gcc -O2 -std=c99 -ffp-contract=off -fPIC -shared (no FMA contraction: every decision
  * below is an FP64 compare whose operands must round exactly like the reference's host twin).
