@@ -721,21 +721,26 @@ def test_config3_full_size_one_million_cloth_matches_oracle():
 
 
 def test_eight_million_soup_variants_agree():
-    """Size-independent property at 8 M triangles on one GPU (the whole config-4 data volume): the lane-private FP64
-    traversal and the split fp32 descent + exact kernel are independent implementations and must report the same
-    pair set and the same pairs_tested; the sort must leave the keys non-decreasing and the permutation a bijection."""
+    """8 M triangles on one GPU (the whole config-4 data volume): the default path (fused build, half traversal), the split fp32
+    descent + exact kernel and the lane-private FP64 traversal are independent implementations and must report the same
+    pair set and the same pairs_tested -- and, since round 3, the ORACLE's at this size; the sort must leave the oracle's keys
+    and permutation."""
     n = 8_000_000
     verts, vidx = synth.soup(n, 0.005, 99)
     sets, tested = [], []
     with mi355cd.CollisionDetector(verts, vidx) as cd:
-        for variant in (1, 0):
+        for variant in (3, 1, 0):                            # 3: the default path (15 625 blocks: the fused build's three-launch cross path, half traversal)
             cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
             pairs, cnt, rc = cd.self_collide(cap=1 << 22)
             assert rc == 0 and cnt > 1000
             sets.append(oracle.pair_set(pairs)); tested.append(cd.stats().pairs_tested)
         keys, perm = cd.export_keys()
         assert cd.check_internal().tolist() == [1, 0, 0, 0, 0] and cd.check_leaves().tolist() == [0, 0, 0, 0]
-    assert np.array_equal(sets[0], sets[1]) and tested[0] == tested[1]
+    assert np.array_equal(sets[0], sets[1]) and np.array_equal(sets[0], sets[2]) and tested[0] == tested[1] == tested[2]
+    # ... and the oracle itself at this size (a few seconds of CPU): pair set, pairs-tested count, keys and permutation
+    r = oracle.pipeline(verts, vidx)
+    assert np.array_equal(sets[0], oracle.pair_set(r["pairs"])) and tested[0] == r["stats"].pairs_tested
+    assert np.array_equal(keys, r["keys"]) and np.array_equal(perm, r["perm"])
     assert (keys[1:] >= keys[:-1]).all()
     assert np.array_equal(np.sort(perm), np.arange(n, dtype=np.uint32))
     # spot-check 2 000 reported pairs and 2 000 random non-reported neighbours with the oracle's exact test
