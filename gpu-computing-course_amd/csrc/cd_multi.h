@@ -376,7 +376,6 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     //  memset would sit between the records' arrival and the pass, 8 us + a launch gap on the step's longest chain)
     if (!(m->flags & CD_MULTI_CROSS_SERIAL)) SOFT_HIP(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), xs));
     int failed_rank = -1;
-    unsigned long long failed_status = 0;
     for (;; ++attempts) {
         if (r->AllGather(m->d_myroot, m->d_roots, 6, ncclDouble, m->comm, xs) != ncclSuccess && !local_err) local_err = CD_ERR_RCCL;
         if (self_peer && (m->flags & CD_MULTI_SELF_SLICE)) k_slice_box<<<1, 1, 0, xs>>>(m->d_roots + 6 * (size_t)me);   // rehearsal at config 4's scale
@@ -398,7 +397,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         SOFT_HIP(hipEventRecord(m->ev_counts, xs));
         SOFT_HIP(hipEventSynchronize(m->ev_counts)); ++syncs;                              // host synchronisation 1 of 2: the counts (the first stream keeps working)
         // every decision taken from the matrix is a function of the WHOLE matrix: identical on every rank
-        for (int a = 0; a < W && failed_rank < 0; ++a) if (m->h_matrix[(size_t)a * RW + W]) { failed_rank = a; failed_status = m->h_matrix[(size_t)a * RW + W]; }
+        for (int a = 0; a < W && failed_rank < 0; ++a) if (m->h_matrix[(size_t)a * RW + W]) failed_rank = a;
         if (failed_rank >= 0 || local_err) break;                                          // (local_err without a published status: the all-gather itself failed here)
         unsigned long long mx = 0;
         for (int a = 0; a < W; ++a) for (int p = 0; p < W; ++p) mx = std::max(mx, m->h_matrix[(size_t)a * RW + p]);
@@ -418,7 +417,6 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         if (n_pairs) *n_pairs = 0;
         if (local_err) return local_err;
         return failed_rank == W ? CD_ERR_ARG : CD_ERR_PEER;
-        (void)failed_status;
     }
 
     // ---- 2: payload exchange on the second stream (everything it reads was complete at the synchronisation above)

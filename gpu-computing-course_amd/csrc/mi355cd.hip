@@ -106,7 +106,7 @@ struct cd_ctx {
     // CD_OPT_GRAPH: the steady-state fused step captured once as a hipGraph and replayed (graph_step); the key is everything a replay bakes in
     bool graph_opt = false;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
-    struct GraphKey { uint64_t cap, spec_n; int sort_mode, variant, frame_mode; uint32_t nt, exact_blocks, dbg; const void *p_pairs, *p_cand, *p_defer, *p_report; uint64_t cand_cap; uint32_t defer_cap; } graph_key = {};
+    struct GraphKey { uint64_t cap, spec_n; int sort_mode, variant, frame_mode; uint32_t nt, exact_blocks, dbg; const void *p_pairs, *p_cand, *p_defer, *p_report; uint64_t cand_cap; uint32_t defer_cap, pad; } graph_key = {};   // (no padding bytes: compared with memcmp)
     struct GraphPost { bool leaves_filled, leaf_records_filled, hierarchy_valid, internal_boxes_valid, last_tree_fused, events_ride, scratch_clean; uint32_t sort_passes; } graph_post = {};
     uint64_t graph_replays = 0, graph_captures = 0;
     int wall_clock_khz = 0;                 // hipDeviceAttributeWallClockRate: ticks of s_memrealtime per millisecond
@@ -660,7 +660,8 @@ int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs
     uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
     const bool direct = is_pinned_pairs(pairs, cap_pairs);
     const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1),
-                               tb.d_pairs, tb.d_cand, tb.d_defer, direct ? (const void *)pairs : (const void *)tb.h_report, tb.cand_cap, tb.defer_cap};
+                               tb.d_pairs, tb.d_cand, tb.d_defer, direct ? (const void *)pairs : (const void *)tb.h_report, tb.cand_cap, tb.defer_cap, 0u};
+    static_assert(sizeof(cd_ctx::GraphKey) == 2 * 8 + 6 * 4 + 4 * 8 + 8 + 2 * 4, "GraphKey has no padding");
     if (!c->graph_exec || std::memcmp(&key, &c->graph_key, sizeof key) != 0) {
         graph_drop(c);
         HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
