@@ -66,7 +66,8 @@ __global__ __launch_bounds__(1024) void k_scan_exclusive(uint32_t *__restrict__ 
 // atomics per pass).
 // Round 3: the FIRST global pass has no rendezvous at all.  k_morton takes whole tiles and leaves, per tile, the counts of the first
 // global digit (tile_hist[tile][256]); a tile of the first pass sums the rows of the earlier tiles (16-byte loads, 16 waves x 4 rows
-// in flight: ~1 us) instead of looking back: 17.4 -> 12.6 us for that pass at 1 M keys (k_morton 13.2 -> 14.0 us).  The later passes'
+// in flight: ~1 us) instead of looking back, and is numbered by blockIdx.x (no arrival-order ticket, one round trip less): 17.4 -> 10.9 us
+// for that pass at 1 M keys (k_morton 13.2 -> 13.4 us).  The later passes'
 // input order only exists once the pass before them has run, so they keep the look-back.
 // The histograms that come with the Morton keys are kept as HIST_COPIES partial tables (workgroup b of k_morton adds to table
 // b mod HIST_COPIES; k_os_pass adds the tables up): its ~500 workgroups all flush at the end of the kernel, and atomics on one
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
     __shared__ uint32_t s_wsum[RADIX / 64];
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    if (tid == 0) s_tile = tile_hist ? blockIdx.x : atomicAdd(ticket, 1u);      // (no look-back, no need for arrival order: the ticket's round trip is saved)
     for (int i = tid; i < OS_WAVES * RADIX; i += OS_THREADS) (&wcnt[0][0])[i] = 0;
     // digit bases = exclusive scan of the 256 raw counts; every tile does it for itself (no scan kernel)
     uint32_t dbase = 0;
