@@ -103,6 +103,50 @@ RcclApi *rccl()
 __global__ void k_slice_box(double *box) { box[0] = box[1] - 0.1 * (box[1] - box[0]); }
 __global__ void k_set_word(unsigned long long *w, unsigned long long v) { *w = v; }
 
+// The box of all the rank's triangles when every vertex belongs to one (checked at cd_create): a streaming min / max over the VERTICES -- 24 coalesced
+// bytes each, no index gathers -- in ONE launch: a workgroup leaves its partial box and arrives on a counter, the workgroup that arrives last folds the
+// partials (device-scope loads) and writes the box; the counter resets itself.  The kernel also zeroes what the second stream needs zeroed before its
+// next jobs (the row of per-peer counts, the counters of the pass over the received queries): the stream's prologue was five launches -- triangle-wise
+// bounds 23 us, a one-workgroup fold 9 us, two fills and the all-gather -- in front of the pack; this is one of ~5 us.
+constexpr int VBOX_BLOCKS = 64, VBOX_THREADS = 1024;      // (at most 64 workgroups: the fold is one wave)
+__global__ __launch_bounds__(VBOX_THREADS) void k_vertex_box(const double *__restrict__ verts, uint32_t nv, double *partial /* [6][VBOX_BLOCKS] */, uint32_t *arrive,
+                                                             double *__restrict__ box /* x1 x2 y1 y2 z1 z2 */, uint32_t *__restrict__ zero0, uint32_t nzero0,
+                                                             uint32_t *__restrict__ zero1, uint32_t nzero1)
+{
+    __shared__ double sm[VBOX_THREADS / 64][6];
+    __shared__ uint32_t s_last;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (blockIdx.x == 0) { for (uint32_t i = tid; i < nzero0; i += VBOX_THREADS) zero0[i] = 0u; }
+    if (blockIdx.x == 1 || gridDim.x == 1) { for (uint32_t i = tid; i < nzero1; i += VBOX_THREADS) zero1[i] = 0u; }
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t v = blockIdx.x * VBOX_THREADS + tid; v < nv; v += gridDim.x * VBOX_THREADS) {
+        const d3 p = load_vertex(verts, v);
+        lo[0] = p.x < lo[0] ? p.x : lo[0]; hi[0] = p.x > hi[0] ? p.x : hi[0];
+        lo[1] = p.y < lo[1] ? p.y : lo[1]; hi[1] = p.y > hi[1] ? p.y : hi[1];
+        lo[2] = p.z < lo[2] ? p.z : lo[2]; hi[2] = p.z > hi[2] ? p.z : hi[2];
+    }
+    for (int a = 0; a < 3; ++a) { const double l = wave_min(lo[a]), h = wave_max(hi[a]); if (lane == 0) { sm[w][2 * a] = l; sm[w][2 * a + 1] = h; } }
+    __syncthreads();
+    if (tid < 6) {
+        const bool is_lo = (tid & 1u) == 0u;
+        double v = sm[0][tid];
+        for (int ww = 1; ww < VBOX_THREADS / 64; ++ww) { const double t = sm[ww][tid]; v = is_lo ? (t < v ? t : v) : (t > v ? t : v); }
+        __hip_atomic_store(&partial[tid * gridDim.x + blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);                                         // the six stores above came from lanes of THIS wave: complete before the arrival
+        s_last = (atomicAdd(arrive, 1u) + 1u == gridDim.x) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last && tid < 64) {                                                  // (one wave: lane b takes workgroup b's partials, all six loads in flight together)
+        double v[6];
+        for (int a = 0; a < 6; ++a) v[a] = tid < gridDim.x ? __hip_atomic_load(&partial[a * gridDim.x + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((a & 1) ? -1e300 : 1e300);
+        for (int a = 0; a < 6; ++a) { const double r = (a & 1) ? wave_max(v[a]) : wave_min(v[a]); if (tid == 0) box[a] = r; }
+        if (tid == 0) *arrive = 0u;                                            // (for the next step)
+    }
+}
+
 enum MEv { ME_START, ME_LOC0, ME_TREE, ME_GATHER, ME_PACK, ME_COUNTS, ME_XCH0, ME_XCH1, ME_LOCAL, ME_CROSS, ME_COUNT };
 
 }  // namespace
@@ -120,6 +164,7 @@ struct cd_multi {
     double *d_myroot = nullptr;                  // 6: the box of all this rank's triangles, from their vertices
     double *d_partial = nullptr;                 // per-block bounds of that reduction (the context's own are the first stream's, for its Morton frame)
     double *d_roots = nullptr;                   // world x 6
+    uint32_t *d_arrive = nullptr;                // k_vertex_box's arrival counter (self-resetting)
     unsigned long long *d_row = nullptr;         // world + 1: records packed for each peer | this rank's status word
     unsigned long long *d_matrix = nullptr;      // world x (world + 1), all-gathered rows
     unsigned long long *h_matrix = nullptr;      // pinned copy
@@ -142,7 +187,7 @@ void multi_free(cd_multi *m)
     if (m->ev_box) hipEventDestroy(m->ev_box);
     if (m->ev_cross) hipEventDestroy(m->ev_cross);
     for (int i = 0; i < ME_COUNT; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
-    hipFree(m->d_myroot); hipFree(m->d_partial); hipFree(m->d_roots); hipFree(m->d_row); hipFree(m->d_matrix); hipFree(m->d_send); hipFree(m->d_recv);
+    hipFree(m->d_arrive); hipFree(m->d_myroot); hipFree(m->d_partial); hipFree(m->d_roots); hipFree(m->d_row); hipFree(m->d_matrix); hipFree(m->d_send); hipFree(m->d_recv);
     if (m->h_matrix) hipHostFree(m->h_matrix);
     if (m->h_roots) hipHostFree(m->h_roots);
     if (m->own_comm && m->comm && rccl()) rccl()->CommDestroy(m->comm);
@@ -163,6 +208,8 @@ int multi_alloc(cd_multi *m)
     HIPCHK(hipEventCreateWithFlags(&m->ev_box, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_cross, hipEventDisableTiming));
     for (int i = 0; i < ME_COUNT; ++i) HIPCHK(hipEventCreate(&m->ev[i]));
+    HIPCHK(hipMalloc(&m->d_arrive, sizeof(uint32_t) * 16));
+    HIPCHK(hipMemset(m->d_arrive, 0, sizeof(uint32_t) * 16));
     HIPCHK(hipMalloc(&m->d_myroot, sizeof(double) * 6));
     HIPCHK(hipMalloc(&m->d_partial, sizeof(double) * BOUNDS_STRIDE * BOUNDS_BLOCKS));
     HIPCHK(hipMalloc(&m->d_roots, sizeof(double) * 6 * W));
@@ -370,17 +417,26 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     // stream starts the rank's pipeline at once and no event ties the two together before the tree is there (an event record
     // between two kernels of a stream is a barrier packet: ~6 us of idle GPU).
     if (!local_err) { const int rc = enqueue_sort(false); if (rc) local_err = rc; }
-    k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, xs>>>(c->d_verts, c->d_vidx, c->nt, m->d_partial);
-    k_frame_from_bounds<<<1, 256, 0, xs>>>(m->d_partial, BOUNDS_BLOCKS, nullptr, m->d_myroot);
-    // (the counters of the pass over the received queries: zeroed here, where the second stream has time -- behind the exchange the
+    // (the counters of the pass over the received queries are zeroed here too, where the second stream has time -- behind the exchange a
     //  memset would sit between the records' arrival and the pass, 8 us + a launch gap on the step's longest chain)
-    if (!(m->flags & CD_MULTI_CROSS_SERIAL)) SOFT_HIP(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), xs));
+    const bool zero_cross = !(m->flags & CD_MULTI_CROSS_SERIAL);
+    bool row_zeroed = false;
+    if (c->all_verts_referenced) {
+        k_vertex_box<<<VBOX_BLOCKS, VBOX_THREADS, 0, xs>>>(c->d_verts, c->nv, m->d_partial, m->d_arrive, m->d_myroot,
+                                                           reinterpret_cast<uint32_t *>(m->d_row), (uint32_t)(2 * RW),
+                                                           reinterpret_cast<uint32_t *>(t1.d_state), zero_cross ? (uint32_t)(sizeof(TravState) / sizeof(uint32_t)) : 0u);
+        row_zeroed = true;
+    } else {
+        k_centroid_bounds<true><<<BOUNDS_BLOCKS, 256, 0, xs>>>(c->d_verts, c->d_vidx, c->nt, m->d_partial);
+        k_frame_from_bounds<<<1, 256, 0, xs>>>(m->d_partial, BOUNDS_BLOCKS, nullptr, m->d_myroot);
+        if (zero_cross) SOFT_HIP(hipMemsetAsync(t1.d_state, 0, sizeof(TravState), xs));
+    }
     int failed_rank = -1;
     for (;; ++attempts) {
         if (r->AllGather(m->d_myroot, m->d_roots, 6, ncclDouble, m->comm, xs) != ncclSuccess && !local_err) local_err = CD_ERR_RCCL;
         if (self_peer && (m->flags & CD_MULTI_SELF_SLICE)) k_slice_box<<<1, 1, 0, xs>>>(m->d_roots + 6 * (size_t)me);   // rehearsal at config 4's scale
         mark(ME_GATHER, xs);
-        SOFT_HIP(hipMemsetAsync(m->d_row, 0, sizeof(unsigned long long) * RW, xs));
+        if (!(row_zeroed && attempts == 0)) SOFT_HIP(hipMemsetAsync(m->d_row, 0, sizeof(unsigned long long) * RW, xs));   // (the first round's: by k_vertex_box)
         if (!local_err && m->d_send)
             k_pack_triangles<<<cdiv(c->nt, PACK_THREADS), PACK_THREADS, 0, xs>>>(c->d_verts, c->d_vidx, c->d_ids, (int)c->nt, m->d_roots, W,
                                                                                   self_peer ? -1 : me, m->d_roots + 6 * (size_t)me,

@@ -109,6 +109,7 @@ struct cd_ctx {
     struct GraphKey { uint64_t cap, spec_n; int sort_mode, variant, frame_mode; uint32_t nt, exact_blocks, dbg; const void *p_pairs, *p_cand, *p_defer, *p_report; uint64_t cand_cap; uint32_t defer_cap, pad; } graph_key = {};   // (no padding bytes: compared with memcmp)
     struct GraphPost { bool leaves_filled, leaf_records_filled, hierarchy_valid, internal_boxes_valid, last_tree_fused, events_ride, scratch_clean; uint32_t sort_passes; } graph_post = {};
     uint64_t graph_replays = 0, graph_captures = 0;
+    bool all_verts_referenced = false;      // every vertex belongs to a triangle (checked at cd_create; the topology never changes afterwards)
     int wall_clock_khz = 0;                 // hipDeviceAttributeWallClockRate: ticks of s_memrealtime per millisecond
     double root_box_host[6] = {};           // AABB of the whole tree, fetched together with other read-backs
     bool root_box_valid = false;
@@ -734,9 +735,14 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return CD_ERR_NO_DEVICE;
     for (uint64_t k = 0; k < 3ull * nt; ++k) if (vidx3[k] >= nv) return CD_ERR_INDEX;
+    bool all_ref = true;                                // is every vertex used by some triangle?  (then the box of the triangles is the box of the vertices: cd_multi.h)
+    { std::vector<uint8_t> used(nv, 0);
+      for (uint64_t k = 0; k < 3ull * nt; ++k) used[vidx3[k]] = 1;
+      for (uint32_t v = 0; v < nv && all_ref; ++v) all_ref = used[v] != 0; }
     cd_ctx *c = new (std::nothrow) cd_ctx();
     if (!c) return CD_ERR_ARG;
     c->nv = nv; c->nt = nt;
+    c->all_verts_referenced = all_ref;
     c->ntiles = cdiv(nt, SORT_TILE);
     { int dev = 0, khz = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess) c->wall_clock_khz = khz; (void)hipGetLastError(); }
     const size_t n = nt;
