@@ -1164,3 +1164,22 @@ def test_pinned_host_pair_buffer_receives_the_pairs_directly():
             assert n == len(want) and rc == (mi355cd.CD_OVERFLOW if len(want) > (1 << 12) else 0)
             got = oracle.pair_set(sub[:min(n, 1 << 12)])
             assert np.isin(got, want).all() and len(np.unique(got)) == len(got)
+
+
+def test_multi_step_box_of_the_triangles_ignores_unreferenced_vertices():
+    """The box a rank publishes is the box of its TRIANGLES.  When every vertex belongs to a triangle the step takes it from the
+    vertices in one streaming launch (k_vertex_box); vertices no triangle uses -- here far outside, so that they would blow the box
+    up -- switch it to the triangle-wise reduction.  Both must give the box node 0 of the tree holds (FP64 bit patterns) and the
+    oracle's pairs."""
+    verts, vidx = synth.cloth_pair(50)
+    r = oracle.pipeline(verts, vidx)
+    stray = np.array([[1e6, -1e6, 1e6], [-1e6, 1e6, -1e6]])
+    for v in (verts, np.concatenate([verts, stray], axis=0)):
+        with mi355cd.CollisionDetector(v, vidx) as cd:
+            with mi355cd.MultiStep(cd, mi355cd.multi_unique_id(), 0, 1, flags=mi355cd.CD_MULTI_SELF_PEER) as ms:
+                for it in range(2):
+                    pairs, n, rc, info = ms.step(cap=1 << 20)
+                    nl = r["stats"].n_pairs
+                    assert rc == 0 and info.local_pairs == nl and info.cross_pairs == nl
+                    assert np.array_equal(oracle.pair_set(pairs[:nl]), oracle.pair_set(r["pairs"]))
+                    assert np.array_equal(cd.root_box().view(np.uint64), r["boxes"][0].view(np.uint64))     # what the step published == node 0's box
