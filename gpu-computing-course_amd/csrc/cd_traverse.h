@@ -524,10 +524,6 @@ constexpr uint32_t HALF_FLUSH_AT = HALF_QCAP - 64;   // an enqueue adds at most 
 #ifndef HALF_T
 #define HALF_T 64
 #endif
-#ifndef HALF_GROUPS
-#define HALF_GROUPS 1
-#endif
-static_assert(HALF_GROUPS == 1 || HALF_GROUPS == 2, "one tag bit in a stack entry");
 constexpr int HALF_THREADS = HALF_T, HALF_WAVES = HALF_THREADS / 64;
 __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
                                                                   TravState *__restrict__ st,
@@ -571,13 +567,10 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     const uint32_t nq = (uint32_t)n, last_leaf = nq - 1u;
     constexpr uint32_t END = 0xffffffffu;
     // the wave owns the 64 consecutive leaves [g0, g_last]  (wave-uniform; readfirstlane tells the compiler)
-    // HALF_GROUPS consecutive groups of 64 leaves per wave: phases 0 / 1 run group by group, phase 2 ONCE over the hit subtrees of
-    // all of them (a lane then has the items of HALF_GROUPS queries to work through: its idle time between the deepest lane's steps shrinks)
-    const uint32_t gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)((vblock * HALF_WAVES + w) * 64u * HALF_GROUPS));
-    uint32_t g0 = gbase, g_last = (g0 + 63u < last_leaf) ? g0 + 63u : last_leaf;
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((vblock * HALF_WAVES + w) * 64u));
+    const uint32_t g_last = (g0 + 63u < last_leaf) ? g0 + 63u : last_leaf;
     uint32_t qi = g0 + lane;
-    bool valid = qi < nq && n > 1;
-    uint32_t curtag = 0u;                               // which of the lane's queries a pushed subtree belongs to (bit 30 of the stack entry)
+    const bool valid = qi < nq && n > 1;
     unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0, tm4 = 0;           // diagnostics: s_memtime stamps at the phase boundaries
     if (diag) tm0 = __builtin_amdgcn_s_memtime();
     uint32_t qcount = 0;                                // wave-uniform: candidates waiting in the queue
@@ -619,7 +612,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     };
     auto push_subtree = [&](int32_t link) {                                   // an internal sibling / child that was hit: descended in phase 2
         if (ablate & 1u) return;                                              // TIMING EXPERIMENT ONLY (wrong results): phase 1 alone
-        if (sptr < HALF_STACK) { lds_stack[sptr][tid] = link | (int32_t)curtag; ++sptr; }
+        if (sptr < HALF_STACK) { lds_stack[sptr][tid] = link; ++sptr; }
         else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)link); }
     };
     // ---- the query box comes out of the RECORDS, not out of qbox[]: leaf j is the left child of recs[j] (then that
@@ -628,13 +621,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     // right half of recs[j] anyway (phase 1a), the right half of recs[j - 1] is in the neighbour lane, and the left
     // halves are what phase 2 reads next: 32 bytes per leaf less from HBM than with a separate query array.
     // The last leaf has no record of its own: it is the right child of recs[n - 2].
-    float qlo0 = 0.f, qlo1 = 0.f, qlo2 = 0.f, qhi0 = 0.f, qhi1 = 0.f, qhi2 = 0.f; uint32_t qcertain = 0u;
-    float sv[HALF_GROUPS][6]; uint32_t sv_cert[HALF_GROUPS], sv_qi[HALF_GROUPS];      // the lane's queries, kept for phase 2
-#pragma unroll
-    for (int gi = 0; gi < HALF_GROUPS; ++gi) {
-    g0 = gbase + 64u * (uint32_t)gi; g_last = (g0 + 63u < last_leaf) ? g0 + 63u : last_leaf;
-    qi = g0 + lane; valid = qi < nq && n > 1;
-    curtag = (uint32_t)gi << 30;
+    float qlo0, qlo1, qlo2, qhi0, qhi1, qhi2; uint32_t qcertain;
     float4 rc = make_float4(0.f, 0.f, 0.f, 0.f), rd = rc;
     {
         float4 la = rc, lb = rc, pc = rc, pd = rc;
@@ -706,20 +693,11 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
             t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lw & REC_LAST_MASK));
         }
     }
-    sv[gi][0] = qlo0; sv[gi][1] = qlo1; sv[gi][2] = qlo2; sv[gi][3] = qhi0; sv[gi][4] = qhi1; sv[gi][5] = qhi2; sv_cert[gi] = qcertain; sv_qi[gi] = qi;
-    }
-    // (from here on qlo / qhi / qcertain / qi are the query of the lane's CURRENT item: re-selected whenever an item comes off the stack)
-    auto select_query = [&](uint32_t tag) {
-#pragma unroll
-        for (int gi = 0; gi < HALF_GROUPS; ++gi)
-            if (gi == 0 || tag == ((uint32_t)gi << 30)) { qlo0 = sv[gi][0]; qlo1 = sv[gi][1]; qlo2 = sv[gi][2]; qhi0 = sv[gi][3]; qhi1 = sv[gi][4]; qhi2 = sv[gi][5]; qcertain = sv_cert[gi]; qi = sv_qi[gi]; }
-        curtag = tag;
-    };
     dg_p1 = steps;
     if (diag) tm3 = __builtin_amdgcn_s_memtime();
     // ---- phase 2: descend the sibling subtrees that were hit
     int32_t node = -1;
-    if (sptr > 0) { --sptr; const int32_t e = lds_stack[sptr][tid]; node = e & 0x3fffffff; if (HALF_GROUPS > 1) select_query((uint32_t)e & 0x40000000u); }
+    if (sptr > 0) { --sptr; node = lds_stack[sptr][tid]; }
     while (true) {
         // work sharing inside the wave (see k_descend): a busy lane hands the top of its stack, with its query, to an idle lane
         if (SHARE_MIN_IDLE <= 64) {
@@ -733,21 +711,11 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
                 if (give) { share_map[w][rank_d] = (uint8_t)lane; --sptr; top = lds_stack[sptr][tid]; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 const int from = take ? (int)share_map[w][rank_r] : (int)lane;
-                // (the query that goes with the entry handed over is the one its TAG names, not the donor's current one)
-                float d0 = qlo0, d1 = qlo1, d2 = qlo2, d3_ = qhi0, d4 = qhi1, d5 = qhi2; uint32_t dq = qi, dc = qcertain;
-                if (HALF_GROUPS > 1) {
-#pragma unroll
-                    for (int gi = 0; gi < HALF_GROUPS; ++gi)
-                        if (gi == 0 || ((uint32_t)top & 0x40000000u) == ((uint32_t)gi << 30)) { d0 = sv[gi][0]; d1 = sv[gi][1]; d2 = sv[gi][2]; d3_ = sv[gi][3]; d4 = sv[gi][4]; d5 = sv[gi][5]; dc = sv_cert[gi]; dq = sv_qi[gi]; }
-                }
                 const int32_t e = __shfl(top, from);
-                const uint32_t s_qi = __shfl(dq, from), s_cert = __shfl(dc, from);
-                const float f0 = __shfl(d0, from), f1 = __shfl(d1, from), f2 = __shfl(d2, from);
-                const float f3 = __shfl(d3_, from), f4 = __shfl(d4, from), f5 = __shfl(d5, from);
-                if (take) {                                                    // (the taker has nothing left of its own: the adopted query becomes its query 0)
-                    node = e & 0x3fffffff; qi = s_qi; qcertain = s_cert; qlo0 = f0; qlo1 = f1; qlo2 = f2; qhi0 = f3; qhi1 = f4; qhi2 = f5; sptr = 0; curtag = 0u;
-                    sv[0][0] = f0; sv[0][1] = f1; sv[0][2] = f2; sv[0][3] = f3; sv[0][4] = f4; sv[0][5] = f5; sv_cert[0] = s_cert; sv_qi[0] = s_qi;
-                }
+                const uint32_t s_qi = __shfl(qi, from), s_cert = __shfl(qcertain, from);
+                const float f0 = __shfl(qlo0, from), f1 = __shfl(qlo1, from), f2 = __shfl(qlo2, from);
+                const float f3 = __shfl(qhi0, from), f4 = __shfl(qhi1, from), f5 = __shfl(qhi2, from);
+                if (take) { node = e; qi = s_qi; qcertain = s_cert; qlo0 = f0; qlo1 = f1; qlo2 = f2; qhi0 = f3; qhi1 = f4; qhi2 = f5; sptr = 0; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         }
@@ -768,16 +736,12 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         const bool intL = band(ol, cl >= 0), intR = band(orr, cr >= 0);
         int32_t nxt = intL ? cl : (intR ? cr : -1);
         if (band(intL, intR)) push_subtree(cr);                            // both internal: descend left, push right
-        const uint32_t cand_q = qi, cand_cert = qcertain;                     // (the popped item below may belong to the lane's other query)
-        if (band(band(active, !bor(intL, intR)), sptr > 0)) {
-            --sptr; const int32_t e = lds_stack[sptr][tid]; nxt = e & 0x3fffffff;
-            if (HALF_GROUPS > 1) select_query((uint32_t)e & 0x40000000u);
-        }
+        if (band(band(active, !bor(intL, intR)), sptr > 0)) { --sptr; nxt = lds_stack[sptr][tid]; }
         node = active ? nxt : -1;
         const bool candL = band(ol, cl < 0), candR = band(orr, cr < 0);
         if (__builtin_amdgcn_ballot_w64(bor(candL, candR)) != 0ull) {        // (most steps meet no leaf: one test instead of two)
-            enqueue(candL, cand_q, (uint32_t)~cl | ((lw & REC_L_EXACT) ? cand_cert : 0u));
-            enqueue(candR, cand_q, (uint32_t)~cr | ((lw & REC_R_EXACT) ? cand_cert : 0u));
+            enqueue(candL, qi, (uint32_t)~cl | ((lw & REC_L_EXACT) ? qcertain : 0u));
+            enqueue(candR, qi, (uint32_t)~cr | ((lw & REC_R_EXACT) ? qcertain : 0u));
         }
     }
     if (diag) tm4 = __builtin_amdgcn_s_memtime();

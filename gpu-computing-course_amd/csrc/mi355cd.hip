@@ -428,12 +428,12 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         const uint32_t half = half_mode ? 1u : 0u;
         const bool plain = !e0 && !e1 && !e2;          // no time stamp rides on these launches: plain launches (a stream capture can record them)
         if (plain && half_mode && !DEEP && c->trav_variant == 3)
-            k_descend_half<<<cdiv(items, 64u * HALF_WAVES * HALF_GROUPS), HALF_THREADS, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
+            k_descend_half<<<cdiv(items, 64u * HALF_WAVES), HALF_THREADS, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
         else if (half_mode && !DEEP && c->trav_variant == 4)
             hipExtLaunchKernelGGL(k_descend_wg, dim3(cdiv(items, (uint32_t)WGF_THREADS)), dim3(WGF_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, n, (const NodeRec32 *)c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
         else if (half_mode && !DEEP)
-            hipExtLaunchKernelGGL(k_descend_half, dim3(cdiv(items, 64u * HALF_WAVES * HALF_GROUPS)), dim3(HALF_THREADS), (uint32_t)pad, s, e0, e1, 0u,
+            hipExtLaunchKernelGGL(k_descend_half, dim3(cdiv(items, 64u * HALF_WAVES)), dim3(HALF_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, n, (const NodeRec32 *)c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
         else if (qpw == 64)
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, false>), grid, dim3(DESC_THREADS), (uint32_t)pad, s, e0, e1, 0u,
