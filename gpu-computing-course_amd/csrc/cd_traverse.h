@@ -20,7 +20,7 @@ struct alignas(128) CtrShard {
 struct alignas(128) TravState {
     unsigned long long n_pairs;        // collision.cuh:40 `count`
     uint32_t n_deferred;               // (query, subtree) items the LDS stack could not hold (deep pass redoes them)
-    uint32_t pad0;
+    uint32_t report_arrive;            // workgroups of k_report that have posted their part (polled completion, see k_report)
     unsigned long long pad[14];
     CtrShard shard[NSHARD];
 };
@@ -40,16 +40,22 @@ struct alignas(256) Report {
     uint32_t sort_flags[9]; uint32_t pad1;
     double root_box[6];
     unsigned long long clk_start_inv, clk_end;   // descent kernel, device wall clock (s_memrealtime ticks): ~(earliest wave start), latest wave end; 0 = not taken
+    unsigned long long seq;                      // polled completion: the step's sequence number, stored LAST (0: this report does not take part)
 };
 static_assert(sizeof(Report) == 256, "report layout");
 
 // `out` and `pairs_out` are PINNED HOST memory (zero-copy): the kernel posts the 256-byte record and the first
 // min(n_pairs, spec_n) pairs straight over the host link, so the step ends with a stream synchronise instead of a
 // DMA copy (whose set-up idles the GPU for ~12 us and runs ~5 us).  Block 0 / wave 0 writes the record.
+// Polled completion (seq != 0): the host does not wait for the stream at all -- it spins on Report::seq in its own memory.  Every
+// workgroup makes its part visible to the host (system-scope fence), then arrives on a device counter; the last one to arrive
+// stores the sequence number with a system-scope release.  The counter is never reset inside a step: a second report of the same
+// step (deep pass) finds it at a multiple of the grid size.
 constexpr int REPORT_THREADS = 256;
 __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__restrict__ st, const uint32_t *__restrict__ sort_flags /* 9 words */,
                                                            const double *__restrict__ root_box, Report *__restrict__ out,
-                                                           const uint32_t *__restrict__ pairs, uint32_t *__restrict__ pairs_out, unsigned long long spec_n)
+                                                           const uint32_t *__restrict__ pairs, uint32_t *__restrict__ pairs_out, unsigned long long spec_n,
+                                                           unsigned long long seq)
 {
     const unsigned long long np = st->n_pairs;
     if (blockIdx.x == 0 && threadIdx.x < 64) {
@@ -77,6 +83,16 @@ __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__re
     uint4 *dst = reinterpret_cast<uint4 *>(pairs_out);
     for (unsigned long long i = (unsigned long long)blockIdx.x * REPORT_THREADS + threadIdx.x; i < quads; i += (unsigned long long)gridDim.x * REPORT_THREADS) dst[i] = src[i];
     if ((take & 1ull) && blockIdx.x == 0 && threadIdx.x == 64) reinterpret_cast<uint2 *>(pairs_out)[take - 1] = reinterpret_cast<const uint2 *>(pairs)[take - 1];
+    if (seq == 0ull) return;                                            // (uniform over the grid)
+    __threadfence_system();                                             // this thread's host writes
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t old = atomicAdd(const_cast<uint32_t *>(&st->report_arrive), 1u);
+        if (old % gridDim.x == gridDim.x - 1u) {
+            __threadfence_system();
+            __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 constexpr int TRAV_THREADS = 256;
@@ -755,7 +771,11 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     }
     if (lane == 0) {
         if (blockIdx.x < 256u) atomicMax(&sh->pad[4], ~clk0);                  // (the earliest start is among the first workgroups dispatched)
-        atomicMax(&sh->pad[11], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        const unsigned long long clk1 = __builtin_amdgcn_s_memrealtime();
+        atomicMax(&sh->pad[11], clk1);
+#ifdef CD_ABLATE                                                               // experiment builds only: every wave's start / end tick, read back by cd_debug_wave_times
+        if ((ablate & 128u) && blockIdx.x < defer_cap) defer_list[blockIdx.x] = make_uint2(((uint32_t)clk0 & 0xffffu) | ((uint32_t)clk1 << 16), (steps & 0xffu) | ((dg_p1 & 0xffu) << 8) | ((dg_p1a & 0xffu) << 16) | (min(wvisits >> 2, 255u) << 24));
+#endif
     }
     if (diag) {
         const unsigned long long hi = wave_sum_u64(dg_hops_in), ho = wave_sum_u64(dg_hops_out), vi = wave_sum_u64(dg_vis);

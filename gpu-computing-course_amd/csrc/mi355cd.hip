@@ -10,6 +10,8 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -105,6 +107,10 @@ struct cd_ctx {
                                             // 2 full (8 passes); forced by CD_OPT_SORT_FULL, or escalated after an overflow on this context
     // CD_OPT_GRAPH: the steady-state fused step captured once as a hipGraph and replayed (graph_step); the key is everything a replay bakes in
     bool graph_opt = false;
+    // CD_OPT_POLL: the step's end is read off the report's sequence word in pinned host memory instead of waiting for the stream (wait_report)
+    bool poll_opt = true;
+    unsigned long long report_seq = 0;      // last sequence number handed to a k_report
+    uint32_t polled_steps = 0, poll_fallbacks = 0;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
     struct GraphKey { uint64_t cap, spec_n; int sort_mode, variant, frame_mode; uint32_t nt, exact_blocks, dbg; const void *p_pairs, *p_cand, *p_defer, *p_report; uint64_t cand_cap; uint32_t defer_cap, pad; } graph_key = {};   // (no padding bytes: compared with memcmp)
     struct GraphPost { bool leaves_filled, leaf_records_filled, hierarchy_valid, internal_boxes_valid, last_tree_fused, events_ride, scratch_clean; uint32_t sort_passes; } graph_post = {};
@@ -460,18 +466,45 @@ struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_can
 // after the caller has synchronised the stream (the multi-GPU step queues two passes and synchronises once).
 int ensure_report(TravBuf &tb)
 {
-    if (!tb.h_report) HIPCHK(hipHostMalloc(&tb.h_report, sizeof(Report) + sizeof(uint32_t) * 2 * SPEC_PAIRS, hipHostMallocDefault));
+    if (!tb.h_report) {
+        HIPCHK(hipHostMalloc(&tb.h_report, sizeof(Report) + sizeof(uint32_t) * 2 * SPEC_PAIRS, hipHostMallocDefault));
+        std::memset(tb.h_report, 0, sizeof(Report));                       // (Report::seq: no stale sequence number)
+    }
     return 0;
 }
 // direct: the first spec_n pairs go straight into the CALLER's buffer (pinned host memory from cd_alloc_host_pairs) instead of the staging area behind the record
-int enqueue_report(cd_ctx *c, TravBuf &tb, bool want_pairs, uint64_t &spec_n, uint32_t *direct = nullptr)
+int enqueue_report(cd_ctx *c, TravBuf &tb, bool want_pairs, uint64_t &spec_n, uint32_t *direct = nullptr, unsigned long long seq = 0)
 {
     { const int rc = ensure_report(tb); if (rc) return rc; }
     if (!want_pairs) spec_n = 0; else if (spec_n > SPEC_PAIRS) spec_n = SPEC_PAIRS;
     // (the pair list is allocated with an even capacity + slack, so the quad copy may read one pair past `take`; a pinned buffer of
     //  cd_alloc_host_pairs has the same slack)
     k_report<<<spec_n ? 32 : 1, REPORT_THREADS, 0, c->stream>>>(tb.d_state, c->d_os_ticket + 8, c->d_boxes, reinterpret_cast<Report *>(tb.h_report),
-                                                              tb.d_pairs, direct ? direct : reinterpret_cast<uint32_t *>(tb.h_report + sizeof(Report)), (unsigned long long)spec_n);
+                                                              tb.d_pairs, direct ? direct : reinterpret_cast<uint32_t *>(tb.h_report + sizeof(Report)), (unsigned long long)spec_n, seq);
+    return 0;
+}
+// Polled completion of a step (CD_OPT_POLL): spin on the sequence word k_report stores last.  Nothing that follows may need the
+// stream's events (the caller checks: no stage events, no time stamps).  A step that takes longer than the spin budget, or never
+// reports (a faulted kernel), ends in the ordinary stream synchronise, which also returns the error.  Every 64th polled step
+// synchronises the stream as well, so that the runtime retires what it keeps per launch.
+bool poll_allowed(const cd_ctx *c) { return c->poll_opt && !c->stage_events && c->stamp_mask == 0; }
+int wait_report(cd_ctx *c, TravBuf &tb, unsigned long long seq)
+{
+    if (seq != 0ull) {
+        const volatile unsigned long long *p = &reinterpret_cast<const volatile Report *>(tb.h_report)->seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t it = 1; *p != seq; ++it) {
+            __builtin_ia32_pause();
+            if ((it & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+        if (*p == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if ((++c->polled_steps & 63u) == 0) HIPCHK(hipStreamSynchronize(c->stream));
+            return 0;
+        }
+        ++c->poll_fallbacks;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 void parse_report(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs, uint64_t spec_n)
@@ -487,9 +520,10 @@ void parse_report(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs,
 }
 int read_state(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs = nullptr, uint64_t spec_n = 0, bool direct = false)
 {
-    int rc = enqueue_report(c, tb, spec_pairs != nullptr, spec_n, direct ? spec_pairs : nullptr);
+    const unsigned long long seq = poll_allowed(c) ? ++c->report_seq : 0ull;
+    int rc = enqueue_report(c, tb, spec_pairs != nullptr, spec_n, direct ? spec_pairs : nullptr, seq);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((rc = wait_report(c, tb, seq))) return rc;
     parse_report(c, tb, h, direct ? nullptr : spec_pairs, spec_n);          // (direct: the pairs are already where the caller wants them)
     return 0;
 }
@@ -1199,6 +1233,18 @@ void cd_free_host_pairs(uint32_t *pairs)
     hipHostFree(pairs);
 }
 
+#ifdef CD_ABLATE
+/* experiment builds only (tools/ab_build.sh abl -DCD_ABLATE; not in the header, not in the shipped library): the (start, end) ticks every wave of
+ * the last k_descend_half wrote with debug key 103 bit 15 set (tools/exp_wave_times.py) */
+int cd_debug_wave_times(cd_ctx *c, uint32_t *out, uint32_t nwaves)
+{
+    if (!c || !out || nwaves > c->tb[0].defer_cap) return CD_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->tb[0].d_defer, sizeof(uint32_t) * 2 * nwaves, hipMemcpyDeviceToHost));
+    return CD_OK;
+}
+#endif
+
 int cd_get_stats(cd_ctx *c, cd_stats *out) { if (!c || !out) return CD_ERR_ARG; *out = c->stats; return CD_OK; }
 int cd_num_triangles(cd_ctx *c, uint32_t *nt) { if (!c || !nt) return CD_ERR_ARG; *nt = c->nt; return CD_OK; }
 
@@ -1210,6 +1256,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (key == CD_OPT_SORT_FULL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->sort_mode = value == 0 ? 0 : (value == 1 ? 3 : 2); return CD_OK; }
     if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }
     if (key == CD_OPT_GRAPH) { c->graph_opt = value != 0; if (!c->graph_opt) graph_drop(c); return CD_OK; }
+    if (key == CD_OPT_POLL) { c->poll_opt = value != 0; return CD_OK; }
     if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
     if (key == 102) { c->dbg_no_shared_path = (uint32_t)value; return CD_OK; }
     if (key == 103) { c->dbg_diag = (uint32_t)value; return CD_OK; }

@@ -1166,6 +1166,41 @@ def test_pinned_host_pair_buffer_receives_the_pairs_directly():
             assert np.isin(got, want).all() and len(np.unique(got)) == len(got)
 
 
+def test_polled_completion_gives_what_the_stream_synchronise_gives():
+    """CD_OPT_POLL (default on, effective when no time stamp is pending): the host reads the end of a step off the sequence word the
+    report kernel stores last, instead of synchronising the stream.  Same pairs, counters and stats either way -- through a pinned
+    and an ordinary buffer, over many back-to-back steps (every 64th synchronises anyway), and on the comb whose step needs a deep
+    pass, i.e. TWO reports in one step."""
+    verts, vidx = synth.cloth_pair(120)
+    r = oracle.pipeline(verts, vidx)
+    want = oracle.pair_set(r["pairs"])
+    with mi355cd.CollisionDetector(verts, vidx) as cd, mi355cd.HostPairs(1 << 16) as hp:
+        cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+        plain = np.empty((1 << 16, 2), dtype=np.uint32)
+        for poll in (1, 0, 1):
+            cd.set_option(mi355cd.CD_OPT_POLL, poll)
+            for it in range(70 if poll else 3):
+                buf = hp.array if it % 2 == 0 else plain
+                buf[:] = 0xffffffff
+                n, rc = cd.self_collide_into(buf)
+                assert rc == 0 and n == len(want) and cd.fast_stats.pairs_tested == r["stats"].pairs_tested, (poll, it)
+                assert np.array_equal(oracle.pair_set(buf[:n]), want), (poll, it)
+        st = cd.stats()
+        assert st.pairs_tested == r["stats"].pairs_tested and st.n_pairs == len(want) and st.ms_descend_clock > 0
+    off = np.zeros(3); span = np.full(3, 1048576.0)
+    verts, vidx = _comb([1 << (59 - k) for k in range(60)], big_first=True)
+    r = oracle.pipeline(verts, vidx, off=off, span=span)
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, off, span)
+        cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+        for it in range(3):
+            pairs, n, rc = cd.self_collide()
+            st = cd.stats()
+            assert st.stack_overflows > 0 and st.traverse_launches == 4
+            assert n == r["stats"].n_pairs > 0 and st.pairs_tested == r["stats"].pairs_tested
+            assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+
+
 def test_multi_step_box_of_the_triangles_ignores_unreferenced_vertices():
     """The box a rank publishes is the box of its TRIANGLES.  When every vertex belongs to a triangle the step takes it from the
     vertices in one streaming launch (k_vertex_box); vertices no triangle uses -- here far outside, so that they would blow the box
