@@ -58,6 +58,9 @@ __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__re
                                                            unsigned long long seq)
 {
     const unsigned long long np = st->n_pairs;
+#ifdef REPORT_NO_ORDER                                                   // (negative control of tools/poll_stress.py: the word goes out FIRST -- the stress must see pairs missing)
+    if (seq != 0ull && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { out->n_pairs = np; __threadfence_system(); __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+#endif
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         const int lane = threadIdx.x;                                   // NSHARD == 64: lane = shard
         const CtrShard sh = st->shard[lane];
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__re
     for (unsigned long long i = (unsigned long long)blockIdx.x * REPORT_THREADS + threadIdx.x; i < quads; i += (unsigned long long)gridDim.x * REPORT_THREADS) dst[i] = src[i];
     if ((take & 1ull) && blockIdx.x == 0 && threadIdx.x == 64) reinterpret_cast<uint2 *>(pairs_out)[take - 1] = reinterpret_cast<const uint2 *>(pairs)[take - 1];
     if (seq == 0ull) return;                                            // (uniform over the grid)
-    __threadfence_system();                                             // this thread's host writes
+    __threadfence_system();                                             // this thread's host writes (a fence orders the calling thread's stores: EVERY thread fences)
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t old = atomicAdd(const_cast<uint32_t *>(&st->report_arrive), 1u);
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
 }
 
 // ====================================================================================================
-// Variant E (default since round 3): the half traversal with a WORKGROUP-shared frontier for the descent.
+// Variant E (CD_OPT_TRAVERSAL 4; NOT the default -- measured slower than variant D, see the end of this comment): the half traversal with a WORKGROUP-shared frontier for the descent.
 //   Phases 0 / 1a / 1b are variant D's, wave by wave (query box out of the records; right-sibling chain walked bottom-up:
 //   in-wave hops over registers, then the shared chain over scalar loads).  What changes is phase 2.  In variant D a lane
 //   descends the sibling subtrees ITS query hit, depth first over a private LDS stack: 2.8 node visits per query, but a
@@ -805,6 +808,9 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
 //   words (level L is counted in cnt[L % 3], filled during level L - 1, cleared during level L + 1), so no wave can read a
 //   count another wave is already adding to.  A frontier that outgrows the ring (dense contact) overflows, item by item, into
 //   the deferred list of the deep pass, as a full private stack did.
+//   MEASURED (profiles/r03_experiments/variant4_workgroup_frontier_ab.log): 86 us against variant D's 62 us with stage events on
+//   (1 M cloth) -- the steps are fewer, but every level is a workgroup barrier and an LDS round trip of the items, and the
+//   levels of a workgroup are as many as its deepest query needs.  Kept as a selectable variant with full parity coverage.
 // ====================================================================================================
 #ifndef WGF_WAVES
 #define WGF_WAVES 4

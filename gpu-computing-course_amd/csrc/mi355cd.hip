@@ -43,6 +43,8 @@ struct TravBuf {
     TravState *d_state = nullptr; bool state_owned = false;                // [0]: inside the context's scratch block (zeroed by the fused memset)
     uint32_t *d_pairs = nullptr; uint64_t pairs_cap = 0;                   // d_pairs points sizeof(Report) bytes into its allocation: [Report][pairs]
     char *h_report = nullptr;                                              // pinned: Report + SPEC_PAIRS pairs, target of the read-back
+    uint32_t synced_reports = 0;                                           // reports into h_report that ended in a stream synchronise (polled completion waits for POLL_WARM of them)
+    const void *direct_ptr = nullptr; uint32_t synced_direct = 0;          // the same for the caller's pinned pair buffer last written directly
     uint2 *d_defer = nullptr; uint32_t defer_cap = 0;
     Candidates *d_cand = nullptr; uint64_t cand_cap = 0;
     int32_t *d_deep = nullptr; uint64_t deep_items = 0;
@@ -111,6 +113,10 @@ struct cd_ctx {
     bool poll_opt = true;
     unsigned long long report_seq = 0;      // last sequence number handed to a k_report
     uint32_t polled_steps = 0, poll_fallbacks = 0;
+    // debug key 104 (tools/poll_stress.py): the pair area the report kernel writes is filled with 0xff before every step and scanned the moment the
+    // sequence word is seen -- a pair that is still 0xff then was overtaken by the word (poll_stale counts such steps; debug key 105 returns the count)
+    bool dbg_poll_check = false;
+    uint32_t poll_stale = 0;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
     struct GraphKey { uint64_t cap, spec_n; int sort_mode, variant, frame_mode; uint32_t nt, exact_blocks, dbg; const void *p_pairs, *p_cand, *p_defer, *p_report; uint64_t cand_cap; uint32_t defer_cap, pad; } graph_key = {};   // (no padding bytes: compared with memcmp)
     struct GraphPost { bool leaves_filled, leaf_records_filled, hierarchy_valid, internal_boxes_valid, last_tree_fused, events_ride, scratch_clean; uint32_t sort_passes; } graph_post = {};
@@ -468,7 +474,9 @@ int ensure_report(TravBuf &tb)
 {
     if (!tb.h_report) {
         HIPCHK(hipHostMalloc(&tb.h_report, sizeof(Report) + sizeof(uint32_t) * 2 * SPEC_PAIRS, hipHostMallocDefault));
-        std::memset(tb.h_report, 0, sizeof(Report));                       // (Report::seq: no stale sequence number)
+#ifndef REPORT_AREA_NOT_ZEROED                                            // (negative control: what a recycled report area does to a fresh context's first polled steps)
+        std::memset(tb.h_report, 0, sizeof(Report));                       // (Report::seq: pinned memory is recycled by the allocator -- no stale sequence number)
+#endif
     }
     return 0;
 }
@@ -487,7 +495,15 @@ int enqueue_report(cd_ctx *c, TravBuf &tb, bool want_pairs, uint64_t &spec_n, ui
 // stream's events (the caller checks: no stage events, no time stamps).  A step that takes longer than the spin budget, or never
 // reports (a faulted kernel), ends in the ordinary stream synchronise, which also returns the error.  Every 64th polled step
 // synchronises the stream as well, so that the runtime retires what it keeps per launch.
-bool poll_allowed(const cd_ctx *c) { return c->poll_opt && !c->stage_events && c->stamp_mask == 0; }
+// The first POLL_WARM reports into a report area (and into a caller's pinned buffer) end in a stream synchronise whatever the option says:
+// the device's first stores to host pages it has never written go through address translation, and only the stream's completion signal is
+// known to wait for that.
+constexpr uint32_t POLL_WARM = 2;
+bool poll_allowed(const cd_ctx *c, TravBuf &tb, const void *direct)
+{
+    if (direct != tb.direct_ptr) { tb.direct_ptr = direct; tb.synced_direct = 0; }
+    return c->poll_opt && !c->stage_events && c->stamp_mask == 0 && tb.synced_reports >= POLL_WARM && (!direct || tb.synced_direct >= POLL_WARM);
+}
 int wait_report(cd_ctx *c, TravBuf &tb, unsigned long long seq)
 {
     if (seq != 0ull) {
@@ -520,10 +536,26 @@ void parse_report(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs,
 }
 int read_state(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs = nullptr, uint64_t spec_n = 0, bool direct = false)
 {
-    const unsigned long long seq = poll_allowed(c) ? ++c->report_seq : 0ull;
+    if (ensure_report(tb)) return CD_ERR_ARG;
+    const unsigned long long seq = poll_allowed(c, tb, direct ? spec_pairs : nullptr) ? ++c->report_seq : 0ull;
+    uint32_t *area = nullptr;
+    if (c->dbg_poll_check && seq && spec_pairs && spec_n) {
+        if (ensure_report(tb)) return CD_ERR_ARG;
+        area = direct ? spec_pairs : reinterpret_cast<uint32_t *>(tb.h_report + sizeof(Report));
+        std::memset(area, 0xff, sizeof(uint32_t) * 2 * (spec_n < SPEC_PAIRS ? spec_n : SPEC_PAIRS));
+    }
     int rc = enqueue_report(c, tb, spec_pairs != nullptr, spec_n, direct ? spec_pairs : nullptr, seq);
     if (rc) return rc;
+    const uint32_t fb0 = c->poll_fallbacks;
     if ((rc = wait_report(c, tb, seq))) return rc;
+    if (seq == 0ull) { ++tb.synced_reports; if (direct) ++tb.synced_direct; }
+    if (area && c->poll_fallbacks == fb0) {
+        const Report &r = *reinterpret_cast<const Report *>(tb.h_report);
+        const uint64_t take = r.n_pairs < spec_n ? r.n_pairs : spec_n;
+        bool stale = false;
+        for (uint64_t i = 0; i < 2 * take; ++i) stale |= reinterpret_cast<volatile uint32_t *>(area)[i] == 0xffffffffu;
+        if (stale) ++c->poll_stale;
+    }
     parse_report(c, tb, h, direct ? nullptr : spec_pairs, spec_n);          // (direct: the pairs are already where the caller wants them)
     return 0;
 }
@@ -1257,6 +1289,9 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }
     if (key == CD_OPT_GRAPH) { c->graph_opt = value != 0; if (!c->graph_opt) graph_drop(c); return CD_OK; }
     if (key == CD_OPT_POLL) { c->poll_opt = value != 0; return CD_OK; }
+    if (key == 104) { c->dbg_poll_check = value != 0; return CD_OK; }
+    if (key == 105) return (int)c->poll_stale;                            // (debug: a count, not a status)
+    if (key == 106) return (int)c->poll_fallbacks;
     if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
     if (key == 102) { c->dbg_no_shared_path = (uint32_t)value; return CD_OK; }
     if (key == 103) { c->dbg_diag = (uint32_t)value; return CD_OK; }

@@ -196,7 +196,8 @@ enum {
                                    /*    Default 0: measured equal to the stream path within noise -- the host is ahead of the GPU either way */
     CD_OPT_POLL             = 6,   /* 1 (default): with no time stamp pending (CD_OPT_STAGE_TIMING 0 and CD_OPT_KERNEL_STAMPS 0) a step's end is read off a   */
                                    /*    sequence word the report kernel stores last into pinned host memory (the host spins on its own memory; after 20 ms,   */
-                                   /*    and every 64th step anyway, it synchronises the stream); 0: always hipStreamSynchronize                             */
+                                   /*    and every 64th step anyway, it synchronises the stream; so do the first two steps into a report area or a pinned    */
+                                   /*    pair buffer the device has not written before); 0: always hipStreamSynchronize                                      */
     CD_OPT_QUERIES_PER_WAVE = 1    /* variant 1: queries one wave works through with dynamic lane refill (x64)         */
 };
 int cd_set_option(cd_ctx *ctx, int key, int64_t value);

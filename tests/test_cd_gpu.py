@@ -1201,6 +1201,26 @@ def test_polled_completion_gives_what_the_stream_synchronise_gives():
             assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
 
 
+def test_polled_completion_never_sees_the_word_before_the_pairs():
+    """The hazard of a polled completion: the sequence word overtaking pairs still on their way to host memory.  Debug key 104 makes the
+    library fill the pair area with 0xff before every step and scan it the moment the word is seen (key 105: steps with a pair missing;
+    tools/poll_stress.py runs this for 20 000 steps a mesh, with the host link loaded, and has a negative control build that posts the
+    word first -- which this scan catches on 96 % of the steps).  A fresh context each, on the mesh (4 948 pairs) round 2's attempt at this
+    failed on."""
+    for rep in range(3):
+        for verts, vidx in (synth.cloth_pair(122), synth.soup(60_000, 0.08, 21)):        # 4 948 pairs; ~29 k pairs (nearly all the report kernel posts)
+            with mi355cd.CollisionDetector(verts, vidx) as cd, mi355cd.HostPairs(1 << 17) as hp:
+                plain = np.empty((1 << 17, 2), dtype=np.uint32)
+                cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0); cd.set_option(104, 1)
+                n0, rc = cd.self_collide_into(plain)                                      # (the first two reports into an area end in a stream synchronise: never-written host pages)
+                want = oracle.pair_set(plain[:n0].copy())
+                for it in range(150):
+                    buf = plain if it % 2 == 0 else hp.array
+                    n, rc = cd.self_collide_into(buf)
+                    assert rc == 0 and n == n0 and np.array_equal(oracle.pair_set(buf[:n]), want), (rep, it)
+                assert cd.lib.cd_set_option(cd._ctx, 105, 0) == 0 and cd.lib.cd_set_option(cd._ctx, 106, 0) == 0
+
+
 def test_multi_step_box_of_the_triangles_ignores_unreferenced_vertices():
     """The box a rank publishes is the box of its TRIANGLES.  When every vertex belongs to a triangle the step takes it from the
     vertices in one streaming launch (k_vertex_box); vertices no triangle uses -- here far outside, so that they would blow the box
