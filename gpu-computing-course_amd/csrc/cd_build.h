@@ -142,6 +142,9 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
             for (uint32_t x = threadIdx.x; x < zp.nw1; x += REFIT_BLK) zp.w1[x] = 0u;
         }
     }
+#if defined(BLK_ABLATE) && BLK_ABLATE == 0
+    return;
+#endif
     __shared__ float t[2 * REFIT_BLK][6];           // 24 KB
     // the sparse table of the deltas (10 KB) is dead once every node knows its range and split; the nodes' own boxes
     // (12 KB) then take its place
@@ -183,10 +186,17 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
         const unsigned long long em = __builtin_amdgcn_ballot_w64(exact);
         if ((tid & 63) == 0) lexact[tid >> 6] = em;
     }
+#if defined(BLK_ABLATE) && BLK_ABLATE == 1
+    return;
+#endif
     // the 9 levels above the leaves and the 9 upper levels of the sparse table, one of each per barrier;
     // global index of local node k at depth dd: ((nbp2 + b) << dd) + (k - 2^dd)
     for (int dd = REFIT_LOG - 1; dd >= 0; --dd) {
+#ifdef BLK_NO_LEVEL_BARRIERS                                                // TIMING EXPERIMENT ONLY (wrong trees)
+        if (dd == REFIT_LOG - 1)
+#endif
         __syncthreads();
+#ifndef BLK_NO_TABLE
         {
             const int k = REFIT_LOG - dd;
             for (int x = tid; x < DL_STRIDE; x += REFIT_BLK) {
@@ -195,13 +205,16 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
                 dt[k][x] = (w >> DK_SHIFT) < (u >> DK_SHIFT) ? (DKey)(w + (1 << (k - 1))) : u;     // a tie keeps the left one
             }
         }
+#endif
         const int cnt = 1 << dd;
+#ifndef BLK_NO_TREE
         if (tid < cnt) {
             const int k = cnt + tid;
             const B32 m = b32_merge(b32_load(t[2 * k]), b32_load(t[2 * k + 1]));
             b32_store(t[k], m);
             if (REFIT_LOG - dd >= seg_min) b32_store(seg32 + 6 * ((((size_t)nbp2 + b) << dd) + tid), m);
         }
+#endif
     }
     __syncthreads();
     // FP64 box of the block's leaves: rounding is monotone, so the leaf with the smallest FP64 x1 is among the leaves whose
@@ -215,6 +228,9 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
         if (m32.lz == tot.lz) atomicMin(&acc[4], f64_ordered(mine.z1));
         if (m32.hz == tot.hz) atomicMax(&acc[5], f64_ordered(mine.z2));
     }
+#if defined(BLK_ABLATE) && BLK_ABLATE == 2
+    return;
+#endif
     const int i = j;                                                       // internal node with the same index
     int first = 0, last = 0, split = 0; bool have = false, cross = false;
     if (i < n - 1) {
@@ -248,9 +264,16 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
             else { const uint32_t g = atomicAdd(cross_count, 1u); if (g < cross_cap) cross_list[g] = i; }
         }
     }
+#if defined(BLK_ABLATE) && BLK_ABLATE == 3
+    return;
+#endif
     __syncthreads();                                                        // every node has its range and split: the table is dead
     b32_store(nb[tid], seg_query32(t, have ? first - b0 : 1, have ? last - b0 : 0));   // the node's own box (an empty query for the others)
     __syncthreads();                                                        // nb[], lsplit[], acc[], lcount of the whole block
+#if defined(BLK_ABLATE) && BLK_ABLATE == 4
+    if (nb[tid][0] == 123.f) split_of[tid] = 1;
+    return;
+#endif
     if (have) {
         // children (bvh.cuh:174-195): the left child is leaf `split` or internal node `split`, the right one leaf / node split + 1
         const bool leafL = split == first, leafR = split + 1 == last;
@@ -405,11 +428,12 @@ __global__ __launch_bounds__(256) void k_cross_records(int n, const NodeMeta *__
 // the two range queries of each of its four nodes as k_cross_records does, all their loads in flight together.
 // Workgroup 0 also folds the FP64 block boxes (in order) into the box of all leaves, boxes[0].
 // ====================================================================================================
-// The levels from two above the blocks upwards as a private copy in LDS (top[6 * k]: heap node k in [1, nbp2 / 2)), folded
-// from the blocks' fp32 boxes: a thread folds the four blocks under one or two nodes of the lowest stored level, the
-// lanes of a wave fold with shuffles, the four wave results meet in LDS -- two barriers instead of one per level.  (The
-// level directly above the blocks is not stored: a piece of it is two block boxes away, and LDS is what limits how many
-// workgroups, i.e. how many searches, a CU holds.)
+// The levels from THREE above the blocks upwards as a private copy in LDS (top[6 * k]: heap node k in [1, nbp2 / 4)), folded
+// from the blocks' fp32 boxes: a thread folds the eight blocks under one node of the lowest stored level, the lanes of a
+// wave fold with shuffles, the four wave results meet in LDS -- two barriers instead of one per level.  (The two levels
+// directly above the blocks are not stored: a piece of them is two / four block boxes away, and LDS is what limits how many
+// workgroups, i.e. how many searches, a CU holds -- with 24 KB a workgroup (levels from two above the blocks) a CU held six, the
+// registers allow seven, and the kernel's ~1 600 workgroups are ONE round only at seven.)
 __device__ __forceinline__ B32 block_box32(const float *__restrict__ seg32, int nbp2, int nblocks, int b)
 {
     const B32 v = b32_load(seg32 + 6 * ((size_t)nbp2 + (b < nblocks ? b : 0)));     // (an unconditional load: several of these go out together)
@@ -418,27 +442,27 @@ __device__ __forceinline__ B32 block_box32(const float *__restrict__ seg32, int 
 __device__ __forceinline__ void top32_to_lds(float *top, const float *__restrict__ seg32, int nbp2, int nblocks)
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int M = nbp2 >> 2;                                                // nodes of the lowest stored level, M .. 2 M - 1
+    const int M = nbp2 >> 3;                                                // nodes of the lowest stored level, M .. 2 M - 1 (<= 256: nbp2 <= 2048)
     if (M >= 1) {                                                           // (workgroup-uniform)
-        const int T = M < 256 ? M : 256;                                    // threads that own nodes
-        const int per = M / T;                                              // 1 or 2 (nbp2 <= 2048)
+        const int T = M;                                                    // threads that own a node
         B32 x = b32_identity();
         if (tid < T) {
-            for (int u = 0; u < per; ++u) {
-                const int node = M + tid * per + u, b = 4 * (tid * per + u);
-                // four consecutive block boxes are 96 contiguous bytes, 16-byte aligned (nbp2 is a multiple of 4 here): six quads
-                const float4 *q = reinterpret_cast<const float4 *>(seg32 + 6 * ((size_t)nbp2 + b));
-                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
-                const B32 id = b32_identity();
-                const B32 b0 = b < nblocks ? B32{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y} : id, b1 = b + 1 < nblocks ? B32{q1.z, q1.w, q2.x, q2.y, q2.z, q2.w} : id;
-                const B32 b2 = b + 2 < nblocks ? B32{q3.x, q3.y, q3.z, q3.w, q4.x, q4.y} : id, b3 = b + 3 < nblocks ? B32{q4.z, q4.w, q5.x, q5.y, q5.z, q5.w} : id;
-                const B32 v = b32_merge(b32_merge(b0, b1), b32_merge(b2, b3));
-                b32_store(top + 6 * node, v);
-                x = b32_merge(x, v);
+            const int b = 8 * tid;
+            // eight consecutive block boxes are 192 contiguous bytes, 16-byte aligned (nbp2 is a multiple of 8 here): twelve quads
+            const float4 *q = reinterpret_cast<const float4 *>(seg32 + 6 * ((size_t)nbp2 + b));
+            float4 v[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) v[u] = q[u];
+            const B32 id = b32_identity();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                                   // blocks b + 2u, b + 2u + 1 out of the quads 3u .. 3u + 2
+                const float4 q0 = v[3 * u], q1 = v[3 * u + 1], q2 = v[3 * u + 2];
+                const B32 b0 = b + 2 * u < nblocks ? B32{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y} : id, b1 = b + 2 * u + 1 < nblocks ? B32{q1.z, q1.w, q2.x, q2.y, q2.z, q2.w} : id;
+                x = b32_merge(x, b32_merge(b0, b1));
             }
-            if (per == 2) b32_store(top + 6 * ((M >> 1) + tid), x);
+            b32_store(top + 6 * (M + tid), x);
         }
-        const int kt = M / per + tid;                                       // the node x is the box of
+        const int kt = M + tid;                                             // the node x is the box of
         // across lanes: after the step with stride s, lanes that are multiples of 2s hold node kt / (2s)
         for (int s = 1; s < 64 && s < T; s <<= 1) {
             x = b32_merge(x, b32_shfl_down(x, s));
@@ -483,16 +507,25 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
                                                      NodeRec32 *__restrict__ recs32, const int32_t *__restrict__ split_of, int32_t *__restrict__ root_name,
                                                      const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap)
 {
-    extern __shared__ float top[];                                          // [max(nbp2 / 2, 1)][6]: heap nodes [1, nbp2 / 2)
+    extern __shared__ float top[];                                          // [max(nbp2 / 4, 1)][6]: heap nodes [1, nbp2 / 4)
     const int tid = threadIdx.x, lane = tid & 63, g = lane / XG, gl = lane % XG;
     // (a workgroup of its own, the last one of the grid: the fold is a chain of dependent loads, short against what the
     //  others do, long when it comes on top of it)
+#ifdef CROSS_ABLATE_ROOT
+    if (blockIdx.x == gridDim.x - 1) return;
+#endif
     if (blockIdx.x == gridDim.x - 1) { root_box_fold(seg, nbp2, nblocks, boxes); return; }   // (workgroup-uniform)
+#ifdef CROSS_ABLATE_TOP
+    return;
+#endif
     constexpr int PER_WAVE = 64 / XG, PER_BLOCK = 256 / XG;
     const uint32_t total = min(*dense_total, dense_cap);
     const long long P = (long long)nbp2 * REFIT_BLK;
     // (the upper levels first: while the waves of a workgroup are still in step, so that its two barriers cost nothing)
     top32_to_lds(top, seg32, nbp2, nblocks);
+#ifdef CROSS_ABLATE_ALL
+    return;                                                                 // TIMING EXPERIMENT ONLY: launch + the upper levels into LDS
+#endif
     for (uint32_t wbase = blockIdx.x * PER_BLOCK + (tid >> 6) * PER_WAVE; wbase < total; wbase += (gridDim.x - 1) * PER_BLOCK) {   // (wbase is wave-uniform)
         // ---- range and split, as k_cross_meta
         const uint32_t kq = wbase + g;
@@ -502,8 +535,10 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
             // (a dependent load costs a round trip even when it hits: values that are already in registers are not fetched again)
             auto delta_v = [](uint64_t ka, int ia, uint64_t kb, int ib) { const uint64_t x = ka ^ kb; return x ? __clzll((long long)x) : 64 + __clz((int)((uint32_t)ia ^ (uint32_t)ib)); };
             const int i = live ? dense[kq] : 0;
-            const uint64_t ki = keys[i];
-            const int dnext = delta_k(keys, n, i, ki, i + 1), dprev = delta_k(keys, n, i, ki, i - 1);
+            // (the node's key and its two neighbours in ONE round trip: unconditional loads at clamped positions -- a load inside a
+            //  branch is waited for inside the branch, and three branches are three round trips)
+            const uint64_t ki = keys[i], kprev = keys[i > 0 ? i - 1 : 0], knext = keys[i + 1 < n ? i + 1 : n - 1];
+            const int dnext = i + 1 < n ? delta_v(ki, i, knext, i + 1) : -1, dprev = i > 0 ? delta_v(ki, i, kprev, i - 1) : -1;
             const int d = (dnext - dprev) >= 0 ? 1 : -1;
             const int delta_min = d > 0 ? dprev : dnext;                    // delta(i, i - d)
             int mlen = 0;
@@ -535,6 +570,10 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
                 }
             }
         }
+#ifdef CROSS_ABLATE_PIECES                                                 // TIMING EXPERIMENT ONLY (wrong records): the searches alone
+        if (live && gl == 0) reinterpret_cast<uint32_t *>(const_cast<float4 *>(rec_left(recs32, n, (uint32_t)split)))[0] = (uint32_t)first + (uint32_t)last;
+        continue;
+#endif
         // (what the record's owner has to fetch besides the boxes: requested before the pieces, used after them)
         const bool leafL = split == first, leafR = split + 1 == last;
         // a child that is itself a cross node (its range leaves its 512-leaf block: exactly k_build_block's test) links itself
@@ -544,53 +583,58 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
             if (leafL) { if (qbox32[first].flags & LB_EXACT) fl |= REC_L_EXACT; } else if (!crossL) linkL = split_of[split];
             if (leafR) { if (qbox32[last].flags & LB_EXACT) fl |= REC_R_EXACT; } else if (!crossR) linkR = split_of[split + 1];
         }
-        // ---- the records: each group answers the two range queries of its own node.  Lane gl takes the (at most two) pieces
-        // of level gl of either range -- 16 levels cover every range shorter than 65536 leaves, a longer one takes a second
-        // sweep over the levels 16..31 -- so a lane's pieces are all of ONE kind (leaves / a stored level of a block's tree /
-        // two block boxes / the LDS copy of the upper levels): its loads go out together, unconditionally (a piece that
-        // is not taken reads a valid dummy and is dropped), then the 16 lanes fold with DPP row shifts.
+        // ---- the records: each group answers the two range queries of its own node.  A range [l, r] is the union of at most one
+        // left and one right piece per level of the iterative bottom-up query; what a piece is made of depends on its level:
+        //   level 0: one leaf box (qbox32); levels 1 .. 9: one stored node of a block's tree (seg32); level 10 / 11: two / four block
+        //   boxes (the levels directly above the blocks are not stored anywhere); levels >= 12: one node of the LDS copy.
+        // The memory items of a child range are 20 + 4 + 8 = 32, of the node 64: lane gl fetches items gl and gl + 16 of either child
+        // -- four 24-byte loads per lane, all unconditional (an item that is not taken reads a valid dummy and is dropped), ONE round
+        // trip for the whole group.  (Before: a lane per level and a branch per kind of level -- divergent branches run one after
+        // the other, each with its own round trip: three of them on this kernel's critical path.)  The LDS levels keep the lane-per-
+        // level form (16 levels a sweep, a second sweep for ranges of 65536 leaves or more); then the 16 lanes fold with DPP row shifts.
         const int sweeps = __builtin_amdgcn_ballot_w64(live && last - first >= 65535) ? 2 : 1;   // (wave-uniform)
         B32 accL = b32_identity(), accR = b32_identity();
+        auto piece = [&](int h, int p, int side, long long &k) {              // is the side's piece of child h taken at level p, and which heap node is it
+            const int l0 = h ? split + 1 : first, r0 = h ? last : split;
+            const long long lp = ((long long)l0 + P + ((1ll << p) - 1)) >> p;   // l at level p (ceil)
+            const long long rp = ((long long)r0 + P + 1) >> p;              // r at level p (floor), half-open
+            k = side ? rp - 1 : lp;
+            return live && lp < rp && ((side ? rp : lp) & 1);
+        };
         for (int sw = 0; sw < sweeps; ++sw) {
             const int p = gl + 16 * sw;
-            long long kk[4]; bool tk[4];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int l0 = h ? split + 1 : first, r0 = h ? last : split;
-                const long long lp = ((long long)l0 + P + ((1ll << p) - 1)) >> p;   // l at level p (ceil)
-                const long long rp = ((long long)r0 + P + 1) >> p;          // r at level p (floor), half-open
-                const bool any = live && lp < rp;
-                tk[2 * h] = any && (lp & 1); tk[2 * h + 1] = any && (rp & 1);
-                kk[2 * h] = lp; kk[2 * h + 1] = rp - 1;
-            }
-            B32 v[4];
-            if (p > REFIT_LOG + 1) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = tk[u] ? b32_load(top + 6 * (int)kk[u]) : b32_identity();
-            } else if (p == REFIT_LOG + 1) {
+            if (p > REFIT_LOG + 2) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int b = tk[u] ? (int)(2 * kk[u] - nbp2) : 0;
-                    v[u] = b32_merge(block_box32(seg32, nbp2, nblocks, b), block_box32(seg32, nbp2, nblocks, b + 1));
-                }
-            } else if (p >= SEG32_MIN_LEVEL) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = b32_load(seg32 + 6 * (size_t)(tk[u] ? kk[u] : (P >> p)));
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const long long j0 = tk[u] ? (kk[u] << p) - P : 0;
-                    v[u] = b32_identity();
-#pragma unroll
-                    for (int e = 0; e < (1 << (SEG32_MIN_LEVEL > 0 ? SEG32_MIN_LEVEL - 1 : 0)); ++e) {     // (all of a lane's leaf loads go out together)
-                        const long long jj = j0 + e;
-                        const B32 lf = b32_of_leaf(qbox32, (int)(jj < n ? jj : n - 1));
-                        if (e < (1 << p) && jj < n) v[u] = b32_merge(v[u], lf);
-                    }
+                    long long k;
+                    if (piece(u >> 1, p, u & 1, k)) { const B32 v = b32_load(top + 6 * (int)k); if (u < 2) accL = b32_merge(accL, v); else accR = b32_merge(accR, v); }
                 }
             }
+        }
+        {
+            static_assert(SEG32_MIN_LEVEL == 1 && XG == 16, "the item numbering below: levels 1 .. REFIT_LOG of a block's tree are in seg32, 16 lanes a node");
+            B32 it[4]; bool tk[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (tk[u]) { if (u < 2) accL = b32_merge(accL, v[u]); else accR = b32_merge(accR, v[u]); }
+            for (int r = 0; r < 4; ++r) {
+                const int h = r >> 1, t = gl + 16 * (r & 1);                // item t of child h
+                const int p = t < 20 ? (t >> 1) : (t < 24 ? REFIT_LOG + 1 : REFIT_LOG + 2);
+                const int side = t < 20 ? (t & 1) : (t < 24 ? ((t - 20) >> 1) : ((t - 24) >> 2));
+                const int e = t < 20 ? 0 : (t < 24 ? ((t - 20) & 1) : ((t - 24) & 3));
+                long long k;
+                bool take = piece(h, p, side, k);
+                const float *ptr;
+                if (p == 0) ptr = reinterpret_cast<const float *>(qbox32 + (take ? (k - P) : 0));              // (the leaf's fp32 box: the first 24 bytes of its 32)
+                else if (p <= REFIT_LOG) ptr = seg32 + 6 * (size_t)(take ? k : (P >> p));
+                else {
+                    const long long b = take ? ((k << (p - REFIT_LOG)) - nbp2 + e) : 0;
+                    take = take && b < nblocks;                             // (a block past the end: nothing there)
+                    ptr = seg32 + 6 * ((size_t)nbp2 + (take ? b : 0));
+                }
+                tk[r] = take;
+                it[r] = b32_load(ptr);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (tk[r]) { if (r < 2) accL = b32_merge(accL, it[r]); else accR = b32_merge(accR, it[r]); }
         }
         accL = dpp_step32<0x101>(accL); accL = dpp_step32<0x102>(accL); accL = dpp_step32<0x104>(accL); accL = dpp_step32<0x108>(accL);
         accR = dpp_step32<0x101>(accR); accR = dpp_step32<0x102>(accR); accR = dpp_step32<0x104>(accR); accR = dpp_step32<0x108>(accR);

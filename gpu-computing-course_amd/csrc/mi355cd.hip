@@ -346,7 +346,7 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         // (the multi-GPU step's "tree is there" event rides on this kernel's dispatch packet: recorded on its own it is a barrier
         //  packet between the tree and the traversal, ~6 us of idle GPU)
         hipEvent_t done = c->tree_done_event; c->tree_done_event = nullptr;
-        const uint32_t xlds = (uint32_t)(sizeof(float) * 6 * (c->nbp2 >= 2 ? c->nbp2 / 2 : 1));
+        const uint32_t xlds = (uint32_t)(sizeof(float) * 6 * (c->nbp2 >= 4 ? c->nbp2 / 4 : 1));
         if (done)
             hipExtLaunchKernelGGL(k_cross_fused, dim3(xb + 1u /* the last workgroup folds the FP64 box of all leaves */), dim3(256), xlds, s, nullptr, done, 0u,
                                   (const uint64_t *)c->d_keys[0], (int)n, (const double *)c->d_seg, (const float *)c->d_seg32, (int)c->nbp2, nblocks, (const LeafBox32 *)c->d_qbox, c->d_boxes,
