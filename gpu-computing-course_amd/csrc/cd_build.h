@@ -578,11 +578,11 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
         const bool leafL = split == first, leafR = split + 1 == last;
         // a child that is itself a cross node (its range leaves its 512-leaf block: exactly k_build_block's test) links itself
         const bool crossL = !leafL && first / REFIT_BLK != split / REFIT_BLK, crossR = !leafR && (split + 1) / REFIT_BLK != last / REFIT_BLK;
-        uint32_t fl = 0; int32_t linkL = ~split, linkR = ~(split + 1);
-        if (live && gl == 0) {
-            if (leafL) { if (qbox32[first].flags & LB_EXACT) fl |= REC_L_EXACT; } else if (!crossL) linkL = split_of[split];
-            if (leafR) { if (qbox32[last].flags & LB_EXACT) fl |= REC_R_EXACT; } else if (!crossR) linkR = split_of[split + 1];
-        }
+        // (unconditional loads at valid positions, consumed after the pieces: a load whose value decides a branch is waited for on
+        //  the spot -- written as `if (flags & EXACT) ...` these were up to two round trips in front of the pieces')
+        const bool own = live && gl == 0;
+        const uint32_t flagL = qbox32[own && leafL ? first : 0].flags, flagR = qbox32[own && leafR ? last : 0].flags;
+        const int32_t soL = split_of[own && !leafL && !crossL ? split : 0], soR = split_of[own && !leafR && !crossR ? split + 1 : 0];
         // ---- the records: each group answers the two range queries of its own node.  A range [l, r] is the union of at most one
         // left and one right piece per level of the iterative bottom-up query; what a piece is made of depends on its level:
         //   level 0: one leaf box (qbox32); levels 1 .. 9: one stored node of a block's tree (seg32); level 10 / 11: two / four block
@@ -638,7 +638,9 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
         }
         accL = dpp_step32<0x101>(accL); accL = dpp_step32<0x102>(accL); accL = dpp_step32<0x104>(accL); accL = dpp_step32<0x108>(accL);
         accR = dpp_step32<0x101>(accR); accR = dpp_step32<0x102>(accR); accR = dpp_step32<0x104>(accR); accR = dpp_step32<0x108>(accR);
-        if (live && gl == 0) {
+        if (own) {
+            const uint32_t fl = ((leafL && (flagL & LB_EXACT)) ? REC_L_EXACT : 0u) | ((leafR && (flagR & LB_EXACT)) ? REC_R_EXACT : 0u);
+            const int32_t linkL = leafL ? ~split : soL, linkR = leafR ? ~(split + 1) : soR;      // (a cross child writes its own name: the link word is not touched below)
             float4 *pl = const_cast<float4 *>(rec_left(recs32, n, (uint32_t)split)), *pr = const_cast<float4 *>(rec_right(recs32, n, (uint32_t)split));
             pl[0] = make_float4(accL.lx, accL.ly, accL.lz, accL.hx);
             pr[0] = make_float4(accR.lx, accR.ly, accR.lz, accR.hx);
