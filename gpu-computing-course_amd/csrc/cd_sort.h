@@ -292,7 +292,12 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     __shared__ uint32_t s_wruns[LOCAL_WAVES];
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
+#if defined(LS_ABLATE) && LS_ABLATE == 0
+    return;                                              // TIMING EXPERIMENT ONLY (tools/exp_sort_ablation.sh): the kernel up to here
+#endif
     const uint32_t p0 = blockIdx.x * win, p1 = min(p0 + win, n);
+    const uint32_t *khw = reinterpret_cast<const uint32_t *>(keys_in) + 1;      // khw[2 i]: the high word of key i
+    const int hshift = run_shift - 32;                                          // (run_shift >= 44: the run bits are in the high word)
     if (tid == 0) { s_enc[0] = s_enc[1] = 0xffffffffu; }
     __syncthreads();
     // Window ends: the run start NEAREST to p0 and to p1 (a run starts where the top 16 bits change; equal distance:
@@ -302,6 +307,8 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     // First the LOCAL_THREADS positions around p0 and p1 (one per thread: runs of a mesh are a few hundred keys, the nearest
     // start is almost always there, and it is THE nearest if it is); the whole range only for an end that found nothing.
     {
+        // (UNCONDITIONAL loads at clamped positions, of the keys' high words only -- run_shift >= 32 --, selected afterwards: a load in
+        //  one arm of a ?: is a branch around the load with its wait inside, i.e. a round trip per probe instead of one for all four)
         constexpr int NEAR = LOCAL_THREADS / 2;
         uint32_t top[2][2];
 #pragma unroll
@@ -309,14 +316,16 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
             const uint32_t p = e ? p1 : p0;
             const long long q = (long long)p - NEAR + (int)tid;
             const bool live = p != 0 && p < n && q >= 0 && q < (long long)n;
-            top[e][0] = (live && q > 0) ? (uint32_t)(keys_in[q - 1] >> run_shift) : 0xffffffffu;
-            top[e][1] = live ? (uint32_t)(keys_in[q] >> run_shift) : 0xffffffffu;
+            top[e][0] = khw[2 * (size_t)((live && q > 0) ? q - 1 : 0)];
+            top[e][1] = khw[2 * (size_t)(live ? q : 0)];
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const uint32_t p = e ? p1 : p0;
             const long long q = (long long)p - NEAR + (int)tid;
             const bool live = p != 0 && p < n && q >= 0 && q < (long long)n;
+            top[e][0] = (live && q > 0) ? top[e][0] >> hshift : 0xffffffffu;
+            top[e][1] = live ? top[e][1] >> hshift : 0xffffffffu;
             if (live && top[e][0] != top[e][1]) {
                 const uint32_t dist = (uint32_t)(q > (long long)p ? q - p : p - q);
                 atomicMin(&s_enc[e], (dist << 1) | (q > (long long)p ? 1u : 0u));
@@ -335,8 +344,19 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
             for (int u = 0; u < PROBES; ++u) {
                 const long long q = (long long)p - HALF + (u * LOCAL_THREADS + (int)tid);
                 const bool live = (e ? far1 : far0) && q >= 0 && q < (long long)n;
-                top[e][u][0] = (live && q > 0) ? (uint32_t)(keys_in[q - 1] >> run_shift) : 0xffffffffu;    // 0xffffffff: "differs" (q == 0 is a start); run_shift >= 44
-                top[e][u][1] = live ? (uint32_t)(keys_in[q] >> run_shift) : 0xffffffffu;
+                top[e][u][0] = khw[2 * (size_t)((live && q > 0) ? q - 1 : 0)];
+                top[e][u][1] = khw[2 * (size_t)(live ? q : 0)];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t p = e ? p1 : p0;
+#pragma unroll
+            for (int u = 0; u < PROBES; ++u) {
+                const long long q = (long long)p - HALF + (u * LOCAL_THREADS + (int)tid);
+                const bool live = (e ? far1 : far0) && q >= 0 && q < (long long)n;
+                top[e][u][0] = (live && q > 0) ? top[e][u][0] >> hshift : 0xffffffffu;    // 0xffffffff: "differs" (q == 0 is a start); run_shift >= 44
+                top[e][u][1] = live ? top[e][u][1] >> hshift : 0xffffffffu;
             }
         }
 #pragma unroll
@@ -361,6 +381,9 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
         for (uint32_t i = p0 + tid; i < p1; i += LOCAL_THREADS) { const uint32_t t = vals_in[i]; keys_out[i] = keys_in[i]; vals_out[i] = t; emit.store(i, t, emit.load(t)); }
         return;
     }
+#if defined(LS_ABLATE) && LS_ABLATE == 1
+    return;                                              // TIMING EXPERIMENT ONLY (tools/exp_sort_ablation.sh): the kernel up to here
+#endif
     const int lo = p0 == 0 ? 0 : (int)((e0 & 1u) ? p0 + (e0 >> 1) : p0 - (e0 >> 1));
     const int hi = p1 >= n ? (int)n : (int)((e1 & 1u) ? p1 + (e1 >> 1) : p1 - (e1 >> 1));
     const uint32_t cnt = (uint32_t)(hi - lo);            // <= LOCAL_W + LOCAL_LIMIT - 1
@@ -384,15 +407,24 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     {
         const int low_bits = run_shift - 32;             // 12 or 16
         const unsigned long long le_mask = lt_mask | (1ull << lane);
-        uint32_t before = 0, ridx[LOCAL_ITEMS];
+        // Every item's high key word in ONE round trip: unconditional loads at clamped positions, all issued before any is used (the
+        // key BEFORE an item is the neighbour lane's, the item round before for lane 0, one more load for the wave's first item).
+        uint32_t before = 0, ridx[LOCAL_ITEMS], hw[LOCAL_ITEMS];
+        const uint32_t prev0 = khw[2 * (size_t)(lo + (base_w > 0 ? (int)min(base_w, cnt) - 1 : 0))];
 #pragma unroll
         for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit) {
             const uint32_t j = base_w + it * 64 + lane;
-            const uint64_t kj = j < cnt ? keys_in[lo + j] : 0ull, kp = (j < cnt && j > 0) ? keys_in[lo + j - 1] : kj;
-            const unsigned long long m = __ballot(j < cnt && (kj >> run_shift) != (kp >> run_shift));
+            hw[it] = khw[2 * (size_t)(lo + (int)(j < cnt ? j : cnt - 1))];
+        }
+#pragma unroll
+        for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit) {
+            const uint32_t j = base_w + it * 64 + lane;
+            const uint32_t edge = it ? (uint32_t)__builtin_amdgcn_readlane((int)hw[it ? it - 1 : 0], 63) : prev0;      // what lane 0 compares with
+            const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)hw[it], 0x138, 0xf, 0xf, false);   // wave_shr:1
+            const unsigned long long m = __ballot(j < cnt && j > 0 && (hw[it] >> hshift) != (hp >> hshift));
             ridx[it] = before + (uint32_t)__popcll(m & le_mask);
             before += (uint32_t)__popcll(m);
-            kh[it] = (uint32_t)(kj >> 32) & ((1u << low_bits) - 1u);
+            kh[it] = hw[it] & ((1u << low_bits) - 1u);
             ix[it] = j;
         }
         if (lane == 0) s_wruns[w] = before;
@@ -403,6 +435,9 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
         for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit)
             kh[it] = base_w + it * 64 + lane < cnt ? (((woff + ridx[it]) << low_bits) | kh[it]) : ~0u;
     }
+#if defined(LS_ABLATE) && LS_ABLATE == 2
+    return;                                              // TIMING EXPERIMENT ONLY (tools/exp_sort_ablation.sh): the kernel up to here
+#endif
     // which digits vary at all inside the window (typically not the top one): one AND / OR reduction for all four
     if (tid == 0) { s_and = 0xffffffffu; s_or = 0u; }
     __syncthreads();
@@ -478,22 +513,36 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
         }
         __syncthreads();                                                   // sitem / wcnt are rewritten by the next pass
     }
+#if defined(LS_ABLATE) && LS_ABLATE == 3
+    return;                                              // TIMING EXPERIMENT ONLY (tools/exp_sort_ablation.sh): the kernel up to here
+#endif
     // The window is now in stable order by the high key half.  The fix-up hop (below: every key placed inside its run of
     // equal high halves by its low half) needs only the run's other keys, and a run lies inside ONE window (equal high
     // halves have equal top bits): whole keys go to LDS, every item finds its final position there, and the kernel
     // writes keys, permutation and (emit) the leaf of that position -- no k_sort_fixup_fill launch after it.
-    uint32_t tv[LOCAL_ITEMS];
+    // (all gathers issued -- unconditionally, a lane without an item fetches the window's first key -- before the first is used)
+    // (into FRESH registers: a value that was defined before the `if` needs a copy inside it -- which waits for the load)
+    uint32_t tv[LOCAL_ITEMS], lowk[LOCAL_ITEMS], high[LOCAL_ITEMS];
+#pragma unroll
+    for (int it = 0; it < LOCAL_ITEMS; ++it) tv[it] = 0u;    // (a valid value everywhere: what emit fetches below is fetched unconditionally)
 #pragma unroll
     for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit) {
         const uint32_t j = base_w + it * 64 + lane;
-        if (j < cnt) {
-            const uint64_t k = keys_in[lo + ix[it]];
-            tv[it] = vals_in[lo + ix[it]];
-            kh[it] = (uint32_t)(k >> 32);                // (from here on the true high half)
-            sitem[j] = make_uint2((uint32_t)k, kh[it]);
-        }
+        const size_t src = (size_t)lo + (j < cnt ? ix[it] : 0u);
+        const uint2 k = reinterpret_cast<const uint2 *>(keys_in)[src];
+        tv[it] = vals_in[src];
+        high[it] = k.y;                                  // the true high half (kh[] held the composite)
+        lowk[it] = k.x;
+    }
+#pragma unroll
+    for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit) {
+        const uint32_t j = base_w + it * 64 + lane;
+        if (j < cnt) sitem[j] = make_uint2(lowk[it], high[it]);
     }
     __syncthreads();
+#if defined(LS_ABLATE) && LS_ABLATE == 4
+    return;                                              // TIMING EXPERIMENT ONLY (tools/exp_sort_ablation.sh): the kernel up to here
+#endif
     // (in chunks of 5 items -- a window of the nominal size has 4 per lane: what emit gathers for an item is requested
     //  before the LDS search of the chunk, and lands while it runs)
     constexpr int CH = LOCAL_ITEMS / 2;
@@ -501,17 +550,17 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     for (int c0 = 0; c0 < LOCAL_ITEMS; c0 += CH) if (c0 < nit) {
         typename Emit::Payload pl[CH];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) if (c0 + u < nit && base_w + (c0 + u) * 64 + lane < cnt) pl[u] = emit.load(tv[c0 + u]);
+        for (int u = 0; u < CH; ++u) pl[u] = emit.load(tv[c0 + u]);      // (unconditional, one basic block: all of a chunk's gathers go out together; a lane or round without an item fetches a valid dummy)
 #pragma unroll
         for (int u = 0; u < CH; ++u) if (c0 + u < nit) {
             const int it = c0 + u;
             const uint32_t j = base_w + it * 64 + lane;
             if (j < cnt) {
-                const uint32_t low = sitem[j].x;
+                const uint32_t low = lowk[it];
                 uint32_t pos;
                 // run too long: flag it (the host redoes the sort with 8 passes) but still emit a valid permutation and valid leaves
-                if (!fixup_position_lds(sitem, cnt, j, low, kh[it], pos)) { atomicExch(overflow, 1u); pos = j; }
-                keys_out[lo + pos] = ((uint64_t)kh[it] << 32) | low; vals_out[lo + pos] = tv[it];
+                if (!fixup_position_lds(sitem, cnt, j, low, high[it], pos)) { atomicExch(overflow, 1u); pos = j; }
+                keys_out[lo + pos] = ((uint64_t)high[it] << 32) | low; vals_out[lo + pos] = tv[it];
                 emit.store(lo + pos, tv[it], pl[u]);
             }
         }
