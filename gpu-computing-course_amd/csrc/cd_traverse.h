@@ -119,6 +119,15 @@ struct QuerySrc {
 // A fused call enqueues the traversal before the host has seen the sort's flags; keys that are not sorted can give
 // child links with cycles, and a descent over them would never end.  Every traversal kernel starts with this
 // (wave-uniform, 9 scalar loads); the host reads the same flags afterwards and redoes the whole step.
+// The same as a value (0: fine): a kernel that has in-bounds work to request first reads the flags at its start and looks at them later --
+// their round trip then runs beside that work instead of in front of it (k_descend_half).
+__device__ __forceinline__ uint32_t sort_flags_or(const QuerySrc &src)
+{
+    uint32_t any = 0;                                   // (no null test: every QuerySrc is built with the context's flag words, and a branch around the loads would wait for them inside it)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) any |= src.sort_flags[i];
+    return any;
+}
 __device__ __forceinline__ bool sort_failed(const QuerySrc &src)
 {
     if (!src.sort_flags) return false;
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
                                                                   Candidates *__restrict__ cand, unsigned long long shard_cap,
                                                                   uint2 *__restrict__ defer_list, uint32_t defer_cap, uint32_t diag)
 {
-    if (sort_failed(src)) return;
+    const uint32_t bad_sort = sort_flags_or(src);      // looked at after phase 0 (whose loads are in bounds whatever the tree is): see sort_flags_or
 #ifdef CD_ABLATE       // TIMING EXPERIMENTS ONLY, never in the shipped build (tools/ab_build.sh abl -DCD_ABLATE; tools/exp_descent_ablation.py): parts of the
     const uint32_t ablate = diag >> 8;   // kernel switched off by debug key 103, bits 8..: 1 no descent, 2 no shared chain, 4 no in-wave hops, 8 no candidate
     diag &= 0xffu;                       // hand-over, 16 no record loads for the query box, 32 no counters.  Results are wrong by construction.
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t dg_p1a = 0, dg_p1 = 0, dg_hops_in = 0, dg_hops_out = 0, dg_vis = 0;   // diagnostics (diag != 0)
-    const uint32_t nb = gridDim.x, per = nb >> 3;       // XCD-aware mapping, see k_descend
+    const uint32_t nb = ((uint32_t)n + 64u * HALF_WAVES - 1u) / (64u * HALF_WAVES), per = nb >> 3;       // (= gridDim.x, without the load of the hidden argument) XCD-aware mapping, see k_descend
 #ifndef HALF_XSUB
 #define HALF_XSUB 4
 #endif
@@ -667,6 +676,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         if (valid && self) ++tested;
     }
     if (diag) tm1 = __builtin_amdgcn_s_memtime();
+    if (bad_sort) return;                               // (wave-uniform) keys not sorted: the links may have cycles or point anywhere; the host redoes the step
     // ---- phase 1a: hops below g_last
     uint32_t s = valid ? qi : END;                                            // cursor; >= g_last: joined the shared chain (or has none: g_last == n-1)
     if (ablate & 4u) s = valid ? g_last : END;
