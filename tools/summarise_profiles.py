@@ -10,7 +10,7 @@ FETCH_SIZE and the doubled value are kept beside it.  rocprofv3 reports FETCH_SI
 import collections, csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_final")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "run_kernel_stats.csv"), os.path.join(dst, "bench_kernel_stats.csv"))
