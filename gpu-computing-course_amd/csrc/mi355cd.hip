@@ -502,7 +502,8 @@ int enqueue_report(cd_ctx *c, TravBuf &tb, bool want_pairs, uint64_t &spec_n, ui
 // the device's first stores to host pages it has never written go through address translation, and only the stream's completion signal is
 // known to wait for that.
 constexpr uint32_t POLL_WARM = 2;
-bool poll_allowed(const cd_ctx *c, TravBuf &tb, const void *direct)
+// May this report be waited for by polling?  Also notes which pinned pair buffer the report goes to (a new one starts cold).
+bool poll_this_report(const cd_ctx *c, TravBuf &tb, const void *direct)
 {
     if (direct != tb.direct_ptr) { tb.direct_ptr = direct; tb.synced_direct = 0; }
     return c->poll_opt && !c->stage_events && c->stamp_mask == 0 && tb.synced_reports >= POLL_WARM && (!direct || tb.synced_direct >= POLL_WARM);
@@ -540,7 +541,7 @@ void parse_report(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs,
 int read_state(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs = nullptr, uint64_t spec_n = 0, bool direct = false)
 {
     if (ensure_report(tb)) return CD_ERR_ARG;
-    const unsigned long long seq = poll_allowed(c, tb, direct ? spec_pairs : nullptr) ? ++c->report_seq : 0ull;
+    const unsigned long long seq = poll_this_report(c, tb, direct ? spec_pairs : nullptr) ? ++c->report_seq : 0ull;
     uint32_t *area = nullptr;
     if (c->dbg_poll_check && seq && spec_pairs && spec_n) {
         if (ensure_report(tb)) return CD_ERR_ARG;

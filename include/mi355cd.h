@@ -200,6 +200,8 @@ enum {
                                    /*    pair buffer the device has not written before); 0: always hipStreamSynchronize                                      */
     CD_OPT_QUERIES_PER_WAVE = 1    /* variant 1: queries one wave works through with dynamic lane refill (x64)         */
 };
+/* Keys >= 100 are measurement hooks of tools/ (extra LDS per workgroup, in-kernel diagnostics, the polled completion's scan and its counters,
+ * ...): not part of the interface, free to change; what they do is said where they are handled (cd_set_option in csrc/mi355cd.hip). */
 int cd_set_option(cd_ctx *ctx, int key, int64_t value);
 
 int cd_get_stats(cd_ctx *ctx, cd_stats *out);
