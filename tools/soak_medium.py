@@ -37,7 +37,9 @@ for case in range(ncase):
     r = oracle.pipeline(verts, vidx)
     with mi355cd.CollisionDetector(verts, vidx) as cd:
         ok = True
-        for rep in range(2):                          # second step: the self-cleaning scratch
+        if os.environ.get("SOAK_NO_STAMPS"):          # the bench's options: no time stamps, so the polled completion (CD_OPT_POLL) is what ends a step
+            cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+        for rep in range(6 if os.environ.get("SOAK_NO_STAMPS") else 2):   # second step: the self-cleaning scratch
             pairs, npairs, rc = cd.self_collide(cap=1 << 23)
             ok &= rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])) and cd.stats().pairs_tested == r["stats"].pairs_tested
         keys, perm = cd.export_keys()
