@@ -440,6 +440,12 @@ def main():
                                       f"{STAMP_EVERY}th: a stamped kernel costs its step ~7 us of idle GPU); descend_device_clock: live, EVERY timed step, the kernel's own "
                                       f"first-wave-start -> last-wave-end on the device wall clock; exact, build_block and total_collision_ms_device: from {prof_steps} "
                                       f"extra untimed steps with all stamps on")
+            # what the descent's steps are filled with (VERDICT r02 asked for it beside the wait share in profiles/rNN/pmc_sq_per_kernel.csv): a wave-step is one
+            # pass of a wave through a hop or a descent step, a node visit one lane's box test(s) in it
+            st = engine.cd.stats()
+            if st.wave_steps:
+                line["descent_lane_use"] = {"node_visits_per_step": int(st.node_visits), "wave_steps_per_step": int(st.wave_steps),
+                                            "lanes_busy_of_64": st.node_visits / float(st.wave_steps), "node_visits_per_query": st.node_visits / float(nt)}
             line["roofline"] = dict(cands[0])
             line["roofline"]["other_kernels"] = cands[1:]
             line["roofline"]["whole_path"] = {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9,
