@@ -514,7 +514,9 @@ int wait_report(cd_ctx *c, TravBuf &tb, unsigned long long seq)
         const volatile unsigned long long *p = &reinterpret_cast<const volatile Report *>(tb.h_report)->seq;
         const auto t0 = std::chrono::steady_clock::now();
         for (uint32_t it = 1; *p != seq; ++it) {
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#endif
             if ((it & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
         }
         if (*p == seq) {
