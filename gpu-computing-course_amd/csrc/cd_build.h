@@ -124,7 +124,8 @@ __device__ __forceinline__ double f64_from_ordered(unsigned long long k)
 // ~3 us of idle GPU per step): the sort's histograms, tickets and look-back granules are dead once the sort is done, so
 // k_build_block clears them for the NEXT step (the sort flags are not touched: a non-zero flag makes the host redo the
 // step, with a memset), and the traversal counters for THIS step.  All pointers null: nothing to do.
-struct ZeroPlan { uint32_t *w0; uint32_t nw0; uint4 *q; uint32_t nq; uint32_t *w1; uint32_t nw1; };
+struct ZeroPlan { uint32_t *w0; uint32_t nw0; uint4 *q; uint32_t nq; uint32_t *w1; uint32_t nw1;
+                  uint32_t *flag; };    // one more word, cleared in every launch: k_cross_fused's "upper levels published" flag (a graph replay carries the same sequence number every time)
 
 __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n,
                                                            const uint64_t *__restrict__ keys, int32_t *__restrict__ split_of,
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
         if (blockIdx.x == gridDim.x - 1) {
             for (uint32_t x = threadIdx.x; x < zp.nw0; x += REFIT_BLK) zp.w0[x] = 0u;
             for (uint32_t x = threadIdx.x; x < zp.nw1; x += REFIT_BLK) zp.w1[x] = 0u;
+            if (threadIdx.x == 0 && zp.flag) *zp.flag = 0u;
         }
     }
 #if defined(BLK_ABLATE) && BLK_ABLATE == 0
@@ -505,9 +507,10 @@ __device__ __forceinline__ void root_box_fold(const double *__restrict__ seg, in
 __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restrict__ keys, int n, const double *__restrict__ seg, const float *__restrict__ seg32,
                                                      int nbp2, int nblocks, const LeafBox32 *__restrict__ qbox32, double *__restrict__ boxes,
                                                      NodeRec32 *__restrict__ recs32, const int32_t *__restrict__ split_of, int32_t *__restrict__ root_name,
-                                                     const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap)
+                                                     const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap,
+                                                     unsigned long long *top_pub /* [3 * nbp2 / 4] the upper levels, published by workgroup 0 */, uint32_t *top_flag, uint32_t top_seq)
 {
-    extern __shared__ float top[];                                          // [max(nbp2 / 4, 1)][6]: heap nodes [1, nbp2 / 4)
+    extern __shared__ float top[];                                          // workgroup 0 only: [max(nbp2 / 4, 1)][6], heap nodes [1, nbp2 / 4)
     const int tid = threadIdx.x, lane = tid & 63, g = lane / XG, gl = lane % XG;
     // (a workgroup of its own, the last one of the grid: the fold is a chain of dependent loads, short against what the
     //  others do, long when it comes on top of it)
@@ -518,15 +521,32 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
 #ifdef CROSS_ABLATE_TOP
     return;
 #endif
+    // The levels from three above the blocks upwards (a node of 8, 16, ... blocks), which only the few nodes with ranges of 4096 leaves or
+    // more ask for: ONE workgroup -- the first of the grid, so it is resident before anybody can wait for it, and it waits for nobody --
+    // folds them (top32_to_lds) and PUBLISHES them: agent-scope stores (the 8 L2s are not coherent inside a kernel), a wait for those
+    // stores, then the launch's sequence number into the flag word.  A lane that needs such a piece (below) polls the flag -- by then the
+    // searches have taken longer than the fold -- and reads the node with agent-scope loads.  Round 2 and the first half of round 3 had
+    // EVERY workgroup fold its own copy into LDS in front of its searches: 4.2 of the kernel's 24 us (and 48 KB of L2 reads a workgroup).
+    if (blockIdx.x == 0) {
+        top32_to_lds(top, seg32, nbp2, nblocks);
+        const int nn = nbp2 >> 2;                                           // heap nodes [1, nn)
+        for (int k = 1 + tid; k < nn; k += 256) {
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(top + 6 * k);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) __hip_atomic_store(top_pub + 3 * (size_t)k + u, src[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_waitcnt(0);                                      // this wave's stores have been acknowledged ...
+        __syncthreads();                                                    // ... every wave's
+        if (tid == 0) __hip_atomic_store(top_flag, top_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     constexpr int PER_WAVE = 64 / XG, PER_BLOCK = 256 / XG;
     const uint32_t total = min(*dense_total, dense_cap);
     const long long P = (long long)nbp2 * REFIT_BLK;
-    // (the upper levels first: while the waves of a workgroup are still in step, so that its two barriers cost nothing)
-    top32_to_lds(top, seg32, nbp2, nblocks);
 #ifdef CROSS_ABLATE_ALL
     return;                                                                 // TIMING EXPERIMENT ONLY: launch + the upper levels into LDS
 #endif
-    for (uint32_t wbase = blockIdx.x * PER_BLOCK + (tid >> 6) * PER_WAVE; wbase < total; wbase += (gridDim.x - 1) * PER_BLOCK) {   // (wbase is wave-uniform)
+    for (uint32_t wbase = (blockIdx.x - 1) * PER_BLOCK + (tid >> 6) * PER_WAVE; wbase < total; wbase += (gridDim.x - 2) * PER_BLOCK) {   // (wbase is wave-uniform; workgroups 1 .. gridDim.x - 2 search)
         // ---- range and split, as k_cross_meta
         const uint32_t kq = wbase + g;
         const bool live = kq < total;
@@ -603,12 +623,31 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
         };
         for (int sw = 0; sw < sweeps; ++sw) {
             const int p = gl + 16 * sw;
-            if (p > REFIT_LOG + 2) {
+            long long kk[4]; bool tk[4]; bool any_top = false;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    long long k;
-                    if (piece(u >> 1, p, u & 1, k)) { const B32 v = b32_load(top + 6 * (int)k); if (u < 2) accL = b32_merge(accL, v); else accR = b32_merge(accR, v); }
+            for (int u = 0; u < 4; ++u) { tk[u] = p > REFIT_LOG + 2 && piece(u >> 1, p, u & 1, kk[u]); any_top |= tk[u]; }
+            if (!__builtin_amdgcn_ballot_w64(any_top)) continue;            // (wave-uniform) nearly always: no range of 4096 leaves or more among the wave's four nodes
+            bool ready = !any_top;
+            for (uint32_t spin = 0; spin < (1u << 20); ++spin) {            // (bounded: a lane that never sees the flag folds its node itself, below)
+                if (!ready) ready = __hip_atomic_load(top_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == top_seq;
+                if (!__builtin_amdgcn_ballot_w64(!ready)) break;            // every lane that needs the upper levels has seen this launch's number
+                __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (tk[u]) {
+                B32 v;
+                if (ready) {
+                    unsigned long long w[3];
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) w[e] = __hip_atomic_load(top_pub + 3 * (size_t)kk[u] + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = B32{__uint_as_float((uint32_t)w[0]), __uint_as_float((uint32_t)(w[0] >> 32)), __uint_as_float((uint32_t)w[1]),
+                            __uint_as_float((uint32_t)(w[1] >> 32)), __uint_as_float((uint32_t)w[2]), __uint_as_float((uint32_t)(w[2] >> 32))};
+                } else {                                                    // the publisher never showed up (cannot happen: it is workgroup 0 and waits for nobody): fold the node's blocks here
+                    v = b32_identity();
+                    const long long b_first = (kk[u] << (p - REFIT_LOG)) - nbp2;
+                    for (long long bb = 0; bb < (1ll << (p - REFIT_LOG)); ++bb) v = b32_merge(v, block_box32(seg32, nbp2, nblocks, (int)(b_first + bb)));
                 }
+                if (u < 2) accL = b32_merge(accL, v); else accR = b32_merge(accR, v);
             }
         }
         {

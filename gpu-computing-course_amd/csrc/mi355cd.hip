@@ -76,6 +76,7 @@ struct cd_ctx {
     uint32_t *d_os_hist = nullptr; uint32_t *d_os_ticket = nullptr; unsigned long long *d_os_look = nullptr;
     double *d_frame = nullptr, *d_partial = nullptr;
     // tree
+    unsigned long long *d_top_pub = nullptr; uint32_t top_seq = 0;          // k_cross_fused: the upper levels of the fp32 tree as its first workgroup publishes them, and the launch counter its flag word carries
     LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; double *d_seg = nullptr; float *d_seg32 = nullptr; uint32_t nbp2 = 1; int32_t *d_cross = nullptr; uint32_t cross_cap = 0;   // segment tree over leaf boxes: nbp2*512 heap nodes
     double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec32 *d_recs32 = nullptr; LeafBox32 *d_qbox = nullptr;
     int32_t *d_root = nullptr;              // name (split) of the root record, one word inside d_small
@@ -113,8 +114,8 @@ struct cd_ctx {
     bool poll_opt = true;
     unsigned long long report_seq = 0;      // last sequence number handed to a k_report
     uint32_t polled_steps = 0, poll_fallbacks = 0;
-    // debug key 104 (tools/poll_stress.py): the pair area the report kernel writes is filled with 0xff before every step and scanned the moment the
-    // sequence word is seen -- a pair that is still 0xff then was overtaken by the word (poll_stale counts such steps; debug key 105 returns the count)
+    // debug key 110 (tools/poll_stress.py): the pair area the report kernel writes is filled with 0xff before every step and scanned the moment the
+    // sequence word is seen -- a pair that is still 0xff then was overtaken by the word (poll_stale counts such steps; debug key 111 returns the count, 112 the fall-backs to the stream)
     bool dbg_poll_check = false;
     uint32_t poll_stale = 0;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
@@ -129,12 +130,16 @@ struct cd_ctx {
 
 namespace {
 
+// k_cross_fused's published upper levels (24 bytes a node, heap nodes [1, TOP_IN_BLOCK / 4)) and, behind them, the flag word
+constexpr size_t TOP_PUB_BYTES = sizeof(unsigned long long) * 3 * (TOP_IN_BLOCK / 4) + 64;
+uint32_t *top_flag_of(cd_ctx *c) { return reinterpret_cast<uint32_t *>(c->d_top_pub + 3 * (TOP_IN_BLOCK / 4)); }
+
 void free_all(cd_ctx *c)
 {
     hipFree(c->d_verts); hipFree(c->d_vidx); hipFree(c->d_ids);
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
-    hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_seg32); hipFree(c->d_cross); hipFree(c->d_boxes);
+    hipFree(c->d_top_pub); hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_seg32); hipFree(c->d_cross); hipFree(c->d_boxes);
     hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox); hipFree(c->d_split_of);
     for (TravBuf &tb : c->tb) {
         if (tb.d_pairs) hipFree(reinterpret_cast<char *>(tb.d_pairs) - sizeof(Report));
@@ -319,12 +324,12 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         // (its time stamps ride on its own dispatch packet: this is the largest kernel of the step, bench.py prices it)
         const bool stamp = (c->stamp_mask & 1u) != 0;
         const bool self_cleaning = c->prezeroed && c->sort_mode <= 1;
-        ZeroPlan zp{nullptr, 0u, nullptr, 0u, nullptr, 0u};
+        ZeroPlan zp{nullptr, 0u, nullptr, 0u, nullptr, 0u, top_flag_of(c)};
         if (self_cleaning) {
             const size_t gran = sizeof(unsigned long long) * (size_t)c->ntiles * RADIX;
             zp = ZeroPlan{c->d_os_hist, (uint32_t)HIST_COPIES * 8u * RADIX + 8u /* histograms + tickets; the flags behind them stay */,
                           reinterpret_cast<uint4 *>(c->d_os_look), (uint32_t)(2 * gran / sizeof(uint4)),
-                          reinterpret_cast<uint32_t *>(c->tb[0].d_state), (uint32_t)(sizeof(TravState) / sizeof(uint32_t))};
+                          reinterpret_cast<uint32_t *>(c->tb[0].d_state), (uint32_t)(sizeof(TravState) / sizeof(uint32_t)), top_flag_of(c)};
         }
         const int seg_min = (c->nbp2 > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK && !c->dbg_split_cross) ? SEG32_MIN_LEVEL : SEG_MIN_LEVEL;
         if (stamp)
@@ -342,18 +347,21 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
                                                        cross_list, cross_count, c->cross_cap);
     // fused build, a tree of 2 .. 2048 blocks: the cross nodes' ranges, splits, links and records in ONE launch (k_cross_fused, cd_build.h)
     if (fused && n > 1 && c->nbp2 > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK && !c->dbg_split_cross) {
-        const uint32_t xb = (uint32_t)nblocks < 8u ? 8u : ((uint32_t)nblocks > 1792u ? 1792u : (uint32_t)nblocks);   // 16 nodes per workgroup and round, ~13 per block; at most what the chip holds at once (7 workgroups per CU)
+        const uint32_t xb = (uint32_t)nblocks < 8u ? 8u : ((uint32_t)nblocks > 1790u ? 1790u : (uint32_t)nblocks);   // 16 nodes per workgroup and round, ~13 per block; with the two workgroups below at most what the chip holds at once (7 workgroups per CU)
         // (the multi-GPU step's "tree is there" event rides on this kernel's dispatch packet: recorded on its own it is a barrier
         //  packet between the tree and the traversal, ~6 us of idle GPU)
         hipEvent_t done = c->tree_done_event; c->tree_done_event = nullptr;
-        const uint32_t xlds = (uint32_t)(sizeof(float) * 6 * (c->nbp2 >= 4 ? c->nbp2 / 4 : 1));
+        const uint32_t xlds = (uint32_t)(sizeof(float) * 6 * (c->nbp2 >= 4 ? c->nbp2 / 4 : 1));       // (used by the publishing workgroup only)
+        uint32_t *top_flag = top_flag_of(c);
+        if (++c->top_seq == 0u) ++c->top_seq;                               // (never 0: what k_build_block leaves in the flag word)
         if (done)
-            hipExtLaunchKernelGGL(k_cross_fused, dim3(xb + 1u /* the last workgroup folds the FP64 box of all leaves */), dim3(256), xlds, s, nullptr, done, 0u,
+            hipExtLaunchKernelGGL(k_cross_fused, dim3(xb + 2u /* the first workgroup publishes the upper levels, the last folds the FP64 box of all leaves */), dim3(256), xlds, s, nullptr, done, 0u,
                                   (const uint64_t *)c->d_keys[0], (int)n, (const double *)c->d_seg, (const float *)c->d_seg32, (int)c->nbp2, nblocks, (const LeafBox32 *)c->d_qbox, c->d_boxes,
-                                  c->d_recs32, (const int32_t *)c->d_split_of, c->d_root, (const int32_t *)c->d_cross, (const uint32_t *)cross_count, c->cross_cap);
+                                  c->d_recs32, (const int32_t *)c->d_split_of, c->d_root, (const int32_t *)c->d_cross, (const uint32_t *)cross_count, c->cross_cap,
+                                  c->d_top_pub, top_flag, c->top_seq);
         else
-            k_cross_fused<<<xb + 1u, 256, xlds, s>>>(c->d_keys[0], (int)n, c->d_seg, c->d_seg32, (int)c->nbp2, nblocks, c->d_qbox, c->d_boxes,
-                                                     c->d_recs32, c->d_split_of, c->d_root, c->d_cross, cross_count, c->cross_cap);
+            k_cross_fused<<<xb + 2u, 256, xlds, s>>>(c->d_keys[0], (int)n, c->d_seg, c->d_seg32, (int)c->nbp2, nblocks, c->d_qbox, c->d_boxes,
+                                                     c->d_recs32, c->d_split_of, c->d_root, c->d_cross, cross_count, c->cross_cap, c->d_top_pub, top_flag, c->top_seq);
         c->internal_boxes_valid = write_internal;
         HIPCHK(evrec(c, EV_REFIT1));
         HIPCHK(hipGetLastError());
@@ -854,6 +862,8 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_parent, sizeof(int32_t) * 2 * n);
     { uint32_t nb = cdiv(nt, REFIT_BLK); c->nbp2 = 1; while (c->nbp2 < nb) c->nbp2 <<= 1; }
     ALLOC(c->d_seg, sizeof(double) * 6 * (size_t)c->nbp2 * REFIT_BLK);
+    ALLOC(c->d_top_pub, TOP_PUB_BYTES);
+    if (hipMemset(c->d_top_pub, 0, TOP_PUB_BYTES) != hipSuccess) { free_all(c); delete c; return -(int)hipGetLastError(); }
     ALLOC(c->d_seg32, sizeof(float) * 6 * ((size_t)c->nbp2 << (REFIT_LOG - SEG32_MIN_LEVEL + 1)));   // fused build: levels SEG32_MIN_LEVEL .. 9 of the blocks' fp32 trees
     c->cross_cap = nt;                                  // every internal node could be one (it never is: about 2 %)
     ALLOC(c->d_cross, sizeof(int32_t) * (size_t)c->cross_cap);
@@ -1295,9 +1305,10 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }
     if (key == CD_OPT_GRAPH) { c->graph_opt = value != 0; if (!c->graph_opt) graph_drop(c); return CD_OK; }
     if (key == CD_OPT_POLL) { c->poll_opt = value != 0; return CD_OK; }
-    if (key == 104) { c->dbg_poll_check = value != 0; return CD_OK; }
-    if (key == 105) return (int)c->poll_stale;                            // (debug: a count, not a status)
-    if (key == 106) return (int)c->poll_fallbacks;
+    if (key == 110) { c->dbg_poll_check = value != 0; return CD_OK; }
+    if (key == 111) return (int)c->poll_stale;                            // (debug: a count, not a status)
+    if (key == 112) return (int)c->poll_fallbacks;
+    if (key == 113) return c->last_tree_fused ? 1 : 0;                   // (debug: which build made the tree that is there -- the tests make sure an A/B of builds compares two builds)
     if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
     if (key == 102) { c->dbg_no_shared_path = (uint32_t)value; return CD_OK; }
     if (key == 103) { c->dbg_diag = (uint32_t)value; return CD_OK; }

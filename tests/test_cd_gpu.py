@@ -612,6 +612,7 @@ def _assert_fused_records_equal_stagewise(verts, vidx, ids=None, split_cross_too
             cd.set_option(104, 0 if fused else 1)
             cd.set_option(105, 1 if fused == 2 else 0)
             cd.build_tree()
+            assert cd.lib.cd_set_option(cd._ctx, 113, 0) == (1 if fused else 0)      # the build that was asked for is the build that ran
             got[fused] = cd.debug_records() + (cd.root_box(),)
     if split_cross_too:
         _compare_records(vidx.shape[0], got[2], got[0])
@@ -1202,8 +1203,8 @@ def test_polled_completion_gives_what_the_stream_synchronise_gives():
 
 
 def test_polled_completion_never_sees_the_word_before_the_pairs():
-    """The hazard of a polled completion: the sequence word overtaking pairs still on their way to host memory.  Debug key 104 makes the
-    library fill the pair area with 0xff before every step and scan it the moment the word is seen (key 105: steps with a pair missing;
+    """The hazard of a polled completion: the sequence word overtaking pairs still on their way to host memory.  Debug key 110 makes the
+    library fill the pair area with 0xff before every step and scan it the moment the word is seen (key 111: steps with a pair missing;
     tools/poll_stress.py runs this for 20 000 steps a mesh, with the host link loaded, and has a negative control build that posts the
     word first -- which this scan catches on 96 % of the steps).  A fresh context each, on the mesh (4 948 pairs) round 2's attempt at this
     failed on."""
@@ -1211,14 +1212,14 @@ def test_polled_completion_never_sees_the_word_before_the_pairs():
         for verts, vidx in (synth.cloth_pair(122), synth.soup(60_000, 0.08, 21)):        # 4 948 pairs; ~29 k pairs (nearly all the report kernel posts)
             with mi355cd.CollisionDetector(verts, vidx) as cd, mi355cd.HostPairs(1 << 17) as hp:
                 plain = np.empty((1 << 17, 2), dtype=np.uint32)
-                cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0); cd.set_option(104, 1)
+                cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0); cd.set_option(110, 1)
                 n0, rc = cd.self_collide_into(plain)                                      # (the first two reports into an area end in a stream synchronise: never-written host pages)
                 want = oracle.pair_set(plain[:n0].copy())
                 for it in range(150):
                     buf = plain if it % 2 == 0 else hp.array
                     n, rc = cd.self_collide_into(buf)
                     assert rc == 0 and n == n0 and np.array_equal(oracle.pair_set(buf[:n]), want), (rep, it)
-                assert cd.lib.cd_set_option(cd._ctx, 105, 0) == 0 and cd.lib.cd_set_option(cd._ctx, 106, 0) == 0
+                assert cd.lib.cd_set_option(cd._ctx, 111, 0) == 0 and cd.lib.cd_set_option(cd._ctx, 112, 0) == 0
 
 
 def test_multi_step_box_of_the_triangles_ignores_unreferenced_vertices():

@@ -1,5 +1,5 @@
-"""Stress of the polled completion (CD_OPT_POLL): is every pair in host memory when the sequence word is?  Debug key 104 makes the library fill the
-pair area with 0xff before each step and scan it the moment it sees the word (key 105: steps with a pair still 0xff, key 106: steps that fell back
+"""Stress of the polled completion (CD_OPT_POLL): is every pair in host memory when the sequence word is?  Debug key 110 makes the library fill the
+pair area with 0xff before each step and scan it the moment it sees the word (key 111: steps with a pair still 0xff, key 112: steps that fell back
 to the stream synchronise).  Meshes from ~1 k to > 32 768 pairs (the most the report kernel posts), ordinary and pinned buffers, STEPS steps each;
 every step's pair set is also compared with the first (synchronised) step's.  With LOAD = 1 a second thread keeps the host link busy in both
 directions (64 MB torch copies on another stream) while the steps run.  usage: poll_stress.py [STEPS [LOAD]]   GPU only."""
@@ -31,13 +31,13 @@ for name, (verts, vidx) in cases:
         cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0); cd.set_option(mi355cd.CD_OPT_POLL, 0)
         n0, rc = cd.self_collide_into(plain)
         want = oracle.pair_set(plain[:n0].copy())
-        cd.set_option(mi355cd.CD_OPT_POLL, 1); cd.set_option(104, 1)
+        cd.set_option(mi355cd.CD_OPT_POLL, 1); cd.set_option(110, 1)
         mism = 0
         for it in range(steps):
             buf = plain if it % 2 == 0 else hp.array
             n, rc = cd.self_collide_into(buf)
             if rc != 0 or n != n0 or not np.array_equal(oracle.pair_set(buf[:n]), want): mism += 1
-        stale = cd.lib.cd_set_option(cd._ctx, 105, 0); fb = cd.lib.cd_set_option(cd._ctx, 106, 0)
+        stale = cd.lib.cd_set_option(cd._ctx, 111, 0); fb = cd.lib.cd_set_option(cd._ctx, 112, 0)
         print(f"{name}: {n0} pairs, {steps} polled steps: pair-set mismatches {mism}, steps with a pair not yet in host memory {stale}, fallbacks to the stream {fb}", flush=True)
         bad += mism + stale
 stop = True
