@@ -1120,6 +1120,15 @@ def test_graph_replay_of_the_steady_state_step_gives_the_same_results():
         for it in range(3):
             pairs, n, rc = cd.self_collide(cap=1 << 20)
             assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r2["pairs"])) and cd.stats().pairs_tested == r2["stats"].pairs_tested
+            assert cd.stats().traverse_launches == 0                   # (a replay)
+            if it == 0:
+                # the records the FIRST replay after the vertices moved leaves behind are the stage-wise build's of the new positions, byte for byte:
+                # nothing a launch derives from the geometry may be carried over from an earlier replay (the cross kernel's published upper levels
+                # and their flag word -- a replay carries the same sequence number every time)
+                with mi355cd.CollisionDetector(v2, vidx) as cd0:
+                    cd0.set_option(104, 1); cd0.build_tree()
+                    assert cd0.lib.cd_set_option(cd0._ctx, 113, 0) == 0
+                    _compare_records(vidx.shape[0], cd.debug_records() + (cd.root_box(),), cd0.debug_records() + (cd0.root_box(),))
         pairs, n, rc = cd.self_collide(cap=1 << 18)          # another capacity: another capture
         assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r2["pairs"]))
         pairs, n, rc = cd.self_collide(cap=16)               # too small: the true count comes back with CD_OVERFLOW
