@@ -122,6 +122,35 @@ def parity_check(pairs, tested, verts, vidx, ids=None, off=None, span=None, own_
     return out
 
 
+def soup_measurement(torch, steps=60, warmup=10):
+    """Secondary workload (inputs item 3: "also report the 1 M soup"): the config-2 generator at 1 000 000 triangles, e = 0.01 -- own
+    vertices per triangle (no shared edges, boxes that are NOT exact in fp32: the exact kernel decides every candidate in FP64), the same
+    call and options as the headline; the last step's pair set and pairs_tested against the oracle.  N = 1 only."""
+    import mi355_synth as synth
+    import mi355cd
+    verts, vidx = synth.soup(1_000_000, 0.01, 1234)
+    with mi355cd.CollisionDetector(verts, vidx) as cd, mi355cd.HostPairs(1 << 22) as hp:
+        cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+        for _ in range(warmup):
+            cd.self_collide_into(hp.array)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tested = 0
+        for _ in range(steps):
+            n, rc = cd.self_collide_into(hp.array)
+            tested += cd.fast_stats.pairs_tested
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError("soup: pair capacity too small")
+        last = np.array(hp.array[:n], copy=True); last_tested = cd.fast_stats.pairs_tested
+        clock = cd.fast_stats.ms_descend_clock
+    pc = parity_check(last, last_tested, verts, vidx)
+    return {"workload": "triangle soup, 1 000 000 triangles of edge 0.01 in the reference's box, own vertices per triangle (config-2 generator at 1 M)",
+            "ms_per_step": dt * 1e3 / steps, "pairs_tested_per_s": tested / dt, "pairs_tested_per_step": int(last_tested), "colliding_pairs": int(n), "steps": steps,
+            "descend_device_clock_ms": clock, "parity_checked": bool(pc["ok"])}
+
+
 def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5, rank=0, world=1, dist=None, torch=None, device=None, multi=False):
     """Secondary path (BASELINE config 5): 4096^2 image, 4096 spheres, frame kept on the device (the reference
     copies every frame to the host for glDrawPixels, anime_ray.cu:128-131; that PCIe copy is not kernel time).
@@ -212,6 +241,8 @@ def main():
     ap.add_argument("--quads", type=int, default=500, help="quads per sheet edge; 500 -> 1 000 000 triangles per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the last timed step's pair set")
+    ap.add_argument("--soup", action="store_true", help="also measure the 1 M soup (SURVEY.md 8d) after the headline: same kernels, other workload -- off by default so that a kernel "
+                                                       "trace of the default command holds the headline workload's launches only")
     ap.add_argument("--no-ray", action="store_true", help="skip the secondary ray-tracer measurement (BASELINE config 5)")
     ap.add_argument("--traversal", type=int, default=None, help="CD_OPT_TRAVERSAL override (0 lane-private FP64, 1 wave-queued)")
     ap.add_argument("--qpw", type=int, default=None, help="CD_OPT_QUERIES_PER_WAVE override")
@@ -484,6 +515,8 @@ def main():
             line["parity_checked"] = bool(int(f.item()))
             line["parity"] = dict(pc, note="rank 0's own check shown; parity_checked = MIN over ranks: every rank's pair list of the last timed step == "
                                            "the oracle's pairs (on the rank's mesh merged with its lower neighbour's) whose larger id the rank owns")
+    if not multi_path and args.soup and rank == 0:
+        line["soup_1M"] = soup_measurement(torch)
     if not args.no_ray and (backend == "nccl" or not multi_path):
         rtm = ray_tracer_measurement(rank=rank, world=world if multi_path else 1, dist=dist if multi_path else None, torch=torch, device=device, multi=multi_path)
         if rank == 0:
