@@ -124,7 +124,7 @@ def parity_check(pairs, tested, verts, vidx, ids=None, off=None, span=None, own_
 
 def soup_measurement(torch, steps=60, warmup=10):
     """Secondary workload (inputs item 3: "also report the 1 M soup"): the config-2 generator at 1 000 000 triangles, e = 0.01 -- own
-    vertices per triangle (no shared edges, boxes that are NOT exact in fp32: the exact kernel decides every candidate in FP64), the same
+    vertices per triangle (no shared edges: the neighbour filter drops nothing and every overlapping leaf pair goes through the SAT), the same
     call and options as the headline; the last step's pair set and pairs_tested against the oracle.  N = 1 only."""
     import mi355_synth as synth
     import mi355cd
