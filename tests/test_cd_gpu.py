@@ -1197,6 +1197,14 @@ def test_polled_completion_gives_what_the_stream_synchronise_gives():
                 assert np.array_equal(oracle.pair_set(buf[:n]), want), (poll, it)
         st = cd.stats()
         assert st.pairs_tested == r["stats"].pairs_tested and st.n_pairs == len(want) and st.ms_descend_clock > 0
+        # a capacity below the pair count, polled: the true count comes back with CD_OVERFLOW, what fits is a subset of the pairs, nothing is written past it
+        for buf in (hp.array[:64], plain[:64]):
+            big = hp.array if buf.base is hp.array or buf is hp.array else plain
+            big[:] = 0xffffffff
+            n, rc = cd.self_collide_into(buf)
+            assert rc == mi355cd.CD_OVERFLOW and n == len(want)
+            got = oracle.pair_set(buf[:64])
+            assert np.isin(got, want).all() and len(np.unique(got)) == 64 and (big[64:72] == 0xffffffff).all()
     off = np.zeros(3); span = np.full(3, 1048576.0)
     verts, vidx = _comb([1 << (59 - k) for k in range(60)], big_first=True)
     r = oracle.pipeline(verts, vidx, off=off, span=span)
