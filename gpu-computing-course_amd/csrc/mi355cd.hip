@@ -181,6 +181,31 @@ __global__ void k_expand_values(const uint64_t *__restrict__ v, uint64_t n, uint
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = expand64(v[i]);
 }
 
+// box.cuh:24-32 / :40-43 and tri_contact.cuh:19-78 on explicit operands (cd_box_pairs, cd_tri_contact_points): the device functions
+// the refit, the descent's FP64 leaf test and k_exact use
+__global__ void k_box_pairs(const double *__restrict__ a, const double *__restrict__ b, uint64_t n, uint8_t *__restrict__ overlap,
+                            double *__restrict__ merged)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const double *pa = a + 6 * i, *pb = b + 6 * i;
+        const Box x{pa[0], pa[1], pa[2], pa[3], pa[4], pa[5]}, y{pb[0], pb[1], pb[2], pb[3], pb[4], pb[5]};
+        if (overlap) overlap[i] = box_overlap(x, y) ? 1 : 0;
+        if (merged) {
+            const Box m = box_merge(x, y);
+            double *o = merged + 6 * i;
+            o[0] = m.x1; o[1] = m.x2; o[2] = m.y1; o[3] = m.y2; o[4] = m.z1; o[5] = m.z2;
+        }
+    }
+}
+__global__ void k_tri_contact_points(const double *__restrict__ t, uint64_t n, uint8_t *__restrict__ out)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const double *p = t + 18 * i;
+        out[i] = tri_contact(d3{p[0], p[1], p[2]}, d3{p[3], p[4], p[5]}, d3{p[6], p[7], p[8]},
+                             d3{p[9], p[10], p[11]}, d3{p[12], p[13], p[14]}, d3{p[15], p[16], p[17]}) ? 1 : 0;
+    }
+}
+
 constexpr int BOUNDS_BLOCKS = 1024;
 
 int ensure_pairs(cd_ctx *c, TravBuf &tb, uint64_t cap)
@@ -1257,6 +1282,49 @@ int cd_expand64_values(const uint64_t *v, uint64_t n, uint64_t *out)
     if (!v || !out) return CD_ERR_ARG;
     if (n == 0) return CD_OK;
     return morton_batch(v, sizeof(uint64_t) * n, n, nullptr, out);
+}
+
+// checkBoxOverlap / Box::merge / checkTriangleContact themselves on caller-supplied operands; no context (one-shot buffers, null stream)
+int cd_box_pairs(const double *a, const double *b, uint64_t n, uint8_t *overlap, double *merged)
+{
+    if (!a || !b || (!overlap && !merged)) return CD_ERR_ARG;
+    if (n == 0) return CD_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return CD_ERR_NO_DEVICE;
+    double *d_a = nullptr, *d_b = nullptr, *d_m = nullptr; uint8_t *d_o = nullptr;
+    const size_t bytes = sizeof(double) * 6 * n;
+    hipError_t e = hipMalloc(&d_a, bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_b, bytes);
+    if (e == hipSuccess && overlap) e = hipMalloc(&d_o, n);
+    if (e == hipSuccess && merged) e = hipMalloc(&d_m, bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_b, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_box_pairs<<<cdiv(n, 256) < 4096u ? cdiv(n, 256) : 4096u, 256>>>(d_a, d_b, n, d_o, d_m);
+        e = hipGetLastError();
+        if (e == hipSuccess && overlap) e = hipMemcpy(overlap, d_o, n, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && merged) e = hipMemcpy(merged, d_m, bytes, hipMemcpyDeviceToHost);
+    }
+    hipFree(d_a); hipFree(d_b); hipFree(d_o); hipFree(d_m);
+    return e == hipSuccess ? CD_OK : -(int)e;
+}
+int cd_tri_contact_points(const double *tri, uint64_t n, uint8_t *out)
+{
+    if (!tri || !out) return CD_ERR_ARG;
+    if (n == 0) return CD_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return CD_ERR_NO_DEVICE;
+    double *d_t = nullptr; uint8_t *d_o = nullptr;
+    hipError_t e = hipMalloc(&d_t, sizeof(double) * 18 * n);
+    if (e == hipSuccess) e = hipMalloc(&d_o, n);
+    if (e == hipSuccess) e = hipMemcpy(d_t, tri, sizeof(double) * 18 * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_tri_contact_points<<<cdiv(n, 256) < 4096u ? cdiv(n, 256) : 4096u, 256>>>(d_t, n, d_o);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(out, d_o, n, hipMemcpyDeviceToHost);
+    }
+    hipFree(d_t); hipFree(d_o);
+    return e == hipSuccess ? CD_OK : -(int)e;
 }
 
 int cd_alloc_host_pairs(uint64_t cap_pairs, uint32_t **pairs)

@@ -59,11 +59,12 @@ def _sheet(nx: int, ny: int, zfun, x0, x1, y0, y1):
     return verts, tris
 
 
-def cloth_pair(quads: int = 500, x_offset: float = 0.0):
+def cloth_pair(quads: int = 500, x_offset: float = 0.0, round_f32: bool = True):
     """Cloth-vs-cloth (BASELINE config 3): two sheets of quads x quads quads, 2 triangles per quad.
 
     quads=500 -> 2 x 500 000 = 1 000 000 triangles, 2 x 501^2 vertices shared inside a sheet (so
-    Triangle::neighborCount matters).  In the reference's y-up frame the sheets span x and z and
+    Triangle::neighborCount matters).  round_f32=False keeps the vertices as full doubles (vec3f.cuh:14-23 stores
+    FP64; only the loader rounds, load_obj.h:38) -- the "double-coords" variant of the bench.  In the reference's y-up frame the sheets span x and z and
     undulate in y:  sheet A  y = -0.1 + 0.02 sin(6x) cos(6z);  sheet B the same surface phase-shifted
     and tilted so the two intersect along curves.  Returns (verts f64[V,3], vidx u32[N,3]).
     """
@@ -81,7 +82,8 @@ def cloth_pair(quads: int = 500, x_offset: float = 0.0):
     vb, tb = _sheet(quads, quads, zb, x0 + 0.0007, x1 + 0.0007, z0 + 0.0011, z1 + 0.0011)
     va = va[:, [0, 2, 1]]
     vb = vb[:, [0, 2, 1]]
-    verts = _f32(np.concatenate([va, vb], axis=0))
+    verts = np.concatenate([va, vb], axis=0)
+    verts = _f32(verts) if round_f32 else np.ascontiguousarray(verts, dtype=np.float64)
     vidx = np.concatenate([ta, tb + np.uint32(va.shape[0])], axis=0).astype(np.uint32)
     return verts, np.ascontiguousarray(vidx)
 

@@ -52,7 +52,7 @@ EXPORTS = [
     "cd_check_triangle_idx", "cd_find_collisions", "cd_build_tree", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
     "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_debug_counters", "cd_debug_records", "cd_num_triangles",
     "cd_set_option", "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
-    "cd_morton3d_points", "cd_expand64_values", "cd_alloc_host_pairs", "cd_free_host_pairs",
+    "cd_morton3d_points", "cd_expand64_values", "cd_box_pairs", "cd_tri_contact_points", "cd_alloc_host_pairs", "cd_free_host_pairs",
     "cd_multi_unique_id", "cd_multi_create", "cd_multi_create_from_comm", "cd_multi_destroy", "cd_multi_set_flags", "cd_multi_step",
 ]
 
@@ -114,6 +114,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_free_host_pairs.restype = None
     lib.cd_morton3d_points.argtypes = [vp, C.c_uint64, vp, vp, vp]
     lib.cd_expand64_values.argtypes = [vp, C.c_uint64, vp]
+    lib.cd_box_pairs.argtypes = [vp, vp, C.c_uint64, vp, vp]
+    lib.cd_tri_contact_points.argtypes = [vp, C.c_uint64, vp]
     lib.cd_multi_unique_id.argtypes = [vp]
     lib.cd_multi_create.argtypes = [C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_uint64, C.c_int]
     lib.cd_multi_create_from_comm.argtypes = [C.POINTER(vp), vp, vp, C.c_uint64, C.c_int]
@@ -398,6 +400,27 @@ def expand64_values(v) -> np.ndarray:
     rc = load_library().cd_expand64_values(_ptr(a), a.shape[0], _ptr(out))
     if rc != CD_OK:
         raise CdError("cd_expand64_values", rc)
+    return out
+
+
+def box_pairs(a, b, want_merged=True):
+    """box.cuh:40-43 checkBoxOverlap and box.cuh:24-32 Box::merge on explicit boxes, on the device (cd_box_pairs)."""
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 6); b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1, 6)
+    ov = np.zeros(a.shape[0], dtype=np.uint8)
+    mg = np.zeros_like(a) if want_merged else None
+    rc = load_library().cd_box_pairs(_ptr(a), _ptr(b), a.shape[0], _ptr(ov), _ptr(mg))
+    if rc != CD_OK:
+        raise CdError("cd_box_pairs", rc)
+    return ov, mg
+
+
+def tri_contact_points(tri) -> np.ndarray:
+    """tri_contact.cuh:19-78 checkTriangleContact on explicit vertex positions [n, 6, 3], on the device (cd_tri_contact_points)."""
+    t = np.ascontiguousarray(tri, dtype=np.float64).reshape(-1, 18)
+    out = np.zeros(t.shape[0], dtype=np.uint8)
+    rc = load_library().cd_tri_contact_points(_ptr(t), t.shape[0], _ptr(out))
+    if rc != CD_OK:
+        raise CdError("cd_tri_contact_points", rc)
     return out
 
 

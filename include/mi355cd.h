@@ -107,6 +107,14 @@ int cd_set_morton_frame(cd_ctx *ctx, int mode, const double offset[3], const dou
 int cd_morton3d_points(const double *xyz, uint64_t n, const double offset[3], const double span[3], uint64_t *keys);
 int cd_expand64_values(const uint64_t *v, uint64_t n, uint64_t *out);
 
+/* box.cuh:40-43 checkBoxOverlap(a, b), box.cuh:24-32 Box::merge(a, b) and tri_contact.cuh:19-78 checkTriangleContact themselves, on n
+ * caller-supplied operands (host pointers; no context), for the same purpose: tests/golden/contact_ref.npz holds outputs of the
+ * reference's box.cuh / tri_contact.cuh compiled unmodified.  Boxes are {x1,x2,y1,y2,z1,z2} (box.cuh:9); overlap[k] = 0/1 and
+ * merged (n x 6) may each be NULL (not both).  tri: n x 18 doubles = P1 P2 P3 Q1 Q2 Q3 positions; out[k] = 0/1 -- no ID rule and
+ * no neighbour gate (those are cd_test_pairs). */
+int cd_box_pairs(const double *a, const double *b, uint64_t n, uint8_t *overlap, double *merged);
+int cd_tri_contact_points(const double *tri, uint64_t n, uint8_t *out);
+
 /* load_obj.h:89-107: centroid + morton3D per face, then sort_by_key(mortons, triangles) -- on the GPU. */
 int cd_morton_sort(cd_ctx *ctx);
 

@@ -6,17 +6,20 @@
  * cpu_baseline leg of bench.py may load it.  The shipped product (libmi355cd.so) never links,
  * loads or calls anything in this directory.
  *
- * Pinning status.  The reference is CUDA C++ (<cuda_runtime.h>, Thrust, nvcc) and is unbuildable in this image without
- * stand-in headers, which this project does not write -- EXCEPT morton.h, which is plain host C++ and is compiled unmodified
- * (oracle/Makefile -> oracle/_ref/libref_morton.so, wrapper oracle/ref_morton.cpp).  So:
- *   - orc_expand64, orc_morton3d, orc_centroid_morton (and the keys orc_sort_by_key orders) are pinned to the REFERENCE'S OWN
- *     OBJECT CODE through tests/golden/morton_ref.npz (2^17 expand inputs, 2^20 in-frame points, the 10^6 centroids of
- *     BASELINE config 3; generator tests/golden/make_morton_ref.py) -- tests/test_oracle_pins.py;
- *   - everything else (delta / determineRange / findSplit / hierarchy, refit, box overlap, neighbour count, the 17-axis contact
- *     test, the traversal, the verifier counters) is PARITY UNPINNED by any replayable reference-held vector: it is pinned by
- *     (i) the reference's own known-answer inputs (check.cuh:19-27 key set), (ii) outputs of the reference recorded in SURVEY.md
- *     when the survey ran the reference sources (range / split table, pair counts on seeded soups), and (iii) an independent
- *     O(N^2) brute force (check.cuh:117-141 restated).
+ * Pinning status.  What of the reference compiles in this image WITHOUT stand-in headers is compiled, unmodified,
+ * into oracle/_ref/ (oracle/Makefile) and its outputs are committed as fixtures the functions below must reproduce bit for bit
+ * (tests/test_oracle_pins.py):
+ *   - morton.h (plain host C++) -> libref_morton.so -> tests/golden/morton_ref.npz: orc_expand64, orc_morton3d, orc_centroid_morton
+ *     and the keys orc_sort_by_key orders (2^17 expand inputs, 2^20 in-frame points, the 10^6 centroids of BASELINE config 3);
+ *   - tri_contact.cuh, box.cuh, triangle.cuh, vec3f.cuh, mathop.cuh (g++ against the genuine <cuda_runtime.h> the image ships in its
+ *     triton wheel) -> libref_contact.so -> tests/golden/contact_ref.npz: orc_tri_contact (1 179 648 pairs, seven families),
+ *     orc_tri_contact_helper, orc_neighbor_count, box_set, box_merge, orc_box_overlap (2^20 pairs), project3 / project6 / cross / dot,
+ *     AND the end result of orc_self_collide -- pair set + pairs tested -- on BASELINE config 2 (reference side: plain O(N^2) over its
+ *     predicates), config 3, the 1 M soup and the full-double cloth;
+ *   - delta / determineRange / findSplit / hierarchy, the internal boxes of the refit and the verifier counters have NO reference-held
+ *     vector (bvh.cuh / collision.cuh / check.cuh need device intrinsics -> stand-ins -> not built).  They cannot change the pair set
+ *     (a leaf is reached iff its own box overlaps the query's) and are pinned by (i) the reference's known-answer inputs
+ *     (check.cuh:19-27), (ii) outputs SURVEY.md recorded when the survey ran the reference sources, (iii) an independent O(N^2).
  *
  * Build: gcc -O2 -std=c99 -ffp-contract=off -fPIC -shared (no FMA contraction: every decision
  * below is an FP64 compare whose operands must round exactly like the reference's host twin).
@@ -348,6 +351,58 @@ void orc_tri_contact_batch(const double *verts, const uint32_t *vidx, const uint
         uint32_t ia = ids ? ids[a] : a, ib = ids ? ids[b] : b;
         out[k] = (uint8_t)(orc_neighbor_count(vidx + 3 * (size_t)a, vidx + 3 * (size_t)b) < 1 &&
                            orc_tri_contact_helper(ia, vidx + 3 * (size_t)a, ib, vidx + 3 * (size_t)b, verts) > 0);
+    }
+}
+
+/* Batch forms of the predicates above on explicit operands: what tests/test_oracle_pins.py replays against the
+ * reference-compiled vectors of tests/golden/contact_ref.npz (layouts as oracle/ref_contact.cpp's entry points). */
+void orc_tri_contact_points_batch(const double *tri, uint64_t n, int32_t *out)
+{
+    for (uint64_t k = 0; k < n; ++k) {
+        const double *t = tri + 18 * k;
+        out[k] = orc_tri_contact(t, t + 3, t + 6, t + 9, t + 12, t + 15);
+    }
+}
+void orc_helper_batch(const double *verts, const uint32_t *va, const uint32_t *ida, const uint32_t *vb, const uint32_t *idb,
+                      uint64_t n, int32_t *out)
+{
+    for (uint64_t k = 0; k < n; ++k) out[k] = orc_tri_contact_helper(ida[k], va + 3 * k, idb[k], vb + 3 * k, verts);
+}
+void orc_neighbor_count_batch(const uint32_t *va, const uint32_t *vb, uint64_t n, int32_t *out)
+{
+    for (uint64_t k = 0; k < n; ++k) out[k] = orc_neighbor_count(va + 3 * k, vb + 3 * k);
+}
+void orc_box_set_batch(const double *verts, const uint32_t *vidx, uint64_t n, double *out)
+{
+    for (uint64_t k = 0; k < n; ++k)
+        box_set(out + 6 * k, verts + 3 * (size_t)vidx[3 * k], verts + 3 * (size_t)vidx[3 * k + 1], verts + 3 * (size_t)vidx[3 * k + 2]);
+}
+void orc_box_merge_batch(const double *a, const double *b, uint64_t n, double *out)
+{
+    for (uint64_t k = 0; k < n; ++k) box_merge(out + 6 * k, a + 6 * k, b + 6 * k);
+}
+void orc_box_overlap_batch(const double *a, const double *b, uint64_t n, int32_t *out)
+{
+    for (uint64_t k = 0; k < n; ++k) out[k] = orc_box_overlap(a + 6 * k, b + 6 * k);
+}
+static inline v3 v3at(const double *p) { v3 r = { p[0], p[1], p[2] }; return r; }
+void orc_project3_batch(const double *v, uint64_t n, int32_t *out)
+{
+    for (uint64_t k = 0; k < n; ++k) { const double *t = v + 12 * k; out[k] = project3(v3at(t), v3at(t + 3), v3at(t + 6), v3at(t + 9)); }
+}
+void orc_project6_batch(const double *v, uint64_t n, int32_t *out)
+{
+    for (uint64_t k = 0; k < n; ++k) {
+        const double *t = v + 21 * k;
+        out[k] = project6(v3at(t), v3at(t + 3), v3at(t + 6), v3at(t + 9), v3at(t + 12), v3at(t + 15), v3at(t + 18));
+    }
+}
+void orc_cross_dot_batch(const double *v, uint64_t n, double *cross_out, double *dot_out)
+{
+    for (uint64_t k = 0; k < n; ++k) {
+        v3 a = v3at(v + 6 * k), b = v3at(v + 6 * k + 3), c = v3cross(a, b);
+        cross_out[3 * k] = c.x; cross_out[3 * k + 1] = c.y; cross_out[3 * k + 2] = c.z;
+        dot_out[k] = v3dot(a, b);
     }
 }
 

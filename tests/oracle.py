@@ -59,6 +59,14 @@ def lib(omp: bool = False) -> C.CDLL:
     L.orc_neighbor_count.argtypes = [vp, vp]; L.orc_neighbor_count.restype = C.c_int
     L.orc_tri_contact.argtypes = [vp] * 6; L.orc_tri_contact.restype = C.c_int
     L.orc_tri_contact_batch.argtypes = [vp, vp, vp, vp, C.c_uint64, vp]; L.orc_tri_contact_batch.restype = None
+    for f, k in ((L.orc_tri_contact_points_batch, 3), (L.orc_helper_batch, 7), (L.orc_neighbor_count_batch, 4), (L.orc_box_set_batch, 4),
+                 (L.orc_box_merge_batch, 4), (L.orc_box_overlap_batch, 4), (L.orc_project3_batch, 3), (L.orc_project6_batch, 3),
+                 (L.orc_cross_dot_batch, 4)):
+        f.argtypes = [vp] * k; f.restype = None
+    for f, pos in ((L.orc_tri_contact_points_batch, 1), (L.orc_helper_batch, 5), (L.orc_neighbor_count_batch, 2), (L.orc_box_set_batch, 2),
+                   (L.orc_box_merge_batch, 2), (L.orc_box_overlap_batch, 2), (L.orc_project3_batch, 1), (L.orc_project6_batch, 1),
+                   (L.orc_cross_dot_batch, 1)):
+        a = list(f.argtypes); a[pos] = C.c_uint64; f.argtypes = a
     L.orc_find_collisions.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_uint64, C.POINTER(OrcStats)]
     L.orc_find_collisions.restype = None
     L.orc_find_collisions_queries.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_uint32, vp, C.c_uint64, C.POINTER(OrcStats)]
@@ -181,6 +189,61 @@ def tri_contact_batch(verts, vidx, pairs, ids=None):
     out = np.zeros(pairs.shape[0], dtype=np.uint8)
     lib().orc_tri_contact_batch(_p(verts), _p(vidx), _p(ids), _p(pairs), pairs.shape[0], _p(out))
     return out
+
+
+# ---- batch forms of the predicates on explicit operands (replayed against tests/golden/contact_ref.npz)
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _cu32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def tri_contact_points(tri):
+    tri = _c64(tri).reshape(-1, 18); out = np.zeros(tri.shape[0], dtype=np.int32)
+    lib().orc_tri_contact_points_batch(_p(tri), tri.shape[0], _p(out)); return out
+
+
+def helper_batch(verts, va, ida, vb, idb):
+    verts, va, ida, vb, idb = _c64(verts), _cu32(va), _cu32(ida), _cu32(vb), _cu32(idb)
+    out = np.zeros(va.shape[0], dtype=np.int32)
+    lib().orc_helper_batch(_p(verts), _p(va), _p(ida), _p(vb), _p(idb), va.shape[0], _p(out)); return out
+
+
+def neighbor_count_batch(va, vb):
+    va, vb = _cu32(va), _cu32(vb); out = np.zeros(va.shape[0], dtype=np.int32)
+    lib().orc_neighbor_count_batch(_p(va), _p(vb), va.shape[0], _p(out)); return out
+
+
+def box_set_batch(verts, vidx):
+    verts, vidx = _c64(verts), _cu32(vidx); out = np.zeros((vidx.shape[0], 6), dtype=np.float64)
+    lib().orc_box_set_batch(_p(verts), _p(vidx), vidx.shape[0], _p(out)); return out
+
+
+def box_merge_batch(a, b):
+    a, b = _c64(a), _c64(b); out = np.zeros_like(a)
+    lib().orc_box_merge_batch(_p(a), _p(b), a.shape[0], _p(out)); return out
+
+
+def box_overlap_batch(a, b):
+    a, b = _c64(a), _c64(b); out = np.zeros(a.shape[0], dtype=np.int32)
+    lib().orc_box_overlap_batch(_p(a), _p(b), a.shape[0], _p(out)); return out
+
+
+def project3_batch(v):
+    v = _c64(v); out = np.zeros(v.shape[0], dtype=np.int32)
+    lib().orc_project3_batch(_p(v), v.shape[0], _p(out)); return out
+
+
+def project6_batch(v):
+    v = _c64(v); out = np.zeros(v.shape[0], dtype=np.int32)
+    lib().orc_project6_batch(_p(v), v.shape[0], _p(out)); return out
+
+
+def cross_dot_batch(v):
+    v = _c64(v); cr = np.zeros((v.shape[0], 3), dtype=np.float64); dt = np.zeros(v.shape[0], dtype=np.float64)
+    lib().orc_cross_dot_batch(_p(v), v.shape[0], _p(cr), _p(dt)); return cr, dt
 
 
 def find_collisions(verts, vidx, perm, left, right, boxes, ids=None, cap=1 << 22):

@@ -1256,3 +1256,76 @@ def test_multi_step_box_of_the_triangles_ignores_unreferenced_vertices():
                     assert rc == 0 and info.local_pairs == nl and info.cross_pairs == nl
                     assert np.array_equal(oracle.pair_set(pairs[:nl]), oracle.pair_set(r["pairs"]))
                     assert np.array_equal(cd.root_box().view(np.uint64), r["boxes"][0].view(np.uint64))     # what the step published == node 0's box
+
+
+# Reference-COMPILED exact-test vectors and END RESULTS (tests/golden/contact_ref.npz, made by the reference's tri_contact.cuh /
+# box.cuh / triangle.cuh / vec3f.cuh compiled unmodified in the build container; see tests/test_oracle_pins.py) against the
+# device functions and against cd_self_collide with default options on BASELINE configs 2 and 3.
+import contact_inputs as ci  # noqa: E402
+from test_oracle_pins import check_end_result, end_mesh, _unbits  # noqa: E402
+
+
+def test_device_exact_test_equals_reference_compiled_vectors():
+    ref = np.load(os.path.join(GOLD, "contact_ref.npz"))
+    tri, fam = ci.tri_pairs()
+    n = tri.shape[0]
+    assert n >= 1_000_000 and ci.sha(tri) == str(ref["tri_in_sha"])
+    want = _unbits(ref["tri_contact_bits"], n)
+    got = mi355cd.tri_contact_points(tri)                                               # tri_contact.cuh:19-78, 1 179 648 pairs
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, (bad[:8], fam[bad[:8]])
+    # the same pairs through cd_test_pairs (the vertex fetch + ID rule + neighbour gate around it): triangles 2k, 2k+1 of one context
+    verts = tri.reshape(-1, 3)
+    vidx = np.arange(6 * n, dtype=np.uint32).reshape(2 * n, 3)
+    pairs = np.arange(2 * n, dtype=np.uint32).reshape(n, 2)
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        assert np.array_equal(cd.test_pairs(pairs).astype(np.int32), want)
+        assert not cd.test_pairs(pairs[:4096, ::-1].copy()).any()                       # ID rule, tri_contact.cuh:81
+    # indexed pairs: checkTriangleContactHelper + Triangle::neighborCount, IDs equal / reversed / ordered
+    pv, va, ida, vb, idb = ci.indexed_pairs()
+    m = va.shape[0]
+    helper = _unbits(ref["helper_bits"], m); nc = ref["neighbor"].astype(np.int32)
+    with mi355cd.CollisionDetector(pv, np.concatenate([va, vb]), np.concatenate([ida, idb])) as cd:
+        got = cd.test_pairs(np.stack([np.arange(m), np.arange(m) + m], axis=1).astype(np.uint32)).astype(np.int32)
+    assert np.array_equal(got, ((nc < 1) & (helper > 0)).astype(np.int32))              # collision.cuh:36-37
+    assert 1000 < int(got.sum()) < int(helper.sum())                                    # the neighbour gate removes some of the helper's hits
+
+
+def test_device_boxes_equal_reference_compiled_vectors():
+    ref = np.load(os.path.join(GOLD, "contact_ref.npz"))
+    a, b = ci.box_pairs()
+    assert ci.sha(np.concatenate([a, b])) == str(ref["box_in_sha"])
+    ov, _ = mi355cd.box_pairs(a, b, want_merged=False)                                  # box.cuh:40-43, 1 048 576 pairs
+    assert np.array_equal(ov.astype(np.int32), _unbits(ref["box_overlap_bits"], a.shape[0]))
+    # Box::set as the leaf boxes of a built tree, Box::merge on the reference's operands
+    pv, va, ida, vb, idb = ci.indexed_pairs()
+    m = va.shape[0]
+    both = np.concatenate([va, vb])
+    with mi355cd.CollisionDetector(pv, both) as cd:
+        cd.set_morton_frame(mi355cd.CD_FRAME_AUTO, None, None)
+        cd.build_tree()
+        keys, perm = cd.export_keys()
+        parent, left, right, boxes, bounded = cd.export_tree()
+    leaf = np.zeros((2 * m, 6), dtype=np.float64)
+    leaf[perm] = boxes[2 * m - 1:]
+    assert ci.sha(leaf) == str(ref["box_set_sha"]) and np.array_equal(leaf[:4096].view(np.uint64), ref["box_set_head"].view(np.uint64))
+    _, mg = mi355cd.box_pairs(leaf[:m], leaf[m:])
+    assert ci.sha(mg) == str(ref["box_merge_sha"]) and np.array_equal(mg[:4096].view(np.uint64), ref["box_merge_head"].view(np.uint64))
+
+
+@pytest.mark.parametrize("name", ["soup100k", "cloth1M", "soup1M", "cloth1M_double"])
+def test_self_collide_default_options_equals_reference_compiled_end_result(name):
+    """cd_self_collide with the library's default options, two consecutive steps: the pair set (SHA-256 of the sorted keys, every
+    64th key, the full list where the fixture holds it) and pairs_tested equal what the REFERENCE'S compiled predicates give for
+    BASELINE config 2 (plain O(N^2) on the reference side), config 3, the 1 M soup and config 3 with full-double vertices."""
+    ref = np.load(os.path.join(GOLD, "contact_ref.npz"))
+    verts, vidx = end_mesh(name)
+    assert ci.sha(verts) == str(ref[name + "_verts_sha"]) and ci.sha(vidx) == str(ref[name + "_vidx_sha"])
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        for step in range(2):
+            pairs, n, rc = cd.self_collide(cap=1 << 22)
+            assert rc == 0
+            check_end_result(ref, name, pairs, cd.stats().pairs_tested)
+        if name == "soup100k":                                                         # and the device's own all-pairs pass (check.cuh:117-141)
+            bp, bn, _ = cd.brute_force(box_filter=True)
+            check_end_result(ref, name, bp, cd.stats().pairs_tested)

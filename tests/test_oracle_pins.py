@@ -311,3 +311,140 @@ def test_fixture_is_what_the_reference_build_produces_now(morton_ref, tmp_path):
     L.ref_morton3D.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]; L.ref_morton3D.restype = None
     L.ref_morton3D(pts.ctypes.data_as(C.c_void_p), pts.shape[0], k.ctypes.data_as(C.c_void_p))
     assert mi.sha(k) == str(morton_ref["points_keys_sha"])
+
+
+# ---------------------------------------------------------------- pins against the REFERENCE'S OWN OBJECT CODE: the exact test
+# tests/golden/contact_ref.npz holds what the reference's tri_contact.cuh:19-87, box.cuh:13-43, triangle.cuh:18-30,
+# vec3f.cuh:118-125,257-291 (+ mathop.cuh:17-44), compiled UNMODIFIED by g++ against the genuine <cuda_runtime.h> this image
+# ships, return for the recipes of tests/contact_inputs.py -- and, for BASELINE configs 2 and 3 (+ the 1 M soup and the
+# full-double cloth), the END RESULT: the pair set and the pairs-tested count that follow from those predicates alone
+# (collision.cuh:31-44 is only their sequence; the tree cannot change the set).  Generator: tests/golden/make_contact_ref.py.
+import contact_inputs as ci  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def contact_ref():
+    return np.load(os.path.join(GOLD, "contact_ref.npz"))
+
+
+def _unbits(packed, n):
+    return np.unpackbits(packed)[:n].astype(np.int32)
+
+
+def test_ref_compiled_layouts(contact_ref):
+    assert contact_ref["sizes"].tolist() == [24, 56, 56]              # vec3f, Triangle, Box as the reference's compiler lays them out
+
+
+def test_ref_compiled_tri_contact(contact_ref):
+    """checkTriangleContact on 1 179 648 pairs in seven families (float-valued, full doubles, exactly coplanar, touching,
+    shared vertex positions, degenerate, integer lattice): every answer equals the reference-compiled one."""
+    tri, fam = ci.tri_pairs()
+    assert tri.shape[0] >= 1000000 and ci.sha(tri) == str(contact_ref["tri_in_sha"])
+    want = _unbits(contact_ref["tri_contact_bits"], tri.shape[0])
+    got = oracle.tri_contact_points(tri)
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, (bad[:8], fam[bad[:8]])
+    assert [int(got[fam == f].sum()) for f in range(len(ci.FAMILIES))] == contact_ref["tri_contact_per_family"].tolist()
+    for f in range(len(ci.FAMILIES)):                                  # every family decides both ways somewhere (or is all-contact by construction)
+        assert got[fam == f].any()
+    assert (got[fam == 0] == 0).any() and (got[fam == 2] == 0).any() and (got[fam == 5] == 0).any() and (got[fam == 6] == 0).any()
+
+
+def test_ref_compiled_helper_and_neighbor_count(contact_ref):
+    verts, va, ida, vb, idb = ci.indexed_pairs()
+    blob = np.concatenate([verts.view(np.uint8).ravel(), va.view(np.uint8).ravel(), ida.view(np.uint8), vb.view(np.uint8).ravel(), idb.view(np.uint8)])
+    assert ci.sha(blob) == str(contact_ref["indexed_in_sha"])
+    n = va.shape[0]
+    assert np.array_equal(oracle.helper_batch(verts, va, ida, vb, idb), _unbits(contact_ref["helper_bits"], n))
+    nc = oracle.neighbor_count_batch(va, vb)
+    assert np.array_equal(nc, contact_ref["neighbor"].astype(np.int32))
+    assert set(np.unique(nc).tolist()) >= {0, 1, 2, 3, 4}             # repeats inside a triangle push the count past 3 (triangle.cuh:19-29)
+    assert (ida >= idb).any() and (ida < idb).any()                    # the ID rule, tri_contact.cuh:81, on both sides
+
+
+def test_ref_compiled_boxes(contact_ref):
+    """Box::set / Box::merge bit patterns and checkBoxOverlap on 2^20 pairs (touching faces, zero thickness, identical)."""
+    verts, va, ida, vb, idb = ci.indexed_pairs()
+    n = va.shape[0]
+    bs = oracle.box_set_batch(verts, np.concatenate([va, vb]))
+    assert np.array_equal(bs[:4096].view(np.uint64), contact_ref["box_set_head"].view(np.uint64)) and ci.sha(bs) == str(contact_ref["box_set_sha"])
+    bm = oracle.box_merge_batch(bs[:n], bs[n:])
+    assert np.array_equal(bm[:4096].view(np.uint64), contact_ref["box_merge_head"].view(np.uint64)) and ci.sha(bm) == str(contact_ref["box_merge_sha"])
+    a, b = ci.box_pairs()
+    assert a.shape[0] >= 1000000 and ci.sha(np.concatenate([a, b])) == str(contact_ref["box_in_sha"])
+    want = _unbits(contact_ref["box_overlap_bits"], a.shape[0])
+    got = oracle.box_overlap_batch(a, b)
+    assert np.array_equal(got, want)
+    touching = ((a[:, 1] == b[:, 0]) | (b[:, 1] == a[:, 0])) & (a[:, 1] > a[:, 0]) & (b[:, 1] > b[:, 0])
+    assert touching.sum() > 10000 and not got[touching].any()          # a shared face is NOT an overlap (strict '>', box.cuh:41)
+    flat = (a[:, 0] == a[:, 1]) | (a[:, 2] == a[:, 3]) | (a[:, 4] == a[:, 5])
+    assert flat.sum() > 10000                                          # zero-thickness boxes are in the set ...
+    assert np.array_equal(oracle.box_overlap_batch(a[flat], a[flat]), np.zeros(int(flat.sum()), dtype=np.int32))   # ... and never overlap themselves
+
+
+def test_ref_compiled_vec3f_helpers(contact_ref):
+    v4, v7, v2 = ci.small_vectors()
+    assert ci.sha(np.concatenate([v4.ravel(), v7.ravel(), v2.ravel()])) == str(contact_ref["small_in_sha"])
+    assert np.array_equal(oracle.project3_batch(v4), _unbits(contact_ref["project3_bits"], v4.shape[0]))
+    assert np.array_equal(oracle.project6_batch(v7), _unbits(contact_ref["project6_bits"], v7.shape[0]))
+    cr, dt = oracle.cross_dot_batch(v2)
+    assert np.array_equal(cr.view(np.uint64), contact_ref["cross"].view(np.uint64)) and np.array_equal(dt.view(np.uint64), contact_ref["dot"].view(np.uint64))
+
+
+def check_end_result(ref, name, pairs, pairs_tested):
+    """pairs / pairs_tested of one run against the reference-compiled END RESULT of config `name` (shared with the GPU tests)."""
+    keys = ci.pair_keys(pairs)
+    assert keys.size == int(ref[name + "_count"]), (name, keys.size, int(ref[name + "_count"]))
+    assert int(pairs_tested) == int(ref[name + "_tested"]), (name, int(pairs_tested), int(ref[name + "_tested"]))
+    assert np.array_equal(keys[::ci.SAMPLE_STRIDE], ref[name + "_sample"])
+    if name + "_pairs" in ref.files:
+        assert np.array_equal(keys, ref[name + "_pairs"])
+    assert ci.sha(keys) == str(ref[name + "_pairs_sha"])
+
+
+def end_mesh(name):
+    for n, mesh, _ in ci.end_configs():
+        if n == name:
+            return mesh
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["soup100k", "cloth1M", "soup1M", "cloth1M_double"])
+def test_ref_compiled_end_result(contact_ref, name):
+    """The oracle's whole pipeline (Morton build + traversal, orc_self_collide) returns the reference-compiled pair set and
+    pairs-tested count on BASELINE config 2 (100 k soup; the reference side is a plain O(N^2) over its predicates),
+    config 3 (1 M cloth), the 1 M soup and the full-double cloth."""
+    verts, vidx = end_mesh(name)
+    assert ci.sha(verts) == str(contact_ref[name + "_verts_sha"]) and ci.sha(vidx) == str(contact_ref[name + "_vidx_sha"])
+    pairs, st, _ = oracle.self_collide(verts, vidx)
+    assert st.overflow == 0
+    check_end_result(contact_ref, name, pairs, st.pairs_tested)
+
+
+def test_ref_compiled_end_result_brute_force_agrees(contact_ref):
+    """The oracle's own O(N^2) (check.cuh:117-141 restated, box filter on) against the same fixture: config 2's first 20 000
+    triangles cannot be cut out of the fixture, so this runs the full 100 k only through the tree (above) and checks here that
+    brute force == tree on a prefix, closing the triangle oracle-tree == reference-compiled == oracle-brute."""
+    verts, vidx = end_mesh("soup100k")
+    sub = vidx[:12000]
+    bp, bn, bt = oracle.brute_force(verts, sub)
+    tp, st, _ = oracle.self_collide(verts, sub)
+    assert np.array_equal(ci.pair_keys(bp), ci.pair_keys(tp)) and bt == st.pairs_tested
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "libref_contact.so")),
+                    reason="oracle/_ref exists only in the build container (the reference does not travel)")
+def test_contact_fixture_is_what_the_reference_build_produces_now(contact_ref):
+    """Build container only: the committed fixture equals a fresh run of the reference-compiled library (tri_contact, all pairs)."""
+    import ctypes as C
+    L = C.CDLL(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "libref_contact.so"))
+    tri, _ = ci.tri_pairs()
+    r = np.zeros(tri.shape[0], dtype=np.int32)
+    L.ref_tri_contact.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]; L.ref_tri_contact.restype = None
+    L.ref_tri_contact(tri.ctypes.data_as(C.c_void_p), tri.shape[0], r.ctypes.data_as(C.c_void_p))
+    assert ci.sha(r.astype(np.uint8)) == str(contact_ref["tri_contact_sha"])
+    a, b = ci.box_pairs()
+    o = np.zeros(a.shape[0], dtype=np.int32)
+    L.ref_box_overlap.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]; L.ref_box_overlap.restype = None
+    L.ref_box_overlap(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), a.shape[0], o.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(np.packbits(o.astype(np.uint8)), contact_ref["box_overlap_bits"])
