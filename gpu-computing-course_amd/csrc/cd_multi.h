@@ -541,7 +541,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     if (fast_path) {
         HostCounters h0 = {}, h1 = {};
         parse_report(c, t0, h0, pairs, spec0);
-        need_general_l = h0.max_shard_candidates > t0.cand_cap / NSHARD || h0.n_deferred > 0;
+        need_general_l = shards_overflowed(t0, h0) || h0.n_deferred > 0;
         if (!need_general_l) {
             n_local = h0.n_pairs; tested += h0.pairs_tested;
             const uint64_t ncopy = std::min<uint64_t>(n_local, cap);
@@ -550,7 +550,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         }
         if (recvd) {
             parse_report(c, t1, h1, m->scratch_pairs.data(), spec1);
-            need_general_x = h1.max_shard_candidates > t1.cand_cap / NSHARD || h1.n_deferred > 0;
+            need_general_x = shards_overflowed(t1, h1) || h1.n_deferred > 0;
         } else need_general_x = false;
         if (recvd && !need_general_x && !need_general_l) {
             n_cross = h1.n_pairs; tested += h1.pairs_tested;

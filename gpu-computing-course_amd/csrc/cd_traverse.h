@@ -15,7 +15,9 @@ struct alignas(128) CtrShard {
     unsigned long long node_visits;
     unsigned long long n_candidates;   // candidates reserved in this shard of the candidate buffer (may exceed its capacity)
     unsigned long long wave_steps;     // descent-loop iterations summed over waves (lane utilisation = node_visits / (64 * wave_steps))
-    unsigned long long pad[12];
+    unsigned long long pad[12];        // [4] / [11]: the descent's own clock (earliest start as its complement, latest end); the rest: diagnostics (DIAG builds of the kernels)
+    unsigned long long n_items;        // split half traversal: (query, subtree) items reserved in this shard of the item buffer (may exceed its capacity); own line
+    unsigned long long pad2[15];
 };
 struct alignas(128) TravState {
     unsigned long long n_pairs;        // collision.cuh:40 `count`
@@ -24,7 +26,7 @@ struct alignas(128) TravState {
     unsigned long long pad[14];
     CtrShard shard[NSHARD];
 };
-static_assert(sizeof(CtrShard) == 128 && sizeof(TravState) == 128 * (NSHARD + 1), "counter layout");
+static_assert(sizeof(CtrShard) == 256 && sizeof(TravState) == 128 + 256 * NSHARD, "counter layout");
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {
@@ -41,6 +43,7 @@ struct alignas(256) Report {
     double root_box[6];
     unsigned long long clk_start_inv, clk_end;   // descent kernel, device wall clock (s_memrealtime ticks): ~(earliest wave start), latest wave end; 0 = not taken
     unsigned long long seq;                      // polled completion: the step's sequence number, stored LAST (0: this report does not take part)
+    unsigned long long max_shard_items;          // split half traversal: the fullest item shard's reservation
 };
 static_assert(sizeof(Report) == 256, "report layout");
 
@@ -49,8 +52,8 @@ static_assert(sizeof(Report) == 256, "report layout");
 // DMA copy (whose set-up idles the GPU for ~12 us and runs ~5 us).  Block 0 / wave 0 writes the record.
 // Polled completion (seq != 0): the host does not wait for the stream at all -- it spins on Report::seq in its own memory.  Every
 // workgroup makes its part visible to the host (system-scope fence), then arrives on a device counter; the last one to arrive
-// stores the sequence number with a system-scope release.  The counter is never reset inside a step: a second report of the same
-// step (deep pass) finds it at a multiple of the grid size.
+// stores the sequence number with a system-scope release (the memory-model argument: DESIGN.md section 6), after putting the counter back
+// to zero for the next report (of this step -- the deep pass, whose grid may differ -- or of the next one).
 constexpr int REPORT_THREADS = 256;
 __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__restrict__ st, const uint32_t *__restrict__ sort_flags /* 9 words */,
                                                            const double *__restrict__ root_box, Report *__restrict__ out,
@@ -58,24 +61,22 @@ __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__re
                                                            unsigned long long seq)
 {
     const unsigned long long np = st->n_pairs;
-#ifdef REPORT_NO_ORDER                                                   // (negative control of tools/poll_stress.py: the word goes out FIRST -- the stress must see pairs missing)
-    if (seq != 0ull && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { out->n_pairs = np; __threadfence_system(); __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-#endif
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         const int lane = threadIdx.x;                                   // NSHARD == 64: lane = shard
         const CtrShard sh = st->shard[lane];
         const unsigned long long tested = wave_sum_u64(sh.pairs_tested), visits = wave_sum_u64(sh.node_visits);
         const unsigned long long steps = wave_sum_u64(sh.wave_steps), cands = wave_sum_u64(sh.n_candidates);
-        unsigned long long mx = sh.n_candidates, c0 = sh.pad[4], c1 = sh.pad[11];
+        unsigned long long mx = sh.n_candidates, mi = sh.n_items, c0 = sh.pad[4], c1 = sh.pad[11];
         for (int o = 32; o; o >>= 1) {
             const unsigned long long u = __shfl_xor(mx, o); mx = u > mx ? u : mx;
+            const unsigned long long ui = __shfl_xor(mi, o); mi = ui > mi ? ui : mi;
             const unsigned long long u0 = __shfl_xor(c0, o); c0 = u0 > c0 ? u0 : c0;
             const unsigned long long u1 = __shfl_xor(c1, o); c1 = u1 > c1 ? u1 : c1;
         }
         if (lane == 0) {
             out->n_pairs = np; out->pairs_tested = tested; out->node_visits = visits; out->max_shard_candidates = mx;
             out->wave_steps = steps; out->candidates = cands; out->n_deferred = st->n_deferred;
-            out->clk_start_inv = c0; out->clk_end = c1;
+            out->clk_start_inv = c0; out->clk_end = c1; out->max_shard_items = mi;
         }
         if (lane < 9) out->sort_flags[lane] = sort_flags[lane];
         if (lane < 6) out->root_box[lane] = root_box[lane];
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__re
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t old = atomicAdd(const_cast<uint32_t *>(&st->report_arrive), 1u);
-        if (old % gridDim.x == gridDim.x - 1u) {
+        if (old == gridDim.x - 1u) {                                    // the last workgroup to arrive
+            atomicExch(const_cast<uint32_t *>(&st->report_arrive), 0u);  // a second report of the same step (deep pass, another grid size) starts from zero
             __threadfence_system();
             __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -545,40 +547,45 @@ __global__ __launch_bounds__(DESC_THREADS) void k_descend(QuerySrc src, uint32_t
 constexpr int HALF_STACK = 8;                // LDS stack entries per lane
 constexpr int HALF_QCAP = 192;               // candidate queue slots per wave
 constexpr uint32_t HALF_FLUSH_AT = HALF_QCAP - 64;   // an enqueue adds at most 64 candidates: drain before it when more than this are waiting
+constexpr int HALF_IQCAP = 256;              // split mode: (lane, subtree) items waiting in LDS per wave (takes the place of the private stacks: 2 KB)
+constexpr uint32_t HALF_IFLUSH_AT = HALF_IQCAP - 64;
 
 // (one wave per workgroup: the waves of this kernel never meet -- no barrier, wave-private LDS -- and a workgroup holds its
 //  slot until its SLOWEST wave is done; with the work per query as uneven as it is, single-wave workgroups give the slots
 //  back sooner: 53.8 -> 52.4 us at 1 M triangles.  Two waves: 53.2 us)
-#ifndef HALF_T
-#define HALF_T 64
-#endif
-constexpr int HALF_THREADS = HALF_T, HALF_WAVES = HALF_THREADS / 64;
+constexpr int HALF_THREADS = 64;
+constexpr int HALF_XSUB = 4;                 // see the XCD mapping below
+
+// Split mode (HALF_CHAIN + k_descend_items): the chain kernel does not descend what it hits.  A wave's 64 lanes need between 0 and ~45
+// descent steps each (1 M cloth: 9.7 steps a wave at 18 of 64 lanes busy, and a wave holds its slot until its slowest lane is done),
+// so every internal sibling a chain hits becomes a 32-byte ITEM -- the query's fp32 box, its index, the subtree -- in the workgroup's
+// shard of a global item buffer (LDS queue per wave, one reservation atomic per hand-over, as the candidates), and a second kernel
+// works the items off with every lane busy: tools/sim/pool_sim.py, profiles/r04_experiments/model_item_pool.log.
+struct alignas(16) SubItem { float lo0, lo1, lo2, hi0, hi1, hi2; uint32_t q /* bit 31 (CAND_CERTAIN): the query box is exact in fp32 */; int32_t node; };
+static_assert(sizeof(SubItem) == 32, "item layout");
+
+enum { HALF_FUSED = 0, HALF_CHAIN = 1 };
+template <int MODE, bool DIAG>
 __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
                                                                   TravState *__restrict__ st,
                                                                   Candidates *__restrict__ cand, unsigned long long shard_cap,
-                                                                  uint2 *__restrict__ defer_list, uint32_t defer_cap, uint32_t diag)
+                                                                  uint2 *__restrict__ defer_list, uint32_t defer_cap,
+                                                                  SubItem *__restrict__ items, unsigned long long item_shard_cap)
 {
     const uint32_t bad_sort = sort_flags_or(src);      // looked at after phase 0 (whose loads are in bounds whatever the tree is): see sort_flags_or
-#ifdef CD_ABLATE       // TIMING EXPERIMENTS ONLY, never in the shipped build (tools/ab_build.sh abl -DCD_ABLATE; tools/exp_descent_ablation.py): parts of the
-    const uint32_t ablate = diag >> 8;   // kernel switched off by debug key 103, bits 8..: 1 no descent, 2 no shared chain, 4 no in-wave hops, 8 no candidate
-    diag &= 0xffu;                       // hand-over, 16 no record loads for the query box, 32 no counters.  Results are wrong by construction.
-#else
-    constexpr uint32_t ablate = 0u;
-#endif
     // The kernel times ITSELF with the device's constant-rate wall clock (s_memrealtime): first wave start -> last wave end, two
     // sharded atomicMax per wave (the start as its complement, so that the zeroed counters need no initial value).  A HIP time
     // stamp on the dispatch packet costs the step ~7 us of idle GPU around the kernel; this costs it nothing measurable.
     const unsigned long long clk0 = __builtin_amdgcn_s_memrealtime();
-    __shared__ int32_t lds_stack[HALF_STACK][HALF_THREADS];
-    __shared__ Candidates queue[HALF_WAVES][HALF_QCAP];
-    __shared__ uint8_t share_map[HALF_WAVES][64];      // work sharing: lane id of the k-th donor
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr bool CHAIN = MODE == HALF_CHAIN;
+    __shared__ int32_t lds_stack[CHAIN ? 1 : HALF_STACK][HALF_THREADS];
+    __shared__ uint2 iqueue[CHAIN ? HALF_IQCAP : 1];   // split mode: (lane of the query, subtree) waiting for the hand-over
+    __shared__ Candidates queue[HALF_QCAP];
+    __shared__ uint8_t share_map[64];                  // work sharing: lane id of the k-th donor
+    const uint32_t lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t dg_p1a = 0, dg_p1 = 0, dg_hops_in = 0, dg_hops_out = 0, dg_vis = 0;   // diagnostics (diag != 0)
-    const uint32_t nb = ((uint32_t)n + 64u * HALF_WAVES - 1u) / (64u * HALF_WAVES), per = nb >> 3;       // (= gridDim.x, without the load of the hidden argument) XCD-aware mapping, see k_descend
-#ifndef HALF_XSUB
-#define HALF_XSUB 4
-#endif
+    uint32_t dg_p1a = 0, dg_p1 = 0, dg_hops_in = 0, dg_hops_out = 0, dg_vis = 0;   // diagnostics (DIAG)
+    const uint32_t nb = ((uint32_t)n + 63u) / 64u, per = nb >> 3;       // (= gridDim.x, without the load of the hidden argument) XCD-aware mapping, see k_descend
     uint32_t vblock = (blockIdx.x < (per << 3)) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
     // ... as HALF_XSUB chunks from different parts of the mesh rather than ONE contiguous eighth: the work per query is not
     // even over a mesh (where the surfaces meet, a query has candidates; elsewhere none), and an XCD with a busy eighth
@@ -595,13 +602,14 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     const uint32_t nq = (uint32_t)n, last_leaf = nq - 1u;
     constexpr uint32_t END = 0xffffffffu;
     // the wave owns the 64 consecutive leaves [g0, g_last]  (wave-uniform; readfirstlane tells the compiler)
-    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((vblock * HALF_WAVES + w) * 64u));
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(vblock * 64u));
     const uint32_t g_last = (g0 + 63u < last_leaf) ? g0 + 63u : last_leaf;
     uint32_t qi = g0 + lane;
     const bool valid = qi < nq && n > 1;
-    unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0, tm4 = 0;           // diagnostics: s_memtime stamps at the phase boundaries
-    if (diag) tm0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0, tm4 = 0;           // DIAG: s_memtime stamps at the phase boundaries
+    if constexpr (DIAG) tm0 = __builtin_amdgcn_s_memtime();
     uint32_t qcount = 0;                                // wave-uniform: candidates waiting in the queue
+    uint32_t icount = 0;                                // wave-uniform: items waiting in the queue (split mode)
     uint32_t tested = 0, steps = 0;
     uint32_t wvisits = 0;                               // wave-uniform: node visits of the whole wave (a popcount of the active mask per step: two scalar instructions, no per-lane add)
     int sptr = 0;
@@ -612,7 +620,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         Candidates cd0 = Candidates{0, 0};
         bool keep = lane < count;
-        if (keep) cd0 = queue[w][qcount - count + lane];
+        if (keep) cd0 = queue[qcount - count + lane];
         if (keep && (cd0.leaf & CAND_CERTAIN)) {
             tested += 2u;                                                      // collision.cuh:31-32, decided exactly by the descent, both directions
             const LeafTri lt = src.leaf[cd0.leaf & CAND_LEAF_MASK];
@@ -635,13 +643,43 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
         if (m == 0ull) return;
         while (qcount > HALF_FLUSH_AT) flush(64);
-        if (c) queue[w][qcount + __popcll(m & lt_mask)] = Candidates{q, leafword};
+        if (c) queue[qcount + __popcll(m & lt_mask)] = Candidates{q, leafword};
         qcount += __popcll(m);
     };
-    auto push_subtree = [&](int32_t link) {                                   // an internal sibling / child that was hit: descended in phase 2
-        if (ablate & 1u) return;                                              // TIMING EXPERIMENT ONLY (wrong results): phase 1 alone
-        if (sptr < HALF_STACK) { lds_stack[sptr][tid] = link; ++sptr; }
-        else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)link); }
+    float qlo0, qlo1, qlo2, qhi0, qhi1, qhi2; uint32_t qcertain;
+    // split mode: hand the last `count` (<= 64) queued items over, one per lane; the item's box comes out of its query's lane
+    // (in the chain kernel lane l holds query g0 + l from start to end)
+    auto iflush = [&](uint32_t count) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint2 it = make_uint2(0u, 0u);
+        const bool have = lane < count;
+        if (have) it = iqueue[icount - count + lane];
+        icount -= count;
+        const int from = (int)(it.x << 2);
+        SubItem si;
+        si.lo0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(qlo0))); si.lo1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(qlo1)));
+        si.lo2 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(qlo2))); si.hi0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(qhi0)));
+        si.hi1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(qhi1))); si.hi2 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(qhi2)));
+        si.q = (g0 + it.x) | (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)qcertain);
+        si.node = (int32_t)it.y;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&sh->n_items, (unsigned long long)count);
+        base = __shfl(base, 0) + lane;
+        if (have && base < item_shard_cap) items[(size_t)(blockIdx.x & (NSHARD - 1)) * item_shard_cap + base] = si;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    // an internal sibling / child that was hit (`c`, per lane): split mode -> an item; else onto the lane's stack, descended in phase 2
+    auto note_subtree = [&](bool c, int32_t link) {
+        if constexpr (CHAIN) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
+            if (m == 0ull) return;
+            while (icount > HALF_IFLUSH_AT) iflush(64);
+            if (c) iqueue[icount + __popcll(m & lt_mask)] = make_uint2(lane, (uint32_t)link);
+            icount += __popcll(m);
+        } else if (c) {
+            if (sptr < HALF_STACK) { lds_stack[sptr][lane] = link; ++sptr; }
+            else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)link); }
+        }
     };
     // ---- the query box comes out of the RECORDS, not out of qbox[]: leaf j is the left child of recs[j] (then that
     // record's left link is ~j) or else the right child of recs[j - 1] -- every s is the split of exactly one node
@@ -649,11 +687,10 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     // right half of recs[j] anyway (phase 1a), the right half of recs[j - 1] is in the neighbour lane, and the left
     // halves are what phase 2 reads next: 32 bytes per leaf less from HBM than with a separate query array.
     // The last leaf has no record of its own: it is the right child of recs[n - 2].
-    float qlo0, qlo1, qlo2, qhi0, qhi1, qhi2; uint32_t qcertain;
     float4 rc = make_float4(0.f, 0.f, 0.f, 0.f), rd = rc;
     {
         float4 la = rc, lb = rc, pc = rc, pd = rc;
-        const bool own = valid && qi < last_leaf && !(ablate & 16u);
+        const bool own = valid && qi < last_leaf;
         if (own) { const float4 *rp = rec_right(recs, n, qi); rc = rp[0]; rd = rp[1]; const float4 *lp = rec_left(recs, n, qi); la = lp[0]; lb = lp[1]; }
         {   // the right half of recs[qi - 1]: the neighbour lane's registers (DPP wave_shr:1, a VALU move); lane 0 gets the
             // record before the wave's first one through the scalar cache (wave-uniform address)
@@ -675,11 +712,10 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         if (valid && !exact) { const Box b = load_box(src.boxes, (n - 1) + (int)qi); self = box_overlap(b, b); }
         if (valid && self) ++tested;
     }
-    if (diag) tm1 = __builtin_amdgcn_s_memtime();
+    if constexpr (DIAG) tm1 = __builtin_amdgcn_s_memtime();
     if (bad_sort) return;                               // (wave-uniform) keys not sorted: the links may have cycles or point anywhere; the host redoes the step
     // ---- phase 1a: hops below g_last
     uint32_t s = valid ? qi : END;                                            // cursor; >= g_last: joined the shared chain (or has none: g_last == n-1)
-    if (ablate & 4u) s = valid ? g_last : END;
     for (int hop = 0; hop < 128; ++hop) {                                     // tree height <= 96: the bound only matters for a corrupt tree
         const bool act = s < g_last;
         const unsigned long long m_act1 = __builtin_amdgcn_ballot_w64(act);
@@ -694,18 +730,18 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         const bool hit = act & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
         const int32_t link = __float_as_int(d.z);
         const uint32_t lw = __float_as_uint(d.w);
-        if (diag) dg_hops_in += act ? 1u : 0u;
-        if (band(hit, link >= 0)) push_subtree(link);
+        if constexpr (DIAG) dg_hops_in += act ? 1u : 0u;
+        note_subtree(band(hit, link >= 0), link);
         s = act ? (lw & REC_LAST_MASK) : s;
         enqueue(band(hit, link < 0), qi, (uint32_t)~link | ((lw & REC_R_EXACT) ? qcertain : 0u));
     }
     dg_p1a = steps;
-    if (diag) tm2 = __builtin_amdgcn_s_memtime();
+    if constexpr (DIAG) tm2 = __builtin_amdgcn_s_memtime();
     // ---- phase 1b: a lane whose cursor has reached g_last or beyond is on the chain of leaf g_last (the `last` values
     // along a root path are exactly that chain's cursors), which all lanes share from their joining point upwards: the
     // wave walks it once with SCALAR loads, and every lane that has joined tests the wave-uniform box.
     {
-        uint32_t t = (ablate & 2u) ? last_leaf : g_last;
+        uint32_t t = g_last;
         for (int hop = 0; hop < 128 && t < last_leaf; ++hop) {
             ++steps;
             const int4 *rq = reinterpret_cast<const int4 *>(rec_right(recs, n, t));    // wave-uniform address: scalar loads
@@ -716,81 +752,78 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
             const int32_t link = d.z;                                         // wave-uniform
             const uint32_t lw = (uint32_t)d.w;
             wvisits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(act));
-            if (diag) dg_hops_out += act ? 1u : 0u;
-            if (link >= 0) { if (hit) push_subtree(link); }
+            if constexpr (DIAG) dg_hops_out += act ? 1u : 0u;
+            if (link >= 0) note_subtree(hit, link);
             else enqueue(hit, qi, (uint32_t)~link | ((lw & REC_R_EXACT) ? qcertain : 0u));
             t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lw & REC_LAST_MASK));
         }
     }
     dg_p1 = steps;
-    if (diag) tm3 = __builtin_amdgcn_s_memtime();
-    // ---- phase 2: descend the sibling subtrees that were hit
-    int32_t node = -1;
-    if (sptr > 0) { --sptr; node = lds_stack[sptr][tid]; }
-    while (true) {
-        // work sharing inside the wave (see k_descend): a busy lane hands the top of its stack, with its query, to an idle lane
-        if (SHARE_MIN_IDLE <= 64) {
-            const bool idle = (node == -1), donor = (node != -1) & (sptr > 0);
-            const unsigned long long m_idle = __builtin_amdgcn_ballot_w64(idle), m_don = __builtin_amdgcn_ballot_w64(donor);
-            if (m_don != 0ull && __popcll(m_idle) >= SHARE_MIN_IDLE) {        // (wave-uniform)
-                const uint32_t nx = min((uint32_t)__popcll(m_don), (uint32_t)__popcll(m_idle));
-                const uint32_t rank_d = __popcll(m_don & lt_mask), rank_r = __popcll(m_idle & lt_mask);
-                const bool give = donor & (rank_d < nx), take = idle & (rank_r < nx);
-                int32_t top = -1;
-                if (give) { share_map[w][rank_d] = (uint8_t)lane; --sptr; top = lds_stack[sptr][tid]; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const int from = take ? (int)share_map[w][rank_r] : (int)lane;
-                const int32_t e = __shfl(top, from);
-                const uint32_t s_qi = __shfl(qi, from), s_cert = __shfl(qcertain, from);
-                const float f0 = __shfl(qlo0, from), f1 = __shfl(qlo1, from), f2 = __shfl(qlo2, from);
-                const float f3 = __shfl(qhi0, from), f4 = __shfl(qhi1, from), f5 = __shfl(qhi2, from);
-                if (take) { node = e; qi = s_qi; qcertain = s_cert; qlo0 = f0; qlo1 = f1; qlo2 = f2; qhi0 = f3; qhi1 = f4; qhi2 = f5; sptr = 0; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if constexpr (DIAG) tm3 = __builtin_amdgcn_s_memtime();
+    if constexpr (CHAIN) {
+        while (icount > 0) iflush(icount < 64u ? icount : 64u);
+    } else {
+        // ---- phase 2: descend the sibling subtrees that were hit
+        int32_t node = -1;
+        if (sptr > 0) { --sptr; node = lds_stack[sptr][lane]; }
+        while (true) {
+            // work sharing inside the wave (see k_descend): a busy lane hands the top of its stack, with its query, to an idle lane
+            if (SHARE_MIN_IDLE <= 64) {
+                const bool idle = (node == -1), donor = (node != -1) & (sptr > 0);
+                const unsigned long long m_idle = __builtin_amdgcn_ballot_w64(idle), m_don = __builtin_amdgcn_ballot_w64(donor);
+                if (m_don != 0ull && __popcll(m_idle) >= SHARE_MIN_IDLE) {        // (wave-uniform)
+                    const uint32_t nx = min((uint32_t)__popcll(m_don), (uint32_t)__popcll(m_idle));
+                    const uint32_t rank_d = __popcll(m_don & lt_mask), rank_r = __popcll(m_idle & lt_mask);
+                    const bool give = donor & (rank_d < nx), take = idle & (rank_r < nx);
+                    int32_t top = -1;
+                    if (give) { share_map[rank_d] = (uint8_t)lane; --sptr; top = lds_stack[sptr][lane]; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const int from = take ? (int)share_map[rank_r] : (int)lane;
+                    const int32_t e = __shfl(top, from);
+                    const uint32_t s_qi = __shfl(qi, from), s_cert = __shfl(qcertain, from);
+                    const float f0 = __shfl(qlo0, from), f1 = __shfl(qlo1, from), f2 = __shfl(qlo2, from);
+                    const float f3 = __shfl(qhi0, from), f4 = __shfl(qhi1, from), f5 = __shfl(qhi2, from);
+                    if (take) { node = e; qi = s_qi; qcertain = s_cert; qlo0 = f0; qlo1 = f1; qlo2 = f2; qhi0 = f3; qhi1 = f4; qhi2 = f5; sptr = 0; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+            }
+            const bool active = (node != -1);
+            const unsigned long long m_act2 = __builtin_amdgcn_ballot_w64(active);
+            if (m_act2 == 0ull) break;
+            ++steps; wvisits += (uint32_t)__popcll(m_act2);
+            // one descent step per active lane, straight-line selects (see k_descend)
+            // (idle lanes fetch record 0 and ignore it: one select for the address instead of fifteen register clears)
+            const uint32_t rn = active ? (uint32_t)node : 0u;
+            const float4 *rpl = rec_left(recs, n, rn), *rpr = rec_right(recs, n, rn);
+            const float4 a = rpl[0], b = rpl[1], c = rpr[0], d = rpr[1];
+            const int32_t cl = __float_as_int(b.z), cr = __float_as_int(d.z);
+            const uint32_t lw = __float_as_uint(d.w);
+            const bool ol  = active & (qlo0 < a.w) & (a.x < qhi0) & (qlo1 < b.x) & (a.y < qhi1) & (qlo2 < b.y) & (a.z < qhi2);
+            const bool orr = active & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
+            if constexpr (DIAG) dg_vis += active ? 1u : 0u;
+            const bool intL = band(ol, cl >= 0), intR = band(orr, cr >= 0);
+            int32_t nxt = intL ? cl : (intR ? cr : -1);
+            note_subtree(band(intL, intR), cr);                                // both internal: descend left, push right
+            if (band(band(active, !bor(intL, intR)), sptr > 0)) { --sptr; nxt = lds_stack[sptr][lane]; }
+            node = active ? nxt : -1;
+            const bool candL = band(ol, cl < 0), candR = band(orr, cr < 0);
+            if (__builtin_amdgcn_ballot_w64(bor(candL, candR)) != 0ull) {        // (most steps meet no leaf: one test instead of two)
+                enqueue(candL, qi, (uint32_t)~cl | ((lw & REC_L_EXACT) ? qcertain : 0u));
+                enqueue(candR, qi, (uint32_t)~cr | ((lw & REC_R_EXACT) ? qcertain : 0u));
             }
         }
-        const bool active = (node != -1);
-        const unsigned long long m_act2 = __builtin_amdgcn_ballot_w64(active);
-        if (m_act2 == 0ull) break;
-        ++steps; wvisits += (uint32_t)__popcll(m_act2);
-        // one descent step per active lane, straight-line selects (see k_descend)
-        // (idle lanes fetch record 0 and ignore it: one select for the address instead of fifteen register clears)
-        const uint32_t rn = active ? (uint32_t)node : 0u;
-        const float4 *rpl = rec_left(recs, n, rn), *rpr = rec_right(recs, n, rn);
-        const float4 a = rpl[0], b = rpl[1], c = rpr[0], d = rpr[1];
-        const int32_t cl = __float_as_int(b.z), cr = __float_as_int(d.z);
-        const uint32_t lw = __float_as_uint(d.w);
-        const bool ol  = active & (qlo0 < a.w) & (a.x < qhi0) & (qlo1 < b.x) & (a.y < qhi1) & (qlo2 < b.y) & (a.z < qhi2);
-        const bool orr = active & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
-        if (diag) dg_vis += active ? 1u : 0u;
-        const bool intL = band(ol, cl >= 0), intR = band(orr, cr >= 0);
-        int32_t nxt = intL ? cl : (intR ? cr : -1);
-        if (band(intL, intR)) push_subtree(cr);                            // both internal: descend left, push right
-        if (band(band(active, !bor(intL, intR)), sptr > 0)) { --sptr; nxt = lds_stack[sptr][tid]; }
-        node = active ? nxt : -1;
-        const bool candL = band(ol, cl < 0), candR = band(orr, cr < 0);
-        if (__builtin_amdgcn_ballot_w64(bor(candL, candR)) != 0ull) {        // (most steps meet no leaf: one test instead of two)
-            enqueue(candL, qi, (uint32_t)~cl | ((lw & REC_L_EXACT) ? qcertain : 0u));
-            enqueue(candR, qi, (uint32_t)~cr | ((lw & REC_R_EXACT) ? qcertain : 0u));
-        }
     }
-    if (diag) tm4 = __builtin_amdgcn_s_memtime();
-    if (ablate & 8u) qcount = 0;
+    if constexpr (DIAG) tm4 = __builtin_amdgcn_s_memtime();
     while (qcount > 0) flush(qcount < 64u ? qcount : 64u);
     const unsigned long long t64 = wave_sum_u64(tested), v64 = wvisits;
-    if (lane == 0 && !(ablate & 32u)) {
+    if (lane == 0) {
         if (t64) atomicAdd(&sh->pairs_tested, t64);
         if (v64) atomicAdd(&sh->node_visits, v64);
         if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
-    }
-    if (lane == 0) {
         if (blockIdx.x < 256u) atomicMax(&sh->pad[4], ~clk0);                  // (the earliest start is among the first workgroups dispatched)
-        const unsigned long long clk1 = __builtin_amdgcn_s_memrealtime();
-        atomicMax(&sh->pad[11], clk1);
-#ifdef CD_ABLATE                                                               // experiment builds only: every wave's start / end tick, read back by cd_debug_wave_times
-        if ((ablate & 128u) && blockIdx.x < defer_cap) defer_list[blockIdx.x] = make_uint2(((uint32_t)clk0 & 0xffffu) | ((uint32_t)clk1 << 16), (steps & 0xffu) | ((dg_p1 & 0xffu) << 8) | ((dg_p1a & 0xffu) << 16) | (min(wvisits >> 2, 255u) << 24));
-#endif
+        if constexpr (!CHAIN) atomicMax(&sh->pad[11], __builtin_amdgcn_s_memrealtime());   // (split mode: the item kernel's waves end the descent)
     }
-    if (diag) {
+    if constexpr (DIAG) {
         const unsigned long long hi = wave_sum_u64(dg_hops_in), ho = wave_sum_u64(dg_hops_out), vi = wave_sum_u64(dg_vis);
         const unsigned long long tm5 = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
@@ -802,79 +835,51 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     }
 }
 
-// ====================================================================================================
-// Variant E (CD_OPT_TRAVERSAL 4; NOT the default -- measured slower than variant D, see the end of this comment): the half traversal with a WORKGROUP-shared frontier for the descent.
-//   Phases 0 / 1a / 1b are variant D's, wave by wave (query box out of the records; right-sibling chain walked bottom-up:
-//   in-wave hops over registers, then the shared chain over scalar loads).  What changes is phase 2.  In variant D a lane
-//   descends the sibling subtrees ITS query hit, depth first over a private LDS stack: 2.8 node visits per query, but a
-//   wave runs as many steps as its deepest lane needs -- 9.7 steps at 18 of 64 lanes busy (1 M cloth) -- and the kernel's time
-//   is the instructions it issues, busy lane or not.  Here every (query, subtree) item a chain hit produces goes onto ONE ring
-//   in LDS per workgroup of WGF_WAVES x 64 consecutive queries, compacted with __ballot / popcount prefixes (one LDS atomic per wave
-//   and push), and the workgroup works the frontier off LEVEL by level: wave w takes items [64 w, 64 w + 64) of the level, every
-//   lane one item -- the item's query box comes out of LDS, the node's record out of memory -- and the children that are hit go
-//   onto the ring as the next level.  A level of 150 items costs three full wave-steps instead of a step of every wave: the
-//   CPU model of this scheme (tools/sim/bfs_sim.py) gives 4.7 wave-steps per 64 queries at 256 queries per workgroup against
-//   9.9 for the private descent, 12.5 levels per workgroup.  One barrier per level: the level counters rotate through three
-//   words (level L is counted in cnt[L % 3], filled during level L - 1, cleared during level L + 1), so no wave can read a
-//   count another wave is already adding to.  A frontier that outgrows the ring (dense contact) overflows, item by item, into
-//   the deferred list of the deep pass, as a full private stack did.
-//   MEASURED (profiles/r03_experiments/variant4_workgroup_frontier_ab.log): 86 us against variant D's 62 us with stage events on
-//   (1 M cloth) -- the steps are fewer, but every level is a workgroup barrier and an LDS round trip of the items, and the
-//   levels of a workgroup are as many as its deepest query needs.  Kept as a selectable variant with full parity coverage.
-// ====================================================================================================
-#ifndef WGF_WAVES
-#define WGF_WAVES 4
-#endif
-constexpr int WGF_THREADS = 64 * WGF_WAVES;
-constexpr uint32_t WGF_RING = 256u * WGF_WAVES;          // items; a power of two
-constexpr int WGF_QCAP = 192;                           // candidate queue slots per wave
-constexpr uint32_t WGF_FLUSH_AT = WGF_QCAP - 128;       // a descent step enqueues at most 2 x 64 candidates
-struct WgItem { uint32_t q; int32_t node; };             // q: query index inside the workgroup
-
-__global__ __launch_bounds__(WGF_THREADS) void k_descend_wg(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
-                                                            TravState *__restrict__ st,
-                                                            Candidates *__restrict__ cand, unsigned long long shard_cap,
-                                                            uint2 *__restrict__ defer_list, uint32_t defer_cap, uint32_t diag)
+// The item kernel of the split half traversal: workgroup b (one wave) works off chunk b / 64 of shard b % 64 of the item buffer -- the
+// shard the chain kernel's workgroups with the same index modulo 64 filled, i.e. items of ITS XCD (workgroups are dealt round-robin
+// over the 8 XCDs): what the chain kernel left in that L2, items and records, is what this wave reads.
+// A descent step is a dependent round trip to a record that is rarely in the L2 (~0.8 us with the chip full), so what a wave's time
+// comes to is the number of steps it makes one after the other -- not the lanes that are busy in them.  A lane walking ITS item depth
+// first makes as many steps as the item's subtree has nodes that are hit (4.5 on average, 45 at most); here the wave keeps ONE frontier
+// of (item, node) entries in LDS and every step takes up to 64 entries off it, whoever's item they belong to (the item's box comes
+// out of its owner lane's registers through the LDS crossbar): the steps of a wave are then the LEVELS of its deepest item, ~10.
+// Children that are hit go back onto the frontier (ballot-compacted); leaves become candidates as everywhere.  A frontier that outgrows
+// its LDS (dense contact) overflows, entry by entry, into the deferred list of the deep pass, as a full private stack does.
+constexpr int ITEM_CHUNK = 64;                // items per wave: item l lives in lane l's registers
+constexpr uint32_t ITEM_FR_CAP = 384;         // frontier entries per wave (3 KB): <= 256 waiting + at most 128 new per step
+__global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_items(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
+                                                                   TravState *__restrict__ st,
+                                                                   Candidates *__restrict__ cand, unsigned long long shard_cap,
+                                                                   uint2 *__restrict__ defer_list, uint32_t defer_cap,
+                                                                   const SubItem *__restrict__ items, unsigned long long item_shard_cap)
 {
-    if (sort_failed(src)) return;
-    __shared__ WgItem ring[WGF_RING];
-    __shared__ float4 qbox_lds[WGF_THREADS][2];           // {lo.xyz, hi.x}, {hi.y, hi.z, certain, -}
-    __shared__ Candidates queue[WGF_WAVES][WGF_QCAP];
-    __shared__ uint32_t cnt[4];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t shard = blockIdx.x & (NSHARD - 1);
+    CtrShard *sh = &st->shard[shard];
+    unsigned long long have = sh->n_items;              // (scalar load; written by the chain kernel, which is complete)
+    if (have > item_shard_cap) have = item_shard_cap;   // (an overflowing shard: the host grows the buffer and redoes the step)
+    const unsigned long long begin = (unsigned long long)(blockIdx.x >> 6) * ITEM_CHUNK;
+    if (begin >= have) return;
+    const uint32_t count = (uint32_t)(begin + ITEM_CHUNK < have ? ITEM_CHUNK : have - begin);
+    const float4 *my = reinterpret_cast<const float4 *>(items + (size_t)shard * item_shard_cap + begin);
+    __shared__ uint2 fr[ITEM_FR_CAP];                   // (owner lane, node)
+    __shared__ Candidates queue[HALF_QCAP];
+    const uint32_t lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    if (tid < 4) cnt[tid] = 0u;
-    const uint32_t nb = gridDim.x, per = nb >> 3;         // XCD-aware mapping, see k_descend_half
-    uint32_t vblock = (blockIdx.x < (per << 3)) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
-    {
-        const uint32_t c = per / 4u;
-        if (c > 0 && blockIdx.x < c * 4u * 8u) { const uint32_t x = blockIdx.x & 7u, l = blockIdx.x >> 3, sub = l / c, off = l % c; vblock = (sub * 8u + x) * c + off; }
-        else if (c > 0) vblock = blockIdx.x;
-    }
-    CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
-    Candidates *my_cand = cand + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_cap;
-    const uint32_t nq = (uint32_t)n, last_leaf = nq - 1u;
-    constexpr uint32_t END = 0xffffffffu;
-    const uint32_t wg0 = vblock * (uint32_t)WGF_THREADS;                      // first leaf of the workgroup
-    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + w * 64u));
-    const uint32_t g_last = (g0 + 63u < last_leaf) ? g0 + 63u : last_leaf;
-    const uint32_t qi = g0 + lane;
-    const bool valid = qi < nq && n > 1;
-    uint32_t qcount = 0;                                // wave-uniform: candidates waiting in this wave's queue
-    uint32_t tested = 0, visits = 0, steps = 0;
-    auto flush = [&](uint32_t count) {
+    Candidates *my_cand = cand + (size_t)shard * shard_cap;
+    uint32_t qcount = 0, tested = 0, steps = 0, wvisits = 0;
+    auto flush = [&](uint32_t cnt) {                    // as in k_descend_half
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         Candidates cd0 = Candidates{0, 0};
-        bool keep = lane < count;
-        if (keep) cd0 = queue[w][qcount - count + lane];
+        bool keep = lane < cnt;
+        if (keep) cd0 = queue[qcount - cnt + lane];
         if (keep && (cd0.leaf & CAND_CERTAIN)) {
-            tested += 2u;                                                      // collision.cuh:31-32, decided exactly by the descent, both directions
+            tested += 2u;
             const LeafTri lt = src.leaf[cd0.leaf & CAND_LEAF_MASK];
             const LeafTri ql = src.leaf[cd0.q];
-            keep = neighbor_count(ql.v0, ql.v1, ql.v2, lt.v0, lt.v1, lt.v2) < 1 && ql.id != lt.id;   // collision.cuh:38, tri_contact.cuh:81
+            keep = neighbor_count(ql.v0, ql.v1, ql.v2, lt.v0, lt.v1, lt.v2) < 1 && ql.id != lt.id;
             cd0.leaf |= CAND_FILTERED;
         }
-        qcount -= count;
+        qcount -= cnt;
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(keep);
         if (mk != 0ull) {
             unsigned long long base = 0;
@@ -887,257 +892,65 @@ __global__ __launch_bounds__(WGF_THREADS) void k_descend_wg(QuerySrc src, int n,
     auto enqueue = [&](bool c, uint32_t q, uint32_t leafword) {
         const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
         if (m == 0ull) return;
-        while (qcount > WGF_QCAP - 64u) flush(64);
-        if (c) queue[w][qcount + __popcll(m & lt_mask)] = Candidates{q, leafword};
+        while (qcount > HALF_FLUSH_AT) flush(64);
+        if (c) queue[qcount + __popcll(m & lt_mask)] = Candidates{q, leafword};
         qcount += __popcll(m);
     };
-    // an internal node some query's box overlaps -> one item of the frontier level counted in *counter (room for `room` items, the
-    // ring minus the level still being read); beyond that, the deep pass's list
-    auto push_items = [&](bool c, uint32_t qlocal, int32_t link, int counter, uint32_t base_pos, uint32_t room) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
-        if (m == 0ull) return;
-        uint32_t b = 0;
-        if (lane == (uint32_t)__builtin_ctzll(m)) b = atomicAdd(&cnt[counter], (uint32_t)__popcll(m));     // (an LDS atomic: ds_add_rtn_u32)
-        b = (uint32_t)__builtin_amdgcn_readlane((int)b, __builtin_ctzll(m)) + (uint32_t)__popcll(m & lt_mask);
-        if (c) {
-            if (b < room) ring[(base_pos + b) & (WGF_RING - 1u)] = WgItem{qlocal, link};
-            else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(wg0 + qlocal, (uint32_t)link); }
-        }
-    };
-    // ---- phase 0: the query box out of the records (see k_descend_half)
-    float qlo0, qlo1, qlo2, qhi0, qhi1, qhi2; uint32_t qcertain;
-    float4 rc = make_float4(0.f, 0.f, 0.f, 0.f), rd = rc;
-    {
-        float4 la = rc, lb = rc, pc = rc, pd = rc;
-        const bool own = valid && qi < last_leaf;
-        if (own) { const float4 *rp = rec_right(recs, n, qi); rc = rp[0]; rd = rp[1]; const float4 *lp = rec_left(recs, n, qi); la = lp[0]; lb = lp[1]; }
-        {
-            int4 e0 = make_int4(0, 0, 0, 0), e1 = e0;
-            if (g0 > 0u && g0 <= last_leaf && n > 1) { const int4 *pp = reinterpret_cast<const int4 *>(rec_right(recs, n, g0 - 1u)); e0 = pp[0]; e1 = pp[1]; }
-            auto shr1 = [](float v, int edge) { return __int_as_float(__builtin_amdgcn_update_dpp(edge, __float_as_int(v), 0x138, 0xf, 0xf, false)); };
-            pc.x = shr1(rc.x, e0.x); pc.y = shr1(rc.y, e0.y); pc.z = shr1(rc.z, e0.z); pc.w = shr1(rc.w, e0.w);
-            pd.x = shr1(rd.x, e1.x); pd.y = shr1(rd.y, e1.y); pd.z = shr1(rd.z, e1.z); pd.w = shr1(rd.w, e1.w);
-        }
-        const bool is_left = own && __float_as_int(lb.z) == (int32_t)~qi;
-        qlo0 = is_left ? la.x : pc.x; qlo1 = is_left ? la.y : pc.y; qlo2 = is_left ? la.z : pc.z;
-        qhi0 = is_left ? la.w : pc.w; qhi1 = is_left ? lb.x : pd.x; qhi2 = is_left ? lb.y : pd.y;
-        const bool exact = is_left ? (__float_as_uint(rd.w) & REC_L_EXACT) != 0u : (__float_as_uint(pd.w) & REC_R_EXACT) != 0u;
-        qcertain = exact ? CAND_CERTAIN : 0u;
-        bool self = exact & (qlo0 < qhi0) & (qlo1 < qhi1) & (qlo2 < qhi2);
-        if (valid && !exact) { const Box b = load_box(src.boxes, (n - 1) + (int)qi); self = box_overlap(b, b); }
-        if (valid && self) ++tested;
-        qbox_lds[tid][0] = make_float4(qlo0, qlo1, qlo2, qhi0);
-        qbox_lds[tid][1] = make_float4(qhi1, qhi2, __uint_as_float(qcertain), 0.f);
-    }
-    __syncthreads();                                                          // cnt[] is zero before the first push
-    // ---- phase 1a: hops below g_last (registers of the wave)
-    uint32_t s = valid ? qi : END;
-    for (int hop = 0; hop < 128; ++hop) {
-        const bool act = s < g_last;
-        if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
-        ++steps;
-        const int from = (int)((act ? (s - g0) : lane) << 2);
-        float4 c, d;
-        c.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.x))); c.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.y)));
-        c.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.z))); c.w = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rc.w)));
-        d.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.x))); d.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.y)));
-        d.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.z))); d.w = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(rd.w)));
-        const bool hit = act & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
-        const int32_t link = __float_as_int(d.z);
+    // ---- lane l takes item l of the chunk; the frontier starts with the items' subtrees
+    float4 i0 = make_float4(0.f, 0.f, 0.f, 0.f), i1 = i0;
+    if (lane < count) { i0 = my[2 * lane]; i1 = my[2 * lane + 1]; fr[lane] = make_uint2(lane, __float_as_uint(i1.w)); }
+    const int mlo0 = __float_as_int(i0.x), mlo1 = __float_as_int(i0.y), mlo2 = __float_as_int(i0.z), mhi0 = __float_as_int(i0.w), mhi1 = __float_as_int(i1.x), mhi2 = __float_as_int(i1.y);
+    const int mq = __float_as_int(i1.z);
+    uint32_t fcount = count;                            // wave-uniform: entries on the frontier
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    while (fcount > 0u) {
+        const uint32_t take = fcount < 64u ? fcount : 64u;
+        const bool active = lane < take;
+        uint2 e = make_uint2(0u, 0u);
+        if (active) e = fr[fcount - take + lane];       // the newest entries first: the frontier stays short
+        fcount -= take;
+        ++steps; wvisits += take;
+        const float4 *rpl = rec_left(recs, n, e.y), *rpr = rec_right(recs, n, e.y);       // (idle lanes fetch record 0 and ignore it)
+        const float4 a = rpl[0], b = rpl[1], c = rpr[0], d = rpr[1];
+        const int from = (int)(e.x << 2);
+        const float qlo0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, mlo0)), qlo1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, mlo1));
+        const float qlo2 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, mlo2)), qhi0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, mhi0));
+        const float qhi1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, mhi1)), qhi2 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, mhi2));
+        const uint32_t qw = (uint32_t)__builtin_amdgcn_ds_bpermute(from, mq);
+        const uint32_t qi = qw & CAND_LEAF_MASK, qcertain = qw & CAND_CERTAIN;
+        const int32_t cl = __float_as_int(b.z), cr = __float_as_int(d.z);
         const uint32_t lw = __float_as_uint(d.w);
-        visits += act ? 1u : 0u;
-        push_items(band(hit, link >= 0), tid, link, 0, 0u, WGF_RING);
-        s = act ? (lw & REC_LAST_MASK) : s;
-        enqueue(band(hit, link < 0), qi, (uint32_t)~link | ((lw & REC_R_EXACT) ? qcertain : 0u));
-    }
-    // ---- phase 1b: the shared chain above the wave (scalar loads)
-    {
-        uint32_t t = g_last;
-        for (int hop = 0; hop < 128 && t < last_leaf; ++hop) {
-            ++steps;
-            const int4 *rq = reinterpret_cast<const int4 *>(rec_right(recs, n, t));
-            const int4 c = rq[0], d = rq[1];
-            const bool act = s <= t;
-            const bool hit = act & (qlo0 < __int_as_float(c.w)) & (__int_as_float(c.x) < qhi0) & (qlo1 < __int_as_float(d.x)) &
-                             (__int_as_float(c.y) < qhi1) & (qlo2 < __int_as_float(d.y)) & (__int_as_float(c.z) < qhi2);
-            const int32_t link = d.z;                                         // wave-uniform
-            const uint32_t lw = (uint32_t)d.w;
-            visits += act ? 1u : 0u;
-            if (link >= 0) push_items(hit, tid, link, 0, 0u, WGF_RING);
-            else enqueue(hit, qi, (uint32_t)~link | ((lw & REC_R_EXACT) ? qcertain : 0u));
-            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lw & REC_LAST_MASK));
-        }
-    }
-    // ---- phase 2: the workgroup's frontier, level by level
-    uint32_t start = 0u, room = WGF_RING;
-    for (int level = 0; level < 4096; ++level) {
-        __syncthreads();
-        uint32_t c = cnt[level % 3];
-        c = c < room ? c : room;                                              // (what did not fit went to the deferred list)
-        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-        if (c == 0u) break;
-        if (tid == 0) cnt[(level + 2) % 3] = 0u;                              // the word the NEXT level's pushes will count in
-        const int next = (level + 1) % 3;
-        const uint32_t next_room = WGF_RING - c, next_start = start + c;
-        for (uint32_t base = w * 64u; base < c; base += (uint32_t)WGF_THREADS) {
-            const uint32_t idx = base + lane;
-            const bool active = idx < c;
-            ++steps;
-            const WgItem it = ring[(start + (active ? idx : base)) & (WGF_RING - 1u)];
-            const float4 qa = qbox_lds[it.q][0], qb = qbox_lds[it.q][1];
-            const uint32_t rn = (uint32_t)it.node;
-            const float4 *rpl = rec_left(recs, n, rn), *rpr = rec_right(recs, n, rn);
-            const float4 a = rpl[0], b = rpl[1], cc = rpr[0], d = rpr[1];
-            const int32_t cl = __float_as_int(b.z), cr = __float_as_int(d.z);
-            const uint32_t lw = __float_as_uint(d.w), qc = __float_as_uint(qb.z);
-            const bool ol  = active & (qa.x < a.w) & (a.x < qa.w) & (qa.y < b.x) & (a.y < qb.x) & (qa.z < b.y) & (a.z < qb.y);
-            const bool orr = active & (qa.x < cc.w) & (cc.x < qa.w) & (qa.y < d.x) & (cc.y < qb.x) & (qa.z < d.y) & (cc.z < qb.y);
-            visits += active ? 1u : 0u;
-            push_items(band(ol, cl >= 0), it.q, cl, next, next_start, next_room);
-            push_items(band(orr, cr >= 0), it.q, cr, next, next_start, next_room);
-            const bool candL = band(ol, cl < 0), candR = band(orr, cr < 0);
-            if (__builtin_amdgcn_ballot_w64(bor(candL, candR)) != 0ull) {
-                const uint32_t gq = wg0 + it.q;
-                enqueue(candL, gq, (uint32_t)~cl | ((lw & REC_L_EXACT) ? qc : 0u));
-                enqueue(candR, gq, (uint32_t)~cr | ((lw & REC_R_EXACT) ? qc : 0u));
+        const bool ol  = active & (qlo0 < a.w) & (a.x < qhi0) & (qlo1 < b.x) & (a.y < qhi1) & (qlo2 < b.y) & (a.z < qhi2);
+        const bool orr = active & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
+        const bool intL = band(ol, cl >= 0), intR = band(orr, cr >= 0);
+        const unsigned long long mL = __builtin_amdgcn_ballot_w64(intL), mR = __builtin_amdgcn_ballot_w64(intR);
+        if ((mL | mR) != 0ull) {
+            const uint32_t nL = __popcll(mL), nR = __popcll(mR);
+            const uint32_t pL = fcount + __popcll(mL & lt_mask), pR = fcount + nL + __popcll(mR & lt_mask);
+            if (intL) {
+                if (pL < ITEM_FR_CAP) fr[pL] = make_uint2(e.x, (uint32_t)cl);
+                else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)cl); }
             }
+            if (intR) {
+                if (pR < ITEM_FR_CAP) fr[pR] = make_uint2(e.x, (uint32_t)cr);
+                else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)cr); }
+            }
+            fcount = fcount + nL + nR < ITEM_FR_CAP ? fcount + nL + nR : ITEM_FR_CAP;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-        start = next_start; room = next_room;
+        const bool candL = band(ol, cl < 0), candR = band(orr, cr < 0);
+        if (__builtin_amdgcn_ballot_w64(bor(candL, candR)) != 0ull) {
+            enqueue(candL, qi, (uint32_t)~cl | ((lw & REC_L_EXACT) ? qcertain : 0u));
+            enqueue(candR, qi, (uint32_t)~cr | ((lw & REC_R_EXACT) ? qcertain : 0u));
+        }
     }
     while (qcount > 0) flush(qcount < 64u ? qcount : 64u);
-    const unsigned long long t64 = wave_sum_u64(tested), v64 = wave_sum_u64(visits);
+    const unsigned long long t64 = wave_sum_u64(tested);
     if (lane == 0) {
         if (t64) atomicAdd(&sh->pairs_tested, t64);
-        if (v64) atomicAdd(&sh->node_visits, v64);
+        if (wvisits) atomicAdd(&sh->node_visits, (unsigned long long)wvisits);
         if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
-    }
-    (void)diag; (void)WGF_FLUSH_AT;
-}
-
-// ====================================================================================================
-// Variant C ("packet"): wavefront-shared traversal.  A wave walks the tree ONCE for its 64 Morton-adjacent
-// queries: the current node is wave-uniform, so its 64-byte record comes through the SCALAR cache
-// (s_load, no per-lane address traffic at all -- the per-lane descents above are bound by the texture
-// addresser's rate for divergent 16-byte accesses), every lane tests ITS query box against both children,
-// and a child is visited if ANY lane overlaps it (__ballot).  The DFS stack is one wave-uniform LDS array;
-// lanes that stopped overlapping a subtree simply fail the tests below it (child boxes nest, also after the
-// monotone outward rounding).  Leaf children are handled exactly as in variant B: overlapping lanes push
-// (query, leaf) candidates onto the wavefront-shared LDS queue with __ballot compaction, full batches of 64
-// go to the global candidate buffer, k_exact decides them exactly.
-// The union of nodes 64 neighbouring queries touch is a few hundred, against ~27 per query x 64 in the
-// per-lane form.  The wave-uniform stack needs at most tree-height entries (<= 96), so there is no overflow path.
-// ====================================================================================================
-constexpr int PK_STACK = 128;
-
-template <bool EXTERNAL>
-__global__ __launch_bounds__(TRAV_THREADS) void k_descend_packet(QuerySrc src, uint32_t nq, int n,
-                                                                 const NodeRec32 *__restrict__ recs, const double *__restrict__ boxes,
-                                                                 TravState *__restrict__ st,
-                                                                 Candidates *__restrict__ cand, unsigned long long shard_cap)
-{
-    if (sort_failed(src)) return;
-    __shared__ int32_t stack[WQ_WAVES][PK_STACK];
-    __shared__ Candidates queue[WQ_WAVES][WQ_QCAP];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t nb = gridDim.x, per = nb >> 3;                          // XCD-aware mapping, see k_descend
-    const uint32_t vblock = (blockIdx.x < (per << 3)) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
-    const uint32_t wave_id = vblock * WQ_WAVES + w;
-    CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
-    Candidates *cand_shard = cand + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_cap;
-    const unsigned long long q0 = (unsigned long long)wave_id * 64ull;
-    if (q0 >= nq || n < 2) return;                                         // whole wave idle (wave-uniform)
-    const uint32_t qi = (uint32_t)q0 + lane;
-    const bool valid = qi < nq;
-    uint32_t tested = 0, visits = 0, steps = 0, qcount = 0;
-    uint32_t self_leaf = 0xffffffffu;
-    // an invalid lane carries an empty box: it overlaps nothing
-    float qlo0 = 3.0e38f, qlo1 = 3.0e38f, qlo2 = 3.0e38f, qhi0 = -3.0e38f, qhi1 = -3.0e38f, qhi2 = -3.0e38f;
-    if (valid) {
-        Box qb;
-        if (EXTERNAL) {
-            const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + qi;
-            qb = box_set(d3{q->v[0], q->v[1], q->v[2]}, d3{q->v[3], q->v[4], q->v[5]}, d3{q->v[6], q->v[7], q->v[8]});
-            qlo0 = __double2float_rd(qb.x1); qhi0 = __double2float_ru(qb.x2);
-            qlo1 = __double2float_rd(qb.y1); qhi1 = __double2float_ru(qb.y2);
-            qlo2 = __double2float_rd(qb.z1); qhi2 = __double2float_ru(qb.z2);
-        } else {
-            const LeafBox32 lb = src.qbox[qi];
-            qlo0 = lb.lo[0]; qlo1 = lb.lo[1]; qlo2 = lb.lo[2]; qhi0 = lb.hi[0]; qhi1 = lb.hi[1]; qhi2 = lb.hi[2];
-            self_leaf = qi;
-            if (lb.flags & LB_SELF) ++tested;                              // the query's own leaf: decided by the refit, exactly, once
-        }
-        ++visits;                                                          // the root
-    }
-    int sptr = 0;
-    int node = *src.root;                                                  // wave-uniform (records are named by split, cd_bvh.h)
-    while (true) {
-        ++steps;
-        // Fetch the wave-uniform 64-byte record through the VECTOR path: lanes 0..15 load one dword each (one
-        // coalesced 64-byte access), then v_readlane broadcasts the 16 dwords into scalar registers.  (A scalar
-        // s_load of the record measured ~1.25 us per step here: scalar-cache misses on a 64 MB tree are slow.)
-        const int un = __builtin_amdgcn_readfirstlane(node);
-        const int rv = reinterpret_cast<const int *>((lane & 8u) ? rec_right(recs, n, (uint32_t)un) : rec_left(recs, n, (uint32_t)un))[lane & 7u];
-        struct { float l_lo[3], l_hi[3], r_lo[3], r_hi[3]; int cl, cr; } r;
-        r.l_lo[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 0));  r.l_lo[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 1));
-        r.l_lo[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 2));  r.l_hi[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 3));
-        r.l_hi[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 4));  r.l_hi[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 5));
-        r.r_lo[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 8));  r.r_lo[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 9));
-        r.r_lo[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 10)); r.r_hi[0] = __int_as_float(__builtin_amdgcn_readlane(rv, 11));
-        r.r_hi[1] = __int_as_float(__builtin_amdgcn_readlane(rv, 12)); r.r_hi[2] = __int_as_float(__builtin_amdgcn_readlane(rv, 13));
-        r.cl = __builtin_amdgcn_readlane(rv, 6); r.cr = __builtin_amdgcn_readlane(rv, 14);
-        const bool ol  = qlo0 < r.l_hi[0] && r.l_lo[0] < qhi0 && qlo1 < r.l_hi[1] && r.l_lo[1] < qhi1 && qlo2 < r.l_hi[2] && r.l_lo[2] < qhi2;
-        const bool orr = qlo0 < r.r_hi[0] && r.r_lo[0] < qhi0 && qlo1 < r.r_hi[1] && r.r_lo[1] < qhi1 && qlo2 < r.r_hi[2] && r.r_lo[2] < qhi2;
-        const unsigned long long mL = __ballot(ol), mR = __ballot(orr);
-        const bool leafL = r.cl < 0, leafR = r.cr < 0;                    // wave-uniform (leaf j is stored as ~j)
-        // ---- leaf children: candidates, compacted over the overlapping lanes
-        if ((leafL && mL) || (leafR && mR)) {
-            const uint32_t ll = (uint32_t)~r.cl, lr = (uint32_t)~r.cr;
-            const bool cL = leafL && ol && ll != self_leaf, cR = leafR && orr && lr != self_leaf;
-            const unsigned long long kL = __ballot(cL), kR = __ballot(cR);
-            const uint32_t nL = __popcll(kL);
-            if (cL) queue[w][qcount + __popcll(kL & lt_mask)] = Candidates{qi, ll};
-            if (cR) queue[w][qcount + nL + __popcll(kR & lt_mask)] = Candidates{qi, lr};
-            qcount += nL + __popcll(kR);
-            // self hits that were filtered still count as overlaps of this lane with a leaf: already counted at setup
-            while (qcount >= 64) {                                         // full batch -> global buffer, 512 B coalesced
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const Candidates cnd = queue[w][qcount - 64 + lane];
-                qcount -= 64;
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(&sh->n_candidates, 64ull);
-                base = __shfl(base, 0);
-                if (base + lane < shard_cap) cand_shard[base + lane] = cnd;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            }
-        }
-        // ---- internal children: visited if ANY lane overlaps them (wave-uniform control flow)
-        const bool goL = !leafL && mL != 0ull, goR = !leafR && mR != 0ull;
-        visits += (uint32_t)(!leafL && ol) + (uint32_t)(!leafR && orr);    // per-lane count == the per-query traversal's visits
-        if (goL && goR) {
-            if (lane == 0) stack[w][sptr] = r.cr;
-            ++sptr;                                                        // <= tree height <= 96 < PK_STACK
-            node = r.cl;
-        } else if (goL) node = r.cl;
-        else if (goR) node = r.cr;
-        else if (sptr > 0) {
-            --sptr;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            node = stack[w][sptr];
-        } else break;
-    }
-    if (qcount > 0) {                                                      // final partial batch
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&sh->n_candidates, (unsigned long long)qcount);
-        base = __shfl(base, 0);
-        if (lane < qcount && base + lane < shard_cap) cand_shard[base + lane] = queue[w][lane];
-    }
-    const unsigned long long t64 = wave_sum_u64(tested), v64 = wave_sum_u64(visits);
-    if (lane == 0) {
-        if (t64) atomicAdd(&sh->pairs_tested, t64);
-        if (v64) atomicAdd(&sh->node_visits, v64);
-        atomicAdd(&sh->wave_steps, (unsigned long long)steps);
+        atomicMax(&sh->pad[11], __builtin_amdgcn_s_memrealtime());
     }
 }
 

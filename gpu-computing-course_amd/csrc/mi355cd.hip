@@ -47,6 +47,7 @@ struct TravBuf {
     const void *direct_ptr = nullptr; uint32_t synced_direct = 0;          // the same for the caller's pinned pair buffer last written directly
     uint2 *d_defer = nullptr; uint32_t defer_cap = 0;
     Candidates *d_cand = nullptr; uint64_t cand_cap = 0;
+    SubItem *d_items = nullptr; uint64_t item_cap = 0;                     // split half traversal: (query, subtree) items, NSHARD shards of item_cap / NSHARD
     int32_t *d_deep = nullptr; uint64_t deep_items = 0;
 };
 
@@ -57,7 +58,9 @@ struct cd_ctx {
     int stage = ST_CREATED;
     int frame_mode = CD_FRAME_REFERENCE;
     uint32_t vbase = 0;
-    int trav_variant = 3;                   // CD_OPT_TRAVERSAL: 0 = lane-private FP64 (A), 1 = split fp32 descent + exact kernel (B), 2 = packet (C), 3 = half traversal (D)
+    int trav_variant = 3;                   // CD_OPT_TRAVERSAL: 0 = lane-private FP64 (A), 1 = fp32 descent from the root + exact kernel (B), 3 = half traversal (D)
+    bool split_half = false;                // CD_OPT_SPLIT_DESCENT: the half traversal as chain kernel + item kernel (k_descend_half<HALF_CHAIN> + k_descend_items)
+    uint32_t item_chunk = 128;              // CD_OPT_ITEM_CHUNK: items one wave of the item kernel works off
     uint32_t queries_per_wave = 64; 
     uint32_t dbg_no_shared_path = 0;              // debug key 102: 1 = k_descend without the shared root path (A/B)
     uint32_t dbg_diag = 0;                  // debug key 103: the descent kernels also fill the diagnostic counters (cd_debug_counters)
@@ -119,7 +122,7 @@ struct cd_ctx {
     bool dbg_poll_check = false;
     uint32_t poll_stale = 0;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
-    struct GraphKey { uint64_t cap, spec_n; int sort_mode, variant, frame_mode; uint32_t nt, exact_blocks, dbg; const void *p_pairs, *p_cand, *p_defer, *p_report; uint64_t cand_cap; uint32_t defer_cap, pad; } graph_key = {};   // (no padding bytes: compared with memcmp)
+    struct GraphKey { uint64_t cap, spec_n; int sort_mode, variant, frame_mode; uint32_t nt, exact_blocks, dbg; const void *p_pairs, *p_cand, *p_defer, *p_report, *p_items; uint64_t cand_cap, item_cap; uint32_t defer_cap, item_chunk; } graph_key = {};   // (no padding bytes: compared with memcmp)
     struct GraphPost { bool leaves_filled, leaf_records_filled, hierarchy_valid, internal_boxes_valid, last_tree_fused, events_ride, scratch_clean; uint32_t sort_passes; } graph_post = {};
     uint64_t graph_replays = 0, graph_captures = 0;
     bool all_verts_referenced = false;      // every vertex belongs to a triangle (checked at cd_create; the topology never changes afterwards)
@@ -144,7 +147,7 @@ void free_all(cd_ctx *c)
     for (TravBuf &tb : c->tb) {
         if (tb.d_pairs) hipFree(reinterpret_cast<char *>(tb.d_pairs) - sizeof(Report));
         if (tb.h_report) hipHostFree(tb.h_report);
-        hipFree(tb.d_defer); hipFree(tb.d_deep); hipFree(tb.d_cand);
+        hipFree(tb.d_defer); hipFree(tb.d_deep); hipFree(tb.d_cand); hipFree(tb.d_items);
         if (tb.state_owned) hipFree(tb.d_state);
     }
     for (int i = 0; i < 2; ++i) { hipFree(c->pp_keys[i]); hipFree(c->pp_vals[i]); }
@@ -445,12 +448,7 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
     const int n = (int)c->nt;
     hipStream_t s = c->stream;
     const uint32_t vb = EXTERNAL ? c->vbase : 0u;
-    if (c->trav_variant == 2 && !DEEP) {
-        const uint64_t shard_cap = tb.cand_cap / NSHARD;
-        k_descend_packet<EXTERNAL><<<cdiv(items, 64 * WQ_WAVES), TRAV_THREADS, c->dbg_lds_pad, s>>>(src, items, n, c->d_recs32, c->d_boxes, tb.d_state, tb.d_cand, shard_cap);
-        evrec(c, EV_DESC1);
-        k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, tb.d_cand, shard_cap, tb.d_pairs, cap_pairs, tb.d_state, 0u);
-    } else if (c->trav_variant == 0) {
+    if (c->trav_variant == 0) {
         k_traverse<EXTERNAL, DEEP><<<cdiv(items, TRAV_THREADS), TRAV_THREADS, 0, s>>>(src, items, n, c->d_meta, c->d_boxes, c->d_leaf, c->d_verts, tb.d_pairs, cap_pairs, tb.d_state,
                                                                                        DEEP ? nullptr : tb.d_defer, DEEP ? 0u : tb.defer_cap, DEEP ? tb.d_deep : nullptr, vb);
     } else {
@@ -472,14 +470,27 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         uint2 *dl = DEEP ? nullptr : tb.d_defer; const uint32_t dcap = DEEP ? 0u : tb.defer_cap; int32_t *deep = DEEP ? tb.d_deep : nullptr;
         const uint32_t half = half_mode ? 1u : 0u;
         const bool plain = !e0 && !e1 && !e2;          // no time stamp rides on these launches: plain launches (a stream capture can record them)
-        if (plain && half_mode && !DEEP && c->trav_variant == 3)
-            k_descend_half<<<cdiv(items, 64u * HALF_WAVES), HALF_THREADS, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
-        else if (half_mode && !DEEP && c->trav_variant == 4)
-            hipExtLaunchKernelGGL(k_descend_wg, dim3(cdiv(items, (uint32_t)WGF_THREADS)), dim3(WGF_THREADS), (uint32_t)pad, s, e0, e1, 0u,
-                                  src, n, (const NodeRec32 *)c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
-        else if (half_mode && !DEEP)
-            hipExtLaunchKernelGGL(k_descend_half, dim3(cdiv(items, 64u * HALF_WAVES)), dim3(HALF_THREADS), (uint32_t)pad, s, e0, e1, 0u,
-                                  src, n, (const NodeRec32 *)c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, c->dbg_diag);
+        if (half_mode && !DEEP) {
+            // the half traversal: one kernel (chain + private descent), or split into the chain kernel and the item kernel.  The
+            // time stamps ride on the first and the last launch of the descent.
+            const bool split = c->split_half && tb.d_items != nullptr;
+            const unsigned long long icap = tb.item_cap / NSHARD;
+            const dim3 hgrid(cdiv(items, 64u)), hblock(HALF_THREADS);
+            hipEvent_t e1a = split ? nullptr : e1;
+#define LAUNCH_HALF(MODE, DIAG)                                                                                                             \
+            do { if (plain) k_descend_half<MODE, DIAG><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, tb.d_items, icap); \
+                 else hipExtLaunchKernelGGL((k_descend_half<MODE, DIAG>), hgrid, hblock, (uint32_t)pad, s, e0, e1a, 0u, src, n, (const NodeRec32 *)c->d_recs32, \
+                                            tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, tb.d_items, icap); } while (0)
+            if (split) { if (c->dbg_diag) LAUNCH_HALF(HALF_CHAIN, true); else LAUNCH_HALF(HALF_CHAIN, false); }
+            else { if (c->dbg_diag) LAUNCH_HALF(HALF_FUSED, true); else LAUNCH_HALF(HALF_FUSED, false); }
+#undef LAUNCH_HALF
+            if (split) {
+                const dim3 igrid((uint32_t)(cdiv((uint32_t)icap, (uint32_t)ITEM_CHUNK) * NSHARD));
+                if (plain) k_descend_items<<<igrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, tb.d_items, icap);
+                else hipExtLaunchKernelGGL(k_descend_items, igrid, hblock, (uint32_t)pad, s, nullptr, e1, 0u, src, n, (const NodeRec32 *)c->d_recs32, tb.d_state, tb.d_cand,
+                                           (unsigned long long)shard_cap, dl, dcap, (const SubItem *)tb.d_items, icap);
+            }
+        }
         else if (qpw == 64)
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, false>), grid, dim3(DESC_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
@@ -498,7 +509,7 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
     }
 }
 
-struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_candidates; uint32_t n_deferred; uint64_t wave_steps, candidates, clk_start_inv, clk_end; };
+struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_candidates; uint32_t n_deferred; uint64_t wave_steps, candidates, clk_start_inv, clk_end, max_shard_items; };
 
 // One host round trip and NO copy: k_report writes counters, the sort's time-out flags, the root box and the first
 // spec_n pairs straight into pinned host memory.  enqueue_report queues the kernel; parse_report reads the record
@@ -565,7 +576,7 @@ int wait_report(cd_ctx *c, TravBuf &tb, unsigned long long seq)
 void parse_report(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs, uint64_t spec_n)
 {
     const Report &r = *reinterpret_cast<const Report *>(tb.h_report);
-    h = HostCounters{r.n_pairs, r.pairs_tested, r.node_visits, r.max_shard_candidates, r.n_deferred, r.wave_steps, r.candidates, r.clk_start_inv, r.clk_end};
+    h = HostCounters{r.n_pairs, r.pairs_tested, r.node_visits, r.max_shard_candidates, r.n_deferred, r.wave_steps, r.candidates, r.clk_start_inv, r.clk_end, r.max_shard_items};
     std::memcpy(c->sort_flags, r.sort_flags, sizeof c->sort_flags);
     std::memcpy(c->root_box_host, r.root_box, sizeof(double) * 6);
     if (spec_n && spec_pairs) {
@@ -599,6 +610,23 @@ int read_state(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs = n
     return 0;
 }
 
+// Did a shard of the candidate buffer or of the item buffer overflow in the pass `h` reports?  (Nothing is written past a shard; the step is redone.)
+bool shards_overflowed(const TravBuf &tb, const HostCounters &h)
+{
+    return h.max_shard_candidates > tb.cand_cap / NSHARD || (tb.d_items && h.max_shard_items > tb.item_cap / NSHARD);
+}
+int grow_candidates(cd_ctx *c, TravBuf &tb, uint64_t max_shard);
+int grow_shards(cd_ctx *c, TravBuf &tb, const HostCounters &h)
+{
+    if (h.max_shard_candidates > tb.cand_cap / NSHARD) { const int rc = grow_candidates(c, tb, h.max_shard_candidates); if (rc) return rc; }
+    if (tb.d_items && h.max_shard_items > tb.item_cap / NSHARD) {
+        hipFree(tb.d_items); tb.d_items = nullptr; tb.item_cap = 0;
+        const uint64_t want = (h.max_shard_items + h.max_shard_items / 4 + 1024) * NSHARD;
+        HIPCHK(hipMalloc(&tb.d_items, sizeof(SubItem) * want));
+        tb.item_cap = want;
+    }
+    return 0;
+}
 int grow_candidates(cd_ctx *c, TravBuf &tb, uint64_t max_shard)
 {
     hipFree(tb.d_cand); tb.d_cand = nullptr; tb.cand_cap = 0;
@@ -617,7 +645,8 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
     const uint32_t nq = external ? (uint32_t)nq_ext : n;
     int rc = ensure_pairs(c, tb, cap_pairs > 0 ? cap_pairs : 1);
     if (rc) return rc;
-    const int per_pass = c->trav_variant == 0 ? 1 : 2;
+    const int per_pass = c->trav_variant == 0 ? 1 : 2;             // descent + exact kernel; the split half traversal's shallow pass: chain + items + exact
+    const int first_pass = (c->trav_variant >= 3 && !external && c->split_half && tb.d_items) ? 3 : per_pass;
     if (c->trav_variant == 0 && !(c->internal_boxes_valid && c->hierarchy_valid)) {   // variant 0 walks meta[] and the FP64 boxes of the internal nodes
         if (!c->hierarchy_valid && (rc = enqueue_hierarchy(c, false))) return rc;
         if ((rc = enqueue_refit(c, true, false))) return rc;
@@ -638,12 +667,12 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
         const uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
         if (nq > 0) {
             if (external) launch_pass<true, false>(c, tb, src, nq, cap_pairs); else launch_pass<false, false>(c, tb, src, nq, cap_pairs);
-            launches += per_pass;
+            launches += first_pass;
         }
         if (!c->events_ride) HIPCHK(evrec(c, EV_TRAV1));      // device time of the kernels only: recorded before the read-back
         if ((rc = read_state(c, tb, h, pairs, spec_n, is_pinned_pairs(pairs, cap_pairs)))) return rc;
         spec_valid = spec_n;
-        if (h.max_shard_candidates > tb.cand_cap / NSHARD) { if ((rc = grow_candidates(c, tb, h.max_shard_candidates))) return rc; continue; }
+        if (shards_overflowed(tb, h)) { if ((rc = grow_shards(c, tb, h))) return rc; continue; }
         if (h.n_deferred > tb.defer_cap) {               // the deferred list was too small: grow it and redo (pairs restart at 0)
             hipFree(tb.d_defer); tb.d_defer = nullptr; tb.defer_cap = 0;
             HIPCHK(hipMalloc(&tb.d_defer, sizeof(uint2) * (size_t)h.n_deferred));
@@ -669,7 +698,7 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
             HIPCHK(evrec(c, EV_DEEP1));
             if ((rc = read_state(c, tb, h))) return rc;
             if (h.n_deferred != 0) return CD_ERR_ARG;    // tree deeper than DEEP_STACK: cannot happen (height <= 96)
-            if (h.max_shard_candidates > tb.cand_cap / NSHARD) { if ((rc = grow_candidates(c, tb, h.max_shard_candidates))) return rc; continue; }
+            if (shards_overflowed(tb, h)) { if ((rc = grow_shards(c, tb, h))) return rc; continue; }
             c->stats.stack_overflows = nd;
             deep_ms = elapsed(c, EV_DEEP0, EV_DEEP1);            // (always recorded: a deep pass is device time of this traversal)
         }
@@ -765,9 +794,9 @@ int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs
     if (rc) return rc;
     uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
     const bool direct = is_pinned_pairs(pairs, cap_pairs);
-    const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1),
-                               tb.d_pairs, tb.d_cand, tb.d_defer, direct ? (const void *)pairs : (const void *)tb.h_report, tb.cand_cap, tb.defer_cap, 0u};
-    static_assert(sizeof(cd_ctx::GraphKey) == 2 * 8 + 6 * 4 + 4 * 8 + 8 + 2 * 4, "GraphKey has no padding");
+    const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1) | (c->split_half ? 4u : 0u),
+                               tb.d_pairs, tb.d_cand, tb.d_defer, direct ? (const void *)pairs : (const void *)tb.h_report, tb.d_items, tb.cand_cap, tb.item_cap, tb.defer_cap, c->item_chunk};
+    static_assert(sizeof(cd_ctx::GraphKey) == 2 * 8 + 6 * 4 + 5 * 8 + 2 * 8 + 2 * 4, "GraphKey has no padding");
     if (!c->graph_exec || std::memcmp(&key, &c->graph_key, sizeof key) != 0) {
         graph_drop(c);
         HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -803,7 +832,7 @@ int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs
     parse_report(c, tb, h, direct ? nullptr : pairs, spec_n);
     c->stage = ST_REFIT; c->root_box_valid = true;
     { const int js = judge_sort_flags(c); if (js != CD_OK) return CD_OK; }                 // (not handled: the stream path redoes the step in the sort's next form)
-    if (h.max_shard_candidates > tb.cand_cap / NSHARD || h.n_deferred > 0) {             // the tree is fine: the traversal again, with the stream path's retries / deep pass
+    if (shards_overflowed(tb, h) || h.n_deferred > 0) {             // the tree is fine: the traversal again, with the stream path's retries / deep pass
         handled = true;
         c->scratch_clean = false;
         return run_traversal(c, tb, nullptr, 0, pairs, cap_pairs, n_pairs);
@@ -899,6 +928,9 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_split_of, sizeof(int32_t) * n);
     c->tb[0].cand_cap = ((4 * n > (1u << 20) ? 4 * n : (1u << 20)) + NSHARD - 1) / NSHARD * NSHARD;
     ALLOC(c->tb[0].d_cand, sizeof(Candidates) * c->tb[0].cand_cap);
+    // (0.6 items per query on the cloth and the soups; a shard that overflows is grown and the step redone)
+    c->tb[0].item_cap = (uint64_t)((3 * (uint64_t)n / 2 / NSHARD + 2048) * NSHARD);
+    ALLOC(c->tb[0].d_items, sizeof(SubItem) * c->tb[0].item_cap);
     c->tb[0].defer_cap = 1u << 16;
     ALLOC(c->tb[0].d_defer, sizeof(uint2) * c->tb[0].defer_cap);
 #undef ALLOC
@@ -1367,7 +1399,9 @@ int cd_num_triangles(cd_ctx *c, uint32_t *nt) { if (!c || !nt) return CD_ERR_ARG
 int cd_set_option(cd_ctx *c, int key, int64_t value)
 {
     if (!c) return CD_ERR_ARG;
-    if (key == CD_OPT_TRAVERSAL) { if (value < 0 || value > 4) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
+    if (key == CD_OPT_TRAVERSAL) { if (value != 0 && value != 1 && value != 3) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
+    if (key == CD_OPT_SPLIT_DESCENT) { c->split_half = value != 0; return CD_OK; }
+    if (key == CD_OPT_ITEM_CHUNK) { if (value < 64 || value > 65536 || value % 64) return CD_ERR_ARG; c->item_chunk = (uint32_t)value; return CD_OK; }
     if (key == CD_OPT_QUERIES_PER_WAVE) { if (value < 64 || value > (1 << 20) || value % 64) return CD_ERR_ARG; c->queries_per_wave = (uint32_t)value; return CD_OK; }
     if (key == CD_OPT_SORT_FULL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->sort_mode = value == 0 ? 0 : (value == 1 ? 3 : 2); return CD_OK; }
     if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }

@@ -18,6 +18,7 @@ CD_ERR_ARG, CD_ERR_ORDER, CD_ERR_NO_DEVICE, CD_ERR_INDEX = -1001, -1002, -1003, 
 CD_FRAME_REFERENCE, CD_FRAME_AUTO, CD_FRAME_CUSTOM = 0, 1, 2
 CD_ERR_SORT, CD_ERR_IO, CD_ERR_FORMAT = -1005, -1006, -1007
 CD_OPT_TRAVERSAL, CD_OPT_QUERIES_PER_WAVE, CD_OPT_SORT_FULL, CD_OPT_STAGE_TIMING, CD_OPT_KERNEL_STAMPS, CD_OPT_GRAPH, CD_OPT_POLL = 0, 1, 2, 3, 4, 5, 6
+CD_OPT_SPLIT_DESCENT, CD_OPT_ITEM_CHUNK = 7, 8
 
 QUERY_DTYPE = np.dtype([("v", "<f8", (9,)), ("id", "<u4"), ("vidx", "<u4", (3,))])
 assert QUERY_DTYPE.itemsize == 88

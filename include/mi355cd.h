@@ -206,6 +206,9 @@ enum {
                                    /*    sequence word the report kernel stores last into pinned host memory (the host spins on its own memory; after 20 ms,   */
                                    /*    and every 64th step anyway, it synchronises the stream; so do the first two steps into a report area or a pinned    */
                                    /*    pair buffer the device has not written before); 0: always hipStreamSynchronize                                      */
+    CD_OPT_SPLIT_DESCENT    = 7,   /* half traversal: 1: the chain kernel hands every internal sibling it hits, as a 32-byte (query box, subtree) item, to a second kernel that descends   */
+                                   /*    the items with full waves; 0: one kernel, every lane descends what its own query hit                                                */
+    CD_OPT_ITEM_CHUNK       = 8,   /* split descent: items one wave of the item kernel works off (multiple of 64)                                                                           */
     CD_OPT_QUERIES_PER_WAVE = 1    /* variant 1: queries one wave works through with dynamic lane refill (x64)         */
 };
 /* Keys >= 100 are measurement hooks of tools/ (extra LDS per workgroup, in-kernel diagnostics, the polled completion's scan and its counters,

@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-VARIANTS = [0, 1, 2, 3, 4]  # CD_OPT_TRAVERSAL: lane-private FP64 descent / per-lane fp32 descent + exact kernel / packet descent + exact kernel /
-                            # half traversal: bottom-up chain of right siblings + per-lane fp32 descent + exact kernel / the same with the
-                            # descent as a workgroup-shared frontier worked off level by level (round 3)
+VARIANTS = [0, 1, 3]        # CD_OPT_TRAVERSAL: lane-private FP64 descent / per-lane fp32 descent from the root + exact kernel /
+                            # half traversal: bottom-up chain of right siblings, the subtrees it hits descended by a second kernel, + exact kernel
+SHALLOW_LAUNCHES = 2        # kernels of the default traversal's first pass: descent + exact
 
 
 def _check_visits(st, ref_stats, variant):
@@ -256,10 +256,8 @@ def test_deep_tree_uses_the_deferred_stack_path(mirrored, variant):
     r = oracle.pipeline(verts, vidx, off=off, span=span)
     if mirrored:
         assert r["stats"].max_stack > 32
-    elif variant == 2:
-        assert st.stack_overflows == 0 and st.traverse_launches == 2     # wave-uniform stack holds the whole height
     elif variant >= 3:
-        pass                                                             # (the half traversals' overflow case: next test; variant 4's frontier is a ring, not a stack)
+        pass                                                             # (the half traversal's overflow case: next test)
     else:
         assert st.stack_overflows > 0 and st.traverse_launches == (4 if variant == 1 else 2)
     assert n == r["stats"].n_pairs > 0
@@ -279,10 +277,10 @@ def test_half_traversal_chain_overflows_into_the_deep_pass():
         cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, off, span)
         pairs, n, rc = cd.self_collide()
         st = cd.stats()
-        assert st.stack_overflows > 0 and st.traverse_launches == 4
+        assert st.stack_overflows > 0 and st.traverse_launches == SHALLOW_LAUNCHES + 2
         assert n == r["stats"].n_pairs > 0 and st.pairs_tested == r["stats"].pairs_tested
         assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
-        for variant in (0, 1, 2):
+        for variant in (0, 1):
             cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
             p2, n2, _ = cd.find_collisions()
             assert np.array_equal(oracle.pair_set(p2), oracle.pair_set(pairs)) and cd.stats().pairs_tested == st.pairs_tested
@@ -1111,7 +1109,7 @@ def test_graph_replay_of_the_steady_state_step_gives_the_same_results():
             pairs, n, rc = cd.self_collide(cap=1 << 20)
             assert rc == 0 and n == r["stats"].n_pairs and np.array_equal(oracle.pair_set(pairs), want), it
             assert cd.stats().pairs_tested == r["stats"].pairs_tested
-            assert cd.stats().traverse_launches == (2 if it == 0 else 0), it         # 0 = the step was one graph launch
+            assert cd.stats().traverse_launches == (SHALLOW_LAUNCHES if it == 0 else 0), it         # 0 = the step was one graph launch
         keys, perm = cd.export_keys()
         assert np.array_equal(keys, r["keys"]) and np.array_equal(perm, r["perm"])
         v2 = verts.copy(); v2[:, 1] += 0.003 * np.sin(40.0 * v2[:, 0]); v2 = v2.astype(np.float32).astype(np.float64)
@@ -1214,7 +1212,7 @@ def test_polled_completion_gives_what_the_stream_synchronise_gives():
         for it in range(3):
             pairs, n, rc = cd.self_collide()
             st = cd.stats()
-            assert st.stack_overflows > 0 and st.traverse_launches == 4
+            assert st.stack_overflows > 0 and st.traverse_launches == SHALLOW_LAUNCHES + 2
             assert n == r["stats"].n_pairs > 0 and st.pairs_tested == r["stats"].pairs_tested
             assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
 
