@@ -144,9 +144,6 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
             if (threadIdx.x == 0 && zp.flag) *zp.flag = 0u;
         }
     }
-#if defined(BLK_ABLATE) && BLK_ABLATE == 0
-    return;
-#endif
     __shared__ float t[2 * REFIT_BLK][6];           // 24 KB
     // the sparse table of the deltas (10 KB) is dead once every node knows its range and split; the nodes' own boxes
     // (12 KB) then take its place
@@ -188,17 +185,10 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
         const unsigned long long em = __builtin_amdgcn_ballot_w64(exact);
         if ((tid & 63) == 0) lexact[tid >> 6] = em;
     }
-#if defined(BLK_ABLATE) && BLK_ABLATE == 1
-    return;
-#endif
     // the 9 levels above the leaves and the 9 upper levels of the sparse table, one of each per barrier;
     // global index of local node k at depth dd: ((nbp2 + b) << dd) + (k - 2^dd)
     for (int dd = REFIT_LOG - 1; dd >= 0; --dd) {
-#ifdef BLK_NO_LEVEL_BARRIERS                                                // TIMING EXPERIMENT ONLY (wrong trees)
-        if (dd == REFIT_LOG - 1)
-#endif
         __syncthreads();
-#ifndef BLK_NO_TABLE
         {
             const int k = REFIT_LOG - dd;
             for (int x = tid; x < DL_STRIDE; x += REFIT_BLK) {
@@ -207,16 +197,13 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
                 dt[k][x] = (w >> DK_SHIFT) < (u >> DK_SHIFT) ? (DKey)(w + (1 << (k - 1))) : u;     // a tie keeps the left one
             }
         }
-#endif
         const int cnt = 1 << dd;
-#ifndef BLK_NO_TREE
         if (tid < cnt) {
             const int k = cnt + tid;
             const B32 m = b32_merge(b32_load(t[2 * k]), b32_load(t[2 * k + 1]));
             b32_store(t[k], m);
             if (REFIT_LOG - dd >= seg_min) b32_store(seg32 + 6 * ((((size_t)nbp2 + b) << dd) + tid), m);
         }
-#endif
     }
     __syncthreads();
     // FP64 box of the block's leaves: rounding is monotone, so the leaf with the smallest FP64 x1 is among the leaves whose
@@ -230,9 +217,6 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
         if (m32.lz == tot.lz) atomicMin(&acc[4], f64_ordered(mine.z1));
         if (m32.hz == tot.hz) atomicMax(&acc[5], f64_ordered(mine.z2));
     }
-#if defined(BLK_ABLATE) && BLK_ABLATE == 2
-    return;
-#endif
     const int i = j;                                                       // internal node with the same index
     int first = 0, last = 0, split = 0; bool have = false, cross = false;
     if (i < n - 1) {
@@ -266,16 +250,9 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
             else { const uint32_t g = atomicAdd(cross_count, 1u); if (g < cross_cap) cross_list[g] = i; }
         }
     }
-#if defined(BLK_ABLATE) && BLK_ABLATE == 3
-    return;
-#endif
     __syncthreads();                                                        // every node has its range and split: the table is dead
     b32_store(nb[tid], seg_query32(t, have ? first - b0 : 1, have ? last - b0 : 0));   // the node's own box (an empty query for the others)
     __syncthreads();                                                        // nb[], lsplit[], acc[], lcount of the whole block
-#if defined(BLK_ABLATE) && BLK_ABLATE == 4
-    if (nb[tid][0] == 123.f) split_of[tid] = 1;
-    return;
-#endif
     if (have) {
         // children (bvh.cuh:174-195): the left child is leaf `split` or internal node `split`, the right one leaf / node split + 1
         const bool leafL = split == first, leafR = split + 1 == last;
@@ -514,13 +491,7 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
     const int tid = threadIdx.x, lane = tid & 63, g = lane / XG, gl = lane % XG;
     // (a workgroup of its own, the last one of the grid: the fold is a chain of dependent loads, short against what the
     //  others do, long when it comes on top of it)
-#ifdef CROSS_ABLATE_ROOT
-    if (blockIdx.x == gridDim.x - 1) return;
-#endif
     if (blockIdx.x == gridDim.x - 1) { root_box_fold(seg, nbp2, nblocks, boxes); return; }   // (workgroup-uniform)
-#ifdef CROSS_ABLATE_TOP
-    return;
-#endif
     // The levels from three above the blocks upwards (a node of 8, 16, ... blocks), which only the few nodes with ranges of 4096 leaves or
     // more ask for: ONE workgroup -- the first of the grid, so it is resident before anybody can wait for it, and it waits for nobody --
     // folds them (top32_to_lds) and PUBLISHES them: agent-scope stores (the 8 L2s are not coherent inside a kernel), a wait for those
@@ -543,9 +514,6 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
     constexpr int PER_WAVE = 64 / XG, PER_BLOCK = 256 / XG;
     const uint32_t total = min(*dense_total, dense_cap);
     const long long P = (long long)nbp2 * REFIT_BLK;
-#ifdef CROSS_ABLATE_ALL
-    return;                                                                 // TIMING EXPERIMENT ONLY: launch + the upper levels into LDS
-#endif
     for (uint32_t wbase = (blockIdx.x - 1) * PER_BLOCK + (tid >> 6) * PER_WAVE; wbase < total; wbase += (gridDim.x - 2) * PER_BLOCK) {   // (wbase is wave-uniform; workgroups 1 .. gridDim.x - 2 search)
         // ---- range and split, as k_cross_meta
         const uint32_t kq = wbase + g;
@@ -590,10 +558,6 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
                 }
             }
         }
-#ifdef CROSS_ABLATE_PIECES                                                 // TIMING EXPERIMENT ONLY (wrong records): the searches alone
-        if (live && gl == 0) reinterpret_cast<uint32_t *>(const_cast<float4 *>(rec_left(recs32, n, (uint32_t)split)))[0] = (uint32_t)first + (uint32_t)last;
-        continue;
-#endif
         // (what the record's owner has to fetch besides the boxes: requested before the pieces, used after them)
         const bool leafL = split == first, leafR = split + 1 == last;
         // a child that is itself a cross node (its range leaves its 512-leaf block: exactly k_build_block's test) links itself
@@ -655,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
             }
         }
         {
-            static_assert(SEG32_MIN_LEVEL == 1 && XG == 16, "the item numbering below: levels 1 .. REFIT_LOG of a block's tree are in seg32, 16 lanes a node");
+            static_assert(SEG32_MIN_LEVEL == 1 && XG == 16 && REFIT_LOG == 9, "the item numbering below: levels 1 .. REFIT_LOG of a block's tree are in seg32, 16 lanes a node; items 0..19 = levels 0..REFIT_LOG (20 == 2 * (REFIT_LOG + 1)), 20..23 level 10, 24..31 level 11");
             B32 it[4]; bool tk[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -292,9 +292,6 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     __shared__ uint32_t s_wruns[LOCAL_WAVES];
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
-#if defined(LS_ABLATE) && LS_ABLATE == 0
-    return;                                              // TIMING EXPERIMENT ONLY (tools/exp_sort_ablation.sh): the kernel up to here
-#endif
     const uint32_t p0 = blockIdx.x * win, p1 = min(p0 + win, n);
     const uint32_t *khw = reinterpret_cast<const uint32_t *>(keys_in) + 1;      // khw[2 i]: the high word of key i
     const int hshift = run_shift - 32;                                          // (run_shift >= 44: the run bits are in the high word)
@@ -381,9 +378,6 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
         for (uint32_t i = p0 + tid; i < p1; i += LOCAL_THREADS) { const uint32_t t = vals_in[i]; keys_out[i] = keys_in[i]; vals_out[i] = t; emit.store(i, t, emit.load(t)); }
         return;
     }
-#if defined(LS_ABLATE) && LS_ABLATE == 1
-    return;                                              // TIMING EXPERIMENT ONLY (tools/exp_sort_ablation.sh): the kernel up to here
-#endif
     const int lo = p0 == 0 ? 0 : (int)((e0 & 1u) ? p0 + (e0 >> 1) : p0 - (e0 >> 1));
     const int hi = p1 >= n ? (int)n : (int)((e1 & 1u) ? p1 + (e1 >> 1) : p1 - (e1 >> 1));
     const uint32_t cnt = (uint32_t)(hi - lo);            // <= LOCAL_W + LOCAL_LIMIT - 1
@@ -435,9 +429,6 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
         for (int it = 0; it < LOCAL_ITEMS; ++it) if (it < nit)
             kh[it] = base_w + it * 64 + lane < cnt ? (((woff + ridx[it]) << low_bits) | kh[it]) : ~0u;
     }
-#if defined(LS_ABLATE) && LS_ABLATE == 2
-    return;                                              // TIMING EXPERIMENT ONLY (tools/exp_sort_ablation.sh): the kernel up to here
-#endif
     // which digits vary at all inside the window (typically not the top one): one AND / OR reduction for all four
     if (tid == 0) { s_and = 0xffffffffu; s_or = 0u; }
     __syncthreads();
@@ -513,9 +504,6 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
         }
         __syncthreads();                                                   // sitem / wcnt are rewritten by the next pass
     }
-#if defined(LS_ABLATE) && LS_ABLATE == 3
-    return;                                              // TIMING EXPERIMENT ONLY (tools/exp_sort_ablation.sh): the kernel up to here
-#endif
     // The window is now in stable order by the high key half.  The fix-up hop (below: every key placed inside its run of
     // equal high halves by its low half) needs only the run's other keys, and a run lies inside ONE window (equal high
     // halves have equal top bits): whole keys go to LDS, every item finds its final position there, and the kernel
@@ -540,9 +528,6 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
         if (j < cnt) sitem[j] = make_uint2(lowk[it], high[it]);
     }
     __syncthreads();
-#if defined(LS_ABLATE) && LS_ABLATE == 4
-    return;                                              // TIMING EXPERIMENT ONLY (tools/exp_sort_ablation.sh): the kernel up to here
-#endif
     // (in chunks of 5 items -- a window of the nominal size has 4 per lane: what emit gathers for an item is requested
     //  before the LDS search of the chunk, and lands while it runs)
     constexpr int CH = LOCAL_ITEMS / 2;

@@ -15,9 +15,7 @@ struct alignas(128) CtrShard {
     unsigned long long node_visits;
     unsigned long long n_candidates;   // candidates reserved in this shard of the candidate buffer (may exceed its capacity)
     unsigned long long wave_steps;     // descent-loop iterations summed over waves (lane utilisation = node_visits / (64 * wave_steps))
-    unsigned long long pad[12];        // [4] / [11]: the descent's own clock (earliest start as its complement, latest end); the rest: diagnostics (DIAG builds of the kernels)
-    unsigned long long n_items;        // split half traversal: (query, subtree) items reserved in this shard of the item buffer (may exceed its capacity); own line
-    unsigned long long pad2[15];
+    unsigned long long pad[12];        // [4] / [11]: the descent's own clock (earliest start as its complement, latest end); the rest: diagnostics (DIAG instances of the kernels)
 };
 struct alignas(128) TravState {
     unsigned long long n_pairs;        // collision.cuh:40 `count`
@@ -26,7 +24,7 @@ struct alignas(128) TravState {
     unsigned long long pad[14];
     CtrShard shard[NSHARD];
 };
-static_assert(sizeof(CtrShard) == 256 && sizeof(TravState) == 128 + 256 * NSHARD, "counter layout");
+static_assert(sizeof(CtrShard) == 128 && sizeof(TravState) == 128 * (NSHARD + 1), "counter layout");
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {
@@ -43,7 +41,6 @@ struct alignas(256) Report {
     double root_box[6];
     unsigned long long clk_start_inv, clk_end;   // descent kernel, device wall clock (s_memrealtime ticks): ~(earliest wave start), latest wave end; 0 = not taken
     unsigned long long seq;                      // polled completion: the step's sequence number, stored LAST (0: this report does not take part)
-    unsigned long long max_shard_items;          // split half traversal: the fullest item shard's reservation
 };
 static_assert(sizeof(Report) == 256, "report layout");
 
@@ -66,17 +63,16 @@ __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__re
         const CtrShard sh = st->shard[lane];
         const unsigned long long tested = wave_sum_u64(sh.pairs_tested), visits = wave_sum_u64(sh.node_visits);
         const unsigned long long steps = wave_sum_u64(sh.wave_steps), cands = wave_sum_u64(sh.n_candidates);
-        unsigned long long mx = sh.n_candidates, mi = sh.n_items, c0 = sh.pad[4], c1 = sh.pad[11];
+        unsigned long long mx = sh.n_candidates, c0 = sh.pad[4], c1 = sh.pad[11];
         for (int o = 32; o; o >>= 1) {
             const unsigned long long u = __shfl_xor(mx, o); mx = u > mx ? u : mx;
-            const unsigned long long ui = __shfl_xor(mi, o); mi = ui > mi ? ui : mi;
             const unsigned long long u0 = __shfl_xor(c0, o); c0 = u0 > c0 ? u0 : c0;
             const unsigned long long u1 = __shfl_xor(c1, o); c1 = u1 > c1 ? u1 : c1;
         }
         if (lane == 0) {
             out->n_pairs = np; out->pairs_tested = tested; out->node_visits = visits; out->max_shard_candidates = mx;
             out->wave_steps = steps; out->candidates = cands; out->n_deferred = st->n_deferred;
-            out->clk_start_inv = c0; out->clk_end = c1; out->max_shard_items = mi;
+            out->clk_start_inv = c0; out->clk_end = c1;
         }
         if (lane < 9) out->sort_flags[lane] = sort_flags[lane];
         if (lane < 6) out->root_box[lane] = root_box[lane];
@@ -547,8 +543,6 @@ __global__ __launch_bounds__(DESC_THREADS) void k_descend(QuerySrc src, uint32_t
 constexpr int HALF_STACK = 8;                // LDS stack entries per lane
 constexpr int HALF_QCAP = 192;               // candidate queue slots per wave
 constexpr uint32_t HALF_FLUSH_AT = HALF_QCAP - 64;   // an enqueue adds at most 64 candidates: drain before it when more than this are waiting
-constexpr int HALF_IQCAP = 256;              // split mode: (lane, subtree) items waiting in LDS per wave (takes the place of the private stacks: 2 KB)
-constexpr uint32_t HALF_IFLUSH_AT = HALF_IQCAP - 64;
 
 // (one wave per workgroup: the waves of this kernel never meet -- no barrier, wave-private LDS -- and a workgroup holds its
 //  slot until its SLOWEST wave is done; with the work per query as uneven as it is, single-wave workgroups give the slots
@@ -556,30 +550,18 @@ constexpr uint32_t HALF_IFLUSH_AT = HALF_IQCAP - 64;
 constexpr int HALF_THREADS = 64;
 constexpr int HALF_XSUB = 4;                 // see the XCD mapping below
 
-// Split mode (HALF_CHAIN + k_descend_items): the chain kernel does not descend what it hits.  A wave's 64 lanes need between 0 and ~45
-// descent steps each (1 M cloth: 9.7 steps a wave at 18 of 64 lanes busy, and a wave holds its slot until its slowest lane is done),
-// so every internal sibling a chain hits becomes a 32-byte ITEM -- the query's fp32 box, its index, the subtree -- in the workgroup's
-// shard of a global item buffer (LDS queue per wave, one reservation atomic per hand-over, as the candidates), and a second kernel
-// works the items off with every lane busy: tools/sim/pool_sim.py, profiles/r04_experiments/model_item_pool.log.
-struct alignas(16) SubItem { float lo0, lo1, lo2, hi0, hi1, hi2; uint32_t q /* bit 31 (CAND_CERTAIN): the query box is exact in fp32 */; int32_t node; };
-static_assert(sizeof(SubItem) == 32, "item layout");
-
-enum { HALF_FUSED = 0, HALF_CHAIN = 1 };
-template <int MODE, bool DIAG>
+template <bool DIAG>
 __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
                                                                   TravState *__restrict__ st,
                                                                   Candidates *__restrict__ cand, unsigned long long shard_cap,
-                                                                  uint2 *__restrict__ defer_list, uint32_t defer_cap,
-                                                                  SubItem *__restrict__ items, unsigned long long item_shard_cap)
+                                                                  uint2 *__restrict__ defer_list, uint32_t defer_cap)
 {
     const uint32_t bad_sort = sort_flags_or(src);      // looked at after phase 0 (whose loads are in bounds whatever the tree is): see sort_flags_or
     // The kernel times ITSELF with the device's constant-rate wall clock (s_memrealtime): first wave start -> last wave end, two
     // sharded atomicMax per wave (the start as its complement, so that the zeroed counters need no initial value).  A HIP time
     // stamp on the dispatch packet costs the step ~7 us of idle GPU around the kernel; this costs it nothing measurable.
     const unsigned long long clk0 = __builtin_amdgcn_s_memrealtime();
-    constexpr bool CHAIN = MODE == HALF_CHAIN;
-    __shared__ int32_t lds_stack[CHAIN ? 1 : HALF_STACK][HALF_THREADS];
-    __shared__ uint2 iqueue[CHAIN ? HALF_IQCAP : 1];   // split mode: (lane of the query, subtree) waiting for the hand-over
+    __shared__ int32_t lds_stack[HALF_STACK][HALF_THREADS];
     __shared__ Candidates queue[HALF_QCAP];
     __shared__ uint8_t share_map[64];                  // work sharing: lane id of the k-th donor
     const uint32_t lane = threadIdx.x;
@@ -609,7 +591,6 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0, tm4 = 0;           // DIAG: s_memtime stamps at the phase boundaries
     if constexpr (DIAG) tm0 = __builtin_amdgcn_s_memtime();
     uint32_t qcount = 0;                                // wave-uniform: candidates waiting in the queue
-    uint32_t icount = 0;                                // wave-uniform: items waiting in the queue (split mode)
     uint32_t tested = 0, steps = 0;
     uint32_t wvisits = 0;                               // wave-uniform: node visits of the whole wave (a popcount of the active mask per step: two scalar instructions, no per-lane add)
     int sptr = 0;
@@ -647,36 +628,9 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         qcount += __popcll(m);
     };
     float qlo0, qlo1, qlo2, qhi0, qhi1, qhi2; uint32_t qcertain;
-    // split mode: hand the last `count` (<= 64) queued items over, one per lane; the item's box comes out of its query's lane
-    // (in the chain kernel lane l holds query g0 + l from start to end)
-    auto iflush = [&](uint32_t count) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        uint2 it = make_uint2(0u, 0u);
-        const bool have = lane < count;
-        if (have) it = iqueue[icount - count + lane];
-        icount -= count;
-        const int from = (int)(it.x << 2);
-        SubItem si;
-        si.lo0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(qlo0))); si.lo1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(qlo1)));
-        si.lo2 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(qlo2))); si.hi0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(qhi0)));
-        si.hi1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(qhi1))); si.hi2 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(qhi2)));
-        si.q = (g0 + it.x) | (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)qcertain);
-        si.node = (int32_t)it.y;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&sh->n_items, (unsigned long long)count);
-        base = __shfl(base, 0) + lane;
-        if (have && base < item_shard_cap) items[(size_t)(blockIdx.x & (NSHARD - 1)) * item_shard_cap + base] = si;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
-    // an internal sibling / child that was hit (`c`, per lane): split mode -> an item; else onto the lane's stack, descended in phase 2
+    // an internal sibling / child that was hit (`c`, per lane): onto the lane's stack, descended in phase 2
     auto note_subtree = [&](bool c, int32_t link) {
-        if constexpr (CHAIN) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
-            if (m == 0ull) return;
-            while (icount > HALF_IFLUSH_AT) iflush(64);
-            if (c) iqueue[icount + __popcll(m & lt_mask)] = make_uint2(lane, (uint32_t)link);
-            icount += __popcll(m);
-        } else if (c) {
+        if (c) {
             if (sptr < HALF_STACK) { lds_stack[sptr][lane] = link; ++sptr; }
             else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)link); }
         }
@@ -760,9 +714,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     }
     dg_p1 = steps;
     if constexpr (DIAG) tm3 = __builtin_amdgcn_s_memtime();
-    if constexpr (CHAIN) {
-        while (icount > 0) iflush(icount < 64u ? icount : 64u);
-    } else {
+    {
         // ---- phase 2: descend the sibling subtrees that were hit
         int32_t node = -1;
         if (sptr > 0) { --sptr; node = lds_stack[sptr][lane]; }
@@ -821,7 +773,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         if (v64) atomicAdd(&sh->node_visits, v64);
         if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
         if (blockIdx.x < 256u) atomicMax(&sh->pad[4], ~clk0);                  // (the earliest start is among the first workgroups dispatched)
-        if constexpr (!CHAIN) atomicMax(&sh->pad[11], __builtin_amdgcn_s_memrealtime());   // (split mode: the item kernel's waves end the descent)
+        atomicMax(&sh->pad[11], __builtin_amdgcn_s_memrealtime());
     }
     if constexpr (DIAG) {
         const unsigned long long hi = wave_sum_u64(dg_hops_in), ho = wave_sum_u64(dg_hops_out), vi = wave_sum_u64(dg_vis);
@@ -832,125 +784,6 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
             atomicAdd(&sh->pad[6], tm1 - tm0); atomicAdd(&sh->pad[7], tm2 - tm1); atomicAdd(&sh->pad[8], tm3 - tm2);
             atomicAdd(&sh->pad[9], tm4 - tm3); atomicAdd(&sh->pad[10], tm5 - tm4);
         }
-    }
-}
-
-// The item kernel of the split half traversal: workgroup b (one wave) works off chunk b / 64 of shard b % 64 of the item buffer -- the
-// shard the chain kernel's workgroups with the same index modulo 64 filled, i.e. items of ITS XCD (workgroups are dealt round-robin
-// over the 8 XCDs): what the chain kernel left in that L2, items and records, is what this wave reads.
-// A descent step is a dependent round trip to a record that is rarely in the L2 (~0.8 us with the chip full), so what a wave's time
-// comes to is the number of steps it makes one after the other -- not the lanes that are busy in them.  A lane walking ITS item depth
-// first makes as many steps as the item's subtree has nodes that are hit (4.5 on average, 45 at most); here the wave keeps ONE frontier
-// of (item, node) entries in LDS and every step takes up to 64 entries off it, whoever's item they belong to (the item's box comes
-// out of its owner lane's registers through the LDS crossbar): the steps of a wave are then the LEVELS of its deepest item, ~10.
-// Children that are hit go back onto the frontier (ballot-compacted); leaves become candidates as everywhere.  A frontier that outgrows
-// its LDS (dense contact) overflows, entry by entry, into the deferred list of the deep pass, as a full private stack does.
-constexpr int ITEM_CHUNK = 64;                // items per wave: item l lives in lane l's registers
-constexpr uint32_t ITEM_FR_CAP = 384;         // frontier entries per wave (3 KB): <= 256 waiting + at most 128 new per step
-__global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_items(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
-                                                                   TravState *__restrict__ st,
-                                                                   Candidates *__restrict__ cand, unsigned long long shard_cap,
-                                                                   uint2 *__restrict__ defer_list, uint32_t defer_cap,
-                                                                   const SubItem *__restrict__ items, unsigned long long item_shard_cap)
-{
-    const uint32_t shard = blockIdx.x & (NSHARD - 1);
-    CtrShard *sh = &st->shard[shard];
-    unsigned long long have = sh->n_items;              // (scalar load; written by the chain kernel, which is complete)
-    if (have > item_shard_cap) have = item_shard_cap;   // (an overflowing shard: the host grows the buffer and redoes the step)
-    const unsigned long long begin = (unsigned long long)(blockIdx.x >> 6) * ITEM_CHUNK;
-    if (begin >= have) return;
-    const uint32_t count = (uint32_t)(begin + ITEM_CHUNK < have ? ITEM_CHUNK : have - begin);
-    const float4 *my = reinterpret_cast<const float4 *>(items + (size_t)shard * item_shard_cap + begin);
-    __shared__ uint2 fr[ITEM_FR_CAP];                   // (owner lane, node)
-    __shared__ Candidates queue[HALF_QCAP];
-    const uint32_t lane = threadIdx.x;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    Candidates *my_cand = cand + (size_t)shard * shard_cap;
-    uint32_t qcount = 0, tested = 0, steps = 0, wvisits = 0;
-    auto flush = [&](uint32_t cnt) {                    // as in k_descend_half
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        Candidates cd0 = Candidates{0, 0};
-        bool keep = lane < cnt;
-        if (keep) cd0 = queue[qcount - cnt + lane];
-        if (keep && (cd0.leaf & CAND_CERTAIN)) {
-            tested += 2u;
-            const LeafTri lt = src.leaf[cd0.leaf & CAND_LEAF_MASK];
-            const LeafTri ql = src.leaf[cd0.q];
-            keep = neighbor_count(ql.v0, ql.v1, ql.v2, lt.v0, lt.v1, lt.v2) < 1 && ql.id != lt.id;
-            cd0.leaf |= CAND_FILTERED;
-        }
-        qcount -= cnt;
-        const unsigned long long mk = __builtin_amdgcn_ballot_w64(keep);
-        if (mk != 0ull) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(&sh->n_candidates, (unsigned long long)__popcll(mk));
-            base = __shfl(base, 0) + __popcll(mk & lt_mask);
-            if (keep && base < shard_cap) my_cand[base] = cd0;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
-    auto enqueue = [&](bool c, uint32_t q, uint32_t leafword) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
-        if (m == 0ull) return;
-        while (qcount > HALF_FLUSH_AT) flush(64);
-        if (c) queue[qcount + __popcll(m & lt_mask)] = Candidates{q, leafword};
-        qcount += __popcll(m);
-    };
-    // ---- lane l takes item l of the chunk; the frontier starts with the items' subtrees
-    float4 i0 = make_float4(0.f, 0.f, 0.f, 0.f), i1 = i0;
-    if (lane < count) { i0 = my[2 * lane]; i1 = my[2 * lane + 1]; fr[lane] = make_uint2(lane, __float_as_uint(i1.w)); }
-    const int mlo0 = __float_as_int(i0.x), mlo1 = __float_as_int(i0.y), mlo2 = __float_as_int(i0.z), mhi0 = __float_as_int(i0.w), mhi1 = __float_as_int(i1.x), mhi2 = __float_as_int(i1.y);
-    const int mq = __float_as_int(i1.z);
-    uint32_t fcount = count;                            // wave-uniform: entries on the frontier
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    while (fcount > 0u) {
-        const uint32_t take = fcount < 64u ? fcount : 64u;
-        const bool active = lane < take;
-        uint2 e = make_uint2(0u, 0u);
-        if (active) e = fr[fcount - take + lane];       // the newest entries first: the frontier stays short
-        fcount -= take;
-        ++steps; wvisits += take;
-        const float4 *rpl = rec_left(recs, n, e.y), *rpr = rec_right(recs, n, e.y);       // (idle lanes fetch record 0 and ignore it)
-        const float4 a = rpl[0], b = rpl[1], c = rpr[0], d = rpr[1];
-        const int from = (int)(e.x << 2);
-        const float qlo0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, mlo0)), qlo1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, mlo1));
-        const float qlo2 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, mlo2)), qhi0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, mhi0));
-        const float qhi1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, mhi1)), qhi2 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, mhi2));
-        const uint32_t qw = (uint32_t)__builtin_amdgcn_ds_bpermute(from, mq);
-        const uint32_t qi = qw & CAND_LEAF_MASK, qcertain = qw & CAND_CERTAIN;
-        const int32_t cl = __float_as_int(b.z), cr = __float_as_int(d.z);
-        const uint32_t lw = __float_as_uint(d.w);
-        const bool ol  = active & (qlo0 < a.w) & (a.x < qhi0) & (qlo1 < b.x) & (a.y < qhi1) & (qlo2 < b.y) & (a.z < qhi2);
-        const bool orr = active & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
-        const bool intL = band(ol, cl >= 0), intR = band(orr, cr >= 0);
-        const unsigned long long mL = __builtin_amdgcn_ballot_w64(intL), mR = __builtin_amdgcn_ballot_w64(intR);
-        if ((mL | mR) != 0ull) {
-            const uint32_t nL = __popcll(mL), nR = __popcll(mR);
-            const uint32_t pL = fcount + __popcll(mL & lt_mask), pR = fcount + nL + __popcll(mR & lt_mask);
-            if (intL) {
-                if (pL < ITEM_FR_CAP) fr[pL] = make_uint2(e.x, (uint32_t)cl);
-                else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)cl); }
-            }
-            if (intR) {
-                if (pR < ITEM_FR_CAP) fr[pR] = make_uint2(e.x, (uint32_t)cr);
-                else { const uint32_t k = atomicAdd(&st->n_deferred, 1u); if (k < defer_cap) defer_list[k] = make_uint2(qi, (uint32_t)cr); }
-            }
-            fcount = fcount + nL + nR < ITEM_FR_CAP ? fcount + nL + nR : ITEM_FR_CAP;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
-        const bool candL = band(ol, cl < 0), candR = band(orr, cr < 0);
-        if (__builtin_amdgcn_ballot_w64(bor(candL, candR)) != 0ull) {
-            enqueue(candL, qi, (uint32_t)~cl | ((lw & REC_L_EXACT) ? qcertain : 0u));
-            enqueue(candR, qi, (uint32_t)~cr | ((lw & REC_R_EXACT) ? qcertain : 0u));
-        }
-    }
-    while (qcount > 0) flush(qcount < 64u ? qcount : 64u);
-    const unsigned long long t64 = wave_sum_u64(tested);
-    if (lane == 0) {
-        if (t64) atomicAdd(&sh->pairs_tested, t64);
-        if (wvisits) atomicAdd(&sh->node_visits, (unsigned long long)wvisits);
-        if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
-        atomicMax(&sh->pad[11], __builtin_amdgcn_s_memrealtime());
     }
 }
 

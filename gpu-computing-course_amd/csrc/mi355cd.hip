@@ -44,10 +44,9 @@ struct TravBuf {
     uint32_t *d_pairs = nullptr; uint64_t pairs_cap = 0;                   // d_pairs points sizeof(Report) bytes into its allocation: [Report][pairs]
     char *h_report = nullptr;                                              // pinned: Report + SPEC_PAIRS pairs, target of the read-back
     uint32_t synced_reports = 0;                                           // reports into h_report that ended in a stream synchronise (polled completion waits for POLL_WARM of them)
-    const void *direct_ptr = nullptr; uint32_t synced_direct = 0;          // the same for the caller's pinned pair buffer last written directly
+    uint64_t direct_id = 0; uint32_t synced_direct = 0;                    // the same for the caller's pinned pair buffer last written directly (its serial number: pinned_pairs_id)
     uint2 *d_defer = nullptr; uint32_t defer_cap = 0;
     Candidates *d_cand = nullptr; uint64_t cand_cap = 0;
-    SubItem *d_items = nullptr; uint64_t item_cap = 0;                     // split half traversal: (query, subtree) items, NSHARD shards of item_cap / NSHARD
     int32_t *d_deep = nullptr; uint64_t deep_items = 0;
 };
 
@@ -59,12 +58,10 @@ struct cd_ctx {
     int frame_mode = CD_FRAME_REFERENCE;
     uint32_t vbase = 0;
     int trav_variant = 3;                   // CD_OPT_TRAVERSAL: 0 = lane-private FP64 (A), 1 = fp32 descent from the root + exact kernel (B), 3 = half traversal (D)
-    bool split_half = false;                // CD_OPT_SPLIT_DESCENT: the half traversal as chain kernel + item kernel (k_descend_half<HALF_CHAIN> + k_descend_items)
-    uint32_t item_chunk = 128;              // CD_OPT_ITEM_CHUNK: items one wave of the item kernel works off
     uint32_t queries_per_wave = 64; 
-    uint32_t dbg_no_shared_path = 0;              // debug key 102: 1 = k_descend without the shared root path (A/B)
-    uint32_t dbg_diag = 0;                  // debug key 103: the descent kernels also fill the diagnostic counters (cd_debug_counters)
-    uint32_t dbg_lds_pad = 0;               // CD_OPT_DEBUG_LDS_PAD: extra dynamic LDS bytes per traversal workgroup (occupancy experiments)        // CD_OPT_QUERIES_PER_WAVE (variant B chunk size)                     // global id of local vertex 0 (cross-rank neighbour filter)
+    uint32_t dbg_no_shared_path = 0;        // CD_DBG_NO_SHARED_PATH: k_descend without the shared root path (A/B)
+    uint32_t dbg_diag = 0;                  // CD_DBG_DIAG: the DIAG instance of the descent kernel runs, which also fills the diagnostic counters (cd_debug_counters)
+    uint32_t dbg_lds_pad = 0;               // CD_DBG_LDS_PAD: extra dynamic LDS bytes per traversal workgroup (occupancy experiments)
     double frame_host[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};   // morton.h:45,51,57
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
@@ -89,8 +86,8 @@ struct cd_ctx {
     bool hierarchy_valid = false;           // meta[] / parent[] hold the tree of the current keys (fused calls build the records without them)
     bool last_tree_fused = false;           // the last fused call built hierarchy + refit in one pass (ms_hierarchy is then part of ms_refit)
     uint32_t stamp_mask = 15;               // CD_OPT_KERNEL_STAMPS: with stage timing off, which time stamps a fused call still takes (1 block build, 2 descent, 4 exact, 8 pipeline start): ~5 us of idle GPU each
-    uint32_t dbg_split_cross = 0;           // debug key 105: the fused build runs k_cross_meta + k_cross_records instead of k_cross_fused (A/B, tests)
-    uint32_t dbg_no_fused_build = 0;        // debug key 104: fused entry points run k_hierarchy + the meta-reading refit (A/B)
+    uint32_t dbg_split_cross = 0;           // CD_DBG_SPLIT_CROSS: the fused build runs k_cross_meta + k_cross_records instead of k_cross_fused (A/B, tests)
+    uint32_t dbg_no_fused_build = 0;        // CD_DBG_STAGEWISE_BUILD: fused entry points run k_hierarchy + the meta-reading refit (A/B)
     uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
     // traversal
     TravBuf tb[2];
@@ -117,12 +114,12 @@ struct cd_ctx {
     bool poll_opt = true;
     unsigned long long report_seq = 0;      // last sequence number handed to a k_report
     uint32_t polled_steps = 0, poll_fallbacks = 0;
-    // debug key 110 (tools/poll_stress.py): the pair area the report kernel writes is filled with 0xff before every step and scanned the moment the
-    // sequence word is seen -- a pair that is still 0xff then was overtaken by the word (poll_stale counts such steps; debug key 111 returns the count, 112 the fall-backs to the stream)
+    // CD_DBG_POLL_SCAN (tools/poll_stress.py, tests): the pair area the report kernel writes is filled with 0xff before every step and scanned the moment the
+    // sequence word is seen -- a pair that is still 0xff then was overtaken by the word (poll_stale counts such steps: CD_DBG_GET_POLL_STALE; _FALLBACKS: the fall-backs to the stream)
     bool dbg_poll_check = false;
     uint32_t poll_stale = 0;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
-    struct GraphKey { uint64_t cap, spec_n; int sort_mode, variant, frame_mode; uint32_t nt, exact_blocks, dbg; const void *p_pairs, *p_cand, *p_defer, *p_report, *p_items; uint64_t cand_cap, item_cap; uint32_t defer_cap, item_chunk; } graph_key = {};   // (no padding bytes: compared with memcmp)
+    struct GraphKey { uint64_t cap, spec_n; int sort_mode, variant, frame_mode; uint32_t nt, exact_blocks, dbg; const void *p_pairs, *p_cand, *p_defer, *p_report; uint64_t cand_cap; uint32_t defer_cap, pad; } graph_key = {};   // (no padding bytes: compared with memcmp)
     struct GraphPost { bool leaves_filled, leaf_records_filled, hierarchy_valid, internal_boxes_valid, last_tree_fused, events_ride, scratch_clean; uint32_t sort_passes; } graph_post = {};
     uint64_t graph_replays = 0, graph_captures = 0;
     bool all_verts_referenced = false;      // every vertex belongs to a triangle (checked at cd_create; the topology never changes afterwards)
@@ -147,7 +144,7 @@ void free_all(cd_ctx *c)
     for (TravBuf &tb : c->tb) {
         if (tb.d_pairs) hipFree(reinterpret_cast<char *>(tb.d_pairs) - sizeof(Report));
         if (tb.h_report) hipHostFree(tb.h_report);
-        hipFree(tb.d_defer); hipFree(tb.d_deep); hipFree(tb.d_cand); hipFree(tb.d_items);
+        hipFree(tb.d_defer); hipFree(tb.d_deep); hipFree(tb.d_cand);
         if (tb.state_owned) hipFree(tb.d_state);
     }
     for (int i = 0; i < 2; ++i) { hipFree(c->pp_keys[i]); hipFree(c->pp_vals[i]); }
@@ -161,15 +158,17 @@ void free_all(cd_ctx *c)
 inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // pair buffers handed out by cd_alloc_host_pairs: pinned host memory the report kernel writes STRAIGHT into (no staging copy on the host)
-struct PinnedPairs { std::mutex mu; std::vector<std::pair<const uint32_t *, uint64_t>> v; };
+// (id: a buffer's serial number -- an address the allocator hands out again is a NEW buffer, with pages the device has never written)
+struct PinnedPairs { std::mutex mu; struct Buf { const uint32_t *p; uint64_t cap, id; }; std::vector<Buf> v; uint64_t next_id = 1; };
 PinnedPairs &pinned_pairs() { static PinnedPairs p; return p; }
-bool is_pinned_pairs(const uint32_t *pairs, uint64_t cap)
+// 0: not a buffer of cd_alloc_host_pairs (or too small for `cap`); else the buffer's serial number
+uint64_t pinned_pairs_id(const uint32_t *pairs, uint64_t cap)
 {
-    if (!pairs) return false;
+    if (!pairs) return 0;
     PinnedPairs &pp = pinned_pairs();
     std::lock_guard<std::mutex> lock(pp.mu);
-    for (const auto &e : pp.v) if (e.first == pairs && cap <= e.second) return true;
-    return false;
+    for (const auto &e : pp.v) if (e.p == pairs && cap <= e.cap) return e.id;
+    return 0;
 }
 constexpr uint64_t SPEC_PAIRS = 1u << 15;     // pairs that come back together with the counters, zero-copy (256 KB)
 
@@ -471,25 +470,13 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         const uint32_t half = half_mode ? 1u : 0u;
         const bool plain = !e0 && !e1 && !e2;          // no time stamp rides on these launches: plain launches (a stream capture can record them)
         if (half_mode && !DEEP) {
-            // the half traversal: one kernel (chain + private descent), or split into the chain kernel and the item kernel.  The
-            // time stamps ride on the first and the last launch of the descent.
-            const bool split = c->split_half && tb.d_items != nullptr;
-            const unsigned long long icap = tb.item_cap / NSHARD;
             const dim3 hgrid(cdiv(items, 64u)), hblock(HALF_THREADS);
-            hipEvent_t e1a = split ? nullptr : e1;
-#define LAUNCH_HALF(MODE, DIAG)                                                                                                             \
-            do { if (plain) k_descend_half<MODE, DIAG><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, tb.d_items, icap); \
-                 else hipExtLaunchKernelGGL((k_descend_half<MODE, DIAG>), hgrid, hblock, (uint32_t)pad, s, e0, e1a, 0u, src, n, (const NodeRec32 *)c->d_recs32, \
-                                            tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, tb.d_items, icap); } while (0)
-            if (split) { if (c->dbg_diag) LAUNCH_HALF(HALF_CHAIN, true); else LAUNCH_HALF(HALF_CHAIN, false); }
-            else { if (c->dbg_diag) LAUNCH_HALF(HALF_FUSED, true); else LAUNCH_HALF(HALF_FUSED, false); }
+#define LAUNCH_HALF(DIAG)                                                                                                                   \
+            do { if (plain) k_descend_half<DIAG><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap); \
+                 else hipExtLaunchKernelGGL((k_descend_half<DIAG>), hgrid, hblock, (uint32_t)pad, s, e0, e1, 0u, src, n, (const NodeRec32 *)c->d_recs32, \
+                                            tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap); } while (0)
+            if (c->dbg_diag) LAUNCH_HALF(true); else LAUNCH_HALF(false);
 #undef LAUNCH_HALF
-            if (split) {
-                const dim3 igrid((uint32_t)(cdiv((uint32_t)icap, (uint32_t)ITEM_CHUNK) * NSHARD));
-                if (plain) k_descend_items<<<igrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, tb.d_items, icap);
-                else hipExtLaunchKernelGGL(k_descend_items, igrid, hblock, (uint32_t)pad, s, nullptr, e1, 0u, src, n, (const NodeRec32 *)c->d_recs32, tb.d_state, tb.d_cand,
-                                           (unsigned long long)shard_cap, dl, dcap, (const SubItem *)tb.d_items, icap);
-            }
         }
         else if (qpw == 64)
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, false>), grid, dim3(DESC_THREADS), (uint32_t)pad, s, e0, e1, 0u,
@@ -509,7 +496,7 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
     }
 }
 
-struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_candidates; uint32_t n_deferred; uint64_t wave_steps, candidates, clk_start_inv, clk_end, max_shard_items; };
+struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_candidates; uint32_t n_deferred; uint64_t wave_steps, candidates, clk_start_inv, clk_end; };
 
 // One host round trip and NO copy: k_report writes counters, the sort's time-out flags, the root box and the first
 // spec_n pairs straight into pinned host memory.  enqueue_report queues the kernel; parse_report reads the record
@@ -517,10 +504,9 @@ struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_can
 int ensure_report(TravBuf &tb)
 {
     if (!tb.h_report) {
-        HIPCHK(hipHostMalloc(&tb.h_report, sizeof(Report) + sizeof(uint32_t) * 2 * SPEC_PAIRS, hipHostMallocDefault));
-#ifndef REPORT_AREA_NOT_ZEROED                                            // (negative control: what a recycled report area does to a fresh context's first polled steps)
+        // (coherent = fine-grained host memory: what the polled completion's system-scope release / acquire pair is defined on)
+        HIPCHK(hipHostMalloc(&tb.h_report, sizeof(Report) + sizeof(uint32_t) * 2 * SPEC_PAIRS, hipHostMallocCoherent));
         std::memset(tb.h_report, 0, sizeof(Report));                       // (Report::seq: pinned memory is recycled by the allocator -- no stale sequence number)
-#endif
     }
     return 0;
 }
@@ -531,9 +517,7 @@ int enqueue_report(cd_ctx *c, TravBuf &tb, bool want_pairs, uint64_t &spec_n, ui
     if (!want_pairs) spec_n = 0; else if (spec_n > SPEC_PAIRS) spec_n = SPEC_PAIRS;
     // (the pair list is allocated with an even capacity + slack, so the quad copy may read one pair past `take`; a pinned buffer of
     //  cd_alloc_host_pairs has the same slack)
-#ifndef REPORT_BLOCKS
-#define REPORT_BLOCKS 32
-#endif
+    constexpr int REPORT_BLOCKS = 32;
     k_report<<<spec_n ? REPORT_BLOCKS : 1, REPORT_THREADS, 0, c->stream>>>(tb.d_state, c->d_os_ticket + 8, c->d_boxes, reinterpret_cast<Report *>(tb.h_report),
                                                               tb.d_pairs, direct ? direct : reinterpret_cast<uint32_t *>(tb.h_report + sizeof(Report)), (unsigned long long)spec_n, seq);
     return 0;
@@ -542,15 +526,16 @@ int enqueue_report(cd_ctx *c, TravBuf &tb, bool want_pairs, uint64_t &spec_n, ui
 // stream's events (the caller checks: no stage events, no time stamps).  A step that takes longer than the spin budget, or never
 // reports (a faulted kernel), ends in the ordinary stream synchronise, which also returns the error.  Every 64th polled step
 // synchronises the stream as well, so that the runtime retires what it keeps per launch.
-// The first POLL_WARM reports into a report area (and into a caller's pinned buffer) end in a stream synchronise whatever the option says:
-// the device's first stores to host pages it has never written go through address translation, and only the stream's completion signal is
-// known to wait for that.
+// Why the host may trust what it reads after seeing the word: DESIGN.md section 6 (system-scope release / acquire on fine-grained host memory,
+// the HSA memory model's own guarantee -- the one the runtime's completion signal rests on too).  The first POLL_WARM reports into a report
+// area (and into a caller's pinned buffer, told apart by serial number, not address) still end in a stream synchronise: not part of that
+// argument, but free, and it makes the first steps of a context go through the path that also returns a launch's errors.
 constexpr uint32_t POLL_WARM = 2;
 // May this report be waited for by polling?  Also notes which pinned pair buffer the report goes to (a new one starts cold).
-bool poll_this_report(const cd_ctx *c, TravBuf &tb, const void *direct)
+bool poll_this_report(const cd_ctx *c, TravBuf &tb, uint64_t direct_id)
 {
-    if (direct != tb.direct_ptr) { tb.direct_ptr = direct; tb.synced_direct = 0; }
-    return c->poll_opt && !c->stage_events && c->stamp_mask == 0 && tb.synced_reports >= POLL_WARM && (!direct || tb.synced_direct >= POLL_WARM);
+    if (direct_id && direct_id != tb.direct_id) { tb.direct_id = direct_id; tb.synced_direct = 0; }     // (a step into an ordinary buffer in between does not make the pinned one cold again)
+    return c->poll_opt && !c->stage_events && c->stamp_mask == 0 && tb.synced_reports >= POLL_WARM && (!direct_id || tb.synced_direct >= POLL_WARM);
 }
 int wait_report(cd_ctx *c, TravBuf &tb, unsigned long long seq)
 {
@@ -576,7 +561,7 @@ int wait_report(cd_ctx *c, TravBuf &tb, unsigned long long seq)
 void parse_report(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs, uint64_t spec_n)
 {
     const Report &r = *reinterpret_cast<const Report *>(tb.h_report);
-    h = HostCounters{r.n_pairs, r.pairs_tested, r.node_visits, r.max_shard_candidates, r.n_deferred, r.wave_steps, r.candidates, r.clk_start_inv, r.clk_end, r.max_shard_items};
+    h = HostCounters{r.n_pairs, r.pairs_tested, r.node_visits, r.max_shard_candidates, r.n_deferred, r.wave_steps, r.candidates, r.clk_start_inv, r.clk_end};
     std::memcpy(c->sort_flags, r.sort_flags, sizeof c->sort_flags);
     std::memcpy(c->root_box_host, r.root_box, sizeof(double) * 6);
     if (spec_n && spec_pairs) {
@@ -584,10 +569,11 @@ void parse_report(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs,
         std::memcpy(spec_pairs, tb.h_report + sizeof(Report), sizeof(uint32_t) * 2 * take);
     }
 }
-int read_state(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs = nullptr, uint64_t spec_n = 0, bool direct = false)
+int read_state(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs = nullptr, uint64_t spec_n = 0, uint64_t direct_id = 0)
 {
     if (ensure_report(tb)) return CD_ERR_ARG;
-    const unsigned long long seq = poll_this_report(c, tb, direct ? spec_pairs : nullptr) ? ++c->report_seq : 0ull;
+    const bool direct = direct_id != 0;
+    const unsigned long long seq = poll_this_report(c, tb, direct_id) ? ++c->report_seq : 0ull;
     uint32_t *area = nullptr;
     if (c->dbg_poll_check && seq && spec_pairs && spec_n) {
         if (ensure_report(tb)) return CD_ERR_ARG;
@@ -610,23 +596,10 @@ int read_state(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs = n
     return 0;
 }
 
-// Did a shard of the candidate buffer or of the item buffer overflow in the pass `h` reports?  (Nothing is written past a shard; the step is redone.)
-bool shards_overflowed(const TravBuf &tb, const HostCounters &h)
-{
-    return h.max_shard_candidates > tb.cand_cap / NSHARD || (tb.d_items && h.max_shard_items > tb.item_cap / NSHARD);
-}
+// Did a shard of the candidate buffer overflow in the pass `h` reports?  (Nothing is written past a shard; the step is redone.)
+bool shards_overflowed(const TravBuf &tb, const HostCounters &h) { return h.max_shard_candidates > tb.cand_cap / NSHARD; }
 int grow_candidates(cd_ctx *c, TravBuf &tb, uint64_t max_shard);
-int grow_shards(cd_ctx *c, TravBuf &tb, const HostCounters &h)
-{
-    if (h.max_shard_candidates > tb.cand_cap / NSHARD) { const int rc = grow_candidates(c, tb, h.max_shard_candidates); if (rc) return rc; }
-    if (tb.d_items && h.max_shard_items > tb.item_cap / NSHARD) {
-        hipFree(tb.d_items); tb.d_items = nullptr; tb.item_cap = 0;
-        const uint64_t want = (h.max_shard_items + h.max_shard_items / 4 + 1024) * NSHARD;
-        HIPCHK(hipMalloc(&tb.d_items, sizeof(SubItem) * want));
-        tb.item_cap = want;
-    }
-    return 0;
-}
+int grow_shards(cd_ctx *c, TravBuf &tb, const HostCounters &h) { return grow_candidates(c, tb, h.max_shard_candidates); }
 int grow_candidates(cd_ctx *c, TravBuf &tb, uint64_t max_shard)
 {
     hipFree(tb.d_cand); tb.d_cand = nullptr; tb.cand_cap = 0;
@@ -645,8 +618,7 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
     const uint32_t nq = external ? (uint32_t)nq_ext : n;
     int rc = ensure_pairs(c, tb, cap_pairs > 0 ? cap_pairs : 1);
     if (rc) return rc;
-    const int per_pass = c->trav_variant == 0 ? 1 : 2;             // descent + exact kernel; the split half traversal's shallow pass: chain + items + exact
-    const int first_pass = (c->trav_variant >= 3 && !external && c->split_half && tb.d_items) ? 3 : per_pass;
+    const int per_pass = c->trav_variant == 0 ? 1 : 2;             // descent + exact kernel
     if (c->trav_variant == 0 && !(c->internal_boxes_valid && c->hierarchy_valid)) {   // variant 0 walks meta[] and the FP64 boxes of the internal nodes
         if (!c->hierarchy_valid && (rc = enqueue_hierarchy(c, false))) return rc;
         if ((rc = enqueue_refit(c, true, false))) return rc;
@@ -667,10 +639,10 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
         const uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
         if (nq > 0) {
             if (external) launch_pass<true, false>(c, tb, src, nq, cap_pairs); else launch_pass<false, false>(c, tb, src, nq, cap_pairs);
-            launches += first_pass;
+            launches += per_pass;
         }
         if (!c->events_ride) HIPCHK(evrec(c, EV_TRAV1));      // device time of the kernels only: recorded before the read-back
-        if ((rc = read_state(c, tb, h, pairs, spec_n, is_pinned_pairs(pairs, cap_pairs)))) return rc;
+        if ((rc = read_state(c, tb, h, pairs, spec_n, pinned_pairs_id(pairs, cap_pairs)))) return rc;
         spec_valid = spec_n;
         if (shards_overflowed(tb, h)) { if ((rc = grow_shards(c, tb, h))) return rc; continue; }
         if (h.n_deferred > tb.defer_cap) {               // the deferred list was too small: grow it and redo (pairs restart at 0)
@@ -793,10 +765,10 @@ int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs
     if (!rc) rc = ensure_report(tb);
     if (rc) return rc;
     uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
-    const bool direct = is_pinned_pairs(pairs, cap_pairs);
-    const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1) | (c->split_half ? 4u : 0u),
-                               tb.d_pairs, tb.d_cand, tb.d_defer, direct ? (const void *)pairs : (const void *)tb.h_report, tb.d_items, tb.cand_cap, tb.item_cap, tb.defer_cap, c->item_chunk};
-    static_assert(sizeof(cd_ctx::GraphKey) == 2 * 8 + 6 * 4 + 5 * 8 + 2 * 8 + 2 * 4, "GraphKey has no padding");
+    const bool direct = pinned_pairs_id(pairs, cap_pairs) != 0;
+    const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1),
+                               tb.d_pairs, tb.d_cand, tb.d_defer, direct ? (const void *)pairs : (const void *)tb.h_report, tb.cand_cap, tb.defer_cap, 0u};
+    static_assert(sizeof(cd_ctx::GraphKey) == 2 * 8 + 6 * 4 + 4 * 8 + 8 + 2 * 4, "GraphKey has no padding");
     if (!c->graph_exec || std::memcmp(&key, &c->graph_key, sizeof key) != 0) {
         graph_drop(c);
         HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -928,9 +900,6 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_split_of, sizeof(int32_t) * n);
     c->tb[0].cand_cap = ((4 * n > (1u << 20) ? 4 * n : (1u << 20)) + NSHARD - 1) / NSHARD * NSHARD;
     ALLOC(c->tb[0].d_cand, sizeof(Candidates) * c->tb[0].cand_cap);
-    // (0.6 items per query on the cloth and the soups; a shard that overflows is grown and the step redone)
-    c->tb[0].item_cap = (uint64_t)((3 * (uint64_t)n / 2 / NSHARD + 2048) * NSHARD);
-    ALLOC(c->tb[0].d_items, sizeof(SubItem) * c->tb[0].item_cap);
     c->tb[0].defer_cap = 1u << 16;
     ALLOC(c->tb[0].d_defer, sizeof(uint2) * c->tb[0].defer_cap);
 #undef ALLOC
@@ -1366,9 +1335,10 @@ int cd_alloc_host_pairs(uint64_t cap_pairs, uint32_t **pairs)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return CD_ERR_NO_DEVICE;
     void *p = nullptr;
-    HIPCHK(hipHostMalloc(&p, sizeof(uint32_t) * 2 * cap_pairs + 16, hipHostMallocDefault));      // +16: the report kernel moves pairs as 16-byte quads
+    // (coherent = fine-grained: the memory the HSA memory model defines system-scope release / acquire between device and host on)
+    HIPCHK(hipHostMalloc(&p, sizeof(uint32_t) * 2 * cap_pairs + 16, hipHostMallocCoherent));     // +16: the report kernel moves pairs as 16-byte quads
     PinnedPairs &pp = pinned_pairs();
-    { std::lock_guard<std::mutex> lock(pp.mu); pp.v.emplace_back(static_cast<const uint32_t *>(p), cap_pairs); }
+    { std::lock_guard<std::mutex> lock(pp.mu); pp.v.push_back(PinnedPairs::Buf{static_cast<const uint32_t *>(p), cap_pairs, pp.next_id++}); }
     *pairs = static_cast<uint32_t *>(p);
     return CD_OK;
 }
@@ -1377,21 +1347,10 @@ void cd_free_host_pairs(uint32_t *pairs)
     if (!pairs) return;
     PinnedPairs &pp = pinned_pairs();
     { std::lock_guard<std::mutex> lock(pp.mu);
-      for (size_t i = 0; i < pp.v.size(); ++i) if (pp.v[i].first == pairs) { pp.v.erase(pp.v.begin() + (long)i); break; } }
+      for (size_t i = 0; i < pp.v.size(); ++i) if (pp.v[i].p == pairs) { pp.v.erase(pp.v.begin() + (long)i); break; } }
     hipHostFree(pairs);
 }
 
-#ifdef CD_ABLATE
-/* experiment builds only (tools/ab_build.sh abl -DCD_ABLATE; not in the header, not in the shipped library): the (start, end) ticks every wave of
- * the last k_descend_half wrote with debug key 103 bit 15 set (tools/exp_wave_times.py) */
-int cd_debug_wave_times(cd_ctx *c, uint32_t *out, uint32_t nwaves)
-{
-    if (!c || !out || nwaves > c->tb[0].defer_cap) return CD_ERR_ARG;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out, c->tb[0].d_defer, sizeof(uint32_t) * 2 * nwaves, hipMemcpyDeviceToHost));
-    return CD_OK;
-}
-#endif
 
 int cd_get_stats(cd_ctx *c, cd_stats *out) { if (!c || !out) return CD_ERR_ARG; *out = c->stats; return CD_OK; }
 int cd_num_triangles(cd_ctx *c, uint32_t *nt) { if (!c || !nt) return CD_ERR_ARG; *nt = c->nt; return CD_OK; }
@@ -1400,25 +1359,35 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
 {
     if (!c) return CD_ERR_ARG;
     if (key == CD_OPT_TRAVERSAL) { if (value != 0 && value != 1 && value != 3) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
-    if (key == CD_OPT_SPLIT_DESCENT) { c->split_half = value != 0; return CD_OK; }
-    if (key == CD_OPT_ITEM_CHUNK) { if (value < 64 || value > 65536 || value % 64) return CD_ERR_ARG; c->item_chunk = (uint32_t)value; return CD_OK; }
     if (key == CD_OPT_QUERIES_PER_WAVE) { if (value < 64 || value > (1 << 20) || value % 64) return CD_ERR_ARG; c->queries_per_wave = (uint32_t)value; return CD_OK; }
     if (key == CD_OPT_SORT_FULL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->sort_mode = value == 0 ? 0 : (value == 1 ? 3 : 2); return CD_OK; }
     if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }
     if (key == CD_OPT_GRAPH) { c->graph_opt = value != 0; if (!c->graph_opt) graph_drop(c); return CD_OK; }
     if (key == CD_OPT_POLL) { c->poll_opt = value != 0; return CD_OK; }
-    if (key == 110) { c->dbg_poll_check = value != 0; return CD_OK; }
-    if (key == 111) return (int)c->poll_stale;                            // (debug: a count, not a status)
-    if (key == 112) return (int)c->poll_fallbacks;
-    if (key == 113) return c->last_tree_fused ? 1 : 0;                   // (debug: which build made the tree that is there -- the tests make sure an A/B of builds compares two builds)
-    if (key == 100) { c->dbg_lds_pad = (uint32_t)value; return CD_OK; }
-    if (key == 102) { c->dbg_no_shared_path = (uint32_t)value; return CD_OK; }
-    if (key == 103) { c->dbg_diag = (uint32_t)value; return CD_OK; }
-    if (key == 104) { c->dbg_no_fused_build = (uint32_t)value; return CD_OK; }
-    if (key == 105) { c->dbg_split_cross = (uint32_t)value; return CD_OK; }
     if (key == CD_OPT_KERNEL_STAMPS) { if (value < 0 || value > 15) return CD_ERR_ARG; c->stamp_mask = (uint32_t)value; return CD_OK; }
-    if (key == 101) { if (value < 1 || value > 65535) return CD_ERR_ARG; c->exact_blocks = (int)value; return CD_OK; }
     return CD_ERR_ARG;
+}
+
+// Measurement hooks and test switches: their own entry point and their own key space, so that no hook can shadow an option
+// (round 3: the polling scan's keys were once numbered like the keys the record tests use to ask for the stage-wise build).
+// Setters return CD_OK; getters write *out (required) and ignore `value`.
+int cd_debug_option(cd_ctx *c, int key, int64_t value, int64_t *out)
+{
+    if (!c) return CD_ERR_ARG;
+    switch (key) {
+    case CD_DBG_LDS_PAD:         c->dbg_lds_pad = (uint32_t)value; return CD_OK;
+    case CD_DBG_EXACT_BLOCKS:    if (value < 1 || value > 65535) return CD_ERR_ARG; c->exact_blocks = (int)value; return CD_OK;
+    case CD_DBG_NO_SHARED_PATH:  c->dbg_no_shared_path = value != 0; return CD_OK;
+    case CD_DBG_DIAG:            c->dbg_diag = value != 0; return CD_OK;
+    case CD_DBG_STAGEWISE_BUILD: c->dbg_no_fused_build = value != 0; return CD_OK;
+    case CD_DBG_SPLIT_CROSS:     c->dbg_split_cross = value != 0; return CD_OK;
+    case CD_DBG_POLL_SCAN:       c->dbg_poll_check = value != 0; return CD_OK;
+    case CD_DBG_GET_POLL_STALE:     if (!out) return CD_ERR_ARG; *out = c->poll_stale; return CD_OK;
+    case CD_DBG_GET_POLL_FALLBACKS: if (!out) return CD_ERR_ARG; *out = c->poll_fallbacks; return CD_OK;
+    case CD_DBG_GET_POLLED_STEPS:   if (!out) return CD_ERR_ARG; *out = c->polled_steps; return CD_OK;
+    case CD_DBG_GET_TREE_WAS_FUSED: if (!out) return CD_ERR_ARG; *out = c->last_tree_fused ? 1 : 0; return CD_OK;
+    default: return CD_ERR_ARG;
+    }
 }
 
 int cd_set_vertex_id_base(cd_ctx *c, uint32_t base) { if (!c) return CD_ERR_ARG; c->vbase = base; return CD_OK; }

@@ -18,7 +18,9 @@ CD_ERR_ARG, CD_ERR_ORDER, CD_ERR_NO_DEVICE, CD_ERR_INDEX = -1001, -1002, -1003, 
 CD_FRAME_REFERENCE, CD_FRAME_AUTO, CD_FRAME_CUSTOM = 0, 1, 2
 CD_ERR_SORT, CD_ERR_IO, CD_ERR_FORMAT = -1005, -1006, -1007
 CD_OPT_TRAVERSAL, CD_OPT_QUERIES_PER_WAVE, CD_OPT_SORT_FULL, CD_OPT_STAGE_TIMING, CD_OPT_KERNEL_STAMPS, CD_OPT_GRAPH, CD_OPT_POLL = 0, 1, 2, 3, 4, 5, 6
-CD_OPT_SPLIT_DESCENT, CD_OPT_ITEM_CHUNK = 7, 8
+# cd_debug_option keys (measurement hooks / test switches; not part of the mirrored interface)
+CD_DBG_LDS_PAD, CD_DBG_EXACT_BLOCKS, CD_DBG_NO_SHARED_PATH, CD_DBG_DIAG, CD_DBG_STAGEWISE_BUILD, CD_DBG_SPLIT_CROSS = 0, 1, 2, 3, 4, 5
+CD_DBG_POLL_SCAN, CD_DBG_GET_POLL_STALE, CD_DBG_GET_POLL_FALLBACKS, CD_DBG_GET_POLLED_STEPS, CD_DBG_GET_TREE_WAS_FUSED = 10, 11, 12, 13, 14
 
 QUERY_DTYPE = np.dtype([("v", "<f8", (9,)), ("id", "<u4"), ("vidx", "<u4", (3,))])
 assert QUERY_DTYPE.itemsize == 88
@@ -53,7 +55,7 @@ EXPORTS = [
     "cd_check_triangle_idx", "cd_find_collisions", "cd_build_tree", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
     "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_debug_counters", "cd_debug_records", "cd_num_triangles",
     "cd_set_option", "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
-    "cd_morton3d_points", "cd_expand64_values", "cd_box_pairs", "cd_tri_contact_points", "cd_alloc_host_pairs", "cd_free_host_pairs",
+    "cd_debug_option", "cd_morton3d_points", "cd_expand64_values", "cd_box_pairs", "cd_tri_contact_points", "cd_alloc_host_pairs", "cd_free_host_pairs",
     "cd_multi_unique_id", "cd_multi_create", "cd_multi_create_from_comm", "cd_multi_destroy", "cd_multi_set_flags", "cd_multi_step",
 ]
 
@@ -115,6 +117,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_free_host_pairs.restype = None
     lib.cd_morton3d_points.argtypes = [vp, C.c_uint64, vp, vp, vp]
     lib.cd_expand64_values.argtypes = [vp, C.c_uint64, vp]
+    lib.cd_debug_option.argtypes = [vp, C.c_int, C.c_int64, C.POINTER(C.c_int64)]
     lib.cd_box_pairs.argtypes = [vp, vp, C.c_uint64, vp, vp]
     lib.cd_tri_contact_points.argtypes = [vp, C.c_uint64, vp]
     lib.cd_multi_unique_id.argtypes = [vp]
@@ -186,6 +189,14 @@ class CollisionDetector:
 
     def set_option(self, key: int, value: int):
         self._chk("cd_set_option", self.lib.cd_set_option(self._ctx, key, value))
+
+    def debug_set(self, key: int, value: int):
+        self._chk("cd_debug_option", self.lib.cd_debug_option(self._ctx, key, value, None))
+
+    def debug_get(self, key: int) -> int:
+        out = C.c_int64(0)
+        self._chk("cd_debug_option", self.lib.cd_debug_option(self._ctx, key, 0, C.byref(out)))
+        return out.value
 
     def update_vertices(self, verts):
         v = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)

@@ -184,7 +184,7 @@ enum {
     CD_OPT_TRAVERSAL        = 0,   /* 0: lane-private FP64 descent, exact test inline (the reference's shape,        */
                                    /*    collision.cuh:19-71); 1: fp32 conservative descent of every query from the   */
                                    /*    root with a wavefront-shared LDS candidate queue + a second kernel for the   */
-                                   /*    exact tests; 2: one wave walks the tree for its 64 queries; 3 (default): half */
+                                   /*    exact tests; 3 (default): half                                                */
                                    /*    traversal -- a query meets only the leaves to its right in Morton order and   */
                                    /*    every hit counts as the two ordered pairs the reference tests   */
     CD_OPT_SORT_FULL        = 2,   /* 0 (default): hybrid -- 2 global passes on 16 key bits (44..59, or 48..63 when a key reaches 2^60), the rest of the high half */
@@ -206,17 +206,30 @@ enum {
                                    /*    sequence word the report kernel stores last into pinned host memory (the host spins on its own memory; after 20 ms,   */
                                    /*    and every 64th step anyway, it synchronises the stream; so do the first two steps into a report area or a pinned    */
                                    /*    pair buffer the device has not written before); 0: always hipStreamSynchronize                                      */
-    CD_OPT_SPLIT_DESCENT    = 7,   /* half traversal: 1: the chain kernel hands every internal sibling it hits, as a 32-byte (query box, subtree) item, to a second kernel that descends   */
-                                   /*    the items with full waves; 0: one kernel, every lane descends what its own query hit                                                */
-    CD_OPT_ITEM_CHUNK       = 8,   /* split descent: items one wave of the item kernel works off (multiple of 64)                                                                           */
     CD_OPT_QUERIES_PER_WAVE = 1    /* variant 1: queries one wave works through with dynamic lane refill (x64)         */
 };
-/* Keys >= 100 are measurement hooks of tools/ (extra LDS per workgroup, in-kernel diagnostics, the polled completion's scan and its counters,
- * ...): not part of the interface, free to change; what they do is said where they are handled (cd_set_option in csrc/mi355cd.hip). */
 int cd_set_option(cd_ctx *ctx, int key, int64_t value);
 
+/* Measurement hooks of tools/ and switches the tests use to ask for one code path or another -- NOT part of the interface that mirrors the
+ * reference, free to change, and in a key space of their own so that none of them can be mistaken for an option above.  Setters take
+ * `value` and return CD_OK; getters (CD_DBG_GET_*) write *out.  None of the setters changes results. */
+enum {
+    CD_DBG_LDS_PAD            = 0,   /* extra dynamic LDS bytes per traversal workgroup (occupancy experiments)                              */
+    CD_DBG_EXACT_BLOCKS       = 1,   /* workgroups of the exact kernel (default 1024)                                                         */
+    CD_DBG_NO_SHARED_PATH     = 2,   /* variant 1 without the shared root path                                                                */
+    CD_DBG_DIAG               = 3,   /* run the descent kernel's DIAG instance: per-phase step counts and s_memtime ticks -> cd_debug_counters */
+    CD_DBG_STAGEWISE_BUILD    = 4,   /* fused entry points build the tree stage by stage (k_hierarchy + refit) instead of in one pass         */
+    CD_DBG_SPLIT_CROSS        = 5,   /* the fused build's cross nodes by k_cross_meta + k_cross_records instead of k_cross_fused               */
+    CD_DBG_POLL_SCAN          = 10,  /* polled completion: poison the pair area before a step, scan it the moment the sequence word is seen   */
+    CD_DBG_GET_POLL_STALE     = 11,  /* ... steps in which the scan found a pair missing (must stay 0)                                        */
+    CD_DBG_GET_POLL_FALLBACKS = 12,  /* ... polled waits that ran into the 20 ms budget and ended in a stream synchronise                     */
+    CD_DBG_GET_POLLED_STEPS   = 13,  /* ... reports whose end was read off the sequence word                                                  */
+    CD_DBG_GET_TREE_WAS_FUSED = 14   /* 1: the tree that is there was made by the one-pass build                                              */
+};
+int cd_debug_option(cd_ctx *ctx, int key, int64_t value, int64_t *out);
+
 int cd_get_stats(cd_ctx *ctx, cd_stats *out);
-/* Diagnostics of the last traversal, filled only after cd_set_option(ctx, 103, 1): sums over the descent's waves of
+/* Diagnostics of the last traversal, filled only after cd_debug_option(ctx, CD_DBG_DIAG, 1, NULL): sums over the descent's waves of
  * {chain steps, chain hops inside / outside the query's 256-leaf block, descent visits inside / outside it, longest
  * chain of each wave, 6 spare}.  Not part of any result. */
 int cd_debug_counters(cd_ctx *ctx, unsigned long long out[12]);

@@ -70,6 +70,9 @@ def test_argument_errors_do_not_need_a_device():
     assert lib.cd_morton3d_points(None, 4, None, None, None) == mi355cd.CD_ERR_ARG
     assert lib.cd_expand64_values(None, 4, None) == mi355cd.CD_ERR_ARG
     assert lib.cd_alloc_host_pairs(0, None) == mi355cd.CD_ERR_ARG
+    assert lib.cd_box_pairs(None, None, 4, None, None) == mi355cd.CD_ERR_ARG
+    assert lib.cd_tri_contact_points(None, 4, None) == mi355cd.CD_ERR_ARG
+    assert lib.cd_debug_option(None, 0, 0, None) == mi355cd.CD_ERR_ARG
     assert lib.cd_multi_step(None, None, 0, None, None) == mi355cd.CD_ERR_ARG
     rl = mi355rt.load_library()
     rctx = C.c_void_p()
@@ -92,7 +95,8 @@ def test_no_device_is_an_error_not_a_fallback():
         mi355rt.RayTracer(s, 64)
     assert e.value.rc == mi355rt.RT_ERR_NO_DEVICE
     # the context-free entry points too: morton3D / expand64Bits on the device, the pinned pair buffer
-    for fn, arg in ((mi355cd.morton3d_points, np.zeros((4, 3))), (mi355cd.expand64_values, np.arange(4, dtype=np.uint64)), (mi355cd.HostPairs, 16)):
+    for fn, arg in ((mi355cd.morton3d_points, np.zeros((4, 3))), (mi355cd.expand64_values, np.arange(4, dtype=np.uint64)), (mi355cd.HostPairs, 16),
+                    (mi355cd.tri_contact_points, np.zeros((2, 6, 3))), (lambda a: mi355cd.box_pairs(a, a), np.zeros((2, 6)))):
         with pytest.raises(mi355cd.CdError) as e:
             fn(arg)
         assert e.value.rc == mi355cd.CD_ERR_NO_DEVICE

@@ -1,6 +1,7 @@
 """GPU parity tests for the collision path: every stage of libmi355cd.so (through the C ABI) against
 the CPU oracle on the same seeded inputs.  Bar: bit-exact (integer keys / indices / tree links, FP64
 box bits, pair index SETS -- the reference's own output order is an atomicAdd race, collision.cuh:40)."""
+import ctypes as C
 import os
 import subprocess
 import sys
@@ -375,7 +376,7 @@ def test_steady_state_steps_clean_their_own_scratch():
         bf, nbf, _ = cd.brute_force(True, cap=1 << 20)
         assert np.array_equal(oracle.pair_set(bf), oracle.pair_set(rb["pairs"]))
         step(cd, rb)
-        for variant in (0, 2, 1, 3):
+        for variant in (0, 1, 3):
             cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
             step(cd, rb); step(cd, rb)
         cd.update_vertices(vo)                                             # k_morton raises the flag, the step is redone with the other digits
@@ -607,10 +608,10 @@ def _assert_fused_records_equal_stagewise(verts, vidx, ids=None, split_cross_too
     got = {}
     for fused in (1, 0, 2):                                 # 2: the fused build with k_cross_meta + k_cross_records (what trees beyond 2048 blocks take)
         with mi355cd.CollisionDetector(verts, vidx, ids) as cd:
-            cd.set_option(104, 0 if fused else 1)
-            cd.set_option(105, 1 if fused == 2 else 0)
+            cd.debug_set(mi355cd.CD_DBG_STAGEWISE_BUILD, 0 if fused else 1)
+            cd.debug_set(mi355cd.CD_DBG_SPLIT_CROSS, 1 if fused == 2 else 0)
             cd.build_tree()
-            assert cd.lib.cd_set_option(cd._ctx, 113, 0) == (1 if fused else 0)      # the build that was asked for is the build that ran
+            assert cd.debug_get(mi355cd.CD_DBG_GET_TREE_WAS_FUSED) == (1 if fused else 0)      # the build that was asked for is the build that ran
             got[fused] = cd.debug_records() + (cd.root_box(),)
     if split_cross_too:
         _compare_records(vidx.shape[0], got[2], got[0])
@@ -1028,7 +1029,7 @@ def test_benched_path_default_options_matches_oracle_at_baseline_size(config):
     assert np.array_equal(left, r["left"]) and np.array_equal(right, r["right"]) and np.array_equal(parent, r["parent"])
     assert np.array_equal(boxes.view(np.uint64), r["boxes"].view(np.uint64)) and (bounded == 2).all()
     with mi355cd.CollisionDetector(verts, vidx) as cd0:
-        cd0.set_option(104, 1)                                  # stage-wise build (proven against the oracle link by link above)
+        cd0.debug_set(mi355cd.CD_DBG_STAGEWISE_BUILD, 1)                                  # stage-wise build (proven against the oracle link by link above)
         cd0.build_tree()
         _compare_records(vidx.shape[0], fused_records, cd0.debug_records() + (cd0.root_box(),))
 
@@ -1124,8 +1125,8 @@ def test_graph_replay_of_the_steady_state_step_gives_the_same_results():
                 # nothing a launch derives from the geometry may be carried over from an earlier replay (the cross kernel's published upper levels
                 # and their flag word -- a replay carries the same sequence number every time)
                 with mi355cd.CollisionDetector(v2, vidx) as cd0:
-                    cd0.set_option(104, 1); cd0.build_tree()
-                    assert cd0.lib.cd_set_option(cd0._ctx, 113, 0) == 0
+                    cd0.debug_set(mi355cd.CD_DBG_STAGEWISE_BUILD, 1); cd0.build_tree()
+                    assert cd0.debug_get(mi355cd.CD_DBG_GET_TREE_WAS_FUSED) == 0
                     _compare_records(vidx.shape[0], cd.debug_records() + (cd.root_box(),), cd0.debug_records() + (cd0.root_box(),))
         pairs, n, rc = cd.self_collide(cap=1 << 18)          # another capacity: another capture
         assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r2["pairs"]))
@@ -1218,8 +1219,8 @@ def test_polled_completion_gives_what_the_stream_synchronise_gives():
 
 
 def test_polled_completion_never_sees_the_word_before_the_pairs():
-    """The hazard of a polled completion: the sequence word overtaking pairs still on their way to host memory.  Debug key 110 makes the
-    library fill the pair area with 0xff before every step and scan it the moment the word is seen (key 111: steps with a pair missing;
+    """The hazard of a polled completion: the sequence word overtaking pairs still on their way to host memory.  CD_DBG_POLL_SCAN makes the
+    library fill the pair area with 0xff before every step and scan it the moment the word is seen (CD_DBG_GET_POLL_STALE: steps with a pair missing;
     tools/poll_stress.py runs this for 20 000 steps a mesh, with the host link loaded, and has a negative control build that posts the
     word first -- which this scan catches on 96 % of the steps).  A fresh context each, on the mesh (4 948 pairs) round 2's attempt at this
     failed on."""
@@ -1227,14 +1228,69 @@ def test_polled_completion_never_sees_the_word_before_the_pairs():
         for verts, vidx in (synth.cloth_pair(122), synth.soup(60_000, 0.08, 21)):        # 4 948 pairs; ~29 k pairs (nearly all the report kernel posts)
             with mi355cd.CollisionDetector(verts, vidx) as cd, mi355cd.HostPairs(1 << 17) as hp:
                 plain = np.empty((1 << 17, 2), dtype=np.uint32)
-                cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0); cd.set_option(110, 1)
+                cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0); cd.debug_set(mi355cd.CD_DBG_POLL_SCAN, 1)
                 n0, rc = cd.self_collide_into(plain)                                      # (the first two reports into an area end in a stream synchronise: never-written host pages)
                 want = oracle.pair_set(plain[:n0].copy())
                 for it in range(150):
                     buf = plain if it % 2 == 0 else hp.array
                     n, rc = cd.self_collide_into(buf)
                     assert rc == 0 and n == n0 and np.array_equal(oracle.pair_set(buf[:n]), want), (rep, it)
-                assert cd.lib.cd_set_option(cd._ctx, 111, 0) == 0 and cd.lib.cd_set_option(cd._ctx, 112, 0) == 0
+                assert cd.debug_get(mi355cd.CD_DBG_GET_POLL_STALE) == 0 and cd.debug_get(mi355cd.CD_DBG_GET_POLL_FALLBACKS) == 0 and cd.debug_get(mi355cd.CD_DBG_GET_POLLED_STEPS) > 100
+
+
+@pytest.mark.parametrize("config", ["cloth1M", "soup100k"])
+def test_the_step_bench_py_times_polled_into_a_pinned_buffer_at_baseline_size(config):
+    """bench.py's timed step EXACTLY -- CD_OPT_STAGE_TIMING 0, CD_OPT_KERNEL_STAMPS 0, cd_self_collide_into a HostPairs buffer, default
+    CD_OPT_POLL -- 80 consecutive steps on BASELINE config 3 (1 M cloth) and config 2 (100 k soup), a fresh context and a fresh pinned
+    buffer each, with the library's scan on (the pair area is poisoned before every step and scanned the moment the sequence word is
+    seen): every step's pair set and pairs_tested equal the REFERENCE-COMPILED end result, the steps after the warm-up were polled
+    (not synchronised), no fall-back to the stream, and no step saw the word before a pair."""
+    ref = np.load(os.path.join(GOLD, "contact_ref.npz"))
+    verts, vidx = end_mesh(config)
+    want = ref[config + "_pairs"]
+    with mi355cd.CollisionDetector(verts, vidx) as cd, mi355cd.HostPairs(1 << 22) as hp:
+        cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+        cd.debug_set(mi355cd.CD_DBG_POLL_SCAN, 1)
+        for it in range(80):
+            n, rc = cd.self_collide_into(hp.array)
+            assert rc == 0 and n == int(ref[config + "_count"]), it
+            assert cd.fast_stats.pairs_tested == int(ref[config + "_tested"]), it
+            if it < 4 or it % 8 == 0 or it >= 76:                        # (sorting 20 k pairs on the host 80 times is the test's time: the scan covers the rest)
+                assert np.array_equal(ci.pair_keys(hp.array[:n]), want), it
+        polled, stale, fb = cd.debug_get(mi355cd.CD_DBG_GET_POLLED_STEPS), cd.debug_get(mi355cd.CD_DBG_GET_POLL_STALE), cd.debug_get(mi355cd.CD_DBG_GET_POLL_FALLBACKS)
+        assert polled >= 76 and stale == 0 and fb == 0, (polled, stale, fb)
+        check_end_result(ref, config, hp.array[:n].copy(), cd.stats().pairs_tested)
+
+
+def test_a_recycled_pinned_buffer_address_starts_cold_and_reports_of_other_grid_sizes_interleave():
+    """ cd_free_host_pairs + cd_alloc_host_pairs may hand the same ADDRESS out again: the library tells buffers apart by serial
+    number, so the new buffer's first reports end in a stream synchronise again (CD_DBG_GET_POLLED_STEPS does not move for POLL_WARM steps).
+    And k_report's arrival counter starts from zero for every launch: a one-workgroup report (no pairs wanted) followed by a 32-workgroup
+    one on the same state, polled, with the scan on."""
+    verts, vidx = synth.cloth_pair(122)
+    r = oracle.pipeline(verts, vidx)
+    want = oracle.pair_set(r["pairs"])
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+        cd.debug_set(mi355cd.CD_DBG_POLL_SCAN, 1)
+        seen = set()
+        for rep in range(6):
+            with mi355cd.HostPairs(1 << 14) as hp:
+                seen.add(hp.array.ctypes.data)
+                p0 = cd.debug_get(mi355cd.CD_DBG_GET_POLLED_STEPS)
+                for it in range(2):                                              # POLL_WARM steps into a buffer the device has not written: synchronised
+                    n, rc = cd.self_collide_into(hp.array)
+                    assert rc == 0 and np.array_equal(oracle.pair_set(hp.array[:n]), want)
+                assert cd.debug_get(mi355cd.CD_DBG_GET_POLLED_STEPS) == p0, rep
+                for it in range(6):
+                    n, rc = cd.self_collide_into(hp.array)
+                    assert rc == 0 and np.array_equal(oracle.pair_set(hp.array[:n]), want)
+                    nn = C.c_uint64(0)                                           # counters only: k_report with ONE workgroup, polled too
+                    rc = cd.lib.cd_self_collide(cd._ctx, None, 0, C.byref(nn))
+                    assert rc == mi355cd.CD_OVERFLOW and nn.value == len(want)
+                assert cd.debug_get(mi355cd.CD_DBG_GET_POLLED_STEPS) >= p0 + 6
+        assert cd.debug_get(mi355cd.CD_DBG_GET_POLL_STALE) == 0 and cd.debug_get(mi355cd.CD_DBG_GET_POLL_FALLBACKS) == 0
+        assert len(seen) < 6                                                     # (the allocator did hand an address out again: the case this test is about)
 
 
 def test_multi_step_box_of_the_triangles_ignores_unreferenced_vertices():
