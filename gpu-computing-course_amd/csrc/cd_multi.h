@@ -169,7 +169,8 @@ struct cd_multi {
     unsigned long long *d_matrix = nullptr;      // world x (world + 1), all-gathered rows
     unsigned long long *h_matrix = nullptr;      // pinned copy
     double *h_roots = nullptr;                   // pinned, world x 6
-    ExtQuery *d_send = nullptr;                  // world slabs of qcap records
+    uint64_t slab_cap = 0;                       // records per peer slab the two buffers below were ALLOCATED with (< qcap only after a growth whose allocation failed)
+    ExtQuery *d_send = nullptr;                  // world slabs of slab_cap records
     ExtQuery *d_recv = nullptr;                  // world x qcap as well: whatever the peers send fits (allocated WITH the slabs, never between matrix and exchange)
     std::vector<uint32_t> scratch_pairs;
 };
@@ -227,11 +228,21 @@ int multi_alloc(cd_multi *m)
 
 // the send slabs and the receive buffer, both world x qcap records: (re)allocated together, only where a failure can still be
 // published through the status word of the NEXT all-gather
+// The new buffers are allocated BEFORE the old ones are released: when an allocation fails the rank keeps a consistent pair (of the
+// old capacity), reports the error through its status word, and the next step -- which sees slab_cap < qcap, the capacity the other
+// ranks have by now -- tries again before anything is packed or received; nothing is ever packed into or received by a null or
+// undersized buffer.
 int multi_slabs(cd_multi *m)
 {
-    hipFree(m->d_send); hipFree(m->d_recv); m->d_send = nullptr; m->d_recv = nullptr;
-    HIPCHK(hipMalloc(&m->d_send, sizeof(ExtQuery) * (size_t)m->world * m->qcap));
-    HIPCHK(hipMalloc(&m->d_recv, sizeof(ExtQuery) * (size_t)m->world * m->qcap));
+    if (m->d_send && m->d_recv && m->slab_cap >= m->qcap) return CD_OK;
+    ExtQuery *ns = nullptr, *nr = nullptr;
+    hipError_t e = (m->flags & CD_MULTI_INJECT_ALLOC_FAILURE) ? hipErrorOutOfMemory : hipSuccess;      // test hook: this rank's next slab allocation fails
+    m->flags &= ~CD_MULTI_INJECT_ALLOC_FAILURE;
+    if (e == hipSuccess) e = hipMalloc(&ns, sizeof(ExtQuery) * (size_t)m->world * m->qcap);
+    if (e == hipSuccess) e = hipMalloc(&nr, sizeof(ExtQuery) * (size_t)m->world * m->qcap);
+    if (e != hipSuccess) { hipFree(ns); hipFree(nr); (void)hipGetLastError(); return -(int)e; }
+    hipFree(m->d_send); hipFree(m->d_recv);
+    m->d_send = ns; m->d_recv = nr; m->slab_cap = m->qcap;
     return CD_OK;
 }
 
@@ -348,6 +359,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     if (!local_err && cap_pairs && !pairs) local_err = CD_ERR_ARG;
     if (!local_err && (m->flags & CD_MULTI_INJECT_FAILURE)) local_err = CD_ERR_INJECTED;   // test hook: this rank's next step fails locally
     m->flags &= ~CD_MULTI_INJECT_FAILURE;
+    if (!local_err && m->slab_cap < m->qcap) { const int rc = multi_slabs(m); if (rc) local_err = rc; }   // a growth of an earlier step whose allocation failed here: again, before anything is packed
     auto late = [&](int rc) { m->sticky_err = rc; c->scratch_clean = false; hipStreamSynchronize(s); hipStreamSynchronize(m->xstream); return rc; };   // an error AFTER the decision: returned, and published by the next step
 #define LATE_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return late(-(int)e_); } while (0)
 #define SOFT_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess && !local_err) local_err = -(int)e_; } while (0)
@@ -437,7 +449,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         if (self_peer && (m->flags & CD_MULTI_SELF_SLICE)) k_slice_box<<<1, 1, 0, xs>>>(m->d_roots + 6 * (size_t)me);   // rehearsal at config 4's scale
         mark(ME_GATHER, xs);
         if (!(row_zeroed && attempts == 0)) SOFT_HIP(hipMemsetAsync(m->d_row, 0, sizeof(unsigned long long) * RW, xs));   // (the first round's: by k_vertex_box)
-        if (!local_err && m->d_send)
+        if (!local_err && m->d_send && m->slab_cap >= m->qcap)
             k_pack_triangles<<<cdiv(c->nt, PACK_THREADS), PACK_THREADS, 0, xs>>>(c->d_verts, c->d_vidx, c->d_ids, (int)c->nt, m->d_roots, W,
                                                                                   self_peer ? -1 : me, m->d_roots + 6 * (size_t)me,
                                                                                   m->d_send, (unsigned long long)m->qcap, m->d_row, c->vbase);

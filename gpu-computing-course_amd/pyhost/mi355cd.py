@@ -38,6 +38,7 @@ class CdStats(C.Structure):
 
 # every symbol include/mi355cd.h declares (tests check the library exports exactly these)
 CD_MULTI_SELF_PEER, CD_MULTI_TIMING, CD_MULTI_SELF_SLICE, CD_MULTI_CROSS_SERIAL, CD_MULTI_INJECT_FAILURE, CD_MULTI_PRIORITY_STREAM = 1, 2, 4, 8, 16, 32
+CD_MULTI_INJECT_ALLOC_FAILURE = 64
 CD_ERR_RCCL, CD_ERR_PEER, CD_ERR_INJECTED = -1008, -1009, -1010
 
 

@@ -284,8 +284,10 @@ enum {
     CD_MULTI_PRIORITY_STREAM = 32, /* at creation only: the second stream (all-gathers, pack, send / receive, the pass over the received queries) gets the */
                                /* device's highest stream priority.  Measured on one GPU (self-peer rehearsal, 1 M triangles): the two streams' kernels */
                                /* then slow each other down -- 0.65 against 0.32 ms per step -- so it is off by default                                     */
-    CD_MULTI_INJECT_FAILURE = 16 /* test hook: this rank's NEXT step fails locally (CD_ERR_INJECTED) before its pipeline starts; the flag */
+    CD_MULTI_INJECT_FAILURE = 16, /* test hook: this rank's NEXT step fails locally (CD_ERR_INJECTED) before its pipeline starts; the flag */
                                /* clears itself.  Every other rank must return CD_ERR_PEER from the same step, none may block      */
+    CD_MULTI_INJECT_ALLOC_FAILURE = 64 /* test hook: this rank's NEXT allocation of its send / receive slabs fails (as out of memory); the flag   */
+                               /* clears itself.  The step in which that happens fails on every rank; the next one allocates again   */
 };
 typedef struct cd_multi_info {
     uint32_t world, rank;          /* as the communicator reports them                                        */
@@ -309,7 +311,14 @@ int cd_multi_unique_id(void *id128);
  * detaches the cd_multi, whose further steps return CD_ERR_ORDER.
  * Failure semantics of cd_multi_step: a rank whose own work fails still joins the step's collectives and publishes its error in
  * the count matrix; every rank then returns from the SAME step -- the failing rank its error, the others CD_ERR_PEER -- before
- * any send / receive is posted.  An error met after that point is returned to its caller and published by that rank's next step. */
+ * any send / receive is posted.  An error met after that point is returned to its caller and published by that rank's next step.
+ * NOT covered by "every rank returns from the same step": (i) a rank whose RCCL all-gather cannot even be ENQUEUED (ncclAllGather
+ * returns an error on that rank alone) -- its peers are inside the collective, the communicator is dead, and only destroying it
+ * ends their wait; (ii) CD_ERR_ORDER / CD_ERR_RCCL / CD_ERR_ARG returned at the entry of cd_multi_step (context destroyed, no RCCL
+ * library, null handle) and a failure of cd_multi_create before its small agreement buffers exist: those ranks never reach a collective,
+ * so their peers must not call into one either -- these are programming or installation errors every rank of a job shares.
+ * A failed allocation of the send / receive slabs (creation or growth) IS covered: the rank keeps its old buffers, publishes the
+ * error, and allocates again at the start of its next step. */
 int cd_multi_create(cd_multi **out, cd_ctx *ctx, const void *id128, int rank, int world, uint64_t query_cap_per_peer, int flags);
 /* The same over a communicator the caller owns (an opaque ncclComm_t); it is not destroyed by cd_multi_destroy. */
 int cd_multi_create_from_comm(cd_multi **out, cd_ctx *ctx, void *nccl_comm, uint64_t query_cap_per_peer, int flags);

@@ -4,11 +4,12 @@ instead of RCCL, which refuses two ranks on one device.  Everything else -- the 
 matrix, the collective capacity growth, slab and receive offsets, both traversal passes -- is the product code path.
 Run as a child process by tests/test_cd_gpu.py (the library choice is per process).
 
-usage: multi_loopback_driver.py QUADS QCAP STEPS X0,X1,... [INJECT_RANK:INJECT_STEP]    (rank r's object sits at x = Xr * 2.88)
+usage: multi_loopback_driver.py QUADS QCAP STEPS X0,X1,... [INJECT_RANK:INJECT_STEP[:alloc]]    (rank r's object sits at x = Xr * 2.88)
 QUADS may be a comma list, one value per rank (shards of unequal size: the default capacity nt / 8 + 1024 then differs per rank
 and must be agreed at creation).  INJECT: that rank sets CD_MULTI_INJECT_FAILURE before that step -- EVERY rank must return an
 error from that step (the rank itself CD_ERR_INJECTED, the others CD_ERR_PEER), none may block, and the following steps must be
-right again.
+right again.  With ":alloc" the rank sets CD_MULTI_INJECT_ALLOC_FAILURE instead: its next allocation of the send / receive slabs
+fails -- give a QCAP small enough that the step has to grow them -- the rank returns the allocation's error, the others CD_ERR_PEER.
 Checks, and exits non-zero on failure: union of all ranks' pairs == oracle on the merged mesh, no duplicates, summed
 pairs_tested == the single tree's, sent/received totals consistent across ranks, peers as the root boxes say."""
 import json
@@ -34,7 +35,9 @@ def main():
     W = len(xs)
     quads_of = [int(q) for q in sys.argv[1].split(",")]
     quads_of = quads_of * W if len(quads_of) == 1 else quads_of
-    inject = tuple(int(v) for v in sys.argv[5].split(":")) if len(sys.argv) > 5 else None
+    inj = sys.argv[5].split(":") if len(sys.argv) > 5 else None
+    inject = (int(inj[0]), int(inj[1])) if inj else None
+    inject_alloc = bool(inj) and len(inj) > 2 and inj[2] == "alloc"
     width = 2.88
     shards, vbase, tbase = [], 0, 0
     for r in range(W):
@@ -60,7 +63,7 @@ def main():
                 out = []
                 for it in range(steps):
                     if inject and inject == (r, it):
-                        ms.set_flags(mi355cd.CD_MULTI_TIMING | mi355cd.CD_MULTI_INJECT_FAILURE)
+                        ms.set_flags(mi355cd.CD_MULTI_TIMING | (mi355cd.CD_MULTI_INJECT_ALLOC_FAILURE if inject_alloc else mi355cd.CD_MULTI_INJECT_FAILURE))
                     try:
                         pairs, n, rc, info = ms.step(cap=1 << 21)
                         out.append((pairs.copy(), n, rc, {k: getattr(info, k) for k, _ in info._fields_}))
@@ -91,7 +94,7 @@ def main():
     for it in range(steps):
         if inject and it == inject[1]:
             rcs = [results[r][it][2] for r in range(W)]
-            want_rcs = [mi355cd.CD_ERR_INJECTED if r == inject[0] else mi355cd.CD_ERR_PEER for r in range(W)]
+            want_rcs = [(-2 if inject_alloc else mi355cd.CD_ERR_INJECTED) if r == inject[0] else mi355cd.CD_ERR_PEER for r in range(W)]     # -2: -hipErrorOutOfMemory
             summary["steps"].append({"injected": True, "rcs": rcs, "checks": {"all_ranks_failed_together": rcs == want_rcs}})
             summary["ok"] = summary["ok"] and rcs == want_rcs
             continue

@@ -604,6 +604,24 @@ def test_multi_step_fails_on_every_rank_together(world_xs, inject):
     assert len(good) == 3 and all(all(st["checks"].values()) for st in good), res
 
 
+def test_multi_step_slab_allocation_failure_in_the_growth_round_fails_together_and_recovers():
+    """ The per-peer capacity starts too small (64 records), so step 0 has to grow the slabs -- and on rank 1 that allocation
+    fails (CD_MULTI_INJECT_ALLOC_FAILURE).  The new buffers are allocated before the old ones are released: rank 1 returns the error,
+    rank 0 CD_ERR_PEER, nobody posts a send or a receive; the NEXT step sees slab_cap < qcap on rank 1, allocates again before anything is
+    packed, and gives the oracle's pair set with the cross pairs in it -- nothing silently missing, nothing received into a null buffer."""
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "multi_loopback_driver.py"), "30", "64", "3", "0,0.9", "1:0:alloc"],
+                       capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    res = json.loads(lines[-1])
+    assert res["ok"] and p.returncode == 0, res
+    assert res["steps"][0].get("injected") and res["steps"][0]["checks"]["all_ranks_failed_together"], res
+    for st in res["steps"][1:]:
+        assert all(st["checks"].values()) and sum(st["cross"]) > 0 and st["query_cap"] > 64, st
+
+
 def _assert_fused_records_equal_stagewise(verts, vidx, ids=None, split_cross_too=True):
     got = {}
     for fused in (1, 0, 2):                                 # 2: the fused build with k_cross_meta + k_cross_records (what trees beyond 2048 blocks take)
@@ -1094,6 +1112,29 @@ def test_config4_neighbour_pair_at_full_shard_size_over_the_loopback_transport()
         assert all(st["checks"].values()), st
         assert st["attempts"] == 1 and st["host_syncs"] == [2, 2], st
         assert st["sent"][0] > 90_000 and st["sent"][1] > 90_000 and sum(st["cross"]) > 1000, st       # ~101 k overlapping triangles each way
+
+
+def test_config4_whole_eight_shards_of_one_million_triangles_over_the_loopback_transport():
+    """BASELINE config 4 WHOLE on the one GPU there is: eight contexts of 1 000 000 triangles each (cloth_pair(500) shifted along x, 10 %
+    overlap between neighbours, global vertex and triangle IDs), stepped twice by cd_multi_step with world 8 over the loopback transport.
+    The union of the eight ranks' pairs == the oracle's pair set on the merged 8 M-triangle mesh, no duplicates; the summed pairs_tested ==
+    the single tree's; every rank exchanges queries with exactly its neighbours in the row (1 2 2 2 2 2 2 1 peers, ~101 k queries each way);
+    one collective attempt, two host synchronisations per rank and step.  What config 4 then still lacks is real links between real GPUs."""
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    xs = ",".join("%.1f" % (0.9 * r) for r in range(8))
+    p = subprocess.run([sys.executable, os.path.join(here, "multi_loopback_driver.py"), "500", "0", "2", xs],
+                       capture_output=True, text=True, timeout=1100)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    res = json.loads(lines[-1])
+    assert res["ok"] and p.returncode == 0, res
+    assert res["world"] == 8 and res["want_peers"] == [1, 2, 2, 2, 2, 2, 2, 1] and res["want_pairs"] > 8 * 20_000
+    for st in res["steps"]:
+        assert all(st["checks"].values()), st
+        assert st["attempts"] == 1 and st["host_syncs"] == [2] * 8, st
+        assert st["sent"][0] > 90_000 and st["sent"][7] > 90_000 and all(v > 180_000 for v in st["sent"][1:7]), st     # ~101 k overlapping triangles per neighbour
+        assert sum(st["cross"]) > 7 * 1000 and st["got_pairs"] == res["want_pairs"], st
 
 
 def test_graph_replay_of_the_steady_state_step_gives_the_same_results():
