@@ -122,13 +122,36 @@ def parity_check(pairs, tested, verts, vidx, ids=None, off=None, span=None, own_
     return out
 
 
-def soup_measurement(torch, steps=60, warmup=10):
-    """Secondary workload (inputs item 3: "also report the 1 M soup"): the config-2 generator at 1 000 000 triangles, e = 0.01 -- own
-    vertices per triangle (no shared edges: the neighbour filter drops nothing and every overlapping leaf pair goes through the SAT), the same
-    call and options as the headline; the last step's pair set and pairs_tested against the oracle.  N = 1 only."""
+def reference_compiled_check(name, pairs, tested):
+    """Checker leg: the pair set and the pairs-tested count against the END RESULT the REFERENCE's own predicates give for this mesh
+    (tests/golden/contact_ref.npz: tri_contact.cuh / box.cuh / triangle.cuh compiled unmodified in the build container)."""
+    import hashlib
+    path = os.path.join(ROOT, "tests", "golden", "contact_ref.npz")
+    if not os.path.exists(path):
+        return None
+    ref = np.load(path)
+    if name + "_pairs_sha" not in ref.files:
+        return None
+    p = np.asarray(pairs, dtype=np.uint64).reshape(-1, 2)
+    keys = np.sort((p[:, 0] << np.uint64(32)) | p[:, 1])
+    return bool(hashlib.sha256(keys.tobytes()).hexdigest() == str(ref[name + "_pairs_sha"]) and int(tested) == int(ref[name + "_tested"]))
+
+
+def secondary_measurement(torch, which, steps=60, warmup=10):
+    """Secondary workloads beside the headline, same call and options, the last step's pair set and pairs_tested against the oracle and
+    against the reference-compiled end result.  N = 1 only.
+      soup_1M         SURVEY.md 8d, inputs item 3 ("also report the 1 M soup"): the config-2 generator at 1 000 000 triangles, e = 0.01 -- own
+                      vertices per triangle (no shared edges: the neighbour filter drops nothing, every overlapping leaf pair goes through the SAT);
+      cloth_1M_double the headline's surfaces with vertices NOT rounded to float32 (vec3f.cuh:14-23 stores FP64; only the loader rounds,
+                      load_obj.h:38): no leaf box is exact in fp32, so every candidate takes k_exact's FP64-box path and the boxes[] fetches."""
     import mi355_synth as synth
     import mi355cd
-    verts, vidx = synth.soup(1_000_000, 0.01, 1234)
+    if which == "soup_1M":
+        verts, vidx = synth.soup(1_000_000, 0.01, 1234)
+        label, fixture = "triangle soup, 1 000 000 triangles of edge 0.01 in the reference's box, own vertices per triangle (config-2 generator at 1 M)", "soup1M"
+    else:
+        verts, vidx = synth.cloth_pair(500, round_f32=False)
+        label, fixture = "cloth-vs-cloth of the headline with full-double vertices (not rounded to float32): the FP64-box path of the exact kernel", "cloth1M_double"
     with mi355cd.CollisionDetector(verts, vidx) as cd, mi355cd.HostPairs(1 << 22) as hp:
         cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
         for _ in range(warmup):
@@ -142,13 +165,12 @@ def soup_measurement(torch, steps=60, warmup=10):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if rc != 0:
-            raise RuntimeError("soup: pair capacity too small")
+            raise RuntimeError(which + ": pair capacity too small")
         last = np.array(hp.array[:n], copy=True); last_tested = cd.fast_stats.pairs_tested
         clock = cd.fast_stats.ms_descend_clock
     pc = parity_check(last, last_tested, verts, vidx)
-    return {"workload": "triangle soup, 1 000 000 triangles of edge 0.01 in the reference's box, own vertices per triangle (config-2 generator at 1 M)",
-            "ms_per_step": dt * 1e3 / steps, "pairs_tested_per_s": tested / dt, "pairs_tested_per_step": int(last_tested), "colliding_pairs": int(n), "steps": steps,
-            "descend_device_clock_ms": clock, "parity_checked": bool(pc["ok"])}
+    return {"workload": label, "ms_per_step": dt * 1e3 / steps, "pairs_tested_per_s": tested / dt, "pairs_tested_per_step": int(last_tested), "colliding_pairs": int(n),
+            "steps": steps, "descend_device_clock_ms": clock, "parity_checked": bool(pc["ok"]), "reference_compiled_end_result": reference_compiled_check(fixture, last, last_tested)}
 
 
 def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5, rank=0, world=1, dist=None, torch=None, device=None, multi=False):
@@ -241,8 +263,8 @@ def main():
     ap.add_argument("--quads", type=int, default=500, help="quads per sheet edge; 500 -> 1 000 000 triangles per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the last timed step's pair set")
-    ap.add_argument("--soup", action="store_true", help="also measure the 1 M soup (SURVEY.md 8d) after the headline: same kernels, other workload -- off by default so that a kernel "
-                                                       "trace of the default command holds the headline workload's launches only")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads measured after the headline (the 1 M soup of SURVEY.md 8d; the cloth with full-double "
+                                                             "vertices): a kernel trace of the command then holds the headline workload's launches only")
     ap.add_argument("--no-ray", action="store_true", help="skip the secondary ray-tracer measurement (BASELINE config 5)")
     ap.add_argument("--traversal", type=int, default=None, help="CD_OPT_TRAVERSAL override (0 lane-private FP64, 1 wave-queued)")
     ap.add_argument("--qpw", type=int, default=None, help="CD_OPT_QUERIES_PER_WAVE override")
@@ -399,13 +421,15 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "triangles_per_gpu": int(nt), "pairs_tested_per_step": tested_total // k,
-                       "colliding_pairs": int(pairs_found), "sharding": "by object" if multi_path else "none"},
+                       "colliding_pairs": int(pairs_found), "sharding": "by object" if multi_path else "none",
+                       "step": ("cd_multi_step" if ms is not None else "cd_self_collide into a pinned pair buffer of cd_alloc_host_pairs, library defaults but CD_OPT_STAGE_TIMING 0 / "
+                                "CD_OPT_KERNEL_STAMPS 0 (the step's end is then read off the report's sequence word: CD_OPT_POLL, default on)")},
             # `value` counts what the reference counts: (query, leaf) pairs whose AABBs strictly overlap, every unordered leaf pair TWICE
             # (collision.cuh:31-44 lets each leaf query the whole tree).  The default half traversal decides each unordered pair ONCE and
             # credits 2 (box.cuh:40-43 and neighborCount are symmetric; equal to the oracle's counter in every test): the device executes
             # half as many exact box decisions as `value` says
             "pairs_tested_counting": "reference-equivalent: the half traversal decides each unordered leaf pair once and credits the 2 ordered tests the reference makes",
-            "box_decisions_executed_per_step": (tested_total // k) // (1 if args.traversal in (0, 1, 2) else 2),
+            "box_decisions_executed_per_step": (tested_total // k) // (1 if args.traversal in (0, 1) else 2),
         }
         if not multi_path:
             prof_steps = min(k, 20)
@@ -484,7 +508,8 @@ def main():
             if not args.no_parity:
                 # checker leg: the LAST TIMED step's pair set + pairs-tested count against the oracle (one more CPU pass, with pairs)
                 pc = parity_check(last_pairs, last_tested, verts, vidx)
-                line["parity_checked"] = pc["ok"]
+                pc["reference_compiled_end_result"] = reference_compiled_check("cloth1M", last_pairs, last_tested) if (args.quads == 500 and args.traversal is None) else None
+                line["parity_checked"] = pc["ok"] and pc["reference_compiled_end_result"] is not False
                 line["parity"] = pc
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(verts, vidx)
@@ -515,8 +540,9 @@ def main():
             line["parity_checked"] = bool(int(f.item()))
             line["parity"] = dict(pc, note="rank 0's own check shown; parity_checked = MIN over ranks: every rank's pair list of the last timed step == "
                                            "the oracle's pairs (on the rank's mesh merged with its lower neighbour's) whose larger id the rank owns")
-    if not multi_path and args.soup and rank == 0:
-        line["soup_1M"] = soup_measurement(torch)
+    if not multi_path and not args.no_extras and rank == 0:
+        line["soup_1M"] = secondary_measurement(torch, "soup_1M")
+        line["cloth_1M_double"] = secondary_measurement(torch, "cloth_1M_double")
     if not args.no_ray and (backend == "nccl" or not multi_path):
         rtm = ray_tracer_measurement(rank=rank, world=world if multi_path else 1, dist=dist if multi_path else None, torch=torch, device=device, multi=multi_path)
         if rank == 0:

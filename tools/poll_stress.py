@@ -31,13 +31,13 @@ for name, (verts, vidx) in cases:
         cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0); cd.set_option(mi355cd.CD_OPT_POLL, 0)
         n0, rc = cd.self_collide_into(plain)
         want = oracle.pair_set(plain[:n0].copy())
-        cd.set_option(mi355cd.CD_OPT_POLL, 1); cd.set_option(110, 1)
+        cd.set_option(mi355cd.CD_OPT_POLL, 1); cd.debug_set(mi355cd.CD_DBG_POLL_SCAN, 1)
         mism = 0
         for it in range(steps):
             buf = plain if it % 2 == 0 else hp.array
             n, rc = cd.self_collide_into(buf)
             if rc != 0 or n != n0 or not np.array_equal(oracle.pair_set(buf[:n]), want): mism += 1
-        stale = cd.lib.cd_set_option(cd._ctx, 111, 0); fb = cd.lib.cd_set_option(cd._ctx, 112, 0)
+        stale = cd.debug_get(mi355cd.CD_DBG_GET_POLL_STALE); fb = cd.debug_get(mi355cd.CD_DBG_GET_POLL_FALLBACKS)
         print(f"{name}: {n0} pairs, {steps} polled steps: pair-set mismatches {mism}, steps with a pair not yet in host memory {stale}, fallbacks to the stream {fb}", flush=True)
         bad += mism + stale
 stop = True

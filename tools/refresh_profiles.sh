@@ -8,17 +8,17 @@ python3 $R/bench.py > $O/bench_plain.json 2> $O/bench_plain.err
 echo "plain bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o run -- python3 $R/bench.py > $O/bench_under_rocprof.json 2> $O/trace.err
 echo "kernel trace done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-parity --steps 20 --warmup 5 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-extras --no-parity --steps 20 --warmup 5 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 echo "FETCH_SIZE pass done"
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/pmc_rdreq -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-parity --steps 20 --warmup 5 > $O/pmc_rdreq.json 2> $O/pmc_rdreq.err
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/pmc_rdreq -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-extras --no-parity --steps 20 --warmup 5 > $O/pmc_rdreq.json 2> $O/pmc_rdreq.err
 echo "size-resolved read request pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-parity --steps 20 --warmup 5 > $O/pmc_write.json 2> $O/pmc_write.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-extras --no-parity --steps 20 --warmup 5 > $O/pmc_write.json 2> $O/pmc_write.err
 echo "WRITE_SIZE pass done"
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-parity --steps 20 --warmup 5 > $O/pmc_l2.json 2> $O/pmc_l2.err
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-extras --no-parity --steps 20 --warmup 5 > $O/pmc_l2.json 2> $O/pmc_l2.err
 echo "L2 hit / miss pass done"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-parity --steps 20 --warmup 5 > $O/pmc_sq.json 2> $O/pmc_sq.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-extras --no-parity --steps 20 --warmup 5 > $O/pmc_sq.json 2> $O/pmc_sq.err
 echo "SQ pass done"
-rocprofv3 --pmc SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_SALU --output-format csv -d $O/pmc_sq2 -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-parity --steps 20 --warmup 5 > $O/pmc_sq2.json 2> $O/pmc_sq2.err
+rocprofv3 --pmc SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_SALU --output-format csv -d $O/pmc_sq2 -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-extras --no-parity --steps 20 --warmup 5 > $O/pmc_sq2.json 2> $O/pmc_sq2.err
 echo "SQ pass 2 (scalar side, issue / wait split) done"
 rm -f $O/trace/run_kernel_trace.csv        # tens of MB; the stats file is the summary
 ls -la $O $O/trace
