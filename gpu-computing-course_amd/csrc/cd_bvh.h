@@ -206,25 +206,12 @@ __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restr
     const uint32_t ntile = (n + SORT_TILE - 1) / SORT_TILE;
     uint32_t seen = 0;                                   // thread d < 256: what h[first_digit][d] held when this tile began (the tile's counts are the difference)
     for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        // the thread's four triangles in TWO round trips (indices, then vertices), not eight: hipcc does not hoist a load out of a
-        // conditional, so the loads are unconditional at a clamped position and only the key's store and count depend on t < n
-        constexpr int PER = SORT_TILE / MORTON_THREADS;
-        uint32_t ia[PER], ib[PER], ic[PER];
 #pragma unroll
-        for (int it = 0; it < PER; ++it) {
-            const uint32_t t = tile * SORT_TILE + it * MORTON_THREADS + threadIdx.x, tc = t < n ? t : n - 1u;
-            ia[it] = vidx[3 * (size_t)tc]; ib[it] = vidx[3 * (size_t)tc + 1]; ic[it] = vidx[3 * (size_t)tc + 2];
-        }
-        d3 p1[PER], p2[PER], p3[PER];
-#pragma unroll
-        for (int it = 0; it < PER; ++it) { p1[it] = load_vertex(verts, ia[it]); p2[it] = load_vertex(verts, ib[it]); p3[it] = load_vertex(verts, ic[it]); }
-#pragma unroll
-        for (int it = 0; it < PER; ++it) {
+        for (int it = 0; it < SORT_TILE / MORTON_THREADS; ++it) {
             const uint32_t t = tile * SORT_TILE + it * MORTON_THREADS + threadIdx.x;
-            // load_obj.h:90: (p1 + p2 + p3) / 3 per axis (centroid_of)
-            const double cx = (p1[it].x + p2[it].x + p3[it].x) / 3, cy = (p1[it].y + p2[it].y + p3[it].y) / 3, cz = (p1[it].z + p2[it].z + p3[it].z) / 3;
-            const uint64_t k = morton3d(cx, cy, cz, frame, frame + 3);
             if (t < n) {
+                const d3 c = centroid_of(verts, vidx, t);
+                const uint64_t k = morton3d(c.x, c.y, c.z, frame, frame + 3);
                 keys[t] = k;
                 hist_add(h, k, first_digit, down);
                 above |= k;

@@ -6,7 +6,8 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_plain.json 2> $O/bench_plain.err
 echo "plain bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o run -- python3 $R/bench.py > $O/bench_under_rocprof.json 2> $O/trace.err
+# (--no-extras: the default command also measures two secondary workloads with the same kernels; the trace holds the headline workload's launches only)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o run -- python3 $R/bench.py --no-extras > $O/bench_under_rocprof.json 2> $O/trace.err
 echo "kernel trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --no-cpu-baseline --no-ray --no-extras --no-parity --steps 20 --warmup 5 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 echo "FETCH_SIZE pass done"
