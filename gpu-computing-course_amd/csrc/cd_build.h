@@ -1,17 +1,18 @@
 // cd_build.h -- the FUSED build of the fused entry points (cd_self_collide / cd_build_tree / cd_multi_step): Karras
 // hierarchy (bvh.cuh:100-199) + AABB refit (bvh.cuh:258-285) + the fp32 traversal records, straight from the sorted keys.
 //
-// What the traversal reads of an internal node is its 64-byte record: both child boxes rounded OUTWARD to fp32.  Rounding
-// is monotone, so it commutes with min / max: the outward-rounded box of a leaf range is the min / max of the leaves'
-// outward-rounded boxes -- bit for bit what rounding the FP64 merge (bvh.cuh:277) gives.  The fused build therefore
+// What the traversal reads of an internal node is its 64-byte record: both child boxes as fp32 copies (cd_bvh.h: lo rounded
+// down; hi rounded down, one ulp up where its cell is ambiguous).  Both maps are monotone, so they commute with min / max:
+// the fp32 copy of a leaf range's box is the min / max of the leaves' fp32 copies -- bit for bit what encoding the FP64
+// merge (bvh.cuh:277) gives.  The fused build therefore
 // keeps ONE fp32 segment tree of the leaf boxes per 512-leaf block (hardware v_min_f32 / v_max_f32, 6 instructions a
 // merge against 18 for the FP64 compare-selects of box.cuh:24-32) and never forms an internal FP64 box, except
 //   * the FP64 boxes of the leaves that are NOT exact in fp32 (k_exact and cd_pack_queries decide their candidates in
 //     FP64; an exact leaf's fp32 box is its FP64 box: leaf_box64, cd_bvh.h), and
 //   * the FP64 box of ALL leaves (node 0: cd_root_box, the multi-GPU root exchange), reduced per block from the few leaves
 //     whose fp32 value equals the block's fp32 extreme (only they can hold the FP64 extreme), then by k_refit_seg_top.
-// "Exact in fp32" flags (REC_L_EXACT / REC_R_EXACT) only matter for LEAF children -- a candidate is a pair of leaves --
-// and a leaf child's box is the leaf's box, whose flag the leaf's thread knows.
+// The CERTAIN / EXACT flags of a record only matter for LEAF children -- a candidate is a pair of leaves --
+// and a leaf child's box is the leaf's box, whose flags the leaf's thread knows.
 // The reference's tree (meta[] / parent[] / FP64 boxes of internal nodes) is materialised by k_hierarchy + the stage-wise
 // refit when somebody asks for it (cd_export_tree, the verifier, traversal variant 0): mi355cd.hip.
 #pragma once
@@ -33,9 +34,10 @@ __device__ __forceinline__ B32 b32_merge(const B32 &a, const B32 &b)
 {
     return B32{hw_min(a.lx, b.lx), hw_min(a.ly, b.ly), hw_min(a.lz, b.lz), hw_max(a.hx, b.hx), hw_max(a.hy, b.hy), hw_max(a.hz, b.hz)};
 }
-__device__ __forceinline__ B32 b32_of(const Box &b)                       // outward: lo down, hi up (what store_rec32 does)
+__device__ __forceinline__ B32 b32_of(const AmbTable &amb, const Box &b)  // the fp32 copy of an FP64 box (cd_bvh.h enc_box32: what store_rec32 does)
 {
-    return B32{__double2float_rd(b.x1), __double2float_rd(b.y1), __double2float_rd(b.z1), __double2float_ru(b.x2), __double2float_ru(b.y2), __double2float_ru(b.z2)};
+    const Enc32 e = enc_box32(amb, b, false);
+    return B32{e.lx, e.ly, e.lz, e.hx, e.hy, e.hz};
 }
 __device__ __forceinline__ B32 b32_load(const float *p)                    // 24-byte node, 8-byte aligned
 {
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
                                                            int32_t *__restrict__ root_name, double *__restrict__ seg, float *__restrict__ seg32, int nbp2,
                                                            int32_t *__restrict__ cross_list, uint32_t *__restrict__ cross_count, uint32_t cross_cap, ZeroPlan zp,
                                                            int seg_min /* lowest level of the block's tree that goes to seg32: SEG32_MIN_LEVEL for the trees k_cross_fused takes,
-                                                                          SEG_MIN_LEVEL beyond (there the kernel is bound by its writes, and levels 1 and 2 are 18 bytes a leaf) */)
+                                                                          SEG_MIN_LEVEL beyond (there the kernel is bound by its writes, and levels 1 and 2 are 18 bytes a leaf) */,
+                                                           AmbTable amb, const uint8_t *__restrict__ vamb)
 {
     {
         const uint32_t G = gridDim.x * REFIT_BLK;
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
     DKey (*dt)[DL_STRIDE] = reinterpret_cast<DKey (*)[DL_STRIDE]>(scratch);
     float (*nb)[6] = reinterpret_cast<float (*)[6]>(scratch);
     __shared__ int16_t lsplit[REFIT_BLK];
-    __shared__ unsigned long long lexact[REFIT_BLK / 64];
+    __shared__ unsigned long long lexact[REFIT_BLK / 64], lcertain[REFIT_BLK / 64];
     __shared__ unsigned long long acc[6];
     __shared__ int32_t lcross[64];
     __shared__ uint32_t lcount, lbase;
@@ -169,21 +172,24 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
     }
     Box mine = box_identity();
     B32 m32 = b32_identity();
-    bool exact = false;
+    bool exact = false, certain = false;
     if (j < n) {
         const LeafTri lt = leaf[j];
-        mine = box_set(load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2));   // box.cuh:13-22
-        m32 = b32_of(mine);
-        exact = box_is_fp32(mine);
+        const d3 A = load_vertex(verts, lt.v0), B = load_vertex(verts, lt.v1), C = load_vertex(verts, lt.v2);
+        mine = box_set(A, B, C);                                           // box.cuh:13-22
+        const Enc32 e = enc_leaf32(mine, A, B, C, vamb, lt.v0, lt.v1, lt.v2);
+        m32 = B32{e.lx, e.ly, e.lz, e.hx, e.hy, e.hz};
+        certain = e.certain;
+        exact = certain && box_is_fp32(mine);
         if (!exact || n == 1) store_box(boxes, (n - 1) + j, mine);        // an exact box is its fp32 copy (leaf_box64, cd_bvh.h); n == 1: the leaf is node 0
         float4 *qp = reinterpret_cast<float4 *>(qbox32 + j);
         qp[0] = make_float4(m32.lx, m32.ly, m32.lz, m32.hx);
-        qp[1] = make_float4(m32.hy, m32.hz, __uint_as_float((exact ? LB_EXACT : 0u) | (box_overlap(mine, mine) ? LB_SELF : 0u)), 0.f);
+        qp[1] = make_float4(m32.hy, m32.hz, __uint_as_float((exact ? LB_EXACT : 0u) | (certain ? LB_CERTAIN : 0u) | (box_overlap(mine, mine) ? LB_SELF : 0u)), 0.f);
     }
     b32_store(t[REFIT_BLK + tid], m32);
     {
-        const unsigned long long em = __builtin_amdgcn_ballot_w64(exact);
-        if ((tid & 63) == 0) lexact[tid >> 6] = em;
+        const unsigned long long em = __builtin_amdgcn_ballot_w64(exact), cm = __builtin_amdgcn_ballot_w64(certain);
+        if ((tid & 63) == 0) { lexact[tid >> 6] = em; lcertain[tid >> 6] = cm; }
     }
     // the 9 levels above the leaves and the 9 upper levels of the sparse table, one of each per barrier;
     // global index of local node k at depth dd: ((nbp2 + b) << dd) + (k - 2^dd)
@@ -260,10 +266,12 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
         const B32 bl = b32_load(leafL ? t[REFIT_BLK + sl] : nb[sl]);
         const B32 br = b32_load(leafR ? t[REFIT_BLK + sr] : nb[sr]);
         const int32_t la = leafL ? ~split : b0 + (int)lsplit[sl], lb = leafR ? ~(split + 1) : b0 + (int)lsplit[sr];
-        const uint32_t fl = ((leafL && ((lexact[sl >> 6] >> (sl & 63)) & 1ull)) ? REC_L_EXACT : 0u) |
+        const uint32_t fl = ((leafL && ((lcertain[sl >> 6] >> (sl & 63)) & 1ull)) ? REC_L_CERTAIN : 0u) |
+                            ((leafR && ((lcertain[sr >> 6] >> (sr & 63)) & 1ull)) ? REC_R_CERTAIN : 0u);
+        const uint32_t fx = ((leafL && ((lexact[sl >> 6] >> (sl & 63)) & 1ull)) ? REC_L_EXACT : 0u) |
                             ((leafR && ((lexact[sr >> 6] >> (sr & 63)) & 1ull)) ? REC_R_EXACT : 0u);
         float4 *pl = const_cast<float4 *>(rec_left(recs32, n, (uint32_t)split)), *pr = const_cast<float4 *>(rec_right(recs32, n, (uint32_t)split));
-        pl[0] = make_float4(bl.lx, bl.ly, bl.lz, bl.hx); pl[1] = make_float4(bl.hy, bl.hz, __int_as_float(la), __uint_as_float((uint32_t)first));
+        pl[0] = make_float4(bl.lx, bl.ly, bl.lz, bl.hx); pl[1] = make_float4(bl.hy, bl.hz, __int_as_float(la), __uint_as_float((uint32_t)first | fx));
         pr[0] = make_float4(br.lx, br.ly, br.lz, br.hx); pr[1] = make_float4(br.hy, br.hz, __int_as_float(lb), __uint_as_float((uint32_t)last | fl));
         if (i == 0) *root_name = split;                                    // (a tree of one block: the root is an in-block node)
     }
@@ -285,10 +293,10 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
 // Box of heap node k at level p (2^p leaves) for the cross nodes' queries: the leaves' fp32 boxes (levels below
 // SEG32_MIN_LEVEL are rebuilt from them), the blocks' fp32 trees (seg32), above the blocks the FP64 boxes of
 // k_refit_seg_top rounded outward.
-__device__ __forceinline__ B32 seg_piece32(const double *__restrict__ seg, const float *__restrict__ seg32, const LeafBox32 *__restrict__ qbox32,
+__device__ __forceinline__ B32 seg_piece32(const AmbTable &amb, const double *__restrict__ seg, const float *__restrict__ seg32, const LeafBox32 *__restrict__ qbox32,
                                            int n, long long P, long long k, int p, int seg_min = SEG_MIN_LEVEL)
 {
-    if (p > REFIT_LOG) return b32_of(load_box(seg, (int)k));
+    if (p > REFIT_LOG) return b32_of(amb, load_box(seg, (int)k));
     if (p >= seg_min) return b32_load(seg32 + 6 * (size_t)k);
     const long long j0 = (k << p) - P;
     B32 x = b32_identity();
@@ -324,7 +332,7 @@ __device__ __forceinline__ B32 b32_shfl_down(const B32 &x, int s)
 __global__ __launch_bounds__(256) void k_cross_records(int n, const NodeMeta *__restrict__ meta, const double *__restrict__ seg, const float *__restrict__ seg32,
                                                        int nbp2, const LeafBox32 *__restrict__ qbox32, double *__restrict__ boxes, NodeRec32 *__restrict__ recs32,
                                                        const int32_t *__restrict__ split_of, int32_t *__restrict__ root_name,
-                                                       const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap)
+                                                       const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap, AmbTable amb)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t total = min(*dense_total, dense_cap);
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(256) void k_cross_records(int n, const NodeMeta *__
             if (lp < rp) {
                 const long long k = is_left ? lp : rp - 1;
                 const bool take = is_left ? (lp & 1) : (rp & 1);
-                if (take) x = seg_piece32(seg, seg32, qbox32, n, P, k, p);
+                if (take) x = seg_piece32(amb, seg, seg32, qbox32, n, P, k, p);
             }
             // steps 1, 2, 4, 8 stay inside a row of 16 lanes (DPP row_shl, a VALU move); a lane whose source would be
             // outside its row keeps the identity -- only lanes whose result is never consumed are affected
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(256) void k_cross_records(int n, const NodeMeta *__
                 if (lp < rp) {
                     const long long k = is_left ? lp : rp - 1;
                     const bool take = is_left ? (lp & 1) : (rp & 1);
-                    if (take) y = seg_piece32(seg, seg32, qbox32, n, P, k, p);
+                    if (take) y = seg_piece32(amb, seg, seg32, qbox32, n, P, k, p);
                 }
                 for (int s = 1; s < 64; s <<= 1) y = b32_merge(y, b32_shfl_down(y, s));
                 res[h] = B32{__shfl(y.lx, 0), __shfl(y.ly, 0), __shfl(y.lz, 0), __shfl(y.hx, 0), __shfl(y.hy, 0), __shfl(y.hz, 0)};
@@ -372,13 +380,13 @@ __global__ __launch_bounds__(256) void k_cross_records(int n, const NodeMeta *__
             x = second ? res[1] : res[0];
         }
         const bool leafL = split == first, leafR = split + 1 == last;       // (wave-uniform)
-        uint32_t fl = 0;
-        if (leafL && (qbox32[first].flags & LB_EXACT)) fl |= REC_L_EXACT;
-        if (leafR && (qbox32[last].flags & LB_EXACT)) fl |= REC_R_EXACT;
+        uint32_t fl = 0, fx = 0;
+        if (leafL) { const uint32_t f = qbox32[first].flags; if (f & LB_CERTAIN) fl |= REC_L_CERTAIN; if (f & LB_EXACT) fx |= REC_L_EXACT; }
+        if (leafR) { const uint32_t f = qbox32[last].flags; if (f & LB_CERTAIN) fl |= REC_R_CERTAIN; if (f & LB_EXACT) fx |= REC_R_EXACT; }
         if (lane == 0) {
             const int32_t la = child_link(meta, split_of, m.x, n - 1);
             float4 *pl = const_cast<float4 *>(rec_left(recs32, n, (uint32_t)split));
-            pl[0] = make_float4(x.lx, x.ly, x.lz, x.hx); pl[1] = make_float4(x.hy, x.hz, __int_as_float(la), __uint_as_float((uint32_t)first));
+            pl[0] = make_float4(x.lx, x.ly, x.lz, x.hx); pl[1] = make_float4(x.hy, x.hz, __int_as_float(la), __uint_as_float((uint32_t)first | fx));
             if (i == 0) { *root_name = split; store_box(boxes, 0, load_box(seg, 1)); }   // the box of all leaves, from k_refit_seg_top
         }
         if (lane == 32) {
@@ -646,13 +654,14 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
         accL = dpp_step32<0x101>(accL); accL = dpp_step32<0x102>(accL); accL = dpp_step32<0x104>(accL); accL = dpp_step32<0x108>(accL);
         accR = dpp_step32<0x101>(accR); accR = dpp_step32<0x102>(accR); accR = dpp_step32<0x104>(accR); accR = dpp_step32<0x108>(accR);
         if (own) {
-            const uint32_t fl = ((leafL && (flagL & LB_EXACT)) ? REC_L_EXACT : 0u) | ((leafR && (flagR & LB_EXACT)) ? REC_R_EXACT : 0u);
+            const uint32_t fl = ((leafL && (flagL & LB_CERTAIN)) ? REC_L_CERTAIN : 0u) | ((leafR && (flagR & LB_CERTAIN)) ? REC_R_CERTAIN : 0u);
+            const uint32_t fx = ((leafL && (flagL & LB_EXACT)) ? REC_L_EXACT : 0u) | ((leafR && (flagR & LB_EXACT)) ? REC_R_EXACT : 0u);
             const int32_t linkL = leafL ? ~split : soL, linkR = leafR ? ~(split + 1) : soR;      // (a cross child writes its own name: the link word is not touched below)
             float4 *pl = const_cast<float4 *>(rec_left(recs32, n, (uint32_t)split)), *pr = const_cast<float4 *>(rec_right(recs32, n, (uint32_t)split));
             pl[0] = make_float4(accL.lx, accL.ly, accL.lz, accL.hx);
             pr[0] = make_float4(accR.lx, accR.ly, accR.lz, accR.hx);
-            if (crossL) { reinterpret_cast<float2 *>(pl + 1)[0] = make_float2(accL.hy, accL.hz); reinterpret_cast<uint32_t *>(pl + 1)[3] = (uint32_t)first; }
-            else pl[1] = make_float4(accL.hy, accL.hz, __int_as_float(linkL), __uint_as_float((uint32_t)first));
+            if (crossL) { reinterpret_cast<float2 *>(pl + 1)[0] = make_float2(accL.hy, accL.hz); reinterpret_cast<uint32_t *>(pl + 1)[3] = (uint32_t)first | fx; }
+            else pl[1] = make_float4(accL.hy, accL.hz, __int_as_float(linkL), __uint_as_float((uint32_t)first | fx));
             if (crossR) { reinterpret_cast<float2 *>(pr + 1)[0] = make_float2(accR.hy, accR.hz); reinterpret_cast<uint32_t *>(pr + 1)[3] = (uint32_t)last | fl; }
             else pr[1] = make_float4(accR.hy, accR.hz, __int_as_float(linkR), __uint_as_float((uint32_t)last | fl));
         }

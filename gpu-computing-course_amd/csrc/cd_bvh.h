@@ -13,9 +13,105 @@ namespace cd {
 //   are written by the PARENT's thread.  Replaces the reference's pointer-linked 112-byte Node (bvh.cuh:25-43).
 typedef int4 NodeMeta;
 
-// fp32 traversal record, one 64-byte line: both child boxes rounded OUTWARD to float (lo down, hi up) +
-// both child links.  Internal-node boxes only cull; a conservative (superset) box can never lose a pair, and
-// every leaf hit is re-decided with the exact FP64 product-form test of box.cuh:40-43 before it counts.
+// ---------------------------------------------------------------- fp32 boxes that keep TIES: the cell table
+// The traversal compares fp32 copies of FP64 box bounds with the reference's strict '<' (box.cuh:40-43 as intervals:
+// a.lo < b.hi).  Plain outward rounding (lo down, hi up) is conservative, but it turns every pair of bounds that are
+// EQUAL and not fp32 values into an overlap of one ulp -- and in a mesh neighbouring triangles share box faces exactly
+// (the same vertex coordinate), so a mesh whose coordinates are full doubles had 5 x the node visits and 70 x the
+// candidates of the same mesh rounded to float.  No lossy representation can tell "equal" from "a hair apart" -- but
+// the table below knows where it matters: a CELL is the set of doubles with the same fp32 floor, cell(x) = rd32(x), and a
+// cell is AMBIGUOUS iff two DISTINCT doubles among the mesh's vertex coordinates of that axis lie in it (every box bound
+// is a vertex coordinate).  Encoding:   lo' = rd32(lo)       hi' = rd32(hi), one ulp up iff cell(hi) is ambiguous.
+//   * different cells: rd32 is monotone and cells are an ulp apart, so lo' < hi' <=> lo < hi, exactly;
+//   * the same cell, unambiguous: lo and hi are the same double (touching): lo' == hi', '<' says no -- exact;
+//   * the same cell, ambiguous: hi' = lo' + ulp, '<' says "maybe" -- conservative, as outward rounding always was.
+// hi' is monotone in hi (a lower cell's base + ulp is at most the next cell's base), so it commutes with max: the fp32
+// box of a leaf range is still the min / max of its leaves' fp32 boxes, bit for bit (cd_build.h).  A box all six of whose
+// bounds lie in unambiguous cells is CERTAIN: any '<' between it and another certain box decides what FP64 decides.
+// A mesh whose coordinates are all fp32 values has no ambiguous cell (distinct floats are distinct cells) and no table:
+// keys == nullptr, hi' = rd32(hi) = hi -- the encoding of earlier rounds, bit for bit.  -0.0 and +0.0 are one cell.
+// Bounds of OTHER meshes (external queries, peer root boxes) are not in the table: those comparisons treat an fp32 tie
+// as "maybe" unless both sides are fp32 values (cd_traverse.h).  The table is rebuilt when the vertices are uploaded
+// (cd_create, cd_update_vertices: mi355cd.hip amb_refresh), not per step: it is a function of the vertices alone.
+struct AmbTable { const unsigned long long *keys; uint32_t shift, mask; };
+constexpr unsigned long long AMB_BIT = 1ull << 63;
+__device__ __forceinline__ uint32_t amb_cell(double x)
+{
+    const uint32_t c = __float_as_uint(__double2float_rd(x));
+    return c == 0x80000000u ? 0u : c;                                      // -0.0 and +0.0 compare equal: one cell
+}
+__device__ __host__ __forceinline__ unsigned long long amb_key(int axis, uint32_t cell) { return (((unsigned long long)axis << 32) | cell) + 1ull; }   // (never 0 = empty slot)
+__device__ __host__ __forceinline__ uint32_t amb_hash(unsigned long long key, uint32_t shift) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift); }
+// Is the cell of x (a vertex coordinate of axis `axis`) ambiguous?  A value that is not in the table -- cannot happen for
+// a bound of this mesh -- counts as ambiguous (conservative).
+__device__ __forceinline__ bool amb_lookup(const AmbTable &t, int axis, double x)
+{
+    if (!t.keys) return false;
+    const unsigned long long key = amb_key(axis, amb_cell(x));
+    uint32_t h = amb_hash(key, t.shift);
+    for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+        const unsigned long long k = t.keys[h];
+        if ((k & ~AMB_BIT) == key) return (k & AMB_BIT) != 0ull;
+        if (k == 0ull) return true;
+        h = (h + 1u) & t.mask;
+    }
+    return true;
+}
+__device__ __forceinline__ float f32_next_up(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    if ((u << 1) == 0u) return __uint_as_float(1u);                        // +-0 -> the smallest positive value
+    return __uint_as_float((u >> 31) ? u - 1u : u + 1u);
+}
+// the fp32 copy of an FP64 box as described above, and whether the box is certain
+struct Enc32 { float lx, ly, lz, hx, hy, hz; bool certain; };
+__device__ __forceinline__ Enc32 enc_box32(const AmbTable &t, const Box &b, bool want_certain)
+{
+    const bool ax = amb_lookup(t, 0, b.x2), ay = amb_lookup(t, 1, b.y2), az = amb_lookup(t, 2, b.z2);
+    bool lo_amb = false;
+    if (want_certain && t.keys) lo_amb = amb_lookup(t, 0, b.x1) | amb_lookup(t, 1, b.y1) | amb_lookup(t, 2, b.z1);
+    Enc32 e;
+    e.lx = __double2float_rd(b.x1); e.ly = __double2float_rd(b.y1); e.lz = __double2float_rd(b.z1);
+    e.hx = __double2float_rd(b.x2); e.hy = __double2float_rd(b.y2); e.hz = __double2float_rd(b.z2);
+    if (ax) e.hx = f32_next_up(e.hx);
+    if (ay) e.hy = f32_next_up(e.hy);
+    if (az) e.hz = f32_next_up(e.hz);
+    e.certain = !(ax | ay | az | lo_amb);
+    return e;
+}
+
+// The same for a LEAF box, whose bounds are coordinates of its own three vertices: the vertices' flags (vamb[v] bit a: the cell of
+// vertex v's coordinate a is ambiguous; written once per upload by k_amb_vertex) stand in for six probes of the table.
+// Equal coordinates lie in one cell, so any vertex that attains a bound has the bound's flag.  vamb == nullptr: no table.
+__device__ __forceinline__ Enc32 enc_leaf32(const Box &b, const d3 A, const d3 B, const d3 C, const uint8_t *__restrict__ vamb, uint32_t va, uint32_t vb, uint32_t vc)
+{
+    uint32_t fa = 0, fb = 0, fc = 0;
+    if (vamb) { fa = vamb[va]; fb = vamb[vb]; fc = vamb[vc]; }
+    auto pick = [&](double bound, double a, double bb, int bit) -> bool { const uint32_t f = (a == bound) ? fa : ((bb == bound) ? fb : fc); return ((f >> bit) & 1u) != 0u; };
+    const bool ax = pick(b.x2, A.x, B.x, 0), ay = pick(b.y2, A.y, B.y, 1), az = pick(b.z2, A.z, B.z, 2);
+    const bool lo_amb = pick(b.x1, A.x, B.x, 0) | pick(b.y1, A.y, B.y, 1) | pick(b.z1, A.z, B.z, 2);
+    Enc32 e;
+    e.lx = __double2float_rd(b.x1); e.ly = __double2float_rd(b.y1); e.lz = __double2float_rd(b.z1);
+    e.hx = __double2float_rd(b.x2); e.hy = __double2float_rd(b.y2); e.hz = __double2float_rd(b.z2);
+    if (ax) e.hx = f32_next_up(e.hx);
+    if (ay) e.hy = f32_next_up(e.hy);
+    if (az) e.hz = f32_next_up(e.hz);
+    e.certain = !(ax | ay | az | lo_amb);
+    return e;
+}
+// vamb[v]: bit a = the cell of vertex v's coordinate a is ambiguous
+__global__ void k_amb_vertex(const double *__restrict__ verts, uint32_t nv, AmbTable t, uint8_t *__restrict__ vamb)
+{
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += gridDim.x * blockDim.x) {
+        const double x = verts[3 * (size_t)v], y = verts[3 * (size_t)v + 1], z = verts[3 * (size_t)v + 2];
+        vamb[v] = (uint8_t)((amb_lookup(t, 0, x) ? 1u : 0u) | (amb_lookup(t, 1, y) ? 2u : 0u) | (amb_lookup(t, 2, z) ? 4u : 0u));
+    }
+}
+
+// fp32 traversal record, one 64-byte line: both child boxes as fp32 copies (lo down; hi down, one ulp up where its cell is
+// ambiguous: above) + both child links.  Internal-node boxes only cull; a conservative (superset) box can never lose a
+// pair, and every leaf hit is decided by the exact FP64 product-form test of box.cuh:40-43 before it counts -- which for
+// two CERTAIN leaf boxes is what the fp32 '<' already decided.
 //
 // Records are NAMED BY SPLIT: recs[s] is the internal node whose left child covers [first, s] and whose right
 // child covers [s + 1, last] (every s in [0, n-2] is the split of exactly one Karras node, so this is a
@@ -27,27 +123,29 @@ typedef int4 NodeMeta;
 // of n x 64 bytes): a hop of that chain reads only the right half, so the chain walks a dense 32-byte-per-node array
 // (rec_right); a descent step reads both (rec_left, rec_right).  NodeRec32 remains the logical record.
 constexpr uint32_t REC_LAST_MASK = 0x3fffffffu;     // n <= 2^30 (the candidate encoding has the same limit)
-constexpr uint32_t REC_L_EXACT = 0x40000000u;       // in `last`: the left / right child box is exactly representable
-constexpr uint32_t REC_R_EXACT = 0x80000000u;       //   in fp32 (box_is_fp32)
+constexpr uint32_t REC_L_CERTAIN = 0x40000000u;     // in `last`: the left / right child is a leaf whose box is CERTAIN (all its bounds in
+constexpr uint32_t REC_R_CERTAIN = 0x80000000u;     //   unambiguous cells: an fp32 '<' against another certain box of this mesh is exact)
+constexpr uint32_t REC_L_EXACT = 0x40000000u;       // in `first`: the left / right child is a leaf whose box is EXACT (certain, and its six
+constexpr uint32_t REC_R_EXACT = 0x80000000u;       //   bounds are fp32 values: the fp32 copy IS the box -- what a query from another mesh needs)
 struct alignas(64) NodeRec32 {
-    float l_lo[3], l_hi[3]; int32_t cl; uint32_t first;     // quad 0, quad 1: left child (first: range start, informational)
-    float r_lo[3], r_hi[3]; int32_t cr; uint32_t last;      // quad 2, quad 3: right child, range end | REC_*_EXACT
+    float l_lo[3], l_hi[3]; int32_t cl; uint32_t first;     // quad 0, quad 1: left child, range start | REC_*_EXACT
+    float r_lo[3], r_hi[3]; int32_t cr; uint32_t last;      // quad 2, quad 3: right child, range end | REC_*_CERTAIN
 };
 static_assert(sizeof(NodeRec32) == 64, "NodeRec32 is two 32-byte halves");
 // quads (16 bytes) of the two halves of record s; `recs` is the allocation's base, n the number of leaves (= record slots)
 __device__ __forceinline__ const float4 *rec_right(const NodeRec32 *recs, int n, uint32_t s) { return reinterpret_cast<const float4 *>(recs) + 2 * (size_t)s; }
 __device__ __forceinline__ const float4 *rec_left(const NodeRec32 *recs, int n, uint32_t s) { return reinterpret_cast<const float4 *>(recs) + 2 * (size_t)n + 2 * (size_t)s; }
 
-// fp32 query box of leaf j, rounded outward like the records', written by the refit: 32 coalesced bytes per query
+// fp32 query box of leaf j, encoded like the records', written by the refit: 32 coalesced bytes per query
 // instead of the 48-byte FP64 box (k_descend and the packers read it; k_descend_half takes the same box and the same
-// exact bit out of the leaf's parent record, which it reads anyway -- cd_traverse.h).  flags bit 0: the box is exact in fp32; bit 1: the FP64 box strictly
+// certain bit out of the leaf's parent record, which it reads anyway -- cd_traverse.h).  flags bit 0: the box is EXACT (fp32 values, certain); bit 2: CERTAIN; bit 1: the FP64 box strictly
 // overlaps itself (box.cuh:40-43 with a == b -- false for a box that is flat along an axis): the query's hit on its
 // own leaf, which every traversal of the reference meets once (collision.cuh:31-32), is decided here, exactly.
 struct alignas(32) LeafBox32 { float lo[3], hi[3]; uint32_t flags, pad; };
 static_assert(sizeof(LeafBox32) == 32, "LeafBox32 layout");
-constexpr uint32_t LB_EXACT = 1u, LB_SELF = 2u;
+constexpr uint32_t LB_EXACT = 1u, LB_SELF = 2u, LB_CERTAIN = 4u;
 
-// FP64 box of leaf j.  A box that is exact in fp32 IS its query box (widening is exact, signed zeros included), and the
+// FP64 box of leaf j.  An EXACT box IS its query box (fp32 values in unambiguous cells: nothing was moved; widening is exact, signed zeros included), and the
 // fused build (cd_build.h) does not store the FP64 copy of such a leaf at all: every reader of leaf boxes on the
 // traversal side comes through here.  (The stage-wise refit writes all of boxes[]: that is what cd_export_tree shows.)
 __device__ __forceinline__ Box load_box(const double *boxes, int node);
@@ -374,14 +472,16 @@ __device__ __forceinline__ bool box_is_fp32(const Box &b)
            (double)(float)b.y2 == b.y2 && (double)(float)b.z1 == b.z1 && (double)(float)b.z2 == b.z2;
 }
 
-__device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ recs, int n, uint32_t split, const Box &bl, const Box &br, int2 ch, uint32_t first, uint32_t last)
+__device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ recs, int n, uint32_t split, const Box &bl, const Box &br, int2 ch, uint32_t first, uint32_t last,
+                                            const AmbTable &amb)
 {
     float4 *pl = const_cast<float4 *>(rec_left(recs, n, split)), *pr = const_cast<float4 *>(rec_right(recs, n, split));
-    pl[0] = make_float4(__double2float_rd(bl.x1), __double2float_rd(bl.y1), __double2float_rd(bl.z1), __double2float_ru(bl.x2));
-    pl[1] = make_float4(__double2float_ru(bl.y2), __double2float_ru(bl.z2), __int_as_float(ch.x), __uint_as_float(first));
-    pr[0] = make_float4(__double2float_rd(br.x1), __double2float_rd(br.y1), __double2float_rd(br.z1), __double2float_ru(br.x2));
-    pr[1] = make_float4(__double2float_ru(br.y2), __double2float_ru(br.z2), __int_as_float(ch.y),
-                        __uint_as_float(last | (box_is_fp32(bl) ? REC_L_EXACT : 0u) | (box_is_fp32(br) ? REC_R_EXACT : 0u)));
+    const Enc32 el = enc_box32(amb, bl, true), er = enc_box32(amb, br, true);        // (the flags only matter where the child is a leaf)
+    pl[0] = make_float4(el.lx, el.ly, el.lz, el.hx);
+    pl[1] = make_float4(el.hy, el.hz, __int_as_float(ch.x),
+                        __uint_as_float(first | ((el.certain && box_is_fp32(bl)) ? REC_L_EXACT : 0u) | ((er.certain && box_is_fp32(br)) ? REC_R_EXACT : 0u)));
+    pr[0] = make_float4(er.lx, er.ly, er.lz, er.hx);
+    pr[1] = make_float4(er.hy, er.hz, __int_as_float(ch.y), __uint_as_float(last | (el.certain ? REC_L_CERTAIN : 0u) | (er.certain ? REC_R_CERTAIN : 0u)));
 }
 
 // Link stored in a record for child `c` (unified Karras id): ~j for leaf j, the child's own split for an internal
@@ -427,10 +527,10 @@ __device__ __forceinline__ Box box_identity()
 // Given the exact boxes of both children, write the node's 64-byte fp32 traversal record -- at its SPLIT -- and return
 // the node's exact box (bvh.cuh:277 merge(childA, childB)).
 __device__ __forceinline__ Box emit_node(const Box &bl, const Box &br, const NodeMeta *__restrict__ meta,
-                                         int cl, int cr, int split, int first, int last, NodeRec32 *__restrict__ recs32, int nleaf_base)
+                                         int cl, int cr, int split, int first, int last, NodeRec32 *__restrict__ recs32, int nleaf_base, const AmbTable &amb)
 {
     store_rec32(recs32, nleaf_base + 1, (uint32_t)split, bl, br, make_int2(child_link(meta, nullptr, cl, nleaf_base), child_link(meta, nullptr, cr, nleaf_base)),
-                (uint32_t)first, (uint32_t)last);
+                (uint32_t)first, (uint32_t)last, amb);
     return box_merge(bl, br);
 }
 
@@ -470,7 +570,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
                                                                int32_t *__restrict__ root_name, int write_internal /* 0: FP64 boxes of the root and the leaves only */,
                                                                double *__restrict__ seg /* P x 6, heap order, node 0 unused */, int nbp2,
                                                                int32_t *__restrict__ cross_list /* cross_cap entries */, uint32_t *__restrict__ cross_count /* its length */,
-                                                               uint32_t cross_cap)
+                                                               uint32_t cross_cap, AmbTable amb, const uint8_t *__restrict__ vamb)
 {
     __shared__ double t[2 * REFIT_BLK][6];          // 48 KB
     __shared__ int32_t lcross[REFIT_BLK];
@@ -481,12 +581,14 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
     Box mine = box_identity();
     if (j < n) {
         const LeafTri lt = leaf[j];
-        mine = box_set(load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2));   // box.cuh:13-22
+        const d3 A = load_vertex(verts, lt.v0), B = load_vertex(verts, lt.v1), C = load_vertex(verts, lt.v2);
+        mine = box_set(A, B, C);                                           // box.cuh:13-22
         store_box(boxes, (n - 1) + j, mine);
         float4 *qp = reinterpret_cast<float4 *>(qbox32 + j);
-        qp[0] = make_float4(__double2float_rd(mine.x1), __double2float_rd(mine.y1), __double2float_rd(mine.z1), __double2float_ru(mine.x2));
-        qp[1] = make_float4(__double2float_ru(mine.y2), __double2float_ru(mine.z2),
-                            __uint_as_float((box_is_fp32(mine) ? LB_EXACT : 0u) | (box_overlap(mine, mine) ? LB_SELF : 0u)), 0.f);
+        const Enc32 e = enc_leaf32(mine, A, B, C, vamb, lt.v0, lt.v1, lt.v2);
+        qp[0] = make_float4(e.lx, e.ly, e.lz, e.hx);
+        qp[1] = make_float4(e.hy, e.hz, __uint_as_float(((e.certain && box_is_fp32(mine)) ? LB_EXACT : 0u) | (e.certain ? LB_CERTAIN : 0u) |
+                                                        (box_overlap(mine, mine) ? LB_SELF : 0u)), 0.f);
     }
     {
         double *d = t[REFIT_BLK + tid];
@@ -519,7 +621,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
         const int ca = (split == first) ? (n - 1) + split : split, cb = (split + 1 == last) ? (n - 1) + split + 1 : split + 1;
         const Box bl = seg_query_lds(t, first - b0, split - b0);
         const Box br = seg_query_lds(t, split + 1 - b0, last - b0);
-        const Box whole = emit_node(bl, br, meta, ca, cb, split, first, last, recs32, n - 1);
+        const Box whole = emit_node(bl, br, meta, ca, cb, split, first, last, recs32, n - 1, amb);
         // The FP64 boxes of internal nodes are the OUTPUT of calBoundingBox (bvh.cuh:277): written on request
         if (write_internal || i == 0) store_box(boxes, i, whole);
         if (i == 0) *root_name = split;
@@ -828,7 +930,7 @@ __global__ __launch_bounds__(256) void k_cross_meta(const uint64_t *__restrict__
 __global__ __launch_bounds__(256) void k_refit_seg_cross(int n, const NodeMeta *__restrict__ meta, const double *__restrict__ seg, int nbp2,
                                                          double *boxes, uint32_t *__restrict__ bounded, NodeRec32 *__restrict__ recs32,
                                                          int32_t *__restrict__ root_name, int write_internal,
-                                                         const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap)
+                                                         const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap, AmbTable amb)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t total = min(*dense_total, dense_cap);
@@ -849,7 +951,7 @@ __global__ __launch_bounds__(256) void k_refit_seg_cross(int n, const NodeMeta *
             br = seg_query_wave(seg, boxes, n, P, split + 1, last, lane);
         }
         if (lane == 0) {
-            const Box whole = emit_node(bl, br, meta, m.x, m.y, split, first, last, recs32, n - 1);
+            const Box whole = emit_node(bl, br, meta, m.x, m.y, split, first, last, recs32, n - 1, amb);
             if (write_internal || i == 0) store_box(boxes, i, whole);
             if (i == 0) *root_name = split;
             bounded[i] = 2;

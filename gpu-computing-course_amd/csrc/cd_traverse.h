@@ -259,7 +259,7 @@ constexpr int WQ_QCAP  = 192;                // queue slots per wave: < 64 left 
 constexpr int WQ_WAVES = TRAV_THREADS / 64;
 constexpr int SHARE_MIN_IDLE = 16;           // idle lanes in a wave before busy lanes hand subtrees over (65 = never); 4 .. 16 measured equal, 1 and 32 worse
 
-// leaf: bit 31 set = both boxes are exact in fp32 (cd_bvh.h box_is_fp32), so the fp32 overlap found by the descent IS
+// leaf: bit 31 set = both boxes are CERTAIN (cd_bvh.h: every bound in an unambiguous cell), so the fp32 overlap found by the descent IS
 // the exact leaf-AABB test and k_exact need not fetch the two FP64 boxes again
 struct Candidates { uint32_t q, leaf; };
 constexpr uint32_t CAND_CERTAIN = 0x80000000u;
@@ -365,13 +365,13 @@ __global__ __launch_bounds__(DESC_THREADS) void k_descend(QuerySrc src, uint32_t
                         qlo0 = __double2float_rd(qb.x1); qhi0 = __double2float_ru(qb.x2);
                         qlo1 = __double2float_rd(qb.y1); qhi1 = __double2float_ru(qb.y2);
                         qlo2 = __double2float_rd(qb.z1); qhi2 = __double2float_ru(qb.z2);
-                        qcertain = box_is_fp32(qb) ? CAND_CERTAIN : 0u;
+                        qcertain = box_is_fp32(qb) ? CAND_CERTAIN : 0u;     // (a query from another mesh: certain against EXACT leaves only, see the step below)
                     } else {
                         const float4 *qp = reinterpret_cast<const float4 *>(src.qbox + qi);
                         const float4 q0 = qp[0], q1 = qp[1];
                         const uint32_t qfl = __float_as_uint(q1.z);
                         qlo0 = q0.x; qlo1 = q0.y; qlo2 = q0.z; qhi0 = q0.w; qhi1 = q1.x; qhi2 = q1.y;
-                        qcertain = (qfl & LB_EXACT) ? CAND_CERTAIN : 0u;
+                        qcertain = (qfl & LB_CERTAIN) ? CAND_CERTAIN : 0u;
                         self_leaf = qi;
                         // the query meets its own leaf in every traversal: that hit was decided by the refit, exactly, once
                         // (not counted in the deep pass, which only continues a traversal that already did)
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(DESC_THREADS) void k_descend(QuerySrc src, uint32_t
                 const uint32_t split = (uint32_t)pn;                           // a record's name IS its split position
                 const bool go_left = g0 <= split;                             // uniform
                 const int32_t sib = go_left ? chr : chl, onp = go_left ? chl : chr;
-                const uint32_t sib_exact = (uint32_t)r3.w & (go_left ? REC_R_EXACT : REC_L_EXACT), onp_exact = (uint32_t)r3.w & (go_left ? REC_L_EXACT : REC_R_EXACT);
+                const uint32_t sib_exact = (uint32_t)r3.w & (go_left ? REC_R_CERTAIN : REC_L_CERTAIN), onp_exact = (uint32_t)r3.w & (go_left ? REC_L_CERTAIN : REC_R_CERTAIN);
                 // record layout: left = lo(r0.x,r0.y,r0.z) hi(r0.w,r1.x,r1.y), right = lo(r2.x,r2.y,r2.z) hi(r2.w,r3.x,r3.y).
                 // The selects are done on the raw words, so that they stay scalar (s_cselect) like their condition.
                 const float slo0 = __int_as_float(go_left ? r2.x : r0.x), slo1 = __int_as_float(go_left ? r2.y : r0.y), slo2 = __int_as_float(go_left ? r2.z : r0.z);
@@ -467,12 +467,25 @@ __global__ __launch_bounds__(DESC_THREADS) void k_descend(QuerySrc src, uint32_t
         const uint32_t rn = active ? (uint32_t)node : 0u;
         const float4 *rpl = rec_left(recs, n, rn), *rpr = rec_right(recs, n, rn);
         const float4 a = rpl[0], b = rpl[1], c = rpr[0], d = rpr[1];
-        // child links: internal -> its split (>= 0), leaf j -> ~j; ch.z: REC_L_EXACT / REC_R_EXACT
-        const int4 ch = make_int4(__float_as_int(b.z), __float_as_int(d.z), (int)(__float_as_uint(d.w) >> 30), 0);
+        // child links: internal -> its split (>= 0), leaf j -> ~j; ch.z: the leaf children's flags -- CERTAIN (in `last`) for this mesh's own
+        // queries, EXACT (in `first`) for queries from another mesh
+        const int4 ch = make_int4(__float_as_int(b.z), __float_as_int(d.z), (int)(__float_as_uint(EXTERNAL ? b.w : d.w) >> 30), 0);
         // left: lo = (a.x, a.y, a.z) hi = (a.w, b.x, b.y); right: lo = (c.x, c.y, c.z) hi = (c.w, d.x, d.y)
         // (bitwise & on purpose: && would be lowered to short-circuit branches with exec-mask juggling)
-        const bool ol  = active & (qlo0 < a.w) & (a.x < qhi0) & (qlo1 < b.x) & (a.y < qhi1) & (qlo2 < b.y) & (a.z < qhi2);
-        const bool orr = active & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
+        bool ol  = active & (qlo0 < a.w) & (a.x < qhi0) & (qlo1 < b.x) & (a.y < qhi1) & (qlo2 < b.y) & (a.z < qhi2);
+        bool orr = active & (qlo0 < c.w) & (c.x < qhi0) & (qlo1 < d.x) & (c.y < qhi1) & (qlo2 < d.y) & (c.z < qhi2);
+        if (EXTERNAL) {
+            // The query's bounds are not in this mesh's cell table (cd_bvh.h): its box is rounded outward, and a node's hi' is only
+            // known to be above every bound of THIS mesh in its cell.  lo_node < hi_query stays conservative as it is (hi_query is
+            // rounded up); lo_query vs hi' needs the tie: equal fp32 values mean "maybe" -- unless both are fp32 values themselves
+            // (the query box exact, the child an EXACT leaf), where equal means touching, exactly.
+            const bool tmL = !band(qcertain != 0u, band(ch.x < 0, (ch.z & 1) != 0)), tmR = !band(qcertain != 0u, band(ch.y < 0, (ch.z & 2) != 0));
+            const bool olt  = active & ((qlo0 < a.w) | ((qlo0 == a.w) & tmL)) & (a.x < qhi0) & ((qlo1 < b.x) | ((qlo1 == b.x) & tmL)) & (a.y < qhi1) &
+                              ((qlo2 < b.y) | ((qlo2 == b.y) & tmL)) & (a.z < qhi2);
+            const bool ort = active & ((qlo0 < c.w) | ((qlo0 == c.w) & tmR)) & (c.x < qhi0) & ((qlo1 < d.x) | ((qlo1 == d.x) & tmR)) & (c.y < qhi1) &
+                              ((qlo2 < d.y) | ((qlo2 == d.y) & tmR)) & (c.z < qhi2);
+            ol = olt; orr = ort;
+        }
         visits += active ? 1u : 0u;
         // (selects on i1, not integer & of promoted bools: the masks then stay in SGPR pairs instead of being
         // materialised as 0 / 1 in VGPRs and compared again)
@@ -657,11 +670,12 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         const bool is_left = own && __float_as_int(lb.z) == (int32_t)~qi;
         qlo0 = is_left ? la.x : pc.x; qlo1 = is_left ? la.y : pc.y; qlo2 = is_left ? la.z : pc.z;
         qhi0 = is_left ? la.w : pc.w; qhi1 = is_left ? lb.x : pd.x; qhi2 = is_left ? lb.y : pd.y;
-        const bool exact = is_left ? (__float_as_uint(rd.w) & REC_L_EXACT) != 0u : (__float_as_uint(pd.w) & REC_R_EXACT) != 0u;
+        const bool exact = is_left ? (__float_as_uint(rd.w) & REC_L_CERTAIN) != 0u : (__float_as_uint(pd.w) & REC_R_CERTAIN) != 0u;   // (the leaf's box is CERTAIN)
         qcertain = exact ? CAND_CERTAIN : 0u;
         // the query's own leaf, which every traversal of the reference meets once (collision.cuh:31-32): box.cuh:40-43 with
-        // a == b is (x1 - x2)^2 > 0 per axis -- for a box that is exact in fp32 that is lo != hi (the difference of two
-        // floats squared does not underflow in FP64), otherwise the FP64 box decides (stored for exactly those leaves)
+        // a == b is (x1 - x2)^2 > 0 per axis -- for a CERTAIN box that is lo' < hi' (equal fp32 copies are equal doubles, different
+        // ones differ by at least the spacing of two fp32 cells, whose square does not underflow in FP64), otherwise the FP64
+        // box decides (stored for every leaf that is not EXACT)
         bool self = exact & (qlo0 < qhi0) & (qlo1 < qhi1) & (qlo2 < qhi2);
         if (valid && !exact) { const Box b = load_box(src.boxes, (n - 1) + (int)qi); self = box_overlap(b, b); }
         if (valid && self) ++tested;
@@ -687,7 +701,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         if constexpr (DIAG) dg_hops_in += act ? 1u : 0u;
         note_subtree(band(hit, link >= 0), link);
         s = act ? (lw & REC_LAST_MASK) : s;
-        enqueue(band(hit, link < 0), qi, (uint32_t)~link | ((lw & REC_R_EXACT) ? qcertain : 0u));
+        enqueue(band(hit, link < 0), qi, (uint32_t)~link | ((lw & REC_R_CERTAIN) ? qcertain : 0u));
     }
     dg_p1a = steps;
     if constexpr (DIAG) tm2 = __builtin_amdgcn_s_memtime();
@@ -708,7 +722,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
             wvisits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(act));
             if constexpr (DIAG) dg_hops_out += act ? 1u : 0u;
             if (link >= 0) note_subtree(hit, link);
-            else enqueue(hit, qi, (uint32_t)~link | ((lw & REC_R_EXACT) ? qcertain : 0u));
+            else enqueue(hit, qi, (uint32_t)~link | ((lw & REC_R_CERTAIN) ? qcertain : 0u));
             t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lw & REC_LAST_MASK));
         }
     }
@@ -760,8 +774,8 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
             node = active ? nxt : -1;
             const bool candL = band(ol, cl < 0), candR = band(orr, cr < 0);
             if (__builtin_amdgcn_ballot_w64(bor(candL, candR)) != 0ull) {        // (most steps meet no leaf: one test instead of two)
-                enqueue(candL, qi, (uint32_t)~cl | ((lw & REC_L_EXACT) ? qcertain : 0u));
-                enqueue(candR, qi, (uint32_t)~cr | ((lw & REC_R_EXACT) ? qcertain : 0u));
+                enqueue(candL, qi, (uint32_t)~cl | ((lw & REC_L_CERTAIN) ? qcertain : 0u));
+                enqueue(candR, qi, (uint32_t)~cr | ((lw & REC_R_CERTAIN) ? qcertain : 0u));
             }
         }
     }
@@ -1032,9 +1046,11 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_queries(const double *__r
         if (p == skip) continue;
         const Box rb = load_box(roots, p);
         if (my_root && !box_overlap(me, rb)) continue;
-        // conservative: the exact strict overlap implies this one (monotone rounding, see DESIGN.md "fp32 boxes")
-        bool hit = live && lo0 < __double2float_ru(rb.x2) && __double2float_rd(rb.x1) < hi0 && lo1 < __double2float_ru(rb.y2) &&
-                   __double2float_rd(rb.y1) < hi1 && lo2 < __double2float_ru(rb.z2) && __double2float_rd(rb.z1) < hi2;
+        // conservative: the exact strict overlap implies this one.  The peer's box is not in this mesh's cell table (cd_bvh.h), so
+        // its lo against the leaf's hi' is '<=' (a tie may hide a bound of the peer below the leaf's); the leaf's lo' against the
+        // peer's hi rounded up can stay strict
+        bool hit = live && lo0 < __double2float_ru(rb.x2) && __double2float_rd(rb.x1) <= hi0 && lo1 < __double2float_ru(rb.y2) &&
+                   __double2float_rd(rb.y1) <= hi1 && lo2 < __double2float_ru(rb.z2) && __double2float_rd(rb.z1) <= hi2;
         if (hit) {
             if (!have_box) {                                                  // (an exact-in-fp32 box is its query box: leaf_box64, cd_bvh.h)
                 mine = exact32 ? Box{(double)lo0, (double)hi0, (double)lo1, (double)hi1, (double)lo2, (double)hi2} : load_box(boxes, (n - 1) + j);

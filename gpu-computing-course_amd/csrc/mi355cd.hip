@@ -79,6 +79,10 @@ struct cd_ctx {
     unsigned long long *d_top_pub = nullptr; uint32_t top_seq = 0;          // k_cross_fused: the upper levels of the fp32 tree as its first workgroup publishes them, and the launch counter its flag word carries
     LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; double *d_seg = nullptr; float *d_seg32 = nullptr; uint32_t nbp2 = 1; int32_t *d_cross = nullptr; uint32_t cross_cap = 0;   // segment tree over leaf boxes: nbp2*512 heap nodes
     double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec32 *d_recs32 = nullptr; LeafBox32 *d_qbox = nullptr;
+    // the cell table of the current vertices (cd_bvh.h AmbTable; amb_refresh): keys == nullptr while every coordinate is an fp32 value
+    AmbTable amb = {nullptr, 0u, 0u};
+    unsigned long long *d_amb_keys = nullptr, *d_amb_mn = nullptr, *d_amb_mx = nullptr; uint64_t amb_cap = 0; uint32_t *d_amb_flag = nullptr;
+    uint8_t *d_vamb = nullptr, *vamb = nullptr;   // per vertex: which of its three coordinates lie in ambiguous cells (vamb: d_vamb, or nullptr while there is no table)
     int32_t *d_root = nullptr;              // name (split) of the root record, one word inside d_small
     bool leaf_records_filled = false;       // leaf[] holds the sorted triangles (leaves_filled: and parent[] / bounded[] are reset)
     bool internal_boxes_valid = false;      // the FP64 boxes of the internal nodes were written by the last refit (fused calls skip them)
@@ -141,6 +145,7 @@ void free_all(cd_ctx *c)
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_top_pub); hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_seg32); hipFree(c->d_cross); hipFree(c->d_boxes);
     hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox); hipFree(c->d_split_of);
+    hipFree(c->d_amb_keys); hipFree(c->d_amb_mn); hipFree(c->d_amb_mx); hipFree(c->d_amb_flag); hipFree(c->d_vamb);
     for (TravBuf &tb : c->tb) {
         if (tb.d_pairs) hipFree(reinterpret_cast<char *>(tb.d_pairs) - sizeof(Report));
         if (tb.h_report) hipHostFree(tb.h_report);
@@ -206,6 +211,36 @@ __global__ void k_tri_contact_points(const double *__restrict__ t, uint64_t n, u
         out[i] = tri_contact(d3{p[0], p[1], p[2]}, d3{p[3], p[4], p[5]}, d3{p[6], p[7], p[8]},
                              d3{p[9], p[10], p[11]}, d3{p[12], p[13], p[14]}, d3{p[15], p[16], p[17]}) ? 1 : 0;
     }
+}
+
+// ---- the cell table of the vertices (cd_bvh.h): which fp32 cells hold two distinct doubles of the same axis
+__global__ void k_amb_scan(const double *__restrict__ v, uint64_t n3, uint32_t *__restrict__ flag)
+{
+    bool any = false;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n3; i += (uint64_t)gridDim.x * blockDim.x) { const double x = v[i]; any |= (double)(float)x != x; }
+    if (__builtin_amdgcn_ballot_w64(any) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+__global__ void k_amb_insert(const double *__restrict__ v, uint64_t n3, unsigned long long *__restrict__ keys, unsigned long long *__restrict__ mn,
+                             unsigned long long *__restrict__ mx, uint32_t shift, uint32_t mask)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n3; i += (uint64_t)gridDim.x * blockDim.x) {
+        double x = v[i];
+        if (x == 0.0) x = 0.0;                                             // -0.0 and +0.0 are the same value
+        const unsigned long long key = amb_key((int)(i % 3), amb_cell(x));
+        uint32_t h = amb_hash(key, shift);
+        for (uint32_t probe = 0; probe <= mask; ++probe) {                 // (the table holds every key at a load below 2 / 3: this ends)
+            const unsigned long long old = atomicCAS(&keys[h], 0ull, key);
+            if (old == 0ull || old == key) break;
+            h = (h + 1u) & mask;
+        }
+        const unsigned long long o = f64_ordered(x);
+        atomicMin(&mn[h], o); atomicMax(&mx[h], o);
+    }
+}
+__global__ void k_amb_mark(unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ mn, const unsigned long long *__restrict__ mx, uint64_t cap)
+{
+    for (uint64_t h = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; h < cap; h += (uint64_t)gridDim.x * blockDim.x)
+        if (keys[h] != 0ull && mn[h] != mx[h]) keys[h] |= AMB_BIT;
 }
 
 constexpr int BOUNDS_BLOCKS = 1024;
@@ -363,15 +398,15 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
             hipExtLaunchKernelGGL(k_build_block, dim3(nblocks), dim3(REFIT_BLK), 0u, s, c->ev[EV_BLK0], c->ev[EV_BLK1], 0u,
                                   (const double *)c->d_verts, (const LeafTri *)c->d_leaf, (int)n, (const uint64_t *)c->d_keys[0], c->d_split_of,
                                   c->d_boxes, c->d_recs32, c->d_qbox, c->d_root, c->d_seg, c->d_seg32, (int)c->nbp2,
-                                  cross_list, cross_count, c->cross_cap, zp, seg_min);
+                                  cross_list, cross_count, c->cross_cap, zp, seg_min, c->amb, (const uint8_t *)c->vamb);
         else                                        // (no time stamps: a plain launch, which a stream capture can record -- graph_step)
             k_build_block<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_keys[0], c->d_split_of, c->d_boxes, c->d_recs32, c->d_qbox, c->d_root,
-                                                        c->d_seg, c->d_seg32, (int)c->nbp2, cross_list, cross_count, c->cross_cap, zp, seg_min);
+                                                        c->d_seg, c->d_seg32, (int)c->nbp2, cross_list, cross_count, c->cross_cap, zp, seg_min, c->amb, (const uint8_t *)c->vamb);
         c->scratch_clean = self_cleaning;       // (judge_sort_flags takes it back when the sort has raised a flag)
     } else
         k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded,
                                                        c->d_recs32, c->d_qbox, c->d_root, write_internal ? 1 : 0, c->d_seg, (int)c->nbp2,
-                                                       cross_list, cross_count, c->cross_cap);
+                                                       cross_list, cross_count, c->cross_cap, c->amb, (const uint8_t *)c->vamb);
     // fused build, a tree of 2 .. 2048 blocks: the cross nodes' ranges, splits, links and records in ONE launch (k_cross_fused, cd_build.h)
     if (fused && n > 1 && c->nbp2 > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK && !c->dbg_split_cross) {
         const uint32_t xb = (uint32_t)nblocks < 8u ? 8u : ((uint32_t)nblocks > 1790u ? 1790u : (uint32_t)nblocks);   // 16 nodes per workgroup and round, ~13 per block; with the two workgroups below at most what the chip holds at once (7 workgroups per CU)
@@ -415,10 +450,10 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         k_cross_meta<<<xblocks, 256, 0, s>>>(c->d_keys[0], (int)n, c->d_meta, c->d_split_of, c->d_cross, cross_count, c->cross_cap,
                                              top_in_meta ? c->d_seg : nullptr, (int)c->nbp2, nblocks);
         k_cross_records<<<xblocks, 256, 0, s>>>((int)n, c->d_meta, c->d_seg, c->d_seg32, (int)c->nbp2, c->d_qbox, c->d_boxes, c->d_recs32,
-                                                c->d_split_of, c->d_root, c->d_cross, cross_count, c->cross_cap);
+                                                c->d_split_of, c->d_root, c->d_cross, cross_count, c->cross_cap, c->amb);
     } else if (n > 1)
         k_refit_seg_cross<<<xblocks, 256, 0, s>>>((int)n, c->d_meta, c->d_seg, (int)c->nbp2, c->d_boxes, c->d_bounded, c->d_recs32,
-                                                  c->d_root, write_internal ? 1 : 0, c->d_cross, cross_count, c->cross_cap);
+                                                  c->d_root, write_internal ? 1 : 0, c->d_cross, cross_count, c->cross_cap, c->amb);
     c->internal_boxes_valid = write_internal;
     HIPCHK(evrec(c, EV_REFIT1));
     HIPCHK(hipGetLastError());
@@ -751,6 +786,48 @@ void graph_drop(cd_ctx *c)
     if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
     if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
 }
+// The cell table follows the VERTICES: rebuilt by cd_create / cd_update_vertices (after their copy), never inside a step.  Every
+// coordinate an fp32 value -- the reference's loader produces those (load_obj.h:38) -- : one streaming pass, no table.
+int amb_refresh(cd_ctx *c)
+{
+    hipStream_t s = c->stream;
+    const uint64_t n3 = 3ull * c->nv;
+    if (!c->d_amb_flag) HIPCHK(hipMalloc(&c->d_amb_flag, sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(c->d_amb_flag, 0, sizeof(uint32_t), s));
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n3 + 255) / 256, 4096);
+    k_amb_scan<<<blocks, 256, 0, s>>>(c->d_verts, n3, c->d_amb_flag);
+    uint32_t inexact = 0;
+    HIPCHK(hipMemcpyAsync(&inexact, c->d_amb_flag, sizeof inexact, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const AmbTable before = c->amb;
+    if (!inexact) { c->amb = AmbTable{nullptr, 0u, 0u}; c->vamb = nullptr; }
+    else {
+        uint64_t cap = 1024; uint32_t lg = 10;
+        while (cap < n3 + n3 / 2) { cap <<= 1; ++lg; }                      // load below 2 / 3
+        if (cap > (1ull << 32)) return CD_ERR_ARG;
+        if (cap != c->amb_cap) {
+            hipFree(c->d_amb_keys); hipFree(c->d_amb_mn); hipFree(c->d_amb_mx); c->d_amb_keys = c->d_amb_mn = c->d_amb_mx = nullptr; c->amb_cap = 0;
+            HIPCHK(hipMalloc(&c->d_amb_keys, sizeof(unsigned long long) * cap));
+            HIPCHK(hipMalloc(&c->d_amb_mn, sizeof(unsigned long long) * cap));
+            HIPCHK(hipMalloc(&c->d_amb_mx, sizeof(unsigned long long) * cap));
+            c->amb_cap = cap;
+        }
+        HIPCHK(hipMemsetAsync(c->d_amb_keys, 0, sizeof(unsigned long long) * cap, s));
+        HIPCHK(hipMemsetAsync(c->d_amb_mn, 0xff, sizeof(unsigned long long) * cap, s));
+        HIPCHK(hipMemsetAsync(c->d_amb_mx, 0, sizeof(unsigned long long) * cap, s));
+        const uint32_t shift = 64u - lg, mask = (uint32_t)(cap - 1);
+        k_amb_insert<<<blocks, 256, 0, s>>>(c->d_verts, n3, c->d_amb_keys, c->d_amb_mn, c->d_amb_mx, shift, mask);
+        k_amb_mark<<<(uint32_t)std::min<uint64_t>((cap + 255) / 256, 4096), 256, 0, s>>>(c->d_amb_keys, c->d_amb_mn, c->d_amb_mx, cap);
+        c->amb = AmbTable{c->d_amb_keys, shift, mask};
+        if (!c->d_vamb) HIPCHK(hipMalloc(&c->d_vamb, c->nv));
+        k_amb_vertex<<<(uint32_t)std::min<uint64_t>((c->nv + 255ull) / 256, 4096), 256, 0, s>>>(c->d_verts, c->nv, c->amb, c->d_vamb);
+        c->vamb = c->d_vamb;
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipGetLastError());
+    }
+    if (before.keys != c->amb.keys || before.shift != c->amb.shift) graph_drop(c);       // (a captured step has the table baked into its launches)
+    return CD_OK;
+}
 bool graph_eligible(const cd_ctx *c)
 {
     return c->graph_opt && !c->stage_events && c->stamp_mask == 0 && c->sort_mode <= 1 && fused_build_next(c) && c->trav_variant == 3 &&
@@ -909,6 +986,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
               (!ids || hipMemcpy(c->d_ids, ids, sizeof(uint32_t) * n, hipMemcpyHostToDevice) == hipSuccess) &&
               hipMemcpy(c->d_frame, c->frame_host, sizeof(double) * 6, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { free_all(c); delete c; return -(int)hipGetLastError(); }
+    { const int rc = amb_refresh(c); if (rc) { free_all(c); delete c; return rc; } }
     *out = c;
     return CD_OK;
 }
@@ -925,10 +1003,11 @@ void cd_destroy(cd_ctx *c)
 int cd_update_vertices(cd_ctx *c, const double *verts_xyz)
 {
     if (!c || !verts_xyz) return CD_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(c->stream));                                // (nothing of an earlier call may still read the old vertices or the old cell table)
     HIPCHK(hipMemcpy(c->d_verts, verts_xyz, sizeof(double) * 3 * (size_t)c->nv, hipMemcpyHostToDevice));
     c->stage = ST_CREATED;
     c->root_box_valid = false;
-    return CD_OK;
+    return amb_refresh(c);
 }
 
 int cd_set_morton_frame(cd_ctx *c, int mode, const double offset[3], const double span[3])

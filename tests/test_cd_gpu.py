@@ -447,6 +447,113 @@ def test_cross_rank_pass_two_contexts_one_gpu(variant):
         e.close()
 
 
+def _cross_pass_by_hand(shards, variant=3):
+    """Two (or more) shards in their own contexts, root boxes exchanged by hand, every shard's leaves that overlap a peer's root packed and
+    traversed by that peer: returns the union of local + cross pairs and the queries sent."""
+    import torch
+    import mi355_multi as multi
+    dev = torch.device("cuda", 0)
+    engines = [multi.HipEngine(v, t, i, dev, vertex_id_base=vb) for (v, t, i, vb) in shards]
+    got, roots, sent = [], [], 0
+    for e in engines:
+        e.cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
+        pairs, n, tested = e.self_collide(1 << 21)
+        got.append(pairs); roots.append(e.root_box())
+    for me in range(len(engines)):
+        for peer in range(len(engines)):
+            if me == peer or not multi.boxes_overlap(roots[me], roots[peer]):
+                continue
+            q = engines[me].pack_queries(roots[peer])
+            sent += q.numel() // multi.QUERY_BYTES
+            cross, n, tested = engines[peer].find_collisions_queries(q, 1 << 21)
+            got.append(cross)
+    for e in engines:
+        e.close()
+    return np.concatenate(got, axis=0), sent
+
+
+@pytest.mark.parametrize("coords", ["float", "double", "double-coarse-cells"])
+def test_cross_pass_between_meshes_whose_boxes_tie_exactly(coords):
+    """Queries from ANOTHER mesh are not in a mesh's cell table (cd_bvh.h): their comparisons treat an fp32 tie as "maybe" unless both
+    sides are fp32 values.  Two contexts hold THE SAME geometry (the second a copy shifted by exactly one grid step along x, other
+    IDs and vertex indices): every box face of one coincides with a face of the other -- ties on every level of both trees --
+    and the coincident triangles are coplanar contacts.  float: fp32 values (ties are exact touches); double: full doubles;
+    double-coarse-cells: the same moved to x + 4096, where an fp32 cell is 4.9e-4 wide and holds many distinct doubles (most cells
+    ambiguous).  Union of local + cross pairs == the oracle on the merged mesh, no duplicates."""
+    quads = 36
+    v0, t0 = synth.cloth_pair(quads, round_f32=(coords == "float"))
+    step = (2.94 - 0.06) / quads
+    v1 = v0.copy(); v1[:, 0] += step
+    if coords == "float":
+        v1 = v1.astype(np.float32).astype(np.float64)
+    if coords == "double-coarse-cells":
+        v0 = v0 + np.array([4096.0, 0.0, 0.0]); v1 = v1 + np.array([4096.0, 0.0, 0.0])
+    n = t0.shape[0]
+    ids0 = np.arange(n, dtype=np.uint32); ids1 = (np.arange(n, dtype=np.uint32)[::-1] + n).astype(np.uint32)
+    shards = [(v0, t0, ids0, 0), (v1, t0.copy(), ids1, v0.shape[0])]
+    got, sent = _cross_pass_by_hand(shards)
+    verts = np.concatenate([v0, v1]); vidx = np.concatenate([t0, t0 + np.uint32(v0.shape[0])]); ids = np.concatenate([ids0, ids1])
+    cen = (verts[vidx[:, 0]] + verts[vidx[:, 1]] + verts[vidx[:, 2]]) / 3
+    ref = oracle.pipeline(verts, vidx, ids, off=cen.min(0), span=(cen.max(0) - cen.min(0)) * (1 + 2.0 ** -20))
+    gs = oracle.pair_set(got)
+    assert len(gs) == len(np.unique(gs)) and np.array_equal(gs, oracle.pair_set(ref["pairs"]))
+    assert sent > n and len(gs) > 1000
+
+
+@pytest.mark.parametrize("kind", ["cloth-shifted", "soup-shifted", "cells-of-many", "tiny-scale"])
+def test_meshes_with_many_ambiguous_cells_match_the_oracle(kind):
+    """The cell table's hard cases, each against the oracle (pair set, pairs_tested, fused records byte-equal to the stage-wise build's,
+    whose internal boxes take the table's answers value by value) and, where small enough, the brute force:
+      cloth-shifted   the double cloth at x, y, z + 1024: cells 1.2e-4 wide, nearly every cell holds several distinct doubles;
+      soup-shifted    a double soup at + 65536 (cells 7.8e-3: most boxes lie inside ONE cell per axis);
+      cells-of-many   vertices snapped to a lattice of 2^-30 around 1.0 (exactly 2^7 doubles per fp32 cell, ties AND sub-cell overlaps);
+      tiny-scale      a double soup scaled by 2^-140 (fp32 subnormals; squares of differences near the FP64 underflow)."""
+    rng = np.random.default_rng(5)
+    if kind == "cloth-shifted":
+        verts, vidx = synth.cloth_pair(70, round_f32=False); verts = verts + 1024.0
+    elif kind == "soup-shifted":
+        verts, vidx = synth.soup(30_000, 0.05, 9); verts = verts * (1.0 + 1e-9) + 65536.0
+    elif kind == "cells-of-many":
+        verts, vidx = synth.soup(20_000, 0.05, 3)
+        verts = 1.0 + np.round(verts * 2.0 ** 10) * 2.0 ** -30                      # a lattice of 2^-30 in [1, 1.003]: fp32 ulp at 1.0 is 2^-23
+    else:
+        verts, vidx = synth.soup(20_000, 0.05, 4); verts = (verts * (1.0 + 1e-12)) * 2.0 ** -140
+    cen = (verts[vidx[:, 0]] + verts[vidx[:, 1]] + verts[vidx[:, 2]]) / 3
+    off = cen.min(0); span = (cen.max(0) - off) * (1 + 2.0 ** -20)
+    r = oracle.pipeline(verts, vidx, off=off, span=span)
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        cd.set_morton_frame(mi355cd.CD_FRAME_AUTO)
+        for variant in VARIANTS:
+            cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
+            for step in range(2):
+                pairs, n, rc = cd.self_collide(cap=1 << 21)
+                assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])), (variant, step)
+                assert cd.stats().pairs_tested == r["stats"].pairs_tested, (variant, step)
+        bp, bn, _ = cd.brute_force(True, cap=1 << 21)
+        assert np.array_equal(oracle.pair_set(bp), oracle.pair_set(r["pairs"]))
+    _assert_fused_records_equal_stagewise(verts, vidx, auto_frame=True)
+
+
+def test_update_vertices_switches_the_cell_table_on_and_off():
+    """The cell table follows the vertices: a context created on fp32-valued vertices (no table), updated to full doubles (table built),
+    to doubles in coarse cells, and back -- stream path and graph replay -- gives the oracle's pairs every time."""
+    vf, vidx = synth.cloth_pair(90)
+    vd, _ = synth.cloth_pair(90, round_f32=False)
+    seq = [("float", vf), ("double", vd), ("double+512", vd + 512.0), ("float", vf), ("double", vd)]
+    with mi355cd.CollisionDetector(vf, vidx) as cd:
+        cd.set_morton_frame(mi355cd.CD_FRAME_AUTO)
+        for graph in (0, 1):
+            cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0); cd.set_option(mi355cd.CD_OPT_GRAPH, graph)
+            for name, v in seq:
+                cd.update_vertices(v)
+                cen = (v[vidx[:, 0]] + v[vidx[:, 1]] + v[vidx[:, 2]]) / 3
+                r = oracle.pipeline(v, vidx, off=cen.min(0), span=(cen.max(0) - cen.min(0)) * (1 + 2.0 ** -20))
+                for step in range(3):
+                    pairs, n, rc = cd.self_collide(cap=1 << 20)
+                    assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])), (graph, name, step)
+                    assert cd.stats().pairs_tested == r["stats"].pairs_tested, (graph, name, step)
+
+
 def test_config4_topology_eight_shards_on_one_gpu():
     """BASELINE config 4's topology on the one GPU there is: EIGHT object shards (40-quad cloth pairs, neighbours
     overlapping by 10 % along x) in eight contexts -- the middle shards have TWO peers -- root boxes exchanged by hand
@@ -622,10 +729,12 @@ def test_multi_step_slab_allocation_failure_in_the_growth_round_fails_together_a
         assert all(st["checks"].values()) and sum(st["cross"]) > 0 and st["query_cap"] > 64, st
 
 
-def _assert_fused_records_equal_stagewise(verts, vidx, ids=None, split_cross_too=True):
+def _assert_fused_records_equal_stagewise(verts, vidx, ids=None, split_cross_too=True, auto_frame=False):
     got = {}
     for fused in (1, 0, 2):                                 # 2: the fused build with k_cross_meta + k_cross_records (what trees beyond 2048 blocks take)
         with mi355cd.CollisionDetector(verts, vidx, ids) as cd:
+            if auto_frame:
+                cd.set_morton_frame(mi355cd.CD_FRAME_AUTO)
             cd.debug_set(mi355cd.CD_DBG_STAGEWISE_BUILD, 0 if fused else 1)
             cd.debug_set(mi355cd.CD_DBG_SPLIT_CROSS, 1 if fused == 2 else 0)
             cd.build_tree()
@@ -649,13 +758,17 @@ def _compare_records(n, a, b):
     assert used.sum() == max(n - 1, 0)
     for a, b in ((rr, rr0), (rl, rl0)):
         assert np.array_equal(a[used][:, :7], b[used][:, :7])
-    # last | flags: the low 30 bits always; bit 30 / 31 only where the left / right child is a leaf
+    # last | CERTAIN flags, first | EXACT flags: the low 30 bits always; bit 30 / 31 only where the left / right child is a leaf
     assert np.array_equal(rr[used][:, 7] & 0x3fffffff, rr0[used][:, 7] & 0x3fffffff)
-    assert np.array_equal(rl[used][:, 7], rl0[used][:, 7])
+    assert np.array_equal(rl[used][:, 7] & 0x3fffffff, rl0[used][:, 7] & 0x3fffffff)
     leafL = rl0[used][:, 6].view(np.int32) < 0
     leafR = rr0[used][:, 6].view(np.int32) < 0
-    assert np.array_equal((rr[used][:, 7] >> 30 & 1)[leafL], (rr0[used][:, 7] >> 30 & 1)[leafL])
-    assert np.array_equal((rr[used][:, 7] >> 31 & 1)[leafR], (rr0[used][:, 7] >> 31 & 1)[leafR])
+    for w, w0 in ((rr, rr0), (rl, rl0)):
+        assert np.array_equal((w[used][:, 7] >> 30 & 1)[leafL], (w0[used][:, 7] >> 30 & 1)[leafL])
+        assert np.array_equal((w[used][:, 7] >> 31 & 1)[leafR], (w0[used][:, 7] >> 31 & 1)[leafR])
+    # EXACT implies CERTAIN, leaf by leaf
+    assert not ((rl[used][:, 7] >> 30 & 1)[leafL] & ~(rr[used][:, 7] >> 30 & 1)[leafL]).any()
+    assert not ((rl[used][:, 7] >> 31 & 1)[leafR] & ~(rr[used][:, 7] >> 31 & 1)[leafR]).any()
 
 
 @pytest.mark.parametrize("kind", ["cloth-float", "soup-double", "mixed", "tiny", "one-block", "two-blocks", "three-blocks", "ragged", "duplicates", "long-ranges",
