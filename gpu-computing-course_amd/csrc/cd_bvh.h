@@ -85,14 +85,15 @@ __device__ __forceinline__ Enc32 enc_box32(const AmbTable &t, const Box &b, bool
 // Equal coordinates lie in one cell, so any vertex that attains a bound has the bound's flag.  vamb == nullptr: no table.
 __device__ __forceinline__ Enc32 enc_leaf32(const Box &b, const d3 A, const d3 B, const d3 C, const uint8_t *__restrict__ vamb, uint32_t va, uint32_t vb, uint32_t vc)
 {
-    uint32_t fa = 0, fb = 0, fc = 0;
-    if (vamb) { fa = vamb[va]; fb = vamb[vb]; fc = vamb[vc]; }
-    auto pick = [&](double bound, double a, double bb, int bit) -> bool { const uint32_t f = (a == bound) ? fa : ((bb == bound) ? fb : fc); return ((f >> bit) & 1u) != 0u; };
-    const bool ax = pick(b.x2, A.x, B.x, 0), ay = pick(b.y2, A.y, B.y, 1), az = pick(b.z2, A.z, B.z, 2);
-    const bool lo_amb = pick(b.x1, A.x, B.x, 0) | pick(b.y1, A.y, B.y, 1) | pick(b.z1, A.z, B.z, 2);
     Enc32 e;
     e.lx = __double2float_rd(b.x1); e.ly = __double2float_rd(b.y1); e.lz = __double2float_rd(b.z1);
     e.hx = __double2float_rd(b.x2); e.hy = __double2float_rd(b.y2); e.hz = __double2float_rd(b.z2);
+    e.certain = true;
+    if (!vamb) return e;                                                   // (uniform: no table, nothing is moved)
+    const uint32_t fa = vamb[va], fb = vamb[vb], fc = vamb[vc];
+    auto pick = [&](double bound, double a, double bb, int bit) -> bool { const uint32_t f = (a == bound) ? fa : ((bb == bound) ? fb : fc); return ((f >> bit) & 1u) != 0u; };
+    const bool ax = pick(b.x2, A.x, B.x, 0), ay = pick(b.y2, A.y, B.y, 1), az = pick(b.z2, A.z, B.z, 2);
+    const bool lo_amb = pick(b.x1, A.x, B.x, 0) | pick(b.y1, A.y, B.y, 1) | pick(b.z1, A.z, B.z, 2);
     if (ax) e.hx = f32_next_up(e.hx);
     if (ay) e.hy = f32_next_up(e.hy);
     if (az) e.hz = f32_next_up(e.hz);

@@ -563,7 +563,7 @@ constexpr uint32_t HALF_FLUSH_AT = HALF_QCAP - 64;   // an enqueue adds at most 
 constexpr int HALF_THREADS = 64;
 constexpr int HALF_XSUB = 4;                 // see the XCD mapping below
 
-template <bool DIAG>
+template <bool DIAG, bool TIES /* the mesh has a cell table (cd_bvh.h): hits between boxes that are not both CERTAIN are looked at comparison by comparison */>
 __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
                                                                   TravState *__restrict__ st,
                                                                   Candidates *__restrict__ cand, unsigned long long shard_cap,
@@ -641,6 +641,21 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         qcount += __popcll(m);
     };
     float qlo0, qlo1, qlo2, qhi0, qhi1, qhi2; uint32_t qcertain;
+    // Is a leaf hit DECIDED by the fp32 test?  Yes when both boxes are CERTAIN (the leaf's flag from its parent's record, the query's
+    // from phase 0).  If not, the six comparisons themselves still tell: an fp32 '<' is the FP64 '<' unless the two bounds lie in one
+    // AMBIGUOUS cell (cd_bvh.h), and then hi' is exactly one ulp above lo' -- so a hit none of whose comparisons has next_up(lo') == hi'
+    // is exact as well.  Only hits that fail this too go to k_exact for the FP64 box test.  (TIES instance only: a mesh without a
+    // table -- every coordinate an fp32 value -- runs the instance without this code.)
+    auto cand_word = [&](bool cnd, bool leaf_certain, float nlo0, float nlo1, float nlo2, float nhi0, float nhi1, float nhi2) -> uint32_t {
+        uint32_t cw = leaf_certain ? qcertain : 0u;
+        if constexpr (!TIES) return cw;                                       // (no table: every box is certain, nothing to look at)
+        if (__builtin_amdgcn_ballot_w64(band(cnd, cw == 0u)) != 0ull) {
+            const bool risky = (f32_next_up(qlo0) == nhi0) | (f32_next_up(nlo0) == qhi0) | (f32_next_up(qlo1) == nhi1) | (f32_next_up(nlo1) == qhi1) |
+                               (f32_next_up(qlo2) == nhi2) | (f32_next_up(nlo2) == qhi2);
+            if (!risky) cw = CAND_CERTAIN;
+        }
+        return cw;
+    };
     // an internal sibling / child that was hit (`c`, per lane): onto the lane's stack, descended in phase 2
     auto note_subtree = [&](bool c, int32_t link) {
         if (c) {
@@ -676,8 +691,10 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         // a == b is (x1 - x2)^2 > 0 per axis -- for a CERTAIN box that is lo' < hi' (equal fp32 copies are equal doubles, different
         // ones differ by at least the spacing of two fp32 cells, whose square does not underflow in FP64), otherwise the FP64
         // box decides (stored for every leaf that is not EXACT)
-        bool self = exact & (qlo0 < qhi0) & (qlo1 < qhi1) & (qlo2 < qhi2);
-        if (valid && !exact) { const Box b = load_box(src.boxes, (n - 1) + (int)qi); self = box_overlap(b, b); }
+        // (a box that is not certain: lo' < hi' is still the FP64 answer on an axis unless hi' is exactly one ulp above lo' -- cand_word below)
+        const bool own_risky = !exact & ((f32_next_up(qlo0) == qhi0) | (f32_next_up(qlo1) == qhi1) | (f32_next_up(qlo2) == qhi2));
+        bool self = !own_risky & (qlo0 < qhi0) & (qlo1 < qhi1) & (qlo2 < qhi2);
+        if (valid && own_risky) { const Box b = load_box(src.boxes, (n - 1) + (int)qi); self = box_overlap(b, b); }
         if (valid && self) ++tested;
     }
     if constexpr (DIAG) tm1 = __builtin_amdgcn_s_memtime();
@@ -701,7 +718,8 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         if constexpr (DIAG) dg_hops_in += act ? 1u : 0u;
         note_subtree(band(hit, link >= 0), link);
         s = act ? (lw & REC_LAST_MASK) : s;
-        enqueue(band(hit, link < 0), qi, (uint32_t)~link | ((lw & REC_R_CERTAIN) ? qcertain : 0u));
+        const bool lh = band(hit, link < 0);
+        enqueue(lh, qi, (uint32_t)~link | cand_word(lh, (lw & REC_R_CERTAIN) != 0u, c.x, c.y, c.z, c.w, d.x, d.y));
     }
     dg_p1a = steps;
     if constexpr (DIAG) tm2 = __builtin_amdgcn_s_memtime();
@@ -722,7 +740,8 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
             wvisits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(act));
             if constexpr (DIAG) dg_hops_out += act ? 1u : 0u;
             if (link >= 0) note_subtree(hit, link);
-            else enqueue(hit, qi, (uint32_t)~link | ((lw & REC_R_CERTAIN) ? qcertain : 0u));
+            else enqueue(hit, qi, (uint32_t)~link | cand_word(hit, (lw & REC_R_CERTAIN) != 0u, __int_as_float(c.x), __int_as_float(c.y), __int_as_float(c.z),
+                                                               __int_as_float(c.w), __int_as_float(d.x), __int_as_float(d.y)));
             t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lw & REC_LAST_MASK));
         }
     }
@@ -774,8 +793,8 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
             node = active ? nxt : -1;
             const bool candL = band(ol, cl < 0), candR = band(orr, cr < 0);
             if (__builtin_amdgcn_ballot_w64(bor(candL, candR)) != 0ull) {        // (most steps meet no leaf: one test instead of two)
-                enqueue(candL, qi, (uint32_t)~cl | ((lw & REC_L_CERTAIN) ? qcertain : 0u));
-                enqueue(candR, qi, (uint32_t)~cr | ((lw & REC_R_CERTAIN) ? qcertain : 0u));
+                enqueue(candL, qi, (uint32_t)~cl | cand_word(candL, (lw & REC_L_CERTAIN) != 0u, a.x, a.y, a.z, a.w, b.x, b.y));
+                enqueue(candR, qi, (uint32_t)~cr | cand_word(candR, (lw & REC_R_CERTAIN) != 0u, c.x, c.y, c.z, c.w, d.x, d.y));
             }
         }
     }

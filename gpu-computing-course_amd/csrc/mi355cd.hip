@@ -506,11 +506,13 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         const bool plain = !e0 && !e1 && !e2;          // no time stamp rides on these launches: plain launches (a stream capture can record them)
         if (half_mode && !DEEP) {
             const dim3 hgrid(cdiv(items, 64u)), hblock(HALF_THREADS);
-#define LAUNCH_HALF(DIAG)                                                                                                                   \
-            do { if (plain) k_descend_half<DIAG><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap); \
-                 else hipExtLaunchKernelGGL((k_descend_half<DIAG>), hgrid, hblock, (uint32_t)pad, s, e0, e1, 0u, src, n, (const NodeRec32 *)c->d_recs32, \
+#define LAUNCH_HALF(DIAG, TIES)                                                                                                             \
+            do { if (plain) k_descend_half<DIAG, TIES><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap); \
+                 else hipExtLaunchKernelGGL((k_descend_half<DIAG, TIES>), hgrid, hblock, (uint32_t)pad, s, e0, e1, 0u, src, n, (const NodeRec32 *)c->d_recs32, \
                                             tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap); } while (0)
-            if (c->dbg_diag) LAUNCH_HALF(true); else LAUNCH_HALF(false);
+            const bool ties = c->amb.keys != nullptr;                      // (a graph capture bakes the instance in: amb_refresh drops the graph when the table comes or goes)
+            if (c->dbg_diag) { if (ties) LAUNCH_HALF(true, true); else LAUNCH_HALF(true, false); }
+            else { if (ties) LAUNCH_HALF(false, true); else LAUNCH_HALF(false, false); }
 #undef LAUNCH_HALF
         }
         else if (qpw == 64)
