@@ -36,7 +36,7 @@ __device__ __forceinline__ B32 b32_merge(const B32 &a, const B32 &b)
 }
 __device__ __forceinline__ B32 b32_of(const AmbTable &amb, const Box &b)  // the fp32 copy of an FP64 box (cd_bvh.h enc_box32: what store_rec32 does)
 {
-    const Enc32 e = enc_box32(amb, b, false);
+    const Enc32 e = enc_box32(amb, b);
     return B32{e.lx, e.ly, e.lz, e.hx, e.hy, e.hz};
 }
 __device__ __forceinline__ B32 b32_load(const float *p)                    // 24-byte node, 8-byte aligned
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
         const LeafTri lt = leaf[j];
         const d3 A = load_vertex(verts, lt.v0), B = load_vertex(verts, lt.v1), C = load_vertex(verts, lt.v2);
         mine = box_set(A, B, C);                                           // box.cuh:13-22
-        const Enc32 e = enc_leaf32(mine, A, B, C, vamb, lt.v0, lt.v1, lt.v2);
+        const Enc32 e = enc_leaf32(amb, mine, A, B, C, vamb, lt.v0, lt.v1, lt.v2);
         m32 = B32{e.lx, e.ly, e.lz, e.hx, e.hy, e.hz};
         certain = e.certain;
         exact = certain && box_is_fp32(mine);

@@ -21,18 +21,22 @@ typedef int4 NodeMeta;
 // candidates of the same mesh rounded to float.  No lossy representation can tell "equal" from "a hair apart" -- but
 // the table below knows where it matters: a CELL is the set of doubles with the same fp32 floor, cell(x) = rd32(x), and a
 // cell is AMBIGUOUS iff two DISTINCT doubles among the mesh's vertex coordinates of that axis lie in it (every box bound
-// is a vertex coordinate).  Encoding:   lo' = rd32(lo)       hi' = rd32(hi), one ulp up iff cell(hi) is ambiguous.
+// is a vertex coordinate).  Encoding:   lo' = rd32(lo)       hi' = rd32(hi), one ulp up iff cell(hi) is ambiguous AND hi is
+// not the cell's base itself (nothing of the cell lies below its base).
 //   * different cells: rd32 is monotone and cells are an ulp apart, so lo' < hi' <=> lo < hi, exactly;
-//   * the same cell, unambiguous: lo and hi are the same double (touching): lo' == hi', '<' says no -- exact;
-//   * the same cell, ambiguous: hi' = lo' + ulp, '<' says "maybe" -- conservative, as outward rounding always was.
+//   * the same cell, hi' not moved: hi is the base, or the only double of its cell -- then lo >= hi: lo' == hi', '<' says no, exact;
+//   * the same cell, hi' moved: hi' = lo' + ulp, '<' says "maybe" -- conservative, as outward rounding always was.
 // hi' is monotone in hi (a lower cell's base + ulp is at most the next cell's base), so it commutes with max: the fp32
-// box of a leaf range is still the min / max of its leaves' fp32 boxes, bit for bit (cd_build.h).  A box all six of whose
-// bounds lie in unambiguous cells is CERTAIN: any '<' between it and another certain box decides what FP64 decides.
+// box of a leaf range is still the min / max of its leaves' fp32 boxes, bit for bit (cd_build.h).  A box none of whose three
+// hi bounds was moved is CERTAIN: any '<' between it and another certain box decides what FP64 decides (a comparison is a lo
+// against a hi, and it is the hi's treatment that makes it exact).
 // A mesh whose coordinates are all fp32 values has no ambiguous cell (distinct floats are distinct cells) and no table:
 // keys == nullptr, hi' = rd32(hi) = hi -- the encoding of earlier rounds, bit for bit.  -0.0 and +0.0 are one cell.
 // Bounds of OTHER meshes (external queries, peer root boxes) are not in the table: those comparisons treat an fp32 tie
 // as "maybe" unless both sides are fp32 values (cd_traverse.h).  The table is rebuilt when the vertices are uploaded
 // (cd_create, cd_update_vertices: mi355cd.hip amb_refresh), not per step: it is a function of the vertices alone.
+// (keys == nullptr, mask != 0: no table although the mesh has coordinates that are not fp32 values -- CD_OPT_CELL_TABLE 0 -- : every such
+//  coordinate counts as lying in an ambiguous cell, which is plain outward rounding, the encoding of rounds 1 - 3)
 struct AmbTable { const unsigned long long *keys; uint32_t shift, mask; };
 constexpr unsigned long long AMB_BIT = 1ull << 63;
 __device__ __forceinline__ uint32_t amb_cell(double x)
@@ -46,7 +50,7 @@ __device__ __host__ __forceinline__ uint32_t amb_hash(unsigned long long key, ui
 // a bound of this mesh -- counts as ambiguous (conservative).
 __device__ __forceinline__ bool amb_lookup(const AmbTable &t, int axis, double x)
 {
-    if (!t.keys) return false;
+    if (!t.keys) return t.mask != 0u && (double)(float)x != x;
     const unsigned long long key = amb_key(axis, amb_cell(x));
     uint32_t h = amb_hash(key, t.shift);
     for (uint32_t probe = 0; probe <= t.mask; ++probe) {
@@ -65,26 +69,25 @@ __device__ __forceinline__ float f32_next_up(float f)
 }
 // the fp32 copy of an FP64 box as described above, and whether the box is certain
 struct Enc32 { float lx, ly, lz, hx, hy, hz; bool certain; };
-__device__ __forceinline__ Enc32 enc_box32(const AmbTable &t, const Box &b, bool want_certain)
+__device__ __forceinline__ Enc32 enc_box32(const AmbTable &t, const Box &b)
 {
-    const bool ax = amb_lookup(t, 0, b.x2), ay = amb_lookup(t, 1, b.y2), az = amb_lookup(t, 2, b.z2);
-    bool lo_amb = false;
-    if (want_certain && t.keys) lo_amb = amb_lookup(t, 0, b.x1) | amb_lookup(t, 1, b.y1) | amb_lookup(t, 2, b.z1);
     Enc32 e;
     e.lx = __double2float_rd(b.x1); e.ly = __double2float_rd(b.y1); e.lz = __double2float_rd(b.z1);
     e.hx = __double2float_rd(b.x2); e.hy = __double2float_rd(b.y2); e.hz = __double2float_rd(b.z2);
-    if (ax) e.hx = f32_next_up(e.hx);
-    if (ay) e.hy = f32_next_up(e.hy);
-    if (az) e.hz = f32_next_up(e.hz);
-    e.certain = !(ax | ay | az | lo_amb);
+    // (a hi that IS its cell's base has nothing of the cell below it: never moved)
+    const bool ux = (double)e.hx != b.x2 && amb_lookup(t, 0, b.x2), uy = (double)e.hy != b.y2 && amb_lookup(t, 1, b.y2), uz = (double)e.hz != b.z2 && amb_lookup(t, 2, b.z2);
+    if (ux) e.hx = f32_next_up(e.hx);
+    if (uy) e.hy = f32_next_up(e.hy);
+    if (uz) e.hz = f32_next_up(e.hz);
+    e.certain = !(ux | uy | uz);
     return e;
 }
-
 // The same for a LEAF box, whose bounds are coordinates of its own three vertices: the vertices' flags (vamb[v] bit a: the cell of
-// vertex v's coordinate a is ambiguous; written once per upload by k_amb_vertex) stand in for six probes of the table.
+// vertex v's coordinate a is ambiguous; written once per upload by k_amb_vertex, mi355cd.hip) stand in for probes of the table.
 // Equal coordinates lie in one cell, so any vertex that attains a bound has the bound's flag.  vamb == nullptr: no table.
-__device__ __forceinline__ Enc32 enc_leaf32(const Box &b, const d3 A, const d3 B, const d3 C, const uint8_t *__restrict__ vamb, uint32_t va, uint32_t vb, uint32_t vc)
+__device__ __forceinline__ Enc32 enc_leaf32(const AmbTable &t, const Box &b, const d3 A, const d3 B, const d3 C, const uint8_t *__restrict__ vamb, uint32_t va, uint32_t vb, uint32_t vc)
 {
+    if (!vamb && t.mask != 0u) return enc_box32(t, b);                      // (uniform: no table by request -- every inexact bound counts as ambiguous)
     Enc32 e;
     e.lx = __double2float_rd(b.x1); e.ly = __double2float_rd(b.y1); e.lz = __double2float_rd(b.z1);
     e.hx = __double2float_rd(b.x2); e.hy = __double2float_rd(b.y2); e.hz = __double2float_rd(b.z2);
@@ -92,21 +95,12 @@ __device__ __forceinline__ Enc32 enc_leaf32(const Box &b, const d3 A, const d3 B
     if (!vamb) return e;                                                   // (uniform: no table, nothing is moved)
     const uint32_t fa = vamb[va], fb = vamb[vb], fc = vamb[vc];
     auto pick = [&](double bound, double a, double bb, int bit) -> bool { const uint32_t f = (a == bound) ? fa : ((bb == bound) ? fb : fc); return ((f >> bit) & 1u) != 0u; };
-    const bool ax = pick(b.x2, A.x, B.x, 0), ay = pick(b.y2, A.y, B.y, 1), az = pick(b.z2, A.z, B.z, 2);
-    const bool lo_amb = pick(b.x1, A.x, B.x, 0) | pick(b.y1, A.y, B.y, 1) | pick(b.z1, A.z, B.z, 2);
-    if (ax) e.hx = f32_next_up(e.hx);
-    if (ay) e.hy = f32_next_up(e.hy);
-    if (az) e.hz = f32_next_up(e.hz);
-    e.certain = !(ax | ay | az | lo_amb);
+    const bool ux = (double)e.hx != b.x2 && pick(b.x2, A.x, B.x, 0), uy = (double)e.hy != b.y2 && pick(b.y2, A.y, B.y, 1), uz = (double)e.hz != b.z2 && pick(b.z2, A.z, B.z, 2);
+    if (ux) e.hx = f32_next_up(e.hx);
+    if (uy) e.hy = f32_next_up(e.hy);
+    if (uz) e.hz = f32_next_up(e.hz);
+    e.certain = !(ux | uy | uz);
     return e;
-}
-// vamb[v]: bit a = the cell of vertex v's coordinate a is ambiguous
-__global__ void k_amb_vertex(const double *__restrict__ verts, uint32_t nv, AmbTable t, uint8_t *__restrict__ vamb)
-{
-    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += gridDim.x * blockDim.x) {
-        const double x = verts[3 * (size_t)v], y = verts[3 * (size_t)v + 1], z = verts[3 * (size_t)v + 2];
-        vamb[v] = (uint8_t)((amb_lookup(t, 0, x) ? 1u : 0u) | (amb_lookup(t, 1, y) ? 2u : 0u) | (amb_lookup(t, 2, z) ? 4u : 0u));
-    }
 }
 
 // fp32 traversal record, one 64-byte line: both child boxes as fp32 copies (lo down; hi down, one ulp up where its cell is
@@ -124,8 +118,8 @@ __global__ void k_amb_vertex(const double *__restrict__ verts, uint32_t nv, AmbT
 // of n x 64 bytes): a hop of that chain reads only the right half, so the chain walks a dense 32-byte-per-node array
 // (rec_right); a descent step reads both (rec_left, rec_right).  NodeRec32 remains the logical record.
 constexpr uint32_t REC_LAST_MASK = 0x3fffffffu;     // n <= 2^30 (the candidate encoding has the same limit)
-constexpr uint32_t REC_L_CERTAIN = 0x40000000u;     // in `last`: the left / right child is a leaf whose box is CERTAIN (all its bounds in
-constexpr uint32_t REC_R_CERTAIN = 0x80000000u;     //   unambiguous cells: an fp32 '<' against another certain box of this mesh is exact)
+constexpr uint32_t REC_L_CERTAIN = 0x40000000u;     // in `last`: the left / right child is a leaf whose box is CERTAIN (none of its hi bounds
+constexpr uint32_t REC_R_CERTAIN = 0x80000000u;     //   moved: an fp32 '<' against another certain box of this mesh is exact)
 constexpr uint32_t REC_L_EXACT = 0x40000000u;       // in `first`: the left / right child is a leaf whose box is EXACT (certain, and its six
 constexpr uint32_t REC_R_EXACT = 0x80000000u;       //   bounds are fp32 values: the fp32 copy IS the box -- what a query from another mesh needs)
 struct alignas(64) NodeRec32 {
@@ -477,7 +471,7 @@ __device__ __forceinline__ void store_rec32(NodeRec32 *__restrict__ recs, int n,
                                             const AmbTable &amb)
 {
     float4 *pl = const_cast<float4 *>(rec_left(recs, n, split)), *pr = const_cast<float4 *>(rec_right(recs, n, split));
-    const Enc32 el = enc_box32(amb, bl, true), er = enc_box32(amb, br, true);        // (the flags only matter where the child is a leaf)
+    const Enc32 el = enc_box32(amb, bl), er = enc_box32(amb, br);        // (the flags only matter where the child is a leaf)
     pl[0] = make_float4(el.lx, el.ly, el.lz, el.hx);
     pl[1] = make_float4(el.hy, el.hz, __int_as_float(ch.x),
                         __uint_as_float(first | ((el.certain && box_is_fp32(bl)) ? REC_L_EXACT : 0u) | ((er.certain && box_is_fp32(br)) ? REC_R_EXACT : 0u)));
@@ -586,7 +580,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_refit_seg_local(const double *__r
         mine = box_set(A, B, C);                                           // box.cuh:13-22
         store_box(boxes, (n - 1) + j, mine);
         float4 *qp = reinterpret_cast<float4 *>(qbox32 + j);
-        const Enc32 e = enc_leaf32(mine, A, B, C, vamb, lt.v0, lt.v1, lt.v2);
+        const Enc32 e = enc_leaf32(amb, mine, A, B, C, vamb, lt.v0, lt.v1, lt.v2);
         qp[0] = make_float4(e.lx, e.ly, e.lz, e.hx);
         qp[1] = make_float4(e.hy, e.hz, __uint_as_float(((e.certain && box_is_fp32(mine)) ? LB_EXACT : 0u) | (e.certain ? LB_CERTAIN : 0u) |
                                                         (box_overlap(mine, mine) ? LB_SELF : 0u)), 0.f);

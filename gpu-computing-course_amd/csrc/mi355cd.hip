@@ -81,7 +81,8 @@ struct cd_ctx {
     double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec32 *d_recs32 = nullptr; LeafBox32 *d_qbox = nullptr;
     // the cell table of the current vertices (cd_bvh.h AmbTable; amb_refresh): keys == nullptr while every coordinate is an fp32 value
     AmbTable amb = {nullptr, 0u, 0u};
-    unsigned long long *d_amb_keys = nullptr, *d_amb_mn = nullptr, *d_amb_mx = nullptr; uint64_t amb_cap = 0; uint32_t *d_amb_flag = nullptr;
+    unsigned long long *d_amb_keys = nullptr, *d_amb_vals = nullptr; uint64_t amb_cap = 0; uint32_t *d_amb_flag = nullptr;
+    bool cell_table_opt = true;             // CD_OPT_CELL_TABLE
     uint8_t *d_vamb = nullptr, *vamb = nullptr;   // per vertex: which of its three coordinates lie in ambiguous cells (vamb: d_vamb, or nullptr while there is no table)
     int32_t *d_root = nullptr;              // name (split) of the root record, one word inside d_small
     bool leaf_records_filled = false;       // leaf[] holds the sorted triangles (leaves_filled: and parent[] / bounded[] are reset)
@@ -145,7 +146,7 @@ void free_all(cd_ctx *c)
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_top_pub); hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_seg32); hipFree(c->d_cross); hipFree(c->d_boxes);
     hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox); hipFree(c->d_split_of);
-    hipFree(c->d_amb_keys); hipFree(c->d_amb_mn); hipFree(c->d_amb_mx); hipFree(c->d_amb_flag); hipFree(c->d_vamb);
+    hipFree(c->d_amb_keys); hipFree(c->d_amb_flag); hipFree(c->d_vamb);
     for (TravBuf &tb : c->tb) {
         if (tb.d_pairs) hipFree(reinterpret_cast<char *>(tb.d_pairs) - sizeof(Report));
         if (tb.h_report) hipHostFree(tb.h_report);
@@ -220,27 +221,38 @@ __global__ void k_amb_scan(const double *__restrict__ v, uint64_t n3, uint32_t *
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n3; i += (uint64_t)gridDim.x * blockDim.x) { const double x = v[i]; any |= (double)(float)x != x; }
     if (__builtin_amdgcn_ballot_w64(any) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
-__global__ void k_amb_insert(const double *__restrict__ v, uint64_t n3, unsigned long long *__restrict__ keys, unsigned long long *__restrict__ mn,
-                             unsigned long long *__restrict__ mx, uint32_t shift, uint32_t mask)
+// Slot h: keys[h] = the cell's key (| AMB_BIT once two distinct doubles were seen in it), vals[h] = the first double that claimed it
+// (as an ordered integer; 0 = not yet written -- no double maps to 0).  A value that finds its cell's slot holding ANOTHER double marks
+// the cell; one that finds its own double does nothing.  The pass is idempotent and order-independent: whatever the interleaving,
+// a cell ends up marked iff two distinct doubles of the mesh lie in it.
+__global__ void k_amb_insert(const double *__restrict__ v, uint64_t n3, unsigned long long *keys, unsigned long long *vals, uint32_t shift, uint32_t mask)
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n3; i += (uint64_t)gridDim.x * blockDim.x) {
         double x = v[i];
         if (x == 0.0) x = 0.0;                                             // -0.0 and +0.0 are the same value
         const unsigned long long key = amb_key((int)(i % 3), amb_cell(x));
         uint32_t h = amb_hash(key, shift);
+        // A mesh has far fewer distinct coordinates than vertices along its regular directions (a grid's columns share their x):
+        // look before touching the slot with an atomic -- a thousand threads on one word retire one after the other.
         for (uint32_t probe = 0; probe <= mask; ++probe) {                 // (the table holds every key at a load below 2 / 3: this ends)
-            const unsigned long long old = atomicCAS(&keys[h], 0ull, key);
+            unsigned long long old = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~AMB_BIT;
+            if (old == 0ull) old = atomicCAS(&keys[h], 0ull, key) & ~AMB_BIT;
             if (old == 0ull || old == key) break;
             h = (h + 1u) & mask;
         }
-        const unsigned long long o = f64_ordered(x);
-        atomicMin(&mn[h], o); atomicMax(&mx[h], o);
+        const unsigned long long o = f64_ordered(x);                       // (never 0: f64_ordered(-NaN with all bits set) aside, outside the contract)
+        unsigned long long w = __hip_atomic_load(&vals[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0ull) w = atomicCAS(&vals[h], 0ull, o);
+        if (w != 0ull && w != o && !(__hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & AMB_BIT)) atomicOr(&keys[h], AMB_BIT);
     }
 }
-__global__ void k_amb_mark(unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ mn, const unsigned long long *__restrict__ mx, uint64_t cap)
+// vamb[v]: bit a = the cell of vertex v's coordinate a is ambiguous (what the leaf encoding of the builds reads instead of six probes)
+__global__ void k_amb_vertex(const double *__restrict__ verts, uint32_t nv, AmbTable t, uint8_t *__restrict__ vamb)
 {
-    for (uint64_t h = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; h < cap; h += (uint64_t)gridDim.x * blockDim.x)
-        if (keys[h] != 0ull && mn[h] != mx[h]) keys[h] |= AMB_BIT;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += gridDim.x * blockDim.x) {
+        const double x = verts[3 * (size_t)v], y = verts[3 * (size_t)v + 1], z = verts[3 * (size_t)v + 2];
+        vamb[v] = (uint8_t)((amb_lookup(t, 0, x) ? 1u : 0u) | (amb_lookup(t, 1, y) ? 2u : 0u) | (amb_lookup(t, 2, z) ? 4u : 0u));
+    }
 }
 
 constexpr int BOUNDS_BLOCKS = 1024;
@@ -510,7 +522,7 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
             do { if (plain) k_descend_half<DIAG, TIES><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap); \
                  else hipExtLaunchKernelGGL((k_descend_half<DIAG, TIES>), hgrid, hblock, (uint32_t)pad, s, e0, e1, 0u, src, n, (const NodeRec32 *)c->d_recs32, \
                                             tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap); } while (0)
-            const bool ties = c->amb.keys != nullptr;                      // (a graph capture bakes the instance in: amb_refresh drops the graph when the table comes or goes)
+            const bool ties = c->amb.keys != nullptr || c->amb.mask != 0u;                      // (a graph capture bakes the instance in: amb_refresh drops the graph when the table comes or goes)
             if (c->dbg_diag) { if (ties) LAUNCH_HALF(true, true); else LAUNCH_HALF(true, false); }
             else { if (ties) LAUNCH_HALF(false, true); else LAUNCH_HALF(false, false); }
 #undef LAUNCH_HALF
@@ -803,23 +815,20 @@ int amb_refresh(cd_ctx *c)
     HIPCHK(hipStreamSynchronize(s));
     const AmbTable before = c->amb;
     if (!inexact) { c->amb = AmbTable{nullptr, 0u, 0u}; c->vamb = nullptr; }
+    else if (!c->cell_table_opt) { c->amb = AmbTable{nullptr, 0u, 1u}; c->vamb = nullptr; }      // every inexact coordinate counts as ambiguous: plain outward rounding
     else {
         uint64_t cap = 1024; uint32_t lg = 10;
         while (cap < n3 + n3 / 2) { cap <<= 1; ++lg; }                      // load below 2 / 3
         if (cap > (1ull << 32)) return CD_ERR_ARG;
         if (cap != c->amb_cap) {
-            hipFree(c->d_amb_keys); hipFree(c->d_amb_mn); hipFree(c->d_amb_mx); c->d_amb_keys = c->d_amb_mn = c->d_amb_mx = nullptr; c->amb_cap = 0;
-            HIPCHK(hipMalloc(&c->d_amb_keys, sizeof(unsigned long long) * cap));
-            HIPCHK(hipMalloc(&c->d_amb_mn, sizeof(unsigned long long) * cap));
-            HIPCHK(hipMalloc(&c->d_amb_mx, sizeof(unsigned long long) * cap));
+            hipFree(c->d_amb_keys); c->d_amb_keys = c->d_amb_vals = nullptr; c->amb_cap = 0;
+            HIPCHK(hipMalloc(&c->d_amb_keys, sizeof(unsigned long long) * 2 * cap));       // keys | vals, one allocation, one memset
+            c->d_amb_vals = c->d_amb_keys + cap;
             c->amb_cap = cap;
         }
-        HIPCHK(hipMemsetAsync(c->d_amb_keys, 0, sizeof(unsigned long long) * cap, s));
-        HIPCHK(hipMemsetAsync(c->d_amb_mn, 0xff, sizeof(unsigned long long) * cap, s));
-        HIPCHK(hipMemsetAsync(c->d_amb_mx, 0, sizeof(unsigned long long) * cap, s));
+        HIPCHK(hipMemsetAsync(c->d_amb_keys, 0, sizeof(unsigned long long) * 2 * cap, s));
         const uint32_t shift = 64u - lg, mask = (uint32_t)(cap - 1);
-        k_amb_insert<<<blocks, 256, 0, s>>>(c->d_verts, n3, c->d_amb_keys, c->d_amb_mn, c->d_amb_mx, shift, mask);
-        k_amb_mark<<<(uint32_t)std::min<uint64_t>((cap + 255) / 256, 4096), 256, 0, s>>>(c->d_amb_keys, c->d_amb_mn, c->d_amb_mx, cap);
+        k_amb_insert<<<blocks, 256, 0, s>>>(c->d_verts, n3, c->d_amb_keys, c->d_amb_vals, shift, mask);
         c->amb = AmbTable{c->d_amb_keys, shift, mask};
         if (!c->d_vamb) HIPCHK(hipMalloc(&c->d_vamb, c->nv));
         k_amb_vertex<<<(uint32_t)std::min<uint64_t>((c->nv + 255ull) / 256, 4096), 256, 0, s>>>(c->d_verts, c->nv, c->amb, c->d_vamb);
@@ -827,7 +836,7 @@ int amb_refresh(cd_ctx *c)
         HIPCHK(hipStreamSynchronize(s));
         HIPCHK(hipGetLastError());
     }
-    if (before.keys != c->amb.keys || before.shift != c->amb.shift) graph_drop(c);       // (a captured step has the table baked into its launches)
+    if (before.keys != c->amb.keys || before.shift != c->amb.shift || before.mask != c->amb.mask) graph_drop(c);       // (a captured step has the table baked into its launches)
     return CD_OK;
 }
 bool graph_eligible(const cd_ctx *c)
@@ -1445,6 +1454,13 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }
     if (key == CD_OPT_GRAPH) { c->graph_opt = value != 0; if (!c->graph_opt) graph_drop(c); return CD_OK; }
     if (key == CD_OPT_POLL) { c->poll_opt = value != 0; return CD_OK; }
+    if (key == CD_OPT_CELL_TABLE) {
+        if (c->cell_table_opt == (value != 0)) return CD_OK;
+        c->cell_table_opt = value != 0;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->stage = ST_CREATED; c->root_box_valid = false;                  // the records of the tree that is there were encoded the other way
+        return amb_refresh(c);
+    }
     if (key == CD_OPT_KERNEL_STAMPS) { if (value < 0 || value > 15) return CD_ERR_ARG; c->stamp_mask = (uint32_t)value; return CD_OK; }
     return CD_ERR_ARG;
 }

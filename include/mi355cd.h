@@ -206,6 +206,12 @@ enum {
                                    /*    sequence word the report kernel stores last into pinned host memory (the host spins on its own memory; after 20 ms,   */
                                    /*    and every 64th step anyway, it synchronises the stream; so do the first two steps into a report area or a pinned    */
                                    /*    pair buffer the device has not written before); 0: always hipStreamSynchronize                                      */
+    CD_OPT_CELL_TABLE       = 7,   /* 1 (default): when the vertices are uploaded (cd_create, cd_update_vertices) and some coordinate is not an fp32 value, a table of the   */
+                                   /*    vertices' fp32 cells is built (which cells hold two distinct doubles), so that the fp32 boxes of the traversal keep equal bounds  */
+                                   /*    equal: touching boxes do not overlap after rounding (a full-double mesh then steps as fast as its float-rounded copy; the table  */
+                                   /*    costs the upload ~0.4 ms per million vertices).  0: no table, every coordinate that is not an fp32 value is rounded outward    */
+                                   /*    (a full-double structured mesh: ~2 x the step time, nothing added to the upload).  Vertices that are all fp32 values -- what   */
+                                   /*    the reference's loader produces, load_obj.h:38 -- never have a table                                                            */
     CD_OPT_QUERIES_PER_WAVE = 1    /* variant 1: queries one wave works through with dynamic lane refill (x64)         */
 };
 int cd_set_option(cd_ctx *ctx, int key, int64_t value);

@@ -523,12 +523,18 @@ def test_meshes_with_many_ambiguous_cells_match_the_oracle(kind):
     r = oracle.pipeline(verts, vidx, off=off, span=span)
     with mi355cd.CollisionDetector(verts, vidx) as cd:
         cd.set_morton_frame(mi355cd.CD_FRAME_AUTO)
-        for variant in VARIANTS:
-            cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
-            for step in range(2):
-                pairs, n, rc = cd.self_collide(cap=1 << 21)
-                assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])), (variant, step)
-                assert cd.stats().pairs_tested == r["stats"].pairs_tested, (variant, step)
+        visits = {}
+        for table in (1, 0, 1):                                     # CD_OPT_CELL_TABLE 0: no table, every inexact coordinate rounded outward (rounds 1-3)
+            cd.set_option(mi355cd.CD_OPT_CELL_TABLE, table)
+            for variant in VARIANTS:
+                cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
+                for step in range(2):
+                    pairs, n, rc = cd.self_collide(cap=1 << 21)
+                    assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])), (table, variant, step)
+                    assert cd.stats().pairs_tested == r["stats"].pairs_tested, (table, variant, step)
+                if variant == 3:
+                    visits[table] = cd.stats().node_visits
+        assert visits[1] <= visits[0]                               # the table can only make boxes tighter
         bp, bn, _ = cd.brute_force(True, cap=1 << 21)
         assert np.array_equal(oracle.pair_set(bp), oracle.pair_set(r["pairs"]))
     _assert_fused_records_equal_stagewise(verts, vidx, auto_frame=True)
