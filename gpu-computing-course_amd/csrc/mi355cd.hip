@@ -501,7 +501,7 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         // variant 3 (half traversal) applies to self-collision queries; external queries are not leaves of this tree
         // and take the full descent of variant 1.  The deep pass of a half traversal continues (query, subtree) items
         // with the full descent, but its candidates keep the half traversal's meaning (`half`).
-        const bool half_mode = c->trav_variant >= 3 && !EXTERNAL;
+        const bool half_mode = c->trav_variant >= 3 && !EXTERNAL && (DEEP || items == (uint32_t)n);     // (k_descend_half derives its grid mapping from n: its queries are ALL the leaves)
         const uint32_t qpw = (DEEP || c->trav_variant >= 3) ? 64u : c->queries_per_wave;
         const uint64_t shard_cap = tb.cand_cap / NSHARD;
         const dim3 grid(cdiv(items, qpw * DESC_WAVES));
