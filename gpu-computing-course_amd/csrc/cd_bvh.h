@@ -151,22 +151,6 @@ __device__ __forceinline__ Box leaf_box64(const double *__restrict__ boxes, cons
     return load_box(boxes, (n - 1) + j);
 }
 
-// box.cuh:40-43 on the FP64 boxes of leaves i (as `a`) and j (as `b`), an axis at a time -- each axis behind the one before (the verdict is
-// a conjunction), so that no more than four doubles are in flight: for a caller with few registers to spare (k_descend_half's inline exact
-// stage, in the middle of the descent).  The boxes are leaf_box64's: the fp32 copy widened when the leaf is EXACT, boxes[] otherwise.
-__device__ __forceinline__ bool leaf_pair_overlap64(const double *__restrict__ boxes, const LeafBox32 *__restrict__ qbox32, int n, int i, int j)
-{
-    const float *fi = reinterpret_cast<const float *>(qbox32 + i), *fj = reinterpret_cast<const float *>(qbox32 + j);
-    const bool xi = (__float_as_uint(fi[6]) & LB_EXACT) != 0u, xj = (__float_as_uint(fj[6]) & LB_EXACT) != 0u;
-    const double *bi = boxes + 6 * (size_t)((n - 1) + i), *bj = boxes + 6 * (size_t)((n - 1) + j);
-    for (int ax = 0; ax < 3; ++ax) {
-        const double ilo = xi ? (double)fi[ax] : bi[2 * ax], ihi = xi ? (double)fi[3 + ax] : bi[2 * ax + 1];
-        const double jlo = xj ? (double)fj[ax] : bj[2 * ax], jhi = xj ? (double)fj[3 + ax] : bj[2 * ax + 1];
-        if (!((ilo - jhi) * (jlo - ihi) > 0)) return false;
-    }
-    return true;
-}
-
 // Sorted-order leaf payload: {ID, vIdx[0..2]} (triangle.cuh:6,9) -- 16 B instead of the 56-byte Triangle.
 struct alignas(16) LeafTri { uint32_t id, v0, v1, v2; };
 

@@ -111,49 +111,6 @@ __device__ __forceinline__ bool tri_contact(const d3 P1, const d3 P2, const d3 P
     return true;
 }
 
-// The same 17 tests for a kernel that must live in 64 VGPRs (k_descend_half's inline exact stage, 8 waves per SIMD).  Written as
-// above, the compiler keeps the six edge vectors and the two normals across the axes (~48 registers beside the 30 of the five
-// translated vertices) and spills.  Here every axis derives what it needs from p2, p3, q1, q2, q3 again -- the same operations on the
-// same operands, so the same bits -- and the five vectors are passed through an empty asm before each axis ("laundered"), which keeps
-// the compiler from recognising the recomputation as common subexpressions and holding them after all.  ~30 % more FP64 operations
-// per pair, no scratch.  cd_tri_contact_points replays the reference-compiled fixture through BOTH forms.
-// PARK: q3 lives in LDS instead (park[0], park[64], park[128]: this lane's column of a [3][64] array of doubles the caller owns) and is
-// read from there at every use -- six registers less again, which is what k_descend_half needs beside its own state.
-__device__ __forceinline__ void launder(d3 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z)); }
-typedef __attribute__((address_space(3))) volatile double lds_vdouble;
-template <bool PARK>
-__device__ __forceinline__ bool tri_contact_lowreg(const d3 P1, const d3 P2, const d3 P3, const d3 Q1, const d3 Q2, const d3 Q3, lds_vdouble *park = nullptr)
-{
-    const d3 p1 = d3{0.0, 0.0, 0.0};
-    d3 p2 = sub(P2, P1), p3 = sub(P3, P1);
-    d3 q1 = sub(Q1, P1), q2 = sub(Q2, P1), q3r = sub(Q3, P1);
-    if constexpr (PARK) { park[0] = q3r.x; park[64] = q3r.y; park[128] = q3r.z; }
-    auto q3 = [&] { if constexpr (PARK) return d3{park[0], park[64], park[128]}; else return q3r; };
-    auto e1 = [&] { return sub(p2, p1); }; auto e2 = [&] { return sub(p3, p2); }; auto e3 = [&] { return sub(p1, p3); };
-    auto f1 = [&] { return sub(q2, q1); }; auto f2 = [&] { return sub(q3(), q2); }; auto f3 = [&] { return sub(q1, q3()); };
-    auto n1 = [&] { return cross(e1(), e2()); }; auto m1 = [&] { return cross(f1(), f2()); };
-    auto p6 = [&](const d3 ax) { return project6(ax, p1, p2, p3, q1, q2, q3()); };
-    auto fresh = [&] { launder(p2); launder(p3); launder(q1); launder(q2); if constexpr (!PARK) launder(q3r); };
-    if (!project3(n1(), q1, q2, q3())) return false;
-    fresh(); if (!project3(m1(), neg(q1), sub(p2, q1), sub(p3, q1))) return false;
-    fresh(); if (!p6(cross(e1(), f1()))) return false;
-    fresh(); if (!p6(cross(e1(), f2()))) return false;
-    fresh(); if (!p6(cross(e1(), f3()))) return false;
-    fresh(); if (!p6(cross(e2(), f1()))) return false;
-    fresh(); if (!p6(cross(e2(), f2()))) return false;
-    fresh(); if (!p6(cross(e2(), f3()))) return false;
-    fresh(); if (!p6(cross(e3(), f1()))) return false;
-    fresh(); if (!p6(cross(e3(), f2()))) return false;
-    fresh(); if (!p6(cross(e3(), f3()))) return false;
-    fresh(); if (!p6(cross(e1(), n1()))) return false;
-    fresh(); if (!p6(cross(e2(), n1()))) return false;
-    fresh(); if (!p6(cross(e3(), n1()))) return false;
-    fresh(); if (!p6(cross(f1(), m1()))) return false;
-    fresh(); if (!p6(cross(f2(), m1()))) return false;
-    fresh(); if (!p6(cross(f3(), m1()))) return false;
-    return true;
-}
-
 __device__ __forceinline__ d3 load_vertex(const double *__restrict__ verts, uint32_t i)
 {
     const double *p = verts + 3 * (size_t)i;

@@ -16,23 +16,15 @@ struct alignas(128) CtrShard {
     unsigned long long n_candidates;   // candidates reserved in this shard of the candidate buffer (may exceed its capacity)
     unsigned long long wave_steps;     // descent-loop iterations summed over waves (lane utilisation = node_visits / (64 * wave_steps))
     unsigned long long pad[12];        // [4] / [11]: the descent's own clock (earliest start as its complement, latest end); the rest: diagnostics (DIAG instances of the kernels)
-    // second line: the survivor pool of the half traversal's inline exact stage (k_descend_half<.., INLINE>).  n_candidates above is what the
-    // waves have RESERVED in this shard of the candidate buffer (returning atomics: a wave waits for each); `claimed` is how far the consumers
-    // have taken batches of survivors over for the SAT; `pubdone` is what the consumers poll.  A line of their own: polling the word the
-    // reservations go through made every reservation slow (the descent ended 10 - 30 us later), polling a word of fire-and-forget atomics does not.
-    unsigned long long claimed;
-    unsigned long long pubdone;        // low POOL_DONE_SHIFT bits: survivors published (= reserved, said again with an atomic nobody waits for); above: waves done
-    unsigned long long pad2[14];
 };
 struct alignas(128) TravState {
     unsigned long long n_pairs;        // collision.cuh:40 `count`
     uint32_t n_deferred;               // (query, subtree) items the LDS stack could not hold (deep pass redoes them)
     uint32_t report_arrive;            // workgroups of k_report that have posted their part (polled completion, see k_report)
-    uint32_t pool_timeouts, pad_b;     // inline exact stage: bounded waits for a reserved survivor slot that ran out (must stay 0; the host redoes the step with k_exact)
-    unsigned long long pad[13];
+    unsigned long long pad[14];
     CtrShard shard[NSHARD];
 };
-static_assert(sizeof(CtrShard) == 256 && sizeof(TravState) == 128 + 256 * NSHARD, "counter layout");
+static_assert(sizeof(CtrShard) == 128 && sizeof(TravState) == 128 * (NSHARD + 1), "counter layout");
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {
@@ -44,7 +36,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // list, so that counters + sort flags + root box + the first pairs come back in a single device-to-host copy.
 struct alignas(256) Report {
     unsigned long long n_pairs, pairs_tested, node_visits, max_shard_candidates, wave_steps, candidates;
-    uint32_t n_deferred, pool_timeouts;
+    uint32_t n_deferred, pad0;
     uint32_t sort_flags[9]; uint32_t pad1;
     double root_box[6];
     unsigned long long clk_start_inv, clk_end;   // descent kernel, device wall clock (s_memrealtime ticks): ~(earliest wave start), latest wave end; 0 = not taken
@@ -79,7 +71,7 @@ __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__re
         }
         if (lane == 0) {
             out->n_pairs = np; out->pairs_tested = tested; out->node_visits = visits; out->max_shard_candidates = mx;
-            out->wave_steps = steps; out->candidates = cands; out->n_deferred = st->n_deferred; out->pool_timeouts = st->pool_timeouts;
+            out->wave_steps = steps; out->candidates = cands; out->n_deferred = st->n_deferred;
             out->clk_start_inv = c0; out->clk_end = c1;
         }
         if (lane < 9) out->sort_flags[lane] = sort_flags[lane];
@@ -561,63 +553,6 @@ __global__ __launch_bounds__(DESC_THREADS) void k_descend(QuerySrc src, uint32_t
 //   block of records in LDS made the hops cheap but cost 3 of 8 workgroups per CU (no gain); running the chain inside
 //   the descent loop to overlap the two latencies added more instructions than it hid (slower).
 // ====================================================================================================
-// The survivor pool of k_descend_half's inline exact stage.  An entry is 32 bytes = two 16-byte halves, each stored by ONE sc1 (write-through)
-// store and each its own flag: {ID a, ID b, a.v0, a.v1} {a.v2, b.v0, b.v1, b.v2}, a = the triangle with the smaller ID (the reference tests an
-// unordered pair with the smaller ID in front: tri_contact.cuh:81 lets only that direction through).  A half is never all ones -- it holds at
-// least two vertex indices, which are < nv <= 2^32 - 1 -- so all ones means "not stored yet" (POOL_EMPTY); a consumer puts both halves back to
-// all ones after reading them: the buffer is all ones between steps.  Everything the SAT needs but the vertices travels in the entry.
-typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-constexpr int POOL_SPIN = 1 << 22;
-constexpr int POOL_ENTRY_SLOTS = 4;          // an entry takes the room of four 8-byte candidates
-constexpr int POOL_DONE_SHIFT = 40;
-__device__ __forceinline__ void store16_sc1(u4v *p, u4v v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void load2x16_sc1(const u4v *p, u4v &a, u4v &b)
-{
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
-}
-__device__ __forceinline__ bool pool_half_empty(u4v h) { return (h.x & h.y & h.z & h.w) == 0xffffffffu; }
-// (the lane number out of the exec-mask counters, by an asm the compiler may neither move nor merge: recomputed wherever it is needed, so
-//  that no register holds it across the SAT -- with threadIdx.x the allocator spilled it, and reloaded it in the descent's loops)
-__device__ __forceinline__ uint32_t lane_now()
-{
-    uint32_t l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
-}
-// a value every lane holds alike (a load from a wave-uniform address), said so to the compiler: into scalar registers
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
-{
-    return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
-           ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
-}
-__device__ __forceinline__ void sat_batch(const double *__restrict__ verts, u4v *entry /* of the batch's first survivor */, uint32_t take,
-                                          uint32_t *__restrict__ pairs, unsigned long long cap, TravState *__restrict__ st, lds_vdouble *park /* [3][64] doubles of LDS nobody else uses now */)
-{
-    const uint32_t lane = lane_now();
-    const bool mine = lane < take;
-    u4v *w = entry + 2 * lane;
-    u4v h0 = u4v{~0u, ~0u, ~0u, ~0u}, h1 = h0;
-    for (int it = 0; it < POOL_SPIN; ++it) {
-        if (mine && (pool_half_empty(h0) || pool_half_empty(h1))) load2x16_sc1(w, h0, h1);
-        if (__builtin_amdgcn_ballot_w64(mine && (pool_half_empty(h0) || pool_half_empty(h1))) == 0ull) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    const bool have = mine && !pool_half_empty(h0) && !pool_half_empty(h1);
-    if (__builtin_amdgcn_ballot_w64(mine && !have) != 0ull && lane == 0) atomicAdd(&st->pool_timeouts, 1u);
-    if (have) { const u4v e = u4v{~0u, ~0u, ~0u, ~0u}; store16_sc1(w, e); store16_sc1(w + 1, e); }
-    bool hit = false;
-    if (have && !((cap >> 63) & 1ull))
-        hit = tri_contact_lowreg<true>(load_vertex(verts, h0.z), load_vertex(verts, h0.w), load_vertex(verts, h1.x),
-                                       load_vertex(verts, h1.y), load_vertex(verts, h1.z), load_vertex(verts, h1.w), park + lane);
-    const unsigned long long mh = __builtin_amdgcn_ballot_w64(hit);
-    if (mh != 0ull) {
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&st->n_pairs, (unsigned long long)__popcll(mh));   // collision.cuh:40
-        base = __shfl(base, 0) + __popcll(mh & ((1ull << lane) - 1ull));
-        if (hit && base < (cap & 0x0fffffffffffffffull)) reinterpret_cast<uint2 *>(pairs)[base] = make_uint2(h0.x, h0.y);
-    }
-}
-
 constexpr int HALF_STACK = 8;                // LDS stack entries per lane
 constexpr int HALF_QCAP = 192;               // candidate queue slots per wave
 constexpr uint32_t HALF_FLUSH_AT = HALF_QCAP - 64;   // an enqueue adds at most 64 candidates: drain before it when more than this are waiting
@@ -628,78 +563,20 @@ constexpr uint32_t HALF_FLUSH_AT = HALF_QCAP - 64;   // an enqueue adds at most 
 constexpr int HALF_THREADS = 64;
 constexpr int HALF_XSUB = 4;                 // see the XCD mapping below
 
-template <bool DIAG, bool TIES /* the mesh has a cell table (cd_bvh.h): hits between boxes that are not both CERTAIN are looked at comparison by comparison */,
-          bool INLINE /* the exact stage runs inside this kernel (below): no k_exact launch behind it */>
+template <bool DIAG, bool TIES /* the mesh has a cell table (cd_bvh.h): hits between boxes that are not both CERTAIN are looked at comparison by comparison */>
 __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
                                                                   TravState *__restrict__ st,
                                                                   Candidates *__restrict__ cand, unsigned long long shard_cap,
-                                                                  uint2 *__restrict__ defer_list, uint32_t defer_cap,
-                                                                  const double *__restrict__ verts, uint32_t *__restrict__ pairs, unsigned long long cap)
+                                                                  uint2 *__restrict__ defer_list, uint32_t defer_cap)
 {
     const uint32_t bad_sort = sort_flags_or(src);      // looked at after phase 0 (whose loads are in bounds whatever the tree is): see sort_flags_or
-    __shared__ int32_t lds_stack[HALF_STACK][HALF_THREADS];
-    __shared__ Candidates queue[HALF_QCAP];
-    __shared__ uint8_t share_map[64];                  // work sharing: lane id of the k-th donor
-    if constexpr (INLINE) {
-        // ---- the exact stage, inside the kernel: the workgroups behind the descent's (blockIdx >= ceil(n / 64): dispatched when the last of the
-        // descent's workgroups has been, i.e. as the chip begins to drain) are CONSUMERS.  A wave's survivors are few and uneven (none over most of
-        // a mesh, dozens where surfaces meet -- in the very waves that descend longest), so a descent wave does not run the SAT itself: it pushes its
-        // survivors into its shard of the candidate buffer (flush) and says when it is done; a consumer takes full batches of 64 out of its shard --
-        // whoever's they are -- and runs the 17-axis SAT (tri_contact.cuh:19-78) with all lanes, in the slots the draining descent leaves empty, and
-        // what k_exact did in a launch of its own is over one batch after the last descent wave is.
-        //   reserved (n_candidates) -> slot stored (its own flag) -> claimed (CAS, by a consumer) -> slot read, put back to POOL_EMPTY.
-        // A claimed slot below `reserved` has a writer that is past its reservation: the wait for it is short.  Every wait is bounded (pool_timeouts).
-        const uint32_t nbd = ((uint32_t)n + 63u) / 64u;
-        if (blockIdx.x >= nbd) {
-            if (bad_sort) return;                          // (the descent's waves return without arriving: nothing to wait for)
-            static_assert(sizeof(lds_stack) >= sizeof(double) * 3 * 64, "the SAT parks three doubles a lane in the stack's LDS");
-            lds_vdouble *park = (lds_vdouble *)&lds_stack[0][0];       // (a consumer has no stack)
-            const uint32_t s_ = (blockIdx.x - nbd) & (NSHARD - 1), in_shard = nbd / NSHARD + (s_ < (nbd % NSHARD) ? 1u : 0u);
-            CtrShard *shc = &st->shard[s_];
-            u4v *pool = reinterpret_cast<u4v *>(cand + (size_t)s_ * shard_cap);
-            const unsigned long long pool_cap = shard_cap / POOL_ENTRY_SLOTS;
-            // batch b of the shard = its entries [64 b, 64 b + 64); the shard's K consumers take the batches round-robin -- no claim, no atomic: a CAS
-            // per batch from every consumer of the shard slowed the descent's own reservations (its waves ended 10 - 30 us later)
-            const uint32_t K = (gridDim.x - nbd) / NSHARD;
-            unsigned long long b = (blockIdx.x - nbd) / NSHARD;
-            bool finished = false;
-            int spins = 0;
-            const unsigned long long tc0 = __builtin_amdgcn_s_memrealtime(); unsigned long long tb_sum = 0, nb_ = 0, tfirst = 0;
-            while (spins < POOL_SPIN) {
-                // (ONE word says how many survivors are published and how many waves are done: when the count of waves is complete, so is the other)
-                const unsigned long long PD = uniform64(__hip_atomic_load(&shc->pubdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                const bool final_seen = (uint32_t)(PD >> POOL_DONE_SHIFT) == in_shard;
-                unsigned long long R = PD & ((1ull << POOL_DONE_SHIFT) - 1ull);
-                if (R > pool_cap) R = pool_cap;            // (an overflowing shard: nothing was stored past its capacity; the host grows it and redoes the step)
-                const unsigned long long first = b * 64ull;
-                const unsigned long long avail = R > first ? R - first : 0ull;
-                const uint32_t take = avail >= 64ull ? 64u : (final_seen ? (uint32_t)avail : 0u);
-                if (take == 0u) {
-                    if (final_seen) { finished = true; break; }            // nothing of this consumer's is left
-                    __builtin_amdgcn_s_sleep(8); ++spins; continue;
-                }
-                const unsigned long long tb0 = __builtin_amdgcn_s_memrealtime();
-                if (!tfirst) tfirst = tb0;
-                sat_batch(verts, pool + 2 * first, take, pairs, cap, st, park);
-                tb_sum += __builtin_amdgcn_s_memrealtime() - tb0; ++nb_;
-                b += K;
-            }
-            if (lane_now() == 0u) {
-                if (!finished) atomicAdd(&st->pool_timeouts, 1u);
-                atomicMax(&shc->pad2[1], __builtin_amdgcn_s_memrealtime());
-                atomicMax(&shc->pad2[0], ~tc0); atomicAdd(&shc->pad2[2], nb_); atomicAdd(&shc->pad2[3], tb_sum);
-                if (tfirst) atomicMax(&shc->pad2[4], ~tfirst);
-                atomicMax(&shc->pad2[5], tc0);
-                atomicMax(&shc->pad2[8], nb_);
-            }
-            return;
-        }
-    }
-    if constexpr (INLINE) { if (!((cap >> 59) & 1ull)) __builtin_amdgcn_s_setprio(3); }   // the descent's waves before the consumers' wherever both are ready to issue
     // The kernel times ITSELF with the device's constant-rate wall clock (s_memrealtime): first wave start -> last wave end, two
     // sharded atomicMax per wave (the start as its complement, so that the zeroed counters need no initial value).  A HIP time
     // stamp on the dispatch packet costs the step ~7 us of idle GPU around the kernel; this costs it nothing measurable.
     const unsigned long long clk0 = __builtin_amdgcn_s_memrealtime();
+    __shared__ int32_t lds_stack[HALF_STACK][HALF_THREADS];
+    __shared__ Candidates queue[HALF_QCAP];
+    __shared__ uint8_t share_map[64];                  // work sharing: lane id of the k-th donor
     const uint32_t lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t dg_p1a = 0, dg_p1 = 0, dg_hops_in = 0, dg_hops_out = 0, dg_vis = 0;   // diagnostics (DIAG)
@@ -738,20 +615,10 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         Candidates cd0 = Candidates{0, 0};
         bool keep = lane < count;
         if (keep) cd0 = queue[qcount - count + lane];
-        if constexpr (INLINE) {
-            // a hit the fp32 comparisons could not decide: the exact FP64 leaf-AABB test (box.cuh:40-43) here, on the two stored boxes
-            // (wave-uniform skip: a mesh of fp32-valued vertices has none)
-            const bool undecided = keep && !(cd0.leaf & CAND_CERTAIN);
-            if (__builtin_amdgcn_ballot_w64(undecided) != 0ull) {
-                if (undecided) keep = leaf_pair_overlap64(src.boxes, src.qbox, n, (int)cd0.q, (int)(cd0.leaf & CAND_LEAF_MASK));   // collision.cuh:31-32
-            }
-            cd0.leaf = (cd0.leaf & CAND_LEAF_MASK) | (keep ? CAND_CERTAIN : 0u);
-        }
-        LeafTri lt = LeafTri{0, 0, 0, 0}, ql = lt;
         if (keep && (cd0.leaf & CAND_CERTAIN)) {
             tested += 2u;                                                      // collision.cuh:31-32, decided exactly by the descent, both directions
-            lt = src.leaf[cd0.leaf & CAND_LEAF_MASK];
-            ql = src.leaf[cd0.q];
+            const LeafTri lt = src.leaf[cd0.leaf & CAND_LEAF_MASK];
+            const LeafTri ql = src.leaf[cd0.q];
             keep = neighbor_count(ql.v0, ql.v1, ql.v2, lt.v0, lt.v1, lt.v2) < 1 && ql.id != lt.id;   // collision.cuh:38, tri_contact.cuh:81
             cd0.leaf |= CAND_FILTERED;
         }
@@ -761,16 +628,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(&sh->n_candidates, (unsigned long long)__popcll(mk));
             base = __shfl(base, 0) + __popcll(mk & lt_mask);
-            if constexpr (INLINE) {
-                if (lane == 0) atomicAdd(&sh->pubdone, (unsigned long long)__popcll(mk));
-                // a survivor for the SAT: a pool entry (above), the smaller ID in front
-                if (keep && base < shard_cap / POOL_ENTRY_SLOTS) {
-                    const bool sw = ql.id > lt.id;
-                    const LeafTri a = sw ? lt : ql, b = sw ? ql : lt;
-                    u4v *e = reinterpret_cast<u4v *>(my_cand) + 2 * base;
-                    store16_sc1(e, u4v{a.id, b.id, a.v0, a.v1}); store16_sc1(e + 1, u4v{a.v2, b.v0, b.v1, b.v2});
-                }
-            } else if (keep && base < shard_cap) my_cand[base] = cd0;
+            if (keep && base < shard_cap) my_cand[base] = cd0;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
@@ -948,12 +806,8 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         if (v64) atomicAdd(&sh->node_visits, v64);
         if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
         if (blockIdx.x < 256u) atomicMax(&sh->pad[4], ~clk0);                  // (the earliest start is among the first workgroups dispatched)
+        atomicMax(&sh->pad[11], __builtin_amdgcn_s_memrealtime());
     }
-    if constexpr (INLINE) {
-        // everything this wave will push is reserved (each reservation was a returning atomic whose value was used): tell the shard's consumers
-        if (lane == 0) atomicAdd(&sh->pubdone, 1ull << POOL_DONE_SHIFT);
-    }
-    if (lane == 0) atomicMax(&sh->pad[11], __builtin_amdgcn_s_memrealtime());
     if constexpr (DIAG) {
         const unsigned long long hi = wave_sum_u64(dg_hops_in), ho = wave_sum_u64(dg_hops_out), vi = wave_sum_u64(dg_vis);
         const unsigned long long tm5 = __builtin_amdgcn_s_memtime();

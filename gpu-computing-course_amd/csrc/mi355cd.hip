@@ -47,9 +47,6 @@ struct TravBuf {
     uint64_t direct_id = 0; uint32_t synced_direct = 0;                    // the same for the caller's pinned pair buffer last written directly (its serial number: pinned_pairs_id)
     uint2 *d_defer = nullptr; uint32_t defer_cap = 0;
     Candidates *d_cand = nullptr; uint64_t cand_cap = 0;
-    uint32_t slot_factor = 1;                                              // candidates' worth of room one reservation of the last pass took (4: pool entries of the inline exact stage)
-    bool cand_pool_ready = false;                                          // every slot of d_cand holds POOL_EMPTY: what the half traversal's inline exact stage starts from and leaves behind (cd_traverse.h);
-                                                                           // false after an allocation and after any pass that used the buffer as a plain candidate list (k_descend + k_exact)
     int32_t *d_deep = nullptr; uint64_t deep_items = 0;
 };
 
@@ -110,11 +107,6 @@ struct cd_ctx {
     bool stage_events = true;               // CD_OPT_STAGE_TIMING
     bool leaves_filled = false;             // the sort's fix-up hop already wrote leaf[], parent = -1, bounded = 0
     bool events_ride = false;               // the last pass recorded EV_TRAV0 / EV_DESC1 / EV_TRAV1 through its kernels' dispatch packets
-    bool inline_exact = true;               // CD_OPT_INLINE_EXACT: the half traversal runs its exact stage inside k_descend_half (no k_exact launch)
-    int trav_end_ev = EV_TRAV1;
-    bool last_pass_inline = false;          // ... and the last pass did: its end is EV_DESC1 when the stamps ride on the dispatch packets
-    uint32_t dbg_pool_consumers = 0;        // CD_DBG_POOL_CONSUMERS: consumer workgroups of the inline exact stage (0: by the grid's size)
-    uint32_t pool_fallbacks = 0;            // steps redone with k_exact because a bounded wait in the inline exact stage ran out (must stay 0)
     bool prezeroed = false;                 // fused path: the scratch block was zeroed by one memset at pipeline start
     hipEvent_t tree_done_event = nullptr;   // set by the multi-GPU step: taken (and cleared) by the launch that completes the tree, if it can carry it
     bool scratch_clean = false;             // ... or by the kernels of the previous fused step (ZeroPlan, cd_build.h): no memset at all
@@ -213,17 +205,12 @@ __global__ void k_box_pairs(const double *__restrict__ a, const double *__restri
         }
     }
 }
-__global__ __launch_bounds__(256) void k_tri_contact_points(const double *__restrict__ t, uint64_t n, uint8_t *__restrict__ out)
+__global__ void k_tri_contact_points(const double *__restrict__ t, uint64_t n, uint8_t *__restrict__ out)
 {
-    __shared__ double park[4 * 3 * 64];                                    // a [3][64] column block per wave
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const double *p = t + 18 * i;
-        const d3 P1{p[0], p[1], p[2]}, P2{p[3], p[4], p[5]}, P3{p[6], p[7], p[8]}, Q1{p[9], p[10], p[11]}, Q2{p[12], p[13], p[14]}, Q3{p[15], p[16], p[17]};
-        // both forms of the test (cd_math.h): the one k_exact / the reference-shaped traversal use and the low-register one of the inline
-        // exact stage.  They must agree; 2 = they did not (no caller's expectation is 2)
-        const bool a = tri_contact(P1, P2, P3, Q1, Q2, Q3), b = tri_contact_lowreg<false>(P1, P2, P3, Q1, Q2, Q3),
-                   c = tri_contact_lowreg<true>(P1, P2, P3, Q1, Q2, Q3, (lds_vdouble *)park + (threadIdx.x & 63u) + 192u * (threadIdx.x >> 6));
-        out[i] = (a == b && a == c) ? (a ? 1 : 0) : 2;
+        out[i] = tri_contact(d3{p[0], p[1], p[2]}, d3{p[3], p[4], p[5]}, d3{p[6], p[7], p[8]},
+                             d3{p[9], p[10], p[11]}, d3{p[12], p[13], p[14]}, d3{p[15], p[16], p[17]}) ? 1 : 0;
     }
 }
 
@@ -529,29 +516,15 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         uint2 *dl = DEEP ? nullptr : tb.d_defer; const uint32_t dcap = DEEP ? 0u : tb.defer_cap; int32_t *deep = DEEP ? tb.d_deep : nullptr;
         const uint32_t half = half_mode ? 1u : 0u;
         const bool plain = !e0 && !e1 && !e2;          // no time stamp rides on these launches: plain launches (a stream capture can record them)
-        // the half traversal with its exact stage inside the kernel (CD_OPT_INLINE_EXACT, default): no k_exact behind it
-        const bool inline_exact = half_mode && !DEEP && c->inline_exact;
-        if (inline_exact && !tb.cand_pool_ready) {                 // (once per buffer: a step leaves every slot as it found it)
-            hipMemsetAsync(tb.d_cand, 0xff, sizeof(Candidates) * tb.cand_cap, s);
-            tb.cand_pool_ready = true;
-        }
-        if (!inline_exact) tb.cand_pool_ready = false;             // a plain candidate list is about to be written
-        tb.slot_factor = inline_exact ? (uint32_t)POOL_ENTRY_SLOTS : 1u;
         if (half_mode && !DEEP) {
-            // inline exact stage: consumer workgroups behind the descent's (cd_traverse.h), a multiple of the shard count
-            const uint32_t hdesc = cdiv(items, 64u);
-            const uint32_t hcons = !inline_exact ? 0u : (c->dbg_pool_consumers ? c->dbg_pool_consumers : std::min(4096u, std::max(256u, hdesc / 16u))) / NSHARD * NSHARD;
-            const dim3 hgrid(hdesc + (inline_exact ? std::max(hcons, (uint32_t)NSHARD) : 0u)), hblock(HALF_THREADS);
-#define LAUNCH_HALF(DIAG, TIES, INL)                                                                                                        \
-            do { if (plain) k_descend_half<DIAG, TIES, INL><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, \
-                                                                                     c->d_verts, tb.d_pairs, (unsigned long long)cap_pairs | (getenv("CD_POOL_NOSAT") ? (1ull << 63) : 0ull) | ((unsigned long long)(getenv("CD_POOL_SLEEP") ? atoi(getenv("CD_POOL_SLEEP")) : 0) << 60) | ((unsigned long long)(getenv("CD_POOL_MODE") ? atoi(getenv("CD_POOL_MODE")) : 0) << 56) | (getenv("CD_POOL_NOPRIO") ? (1ull << 59) : 0ull)); \
-                 else hipExtLaunchKernelGGL((k_descend_half<DIAG, TIES, INL>), hgrid, hblock, (uint32_t)pad, s, e0, e1, 0u, src, n, (const NodeRec32 *)c->d_recs32, \
-                                            tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, (const double *)c->d_verts, tb.d_pairs, (unsigned long long)cap_pairs | (getenv("CD_POOL_NOSAT") ? (1ull << 63) : 0ull) | ((unsigned long long)(getenv("CD_POOL_SLEEP") ? atoi(getenv("CD_POOL_SLEEP")) : 0) << 60) | ((unsigned long long)(getenv("CD_POOL_MODE") ? atoi(getenv("CD_POOL_MODE")) : 0) << 56) | (getenv("CD_POOL_NOPRIO") ? (1ull << 59) : 0ull)); } while (0)
-#define LAUNCH_HALF2(DIAG, TIES) do { if (inline_exact) LAUNCH_HALF(DIAG, TIES, true); else LAUNCH_HALF(DIAG, TIES, false); } while (0)
+            const dim3 hgrid(cdiv(items, 64u)), hblock(HALF_THREADS);
+#define LAUNCH_HALF(DIAG, TIES)                                                                                                             \
+            do { if (plain) k_descend_half<DIAG, TIES><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap); \
+                 else hipExtLaunchKernelGGL((k_descend_half<DIAG, TIES>), hgrid, hblock, (uint32_t)pad, s, e0, e1, 0u, src, n, (const NodeRec32 *)c->d_recs32, \
+                                            tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap); } while (0)
             const bool ties = c->amb.keys != nullptr || c->amb.mask != 0u;                      // (a graph capture bakes the instance in: amb_refresh drops the graph when the table comes or goes)
-            if (c->dbg_diag) { if (ties) LAUNCH_HALF2(true, true); else LAUNCH_HALF2(true, false); }
-            else { if (ties) LAUNCH_HALF2(false, true); else LAUNCH_HALF2(false, false); }
-#undef LAUNCH_HALF2
+            if (c->dbg_diag) { if (ties) LAUNCH_HALF(true, true); else LAUNCH_HALF(true, false); }
+            else { if (ties) LAUNCH_HALF(false, true); else LAUNCH_HALF(false, false); }
 #undef LAUNCH_HALF
         }
         else if (qpw == 64)
@@ -561,8 +534,6 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, true>), grid, dim3(DESC_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
         if (!DEEP && !ride && !c->quiet_pass) evrec(c, EV_DESC1);
-        if (!DEEP) c->last_pass_inline = inline_exact;
-        if (inline_exact) { c->events_ride = ride; return; }
         if (plain)
             k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, tb.d_cand, (unsigned long long)shard_cap, tb.d_pairs,
                                                                         (unsigned long long)cap_pairs, tb.d_state, half);
@@ -574,7 +545,7 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
     }
 }
 
-struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_candidates; uint32_t n_deferred; uint64_t wave_steps, candidates, clk_start_inv, clk_end; uint32_t pool_timeouts; };
+struct HostCounters { uint64_t n_pairs, pairs_tested, node_visits, max_shard_candidates; uint32_t n_deferred; uint64_t wave_steps, candidates, clk_start_inv, clk_end; };
 
 // One host round trip and NO copy: k_report writes counters, the sort's time-out flags, the root box and the first
 // spec_n pairs straight into pinned host memory.  enqueue_report queues the kernel; parse_report reads the record
@@ -639,7 +610,7 @@ int wait_report(cd_ctx *c, TravBuf &tb, unsigned long long seq)
 void parse_report(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs, uint64_t spec_n)
 {
     const Report &r = *reinterpret_cast<const Report *>(tb.h_report);
-    h = HostCounters{r.n_pairs, r.pairs_tested, r.node_visits, r.max_shard_candidates, r.n_deferred, r.wave_steps, r.candidates, r.clk_start_inv, r.clk_end, r.pool_timeouts};
+    h = HostCounters{r.n_pairs, r.pairs_tested, r.node_visits, r.max_shard_candidates, r.n_deferred, r.wave_steps, r.candidates, r.clk_start_inv, r.clk_end};
     std::memcpy(c->sort_flags, r.sort_flags, sizeof c->sort_flags);
     std::memcpy(c->root_box_host, r.root_box, sizeof(double) * 6);
     if (spec_n && spec_pairs) {
@@ -675,19 +646,18 @@ int read_state(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs = n
 }
 
 // Did a shard of the candidate buffer overflow in the pass `h` reports?  (Nothing is written past a shard; the step is redone.)
-bool shards_overflowed(const TravBuf &tb, const HostCounters &h) { return h.max_shard_candidates > tb.cand_cap / NSHARD / tb.slot_factor; }
+bool shards_overflowed(const TravBuf &tb, const HostCounters &h) { return h.max_shard_candidates > tb.cand_cap / NSHARD; }
 int grow_candidates(cd_ctx *c, TravBuf &tb, uint64_t max_shard);
-int grow_shards(cd_ctx *c, TravBuf &tb, const HostCounters &h) { return grow_candidates(c, tb, h.max_shard_candidates * tb.slot_factor); }
+int grow_shards(cd_ctx *c, TravBuf &tb, const HostCounters &h) { return grow_candidates(c, tb, h.max_shard_candidates); }
 int grow_candidates(cd_ctx *c, TravBuf &tb, uint64_t max_shard)
 {
-    hipFree(tb.d_cand); tb.d_cand = nullptr; tb.cand_cap = 0; tb.cand_pool_ready = false;
+    hipFree(tb.d_cand); tb.d_cand = nullptr; tb.cand_cap = 0;
     const uint64_t want = (max_shard + max_shard / 4 + 1024) * NSHARD;
     HIPCHK(hipMalloc(&tb.d_cand, sizeof(Candidates) * want));
     tb.cand_cap = want;
     return 0;
 }
 
-void graph_drop(cd_ctx *c);
 // Traversal (local leaves or external queries).  Blocks: reads the counters, runs the deep pass when needed.
 int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs)
 {
@@ -723,10 +693,6 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
         if (!c->events_ride) HIPCHK(evrec(c, EV_TRAV1));      // device time of the kernels only: recorded before the read-back
         if ((rc = read_state(c, tb, h, pairs, spec_n, pinned_pairs_id(pairs, cap_pairs)))) return rc;
         spec_valid = spec_n;
-        if (h.pool_timeouts) {                           // a bounded wait of the inline exact stage ran out (never seen): this context goes back to k_exact, the step is redone
-            c->inline_exact = false; ++c->pool_fallbacks; tb.cand_pool_ready = false; graph_drop(c);
-            continue;
-        }
         if (shards_overflowed(tb, h)) { if ((rc = grow_shards(c, tb, h))) return rc; continue; }
         if (h.n_deferred > tb.defer_cap) {               // the deferred list was too small: grow it and redo (pairs restart at 0)
             hipFree(tb.d_defer); tb.d_defer = nullptr; tb.defer_cap = 0;
@@ -770,12 +736,10 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
         HIPCHK(hipStreamSynchronize(s));
     }
     // (a time stamp that was not taken in this call must not be read: the event holds an earlier call's)
-    const bool inl = c->last_pass_inline && nq > 0;       // the exact stage ran inside the descent kernel: that kernel's end is the traversal's
-    const bool have_d = !c->events_ride || (c->stamp_mask & 2u), have_x = inl ? have_d : (!c->events_ride || (c->stamp_mask & 4u));
-    c->trav_end_ev = (inl && c->events_ride) ? EV_DESC1 : EV_TRAV1;
-    c->stats.ms_traverse = (have_d && have_x) ? elapsed(c, EV_TRAV0, c->trav_end_ev) + deep_ms : 0.f;
+    const bool have_d = !c->events_ride || (c->stamp_mask & 2u), have_x = !c->events_ride || (c->stamp_mask & 4u);
+    c->stats.ms_traverse = (have_d && have_x) ? elapsed(c, EV_TRAV0, EV_TRAV1) + deep_ms : 0.f;
     c->stats.ms_descend = (c->trav_variant != 0 && nq > 0 && have_d) ? elapsed(c, EV_TRAV0, EV_DESC1) : 0.f;
-    c->stats.ms_exact = (c->trav_variant != 0 && nq > 0 && have_d && have_x && !inl) ? elapsed(c, EV_DESC1, EV_TRAV1) : 0.f;
+    c->stats.ms_exact = (c->trav_variant != 0 && nq > 0 && have_d && have_x) ? elapsed(c, EV_DESC1, EV_TRAV1) : 0.f;
     c->stats.traverse_launches = launches;
     c->stats.n_pairs = found; c->stats.pairs_tested = h.pairs_tested; c->stats.node_visits = h.node_visits;
     c->stats.wave_steps = h.wave_steps; c->stats.candidates = h.candidates;
@@ -878,8 +842,7 @@ int amb_refresh(cd_ctx *c)
 bool graph_eligible(const cd_ctx *c)
 {
     return c->graph_opt && !c->stage_events && c->stamp_mask == 0 && c->sort_mode <= 1 && fused_build_next(c) && c->trav_variant == 3 &&
-           c->scratch_clean && !c->dbg_diag && !c->dbg_lds_pad && c->nt > 1 && c->tree_done_event == nullptr &&
-           (!c->inline_exact || c->tb[0].cand_pool_ready);                  // (the pool's one-time fill is not a thing to capture: a stream-path step makes it first)
+           c->scratch_clean && !c->dbg_diag && !c->dbg_lds_pad && c->nt > 1 && c->tree_done_event == nullptr;
 }
 int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs, bool &handled)
 {
@@ -891,7 +854,7 @@ int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs
     if (rc) return rc;
     uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
     const bool direct = pinned_pairs_id(pairs, cap_pairs) != 0;
-    const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1) | (c->inline_exact ? 4u : 0u),
+    const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1),
                                tb.d_pairs, tb.d_cand, tb.d_defer, direct ? (const void *)pairs : (const void *)tb.h_report, tb.cand_cap, tb.defer_cap, 0u};
     static_assert(sizeof(cd_ctx::GraphKey) == 2 * 8 + 6 * 4 + 4 * 8 + 8 + 2 * 4, "GraphKey has no padding");
     if (!c->graph_exec || std::memcmp(&key, &c->graph_key, sizeof key) != 0) {
@@ -929,8 +892,7 @@ int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs
     parse_report(c, tb, h, direct ? nullptr : pairs, spec_n);
     c->stage = ST_REFIT; c->root_box_valid = true;
     { const int js = judge_sort_flags(c); if (js != CD_OK) return CD_OK; }                 // (not handled: the stream path redoes the step in the sort's next form)
-    if (h.pool_timeouts) { c->inline_exact = false; ++c->pool_fallbacks; tb.cand_pool_ready = false; graph_drop(c); }
-    if (shards_overflowed(tb, h) || h.n_deferred > 0 || h.pool_timeouts) {             // the tree is fine: the traversal again, with the stream path's retries / deep pass
+    if (shards_overflowed(tb, h) || h.n_deferred > 0) {             // the tree is fine: the traversal again, with the stream path's retries / deep pass
         handled = true;
         c->scratch_clean = false;
         return run_traversal(c, tb, nullptr, 0, pairs, cap_pairs, n_pairs);
@@ -1225,8 +1187,8 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         c->stats.ms_hierarchy = c->last_tree_fused ? 0.f : elapsed(c, EV_HIER0, EV_HIER1);
         c->stats.ms_refit = elapsed(c, EV_REFIT0, EV_REFIT1);
     } else c->stats.ms_morton = c->stats.ms_sort = c->stats.ms_hierarchy = c->stats.ms_refit = 0.f;
-    const bool all_stamps = c->stage_events || (c->stamp_mask & 14u) == 14u || (c->last_pass_inline && (c->stamp_mask & 10u) == 10u);
-    c->stats.ms_pipeline = all_stamps ? elapsed(c, EV_MORTON0, c->trav_end_ev) + (c->stats.ms_traverse - elapsed(c, EV_TRAV0, c->trav_end_ev)) : 0.f;   // + deep pass, if any
+    const bool all_stamps = c->stage_events || (c->stamp_mask & 14u) == 14u;
+    c->stats.ms_pipeline = all_stamps ? elapsed(c, EV_MORTON0, EV_TRAV1) + (c->stats.ms_traverse - elapsed(c, EV_TRAV0, EV_TRAV1)) : 0.f;   // + deep pass, if any
     c->stats.ms_build_block = (c->last_tree_fused && (c->stamp_mask & 1u)) ? elapsed(c, EV_BLK0, EV_BLK1) : 0.f;
     c->stage = ST_REFIT;
     c->root_box_valid = true;
@@ -1361,24 +1323,6 @@ int cd_debug_counters(cd_ctx *c, unsigned long long out[12])
     std::vector<TravState> h(1);
     HIPCHK(hipMemcpy(h.data(), c->tb[0].d_state, sizeof(TravState), hipMemcpyDeviceToHost));
     for (int k = 0; k < 12; ++k) { out[k] = 0; for (int i = 0; i < NSHARD; ++i) out[k] += h[0].shard[i].pad[k]; }
-    if (getenv("CD_POOL_DIAG")) {
-        unsigned long long mx[12] = {0}; unsigned long long sm[12] = {0};
-        for (int i = 0; i < NSHARD; ++i) for (int k = 0; k < 12; ++k) { mx[k] = std::max(mx[k], h[0].shard[i].pad2[k]); sm[k] += h[0].shard[i].pad2[k]; }
-        unsigned long long pstart = 0, pend = 0;
-        for (int i = 0; i < NSHARD; ++i) { pstart = std::max(pstart, h[0].shard[i].pad[4]); pend = std::max(pend, h[0].shard[i].pad[11]); }
-        const unsigned long long t0 = ~pstart;
-        out[0] = pend - t0;            // producers' end
-        out[1] = ~mx[0] - t0;          // first consumer start
-        out[2] = mx[1] - t0;           // last consumer end
-        out[3] = sm[2];                // batches
-        out[4] = sm[3];                // ticks in batches
-        out[5] = ~mx[4] - t0;          // first batch start
-        out[6] = mx[5] - t0;           // last consumer start
-        out[7] = ~mx[6] - t0;          // first final seen
-        out[8] = mx[7] - t0;           // last final seen
-        out[9] = mx[8];                // most batches of a consumer
-        out[10] = c->wall_clock_khz;
-    }
     return CD_OK;
 }
 
@@ -1518,7 +1462,6 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
         return amb_refresh(c);
     }
     if (key == CD_OPT_KERNEL_STAMPS) { if (value < 0 || value > 15) return CD_ERR_ARG; c->stamp_mask = (uint32_t)value; return CD_OK; }
-    if (key == CD_OPT_INLINE_EXACT) { c->inline_exact = value != 0; graph_drop(c); return CD_OK; }       // (a captured step has its kernels baked in)
     return CD_ERR_ARG;
 }
 
@@ -1535,14 +1478,11 @@ int cd_debug_option(cd_ctx *c, int key, int64_t value, int64_t *out)
     case CD_DBG_DIAG:            c->dbg_diag = value != 0; return CD_OK;
     case CD_DBG_STAGEWISE_BUILD: c->dbg_no_fused_build = value != 0; return CD_OK;
     case CD_DBG_SPLIT_CROSS:     c->dbg_split_cross = value != 0; return CD_OK;
-    case CD_DBG_POOL_CONSUMERS:  if (value < 0 || value > 65536) return CD_ERR_ARG; c->dbg_pool_consumers = (uint32_t)value; graph_drop(c); return CD_OK;
     case CD_DBG_POLL_SCAN:       c->dbg_poll_check = value != 0; return CD_OK;
     case CD_DBG_GET_POLL_STALE:     if (!out) return CD_ERR_ARG; *out = c->poll_stale; return CD_OK;
     case CD_DBG_GET_POLL_FALLBACKS: if (!out) return CD_ERR_ARG; *out = c->poll_fallbacks; return CD_OK;
     case CD_DBG_GET_POLLED_STEPS:   if (!out) return CD_ERR_ARG; *out = c->polled_steps; return CD_OK;
     case CD_DBG_GET_TREE_WAS_FUSED: if (!out) return CD_ERR_ARG; *out = c->last_tree_fused ? 1 : 0; return CD_OK;
-    case CD_DBG_GET_POOL_FALLBACKS: if (!out) return CD_ERR_ARG; *out = c->pool_fallbacks; return CD_OK;
-    case CD_DBG_GET_PASS_WAS_INLINE: if (!out) return CD_ERR_ARG; *out = c->last_pass_inline ? 1 : 0; return CD_OK;
     default: return CD_ERR_ARG;
     }
 }

@@ -212,9 +212,6 @@ enum {
                                    /*    costs the upload ~0.4 ms per million vertices).  0: no table, every coordinate that is not an fp32 value is rounded outward    */
                                    /*    (a full-double structured mesh: ~2 x the step time, nothing added to the upload).  Vertices that are all fp32 values -- what   */
                                    /*    the reference's loader produces, load_obj.h:38 -- never have a table                                                            */
-    CD_OPT_INLINE_EXACT     = 8,   /* 1 (default): the half traversal (CD_OPT_TRAVERSAL 3) runs its exact stage -- FP64 box test where still needed, neighbour filter, ID rule,  */
-                                   /*    17-axis SAT -- inside the descent kernel: a wave pushes its survivors into a pool, waves that have finished take full batches of 64   */
-                                   /*    out of it; no exact kernel is launched behind the descent (one launch and ~10 us less per step).  0: descent + exact kernel          */
     CD_OPT_QUERIES_PER_WAVE = 1    /* variant 1: queries one wave works through with dynamic lane refill (x64)         */
 };
 int cd_set_option(cd_ctx *ctx, int key, int64_t value);
@@ -229,14 +226,11 @@ enum {
     CD_DBG_DIAG               = 3,   /* run the descent kernel's DIAG instance: per-phase step counts and s_memtime ticks -> cd_debug_counters */
     CD_DBG_STAGEWISE_BUILD    = 4,   /* fused entry points build the tree stage by stage (k_hierarchy + refit) instead of in one pass         */
     CD_DBG_SPLIT_CROSS        = 5,   /* the fused build's cross nodes by k_cross_meta + k_cross_records instead of k_cross_fused               */
-    CD_DBG_POOL_CONSUMERS     = 6,   /* consumer workgroups of the inline exact stage (CD_OPT_INLINE_EXACT); 0 (default): a sixteenth of the descent's, 256 .. 4096 */
     CD_DBG_POLL_SCAN          = 10,  /* polled completion: poison the pair area before a step, scan it the moment the sequence word is seen   */
     CD_DBG_GET_POLL_STALE     = 11,  /* ... steps in which the scan found a pair missing (must stay 0)                                        */
     CD_DBG_GET_POLL_FALLBACKS = 12,  /* ... polled waits that ran into the 20 ms budget and ended in a stream synchronise                     */
     CD_DBG_GET_POLLED_STEPS   = 13,  /* ... reports whose end was read off the sequence word                                                  */
-    CD_DBG_GET_TREE_WAS_FUSED = 14,  /* 1: the tree that is there was made by the one-pass build                                              */
-    CD_DBG_GET_POOL_FALLBACKS = 15,  /* steps redone with the exact kernel because a bounded wait of the inline exact stage ran out (must stay 0) */
-    CD_DBG_GET_PASS_WAS_INLINE = 16  /* 1: the last traversal's exact stage ran inside the descent kernel (CD_OPT_INLINE_EXACT)                */
+    CD_DBG_GET_TREE_WAS_FUSED = 14   /* 1: the tree that is there was made by the one-pass build                                              */
 };
 int cd_debug_option(cd_ctx *ctx, int key, int64_t value, int64_t *out);
 
