@@ -151,6 +151,61 @@ __device__ __forceinline__ Box leaf_box64(const double *__restrict__ boxes, cons
     return load_box(boxes, (n - 1) + j);
 }
 
+// ---------------------------------------------------------------- which workgroup of the half traversal takes which 64 leaves
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD and its 4 MiB L2).  An XCD works on HALF_XSUB chunks of consecutive
+// groups from different parts of the mesh rather than ONE contiguous eighth: its L2 still sees an eighth of the tree, and the work per query is not
+// even over a mesh (where the surfaces meet, a query has candidates; elsewhere none) -- an XCD with a busy eighth was the kernel's tail.
+// 1 M cloth: 1 / 2 / 4 / 8 / 16 chunks -> 57.8 / 57.9 / 54.1 / 54.4 / 54.6 us.  Speed only: any bijection of [0, nb) gives the same results.
+constexpr int HALF_XSUB = 4;
+__device__ __forceinline__ uint32_t half_vblock(uint32_t b, uint32_t nb)
+{
+    const uint32_t per = nb >> 3;
+    uint32_t v = (b < (per << 3)) ? (b & 7u) * per + (b >> 3) : b;
+    const uint32_t c = per / HALF_XSUB;
+    if (c > 0 && b < c * HALF_XSUB * 8u) {
+        const uint32_t x = b & 7u, l = b >> 3, sub = l / c, off = l % c;
+        v = (sub * 8u + x) * c + off;
+    } else if (c > 0) v = b;                             // (the remainder keeps its own index: c * HALF_XSUB * 8 <= b < nb are not produced above)
+    return v;
+}
+// The ORDER HINT.  The half traversal's kernel ends with its unluckiest wave slot: 1.9 rounds of waves that take 13 .. 40 us each, dispatched in index order
+// (profiles/r03_experiments/descent_ablation.log: dispatch order 51.8 us, the same waves longest-first 40.5).  Nothing known inside a step predicts a long
+// wave -- but the previous step does: a mesh moves little between two steps, the groups of leaves where surfaces meet stay where they were.  Every wave leaves
+// how long it took (a class of 1.28 us, ORDER_CLASSES of them) in cost[its group]; the NEXT step's build sorts, per XCD, the groups that XCD works on by that
+// class, longest first (stable: equal classes keep half_vblock's order), into order[]: workgroup b then takes group order[b].  Which groups an XCD works on
+// does not change, so its L2 sees what it saw.  A hint only: cost[] may hold anything (zeros in the first step, another mesh's times after
+// cd_update_vertices) -- order[] is a permutation whatever it holds, and any permutation gives the same results.
+// One workgroup of T threads per XCD list (x = 0 .. 7), in LDS the caller lends it (ORDER_LDS_BYTES<T>); lists of more than ORDER_MAX_ITEMS groups
+// (4 M triangles) are left in half_vblock's order.  A stable counting sort in four barriers: the classes of the list into LDS (one gather), a count per
+// thread and class over the thread's run of consecutive items, a scan down each class's column, the items placed run by run.
+constexpr int ORDER_CLASSES = 32, ORDER_SHIFT = 7 /* 2^7 ticks of the 100 MHz wall clock */, ORDER_MAX_ITEMS = 8192;
+template <int T> struct OrderLds { uint8_t cls[ORDER_MAX_ITEMS]; uint16_t cnt[T][ORDER_CLASSES]; uint32_t base[ORDER_CLASSES]; };
+template <int T>
+__device__ __forceinline__ void build_half_order(uint32_t x, uint32_t nb, const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, OrderLds<T> &L)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cnt = x < nb ? (nb - x + 7u) / 8u : 0u;                   // workgroups b = 8 l + x < nb
+    if (cnt > (uint32_t)ORDER_MAX_ITEMS) { for (uint32_t l = tid; l < cnt; l += T) order[8u * l + x] = half_vblock(8u * l + x, nb); return; }
+    for (uint32_t l = tid; l < cnt; l += T) { const uint32_t c = cost[half_vblock(8u * l + x, nb)]; L.cls[l] = (uint8_t)(c < ORDER_CLASSES ? c : ORDER_CLASSES - 1); }
+    for (int k = 0; k < ORDER_CLASSES; ++k) L.cnt[tid][k] = 0;
+    __syncthreads();
+    const uint32_t per = (cnt + T - 1) / T, l0 = tid * per < cnt ? tid * per : cnt, l1 = l0 + per < cnt ? l0 + per : cnt;   // this thread's run of the list
+    for (uint32_t l = l0; l < l1; ++l) ++L.cnt[tid][L.cls[l]];
+    __syncthreads();
+    if (tid < ORDER_CLASSES) {                                               // class tid: the threads' counts -> how many of the class lie in EARLIER runs
+        uint32_t run = 0;
+        for (int t = 0; t < T; ++t) { const uint32_t v = L.cnt[t][tid]; L.cnt[t][tid] = (uint16_t)run; run += v; }
+        L.base[tid] = run;
+    }
+    __syncthreads();
+    uint32_t before = 0;
+    if (tid < ORDER_CLASSES) for (uint32_t c = ORDER_CLASSES - 1; c > tid; --c) before += L.base[c];   // the longest class first
+    __syncthreads();
+    if (tid < ORDER_CLASSES) L.base[tid] = before;
+    __syncthreads();
+    for (uint32_t l = l0; l < l1; ++l) { const uint32_t c = L.cls[l]; const uint32_t pos = L.base[c] + L.cnt[tid][c]++; order[8u * pos + x] = half_vblock(8u * l + x, nb); }
+}
+
 // Sorted-order leaf payload: {ID, vIdx[0..2]} (triangle.cuh:6,9) -- 16 B instead of the 56-byte Triangle.
 struct alignas(16) LeafTri { uint32_t id, v0, v1, v2; };
 

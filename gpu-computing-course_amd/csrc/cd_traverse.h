@@ -561,13 +561,14 @@ constexpr uint32_t HALF_FLUSH_AT = HALF_QCAP - 64;   // an enqueue adds at most 
 //  slot until its SLOWEST wave is done; with the work per query as uneven as it is, single-wave workgroups give the slots
 //  back sooner: 53.8 -> 52.4 us at 1 M triangles.  Two waves: 53.2 us)
 constexpr int HALF_THREADS = 64;
-constexpr int HALF_XSUB = 4;                 // see the XCD mapping below
 
 template <bool DIAG, bool TIES /* the mesh has a cell table (cd_bvh.h): hits between boxes that are not both CERTAIN are looked at comparison by comparison */>
 __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
                                                                   TravState *__restrict__ st,
                                                                   Candidates *__restrict__ cand, unsigned long long shard_cap,
-                                                                  uint2 *__restrict__ defer_list, uint32_t defer_cap)
+                                                                  uint2 *__restrict__ defer_list, uint32_t defer_cap,
+                                                                  const uint32_t *__restrict__ order /* NULL, or the order hint: workgroup -> group of 64 leaves */,
+                                                                  uint32_t *__restrict__ cost /* NULL, or per group of 64 leaves: how long its wave took (for the next step's hint) */)
 {
     const uint32_t bad_sort = sort_flags_or(src);      // looked at after phase 0 (whose loads are in bounds whatever the tree is): see sort_flags_or
     // The kernel times ITSELF with the device's constant-rate wall clock (s_memrealtime): first wave start -> last wave end, two
@@ -580,18 +581,10 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     const uint32_t lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t dg_p1a = 0, dg_p1 = 0, dg_hops_in = 0, dg_hops_out = 0, dg_vis = 0;   // diagnostics (DIAG)
-    const uint32_t nb = ((uint32_t)n + 63u) / 64u, per = nb >> 3;       // (= gridDim.x, without the load of the hidden argument) XCD-aware mapping, see k_descend
-    uint32_t vblock = (blockIdx.x < (per << 3)) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
-    // ... as HALF_XSUB chunks from different parts of the mesh rather than ONE contiguous eighth: the work per query is not
-    // even over a mesh (where the surfaces meet, a query has candidates; elsewhere none), and an XCD with a busy eighth
-    // was the kernel's tail.  1 M cloth: 1 / 2 / 4 / 8 / 16 chunks -> 57.8 / 57.9 / 54.1 / 54.4 / 54.6 us.
-    if (HALF_XSUB > 1) {
-        const uint32_t c = per / HALF_XSUB;
-        if (c > 0 && blockIdx.x < c * HALF_XSUB * 8u) {
-            const uint32_t x = blockIdx.x & 7u, l = blockIdx.x >> 3, sub = l / c, off = l % c;
-            vblock = (sub * 8u + x) * c + off;
-        } else if (c > 0) vblock = blockIdx.x;          // (the remainder keeps its own index: c * HALF_XSUB * 8 <= blockIdx.x < nb are not produced above)
-    }
+    // XCD-aware mapping of workgroups to groups of 64 leaves: half_vblock (cd_bvh.h) -- or, when this step's build has left one, the ORDER HINT: the same
+    // groups per XCD, the ones that took longest in the previous step first (cd_bvh.h, build_half_order).  Any bijection gives the same results.
+    const uint32_t nb = ((uint32_t)n + 63u) / 64u;                          // (= gridDim.x, without the load of the hidden argument)
+    const uint32_t vblock = order ? order[blockIdx.x] : half_vblock(blockIdx.x, nb);
     CtrShard *sh = &st->shard[blockIdx.x & (NSHARD - 1)];
     Candidates *my_cand = cand + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_cap;
     const uint32_t nq = (uint32_t)n, last_leaf = nq - 1u;
@@ -806,7 +799,9 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         if (v64) atomicAdd(&sh->node_visits, v64);
         if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
         if (blockIdx.x < 256u) atomicMax(&sh->pad[4], ~clk0);                  // (the earliest start is among the first workgroups dispatched)
-        atomicMax(&sh->pad[11], __builtin_amdgcn_s_memrealtime());
+        const unsigned long long clk1 = __builtin_amdgcn_s_memrealtime();
+        atomicMax(&sh->pad[11], clk1);
+        if (cost) { const unsigned long long cl = (clk1 - clk0) >> ORDER_SHIFT; cost[vblock] = cl < (unsigned long long)(ORDER_CLASSES - 1) ? (uint32_t)cl : (uint32_t)(ORDER_CLASSES - 1); }
     }
     if constexpr (DIAG) {
         const unsigned long long hi = wave_sum_u64(dg_hops_in), ho = wave_sum_u64(dg_hops_out), vi = wave_sum_u64(dg_vis);
@@ -838,11 +833,19 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
                                                          const double *__restrict__ verts, uint32_t vbase,
                                                          const Candidates *__restrict__ cand, unsigned long long shard_cap,
                                                          uint32_t *__restrict__ pairs, unsigned long long cap, TravState *__restrict__ st,
-                                                         uint32_t half /* candidates of a half traversal (k_descend_half): q and leaf are an unordered pair */)
+                                                         uint32_t half /* candidates of a half traversal (k_descend_half): q and leaf are an unordered pair */,
+                                                         uint32_t work_blocks /* the workgroups that work on candidates; behind them, after a half traversal, 8 that sort the times its waves
+                                                                                 have just left into the NEXT step's order hint (cd_bvh.h, build_half_order) -- beside this kernel's latency chain, for nothing */,
+                                                         uint32_t order_groups, const uint32_t *__restrict__ cost, uint32_t *__restrict__ order)
 {
+    // pair staging and SAT queue; the workgroups that build the order hint use the same bytes for their sort
+    constexpr size_t XL_BYTES = sizeof(uint2) * EXACT_PB + sizeof(SatItem) * EXACT_SQ;
+    static_assert(XL_BYTES >= sizeof(OrderLds<EXACT_THREADS>), "the order hint's sort fits the exact kernel's staging area");
+    __shared__ __align__(16) unsigned char xl[XL_BYTES];
+    if (blockIdx.x >= work_blocks) { build_half_order<EXACT_THREADS>(blockIdx.x - work_blocks, order_groups, cost, order, *reinterpret_cast<OrderLds<EXACT_THREADS> *>(xl)); return; }
+    uint2 *pbuf = reinterpret_cast<uint2 *>(xl);
+    SatItem *sq = reinterpret_cast<SatItem *>(xl + sizeof(uint2) * EXACT_PB);
     __shared__ unsigned long long pre[NSHARD + 1];      // exclusive prefix of the shard counts
-    __shared__ uint2 pbuf[EXACT_PB];
-    __shared__ SatItem sq[EXACT_SQ];
     __shared__ uint32_t pcount, sqcount;
     __shared__ unsigned long long pbase;
     __shared__ uint32_t wtested[EXACT_THREADS / 64];
@@ -893,13 +896,13 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
     // SAT batch each, instead of queueing four batches deep in a few workgroups; a million candidates still give every lane
     // EXACT_ITEMS independent loads.
     const unsigned long long nchunks = (total + EXACT_THREADS - 1) / EXACT_THREADS;
-    for (unsigned long long c0 = blockIdx.x; c0 < nchunks; c0 += (unsigned long long)gridDim.x * EXACT_ITEMS) {   // uniform trip count per workgroup
+    for (unsigned long long c0 = blockIdx.x; c0 < nchunks; c0 += (unsigned long long)work_blocks * EXACT_ITEMS) {   // uniform trip count per workgroup
         // stage 1 on EXACT_ITEMS candidates per lane at once: their loads are independent and in flight together
         // (the stage is a chain of two dependent round trips per candidate -- latency, not bandwidth)
         Candidates c[EXACT_ITEMS]; bool ok[EXACT_ITEMS];
 #pragma unroll
         for (int j = 0; j < EXACT_ITEMS; ++j) {
-            const unsigned long long k = (c0 + (unsigned long long)j * gridDim.x) * EXACT_THREADS + tid;
+            const unsigned long long k = (c0 + (unsigned long long)j * work_blocks) * EXACT_THREADS + tid;
             ok[j] = k < total;
             c[j] = Candidates{0, 0};
             if (ok[j]) {

@@ -107,6 +107,9 @@ struct cd_ctx {
     bool stage_events = true;               // CD_OPT_STAGE_TIMING
     bool leaves_filled = false;             // the sort's fix-up hop already wrote leaf[], parent = -1, bounded = 0
     bool events_ride = false;               // the last pass recorded EV_TRAV0 / EV_DESC1 / EV_TRAV1 through its kernels' dispatch packets
+    bool order_hint = true;                 // CD_OPT_ORDER_HINT: the half traversal takes its groups of 64 leaves longest-first, by the previous step's times (cd_bvh.h, build_half_order)
+    bool order_ready = false;               // d_order holds a permutation (the exact kernel behind an earlier half traversal has built it)
+    uint32_t *d_cost = nullptr, *d_order = nullptr;   // per group of 64 leaves: its wave's time class in the last half traversal; this step's order hint
     bool prezeroed = false;                 // fused path: the scratch block was zeroed by one memset at pipeline start
     hipEvent_t tree_done_event = nullptr;   // set by the multi-GPU step: taken (and cleared) by the launch that completes the tree, if it can carry it
     bool scratch_clean = false;             // ... or by the kernels of the previous fused step (ZeroPlan, cd_build.h): no memset at all
@@ -145,7 +148,7 @@ void free_all(cd_ctx *c)
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_top_pub); hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_seg32); hipFree(c->d_cross); hipFree(c->d_boxes);
-    hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox); hipFree(c->d_split_of);
+    hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox); hipFree(c->d_split_of); hipFree(c->d_cost); hipFree(c->d_order);
     hipFree(c->d_amb_keys); hipFree(c->d_amb_flag); hipFree(c->d_vamb);
     for (TravBuf &tb : c->tb) {
         if (tb.d_pairs) hipFree(reinterpret_cast<char *>(tb.d_pairs) - sizeof(Report));
@@ -518,10 +521,12 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         const bool plain = !e0 && !e1 && !e2;          // no time stamp rides on these launches: plain launches (a stream capture can record them)
         if (half_mode && !DEEP) {
             const dim3 hgrid(cdiv(items, 64u)), hblock(HALF_THREADS);
+            const uint32_t *h_order = (c->order_hint && c->order_ready) ? c->d_order : nullptr;      // (the order hint: cd_bvh.h, build_half_order)
+            uint32_t *h_cost = c->order_hint ? c->d_cost : nullptr;
 #define LAUNCH_HALF(DIAG, TIES)                                                                                                             \
-            do { if (plain) k_descend_half<DIAG, TIES><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap); \
+            do { if (plain) k_descend_half<DIAG, TIES><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, h_order, h_cost); \
                  else hipExtLaunchKernelGGL((k_descend_half<DIAG, TIES>), hgrid, hblock, (uint32_t)pad, s, e0, e1, 0u, src, n, (const NodeRec32 *)c->d_recs32, \
-                                            tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap); } while (0)
+                                            tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, h_order, h_cost); } while (0)
             const bool ties = c->amb.keys != nullptr || c->amb.mask != 0u;                      // (a graph capture bakes the instance in: amb_refresh drops the graph when the table comes or goes)
             if (c->dbg_diag) { if (ties) LAUNCH_HALF(true, true); else LAUNCH_HALF(true, false); }
             else { if (ties) LAUNCH_HALF(false, true); else LAUNCH_HALF(false, false); }
@@ -534,13 +539,18 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, true>), grid, dim3(DESC_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
         if (!DEEP && !ride && !c->quiet_pass) evrec(c, EV_DESC1);
+        // behind a half traversal of the context's own leaves the exact kernel also builds the NEXT step's order hint (8 more workgroups)
+        const bool build_order = half_mode && !DEEP && c->order_hint && n > 64 && &tb == &c->tb[0];
+        const uint32_t xblocks = (uint32_t)c->exact_blocks, xgrid = xblocks + (build_order ? 8u : 0u), ogroups = ((uint32_t)n + 63u) / 64u;
+        const uint32_t *o_cost = build_order ? c->d_cost : nullptr; uint32_t *o_order = build_order ? c->d_order : nullptr;
         if (plain)
-            k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, tb.d_cand, (unsigned long long)shard_cap, tb.d_pairs,
-                                                                        (unsigned long long)cap_pairs, tb.d_state, half);
+            k_exact<EXTERNAL><<<xgrid, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, tb.d_cand, (unsigned long long)shard_cap, tb.d_pairs,
+                                                              (unsigned long long)cap_pairs, tb.d_state, half, xblocks, ogroups, o_cost, o_order);
         else
-            hipExtLaunchKernelGGL((k_exact<EXTERNAL>), dim3(c->exact_blocks), dim3(EXACT_THREADS), 0u, s, nullptr, e2, 0u,
+            hipExtLaunchKernelGGL((k_exact<EXTERNAL>), dim3(xgrid), dim3(EXACT_THREADS), 0u, s, nullptr, e2, 0u,
                                   src, n, (const LeafTri *)c->d_leaf, (const double *)c->d_boxes, (const double *)c->d_verts, vb, (const Candidates *)tb.d_cand,
-                                  (unsigned long long)shard_cap, tb.d_pairs, (unsigned long long)cap_pairs, tb.d_state, half);
+                                  (unsigned long long)shard_cap, tb.d_pairs, (unsigned long long)cap_pairs, tb.d_state, half, xblocks, ogroups, o_cost, o_order);
+        if (build_order) c->order_ready = true;
         c->events_ride = ride;
     }
 }
@@ -854,7 +864,7 @@ int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs
     if (rc) return rc;
     uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
     const bool direct = pinned_pairs_id(pairs, cap_pairs) != 0;
-    const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1),
+    const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1) | (c->order_hint ? 4u : 0u),
                                tb.d_pairs, tb.d_cand, tb.d_defer, direct ? (const void *)pairs : (const void *)tb.h_report, tb.cand_cap, tb.defer_cap, 0u};
     static_assert(sizeof(cd_ctx::GraphKey) == 2 * 8 + 6 * 4 + 4 * 8 + 8 + 2 * 4, "GraphKey has no padding");
     if (!c->graph_exec || std::memcmp(&key, &c->graph_key, sizeof key) != 0) {
@@ -986,6 +996,9 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_recs32, sizeof(NodeRec32) * n);
     ALLOC(c->d_qbox, sizeof(LeafBox32) * n);
     ALLOC(c->d_split_of, sizeof(int32_t) * n);
+    { const size_t groups = ((size_t)n + 63) / 64;
+      ALLOC(c->d_cost, sizeof(uint32_t) * groups); ALLOC(c->d_order, sizeof(uint32_t) * groups);
+      if (hipMemset(c->d_cost, 0, sizeof(uint32_t) * groups) != hipSuccess) { free_all(c); delete c; return CD_ERR_ARG; } }   // (no times yet: the first hint is half_vblock's own order)
     c->tb[0].cand_cap = ((4 * n > (1u << 20) ? 4 * n : (1u << 20)) + NSHARD - 1) / NSHARD * NSHARD;
     ALLOC(c->tb[0].d_cand, sizeof(Candidates) * c->tb[0].cand_cap);
     c->tb[0].defer_cap = 1u << 16;
@@ -1461,6 +1474,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
         c->stage = ST_CREATED; c->root_box_valid = false;                  // the records of the tree that is there were encoded the other way
         return amb_refresh(c);
     }
+    if (key == CD_OPT_ORDER_HINT) { c->order_hint = value != 0; c->order_ready = false; graph_drop(c); return CD_OK; }       // (a captured step has its launches baked in)
     if (key == CD_OPT_KERNEL_STAMPS) { if (value < 0 || value > 15) return CD_ERR_ARG; c->stamp_mask = (uint32_t)value; return CD_OK; }
     return CD_ERR_ARG;
 }

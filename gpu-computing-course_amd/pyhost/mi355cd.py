@@ -19,6 +19,7 @@ CD_FRAME_REFERENCE, CD_FRAME_AUTO, CD_FRAME_CUSTOM = 0, 1, 2
 CD_ERR_SORT, CD_ERR_IO, CD_ERR_FORMAT = -1005, -1006, -1007
 CD_OPT_TRAVERSAL, CD_OPT_QUERIES_PER_WAVE, CD_OPT_SORT_FULL, CD_OPT_STAGE_TIMING, CD_OPT_KERNEL_STAMPS, CD_OPT_GRAPH, CD_OPT_POLL = 0, 1, 2, 3, 4, 5, 6
 CD_OPT_CELL_TABLE = 7
+CD_OPT_ORDER_HINT = 8
 # cd_debug_option keys (measurement hooks / test switches; not part of the mirrored interface)
 CD_DBG_LDS_PAD, CD_DBG_EXACT_BLOCKS, CD_DBG_NO_SHARED_PATH, CD_DBG_DIAG, CD_DBG_STAGEWISE_BUILD, CD_DBG_SPLIT_CROSS = 0, 1, 2, 3, 4, 5
 CD_DBG_POLL_SCAN, CD_DBG_GET_POLL_STALE, CD_DBG_GET_POLL_FALLBACKS, CD_DBG_GET_POLLED_STEPS, CD_DBG_GET_TREE_WAS_FUSED = 10, 11, 12, 13, 14

@@ -212,6 +212,10 @@ enum {
                                    /*    costs the upload ~0.4 ms per million vertices).  0: no table, every coordinate that is not an fp32 value is rounded outward    */
                                    /*    (a full-double structured mesh: ~2 x the step time, nothing added to the upload).  Vertices that are all fp32 values -- what   */
                                    /*    the reference's loader produces, load_obj.h:38 -- never have a table                                                            */
+    CD_OPT_ORDER_HINT       = 8,   /* 1 (default): the half traversal (CD_OPT_TRAVERSAL 3) of a fused call takes its groups of 64 leaves in the order of how long each took in the    */
+                                   /*    context's PREVIOUS traversal, longest first (per XCD; the kernel ends with its unluckiest wave slot, and a mesh moves little between two      */
+                                   /*    steps).  A scheduling hint: every group is traversed in every step, results do not depend on it; the first step, and steps after the mesh   */
+                                   /*    has changed beyond recognition, run in the plain order or a stale one.  0: always the plain order                                            */
     CD_OPT_QUERIES_PER_WAVE = 1    /* variant 1: queries one wave works through with dynamic lane refill (x64)         */
 };
 int cd_set_option(cd_ctx *ctx, int key, int64_t value);
