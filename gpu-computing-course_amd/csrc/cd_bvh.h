@@ -157,7 +157,10 @@ __device__ __forceinline__ Box leaf_box64(const double *__restrict__ boxes, cons
 // even over a mesh (where the surfaces meet, a query has candidates; elsewhere none) -- an XCD with a busy eighth was the kernel's tail.
 // 1 M cloth: 1 / 2 / 4 / 8 / 16 chunks -> 57.8 / 57.9 / 54.1 / 54.4 / 54.6 us.  Speed only: any bijection of [0, nb) gives the same results.
 constexpr int HALF_XSUB = 4;
-__device__ __forceinline__ uint32_t half_vblock(uint32_t b, uint32_t nb)
+__host__ __device__ __forceinline__ uint32_t half_vblock_hd(uint32_t b, uint32_t nb);
+__device__ __forceinline__ uint32_t half_vblock(uint32_t b, uint32_t nb) { return half_vblock_hd(b, nb); }
+inline uint32_t half_vblock_host(uint32_t b, uint32_t nb) { return half_vblock_hd(b, nb); }
+__host__ __device__ __forceinline__ uint32_t half_vblock_hd(uint32_t b, uint32_t nb)
 {
     const uint32_t per = nb >> 3;
     uint32_t v = (b < (per << 3)) ? (b & 7u) * per + (b >> 3) : b;

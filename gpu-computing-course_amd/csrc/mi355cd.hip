@@ -1497,6 +1497,24 @@ int cd_debug_option(cd_ctx *c, int key, int64_t value, int64_t *out)
     case CD_DBG_GET_POLL_FALLBACKS: if (!out) return CD_ERR_ARG; *out = c->poll_fallbacks; return CD_OK;
     case CD_DBG_GET_POLLED_STEPS:   if (!out) return CD_ERR_ARG; *out = c->polled_steps; return CD_OK;
     case CD_DBG_GET_TREE_WAS_FUSED: if (!out) return CD_ERR_ARG; *out = c->last_tree_fused ? 1 : 0; return CD_OK;
+    case CD_DBG_GET_ORDER_STATE: {          // the order hint as it stands: 0 none built, 1 a permutation of the groups that differs from the plain order, 2 the plain order itself, -1 NOT a permutation (a bug)
+        if (!out) return CD_ERR_ARG;
+        *out = 0;
+        if (!c->order_ready) return CD_OK;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const uint32_t groups = (c->nt + 63u) / 64u;
+        std::vector<uint32_t> o(groups), plain(groups);
+        HIPCHK(hipMemcpy(o.data(), c->d_order, sizeof(uint32_t) * groups, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> seen(groups, 0);
+        bool perm = true, same = true;
+        for (uint32_t b = 0; b < groups; ++b) {
+            if (o[b] >= groups || seen[o[b]]) { perm = false; break; }
+            seen[o[b]] = 1;
+            same = same && o[b] == half_vblock_host(b, groups);
+        }
+        *out = !perm ? -1 : (same ? 2 : 1);
+        return CD_OK;
+    }
     default: return CD_ERR_ARG;
     }
 }

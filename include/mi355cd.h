@@ -234,7 +234,9 @@ enum {
     CD_DBG_GET_POLL_STALE     = 11,  /* ... steps in which the scan found a pair missing (must stay 0)                                        */
     CD_DBG_GET_POLL_FALLBACKS = 12,  /* ... polled waits that ran into the 20 ms budget and ended in a stream synchronise                     */
     CD_DBG_GET_POLLED_STEPS   = 13,  /* ... reports whose end was read off the sequence word                                                  */
-    CD_DBG_GET_TREE_WAS_FUSED = 14   /* 1: the tree that is there was made by the one-pass build                                              */
+    CD_DBG_GET_TREE_WAS_FUSED = 14,  /* 1: the tree that is there was made by the one-pass build                                              */
+    CD_DBG_GET_ORDER_STATE    = 15   /* the order hint (CD_OPT_ORDER_HINT) as it stands: 0 none built yet; 1 a permutation of the groups of 64 leaves that differs from the plain order;    */
+                                     /* 2 the plain order itself; -1 not a permutation (must never be)                                                                                        */
 };
 int cd_debug_option(cd_ctx *ctx, int key, int64_t value, int64_t *out);
 

@@ -389,6 +389,57 @@ def test_steady_state_steps_clean_their_own_scratch():
         step(cd, ra)
 
 
+def test_order_hint_is_a_permutation_and_changes_nothing_but_the_order():
+    """CD_OPT_ORDER_HINT (default on): from the second fused step on the half traversal takes its groups of 64 leaves in the order of
+    the previous traversal's wave times, longest first per XCD.  The hint must be a permutation of the groups whatever the times were
+    measured on -- this mesh, the same mesh moved, a different mesh altogether (cd_update_vertices), a stage-wise traversal in between --
+    and pairs, pairs tested and every other counter must be what they are without it."""
+    va, ta = synth.cloth_pair(130)                                          # 67 600 triangles: 1 057 groups, lists of 132 / 133 groups per XCD
+    vb = va.copy(); vb[va.shape[0] // 2:, 0] += 0.4                        # sheet B shifted: the contact curves are elsewhere
+    vc = va.copy(); h = va.shape[0] // 2
+    vc[h:, 0] = 3.0 - va[h:, 0]; vc[h:, 1] = -0.2 - va[h:, 1]             # sheet B mirrored in x and y: where the sheets meet has nothing to do with before
+    ra, rb, rc_ = oracle.pipeline(va, ta), oracle.pipeline(vb, ta), oracle.pipeline(vc, ta)
+
+    def step(cd, r):
+        pairs, n, rc = cd.self_collide(cap=1 << 21)
+        st = cd.stats()
+        assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])) and st.pairs_tested == r["stats"].pairs_tested
+        return st
+
+    with mi355cd.CollisionDetector(va, ta) as cd:
+        assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 0            # nothing built before the first traversal
+        st1 = step(cd, ra)
+        assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in (1, 2)       # built behind the first traversal (from its times), used by the second
+        st2 = step(cd, ra); st3 = step(cd, ra)
+        assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 1            # the waves of a cloth pair do not all take the same time
+        assert st2.node_visits == st1.node_visits == st3.node_visits and st2.candidates == st1.candidates
+        cd.update_vertices(vb)                                              # a stale hint: times of the mesh before it moved
+        for _ in range(2): step(cd, rb); assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 1
+        cd.update_vertices(vc)                                              # times of a mesh whose contact curves lie elsewhere altogether
+        for _ in range(2): step(cd, rc_); assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in (1, 2)
+        cd.morton_sort(); cd.build_hierarchy(); cd.refit_boxes()            # the stage-wise API: its traversal takes the hint that is there and leaves the next
+        pairs, n, rc = cd.find_collisions(cap=1 << 21)
+        assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(rc_["pairs"])) and cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in (1, 2)
+        cd.update_vertices(va)
+        step(cd, ra)
+        cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 0)                         # off: the plain order, no hint kept
+        st_off = step(cd, ra)
+        assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 0
+        assert st_off.node_visits == st1.node_visits and st_off.candidates == st1.candidates
+        cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 1)
+        step(cd, ra); step(cd, ra)
+        assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 1
+        for variant in (1, 0, 3):                                           # other traversals neither read nor write it
+            cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant); step(cd, ra)
+    # a mesh of less than one group per XCD, and one group exactly
+    for nt in (64, 65, 500):
+        v, t = synth.soup(nt, 0.2, 9)
+        r = oracle.pipeline(v, t)
+        with mi355cd.CollisionDetector(v, t) as cd:
+            for _ in range(3): step(cd, r)
+            assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in ((0,) if nt <= 64 else (1, 2))
+
+
 def test_cd_main_harness_on_generated_obj(tmp_path):
     """BASELINE config 1, plumbing: the C++ harness (main.cu twin) on a generated OBJ in the reference's dialect."""
     text = synth.grids_obj_text(32)
