@@ -505,6 +505,27 @@ def main():
             line["roofline"]["other_kernels"] = cands[1:]
             line["roofline"]["whole_path"] = {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9,
                                               "frac": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": whole_traffic, "traffic_raw": whole_traffic_raw}
+            # The ORDER HINT (CD_OPT_ORDER_HINT, default on: the descent takes its groups of 64 leaves longest-first, by the previous step's wave times;
+            # include/mi355cd.h).  A bench steps ONE mesh K times, so the hint it measures with is as good as a hint gets; a simulation's mesh moves
+            # between steps and its hint is a step old.  What the step costs WITHOUT it is therefore measured too, right here, the same way:
+            engine.cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+            engine.cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 0)
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            off_steps, off_clock = min(k, 100), 0.0
+            for _ in range(off_steps):
+                step()
+                off_clock += engine.cd.fast_stats.ms_descend_clock
+            torch.cuda.synchronize()
+            off_ms = (time.perf_counter() - t1) * 1e3 / off_steps
+            engine.cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 1)
+            line["order_hint"] = {"default": "on", "what": "scheduling only: every group of 64 leaves is traversed in every step, in the order of the previous step's wave times "
+                                                           "(longest first, per XCD); pairs and counters do not depend on it (tests/test_cd_gpu.py)",
+                                  "ms_per_step_without": off_ms, "pairs_tested_per_s_without": (tested_total / k) / (off_ms * 1e-3),
+                                  "descend_device_clock_ms_without": off_clock / off_steps, "steps_without": off_steps,
+                                  "note": "the timed region steps one mesh K times: its hint is the best a hint can be (a moving mesh's is one step old)"}
             if not args.no_parity:
                 # checker leg: the LAST TIMED step's pair set + pairs-tested count against the oracle (one more CPU pass, with pairs)
                 pc = parity_check(last_pairs, last_tested, verts, vidx)

@@ -1029,6 +1029,8 @@ int cd_update_vertices(cd_ctx *c, const double *verts_xyz)
     if (!c || !verts_xyz) return CD_ERR_ARG;
     HIPCHK(hipStreamSynchronize(c->stream));                                // (nothing of an earlier call may still read the old vertices or the old cell table)
     HIPCHK(hipMemcpy(c->d_verts, verts_xyz, sizeof(double) * 3 * (size_t)c->nv, hipMemcpyHostToDevice));
+    c->order_ready = false;                 // the order hint is about the vertices it was measured on: a mesh that moved sorts differently, and a hint for other groups is
+                                            // worse than none (tools/hint_moving.py: +2 us with the sheets a quarter of a quad apart from where they were)
     c->stage = ST_CREATED;
     c->root_box_valid = false;
     return amb_refresh(c);
@@ -1037,6 +1039,7 @@ int cd_update_vertices(cd_ctx *c, const double *verts_xyz)
 int cd_set_morton_frame(cd_ctx *c, int mode, const double offset[3], const double span[3])
 {
     if (!c) return CD_ERR_ARG;
+    c->order_ready = false;                 // (another frame, another sorted order: the order hint's groups are not the next step's)
     if (mode == CD_FRAME_REFERENCE) {
         const double ref[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};
         memcpy(c->frame_host, ref, sizeof ref);
@@ -1336,6 +1339,17 @@ int cd_debug_counters(cd_ctx *c, unsigned long long out[12])
     std::vector<TravState> h(1);
     HIPCHK(hipMemcpy(h.data(), c->tb[0].d_state, sizeof(TravState), hipMemcpyDeviceToHost));
     for (int k = 0; k < 12; ++k) { out[k] = 0; for (int i = 0; i < NSHARD; ++i) out[k] += h[0].shard[i].pad[k]; }
+    return CD_OK;
+}
+
+/* Debug only: the order hint's two arrays, ceil(nt / 64) words each -- the time class every group's wave left in the last half traversal, and the order built from them. */
+int cd_debug_hint(cd_ctx *c, uint32_t *cost, uint32_t *order)
+{
+    if (!c) return CD_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const size_t groups = ((size_t)c->nt + 63) / 64;
+    if (cost) HIPCHK(hipMemcpy(cost, c->d_cost, sizeof(uint32_t) * groups, hipMemcpyDeviceToHost));
+    if (order) { if (!c->order_ready) return CD_ERR_ORDER; HIPCHK(hipMemcpy(order, c->d_order, sizeof(uint32_t) * groups, hipMemcpyDeviceToHost)); }
     return CD_OK;
 }
 

@@ -390,10 +390,10 @@ def test_steady_state_steps_clean_their_own_scratch():
 
 
 def test_order_hint_is_a_permutation_and_changes_nothing_but_the_order():
-    """CD_OPT_ORDER_HINT (default on): from the second fused step on the half traversal takes its groups of 64 leaves in the order of
-    the previous traversal's wave times, longest first per XCD.  The hint must be a permutation of the groups whatever the times were
-    measured on -- this mesh, the same mesh moved, a different mesh altogether (cd_update_vertices), a stage-wise traversal in between --
-    and pairs, pairs tested and every other counter must be what they are without it."""
+    """CD_OPT_ORDER_HINT (default on): a half traversal of the same vertices as the one before takes its groups of 64 leaves in the order
+    of that one's wave times, longest first per XCD.  The hint must be a permutation of the groups whatever the times were -- this mesh's,
+    a mesh with other contact curves, a stage-wise traversal in between --, cd_update_vertices must drop it (the next step builds a new
+    one), and pairs, pairs tested and every other counter must be what they are without it."""
     va, ta = synth.cloth_pair(130)                                          # 67 600 triangles: 1 057 groups, lists of 132 / 133 groups per XCD
     vb = va.copy(); vb[va.shape[0] // 2:, 0] += 0.4                        # sheet B shifted: the contact curves are elsewhere
     vc = va.copy(); h = va.shape[0] // 2
@@ -413,10 +413,14 @@ def test_order_hint_is_a_permutation_and_changes_nothing_but_the_order():
         st2 = step(cd, ra); st3 = step(cd, ra)
         assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 1            # the waves of a cloth pair do not all take the same time
         assert st2.node_visits == st1.node_visits == st3.node_visits and st2.candidates == st1.candidates
-        cd.update_vertices(vb)                                              # a stale hint: times of the mesh before it moved
+        cd.update_vertices(vb)                                              # the mesh moved: the hint is dropped, the next traversal leaves a new one
+        assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 0
         for _ in range(2): step(cd, rb); assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 1
-        cd.update_vertices(vc)                                              # times of a mesh whose contact curves lie elsewhere altogether
-        for _ in range(2): step(cd, rc_); assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in (1, 2)
+        cd.update_vertices(vc)                                              # a mesh whose contact curves lie elsewhere altogether
+        for _ in range(3): step(cd, rc_); assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in (1, 2)
+        cost, order = cd.debug_hint()
+        assert np.array_equal(np.sort(order), np.arange(order.shape[0], dtype=np.uint32)) and cost.max() < 32
+        assert np.all(np.diff(cost[order[0::8]].astype(np.int64)) <= 0)     # XCD 0's list: longest class first
         cd.morton_sort(); cd.build_hierarchy(); cd.refit_boxes()            # the stage-wise API: its traversal takes the hint that is there and leaves the next
         pairs, n, rc = cd.find_collisions(cap=1 << 21)
         assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(rc_["pairs"])) and cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in (1, 2)
