@@ -486,7 +486,7 @@ def main():
                         "l2_hit_rate": l2_of.get(symbol),
                         "algorithmic_bytes_per_launch": bytes_per_tri * nt, "avg_launch_ms": ms}
 
-            cands = [roof("k_descend_half", "k_descend_half (fp32 BVH descent, half traversal; its candidates go to k_exact)", kern["descend"], TRAVERSAL_BYTES_PER_TRI),
+            cands = [roof("k_descend_half", "k_descend_half (fp32 BVH descent, half traversal, groups of 64 leaves in the order hint's order; its candidates go to k_exact)", kern["descend"], TRAVERSAL_BYTES_PER_TRI),
                      roof("k_build_block", "k_build_block (Karras hierarchy + AABB refit + traversal records of the 512-leaf blocks, fused)",
                           kern["build_block"], BUILD_BYTES_PER_TRI)]
             cands.sort(key=lambda r: -r["avg_launch_ms"])
@@ -508,24 +508,27 @@ def main():
             # The ORDER HINT (CD_OPT_ORDER_HINT, default on: the descent takes its groups of 64 leaves longest-first, by the previous step's wave times;
             # include/mi355cd.h).  A bench steps ONE mesh K times, so the hint it measures with is as good as a hint gets; a simulation's mesh moves
             # between steps and its hint is a step old.  What the step costs WITHOUT it is therefore measured too, right here, the same way:
+            # (with --no-extras this leg is skipped too: the committed kernel trace is of `bench.py --no-extras` and holds the headline's launches only)
             engine.cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
-            engine.cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 0)
-            for _ in range(10):
-                step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            off_steps, off_clock = min(k, 100), 0.0
-            for _ in range(off_steps):
-                step()
-                off_clock += engine.cd.fast_stats.ms_descend_clock
-            torch.cuda.synchronize()
-            off_ms = (time.perf_counter() - t1) * 1e3 / off_steps
-            engine.cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 1)
-            line["order_hint"] = {"default": "on", "what": "scheduling only: every group of 64 leaves is traversed in every step, in the order of the previous step's wave times "
-                                                           "(longest first, per XCD); pairs and counters do not depend on it (tests/test_cd_gpu.py)",
-                                  "ms_per_step_without": off_ms, "pairs_tested_per_s_without": (tested_total / k) / (off_ms * 1e-3),
-                                  "descend_device_clock_ms_without": off_clock / off_steps, "steps_without": off_steps,
-                                  "note": "the timed region steps one mesh K times: its hint is the best a hint can be (a moving mesh's is one step old)"}
+            line["order_hint"] = {"default": "on", "what": "scheduling only: every group of 64 leaves is traversed in every step; a step on the SAME vertices as the one before takes the groups "
+                                                           "in the order of that step's wave times (longest first, per XCD); pairs and counters do not depend on it (tests/test_cd_gpu.py); "
+                                                           "cd_update_vertices drops the hint: a mesh that moves between steps runs as `without`",
+                                  "note": "the timed region steps one mesh K times, which is what the hint serves; what the same step costs without it is measured beside it"}
+            if not args.no_extras:
+                engine.cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 0)
+                for _ in range(10):
+                    step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                off_steps, off_clock = min(k, 100), 0.0
+                for _ in range(off_steps):
+                    step()
+                    off_clock += engine.cd.fast_stats.ms_descend_clock
+                torch.cuda.synchronize()
+                off_ms = (time.perf_counter() - t1) * 1e3 / off_steps
+                engine.cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 1)
+                line["order_hint"].update({"ms_per_step_without": off_ms, "pairs_tested_per_s_without": (tested_total / k) / (off_ms * 1e-3),
+                                           "descend_device_clock_ms_without": off_clock / off_steps, "steps_without": off_steps})
             if not args.no_parity:
                 # checker leg: the LAST TIMED step's pair set + pairs-tested count against the oracle (one more CPU pass, with pairs)
                 pc = parity_check(last_pairs, last_tested, verts, vidx)
