@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--no-ray", action="store_true", help="skip the secondary ray-tracer measurement (BASELINE config 5)")
     ap.add_argument("--traversal", type=int, default=None, help="CD_OPT_TRAVERSAL override (0 lane-private FP64, 1 wave-queued)")
     ap.add_argument("--qpw", type=int, default=None, help="CD_OPT_QUERIES_PER_WAVE override")
+    ap.add_argument("--no-order-hint", action="store_true", help="CD_OPT_ORDER_HINT 0 for the whole run: the timed region steps in the plain order (what a mesh that moves between "
+                                                                  "steps gets); by default the line carries that measurement beside the headline (order_hint.ms_per_step_without)")
     args = ap.parse_args()
 
     import torch
@@ -324,6 +326,8 @@ def main():
         engine.cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, off, span)
     if args.traversal is not None:
         engine.cd.set_option(mi355cd.CD_OPT_TRAVERSAL, args.traversal)
+    if args.no_order_hint:
+        engine.cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 0)
     if args.qpw is not None:
         engine.cd.set_option(mi355cd.CD_OPT_QUERIES_PER_WAVE, args.qpw)
     cap = 1 << 22
@@ -514,7 +518,9 @@ def main():
                                                            "in the order of that step's wave times (longest first, per XCD); pairs and counters do not depend on it (tests/test_cd_gpu.py); "
                                                            "cd_update_vertices drops the hint: a mesh that moves between steps runs as `without`",
                                   "note": "the timed region steps one mesh K times, which is what the hint serves; what the same step costs without it is measured beside it"}
-            if not args.no_extras:
+            if args.no_order_hint:
+                line["order_hint"]["default"] = "on; OFF in this run (--no-order-hint)"
+            elif not args.no_extras:
                 engine.cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 0)
                 for _ in range(10):
                     step()
