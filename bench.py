@@ -509,15 +509,16 @@ def main():
             line["roofline"]["other_kernels"] = cands[1:]
             line["roofline"]["whole_path"] = {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9,
                                               "frac": TOTAL_BYTES_PER_TRI * nt / (dev_total * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": whole_traffic, "traffic_raw": whole_traffic_raw}
-            # The ORDER HINT (CD_OPT_ORDER_HINT, default on: the descent takes its groups of 64 leaves longest-first, by the previous step's wave times;
-            # include/mi355cd.h).  A bench steps ONE mesh K times, so the hint it measures with is as good as a hint gets; a simulation's mesh moves
-            # between steps and its hint is a step old.  What the step costs WITHOUT it is therefore measured too, right here, the same way:
+            # The ORDER HINT (CD_OPT_ORDER_HINT, default on: the descent takes its groups of 64 leaves longest-first, by the previous step's wave times, which are
+            # remembered per triangle; include/mi355cd.h).  A bench steps ONE mesh K times, so the hint it measures with is as good as a hint gets (-7 us); a mesh that
+            # moves between steps keeps about two thirds of that (tools/hint_moving.py: sheets a quad apart per frame, -4 us).  What the step costs WITHOUT it is
+            # measured too, right here, the same way:
             # (with --no-extras this leg is skipped too: the committed kernel trace is of `bench.py --no-extras` and holds the headline's launches only)
             engine.cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
-            line["order_hint"] = {"default": "on", "what": "scheduling only: every group of 64 leaves is traversed in every step; a step on the SAME vertices as the one before takes the groups "
-                                                           "in the order of that step's wave times (longest first, per XCD); pairs and counters do not depend on it (tests/test_cd_gpu.py); "
-                                                           "cd_update_vertices drops the hint: a mesh that moves between steps runs as `without`",
-                                  "note": "the timed region steps one mesh K times, which is what the hint serves; what the same step costs without it is measured beside it"}
+            line["order_hint"] = {"default": "on", "what": "scheduling only: every group of 64 leaves is traversed in every step, in the order of the previous step's wave times (longest first, per "
+                                                           "XCD); the times are remembered per triangle, so the hint follows a mesh that moves; pairs and counters do not depend on it (tests/test_cd_gpu.py)",
+                                  "note": "the timed region steps one mesh K times: its hint is the best a hint can be (-7 us; a mesh moving a quad per frame: -4 us, tools/hint_moving.py); "
+                                          "what the same step costs without it is measured beside it"}
             if args.no_order_hint:
                 line["order_hint"]["default"] = "on; OFF in this run (--no-order-hint)"
             elif not args.no_extras:

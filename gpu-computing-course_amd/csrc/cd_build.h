@@ -136,7 +136,10 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
                                                            int32_t *__restrict__ cross_list, uint32_t *__restrict__ cross_count, uint32_t cross_cap, ZeroPlan zp,
                                                            int seg_min /* lowest level of the block's tree that goes to seg32: SEG32_MIN_LEVEL for the trees k_cross_fused takes,
                                                                           SEG_MIN_LEVEL beyond (there the kernel is bound by its writes, and levels 1 and 2 are 18 bytes a leaf) */,
-                                                           AmbTable amb, const uint8_t *__restrict__ vamb)
+                                                           AmbTable amb, const uint8_t *__restrict__ vamb,
+                                                           const uint32_t *__restrict__ hint_perm, const uint8_t *__restrict__ hint_tri, uint32_t *__restrict__ hint_cost /* all NULL, or the
+                                                                          half traversal's order hint (cd_bvh.h): sorted position -> triangle, the time class the last traversal left with
+                                                                          every triangle; out: per group of 64 leaves -- one wave of this kernel -- the max over its leaves */)
 {
     {
         const uint32_t G = gridDim.x * REFIT_BLK;
@@ -222,6 +225,12 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
         if (m32.hy == tot.hy) atomicMax(&acc[3], f64_ordered(mine.y2));
         if (m32.lz == tot.lz) atomicMin(&acc[4], f64_ordered(mine.z1));
         if (m32.hz == tot.hz) atomicMax(&acc[5], f64_ordered(mine.z2));
+    }
+    if (hint_cost) {                                                       // (uniform) the group's score for the order hint: asked for here, the answer is not needed by anything below
+        uint32_t c = j < n ? (uint32_t)hint_tri[hint_perm[j]] : 0u;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { const uint32_t u = (uint32_t)__shfl_xor((int)c, o); c = u > c ? u : c; }
+        if ((tid & 63) == 0 && j < n) hint_cost[j >> 6] = c;
     }
     const int i = j;                                                       // internal node with the same index
     int first = 0, last = 0, split = 0; bool have = false, cross = false;
@@ -493,20 +502,25 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
                                                      int nbp2, int nblocks, const LeafBox32 *__restrict__ qbox32, double *__restrict__ boxes,
                                                      NodeRec32 *__restrict__ recs32, const int32_t *__restrict__ split_of, int32_t *__restrict__ root_name,
                                                      const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap,
-                                                     unsigned long long *top_pub /* [3 * nbp2 / 4] the upper levels, published by workgroup 0 */, uint32_t *top_flag, uint32_t top_seq)
+                                                     unsigned long long *top_pub /* [3 * nbp2 / 4] the upper levels, published by workgroup 0 */, uint32_t *top_flag, uint32_t top_seq,
+                                                     uint32_t nord /* 0, or 8: the FIRST workgroups of the grid sort the groups' scores (k_build_block) into the half traversal's order hint,
+                                                                      one XCD list each (cd_bvh.h, build_half_order) -- beside this kernel's latency chain, in the dynamic LDS */,
+                                                     uint32_t order_groups, const uint32_t *__restrict__ hint_cost, uint32_t *__restrict__ hint_order)
 {
     extern __shared__ float top[];                                          // workgroup 0 only: [max(nbp2 / 4, 1)][6], heap nodes [1, nbp2 / 4)
+    if (blockIdx.x < nord) { build_half_order<256>(blockIdx.x, order_groups, hint_cost, hint_order, *reinterpret_cast<OrderLds<256> *>(top)); return; }
+    const uint32_t bid = blockIdx.x - nord, nbid = gridDim.x - nord;       // (the roles below count without them)
     const int tid = threadIdx.x, lane = tid & 63, g = lane / XG, gl = lane % XG;
     // (a workgroup of its own, the last one of the grid: the fold is a chain of dependent loads, short against what the
     //  others do, long when it comes on top of it)
-    if (blockIdx.x == gridDim.x - 1) { root_box_fold(seg, nbp2, nblocks, boxes); return; }   // (workgroup-uniform)
+    if (bid == nbid - 1) { root_box_fold(seg, nbp2, nblocks, boxes); return; }   // (workgroup-uniform)
     // The levels from three above the blocks upwards (a node of 8, 16, ... blocks), which only the few nodes with ranges of 4096 leaves or
     // more ask for: ONE workgroup -- the first of the grid, so it is resident before anybody can wait for it, and it waits for nobody --
     // folds them (top32_to_lds) and PUBLISHES them: agent-scope stores (the 8 L2s are not coherent inside a kernel), a wait for those
     // stores, then the launch's sequence number into the flag word.  A lane that needs such a piece (below) polls the flag -- by then the
     // searches have taken longer than the fold -- and reads the node with agent-scope loads.  Round 2 and the first half of round 3 had
     // EVERY workgroup fold its own copy into LDS in front of its searches: 4.2 of the kernel's 24 us (and 48 KB of L2 reads a workgroup).
-    if (blockIdx.x == 0) {
+    if (bid == 0) {
         top32_to_lds(top, seg32, nbp2, nblocks);
         const int nn = nbp2 >> 2;                                           // heap nodes [1, nn)
         for (int k = 1 + tid; k < nn; k += 256) {
@@ -522,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
     constexpr int PER_WAVE = 64 / XG, PER_BLOCK = 256 / XG;
     const uint32_t total = min(*dense_total, dense_cap);
     const long long P = (long long)nbp2 * REFIT_BLK;
-    for (uint32_t wbase = (blockIdx.x - 1) * PER_BLOCK + (tid >> 6) * PER_WAVE; wbase < total; wbase += (gridDim.x - 2) * PER_BLOCK) {   // (wbase is wave-uniform; workgroups 1 .. gridDim.x - 2 search)
+    for (uint32_t wbase = (bid - 1) * PER_BLOCK + (tid >> 6) * PER_WAVE; wbase < total; wbase += (nbid - 2) * PER_BLOCK) {   // (wbase is wave-uniform; workgroups 1 .. nbid - 2 search)
         // ---- range and split, as k_cross_meta
         const uint32_t kq = wbase + g;
         const bool live = kq < total;

@@ -173,15 +173,20 @@ __host__ __device__ __forceinline__ uint32_t half_vblock_hd(uint32_t b, uint32_t
 }
 // The ORDER HINT.  The half traversal's kernel ends with its unluckiest wave slot: 1.9 rounds of waves that take 13 .. 40 us each, dispatched in index order
 // (profiles/r03_experiments/descent_ablation.log: dispatch order 51.8 us, the same waves longest-first 40.5).  Nothing known inside a step predicts a long
-// wave -- but the previous step does: a mesh moves little between two steps, the groups of leaves where surfaces meet stay where they were.  Every wave leaves
-// how long it took (a class of 1.28 us, ORDER_CLASSES of them) in cost[its group]; the NEXT step's build sorts, per XCD, the groups that XCD works on by that
-// class, longest first (stable: equal classes keep half_vblock's order), into order[]: workgroup b then takes group order[b].  Which groups an XCD works on
-// does not change, so its L2 sees what it saw.  A hint only: cost[] may hold anything (zeros in the first step, another mesh's times after
-// cd_update_vertices) -- order[] is a permutation whatever it holds, and any permutation gives the same results.
-// One workgroup of T threads per XCD list (x = 0 .. 7), in LDS the caller lends it (ORDER_LDS_BYTES<T>); lists of more than ORDER_MAX_ITEMS groups
-// (4 M triangles) are left in half_vblock's order.  A stable counting sort in four barriers: the classes of the list into LDS (one gather), a count per
-// thread and class over the thread's run of consecutive items, a scan down each class's column, the items placed run by run.
-constexpr int ORDER_CLASSES = 32, ORDER_SHIFT = 7 /* 2^7 ticks of the 100 MHz wall clock */, ORDER_MAX_ITEMS = 8192;
+// wave -- but the previous step does, if its times are carried over BY TRIANGLE: a mesh that moves a quarter of a quad sorts into other groups of 64 (positions
+// shift along the whole Morton order: times remembered by position are a random order, which is worse than the index order), while the triangles near a contact
+// curve are still near it.  Every wave leaves its duration (a class of 1.28 us, ORDER_CLASSES of them) with each of its 64 TRIANGLES (tri_cost[original index], a
+// byte); the next step's k_build_block, whose wave w of block b holds exactly the leaves of one group, takes the MAX of its leaves' bytes as the group's score
+// (cost[group]); 8 workgroups of k_cross_fused then sort, per XCD, the groups that XCD works on by score, longest first (stable: equal scores keep half_vblock's
+// order), into order[]: the descent's workgroup b takes group order[b].  Which groups an XCD works on does not change, so its L2 sees what it saw.
+// A hint only: tri_cost[] may hold anything (zeros in the first step) -- order[] is a permutation whatever it holds, and any permutation gives the same results.
+// tools/hint_predictors.py (orders installed from outside): sheet B moving 0.25 / 1 / 4 quads a frame, descent 53.5 us in the index order, 47.5 with the frame's
+// OWN times (a perfect predictor), 55 by position, 49.8 / 48.7 / 53.8 by triangle with the max (51 / 51 / 54 with the mean).
+// One workgroup of T threads per XCD list (x = 0 .. 7), in LDS the caller lends it (OrderLds<T>); lists of more than ORDER_MAX_ITEMS groups are left in
+// half_vblock's order (the host does not ask for a hint then: k_cross_fused serves trees of up to 2048 blocks = 1 M leaves = 2048 groups a list).  A stable counting
+// sort in five barriers: the scores of the list into LDS (one gather), a count per thread and class over the thread's run of consecutive items, a scan down each
+// class's column, the items placed run by run.
+constexpr int ORDER_CLASSES = 32, ORDER_SHIFT = 7 /* 2^7 ticks of the 100 MHz wall clock */, ORDER_MAX_ITEMS = 2048;
 template <int T> struct OrderLds { uint8_t cls[ORDER_MAX_ITEMS]; uint16_t cnt[T][ORDER_CLASSES]; uint32_t base[ORDER_CLASSES]; };
 template <int T>
 __device__ __forceinline__ void build_half_order(uint32_t x, uint32_t nb, const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, OrderLds<T> &L)

@@ -568,7 +568,8 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
                                                                   Candidates *__restrict__ cand, unsigned long long shard_cap,
                                                                   uint2 *__restrict__ defer_list, uint32_t defer_cap,
                                                                   const uint32_t *__restrict__ order /* NULL, or the order hint: workgroup -> group of 64 leaves */,
-                                                                  uint32_t *__restrict__ cost /* NULL, or per group of 64 leaves: how long its wave took (for the next step's hint) */)
+                                                                  const uint32_t *__restrict__ perm, uint8_t *__restrict__ tri_cost /* both NULL, or: sorted position -> triangle, and per TRIANGLE
+                                                                                   how long its wave took, a class of 1.28 us (the next step's hint is made from these: cd_bvh.h) */)
 {
     const uint32_t bad_sort = sort_flags_or(src);      // looked at after phase 0 (whose loads are in bounds whatever the tree is): see sort_flags_or
     // The kernel times ITSELF with the device's constant-rate wall clock (s_memrealtime): first wave start -> last wave end, two
@@ -594,6 +595,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     const uint32_t g_last = (g0 + 63u < last_leaf) ? g0 + 63u : last_leaf;
     uint32_t qi = g0 + lane;
     const bool valid = qi < nq && n > 1;
+    const uint32_t my_tri = (tri_cost && qi < nq) ? perm[qi] : 0u;           // (asked for now, used at the very end: no wait of its own)
     unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0, tm4 = 0;           // DIAG: s_memtime stamps at the phase boundaries
     if constexpr (DIAG) tm0 = __builtin_amdgcn_s_memtime();
     uint32_t qcount = 0;                                // wave-uniform: candidates waiting in the queue
@@ -799,9 +801,11 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         if (v64) atomicAdd(&sh->node_visits, v64);
         if (steps) atomicAdd(&sh->wave_steps, (unsigned long long)steps);
         if (blockIdx.x < 256u) atomicMax(&sh->pad[4], ~clk0);                  // (the earliest start is among the first workgroups dispatched)
-        const unsigned long long clk1 = __builtin_amdgcn_s_memrealtime();
-        atomicMax(&sh->pad[11], clk1);
-        if (cost) { const unsigned long long cl = (clk1 - clk0) >> ORDER_SHIFT; cost[vblock] = cl < (unsigned long long)(ORDER_CLASSES - 1) ? (uint32_t)cl : (uint32_t)(ORDER_CLASSES - 1); }
+        atomicMax(&sh->pad[11], __builtin_amdgcn_s_memrealtime());
+    }
+    if (tri_cost) {                                                          // (wave-uniform) the wave's time goes with each of its triangles
+        const unsigned long long cl = (__builtin_amdgcn_s_memrealtime() - clk0) >> ORDER_SHIFT;
+        if (g0 + lane < nq) tri_cost[my_tri] = (uint8_t)(cl < (unsigned long long)(ORDER_CLASSES - 1) ? cl : (unsigned long long)(ORDER_CLASSES - 1));
     }
     if constexpr (DIAG) {
         const unsigned long long hi = wave_sum_u64(dg_hops_in), ho = wave_sum_u64(dg_hops_out), vi = wave_sum_u64(dg_vis);
@@ -833,18 +837,10 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
                                                          const double *__restrict__ verts, uint32_t vbase,
                                                          const Candidates *__restrict__ cand, unsigned long long shard_cap,
                                                          uint32_t *__restrict__ pairs, unsigned long long cap, TravState *__restrict__ st,
-                                                         uint32_t half /* candidates of a half traversal (k_descend_half): q and leaf are an unordered pair */,
-                                                         uint32_t work_blocks /* the workgroups that work on candidates; behind them, after a half traversal, 8 that sort the times its waves
-                                                                                 have just left into the NEXT step's order hint (cd_bvh.h, build_half_order) -- beside this kernel's latency chain, for nothing */,
-                                                         uint32_t order_groups, const uint32_t *__restrict__ cost, uint32_t *__restrict__ order)
+                                                         uint32_t half /* candidates of a half traversal (k_descend_half): q and leaf are an unordered pair */)
 {
-    // pair staging and SAT queue; the workgroups that build the order hint use the same bytes for their sort
-    constexpr size_t XL_BYTES = sizeof(uint2) * EXACT_PB + sizeof(SatItem) * EXACT_SQ;
-    static_assert(XL_BYTES >= sizeof(OrderLds<EXACT_THREADS>), "the order hint's sort fits the exact kernel's staging area");
-    __shared__ __align__(16) unsigned char xl[XL_BYTES];
-    if (blockIdx.x >= work_blocks) { build_half_order<EXACT_THREADS>(blockIdx.x - work_blocks, order_groups, cost, order, *reinterpret_cast<OrderLds<EXACT_THREADS> *>(xl)); return; }
-    uint2 *pbuf = reinterpret_cast<uint2 *>(xl);
-    SatItem *sq = reinterpret_cast<SatItem *>(xl + sizeof(uint2) * EXACT_PB);
+    __shared__ uint2 pbuf[EXACT_PB];
+    __shared__ SatItem sq[EXACT_SQ];
     __shared__ unsigned long long pre[NSHARD + 1];      // exclusive prefix of the shard counts
     __shared__ uint32_t pcount, sqcount;
     __shared__ unsigned long long pbase;
@@ -896,13 +892,13 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
     // SAT batch each, instead of queueing four batches deep in a few workgroups; a million candidates still give every lane
     // EXACT_ITEMS independent loads.
     const unsigned long long nchunks = (total + EXACT_THREADS - 1) / EXACT_THREADS;
-    for (unsigned long long c0 = blockIdx.x; c0 < nchunks; c0 += (unsigned long long)work_blocks * EXACT_ITEMS) {   // uniform trip count per workgroup
+    for (unsigned long long c0 = blockIdx.x; c0 < nchunks; c0 += (unsigned long long)gridDim.x * EXACT_ITEMS) {   // uniform trip count per workgroup
         // stage 1 on EXACT_ITEMS candidates per lane at once: their loads are independent and in flight together
         // (the stage is a chain of two dependent round trips per candidate -- latency, not bandwidth)
         Candidates c[EXACT_ITEMS]; bool ok[EXACT_ITEMS];
 #pragma unroll
         for (int j = 0; j < EXACT_ITEMS; ++j) {
-            const unsigned long long k = (c0 + (unsigned long long)j * work_blocks) * EXACT_THREADS + tid;
+            const unsigned long long k = (c0 + (unsigned long long)j * gridDim.x) * EXACT_THREADS + tid;
             ok[j] = k < total;
             c[j] = Candidates{0, 0};
             if (ok[j]) {

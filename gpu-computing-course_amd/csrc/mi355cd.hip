@@ -108,8 +108,10 @@ struct cd_ctx {
     bool leaves_filled = false;             // the sort's fix-up hop already wrote leaf[], parent = -1, bounded = 0
     bool events_ride = false;               // the last pass recorded EV_TRAV0 / EV_DESC1 / EV_TRAV1 through its kernels' dispatch packets
     bool order_hint = true;                 // CD_OPT_ORDER_HINT: the half traversal takes its groups of 64 leaves longest-first, by the previous step's times (cd_bvh.h, build_half_order)
-    bool order_ready = false;               // d_order holds a permutation (the exact kernel behind an earlier half traversal has built it)
-    uint32_t *d_cost = nullptr, *d_order = nullptr;   // per group of 64 leaves: its wave's time class in the last half traversal; this step's order hint
+    bool order_ready = false;               // d_order holds THIS tree's order hint (its fused build has made it)
+    uint32_t *d_cost = nullptr, *d_order = nullptr;   // per group of 64 leaves: the score k_build_block gives it (max of its triangles' time classes); the order made from the scores
+    bool order_pending = false;             // k_build_block has scored the groups: the k_cross_fused behind it sorts them
+    uint8_t *d_tri_cost = nullptr;          // per triangle (original index): the time class its wave left in the last half traversal
     bool prezeroed = false;                 // fused path: the scratch block was zeroed by one memset at pipeline start
     hipEvent_t tree_done_event = nullptr;   // set by the multi-GPU step: taken (and cleared) by the launch that completes the tree, if it can carry it
     bool scratch_clean = false;             // ... or by the kernels of the previous fused step (ZeroPlan, cd_build.h): no memset at all
@@ -148,7 +150,7 @@ void free_all(cd_ctx *c)
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_top_pub); hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_seg32); hipFree(c->d_cross); hipFree(c->d_boxes);
-    hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox); hipFree(c->d_split_of); hipFree(c->d_cost); hipFree(c->d_order);
+    hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox); hipFree(c->d_split_of); hipFree(c->d_cost); hipFree(c->d_order); hipFree(c->d_tri_cost);
     hipFree(c->d_amb_keys); hipFree(c->d_amb_flag); hipFree(c->d_vamb);
     for (TravBuf &tb : c->tb) {
         if (tb.d_pairs) hipFree(reinterpret_cast<char *>(tb.d_pairs) - sizeof(Report));
@@ -307,6 +309,7 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
 {
     const uint32_t n = c->nt;
     hipStream_t s = c->stream;
+    c->order_ready = false;                                                 // (the order hint belongs to a sorted order: this sort's fused build makes the next)
     HIPCHK(evrec(c, EV_MORTON0));
     // auto frame: per-block centroid bounds here (frame_ready: they are still there from this step's first sort); k_morton
     // folds them into the frame itself
@@ -409,14 +412,19 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
                           reinterpret_cast<uint32_t *>(c->tb[0].d_state), (uint32_t)(sizeof(TravState) / sizeof(uint32_t)), top_flag_of(c)};
         }
         const int seg_min = (c->nbp2 > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK && !c->dbg_split_cross) ? SEG32_MIN_LEVEL : SEG_MIN_LEVEL;
+        // the half traversal's order hint (cd_bvh.h): this kernel scores the groups of 64 leaves, 8 workgroups of k_cross_fused sort them -- for trees that kernel serves
+        const bool hint = c->order_hint && c->trav_variant >= 3 && n > 64u && c->nbp2 > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK && !c->dbg_split_cross;
+        const uint32_t *hp = hint ? c->d_perm[0] : nullptr; const uint8_t *ht = hint ? c->d_tri_cost : nullptr; uint32_t *hc = hint ? c->d_cost : nullptr;
         if (stamp)
             hipExtLaunchKernelGGL(k_build_block, dim3(nblocks), dim3(REFIT_BLK), 0u, s, c->ev[EV_BLK0], c->ev[EV_BLK1], 0u,
                                   (const double *)c->d_verts, (const LeafTri *)c->d_leaf, (int)n, (const uint64_t *)c->d_keys[0], c->d_split_of,
                                   c->d_boxes, c->d_recs32, c->d_qbox, c->d_root, c->d_seg, c->d_seg32, (int)c->nbp2,
-                                  cross_list, cross_count, c->cross_cap, zp, seg_min, c->amb, (const uint8_t *)c->vamb);
+                                  cross_list, cross_count, c->cross_cap, zp, seg_min, c->amb, (const uint8_t *)c->vamb, hp, ht, hc);
         else                                        // (no time stamps: a plain launch, which a stream capture can record -- graph_step)
             k_build_block<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_keys[0], c->d_split_of, c->d_boxes, c->d_recs32, c->d_qbox, c->d_root,
-                                                        c->d_seg, c->d_seg32, (int)c->nbp2, cross_list, cross_count, c->cross_cap, zp, seg_min, c->amb, (const uint8_t *)c->vamb);
+                                                        c->d_seg, c->d_seg32, (int)c->nbp2, cross_list, cross_count, c->cross_cap, zp, seg_min, c->amb, (const uint8_t *)c->vamb,
+                                                        hp, ht, hc);
+        c->order_pending = hint;
         c->scratch_clean = self_cleaning;       // (judge_sort_flags takes it back when the sort has raised a flag)
     } else
         k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded,
@@ -428,17 +436,22 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         // (the multi-GPU step's "tree is there" event rides on this kernel's dispatch packet: recorded on its own it is a barrier
         //  packet between the tree and the traversal, ~6 us of idle GPU)
         hipEvent_t done = c->tree_done_event; c->tree_done_event = nullptr;
-        const uint32_t xlds = (uint32_t)(sizeof(float) * 6 * (c->nbp2 >= 4 ? c->nbp2 / 4 : 1));       // (used by the publishing workgroup only)
+        const uint32_t nord = c->order_pending ? 8u : 0u, ogroups = (n + 63u) / 64u;
+        c->order_pending = false;
+        const uint32_t xlds = std::max((uint32_t)(sizeof(float) * 6 * (c->nbp2 >= 4 ? c->nbp2 / 4 : 1)) /* (used by the publishing workgroup only) */,
+                                       nord ? (uint32_t)sizeof(OrderLds<256>) : 0u /* (the order hint's 8 workgroups) */);
         uint32_t *top_flag = top_flag_of(c);
         if (++c->top_seq == 0u) ++c->top_seq;                               // (never 0: what k_build_block leaves in the flag word)
         if (done)
-            hipExtLaunchKernelGGL(k_cross_fused, dim3(xb + 2u /* the first workgroup publishes the upper levels, the last folds the FP64 box of all leaves */), dim3(256), xlds, s, nullptr, done, 0u,
+            hipExtLaunchKernelGGL(k_cross_fused, dim3(nord + xb + 2u /* [the order hint's 8,] then: the first workgroup publishes the upper levels, the last folds the FP64 box of all leaves */), dim3(256), xlds, s, nullptr, done, 0u,
                                   (const uint64_t *)c->d_keys[0], (int)n, (const double *)c->d_seg, (const float *)c->d_seg32, (int)c->nbp2, nblocks, (const LeafBox32 *)c->d_qbox, c->d_boxes,
                                   c->d_recs32, (const int32_t *)c->d_split_of, c->d_root, (const int32_t *)c->d_cross, (const uint32_t *)cross_count, c->cross_cap,
-                                  c->d_top_pub, top_flag, c->top_seq);
+                                  c->d_top_pub, top_flag, c->top_seq, nord, ogroups, (const uint32_t *)c->d_cost, c->d_order);
         else
-            k_cross_fused<<<xb + 2u, 256, xlds, s>>>(c->d_keys[0], (int)n, c->d_seg, c->d_seg32, (int)c->nbp2, nblocks, c->d_qbox, c->d_boxes,
-                                                     c->d_recs32, c->d_split_of, c->d_root, c->d_cross, cross_count, c->cross_cap, c->d_top_pub, top_flag, c->top_seq);
+            k_cross_fused<<<nord + xb + 2u, 256, xlds, s>>>(c->d_keys[0], (int)n, c->d_seg, c->d_seg32, (int)c->nbp2, nblocks, c->d_qbox, c->d_boxes,
+                                                            c->d_recs32, c->d_split_of, c->d_root, c->d_cross, cross_count, c->cross_cap, c->d_top_pub, top_flag, c->top_seq,
+                                                            nord, ogroups, c->d_cost, c->d_order);
+        if (nord) c->order_ready = true;
         c->internal_boxes_valid = write_internal;
         HIPCHK(evrec(c, EV_REFIT1));
         HIPCHK(hipGetLastError());
@@ -522,11 +535,11 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         if (half_mode && !DEEP) {
             const dim3 hgrid(cdiv(items, 64u)), hblock(HALF_THREADS);
             const uint32_t *h_order = (c->order_hint && c->order_ready) ? c->d_order : nullptr;      // (the order hint: cd_bvh.h, build_half_order)
-            uint32_t *h_cost = c->order_hint ? c->d_cost : nullptr;
+            const uint32_t *h_perm = c->order_hint ? c->d_perm[0] : nullptr; uint8_t *h_tri = c->order_hint ? c->d_tri_cost : nullptr;
 #define LAUNCH_HALF(DIAG, TIES)                                                                                                             \
-            do { if (plain) k_descend_half<DIAG, TIES><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, h_order, h_cost); \
+            do { if (plain) k_descend_half<DIAG, TIES><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, h_order, h_perm, h_tri); \
                  else hipExtLaunchKernelGGL((k_descend_half<DIAG, TIES>), hgrid, hblock, (uint32_t)pad, s, e0, e1, 0u, src, n, (const NodeRec32 *)c->d_recs32, \
-                                            tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, h_order, h_cost); } while (0)
+                                            tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, h_order, h_perm, h_tri); } while (0)
             const bool ties = c->amb.keys != nullptr || c->amb.mask != 0u;                      // (a graph capture bakes the instance in: amb_refresh drops the graph when the table comes or goes)
             if (c->dbg_diag) { if (ties) LAUNCH_HALF(true, true); else LAUNCH_HALF(true, false); }
             else { if (ties) LAUNCH_HALF(false, true); else LAUNCH_HALF(false, false); }
@@ -539,18 +552,13 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, true>), grid, dim3(DESC_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
         if (!DEEP && !ride && !c->quiet_pass) evrec(c, EV_DESC1);
-        // behind a half traversal of the context's own leaves the exact kernel also builds the NEXT step's order hint (8 more workgroups)
-        const bool build_order = half_mode && !DEEP && c->order_hint && n > 64 && &tb == &c->tb[0];
-        const uint32_t xblocks = (uint32_t)c->exact_blocks, xgrid = xblocks + (build_order ? 8u : 0u), ogroups = ((uint32_t)n + 63u) / 64u;
-        const uint32_t *o_cost = build_order ? c->d_cost : nullptr; uint32_t *o_order = build_order ? c->d_order : nullptr;
         if (plain)
-            k_exact<EXTERNAL><<<xgrid, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, tb.d_cand, (unsigned long long)shard_cap, tb.d_pairs,
-                                                              (unsigned long long)cap_pairs, tb.d_state, half, xblocks, ogroups, o_cost, o_order);
+            k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, tb.d_cand, (unsigned long long)shard_cap, tb.d_pairs,
+                                                                        (unsigned long long)cap_pairs, tb.d_state, half);
         else
-            hipExtLaunchKernelGGL((k_exact<EXTERNAL>), dim3(xgrid), dim3(EXACT_THREADS), 0u, s, nullptr, e2, 0u,
+            hipExtLaunchKernelGGL((k_exact<EXTERNAL>), dim3(c->exact_blocks), dim3(EXACT_THREADS), 0u, s, nullptr, e2, 0u,
                                   src, n, (const LeafTri *)c->d_leaf, (const double *)c->d_boxes, (const double *)c->d_verts, vb, (const Candidates *)tb.d_cand,
-                                  (unsigned long long)shard_cap, tb.d_pairs, (unsigned long long)cap_pairs, tb.d_state, half, xblocks, ogroups, o_cost, o_order);
-        if (build_order) c->order_ready = true;
+                                  (unsigned long long)shard_cap, tb.d_pairs, (unsigned long long)cap_pairs, tb.d_state, half);
         c->events_ride = ride;
     }
 }
@@ -997,8 +1005,8 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_qbox, sizeof(LeafBox32) * n);
     ALLOC(c->d_split_of, sizeof(int32_t) * n);
     { const size_t groups = ((size_t)n + 63) / 64;
-      ALLOC(c->d_cost, sizeof(uint32_t) * groups); ALLOC(c->d_order, sizeof(uint32_t) * groups);
-      if (hipMemset(c->d_cost, 0, sizeof(uint32_t) * groups) != hipSuccess) { free_all(c); delete c; return CD_ERR_ARG; } }   // (no times yet: the first hint is half_vblock's own order)
+      ALLOC(c->d_cost, sizeof(uint32_t) * groups); ALLOC(c->d_order, sizeof(uint32_t) * groups); ALLOC(c->d_tri_cost, n);
+      if (hipMemset(c->d_cost, 0, sizeof(uint32_t) * groups) != hipSuccess || hipMemset(c->d_tri_cost, 0, n) != hipSuccess) { free_all(c); delete c; return CD_ERR_ARG; } }   // (no times yet: the first hint is half_vblock's own order)
     c->tb[0].cand_cap = ((4 * n > (1u << 20) ? 4 * n : (1u << 20)) + NSHARD - 1) / NSHARD * NSHARD;
     ALLOC(c->tb[0].d_cand, sizeof(Candidates) * c->tb[0].cand_cap);
     c->tb[0].defer_cap = 1u << 16;
@@ -1029,8 +1037,6 @@ int cd_update_vertices(cd_ctx *c, const double *verts_xyz)
     if (!c || !verts_xyz) return CD_ERR_ARG;
     HIPCHK(hipStreamSynchronize(c->stream));                                // (nothing of an earlier call may still read the old vertices or the old cell table)
     HIPCHK(hipMemcpy(c->d_verts, verts_xyz, sizeof(double) * 3 * (size_t)c->nv, hipMemcpyHostToDevice));
-    c->order_ready = false;                 // the order hint is about the vertices it was measured on: a mesh that moved sorts differently, and a hint for other groups is
-                                            // worse than none (tools/hint_moving.py: +2 us with the sheets a quarter of a quad apart from where they were)
     c->stage = ST_CREATED;
     c->root_box_valid = false;
     return amb_refresh(c);
@@ -1039,7 +1045,6 @@ int cd_update_vertices(cd_ctx *c, const double *verts_xyz)
 int cd_set_morton_frame(cd_ctx *c, int mode, const double offset[3], const double span[3])
 {
     if (!c) return CD_ERR_ARG;
-    c->order_ready = false;                 // (another frame, another sorted order: the order hint's groups are not the next step's)
     if (mode == CD_FRAME_REFERENCE) {
         const double ref[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};
         memcpy(c->frame_host, ref, sizeof ref);
@@ -1342,14 +1347,28 @@ int cd_debug_counters(cd_ctx *c, unsigned long long out[12])
     return CD_OK;
 }
 
-/* Debug only: the order hint's two arrays, ceil(nt / 64) words each -- the time class every group's wave left in the last half traversal, and the order built from them. */
-int cd_debug_hint(cd_ctx *c, uint32_t *cost, uint32_t *order)
+/* Debug only: the order hint's arrays -- per group of 64 leaves (ceil(nt / 64) words each) the score of the last fused build and the order made from the scores; per triangle (nt bytes) the time class its wave left in the last half traversal. */
+int cd_debug_hint(cd_ctx *c, uint32_t *cost, uint32_t *order, uint8_t *tri)
 {
     if (!c) return CD_ERR_ARG;
     HIPCHK(hipStreamSynchronize(c->stream));
     const size_t groups = ((size_t)c->nt + 63) / 64;
+    if (tri) HIPCHK(hipMemcpy(tri, c->d_tri_cost, c->nt, hipMemcpyDeviceToHost));
     if (cost) HIPCHK(hipMemcpy(cost, c->d_cost, sizeof(uint32_t) * groups, hipMemcpyDeviceToHost));
     if (order) { if (!c->order_ready) return CD_ERR_ORDER; HIPCHK(hipMemcpy(order, c->d_order, sizeof(uint32_t) * groups, hipMemcpyDeviceToHost)); }
+    return CD_OK;
+}
+
+/* Debug only: install an order for the next half traversal (must be a permutation of the groups; checked). */
+int cd_debug_hint_set(cd_ctx *c, const uint32_t *order)
+{
+    if (!c || !order) return CD_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint32_t groups = (c->nt + 63u) / 64u;
+    std::vector<uint8_t> seen(groups, 0);
+    for (uint32_t b = 0; b < groups; ++b) { if (order[b] >= groups || seen[order[b]]) return CD_ERR_ARG; seen[order[b]] = 1; }
+    HIPCHK(hipMemcpy(c->d_order, order, sizeof(uint32_t) * groups, hipMemcpyHostToDevice));
+    c->order_ready = true;
     return CD_OK;
 }
 
@@ -1488,7 +1507,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
         c->stage = ST_CREATED; c->root_box_valid = false;                  // the records of the tree that is there were encoded the other way
         return amb_refresh(c);
     }
-    if (key == CD_OPT_ORDER_HINT) { c->order_hint = value != 0; c->order_ready = false; graph_drop(c); return CD_OK; }       // (a captured step has its launches baked in)
+    if (key == CD_OPT_ORDER_HINT) { c->order_hint = value != 0; c->order_ready = false; c->order_pending = false; graph_drop(c); return CD_OK; }       // (a captured step has its launches baked in)
     if (key == CD_OPT_KERNEL_STAMPS) { if (value < 0 || value > 15) return CD_ERR_ARG; c->stamp_mask = (uint32_t)value; return CD_OK; }
     return CD_ERR_ARG;
 }

@@ -59,7 +59,7 @@ EXPORTS = [
     "cd_check_triangle_idx", "cd_find_collisions", "cd_build_tree", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
     "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_debug_counters", "cd_debug_records", "cd_num_triangles",
     "cd_set_option", "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
-    "cd_debug_option", "cd_debug_hint", "cd_morton3d_points", "cd_expand64_values", "cd_box_pairs", "cd_tri_contact_points", "cd_alloc_host_pairs", "cd_free_host_pairs",
+    "cd_debug_option", "cd_debug_hint", "cd_debug_hint_set", "cd_morton3d_points", "cd_expand64_values", "cd_box_pairs", "cd_tri_contact_points", "cd_alloc_host_pairs", "cd_free_host_pairs",
     "cd_multi_unique_id", "cd_multi_create", "cd_multi_create_from_comm", "cd_multi_destroy", "cd_multi_set_flags", "cd_multi_step",
 ]
 
@@ -109,7 +109,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_get_stats.argtypes = [vp, C.POINTER(CdStats)]
     lib.cd_debug_counters.argtypes = [vp, vp]
     lib.cd_debug_records.argtypes = [vp, vp, vp, vp]
-    lib.cd_debug_hint.argtypes = [vp, vp, vp]
+    lib.cd_debug_hint.argtypes = [vp, vp, vp, vp]
+    lib.cd_debug_hint_set.argtypes = [vp, vp]
     lib.cd_num_triangles.argtypes = [vp, u32p]
     lib.cd_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.cd_set_vertex_id_base.argtypes = [vp, C.c_uint32]
@@ -326,11 +327,15 @@ class CollisionDetector:
         self._chk("cd_debug_counters", self.lib.cd_debug_counters(self._ctx, out.ctypes.data))
         return out
 
-    def debug_hint(self, with_order: bool = True):
+    def debug_hint(self, with_order: bool = True, with_tri: bool = False):
         g = (self.nt + 63) // 64
-        cost = np.zeros(g, dtype=np.uint32); order = np.zeros(g, dtype=np.uint32)
-        self._chk("cd_debug_hint", self.lib.cd_debug_hint(self._ctx, _ptr(cost), _ptr(order) if with_order else None))
-        return cost, (order if with_order else None)
+        cost = np.zeros(g, dtype=np.uint32); order = np.zeros(g, dtype=np.uint32); tri = np.zeros(self.nt, dtype=np.uint8)
+        self._chk("cd_debug_hint", self.lib.cd_debug_hint(self._ctx, _ptr(cost), _ptr(order) if with_order else None, _ptr(tri) if with_tri else None))
+        return (cost, (order if with_order else None), tri) if with_tri else (cost, (order if with_order else None))
+
+    def debug_hint_set(self, order: np.ndarray):
+        o = np.ascontiguousarray(order, dtype=np.uint32)
+        self._chk("cd_debug_hint_set", self.lib.cd_debug_hint_set(self._ctx, _ptr(o)))
 
     def debug_records(self):
         """(right halves u32[n, 8], left halves u32[n, 8], query boxes u32[n, 8], root split) of the current tree."""

@@ -212,11 +212,11 @@ enum {
                                    /*    costs the upload ~0.4 ms per million vertices).  0: no table, every coordinate that is not an fp32 value is rounded outward    */
                                    /*    (a full-double structured mesh: ~2 x the step time, nothing added to the upload).  Vertices that are all fp32 values -- what   */
                                    /*    the reference's loader produces, load_obj.h:38 -- never have a table                                                            */
-    CD_OPT_ORDER_HINT       = 8,   /* 1 (default): a half traversal (CD_OPT_TRAVERSAL 3) of the SAME vertices as the context's previous one takes its groups of 64 leaves in the   */
-                                   /*    order of how long each took then, longest first (per XCD; the kernel ends with its unluckiest wave slot).  Scheduling only: every group is  */
-                                   /*    traversed in every step, results do not depend on it.  It applies to repeated steps on unchanged vertices -- a benchmark's timed loop, a     */
-                                   /*    paused scene; cd_update_vertices drops the hint (a mesh that moved sorts into other groups: a hint measured before the move does not help,   */
-                                   /*    tools/hint_moving.py), the step after it runs in the plain order.  0: always the plain order                                                  */
+    CD_OPT_ORDER_HINT       = 8,   /* 1 (default): the half traversal (CD_OPT_TRAVERSAL 3) of a fused call takes its groups of 64 leaves longest-first (per XCD; the kernel ends with its    */
+                                   /*    unluckiest wave slot), by how long the PREVIOUS traversal's waves took -- remembered per triangle, so that the hint survives a mesh that moves and  */
+                                   /*    sorts differently: 1 M cloth at rest -7 us per step, sheets moving a quad per frame -4 us.  Scheduling only: every group is traversed in every      */
+                                   /*    step, results do not depend on it.  Trees of more than 2048 blocks (1 M triangles) and the stage-wise API run in the plain order.  0: always the   */
+                                   /*    plain order                                                                                                                                       */
     CD_OPT_QUERIES_PER_WAVE = 1    /* variant 1: queries one wave works through with dynamic lane refill (x64)         */
 };
 int cd_set_option(cd_ctx *ctx, int key, int64_t value);
@@ -246,9 +246,13 @@ int cd_get_stats(cd_ctx *ctx, cd_stats *out);
  * {chain steps, chain hops inside / outside the query's 256-leaf block, descent visits inside / outside it, longest
  * chain of each wave, 6 spare}.  Not part of any result. */
 int cd_debug_counters(cd_ctx *ctx, unsigned long long out[12]);
-/* The order hint's arrays (CD_OPT_ORDER_HINT), ceil(nt / 64) words each, either may be NULL: the time class (1.28 us each) the wave of every group of 64 leaves
- * left in the last half traversal, and the order built from them (CD_ERR_ORDER while none has been).  Not part of any result. */
-int cd_debug_hint(cd_ctx *ctx, uint32_t *cost, uint32_t *order);
+/* The order hint's arrays (CD_OPT_ORDER_HINT), any may be NULL: per group of 64 leaves (ceil(nt / 64) words each) the score the last fused build gave it and the order
+ * made from the scores (CD_ERR_ORDER while the tree that is there has none); per triangle, by its index in the face list (nt bytes), the time class (1.28 us each) its
+ * wave left in the last half traversal.  Not part of any result. */
+int cd_debug_hint(cd_ctx *ctx, uint32_t *cost, uint32_t *order, uint8_t *tri);
+/* ... and the other way: install `order` (a permutation of the groups, checked: CD_ERR_ARG otherwise) as the hint the next half traversal of the tree that is there takes
+ * (experiments with predictors: build the tree with cd_build_tree, install, cd_find_collisions). */
+int cd_debug_hint_set(cd_ctx *ctx, const uint32_t *order);
 /* Diagnostics: the fp32 traversal records of the current tree as the descent reads them -- recs: n x 64 bytes (n x 32 bytes
  * of right halves {lo[3], hi[3], link, last | flags}, then n x 32 bytes of left halves {lo[3], hi[3], link, first}, both
  * indexed by split), qboxes: n x 32 bytes {lo[3], hi[3], flags, 0}, root: the root record's split.  Either may be NULL. */

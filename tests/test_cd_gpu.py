@@ -390,10 +390,11 @@ def test_steady_state_steps_clean_their_own_scratch():
 
 
 def test_order_hint_is_a_permutation_and_changes_nothing_but_the_order():
-    """CD_OPT_ORDER_HINT (default on): a half traversal of the same vertices as the one before takes its groups of 64 leaves in the order
-    of that one's wave times, longest first per XCD.  The hint must be a permutation of the groups whatever the times were -- this mesh's,
-    a mesh with other contact curves, a stage-wise traversal in between --, cd_update_vertices must drop it (the next step builds a new
-    one), and pairs, pairs tested and every other counter must be what they are without it."""
+    """CD_OPT_ORDER_HINT (default on): the half traversal of a fused call takes its groups of 64 leaves longest-first per XCD, by the
+    previous traversal's wave times, which every wave leaves with its TRIANGLES (so the hint survives a mesh that moves and sorts
+    differently).  The order must be a permutation of the groups whatever the times were -- this mesh's, the same mesh moved, a mesh
+    with other contact curves, a stage-wise traversal in between -- and pairs, pairs tested and every other counter must be what they
+    are without it."""
     va, ta = synth.cloth_pair(130)                                          # 67 600 triangles: 1 057 groups, lists of 132 / 133 groups per XCD
     vb = va.copy(); vb[va.shape[0] // 2:, 0] += 0.4                        # sheet B shifted: the contact curves are elsewhere
     vc = va.copy(); h = va.shape[0] // 2
@@ -406,33 +407,56 @@ def test_order_hint_is_a_permutation_and_changes_nothing_but_the_order():
         assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])) and st.pairs_tested == r["stats"].pairs_tested
         return st
 
+    def check_arrays(cd):
+        cost, order, tri = cd.debug_hint(with_tri=True)
+        assert np.array_equal(np.sort(order), np.arange(order.shape[0], dtype=np.uint32)) and cost.max() < 32 and tri.max() < 32
+        for x in range(8):
+            assert np.all(np.diff(cost[order[x::8]].astype(np.int64)) <= 0)   # every XCD's list: the highest score first
+        keys, perm = cd.export_keys()
+        pad = np.concatenate([tri[perm], np.zeros(order.shape[0] * 64 - perm.shape[0], dtype=np.uint8)]).reshape(-1, 64)
+        return cost, pad
+
     with mi355cd.CollisionDetector(va, ta) as cd:
-        assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 0            # nothing built before the first traversal
+        assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 0            # nothing built before the first fused build
         st1 = step(cd, ra)
-        assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in (1, 2)       # built behind the first traversal (from its times), used by the second
+        assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 2            # built by the first step's build from no times at all: the plain order
+        cost, pad = check_arrays(cd)
+        assert cost.max() == 0 and cd.debug_hint(with_tri=True)[2].min() >= 1 and np.all(pad.max(1)[:-1] == pad.min(1)[:-1])   # ... and the traversal left every triangle its wave's class
         st2 = step(cd, ra); st3 = step(cd, ra)
         assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 1            # the waves of a cloth pair do not all take the same time
         assert st2.node_visits == st1.node_visits == st3.node_visits and st2.candidates == st1.candidates
-        cd.update_vertices(vb)                                              # the mesh moved: the hint is dropped, the next traversal leaves a new one
-        assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 0
-        for _ in range(2): step(cd, rb); assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 1
+        cd.update_vertices(vb)                                              # the mesh moved: its triangles carry the times into whatever groups they sort into now
+        for _ in range(2):
+            step(cd, rb); assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 1
+        prev_tri = cd.debug_hint(with_tri=True)[2]
         cd.update_vertices(vc)                                              # a mesh whose contact curves lie elsewhere altogether
-        for _ in range(3): step(cd, rc_); assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in (1, 2)
-        cost, order = cd.debug_hint()
-        assert np.array_equal(np.sort(order), np.arange(order.shape[0], dtype=np.uint32)) and cost.max() < 32
-        assert np.all(np.diff(cost[order[0::8]].astype(np.int64)) <= 0)     # XCD 0's list: longest class first
-        cd.morton_sort(); cd.build_hierarchy(); cd.refit_boxes()            # the stage-wise API: its traversal takes the hint that is there and leaves the next
+        step(cd, rc_)
+        cost, pad = check_arrays(cd)                                        # (pad: THIS traversal's classes by sorted position)
+        keys, perm = cd.export_keys()
+        want = np.concatenate([prev_tri[perm], np.zeros(cost.shape[0] * 64 - perm.shape[0], dtype=np.uint8)]).reshape(-1, 64).max(1)
+        assert np.array_equal(cost, want.astype(np.uint32))                 # a group's score = the max of what its triangles brought along
+        for _ in range(2): step(cd, rc_)
+        cd.morton_sort(); cd.build_hierarchy(); cd.refit_boxes()            # the stage-wise API builds no hint: its traversal runs in the plain order
+        assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 0
         pairs, n, rc = cd.find_collisions(cap=1 << 21)
-        assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(rc_["pairs"])) and cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in (1, 2)
+        assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(rc_["pairs"]))
         cd.update_vertices(va)
         step(cd, ra)
-        cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 0)                         # off: the plain order, no hint kept
+        cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 0)                         # off: the plain order, nothing built, nothing remembered
         st_off = step(cd, ra)
         assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 0
         assert st_off.node_visits == st1.node_visits and st_off.candidates == st1.candidates
         cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 1)
         step(cd, ra); step(cd, ra)
         assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 1
+        # an order installed from outside (cd_debug_hint_set): any permutation gives the same pairs; a non-permutation is refused
+        cd.build_tree()
+        g = (ta.shape[0] + 63) // 64
+        cd.debug_hint_set(np.random.default_rng(1).permutation(g).astype(np.uint32))
+        pairs, n, rc = cd.find_collisions(cap=1 << 21)
+        assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(ra["pairs"])) and cd.stats().pairs_tested == ra["stats"].pairs_tested
+        with pytest.raises(mi355cd.CdError):
+            cd.debug_hint_set(np.zeros(g, dtype=np.uint32))
         for variant in (1, 0, 3):                                           # other traversals neither read nor write it
             cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant); step(cd, ra)
     # a mesh of less than one group per XCD, and one group exactly
@@ -441,7 +465,7 @@ def test_order_hint_is_a_permutation_and_changes_nothing_but_the_order():
         r = oracle.pipeline(v, t)
         with mi355cd.CollisionDetector(v, t) as cd:
             for _ in range(3): step(cd, r)
-            assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in ((0,) if nt <= 64 else (1, 2))
+            assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in ((0,) if nt <= 512 else (1, 2))   # (one block: no cross kernel, no hint)
 
 
 def test_cd_main_harness_on_generated_obj(tmp_path):

@@ -15,27 +15,26 @@ buf = np.empty((1 << 22, 2), dtype=np.uint32)
 for name, (verts, vidx) in (("cloth1M", synth.cloth_pair(500)), ("soup1M", synth.soup(1_000_000, 0.01, 1234))):
     with mi355cd.CollisionDetector(verts, vidx) as cd:
         cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+        def group_times():
+            """the classes the last traversal's waves left, by group of 64 sorted positions (every triangle of a group holds its wave's class)"""
+            _, _, tri = cd.debug_hint(with_order=False, with_tri=True)
+            _, perm = cd.export_keys()
+            return tri[perm[::64]].astype(np.float64)
         for hint in (0, 1):
             cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 1)
             for _ in range(10): cd.self_collide_into(buf)
+            taken = None
             if not hint:
-                # times of a step in the PLAIN order: switch the hint off for one step?  (cost[] is only written with the hint on: take the first step after an upload instead)
-                cd.update_vertices(verts); cd.self_collide_into(buf)
-                cost, order = cd.debug_hint(); clock = cd.fast_stats.ms_descend_clock * 1e3
-                g = cost.shape[0]
-                # the plain order: workgroup b takes half_vblock(b): recover it from a context whose hint is the plain order -- the order just built is NOT it; use list position = index order per XCD
-                taken = None
+                cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 0); cd.build_tree()                    # a tree without an order ...
+                cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 1); cd.find_collisions(cap=1 << 22)    # ... traversed in the plain order, leaving its times
+                clock = cd.stats().ms_descend_clock * 1e3
             else:
-                for _ in range(5): cd.self_collide_into(buf)
-                prev_cost, prev_order = cd.debug_hint()          # the order this step will take, and the times it was built from
                 cd.self_collide_into(buf)
-                cost, order = cd.debug_hint(); clock = cd.fast_stats.ms_descend_clock * 1e3
-                taken = prev_order
-            dur = (cost.astype(np.float64) + 0.5) * 1.28
+                _, taken = cd.debug_hint()                                                      # the order this step took
+                clock = cd.fast_stats.ms_descend_clock * 1e3
+            dur = (group_times() + 0.5) * 1.28
             line = f"{name} hint {'on ' if hint else 'off'}: kernel's clock {clock:5.1f} us | waves: mean {dur.mean():.1f} p50 {np.median(dur):.1f} p90 {np.percentile(dur, 90):.1f} p99 {np.percentile(dur, 99):.1f} max {dur.max():.1f} us (top class = 40+) | load sum / 8192 = {dur.sum() / 8192:.1f} us"
             if taken is not None:
-                per = []
-                for x in range(8):
-                    per.append(makespan(dur[taken[x::8]], 1024))
+                per = [makespan(dur[taken[x::8]], 1024) for x in range(8)]
                 line += f" | list scheduling of these times in the order taken, per XCD on 1024 slots: {min(per):.1f} .. {max(per):.1f} us; longest-first on the SAME times: {max(makespan(np.sort(dur[taken[x::8]])[::-1], 1024) for x in range(8)):.1f}"
             print(line, flush=True)
