@@ -468,6 +468,27 @@ def test_order_hint_is_a_permutation_and_changes_nothing_but_the_order():
             assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in ((0,) if nt <= 512 else (1, 2))   # (one block: no cross kernel, no hint)
 
 
+def test_order_hint_on_random_meshes_that_move():
+    """Steps on meshes whose vertices are jittered between steps (cd_update_vertices): every step takes the order hint its fused build made from the
+    times the triangles brought along from the step before -- whatever they sort into now -- and must give the oracle's pairs and pairs tested."""
+    rng = np.random.default_rng(2024)
+    for case in range(6):
+        if case % 2 == 0:
+            verts, vidx = synth.soup(int(rng.choice([3000, 40_000, 90_000])), float(rng.choice([0.02, 0.05])), int(rng.integers(1 << 30)))
+        else:
+            verts, vidx = synth.cloth_pair(int(rng.choice([30, 90, 140])))
+        with mi355cd.CollisionDetector(verts, vidx) as cd:
+            states = []
+            for stepno in range(4):
+                v = verts if stepno == 0 else np.float32(verts + rng.normal(0.0, 0.003 * stepno, verts.shape)).astype(np.float64)
+                cd.update_vertices(v)
+                r = oracle.pipeline(v, vidx)
+                pairs, n, rc = cd.self_collide(cap=1 << 21)
+                assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])) and cd.stats().pairs_tested == r["stats"].pairs_tested, (case, stepno)
+                states.append(cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE))
+            assert all(st in (0, 1, 2) for st in states) and (vidx.shape[0] <= 512 or states[-1] in (1, 2)), (case, states)
+
+
 def test_cd_main_harness_on_generated_obj(tmp_path):
     """BASELINE config 1, plumbing: the C++ harness (main.cu twin) on a generated OBJ in the reference's dialect."""
     text = synth.grids_obj_text(32)
