@@ -837,7 +837,11 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
                                                          const double *__restrict__ verts, uint32_t vbase,
                                                          const Candidates *__restrict__ cand, unsigned long long shard_cap,
                                                          uint32_t *__restrict__ pairs, unsigned long long cap, TravState *__restrict__ st,
-                                                         uint32_t half /* candidates of a half traversal (k_descend_half): q and leaf are an unordered pair */)
+                                                         uint32_t half /* candidates of a half traversal (k_descend_half): q and leaf are an unordered pair */,
+                                                         uint32_t *__restrict__ post /* NULL, or PINNED HOST memory: the first post_n pairs are also stored there, at their positions in the
+                                                                                        list -- the report kernel behind this one then posts the counters only (the pairs' 160 KB through
+                                                                                        32 workgroups of a kernel of their own were 4.6 us of the step; here they leave with the appends) */,
+                                                         unsigned long long post_n)
 {
     __shared__ uint2 pbuf[EXACT_PB];
     __shared__ SatItem sq[EXACT_SQ];
@@ -883,6 +887,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
             else {                                                             // staging full: append directly (collision.cuh:40)
                 const unsigned long long cur = atomicAdd(&st->n_pairs, 1ull);
                 if (cur < cap) { pairs[2 * cur] = q_id; pairs[2 * cur + 1] = lt.id; }
+                if (post && cur < post_n) reinterpret_cast<uint2 *>(post)[cur] = make_uint2(q_id, lt.id);
             }
         }
     };
@@ -967,6 +972,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
     for (uint32_t i = tid; i < staged; i += EXACT_THREADS) {
         const unsigned long long cur = pbase + i;
         if (cur < cap) reinterpret_cast<uint2 *>(pairs)[cur] = pbuf[i];
+        if (post && cur < post_n) reinterpret_cast<uint2 *>(post)[cur] = pbuf[i];
     }
 }
 

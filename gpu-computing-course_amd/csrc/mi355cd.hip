@@ -48,6 +48,9 @@ struct TravBuf {
     uint2 *d_defer = nullptr; uint32_t defer_cap = 0;
     Candidates *d_cand = nullptr; uint64_t cand_cap = 0;
     int32_t *d_deep = nullptr; uint64_t deep_items = 0;
+    // the report of the pass being enqueued, decided BEFORE its kernels are (run_traversal, prepare_report): the exact kernel posts the first pairs into pinned host memory itself
+    uint32_t *post_dst = nullptr; uint64_t post_n = 0;                     // where to (the caller's pinned buffer, or the staging area behind the report), how many at most
+    bool prepared = false; unsigned long long prep_seq = 0; uint32_t *prep_area = nullptr; bool posted = false;   // the polled completion's sequence number and the scan's area of that report; the pass's k_exact did post
 };
 
 struct cd_multi;
@@ -107,6 +110,7 @@ struct cd_ctx {
     bool stage_events = true;               // CD_OPT_STAGE_TIMING
     bool leaves_filled = false;             // the sort's fix-up hop already wrote leaf[], parent = -1, bounded = 0
     bool events_ride = false;               // the last pass recorded EV_TRAV0 / EV_DESC1 / EV_TRAV1 through its kernels' dispatch packets
+    uint32_t dbg_report_copies = 0;        // CD_DBG_REPORT_COPIES: the report kernel copies the first pairs to the host (32 workgroups) instead of the exact kernel posting them (A/B)
     bool order_hint = true;                 // CD_OPT_ORDER_HINT: the half traversal takes its groups of 64 leaves longest-first, by the previous step's times (cd_bvh.h, build_half_order)
     bool order_ready = false;               // d_order holds THIS tree's order hint (its fused build has made it)
     uint32_t *d_cost = nullptr, *d_order = nullptr;   // per group of 64 leaves: the score k_build_block gives it (max of its triangles' time classes); the order made from the scores
@@ -552,13 +556,15 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, true>), grid, dim3(DESC_THREADS), (uint32_t)pad, s, e0, e1, 0u,
                                   src, items, n, qarg, (const NodeRec32 *)c->d_recs32, (const double *)c->d_boxes, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, deep, vb, half);
         if (!DEEP && !ride && !c->quiet_pass) evrec(c, EV_DESC1);
+        uint32_t *post = DEEP ? nullptr : tb.post_dst; const unsigned long long post_n = DEEP ? 0ull : (unsigned long long)tb.post_n;
+        if (!DEEP) { tb.posted = post != nullptr; tb.post_dst = nullptr; tb.post_n = 0; }     // (asked for by run_traversal for THIS pass only)
         if (plain)
             k_exact<EXTERNAL><<<c->exact_blocks, EXACT_THREADS, 0, s>>>(src, n, c->d_leaf, c->d_boxes, c->d_verts, vb, tb.d_cand, (unsigned long long)shard_cap, tb.d_pairs,
-                                                                        (unsigned long long)cap_pairs, tb.d_state, half);
+                                                                        (unsigned long long)cap_pairs, tb.d_state, half, post, post_n);
         else
             hipExtLaunchKernelGGL((k_exact<EXTERNAL>), dim3(c->exact_blocks), dim3(EXACT_THREADS), 0u, s, nullptr, e2, 0u,
                                   src, n, (const LeafTri *)c->d_leaf, (const double *)c->d_boxes, (const double *)c->d_verts, vb, (const Candidates *)tb.d_cand,
-                                  (unsigned long long)shard_cap, tb.d_pairs, (unsigned long long)cap_pairs, tb.d_state, half);
+                                  (unsigned long long)shard_cap, tb.d_pairs, (unsigned long long)cap_pairs, tb.d_state, half, post, post_n);
         c->events_ride = ride;
     }
 }
@@ -585,8 +591,11 @@ int enqueue_report(cd_ctx *c, TravBuf &tb, bool want_pairs, uint64_t &spec_n, ui
     // (the pair list is allocated with an even capacity + slack, so the quad copy may read one pair past `take`; a pinned buffer of
     //  cd_alloc_host_pairs has the same slack)
     constexpr int REPORT_BLOCKS = 32;
-    k_report<<<spec_n ? REPORT_BLOCKS : 1, REPORT_THREADS, 0, c->stream>>>(tb.d_state, c->d_os_ticket + 8, c->d_boxes, reinterpret_cast<Report *>(tb.h_report),
-                                                              tb.d_pairs, direct ? direct : reinterpret_cast<uint32_t *>(tb.h_report + sizeof(Report)), (unsigned long long)spec_n, seq);
+    // (the pass's exact kernel has posted the pairs itself: the report is the 256-byte record, one workgroup)
+    const uint64_t copy_n = tb.posted ? 0 : spec_n;
+    tb.posted = false;
+    k_report<<<copy_n ? REPORT_BLOCKS : 1, REPORT_THREADS, 0, c->stream>>>(tb.d_state, c->d_os_ticket + 8, c->d_boxes, reinterpret_cast<Report *>(tb.h_report),
+                                                              tb.d_pairs, direct ? direct : reinterpret_cast<uint32_t *>(tb.h_report + sizeof(Report)), (unsigned long long)copy_n, seq);
     return 0;
 }
 // Polled completion of a step (CD_OPT_POLL): spin on the sequence word k_report stores last.  Nothing that follows may need the
@@ -636,17 +645,34 @@ void parse_report(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs,
         std::memcpy(spec_pairs, tb.h_report + sizeof(Report), sizeof(uint32_t) * 2 * take);
     }
 }
+// What read_state needs decided before it enqueues the report -- is the step's end polled (its sequence number), is the pair area poisoned for the scan -- decided here, so that
+// run_traversal can do it BEFORE the pass's kernels are enqueued: with `post` the pass's exact kernel stores the first pairs into the pinned area itself (k_exact), and a poison
+// written after that would be written over the pairs.
+int prepare_report(cd_ctx *c, TravBuf &tb, uint32_t *spec_pairs, uint64_t spec_n, uint64_t direct_id, bool post)
+{
+    if (ensure_report(tb)) return CD_ERR_ARG;
+    const bool direct = direct_id != 0;
+    if (spec_n > SPEC_PAIRS) spec_n = SPEC_PAIRS;
+    tb.prep_seq = poll_this_report(c, tb, direct_id) ? ++c->report_seq : 0ull;
+    tb.prep_area = nullptr;
+    uint32_t *dst = direct ? spec_pairs : reinterpret_cast<uint32_t *>(tb.h_report + sizeof(Report));
+    if (c->dbg_poll_check && tb.prep_seq && spec_pairs && spec_n) {
+        tb.prep_area = dst;
+        std::memset(dst, 0xff, sizeof(uint32_t) * 2 * spec_n);
+    }
+    tb.post_dst = (post && spec_pairs && spec_n) ? dst : nullptr;
+    tb.post_n = tb.post_dst ? spec_n : 0;
+    tb.prepared = true;
+    return 0;
+}
 int read_state(cd_ctx *c, TravBuf &tb, HostCounters &h, uint32_t *spec_pairs = nullptr, uint64_t spec_n = 0, uint64_t direct_id = 0)
 {
     if (ensure_report(tb)) return CD_ERR_ARG;
     const bool direct = direct_id != 0;
-    const unsigned long long seq = poll_this_report(c, tb, direct_id) ? ++c->report_seq : 0ull;
-    uint32_t *area = nullptr;
-    if (c->dbg_poll_check && seq && spec_pairs && spec_n) {
-        if (ensure_report(tb)) return CD_ERR_ARG;
-        area = direct ? spec_pairs : reinterpret_cast<uint32_t *>(tb.h_report + sizeof(Report));
-        std::memset(area, 0xff, sizeof(uint32_t) * 2 * (spec_n < SPEC_PAIRS ? spec_n : SPEC_PAIRS));
-    }
+    if (!tb.prepared) prepare_report(c, tb, spec_pairs, spec_n, direct_id, false);
+    const unsigned long long seq = tb.prep_seq;
+    uint32_t *area = tb.prep_area;
+    tb.prepared = false; tb.post_dst = nullptr; tb.post_n = 0;
     int rc = enqueue_report(c, tb, spec_pairs != nullptr, spec_n, direct ? spec_pairs : nullptr, seq);
     if (rc) return rc;
     const uint32_t fb0 = c->poll_fallbacks;
@@ -704,6 +730,8 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
         if (!will_ride) HIPCHK(evrec(c, EV_TRAV0));
         if (!(c->prezeroed && attempt == 0 && &tb == &c->tb[0])) HIPCHK(hipMemsetAsync(tb.d_state, 0, sizeof(TravState), s));
         const uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
+        // (the exact kernel posts the first pairs itself when it is the one that appends them: every traversal but variant 0's)
+        if ((rc = prepare_report(c, tb, pairs, spec_n, pinned_pairs_id(pairs, cap_pairs), c->trav_variant != 0 && nq > 0 && !c->dbg_report_copies))) return rc;
         if (nq > 0) {
             if (external) launch_pass<true, false>(c, tb, src, nq, cap_pairs); else launch_pass<false, false>(c, tb, src, nq, cap_pairs);
             launches += per_pass;
@@ -1525,6 +1553,7 @@ int cd_debug_option(cd_ctx *c, int key, int64_t value, int64_t *out)
     case CD_DBG_DIAG:            c->dbg_diag = value != 0; return CD_OK;
     case CD_DBG_STAGEWISE_BUILD: c->dbg_no_fused_build = value != 0; return CD_OK;
     case CD_DBG_SPLIT_CROSS:     c->dbg_split_cross = value != 0; return CD_OK;
+    case CD_DBG_REPORT_COPIES:   c->dbg_report_copies = value != 0; graph_drop(c); return CD_OK;
     case CD_DBG_POLL_SCAN:       c->dbg_poll_check = value != 0; return CD_OK;
     case CD_DBG_GET_POLL_STALE:     if (!out) return CD_ERR_ARG; *out = c->poll_stale; return CD_OK;
     case CD_DBG_GET_POLL_FALLBACKS: if (!out) return CD_ERR_ARG; *out = c->poll_fallbacks; return CD_OK;

@@ -231,6 +231,7 @@ enum {
     CD_DBG_DIAG               = 3,   /* run the descent kernel's DIAG instance: per-phase step counts and s_memtime ticks -> cd_debug_counters */
     CD_DBG_STAGEWISE_BUILD    = 4,   /* fused entry points build the tree stage by stage (k_hierarchy + refit) instead of in one pass         */
     CD_DBG_SPLIT_CROSS        = 5,   /* the fused build's cross nodes by k_cross_meta + k_cross_records instead of k_cross_fused               */
+    CD_DBG_REPORT_COPIES      = 6,   /* 1: the report kernel copies the first pairs into the host buffer (32 workgroups), as before round 4, instead of the exact kernel posting them (A/B) */
     CD_DBG_POLL_SCAN          = 10,  /* polled completion: poison the pair area before a step, scan it the moment the sequence word is seen   */
     CD_DBG_GET_POLL_STALE     = 11,  /* ... steps in which the scan found a pair missing (must stay 0)                                        */
     CD_DBG_GET_POLL_FALLBACKS = 12,  /* ... polled waits that ran into the 20 ms budget and ended in a stream synchronise                     */

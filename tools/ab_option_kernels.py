@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """As ab_option.py, plus the per-kernel device times of each value (a few extra steps with every kernel stamp on: build_block, descent, exact, pipeline).
-usage: ab_option_kernels.py KEY V0 V1 [ROUNDS STEPS QUADS]   GPU only."""
+usage: ab_option_kernels.py KEY V0 V1 [ROUNDS STEPS QUADS]   (KEY = dbg:N: a cd_debug_option key)   GPU only."""
 import os, sys, statistics, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "gpu-computing-course_amd", "pyhost")]
 import numpy as np
 import mi355_synth as synth, mi355cd
-key, v0, v1 = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+dbg = sys.argv[1].startswith("dbg:")          # KEY = dbg:N addresses a cd_debug_option key
+key, v0, v1 = int(sys.argv[1].split(":")[-1]), int(sys.argv[2]), int(sys.argv[3])
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 100
 quads = int(sys.argv[6]) if len(sys.argv) > 6 else 500
@@ -18,7 +19,7 @@ with mi355cd.CollisionDetector(verts, vidx) as cd:
     wall = {v0: [], v1: []}; res = {}; kern = {v0: [], v1: []}
     for r in range(rounds):
         for v in ((v0, v1) if r % 2 == 0 else (v1, v0)):
-            cd.set_option(key, v)
+            (cd.debug_set if dbg else cd.set_option)(key, v)
             for _ in range(5): cd.self_collide_into(buf)
             t0 = time.perf_counter()
             for _ in range(steps): n, rc = cd.self_collide_into(buf)
