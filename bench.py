@@ -17,6 +17,8 @@ N > 1 : BASELINE config 4, one 1 M-triangle cloth object per rank, neighbours ov
 
 Prints ONE JSON line on rank 0.  Launch for N > 1:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+or plainly `python3 bench.py --gpus N ...`: without WORLD_SIZE / RANK in the environment the script starts that command itself, as
+a child process and before anything touches the GPU, relays rank 0's line and returns the child's exit code.
 """
 from __future__ import annotations
 
@@ -173,6 +175,67 @@ def secondary_measurement(torch, which, steps=60, warmup=10):
             "steps": steps, "descend_device_clock_ms": clock, "parity_checked": bool(pc["ok"]), "reference_compiled_end_result": reference_compiled_check(fixture, last, last_tested)}
 
 
+def size_measurement(torch, which, steps=40, warmup=8):
+    """The step ABOVE 1 M triangles on one GPU, same call and options as the headline, untimed-region extras like soup_1M:
+      cloth_4M          cloth-vs-cloth with 1000 x 1000 quads per sheet = 4 000 000 triangles (the headline's surfaces, twice as fine);
+      config4_merged_8M BASELINE config 4's eight shards of 1 M triangles as ONE mesh of 8 000 000 (mi355_synth.config4_merged) -- the single-GPU
+                        point a scaling curve over 8 GPUs is read against.
+    ms_per_step (wall, polled completion), then untimed profiling steps: every kernel stamp on (build_block / descend / exact / device pipeline time) and
+    per-stage events (morton / sort / build / traverse); whole_path = 460 B x N / device time against the 8 TB/s roof.  The last timed step's pair set and
+    pairs_tested are checked against the CPU oracle on the same mesh."""
+    import mi355_synth as synth
+    import mi355cd
+    ids = frame = None
+    if which == "cloth_4M":
+        verts, vidx = synth.cloth_pair(1000)
+        label = "cloth-vs-cloth, 2 sheets x 1000x1000 quads = 4 000 000 triangles, self-collision"
+    else:
+        verts, vidx, ids, off, span = synth.config4_merged(8, 500); frame = (off, span)
+        label = "BASELINE config 4's eight 1 M-triangle cloth objects (10 % x-overlap between neighbours) merged into ONE mesh of 8 000 000 triangles, self-collision on one GPU"
+    nt = int(vidx.shape[0])
+    cap = 1 << 22
+    with mi355cd.CollisionDetector(verts, vidx, ids) as cd, mi355cd.HostPairs(cap) as hp:
+        if frame is not None:
+            cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, frame[0], frame[1])
+        cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+        for _ in range(warmup):
+            n, rc = cd.self_collide_into(hp.array)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tested = 0
+        for _ in range(steps):
+            n, rc = cd.self_collide_into(hp.array)
+            tested += cd.fast_stats.pairs_tested
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError(which + ": pair capacity too small")
+        last = np.array(hp.array[:n], copy=True); last_tested = cd.fast_stats.pairs_tested
+        prof = 10
+        kern = {"build_block": 0.0, "descend": 0.0, "exact": 0.0}; pipeline = 0.0
+        cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 15)
+        for _ in range(prof):
+            cd.self_collide_into(hp.array); st = cd.stats()
+            kern["build_block"] += st.ms_build_block / prof; kern["descend"] += st.ms_descend / prof; kern["exact"] += st.ms_exact / prof; pipeline += st.ms_pipeline / prof
+        stage = {"morton": 0.0, "sort": 0.0, "build_fused(hierarchy+refit+records)": 0.0, "traverse": 0.0}
+        cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 1)
+        for _ in range(prof):
+            cd.self_collide_into(hp.array); st = cd.stats()
+            stage["morton"] += st.ms_morton / prof; stage["sort"] += st.ms_sort / prof
+            stage["build_fused(hierarchy+refit+records)"] += (st.ms_hierarchy + st.ms_refit) / prof; stage["traverse"] += st.ms_traverse / prof
+        sort_passes = int(st.sort_passes)
+    if ids is None:
+        pc = parity_check(last, last_tested, verts, vidx)
+    else:
+        pc = parity_check(last, last_tested, verts, vidx, ids, off=frame[0], span=frame[1])
+    ach = TOTAL_BYTES_PER_TRI * nt / (pipeline * 1e-3) / 1e9
+    return {"workload": label, "triangles": nt, "ms_per_step": dt * 1e3 / steps, "pairs_tested_per_s": tested / dt, "pairs_tested_per_step": int(last_tested), "colliding_pairs": int(n),
+            "steps": steps, "total_collision_ms_device": pipeline, "kernel_ms": kern, "stage_ms": stage, "sort_passes": sort_passes,
+            "kernel_ms_note": f"from {prof} extra untimed steps with all kernel stamps on (HIP events on the kernels' own dispatch packets); stage_ms from {prof} more with per-stage events (their sum exceeds the device time by the event gaps)",
+            "whole_path": {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS},
+            "parity_checked": bool(pc["ok"]), "parity": pc}
+
+
 def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5, rank=0, world=1, dist=None, torch=None, device=None, multi=False):
     """Secondary path (BASELINE config 5): 4096^2 image, 4096 spheres, frame kept on the device (the reference
     copies every frame to the host for glDrawPixels, anime_ray.cu:128-131; that PCIe copy is not kernel time).
@@ -255,6 +318,24 @@ def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5, rank=0, world=1, 
     return out
 
 
+def self_launch(n):
+    """`python3 bench.py --gpus N` without a launcher around it: start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process, pass its output through (rank 0 prints
+    the ONE JSON line) and hand back its return code.  Nothing in this process has imported torch or touched the GPU."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                 # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without WORLD_SIZE: launching %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +353,11 @@ def main():
                                                                   "steps gets); by default the line carries that measurement beside the headline (order_hint.ms_per_step_without)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python3 bench.py --gpus N` started plainly: this process becomes the LAUNCHER -- before torch is imported, so before anything here
+        # touches the GPU -- and runs the one-rank-per-GPU job as a CHILD (never an exec), relays rank 0's line and returns the child's code
+        sys.exit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     import mi355_synth as synth
@@ -284,8 +370,7 @@ def main():
     if os.environ.get("MI355_DIST_BACKEND", "nccl") != "nccl":
         local_rank = 0                                                # rehearsal: every rank on cuda:0
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or start `python3 bench.py --gpus N` plainly: it launches them itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -577,6 +662,8 @@ def main():
     if not multi_path and not args.no_extras and rank == 0:
         line["soup_1M"] = secondary_measurement(torch, "soup_1M")
         line["cloth_1M_double"] = secondary_measurement(torch, "cloth_1M_double")
+        line["cloth_4M"] = size_measurement(torch, "cloth_4M")
+        line["config4_merged_8M"] = size_measurement(torch, "config4_merged_8M")
     if not args.no_ray and (backend == "nccl" or not multi_path):
         rtm = ray_tracer_measurement(rank=rank, world=world if multi_path else 1, dist=dist if multi_path else None, torch=torch, device=device, multi=multi_path)
         if rank == 0:

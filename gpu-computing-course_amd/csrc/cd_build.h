@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256) void k_cross_records(int n, const NodeMeta *__
 }
 
 // ====================================================================================================
-// k_cross_meta + k_cross_records in ONE launch, for trees of up to TOP_IN_BLOCK blocks.  Two things tied those kernels to
+// k_cross_meta + k_cross_records in ONE launch (round 5: for trees of any size; the upper levels of a tree of more than TOP_IN_BLOCK blocks are
+// published by k_top_publish / k_top_publish_upper in front of it).  Two things tied those kernels to
 // separate launches, and both can be had without a kernel boundary:
 //   * the levels above the blocks, which the range queries read and which block 0 of k_cross_meta builds: every
 //     workgroup folds the (at most 2048) fp32 block boxes into its own copy of those levels in LDS -- 24 bytes per
@@ -435,7 +436,18 @@ __device__ __forceinline__ B32 block_box32(const float *__restrict__ seg32, int 
     const B32 v = b32_load(seg32 + 6 * ((size_t)nbp2 + (b < nblocks ? b : 0)));     // (an unconditional load: several of these go out together)
     return b < nblocks ? v : b32_identity();
 }
-__device__ __forceinline__ void top32_to_lds(float *top, const float *__restrict__ seg32, int nbp2, int nblocks)
+// (blk: the fp32 boxes of the nbp2 blocks -- of the whole tree, seg32 + 6 nbp2, or of one span of TOP_IN_BLOCK blocks of a larger tree, k_top_publish --
+//  of which the first nblocks exist.  low(k, box): round 5 -- the two levels directly above the blocks, heap nodes [nbp2 / 4, nbp2), are handed to the caller
+//  as the thread that holds their eight blocks forms them: they are published too, so that a piece of them is ONE fetch for a cross node instead of two / four
+//  block boxes -- which makes room among a group's 32 memory items for the levels 1 and 2, rebuilt from leaves since k_build_block no longer stores them.)
+struct U3 { unsigned long long a, b, c; };
+__device__ __forceinline__ U3 b32_words(const B32 &v)
+{
+    auto w = [](float lo, float hi) { return (unsigned long long)__float_as_uint(lo) | ((unsigned long long)__float_as_uint(hi) << 32); };
+    return U3{w(v.lx, v.ly), w(v.lz, v.hx), w(v.hy, v.hz)};
+}
+template <class Low>
+__device__ __forceinline__ void top32_to_lds(float *top, const float *__restrict__ blk, int nbp2, int nblocks, Low low)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int M = nbp2 >> 3;                                                // nodes of the lowest stored level, M .. 2 M - 1 (<= 256: nbp2 <= 2048)
@@ -445,17 +457,22 @@ __device__ __forceinline__ void top32_to_lds(float *top, const float *__restrict
         if (tid < T) {
             const int b = 8 * tid;
             // eight consecutive block boxes are 192 contiguous bytes, 16-byte aligned (nbp2 is a multiple of 8 here): twelve quads
-            const float4 *q = reinterpret_cast<const float4 *>(seg32 + 6 * ((size_t)nbp2 + b));
+            const float4 *q = reinterpret_cast<const float4 *>(blk + 6 * (size_t)b);
             float4 v[12];
 #pragma unroll
             for (int u = 0; u < 12; ++u) v[u] = q[u];
             const B32 id = b32_identity();
+            B32 pr[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {                                   // blocks b + 2u, b + 2u + 1 out of the quads 3u .. 3u + 2
                 const float4 q0 = v[3 * u], q1 = v[3 * u + 1], q2 = v[3 * u + 2];
                 const B32 b0 = b + 2 * u < nblocks ? B32{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y} : id, b1 = b + 2 * u + 1 < nblocks ? B32{q1.z, q1.w, q2.x, q2.y, q2.z, q2.w} : id;
-                x = b32_merge(x, b32_merge(b0, b1));
+                pr[u] = b32_merge(b0, b1);
+                low((nbp2 >> 1) + 4 * tid + u, pr[u]);                      // a node of two blocks
             }
+            const B32 q0 = b32_merge(pr[0], pr[1]), q1 = b32_merge(pr[2], pr[3]);
+            low((nbp2 >> 2) + 2 * tid, q0); low((nbp2 >> 2) + 2 * tid + 1, q1);   // of four
+            x = b32_merge(q0, q1);
             b32_store(top + 6 * (M + tid), x);
         }
         const int kt = M + tid;                                             // the node x is the box of
@@ -475,6 +492,17 @@ __device__ __forceinline__ void top32_to_lds(float *top, const float *__restrict
         }
     }
     __syncthreads();
+}
+// A tree of 2 or 4 blocks has nothing but those two levels: one thread forms its one or three nodes.
+template <class Low>
+__device__ __forceinline__ void top32_tiny(const float *__restrict__ blk, int nbp2, int nblocks, Low low)
+{
+    if (threadIdx.x != 0) return;
+    auto blkbox = [&](int b) { const B32 v = b32_load(blk + 6 * (size_t)(b < nblocks ? b : 0)); return b < nblocks ? v : b32_identity(); };
+    const B32 l = b32_merge(blkbox(0), blkbox(1));
+    if (nbp2 == 2) { low(1, l); return; }
+    const B32 r = b32_merge(blkbox(2), blkbox(3));                         // nbp2 == 4
+    low(2, l); low(3, r); low(1, b32_merge(l, r));
 }
 
 // The FP64 box of all leaves from the blocks' FP64 boxes, by one workgroup, ties in order (lower block = LEFT operand of
@@ -498,17 +526,61 @@ __device__ __forceinline__ void root_box_fold(const double *__restrict__ seg, in
     }
 }
 
+// Trees of more than TOP_IN_BLOCK blocks (more than 1 M leaves): the levels k_cross_fused's first workgroup publishes for a small tree come from two
+// launches of their own in front of it -- a kernel boundary instead of the flag protocol; ~10 us against the 0.7 ms such a step takes.
+//   k_top_publish:       a workgroup per span of TOP_IN_BLOCK blocks folds the levels above the blocks up to the span's root (top32_to_lds)
+//                        and stores them at their heap positions in top_pub: local node k at depth d is heap node ((nspans + span) << d) + (k - 2^d);
+//   k_top_publish_upper: ONE workgroup folds the span roots (heap nodes [nspans, 2 nspans), nspans <= 1024: n <= 2^30) into the nodes [1, nspans)
+//                        and sets the flag word to this launch's sequence number (what k_cross_fused's lanes look for).
+__global__ __launch_bounds__(256) void k_top_publish(const float *__restrict__ seg32, int nbp2, int nblocks, unsigned long long *__restrict__ top_pub)
+{
+    __shared__ float top[6 * (TOP_IN_BLOCK / 4)];
+    const int span = blockIdx.x, nspans = nbp2 / TOP_IN_BLOCK, tid = threadIdx.x;
+    const int live = nblocks - span * TOP_IN_BLOCK;
+    auto heap = [&](int k) { const int d = 31 - __clz(k); return ((size_t)(nspans + span) << d) + (size_t)(k - (1 << d)); };   // local node k of the span -> heap node of the tree
+    top32_to_lds(top, seg32 + 6 * ((size_t)nbp2 + (size_t)span * TOP_IN_BLOCK), TOP_IN_BLOCK, live < 0 ? 0 : (live > TOP_IN_BLOCK ? TOP_IN_BLOCK : live),
+                 [&](int k, const B32 &v) { const U3 w = b32_words(v); unsigned long long *d = top_pub + 3 * heap(k); d[0] = w.a; d[1] = w.b; d[2] = w.c; });
+    for (int k = 1 + tid; k < TOP_IN_BLOCK / 4; k += 256) {
+        const size_t g = heap(k);
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(top + 6 * k);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) top_pub[3 * g + u] = src[u];
+    }
+}
+constexpr int TOP_MAX_SPANS = 1024;                                         // 2^30 leaves / 512 / TOP_IN_BLOCK
+__global__ __launch_bounds__(256) void k_top_publish_upper(unsigned long long *__restrict__ top_pub, int nspans, uint32_t *__restrict__ top_flag, uint32_t top_seq)
+{
+    __shared__ float h[2 * TOP_MAX_SPANS][6];
+    const int tid = threadIdx.x;
+    for (int k = nspans + tid; k < 2 * nspans; k += 256) {
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(h[k]);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) dst[u] = top_pub[3 * (size_t)k + u];
+    }
+    for (int w = nspans >> 1; w >= 1; w >>= 1) {                            // level of the nodes [w, 2 w)
+        __syncthreads();
+        for (int k = w + tid; k < 2 * w; k += 256) {
+            const B32 m = b32_merge(b32_load(h[2 * k]), b32_load(h[2 * k + 1]));
+            b32_store(h[k], m);
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(h[k]);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) top_pub[3 * (size_t)k + u] = src[u];
+        }
+    }
+    if (tid == 0) *top_flag = top_seq;
+}
+
 __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restrict__ keys, int n, const double *__restrict__ seg, const float *__restrict__ seg32,
                                                      int nbp2, int nblocks, const LeafBox32 *__restrict__ qbox32, double *__restrict__ boxes,
                                                      NodeRec32 *__restrict__ recs32, const int32_t *__restrict__ split_of, int32_t *__restrict__ root_name,
                                                      const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap,
                                                      unsigned long long *top_pub /* [3 * nbp2 / 4] the upper levels, published by workgroup 0 */, uint32_t *top_flag, uint32_t top_seq,
-                                                     uint32_t nord /* 0, or 8: the FIRST workgroups of the grid sort the groups' scores (k_build_block) into the half traversal's order hint,
-                                                                      one XCD list each (cd_bvh.h, build_half_order) -- beside this kernel's latency chain, in the dynamic LDS */,
+                                                     uint32_t nord /* 0, or 8 x chunks: the FIRST workgroups of the grid sort the groups' scores (k_build_block) into the half traversal's order hint,
+                                                                      one chunk of ORDER_MAX_ITEMS groups of one XCD list each (cd_bvh.h, build_half_order) -- beside this kernel's latency chain, in the dynamic LDS */,
                                                      uint32_t order_groups, const uint32_t *__restrict__ hint_cost, uint32_t *__restrict__ hint_order)
 {
     extern __shared__ float top[];                                          // workgroup 0 only: [max(nbp2 / 4, 1)][6], heap nodes [1, nbp2 / 4)
-    if (blockIdx.x < nord) { build_half_order<256>(blockIdx.x, order_groups, hint_cost, hint_order, *reinterpret_cast<OrderLds<256> *>(top)); return; }
+    if (blockIdx.x < nord) { build_half_order<256>(blockIdx.x & 7u, blockIdx.x >> 3, order_groups, hint_cost, hint_order, *reinterpret_cast<OrderLds<256> *>(top)); return; }
     const uint32_t bid = blockIdx.x - nord, nbid = gridDim.x - nord;       // (the roles below count without them)
     const int tid = threadIdx.x, lane = tid & 63, g = lane / XG, gl = lane % XG;
     // (a workgroup of its own, the last one of the grid: the fold is a chain of dependent loads, short against what the
@@ -521,8 +593,15 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
     // searches have taken longer than the fold -- and reads the node with agent-scope loads.  Round 2 and the first half of round 3 had
     // EVERY workgroup fold its own copy into LDS in front of its searches: 4.2 of the kernel's 24 us (and 48 KB of L2 reads a workgroup).
     if (bid == 0) {
-        top32_to_lds(top, seg32, nbp2, nblocks);
-        const int nn = nbp2 >> 2;                                           // heap nodes [1, nn)
+        if (nbp2 > TOP_IN_BLOCK) return;                                    // a large tree: k_top_publish + k_top_publish_upper have run in front of this launch
+        auto low = [&](int k, const B32 &v) {                               // (the two levels directly above the blocks go out as their thread forms them)
+            const U3 w = b32_words(v); unsigned long long *d = top_pub + 3 * (size_t)k;
+            __hip_atomic_store(d, w.a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(d + 1, w.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d + 2, w.c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (nbp2 < 8) top32_tiny(seg32 + 6 * (size_t)nbp2, nbp2, nblocks, low);
+        else top32_to_lds(top, seg32 + 6 * (size_t)nbp2, nbp2, nblocks, low);
+        const int nn = nbp2 < 8 ? 1 : nbp2 >> 2;                            // heap nodes [1, nn) are in LDS
         for (int k = 1 + tid; k < nn; k += 256) {
             const unsigned long long *src = reinterpret_cast<const unsigned long long *>(top + 6 * k);
 #pragma unroll
@@ -591,9 +670,9 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
         const int32_t soL = split_of[own && !leafL && !crossL ? split : 0], soR = split_of[own && !leafR && !crossR ? split + 1 : 0];
         // ---- the records: each group answers the two range queries of its own node.  A range [l, r] is the union of at most one
         // left and one right piece per level of the iterative bottom-up query; what a piece is made of depends on its level:
-        //   level 0: one leaf box (qbox32); levels 1 .. 9: one stored node of a block's tree (seg32); level 10 / 11: two / four block
-        //   boxes (the levels directly above the blocks are not stored anywhere); levels >= 12: one node of the LDS copy.
-        // The memory items of a child range are 20 + 4 + 8 = 32, of the node 64: lane gl fetches items gl and gl + 16 of either child
+        //   levels 0 .. 2: one / two / four leaf boxes (qbox32; round 5: k_build_block is bound by its writes, and the levels 1 and 2 of its trees were
+        //   18 bytes a leaf); levels 3 .. 9: one stored node of a block's tree (seg32); levels >= 10: one published node (top_pub).
+        // The memory items of a child range are 14 + 14 = 28, of the node 56: lane gl fetches items gl and gl + 16 of either child
         // -- four 24-byte loads per lane, all unconditional (an item that is not taken reads a valid dummy and is dropped), ONE round
         // trip for the whole group.  (Before: a lane per level and a branch per kind of level -- divergent branches run one after
         // the other, each with its own round trip: three of them on this kernel's critical path.)  The LDS levels keep the lane-per-
@@ -611,8 +690,8 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
             const int p = gl + 16 * sw;
             long long kk[4]; bool tk[4]; bool any_top = false;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { tk[u] = p > REFIT_LOG + 2 && piece(u >> 1, p, u & 1, kk[u]); any_top |= tk[u]; }
-            if (!__builtin_amdgcn_ballot_w64(any_top)) continue;            // (wave-uniform) nearly always: no range of 4096 leaves or more among the wave's four nodes
+            for (int u = 0; u < 4; ++u) { tk[u] = p > REFIT_LOG && piece(u >> 1, p, u & 1, kk[u]); any_top |= tk[u]; }
+            if (!__builtin_amdgcn_ballot_w64(any_top)) continue;            // (wave-uniform) no range among the wave's four nodes takes a piece of two blocks or more
             bool ready = !any_top;
 #ifdef CROSS_FORCE_FALLBACK                                                // (test builds: nobody sees the flag, every upper-level piece is folded by the lane that needs it)
             for (uint32_t spin = 0; spin < 0u; ++spin) {
@@ -641,24 +720,25 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
             }
         }
         {
-            static_assert(SEG32_MIN_LEVEL == 1 && XG == 16 && REFIT_LOG == 9, "the item numbering below: levels 1 .. REFIT_LOG of a block's tree are in seg32, 16 lanes a node; items 0..19 = levels 0..REFIT_LOG (20 == 2 * (REFIT_LOG + 1)), 20..23 level 10, 24..31 level 11");
+            // items of a child range: the levels below SEG32_MIN_LEVEL leaf by leaf (level p: 2 sides x 2^p leaves, items 2^(p+1) - 2 ...), then one item
+            // per side of the levels SEG32_MIN_LEVEL .. REFIT_LOG of a block's tree (seg32); levels above the blocks: the published nodes (above)
+            constexpr int SMIN = SEG32_MIN_LEVEL, LEAF_ITEMS = 2 * ((1 << SMIN) - 1), N_ITEMS = LEAF_ITEMS + 2 * (REFIT_LOG + 1 - SMIN);
+            static_assert(XG == 16 && N_ITEMS <= 2 * XG, "a lane fetches items gl and gl + 16 of either child");
             B32 it[4]; bool tk[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int h = r >> 1, t = gl + 16 * (r & 1);                // item t of child h
-                const int p = t < 20 ? (t >> 1) : (t < 24 ? REFIT_LOG + 1 : REFIT_LOG + 2);
-                const int side = t < 20 ? (t & 1) : (t < 24 ? ((t - 20) >> 1) : ((t - 24) >> 2));
-                const int e = t < 20 ? 0 : (t < 24 ? ((t - 20) & 1) : ((t - 24) & 3));
+                int p, side, e;
+                if (t < LEAF_ITEMS) { const int lg = 31 - __clz(t + 2); p = lg - 1; const int idx = t + 2 - (1 << lg); side = idx >> p; e = idx & ((1 << p) - 1); }
+                else { const int u = t - LEAF_ITEMS; p = SMIN + (u >> 1); side = u & 1; e = 0; if (p > REFIT_LOG) p = REFIT_LOG; }
                 long long k;
-                bool take = piece(h, p, side, k);
+                bool take = t < N_ITEMS && piece(h, p, side, k);
                 const float *ptr;
-                if (p == 0) ptr = reinterpret_cast<const float *>(qbox32 + (take ? (k - P) : 0));              // (the leaf's fp32 box: the first 24 bytes of its 32)
-                else if (p <= REFIT_LOG) ptr = seg32 + 6 * (size_t)(take ? k : (P >> p));
-                else {
-                    const long long b = take ? ((k << (p - REFIT_LOG)) - nbp2 + e) : 0;
-                    take = take && b < nblocks;                             // (a block past the end: nothing there)
-                    ptr = seg32 + 6 * ((size_t)nbp2 + (take ? b : 0));
-                }
+                if (p < SMIN) {
+                    const long long jj = take ? ((k << p) - P + e) : 0;     // leaf e of the piece (the leaf's fp32 box: the first 24 bytes of its 32)
+                    take = take && jj < n;                                  // (past the last leaf: nothing there)
+                    ptr = reinterpret_cast<const float *>(qbox32 + (take ? jj : 0));
+                } else ptr = seg32 + 6 * (size_t)(take ? k : (P >> p));
                 tk[r] = take;
                 it[r] = b32_load(ptr);
             }

@@ -182,19 +182,23 @@ __host__ __device__ __forceinline__ uint32_t half_vblock_hd(uint32_t b, uint32_t
 // A hint only: tri_cost[] may hold anything (zeros in the first step) -- order[] is a permutation whatever it holds, and any permutation gives the same results.
 // tools/hint_predictors.py (orders installed from outside): sheet B moving 0.25 / 1 / 4 quads a frame, descent 53.5 us in the index order, 47.5 with the frame's
 // OWN times (a perfect predictor), 55 by position, 49.8 / 48.7 / 53.8 by triangle with the max (51 / 51 / 54 with the mean).
-// One workgroup of T threads per XCD list (x = 0 .. 7), in LDS the caller lends it (OrderLds<T>); lists of more than ORDER_MAX_ITEMS groups are left in
-// half_vblock's order (the host does not ask for a hint then: k_cross_fused serves trees of up to 2048 blocks = 1 M leaves = 2048 groups a list).  A stable counting
+// One workgroup of T threads per XCD list (x = 0 .. 7) and chunk of ORDER_MAX_ITEMS list positions, in LDS the caller lends it (OrderLds<T>).  A stable counting
 // sort in five barriers: the scores of the list into LDS (one gather), a count per thread and class over the thread's run of consecutive items, a scan down each
 // class's column, the items placed run by run.
 constexpr int ORDER_CLASSES = 32, ORDER_SHIFT = 7 /* 2^7 ticks of the 100 MHz wall clock */, ORDER_MAX_ITEMS = 2048;
 template <int T> struct OrderLds { uint8_t cls[ORDER_MAX_ITEMS]; uint16_t cnt[T][ORDER_CLASSES]; uint32_t base[ORDER_CLASSES]; };
+// (round 5) A list of more than ORDER_MAX_ITEMS groups -- a tree of more than 1 M leaves -- is sorted CHUNK by chunk of ORDER_MAX_ITEMS consecutive list
+// positions, a workgroup each: the descent works a chunk's groups off longest first, and what decides when the kernel ends, the last chunk, is packed like a small tree's list.
 template <int T>
-__device__ __forceinline__ void build_half_order(uint32_t x, uint32_t nb, const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, OrderLds<T> &L)
+__device__ __forceinline__ void build_half_order(uint32_t x, uint32_t chunk, uint32_t nb, const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, OrderLds<T> &L)
 {
     const uint32_t tid = threadIdx.x;
-    const uint32_t cnt = x < nb ? (nb - x + 7u) / 8u : 0u;                   // workgroups b = 8 l + x < nb
-    if (cnt > (uint32_t)ORDER_MAX_ITEMS) { for (uint32_t l = tid; l < cnt; l += T) order[8u * l + x] = half_vblock(8u * l + x, nb); return; }
-    for (uint32_t l = tid; l < cnt; l += T) { const uint32_t c = cost[half_vblock(8u * l + x, nb)]; L.cls[l] = (uint8_t)(c < ORDER_CLASSES ? c : ORDER_CLASSES - 1); }
+    const uint32_t all = x < nb ? (nb - x + 7u) / 8u : 0u;                   // workgroups b = 8 l + x < nb
+    const uint32_t lbase = chunk * (uint32_t)ORDER_MAX_ITEMS;                // this chunk: list positions lbase .. lbase + cnt - 1
+    const uint32_t cnt = all > lbase ? (all - lbase < (uint32_t)ORDER_MAX_ITEMS ? all - lbase : (uint32_t)ORDER_MAX_ITEMS) : 0u;
+    order += 8u * lbase; 
+    auto vb = [&](uint32_t l) { return half_vblock(8u * (lbase + l) + x, nb); };
+    for (uint32_t l = tid; l < cnt; l += T) { const uint32_t c = cost[vb(l)]; L.cls[l] = (uint8_t)(c < ORDER_CLASSES ? c : ORDER_CLASSES - 1); }
     for (int k = 0; k < ORDER_CLASSES; ++k) L.cnt[tid][k] = 0;
     __syncthreads();
     const uint32_t per = (cnt + T - 1) / T, l0 = tid * per < cnt ? tid * per : cnt, l1 = l0 + per < cnt ? l0 + per : cnt;   // this thread's run of the list
@@ -211,7 +215,7 @@ __device__ __forceinline__ void build_half_order(uint32_t x, uint32_t nb, const 
     __syncthreads();
     if (tid < ORDER_CLASSES) L.base[tid] = before;
     __syncthreads();
-    for (uint32_t l = l0; l < l1; ++l) { const uint32_t c = L.cls[l]; const uint32_t pos = L.base[c] + L.cnt[tid][c]++; order[8u * pos + x] = half_vblock(8u * l + x, nb); }
+    for (uint32_t l = l0; l < l1; ++l) { const uint32_t c = L.cls[l]; const uint32_t pos = L.base[c] + L.cnt[tid][c]++; order[8u * pos + x] = vb(l); }
 }
 
 // Sorted-order leaf payload: {ID, vIdx[0..2]} (triangle.cuh:6,9) -- 16 B instead of the 56-byte Triangle.
@@ -571,7 +575,7 @@ constexpr int REFIT_BLK = 512;     // leaves per workgroup
 constexpr int REFIT_LOG = 9;
 constexpr int SEG_MIN_LEVEL = 3;   // lowest level of the segment tree that is stored in memory (see seg_piece)
 #ifndef SEG32_MIN
-#define SEG32_MIN 1
+#define SEG32_MIN 3
 #endif
 constexpr int SEG32_MIN_LEVEL = SEG32_MIN;   // the same for the fp32 trees of the fused build (seg32): its lower levels are 24 bytes a node, and every level
                                      // that is not stored is a dependent gather of 2^level leaf boxes on the cross nodes' critical path

@@ -106,12 +106,28 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_hist(const uint64_t *__rest
     }
 }
 
+// The per-tile digit counts of k_morton summed over chunks of OS_CHUNK tiles, for sorts of more than OS_CHUNK_MIN_TILES tiles (k_os_pass, first pass): a workgroup
+// per chunk, a thread per digit, the chunk's rows in flight together.
+constexpr int OS_CHUNK = 32, OS_CHUNK_MIN_TILES = 512;
+__global__ __launch_bounds__(RADIX) void k_tile_chunks(const uint32_t *__restrict__ tile_hist, uint32_t ntiles, uint32_t *__restrict__ chunk_tot)
+{
+    const uint32_t c = blockIdx.x, d = threadIdx.x, t0 = c * OS_CHUNK;
+    uint32_t v[OS_CHUNK];
+#pragma unroll
+    for (int u = 0; u < OS_CHUNK; ++u) v[u] = t0 + u < ntiles ? tile_hist[(size_t)(t0 + u) * RADIX + d] : 0u;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int u = 0; u < OS_CHUNK; ++u) sum += v[u];
+    chunk_tot[(size_t)c * RADIX + d] = sum;
+}
+
 __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                           uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                           uint32_t n, int shift, const uint32_t *__restrict__ digit_hist /* [256] raw counts of this digit, hist_copies partial tables HIST_STRIDE words apart */,
                                                           unsigned long long *lookback /* [ntiles][256] */, uint32_t *ticket /* [pass]; ticket[8 - pass] = timeout flag */, int first_pass, int hist_copies,
                                                           const uint32_t *__restrict__ tile_hist /* NULL, or [ntiles][256]: this digit's counts per INPUT tile, left by the kernel that wrote the keys
-                                                                                                    (k_morton): the tile offsets are their sums, no look-back */)
+                                                                                                    (k_morton): the tile offsets are their sums, no look-back */,
+                                                          const uint32_t *__restrict__ chunk_tot /* NULL, or [ntiles / OS_CHUNK][256]: the same counts summed over chunks of OS_CHUNK tiles (k_tile_chunks) */)
 {
     __shared__ uint32_t wcnt[OS_WAVES][RADIX];
     __shared__ uint32_t gbase[RADIX];
@@ -139,18 +155,26 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
     // The first global pass of a sort whose keys come with per-tile digit counts (k_morton): how many keys of digit d the EARLIER
     // tiles hold is a sum over rows that were complete before this kernel started -- plain loads, no dependence between the tiles of
     // this pass at all, where the look-back below is a rendezvous of all of them (~9 us of a 17 us pass at 245 tiles).
+    // (round 5) The sum over ALL earlier tiles is quadratic in the number of tiles: 30 MB of L2 reads at 1 M keys (245 tiles), 1.9 GB at 8 M -- that pass took 113 us
+    // there, longer than the pass WITH look-back.  Beyond OS_CHUNK_MIN_TILES tiles a small kernel in front (k_tile_chunks) sums the rows of every chunk of OS_CHUNK
+    // tiles; a tile then adds the totals of the chunks before its own and the rows of the earlier tiles of its own chunk.
     if (tile_hist) {
-        // 64 lanes x 4 digits cover a row (16-byte loads), the 16 waves take every 16th earlier tile, four rows in flight per lane
-        const uint4 *rows = reinterpret_cast<const uint4 *>(tile_hist);
+        // 64 lanes x 4 digits cover a row (16-byte loads), the 16 waves take every 16th row, four rows in flight per lane
         uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, a2 = a0, a3 = a0;
-        uint32_t t2 = (uint32_t)w;
-        for (; t2 + 3u * OS_WAVES < tile; t2 += 4u * OS_WAVES) {
-            const uint4 r0 = rows[(size_t)t2 * (RADIX / 4) + lane], r1 = rows[(size_t)(t2 + OS_WAVES) * (RADIX / 4) + lane];
-            const uint4 r2 = rows[(size_t)(t2 + 2u * OS_WAVES) * (RADIX / 4) + lane], r3 = rows[(size_t)(t2 + 3u * OS_WAVES) * (RADIX / 4) + lane];
-            a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w; a1.x += r1.x; a1.y += r1.y; a1.z += r1.z; a1.w += r1.w;
-            a2.x += r2.x; a2.y += r2.y; a2.z += r2.z; a2.w += r2.w; a3.x += r3.x; a3.y += r3.y; a3.z += r3.z; a3.w += r3.w;
-        }
-        for (; t2 < tile; t2 += OS_WAVES) { const uint4 r0 = rows[(size_t)t2 * (RADIX / 4) + lane]; a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w; }
+        auto add_rows = [&](const uint32_t *table, uint32_t from, uint32_t to) {
+            const uint4 *rows = reinterpret_cast<const uint4 *>(table);
+            uint32_t t2 = from + (uint32_t)w;
+            for (; t2 + 3u * OS_WAVES < to; t2 += 4u * OS_WAVES) {
+                const uint4 r0 = rows[(size_t)t2 * (RADIX / 4) + lane], r1 = rows[(size_t)(t2 + OS_WAVES) * (RADIX / 4) + lane];
+                const uint4 r2 = rows[(size_t)(t2 + 2u * OS_WAVES) * (RADIX / 4) + lane], r3 = rows[(size_t)(t2 + 3u * OS_WAVES) * (RADIX / 4) + lane];
+                a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w; a1.x += r1.x; a1.y += r1.y; a1.z += r1.z; a1.w += r1.w;
+                a2.x += r2.x; a2.y += r2.y; a2.z += r2.z; a2.w += r2.w; a3.x += r3.x; a3.y += r3.y; a3.z += r3.z; a3.w += r3.w;
+            }
+            for (; t2 < to; t2 += OS_WAVES) { const uint4 r0 = rows[(size_t)t2 * (RADIX / 4) + lane]; a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w; }
+        };
+        const uint32_t own = chunk_tot ? tile / (uint32_t)OS_CHUNK : 0u;     // (workgroup-uniform)
+        if (chunk_tot) add_rows(chunk_tot, 0u, own);
+        add_rows(tile_hist, own * (uint32_t)OS_CHUNK, tile);
         reinterpret_cast<uint4 *>(&tpart[w][0])[lane] = make_uint4(a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y, a0.z + a1.z + a2.z + a3.z, a0.w + a1.w + a2.w + a3.w);
     }
 

@@ -73,6 +73,7 @@ struct cd_ctx {
     // sort
     uint64_t *d_keys[2] = {nullptr, nullptr}; uint32_t *d_perm[2] = {nullptr, nullptr};
     uint32_t *d_counts = nullptr; uint32_t ntiles = 0;
+    uint32_t *d_chunk_tot = nullptr;        // d_counts summed over chunks of OS_CHUNK tiles (sorts of more than OS_CHUNK_MIN_TILES tiles: k_tile_chunks)
     // onesweep state, part of one scratch block (layout: cd_create): [8][256] u32 histograms | 8 u32 tickets (padded) | [8][ntiles][256] u64 granules
     void *d_os = nullptr; size_t os_bytes = 0 /* whole block */, zero_bytes = 0 /* its front part: all a fused call with the hybrid sort needs zeroed */, sort_hi_bytes = 0 /* of that, the sort's own */;
     unsigned long long *d_os_look_lo = nullptr;   // granules of the digit passes 0..5 (behind the front part); d_os_look: passes 6 and 7
@@ -111,6 +112,7 @@ struct cd_ctx {
     bool leaves_filled = false;             // the sort's fix-up hop already wrote leaf[], parent = -1, bounded = 0
     bool events_ride = false;               // the last pass recorded EV_TRAV0 / EV_DESC1 / EV_TRAV1 through its kernels' dispatch packets
     uint32_t dbg_report_copies = 0;        // CD_DBG_REPORT_COPIES: the report kernel copies the first pairs to the host (32 workgroups) instead of the exact kernel posting them (A/B)
+    bool order_hint_large = false;          // CD_OPT_ORDER_HINT 2: also for trees of more than 1 M leaves (sorted chunk by chunk; measured slower there)
     bool order_hint = true;                 // CD_OPT_ORDER_HINT: the half traversal takes its groups of 64 leaves longest-first, by the previous step's times (cd_bvh.h, build_half_order)
     bool order_ready = false;               // d_order holds THIS tree's order hint (its fused build has made it)
     uint32_t *d_cost = nullptr, *d_order = nullptr;   // per group of 64 leaves: the score k_build_block gives it (max of its triangles' time classes); the order made from the scores
@@ -144,15 +146,17 @@ struct cd_ctx {
 
 namespace {
 
-// k_cross_fused's published upper levels (24 bytes a node, heap nodes [1, TOP_IN_BLOCK / 4)) and, behind them, the flag word
-constexpr size_t TOP_PUB_BYTES = sizeof(unsigned long long) * 3 * (TOP_IN_BLOCK / 4) + 64;
-uint32_t *top_flag_of(cd_ctx *c) { return reinterpret_cast<uint32_t *>(c->d_top_pub + 3 * (TOP_IN_BLOCK / 4)); }
+// k_cross_fused's published levels above the blocks (24 bytes a node, heap nodes [1, nbp2)) and, behind them, the flag word
+// (a tree of more than TOP_IN_BLOCK blocks: from k_top_publish / k_top_publish_upper)
+size_t top_pub_nodes(const cd_ctx *c) { return std::max<size_t>(TOP_IN_BLOCK, c->nbp2); }
+size_t top_pub_bytes(const cd_ctx *c) { return sizeof(unsigned long long) * 3 * top_pub_nodes(c) + 64; }
+uint32_t *top_flag_of(cd_ctx *c) { return reinterpret_cast<uint32_t *>(c->d_top_pub + 3 * top_pub_nodes(c)); }
 
 void free_all(cd_ctx *c)
 {
     hipFree(c->d_verts); hipFree(c->d_vidx); hipFree(c->d_ids);
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
-    hipFree(c->d_counts); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
+    hipFree(c->d_counts); hipFree(c->d_chunk_tot); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_top_pub); hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_seg32); hipFree(c->d_cross); hipFree(c->d_boxes);
     hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox); hipFree(c->d_split_of); hipFree(c->d_cost); hipFree(c->d_order); hipFree(c->d_tri_cost);
     hipFree(c->d_amb_keys); hipFree(c->d_amb_flag); hipFree(c->d_vamb);
@@ -341,11 +345,15 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
                                                 auto_frame ? c->d_partial : nullptr, (uint32_t)BOUNDS_BLOCKS, c->d_frame, nullptr, c->d_counts);
     HIPCHK(evrec(c, EV_MORTON1));
     // onesweep: one pass over the data per digit; the digit histograms came with the keys
+    // (more than 512 tiles: the first pass adds up chunk totals of the per-tile counts instead of every earlier tile's row -- cd_sort.h)
+    const bool chunked = c->ntiles > (uint32_t)OS_CHUNK_MIN_TILES;
+    if (chunked) k_tile_chunks<<<cdiv(c->ntiles, (uint32_t)OS_CHUNK), RADIX, 0, s>>>(c->d_counts, c->ntiles, c->d_chunk_tot);
     for (int pass = first_digit; pass < 8; ++pass) {
         k_os_pass<<<c->ntiles, OS_THREADS, 0, s>>>(c->d_keys[cur], c->d_perm[cur], c->d_keys[cur ^ 1], c->d_perm[cur ^ 1], n, pass * RADIX_BITS - down,
                                                     c->d_os_hist + pass * RADIX,
                                                     (pass >= 6 ? c->d_os_look + (size_t)(pass - 6) * c->ntiles * RADIX : c->d_os_look_lo + (size_t)pass * c->ntiles * RADIX),
-                                                    c->d_os_ticket + pass, pass == first_digit, HIST_COPIES, pass == first_digit ? c->d_counts : nullptr);
+                                                    c->d_os_ticket + pass, pass == first_digit, HIST_COPIES, pass == first_digit ? c->d_counts : nullptr,
+                                                    pass == first_digit && chunked ? c->d_chunk_tot : nullptr);
         cur ^= 1;
     }
     c->leaves_filled = false; c->leaf_records_filled = false;
@@ -415,9 +423,11 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
                           reinterpret_cast<uint4 *>(c->d_os_look), (uint32_t)(2 * gran / sizeof(uint4)),
                           reinterpret_cast<uint32_t *>(c->tb[0].d_state), (uint32_t)(sizeof(TravState) / sizeof(uint32_t)), top_flag_of(c)};
         }
-        const int seg_min = (c->nbp2 > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK && !c->dbg_split_cross) ? SEG32_MIN_LEVEL : SEG_MIN_LEVEL;
+        const int seg_min = (c->nbp2 > 1 && !c->dbg_split_cross) ? SEG32_MIN_LEVEL : SEG_MIN_LEVEL;
         // the half traversal's order hint (cd_bvh.h): this kernel scores the groups of 64 leaves, 8 workgroups of k_cross_fused sort them -- for trees that kernel serves
-        const bool hint = c->order_hint && c->trav_variant >= 3 && n > 64u && c->nbp2 > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK && !c->dbg_split_cross;
+        // (trees of more than TOP_IN_BLOCK blocks -- more than 1 M leaves -- only with CD_OPT_ORDER_HINT 2: their descent runs many rounds of waves, the tail the hint packs is a
+        //  tenth of it and the locality it gives up costs more -- 4 M cloth 173 -> 176 us, 8 M 454 -> 471 us with the hint)
+        const bool hint = c->order_hint && c->trav_variant >= 3 && n > 64u && c->nbp2 > 1 && !c->dbg_split_cross && (c->nbp2 <= (uint32_t)TOP_IN_BLOCK || c->order_hint_large);
         const uint32_t *hp = hint ? c->d_perm[0] : nullptr; const uint8_t *ht = hint ? c->d_tri_cost : nullptr; uint32_t *hc = hint ? c->d_cost : nullptr;
         if (stamp)
             hipExtLaunchKernelGGL(k_build_block, dim3(nblocks), dim3(REFIT_BLK), 0u, s, c->ev[EV_BLK0], c->ev[EV_BLK1], 0u,
@@ -434,18 +444,25 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded,
                                                        c->d_recs32, c->d_qbox, c->d_root, write_internal ? 1 : 0, c->d_seg, (int)c->nbp2,
                                                        cross_list, cross_count, c->cross_cap, c->amb, (const uint8_t *)c->vamb);
-    // fused build, a tree of 2 .. 2048 blocks: the cross nodes' ranges, splits, links and records in ONE launch (k_cross_fused, cd_build.h)
-    if (fused && n > 1 && c->nbp2 > 1 && c->nbp2 <= (uint32_t)TOP_IN_BLOCK && !c->dbg_split_cross) {
+    // fused build, a tree of 2 blocks or more: the cross nodes' ranges, splits, links and records in ONE launch (k_cross_fused, cd_build.h)
+    if (fused && n > 1 && c->nbp2 > 1 && !c->dbg_split_cross) {
         const uint32_t xb = (uint32_t)nblocks < 8u ? 8u : ((uint32_t)nblocks > 1790u ? 1790u : (uint32_t)nblocks);   // 16 nodes per workgroup and round, ~13 per block; with the two workgroups below at most what the chip holds at once (7 workgroups per CU)
         // (the multi-GPU step's "tree is there" event rides on this kernel's dispatch packet: recorded on its own it is a barrier
         //  packet between the tree and the traversal, ~6 us of idle GPU)
         hipEvent_t done = c->tree_done_event; c->tree_done_event = nullptr;
-        const uint32_t nord = c->order_pending ? 8u : 0u, ogroups = (n + 63u) / 64u;
+        const uint32_t ogroups = (n + 63u) / 64u;
+        const uint32_t nord = c->order_pending ? 8u * (((ogroups + 7u) / 8u + (uint32_t)ORDER_MAX_ITEMS - 1u) / (uint32_t)ORDER_MAX_ITEMS) : 0u;   // a workgroup per XCD list and chunk of it
         c->order_pending = false;
-        const uint32_t xlds = std::max((uint32_t)(sizeof(float) * 6 * (c->nbp2 >= 4 ? c->nbp2 / 4 : 1)) /* (used by the publishing workgroup only) */,
-                                       nord ? (uint32_t)sizeof(OrderLds<256>) : 0u /* (the order hint's 8 workgroups) */);
+        const bool large = c->nbp2 > (uint32_t)TOP_IN_BLOCK;                // the upper levels come from launches of their own (below)
+        const uint32_t xlds = std::max((uint32_t)(large ? 64u : sizeof(float) * 6 * (c->nbp2 >= 4 ? c->nbp2 / 4 : 1)) /* (used by the publishing workgroup only) */,
+                                       nord ? (uint32_t)sizeof(OrderLds<256>) : 0u /* (the order hint's workgroups) */);
         uint32_t *top_flag = top_flag_of(c);
         if (++c->top_seq == 0u) ++c->top_seq;                               // (never 0: what k_build_block leaves in the flag word)
+        if (large) {
+            const int nspans = (int)(c->nbp2 / (uint32_t)TOP_IN_BLOCK);
+            k_top_publish<<<nspans, 256, 0, s>>>(c->d_seg32, (int)c->nbp2, nblocks, c->d_top_pub);
+            k_top_publish_upper<<<1, 256, 0, s>>>(c->d_top_pub, nspans, top_flag, c->top_seq);
+        }
         if (done)
             hipExtLaunchKernelGGL(k_cross_fused, dim3(nord + xb + 2u /* [the order hint's 8,] then: the first workgroup publishes the upper levels, the last folds the FP64 box of all leaves */), dim3(256), xlds, s, nullptr, done, 0u,
                                   (const uint64_t *)c->d_keys[0], (int)n, (const double *)c->d_seg, (const float *)c->d_seg32, (int)c->nbp2, nblocks, (const LeafBox32 *)c->d_qbox, c->d_boxes,
@@ -539,7 +556,8 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
         if (half_mode && !DEEP) {
             const dim3 hgrid(cdiv(items, 64u)), hblock(HALF_THREADS);
             const uint32_t *h_order = (c->order_hint && c->order_ready) ? c->d_order : nullptr;      // (the order hint: cd_bvh.h, build_half_order)
-            const uint32_t *h_perm = c->order_hint ? c->d_perm[0] : nullptr; uint8_t *h_tri = c->order_hint ? c->d_tri_cost : nullptr;
+            const bool h_rec = c->order_hint && (c->nbp2 <= (uint32_t)TOP_IN_BLOCK || c->order_hint_large);      // (the waves leave their times only where a build will read them)
+            const uint32_t *h_perm = h_rec ? c->d_perm[0] : nullptr; uint8_t *h_tri = h_rec ? c->d_tri_cost : nullptr;
 #define LAUNCH_HALF(DIAG, TIES)                                                                                                             \
             do { if (plain) k_descend_half<DIAG, TIES><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, h_order, h_perm, h_tri); \
                  else hipExtLaunchKernelGGL((k_descend_half<DIAG, TIES>), hgrid, hblock, (uint32_t)pad, s, e0, e1, 0u, src, n, (const NodeRec32 *)c->d_recs32, \
@@ -827,7 +845,7 @@ int pp_sort(cd_ctx *c, uint32_t m)
     int cur = 0;
     for (int pass = 0; pass < 8; ++pass) {
         k_os_pass<<<ntiles, OS_THREADS, 0, s>>>(c->pp_keys[cur], c->pp_vals[cur], c->pp_keys[cur ^ 1], c->pp_vals[cur ^ 1], m, pass * RADIX_BITS,
-                                                hist + pass * RADIX, look + (size_t)pass * ntiles * RADIX, ticket + pass, pass == 0, 1, nullptr);
+                                                hist + pass * RADIX, look + (size_t)pass * ntiles * RADIX, ticket + pass, pass == 0, 1, nullptr, nullptr);
         cur ^= 1;
     }
     return 0;
@@ -995,6 +1013,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     if (ids) ALLOC(c->d_ids, sizeof(uint32_t) * n);
     for (int i = 0; i < 2; ++i) { ALLOC(c->d_keys[i], sizeof(uint64_t) * n); ALLOC(c->d_perm[i], sizeof(uint32_t) * n); }
     ALLOC(c->d_counts, sizeof(uint32_t) * RADIX * c->ntiles);
+    ALLOC(c->d_chunk_tot, sizeof(uint32_t) * RADIX * cdiv(c->ntiles, (uint32_t)OS_CHUNK));
     // one scratch block so that the fused pipeline zeroes everything with ONE memset, and as little as the sort form needs:
     //   [onesweep: histograms | tickets, flags | look-back granules of passes 6, 7] [small counters: 128 words] [TravState]   <- hybrid sort: this much
     //   [look-back granules of passes 0..5]                                                                                  <- the other forms: all of it
@@ -1022,8 +1041,8 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_parent, sizeof(int32_t) * 2 * n);
     { uint32_t nb = cdiv(nt, REFIT_BLK); c->nbp2 = 1; while (c->nbp2 < nb) c->nbp2 <<= 1; }
     ALLOC(c->d_seg, sizeof(double) * 6 * (size_t)c->nbp2 * REFIT_BLK);
-    ALLOC(c->d_top_pub, TOP_PUB_BYTES);
-    if (hipMemset(c->d_top_pub, 0, TOP_PUB_BYTES) != hipSuccess) { free_all(c); delete c; return -(int)hipGetLastError(); }
+    ALLOC(c->d_top_pub, top_pub_bytes(c));
+    if (hipMemset(c->d_top_pub, 0, top_pub_bytes(c)) != hipSuccess) { free_all(c); delete c; return -(int)hipGetLastError(); }
     ALLOC(c->d_seg32, sizeof(float) * 6 * ((size_t)c->nbp2 << (REFIT_LOG - SEG32_MIN_LEVEL + 1)));   // fused build: levels SEG32_MIN_LEVEL .. 9 of the blocks' fp32 trees
     c->cross_cap = nt;                                  // every internal node could be one (it never is: about 2 %)
     ALLOC(c->d_cross, sizeof(int32_t) * (size_t)c->cross_cap);
@@ -1535,7 +1554,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
         c->stage = ST_CREATED; c->root_box_valid = false;                  // the records of the tree that is there were encoded the other way
         return amb_refresh(c);
     }
-    if (key == CD_OPT_ORDER_HINT) { c->order_hint = value != 0; c->order_ready = false; c->order_pending = false; graph_drop(c); return CD_OK; }       // (a captured step has its launches baked in)
+    if (key == CD_OPT_ORDER_HINT) { c->order_hint = value != 0; c->order_hint_large = value == 2; c->order_ready = false; c->order_pending = false; graph_drop(c); return CD_OK; }       // (a captured step has its launches baked in)
     if (key == CD_OPT_KERNEL_STAMPS) { if (value < 0 || value > 15) return CD_ERR_ARG; c->stamp_mask = (uint32_t)value; return CD_OK; }
     return CD_ERR_ARG;
 }

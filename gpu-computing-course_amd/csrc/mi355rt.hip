@@ -45,7 +45,14 @@ __device__ __forceinline__ void prepare_one(const RtSphere *__restrict__ s, cons
 // n = dz / sqrtf(r*r) and the three colour products (sphere.cuh:41, anime_ray.cu:77-80) depend on nothing but the
 // winning sphere, so they are evaluated once per pixel after the loop instead of once per hit (same operands, same
 // operations, same bits).  That takes the IEEE division and the shade fetch out of the divergent hit branch.
-struct Px { float maxz, dz; int win; };
+// Round 5: the depth is LAZY too.  A pixel's first hit wins whatever its t is (t = dz + z > -INF = -2e10f, anime_ray.cu:69,75, as soon
+// as dz is a number and z is not absurd), so it only leaves the square root's ARGUMENT and the sphere's z behind; sqrtf and the sum are
+// evaluated when a SECOND sphere covers the pixel (both then, compared as before) or in the epilogue -- the very operations on the very
+// operands, once per covered pixel instead of once per (sphere, pixel).  Most covered pixels of a frame see one sphere: the ~35-instruction
+// branch that every lane of a wave walks through when one of them is inside a disc shrinks to three selects.
+//   win < 0: no hit yet (b = -INF);  win & PX_LAZY: a = rr - dx2 - dy2, b = the sphere's z;  else: a = dz, b = t (the running maximum)
+struct Px { float b, a; int win; };
+constexpr int PX_LAZY = 0x40000000;
 
 // One sphere against one pixel: sphere.cuh:36-43 + anime_ray.cu:75-81.
 __device__ __forceinline__ void shade_one(Px &p, float ox, float oy, const SphGeom g, int i)
@@ -54,12 +61,16 @@ __device__ __forceinline__ void shade_one(Px &p, float ox, float oy, const SphGe
     const float dy = oy - g.cy;
     const float dx2 = dx * dx, dy2 = dy * dy;
     if (dx2 + dy2 < g.rr) {
-        const float dz = sqrtf(g.rr - dx2 - dy2);
-        const float t = dz + g.z;
-        // anime_ray.cu:75 is a strict > in ascending sphere order, i.e. the lowest index wins a tie; stated
-        // explicitly so that the spheres may arrive in any order (binned lists are unordered)
-        // (a branch-free form of this -- bitwise | and &, three selects -- measured the same: 30.6 vs 30.8 us per frame)
-        if (t > p.maxz || (t == p.maxz && i < p.win)) { p.maxz = t; p.dz = dz; p.win = i; }
+        const float arg = g.rr - dx2 - dy2;
+        if (p.win < 0 && arg >= 0.f && g.z > -1e10f) { p.a = arg; p.b = g.z; p.win = i | PX_LAZY; }   // t >= z > -2e10f: it wins against "nothing yet"
+        else {
+            if (p.win >= 0 && (p.win & PX_LAZY)) { const float dz0 = sqrtf(p.a); p.b = dz0 + p.b; p.a = dz0; p.win &= ~PX_LAZY; }
+            const float dz = sqrtf(arg);
+            const float t = dz + g.z;
+            // anime_ray.cu:75 is a strict > in ascending sphere order, i.e. the lowest index wins a tie; stated
+            // explicitly so that the spheres may arrive in any order (binned lists are unordered)
+            if (t > p.b || (t == p.b && i < p.win)) { p.b = t; p.a = dz; p.win = i; }
+        }
     }
 }
 
@@ -69,8 +80,9 @@ __device__ __forceinline__ uint32_t pack_px(const Px &p, const SphShade *__restr
     // pixels of a frame are such (the compiler skips the block below for a whole wave when none of its lanes has a hit)
     uint32_t out = 255u << 24;
     if (p.win >= 0) {
-        const SphShade h = shade[p.win];
-        const float n = p.dz / h.sr;                                                   // sphere.cuh:41
+        const SphShade h = shade[p.win & ~PX_LAZY];
+        const float dz = (p.win & PX_LAZY) ? sqrtf(p.a) : p.a;                         // sphere.cuh:40
+        const float n = dz / h.sr;                                                     // sphere.cuh:41
         const float r = h.r * n, g = h.g * n, b = h.b * n;                             // anime_ray.cu:77-79
         // anime_ray.cu:84-87: (int)(c * 255) stored to unsigned char; alpha 255
         const uint32_t ri = (uint32_t)(unsigned char)(int)(r * 255);

@@ -101,6 +101,23 @@ def cloth_shard(rank: int, quads: int = 500, overlap: float = 0.10):
     return verts, vidx, ids, rank * verts.shape[0]
 
 
+def config4_merged(world: int = 8, quads: int = 500, overlap: float = 0.10):
+    """BASELINE config 4's eight shards as ONE mesh (the single-GPU point a scaling curve is read against): the concatenation of
+    cloth_shard(0..world-1) with global vertex indices and triangle IDs, and the Morton frame of the merged centroids
+    (off = min, span = (max - min)(1 + 2^-20): what CD_FRAME_AUTO computes).  Returns (verts, vidx, ids, off, span)."""
+    vs, ts, ids = [], [], []
+    for r in range(world):
+        v, t, i, vb = cloth_shard(r, quads, overlap)
+        vs.append(v); ts.append(t + np.uint32(vb)); ids.append(i)
+    verts = np.concatenate(vs); vidx = np.ascontiguousarray(np.concatenate(ts).astype(np.uint32)); ids = np.concatenate(ids).astype(np.uint32)
+    lo = np.full(3, np.inf); hi = np.full(3, -np.inf)
+    for a in range(0, vidx.shape[0], 1 << 20):                       # centroids as the library forms them, (p1 + p2 + p3) / 3, in slabs
+        t = vidx[a:a + (1 << 20)]
+        cen = (verts[t[:, 0]] + verts[t[:, 1]] + verts[t[:, 2]]) / 3
+        lo = np.minimum(lo, cen.min(0)); hi = np.maximum(hi, cen.max(0))
+    return verts, vidx, ids, lo, (hi - lo) * (1.0 + 2.0 ** -20)
+
+
 def grids_obj_text(m: int = 32) -> str:
     """Plumbing input (BASELINE config 1): two interpenetrating m x m grids (~4 k triangles at m=32)
     written in the only OBJ dialect the reference loader accepts: `v x y z` and `f a/ta b/tb c/tc`

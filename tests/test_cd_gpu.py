@@ -468,6 +468,35 @@ def test_order_hint_is_a_permutation_and_changes_nothing_but_the_order():
             assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) in ((0,) if nt <= 512 else (1, 2))   # (one block: no cross kernel, no hint)
 
 
+def test_order_hint_of_a_large_tree_is_sorted_chunk_by_chunk():
+    """A tree of more than 1 M leaves (round 5: k_cross_fused serves every size) with CD_OPT_ORDER_HINT 2: an XCD list of the order hint holds more than
+    ORDER_MAX_ITEMS = 2048 groups and is sorted chunk by chunk of 2048 list positions, a workgroup each.  order[] is a permutation, every chunk of every list has its highest score first,
+    a chunk holds exactly the groups half_vblock puts there, and pairs / pairs tested are the oracle's, step after step."""
+    verts, vidx = synth.cloth_pair(800)                                     # 2 560 000 triangles: 40 000 groups, lists of 5 000 = chunks of 2048 + 2048 + 904
+    r = oracle.pipeline(verts, vidx)
+    want = oracle.pair_set(r["pairs"])
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        pairs, n, rc = cd.self_collide(cap=1 << 21)
+        assert rc == 0 and cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 0                 # by default a tree of this size runs in the plain order: no hint is built
+        cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 2)
+        plain = None
+        for it in range(3):
+            pairs, n, rc = cd.self_collide(cap=1 << 21)
+            assert rc == 0 and np.array_equal(oracle.pair_set(pairs), want) and cd.stats().pairs_tested == r["stats"].pairs_tested, it
+            cost, order, tri = cd.debug_hint(with_tri=True)
+            assert np.array_equal(np.sort(order), np.arange(order.shape[0], dtype=np.uint32)) and cost.max() < 32
+            if it == 0:
+                assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 2 and cost.max() == 0      # no times yet: the plain order (half_vblock's)
+                plain = order.copy()
+            else:
+                assert cd.debug_get(mi355cd.CD_DBG_GET_ORDER_STATE) == 1 and cost.max() > cost.min()
+            for x in range(8):
+                lst, base = order[x::8], plain[x::8]
+                for c0 in range(0, lst.shape[0], 2048):
+                    assert np.all(np.diff(cost[lst[c0:c0 + 2048]].astype(np.int64)) <= 0), (it, x, c0)
+                    assert np.array_equal(np.sort(lst[c0:c0 + 2048]), np.sort(base[c0:c0 + 2048])), (it, x, c0)
+
+
 def test_order_hint_on_random_meshes_that_move():
     """Steps on meshes whose vertices are jittered between steps (cd_update_vertices): every step takes the order hint its fused build made from the
     times the triangles brought along from the step before -- whatever they sort into now -- and must give the oracle's pairs and pairs tested."""
@@ -837,7 +866,7 @@ def test_multi_step_slab_allocation_failure_in_the_growth_round_fails_together_a
 
 def _assert_fused_records_equal_stagewise(verts, vidx, ids=None, split_cross_too=True, auto_frame=False):
     got = {}
-    for fused in (1, 0, 2):                                 # 2: the fused build with k_cross_meta + k_cross_records (what trees beyond 2048 blocks take)
+    for fused in (1, 0, 2):                                 # 2: the fused build with k_cross_meta + k_cross_records (CD_DBG_SPLIT_CROSS: the three-launch form of the cross stage)
         with mi355cd.CollisionDetector(verts, vidx, ids) as cd:
             if auto_frame:
                 cd.set_morton_frame(mi355cd.CD_FRAME_AUTO)
@@ -878,10 +907,10 @@ def _compare_records(n, a, b):
 
 
 @pytest.mark.parametrize("kind", ["cloth-float", "soup-double", "mixed", "tiny", "one-block", "two-blocks", "three-blocks", "ragged", "duplicates", "long-ranges",
-                                  "1024-blocks", "2048-blocks", "4096-blocks"])
+                                  "1024-blocks", "2048-blocks", "4096-blocks", "16384-blocks-three-empty-spans"])
 def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
-    """The fused build (cd_build.h: hierarchy from adjacent deltas, fp32 segment trees, cross nodes by k_cross_fused -- or, beyond
-    2048 blocks, by k_cross_meta + k_cross_records) against the
+    """The fused build (cd_build.h: hierarchy from adjacent deltas, fp32 segment trees, cross nodes by k_cross_fused -- beyond 2048 blocks
+    with the upper levels from k_top_publish / k_top_publish_upper -- or, on request, by k_cross_meta + k_cross_records) against the
     stage-wise one (k_hierarchy + the FP64 refit, key 104): the traversal records must be the same bytes -- child boxes
     rounded outward, child links, range ends, the root's name, and the exact-in-fp32 bits of LEAF children (those of
     internal children are not read by any kernel and not compared) -- and so must the fp32 query boxes."""
@@ -910,8 +939,10 @@ def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
         verts, vidx = synth.soup(200_000, 0.01, 11)
     elif kind == "1024-blocks":                     # 586 blocks of 512 leaves: four block boxes per thread in the top levels
         verts, vidx = synth.soup(300_000, 0.01, 12)
-    elif kind == "4096-blocks":                     # 2149 blocks: beyond what one workgroup folds -- spans of 2048 blocks, then their roots
+    elif kind == "4096-blocks":                     # 2149 blocks: beyond what one workgroup folds -- spans of 2048 blocks, then their roots (k_top_publish, k_top_publish_upper)
         verts, vidx = synth.soup(1_100_000, 0.005, 13)
+    elif kind == "16384-blocks-three-empty-spans":  # 9180 blocks in 16384 slots: eight spans of 2048, the fifth partly filled, the last three empty; an XCD list of the order hint in 2 chunks
+        verts, vidx = synth.soup(4_700_000, 0.004, 15)
     else:
         verts, vidx = synth.soup(512 * 7 + 1, 0.05, 9)
     _assert_fused_records_equal_stagewise(verts, vidx)
@@ -966,7 +997,7 @@ def test_eight_million_soup_variants_agree():
     verts, vidx = synth.soup(n, 0.005, 99)
     sets, tested = [], []
     with mi355cd.CollisionDetector(verts, vidx) as cd:
-        for variant in (3, 1, 0):                            # 3: the default path (15 625 blocks: the fused build's three-launch cross path, half traversal)
+        for variant in (3, 1, 0):                            # 3: the default path (15 625 blocks: the fused build, its upper levels from k_top_publish / k_top_publish_upper; half traversal)
             cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
             pairs, cnt, rc = cd.self_collide(cap=1 << 22)
             assert rc == 0 and cnt > 1000

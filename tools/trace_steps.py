@@ -1,15 +1,23 @@
 """Runs N fused steps on a bench workload with options from the command line -- to be run under rocprofv3 --kernel-trace --stats.
-usage: trace_steps.py MESH [KEY=VALUE ...]    MESH: cloth1M | soup1M | soup100k | cloth1Md"""
+usage: trace_steps.py MESH [KEY=VALUE ...]    MESH: cloth1M | soup1M | soup100k | cloth1Md | cloth4M | cfg4_8M | soup8M
+env STEPS (default 200)"""
 import os, sys
 sys.path[:0] = [os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpu-computing-course_amd", "pyhost")]
 import numpy as np, mi355_synth as synth, mi355cd
 mesh = sys.argv[1]
-v, t = {"cloth1M": lambda: synth.cloth_pair(500), "soup1M": lambda: synth.soup(1_000_000, 0.01, 1234), "soup100k": lambda: synth.soup(100_000, 0.02, 1234),
+frame = None
+if mesh == "cfg4_8M":
+    v, t, ids, off, span = synth.config4_merged(8, 500); frame = (off, span)
+else:
+  ids = None
+  v, t = {"cloth4M": lambda: synth.cloth_pair(1000), "soup8M": lambda: synth.soup(8_000_000, 0.005, 1234), "cloth1M": lambda: synth.cloth_pair(500), "soup1M": lambda: synth.soup(1_000_000, 0.01, 1234), "soup100k": lambda: synth.soup(100_000, 0.02, 1234),
         "cloth1Md": lambda: synth.cloth_pair(500, round_f32=False)}[mesh]()
 buf = np.empty((1 << 22, 2), dtype=np.uint32)
-with mi355cd.CollisionDetector(v, t) as cd:
+STEPS = int(os.environ.get("STEPS", "200"))
+with mi355cd.CollisionDetector(v, t, ids) as cd:
+    if frame: cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, frame[0], frame[1])
     cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
     for kv in sys.argv[2:]:
         k, val = kv.split("="); cd.set_option(int(k), int(val))
-    for _ in range(200): n, rc = cd.self_collide_into(buf)
+    for _ in range(STEPS): n, rc = cd.self_collide_into(buf)
     print(mesh, sys.argv[2:], "pairs", n, "tested", cd.fast_stats.pairs_tested, "rc", rc)
