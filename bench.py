@@ -270,6 +270,22 @@ def ray_tracer_measurement(dim=4096, n_spheres=4096, frames=5, rank=0, world=1, 
                     rt.render_repeat(shifts, 16, download=False)
                     rb.append(rt.stats().ms_render)
                 out[name]["ms_per_frame_back_to_back"] = statistics.median(rb)
+                # the animation loop (anime_ray.cu:115-131: the spheres move, the frame is rendered, per frame) as rt_anim_loop runs it: ONE launch per frame, frame f
+                # rendering while the spheres move on to frame f + 1 and are binned for it in the same launch -- k_prepare is off the frame's critical path
+                rt.anim_init()
+                la = []
+                for _ in range(3):
+                    rt.anim_loop(32, 2, 35, 1, 18, download=False)
+                    la.append(rt.stats().ms_render)
+                out[name]["ms_per_frame_animation_loop"] = statistics.median(la)
+                last = rt.anim_loop(1, 2, 35, 1, 18, download=True)
+                ash, _, _ = rt.anim_state()
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle as _orc
+                yl = dim // 2
+                out[name]["animation_loop_parity_checked"] = bool(np.array_equal(last[yl:yl + 64], _orc.rt_render(spheres, ash, dim, rows=(yl, yl + 64))[yl:yl + 64]))
+                out[name]["animation_loop_note"] = ("97 frames of the curve-move animation through rt_anim_loop; rows [%d, %d) of the last one pixel-equal to the CPU oracle rendering the "
+                                                    "state read back from the device" % (yl, yl + 64))
         rt.set_mode(mi355rt.RT_MODE_BINNED)
         if multi:
             # whole-job frame rate: K frames per rank (its rows), barrier + synchronize both sides, max over ranks

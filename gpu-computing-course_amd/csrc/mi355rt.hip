@@ -45,14 +45,10 @@ __device__ __forceinline__ void prepare_one(const RtSphere *__restrict__ s, cons
 // n = dz / sqrtf(r*r) and the three colour products (sphere.cuh:41, anime_ray.cu:77-80) depend on nothing but the
 // winning sphere, so they are evaluated once per pixel after the loop instead of once per hit (same operands, same
 // operations, same bits).  That takes the IEEE division and the shade fetch out of the divergent hit branch.
-// Round 5: the depth is LAZY too.  A pixel's first hit wins whatever its t is (t = dz + z > -INF = -2e10f, anime_ray.cu:69,75, as soon
-// as dz is a number and z is not absurd), so it only leaves the square root's ARGUMENT and the sphere's z behind; sqrtf and the sum are
-// evaluated when a SECOND sphere covers the pixel (both then, compared as before) or in the epilogue -- the very operations on the very
-// operands, once per covered pixel instead of once per (sphere, pixel).  Most covered pixels of a frame see one sphere: the ~35-instruction
-// branch that every lane of a wave walks through when one of them is inside a disc shrinks to three selects.
-//   win < 0: no hit yet (b = -INF);  win & PX_LAZY: a = rr - dx2 - dy2, b = the sphere's z;  else: a = dz, b = t (the running maximum)
-struct Px { float b, a; int win; };
-constexpr int PX_LAZY = 0x40000000;
+// (Round 5 tried a LAZY depth -- a pixel's first hit leaves the square root's argument behind, sqrtf runs when a second sphere covers the pixel or in the
+//  epilogue: pixel-exact, and 1.6 us per frame SLOWER, the second-hit path runs for a whole 8x8 block as soon as two discs meet in it;
+//  profiles/r05_experiments/rt_render.log.)
+struct Px { float maxz, dz; int win; };
 
 // One sphere against one pixel: sphere.cuh:36-43 + anime_ray.cu:75-81.
 __device__ __forceinline__ void shade_one(Px &p, float ox, float oy, const SphGeom g, int i)
@@ -61,16 +57,12 @@ __device__ __forceinline__ void shade_one(Px &p, float ox, float oy, const SphGe
     const float dy = oy - g.cy;
     const float dx2 = dx * dx, dy2 = dy * dy;
     if (dx2 + dy2 < g.rr) {
-        const float arg = g.rr - dx2 - dy2;
-        if (p.win < 0 && arg >= 0.f && g.z > -1e10f) { p.a = arg; p.b = g.z; p.win = i | PX_LAZY; }   // t >= z > -2e10f: it wins against "nothing yet"
-        else {
-            if (p.win >= 0 && (p.win & PX_LAZY)) { const float dz0 = sqrtf(p.a); p.b = dz0 + p.b; p.a = dz0; p.win &= ~PX_LAZY; }
-            const float dz = sqrtf(arg);
-            const float t = dz + g.z;
-            // anime_ray.cu:75 is a strict > in ascending sphere order, i.e. the lowest index wins a tie; stated
-            // explicitly so that the spheres may arrive in any order (binned lists are unordered)
-            if (t > p.b || (t == p.b && i < p.win)) { p.b = t; p.a = dz; p.win = i; }
-        }
+        const float dz = sqrtf(g.rr - dx2 - dy2);
+        const float t = dz + g.z;
+        // anime_ray.cu:75 is a strict > in ascending sphere order, i.e. the lowest index wins a tie; stated
+        // explicitly so that the spheres may arrive in any order (binned lists are unordered)
+        // (a branch-free form of this -- bitwise | and &, three selects -- measured the same: 30.6 vs 30.8 us per frame)
+        if (t > p.maxz || (t == p.maxz && i < p.win)) { p.maxz = t; p.dz = dz; p.win = i; }
     }
 }
 
@@ -80,9 +72,8 @@ __device__ __forceinline__ uint32_t pack_px(const Px &p, const SphShade *__restr
     // pixels of a frame are such (the compiler skips the block below for a whole wave when none of its lanes has a hit)
     uint32_t out = 255u << 24;
     if (p.win >= 0) {
-        const SphShade h = shade[p.win & ~PX_LAZY];
-        const float dz = (p.win & PX_LAZY) ? sqrtf(p.a) : p.a;                         // sphere.cuh:40
-        const float n = dz / h.sr;                                                     // sphere.cuh:41
+        const SphShade h = shade[p.win];
+        const float n = p.dz / h.sr;                                                   // sphere.cuh:41
         const float r = h.r * n, g = h.g * n, b = h.b * n;                             // anime_ray.cu:77-79
         // anime_ray.cu:84-87: (int)(c * 255) stored to unsigned char; alpha 255
         const uint32_t ri = (uint32_t)(unsigned char)(int)(r * 255);
@@ -92,6 +83,7 @@ __device__ __forceinline__ uint32_t pack_px(const Px &p, const SphShade *__restr
     }
     return out;
 }
+
 
 // Exact conservative cull of one sphere against the pixel rectangle [X0,X1] x [Y0,Y1] (inclusive).  For a column x
 // of the rectangle dx(x) = fl(ox(x) - cx) is monotone in x, so over the rectangle |dx| >= m where m = dx(X0) if that
@@ -183,20 +175,26 @@ __device__ __forceinline__ void bin_sphere(const SphGeom g, const SphShade h, in
 // The per-sphere prepass; in binned mode (tile_list != nullptr) the same thread also bins its sphere, and the launch
 // zeroes the list counters of the NEXT frame (two sets, used alternately: no memset between frames).
 constexpr int PREP_THREADS = 64;       // one wave per workgroup: 4096 spheres spread over 64 CUs instead of 16
-__global__ __launch_bounds__(PREP_THREADS) void k_prepare(const RtSphere *__restrict__ s, const int32_t *__restrict__ shifts, int n,
-                                                 SphGeom *__restrict__ geom, SphShade *__restrict__ shade,
-                                                 int dim, int c_shift_x, int c_shift_y, int nsx, int ty0, int ty1,
-                                                 int *__restrict__ super_list, int *__restrict__ super_count,
-                                                 TileEnt *__restrict__ tile_list, int *__restrict__ tile_count,
-                                                 int *__restrict__ next_counts, int n_counts)
+struct PrepArgs {
+    const RtSphere *s; const int32_t *shifts; int n;
+    SphGeom *geom; SphShade *shade;
+    int dim, c_shift_x, c_shift_y, nsx, ty0, ty1;
+    int *super_list, *super_count; TileEnt *tile_list; int *tile_count;
+    int *next_counts; int n_counts;
+};
+__device__ __forceinline__ void prepare_and_bin(const PrepArgs &a, int i)
+{
+    SphGeom g; SphShade h;
+    prepare_one(a.s, a.shifts, i, g, h);
+    a.geom[i] = g; a.shade[i] = h;
+    if (a.tile_list) bin_sphere(g, h, i, a.n, a.dim, a.c_shift_x, a.c_shift_y, a.nsx, a.ty0, a.ty1, a.super_list, a.super_count, a.tile_list, a.tile_count);
+}
+__global__ __launch_bounds__(PREP_THREADS) void k_prepare(PrepArgs a)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (next_counts) for (int j = i; j < n_counts; j += gridDim.x * blockDim.x) next_counts[j] = 0;
-    if (i >= n) return;
-    SphGeom g; SphShade h;
-    prepare_one(s, shifts, i, g, h);
-    geom[i] = g; shade[i] = h;
-    if (tile_list) bin_sphere(g, h, i, n, dim, c_shift_x, c_shift_y, nsx, ty0, ty1, super_list, super_count, tile_list, tile_count);
+    if (a.next_counts) for (int j = i; j < a.n_counts; j += gridDim.x * blockDim.x) a.next_counts[j] = 0;
+    if (i >= a.n) return;
+    prepare_and_bin(a, i);
 }
 
 // Thread layout inside a 64x64 tile: tx = tid & 15 owns 4 consecutive columns, ty = tid >> 4 owns rows
@@ -209,20 +207,28 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare(const RtSphere *__rest
 // cache too: count -> entries -> pixels is the whole dependency chain, no LDS, no barrier.  A tile with more than
 // TILE_CAP survivors walks its super-tile's index list instead, culling with may_touch (workgroup-uniform) as it goes:
 // any number of spheres works, only slower.
+struct RenderArgs {
+    const SphGeom *geom; const SphShade *shade; int n;
+    int dim, c_shift_x, c_shift_y, tile_y0;
+    uint32_t *rgba; uint32_t *tile_tests;
+    const int *super_list, *super_count; int nsx;
+    const TileEnt *tile_list; const int *tile_count;
+};
 template <bool BINNED>
-__global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ geom, const SphShade *__restrict__ shade, int n,
-                                                    int dim, int c_shift_x, int c_shift_y, int tile_y0,
-                                                    uint32_t *__restrict__ rgba, uint32_t *__restrict__ tile_tests,
-                                                    const int *__restrict__ super_list, const int *__restrict__ super_count, int nsx,
-                                                    const TileEnt *__restrict__ tile_list, const int *__restrict__ tile_count)
+__device__ __forceinline__ void render_tile(const RenderArgs &ra, const int bx, const int by)
 {
+    const SphGeom *__restrict__ geom = ra.geom; const SphShade *__restrict__ shade = ra.shade; const int n = ra.n;
+    const int dim = ra.dim, c_shift_x = ra.c_shift_x, c_shift_y = ra.c_shift_y, tile_y0 = ra.tile_y0;
+    uint32_t *__restrict__ rgba = ra.rgba; uint32_t *__restrict__ tile_tests = ra.tile_tests;
+    const int *__restrict__ super_list = ra.super_list, *__restrict__ super_count = ra.super_count; const int nsx = ra.nsx;
+    const TileEnt *__restrict__ tile_list = ra.tile_list; const int *__restrict__ tile_count = ra.tile_count;
     const int tid = threadIdx.x;
     // BINNED: a workgroup renders HALF a tile (64 x 32 pixels, blockIdx.y counts halves): 8 pixels per thread instead of 16
     // keep the kernel under 64 VGPRs (8 waves per SIMD instead of 5) and make the work items small against the frame's tail
     constexpr int SPLIT = BINNED ? RT_SPLIT : 1;                         // workgroups per tile
     constexpr int NA = 4 / SPLIT;                                        // rows of pixel slots per thread
-    const int X0 = blockIdx.x * TILE, Y0 = ((int)(blockIdx.y / SPLIT) + tile_y0) * TILE;
-    const int HY = (int)(blockIdx.y % SPLIT) * (TILE / SPLIT);
+    const int X0 = bx * TILE, Y0 = ((int)(by / SPLIT) + tile_y0) * TILE;
+    const int HY = (int)(by % SPLIT) * (TILE / SPLIT);
     // BRUTE: tx = tid & 15 owns 4 consecutive columns, ty = tid >> 4 owns rows ty, ty+16, ty+32, ty+48 (every sphere
     // is tested against every pixel: the mapping only has to store well).
     // BINNED: what a wave pays for a sphere is decided by its pixels that are processed TOGETHER -- the sqrt / depth
@@ -298,6 +304,7 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
         if (tid == 0 && HY == 0 && tile_tests) tile_tests[t] = mytests;                         // sphere tests per pixel of this tile (summed by the host)
     }
     if (BINNED) {
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
         // pixel (8b + lx, 8a + ly) of the region -> LDS (row stride 36 words: the eight rows of a block land in different
         // banks), then every lane stores 4 consecutive pixels of rows ly and ly + 8.  Wave-private: no barrier.
         __shared__ uint32_t quad[THREADS / 64][8 * NA][36];
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
             const int r = 8 * k + (ln >> 3), cx = 4 * (ln & 7);
             const uint4 o = *reinterpret_cast<const uint4 *>(&quad[wv][r][cx]);
             // (a frame is written once and not read by this library: non-temporal stores -- 30.1 -> 29.3 us per frame)
-            { typedef uint32_t v4u __attribute__((ext_vector_type(4))); const v4u ov = {o.x, o.y, o.z, o.w};
+            { const v4u ov = {o.x, o.y, o.z, o.w};
               __builtin_nontemporal_store(ov, reinterpret_cast<v4u *>(rgba + (size_t)(Y0 + qy + r) * dim + (X0 + qx + cx))); }   // offset = x + y*dim, anime_ray.cu:64
         }
     } else {
@@ -324,6 +331,9 @@ __global__ __launch_bounds__(THREADS) void k_render(const SphGeom *__restrict__ 
         }
     }
 }
+
+template <bool BINNED>
+__global__ __launch_bounds__(THREADS) void k_render(RenderArgs ra) { render_tile<BINNED>(ra, (int)blockIdx.x, (int)blockIdx.y); }
 
 // ---------------------------------------------------------------- animation state (sphere.cuh:50-118)
 // XORWOW as <curand_kernel.h> implements it for curand_init(seed, 0, 0): no skip-ahead, seed scrambled by two odd
@@ -364,21 +374,16 @@ __global__ __launch_bounds__(256) void k_anim_init(int n, Xorwow *__restrict__ s
     angles[i] = 0.0;
 }
 
-__global__ __launch_bounds__(256) void k_anim_axis(int n, Xorwow *__restrict__ st, int32_t *__restrict__ shifts, int shake_width)   // sphere.cuh:66-77
+__device__ __forceinline__ void anim_axis_one(int i, Xorwow *__restrict__ st, int32_t *__restrict__ shifts, int shake_width)   // sphere.cuh:66-77
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     Xorwow s = st[i];
     const int x_shift = (int)dev_rnd(shake_width, s);
     const int y_shift = (int)dev_rnd(shake_width, s);
     shifts[4 * i] = x_shift; shifts[4 * i + 1] = y_shift;
     st[i] = s;
 }
-
-__global__ __launch_bounds__(256) void k_anim_curve(int n, int32_t *__restrict__ shifts, double *__restrict__ angles)              // sphere.cuh:82-97
+__device__ __forceinline__ void anim_curve_one(int i, int32_t *__restrict__ shifts, double *__restrict__ angles)              // sphere.cuh:82-97
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const int speed = shifts[4 * i + 2];
     const float a = (float)angles[i];
     // correctly rounded float cosine / sine (through the double functions); CUDA's cosf / sinf are within 2 ulp of these
@@ -387,12 +392,9 @@ __global__ __launch_bounds__(256) void k_anim_curve(int n, int32_t *__restrict__
     shifts[4 * i] += x_shift; shifts[4 * i + 1] += y_shift;
     angles[i] = fmod(angles[i] + ANIM_PI / 12 * shifts[4 * i + 3], 2 * ANIM_PI);
 }
-
-__global__ __launch_bounds__(256) void k_anim_speed_angle(int n, Xorwow *__restrict__ st, int32_t *__restrict__ shifts, double *__restrict__ angles,
-                                                          int update_prob, int max_speed)                                       // sphere.cuh:102-118
+__device__ __forceinline__ void anim_speed_angle_one(int i, Xorwow *__restrict__ st, int32_t *__restrict__ shifts, double *__restrict__ angles,
+                                                     int update_prob, int max_speed)                                            // sphere.cuh:102-118
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     Xorwow s = st[i];
     const int p = (int)dev_rnd(10, s);
     if (p < update_prob) {
@@ -401,6 +403,60 @@ __global__ __launch_bounds__(256) void k_anim_speed_angle(int n, Xorwow *__restr
         angles[i] = fmod(angles[i] + ((int)dev_rnd(2, s)) * ANIM_PI, 2 * ANIM_PI);
     }
     st[i] = s;
+}
+
+__global__ __launch_bounds__(256) void k_anim_axis(int n, Xorwow *__restrict__ st, int32_t *__restrict__ shifts, int shake_width)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) anim_axis_one(i, st, shifts, shake_width);
+}
+__global__ __launch_bounds__(256) void k_anim_curve(int n, int32_t *__restrict__ shifts, double *__restrict__ angles)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) anim_curve_one(i, shifts, angles);
+}
+__global__ __launch_bounds__(256) void k_anim_speed_angle(int n, Xorwow *__restrict__ st, int32_t *__restrict__ shifts, double *__restrict__ angles,
+                                                          int update_prob, int max_speed)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) anim_speed_angle_one(i, st, shifts, angles, update_prob, max_speed);
+}
+
+// ---------------------------------------------------------------- the animation loop, one launch per frame (round 5)
+// generate_frame (anime_ray.cu:98-140) runs, per frame: [the spheres' shifts move] -> kernel -> D2H.  Frame f + 1's shifts and lists depend on nothing
+// frame f's pixels do, so ONE launch renders frame f (its own list set) while the workgroups of its first grid row move the spheres on to frame f + 1
+// and prepare + bin them into the OTHER list set: k_prepare's 7 us -- three dependent round trips around a kernel boundary, a quarter of a frame --
+// run beside 8192 rendering workgroups instead of in front of them.  No data crosses workgroups inside the launch: the render role reads set f & 1 and
+// the counters f % 3, the prepare role writes set (f + 1) & 1 and the counters (f + 1) % 3 and zeroes the counters (f + 2) % 3 (last read by frame f - 1's
+// render, a launch ago).  A sphere's state is its thread's alone (idx == position is required: rt_anim_loop checks), so moving it and preparing it in one
+// thread is the reference's kernel sequence, sphere by sphere.
+struct AnimStep { int shake /* 0: none, 1: updateSphereShiftsWithAxisMove, 2: ...WithCurveMove + updateSphereCurveSpeedAngle */, p0, p1, p2;
+                  Xorwow *st; int32_t *shifts; double *angles; };
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_frame(RenderArgs ra, PrepArgs pa, AnimStep an, int prep /* 0: the last frame of the loop, nothing to prepare */)
+{
+    if (blockIdx.y == 0) {                                              // (workgroup-uniform) the prepare row
+        if (!prep) return;
+        const int gtid = blockIdx.x * THREADS + threadIdx.x, gsz = gridDim.x * THREADS;
+        for (int j = gtid; j < pa.n_counts; j += gsz) pa.next_counts[j] = 0;
+        for (int i = gtid; i < pa.n; i += gsz) {
+            if (an.shake == 1) anim_axis_one(i, an.st, an.shifts, an.p0);
+            else if (an.shake == 2) { anim_curve_one(i, an.shifts, an.angles); anim_speed_angle_one(i, an.st, an.shifts, an.angles, an.p1, an.p2); }
+            prepare_and_bin(pa, i);
+        }
+        return;
+    }
+    render_tile<true>(ra, (int)blockIdx.x, (int)blockIdx.y - 1);
+}
+// The loop's first frame has nobody to prepare it: the spheres move and are prepared by a launch of their own.
+__global__ __launch_bounds__(THREADS) void k_anim_prepare(PrepArgs pa, AnimStep an)
+{
+    const int gtid = blockIdx.x * THREADS + threadIdx.x, gsz = gridDim.x * THREADS;
+    for (int j = gtid; j < pa.n_counts; j += gsz) pa.next_counts[j] = 0;
+    for (int i = gtid; i < pa.n; i += gsz) {
+        if (an.shake == 1) anim_axis_one(i, an.st, an.shifts, an.p0);
+        else if (an.shake == 2) { anim_curve_one(i, an.shifts, an.angles); anim_speed_angle_one(i, an.st, an.shifts, an.angles, an.p1, an.p2); }
+        prepare_and_bin(pa, i);
+    }
 }
 
 }  // namespace
@@ -412,12 +468,14 @@ struct rt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     RtSphere *d_spheres = nullptr; int32_t *d_shifts = nullptr;
     Xorwow *d_rng = nullptr; double *d_angles = nullptr; bool anim_ready = false;   // animation state, sphere.cuh:50-61
-    SphGeom *d_geom = nullptr; SphShade *d_shade = nullptr;
+    // What a frame's render reads is a SET, two of them used alternately (frame & 1): the animation loop prepares frame f + 1 while frame f renders (k_frame)
+    SphGeom *d_geom[2] = {nullptr, nullptr}; SphShade *d_shade[2] = {nullptr, nullptr};
     uint32_t *d_rgba = nullptr;
-    int *d_super_list = nullptr;                                // [nsuper][n] indices of the spheres that may touch a super-tile (unordered)
-    TileEnt *d_tile_list = nullptr;                             // [ntiles][TILE_CAP]
-    int *d_counts[2] = {nullptr, nullptr};                      // two sets of [ntiles tile counts | nsuper super-tile counts], used alternately by
-    int n_counts = 0, ntiles = 0; uint32_t frame = 0;           //   successive frames: a frame's k_prepare zeroes the set of the next one
+    int *d_super_list[2] = {nullptr, nullptr};                  // [nsuper][n] indices of the spheres that may touch a super-tile (unordered)
+    TileEnt *d_tile_list[2] = {nullptr, nullptr};               // [ntiles][TILE_CAP]
+    int *d_counts[3] = {nullptr, nullptr, nullptr};             // three sets of [ntiles tile counts | nsuper super-tile counts] (frame % 3): a frame's prepare zeroes
+    int n_counts = 0, ntiles = 0; uint32_t frame = 0;           //   the set of the next one -- which, in the loop, the frame BEFORE is no longer reading
+    bool idx_identity = true;                                   // every sphere's idx is its position (what the loop's fused launch needs)
     uint32_t *d_tile_tests = nullptr, *h_tile_tests = nullptr;  // sphere tests per pixel of every tile; pinned copy
     rt_stats stats = {};
 };
@@ -426,8 +484,8 @@ namespace {
 void rt_free(rt_ctx *c)
 {
     hipFree(c->d_rng); hipFree(c->d_angles);
-    hipFree(c->d_spheres); hipFree(c->d_shifts); hipFree(c->d_geom); hipFree(c->d_shade); hipFree(c->d_rgba); hipFree(c->d_super_list);
-    hipFree(c->d_tile_list); hipFree(c->d_counts[0]); hipFree(c->d_tile_tests);
+    hipFree(c->d_spheres); hipFree(c->d_shifts); hipFree(c->d_geom[0]); hipFree(c->d_shade[0]); hipFree(c->d_rgba); hipFree(c->d_super_list[0]);
+    hipFree(c->d_tile_list[0]); hipFree(c->d_counts[0]); hipFree(c->d_tile_tests);
     if (c->h_tile_tests) hipHostFree(c->h_tile_tests);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -457,19 +515,22 @@ int rt_create(rt_ctx **out, const RtSphere *spheres, int32_t n_spheres, int32_t 
     ok(hipMalloc(&c->d_shifts, sizeof(int32_t) * 4 * (size_t)n_spheres));
     ok(hipMalloc(&c->d_rng, sizeof(Xorwow) * (size_t)n_spheres));
     ok(hipMalloc(&c->d_angles, sizeof(double) * (size_t)n_spheres));
-    ok(hipMalloc(&c->d_geom, sizeof(SphGeom) * (size_t)n_spheres));
-    ok(hipMalloc(&c->d_shade, sizeof(SphShade) * (size_t)n_spheres));
+    ok(hipMalloc(&c->d_geom[0], sizeof(SphGeom) * 2 * (size_t)n_spheres));
+    ok(hipMalloc(&c->d_shade[0], sizeof(SphShade) * 2 * (size_t)n_spheres));
+    if (e == hipSuccess) { c->d_geom[1] = c->d_geom[0] + n_spheres; c->d_shade[1] = c->d_shade[0] + n_spheres; }
     ok(hipMalloc(&c->d_rgba, sizeof(uint32_t) * (size_t)dim * dim));
-    
+    for (int i = 0; i < n_spheres; ++i) c->idx_identity = c->idx_identity && spheres[i].idx == i;
     { const size_t ns = (size_t)((dim + SUPER - 1) / SUPER) * ((dim + SUPER - 1) / SUPER);
       c->ntiles = (dim / TILE) * (dim / TILE);
       c->n_counts = c->ntiles + (int)ns;
-      ok(hipMalloc(&c->d_counts[0], sizeof(int) * 2 * (size_t)c->n_counts));
-      if (e == hipSuccess) { c->d_counts[1] = c->d_counts[0] + c->n_counts; ok(hipMemset(c->d_counts[0], 0, sizeof(int) * 2 * (size_t)c->n_counts)); }
-      ok(hipMalloc(&c->d_tile_list, sizeof(TileEnt) * (size_t)c->ntiles * TILE_CAP));
+      ok(hipMalloc(&c->d_counts[0], sizeof(int) * 3 * (size_t)c->n_counts));
+      if (e == hipSuccess) { c->d_counts[1] = c->d_counts[0] + c->n_counts; c->d_counts[2] = c->d_counts[1] + c->n_counts; ok(hipMemset(c->d_counts[0], 0, sizeof(int) * 3 * (size_t)c->n_counts)); }
+      ok(hipMalloc(&c->d_tile_list[0], sizeof(TileEnt) * 2 * (size_t)c->ntiles * TILE_CAP));
+      if (e == hipSuccess) c->d_tile_list[1] = c->d_tile_list[0] + (size_t)c->ntiles * TILE_CAP;
       ok(hipMalloc(&c->d_tile_tests, sizeof(uint32_t) * (size_t)c->ntiles));
       ok(hipHostMalloc(&c->h_tile_tests, sizeof(uint32_t) * (size_t)c->ntiles, hipHostMallocDefault));
-      ok(hipMalloc(&c->d_super_list, sizeof(int) * ns * (size_t)n_spheres)); }
+      ok(hipMalloc(&c->d_super_list[0], sizeof(int) * 2 * ns * (size_t)n_spheres));
+      if (e == hipSuccess) c->d_super_list[1] = c->d_super_list[0] + ns * (size_t)n_spheres; }
     if (e == hipSuccess) ok(hipMemcpy(c->d_spheres, spheres, sizeof(RtSphere) * (size_t)n_spheres, hipMemcpyHostToDevice));
     if (e != hipSuccess) { rt_free(c); delete c; return -(int)e; }
     *out = c;
@@ -489,6 +550,8 @@ int rt_set_spheres(rt_ctx *c, const RtSphere *spheres)
     if (!c || !spheres) return RT_ERR_ARG;
     for (int i = 0; i < c->n; ++i) if (spheres[i].idx < 0 || spheres[i].idx >= c->n) return RT_ERR_ARG;
     HIPCHK(hipMemcpy(c->d_spheres, spheres, sizeof(RtSphere) * (size_t)c->n, hipMemcpyHostToDevice));
+    c->idx_identity = true;
+    for (int i = 0; i < c->n; ++i) c->idx_identity = c->idx_identity && spheres[i].idx == i;
     return RT_OK;
 }
 
@@ -497,6 +560,22 @@ int rt_set_mode(rt_ctx *c, int mode)
     if (!c || (mode != RT_MODE_BRUTE && mode != RT_MODE_BINNED)) return RT_ERR_ARG;
     c->mode = mode;
     return RT_OK;
+}
+
+// the arguments of frame number `frame`: list set frame & 1, counters frame % 3 (its prepare zeroes the counters of frame + 1)
+static PrepArgs prep_args(rt_ctx *c, uint32_t frame, int32_t csx, int32_t csy, int ty0, int ty1)
+{
+    const int nsx = (c->dim + SUPER - 1) / SUPER, k = (int)(frame & 1u);
+    int *cur = c->d_counts[frame % 3u], *nxt = c->d_counts[(frame + 1u) % 3u];
+    return PrepArgs{c->d_spheres, c->d_shifts, c->n, c->d_geom[k], c->d_shade[k], c->dim, (int)csx, (int)csy, nsx, ty0, ty1,
+                    c->d_super_list[k], cur + c->ntiles, c->d_tile_list[k], cur, nxt, c->n_counts};
+}
+static RenderArgs render_args(rt_ctx *c, uint32_t frame, int32_t csx, int32_t csy, int ty0)
+{
+    const int nsx = (c->dim + SUPER - 1) / SUPER, k = (int)(frame & 1u);
+    const int *cur = c->d_counts[frame % 3u];
+    return RenderArgs{c->d_geom[k], c->d_shade[k], c->n, c->dim, (int)csx, (int)csy, ty0, c->d_rgba, c->d_tile_tests,
+                      c->d_super_list[k], cur + c->ntiles, nsx, c->d_tile_list[k], cur};
 }
 
 // `frames` > 1: the same frame that many times back to back (rt_render_repeat); time stamps on the first and the last kernel only
@@ -512,22 +591,18 @@ static int render_frames(rt_ctx *c, const int32_t *shifts4, int32_t csx, int32_t
     for (int f = 0; f < frames; ++f) {
     hipEvent_t e0 = f == 0 ? c->ev0 : nullptr, e1 = f == frames - 1 ? c->ev1 : nullptr;
     if (c->mode == RT_MODE_BINNED) {
-        const int nsx = (c->dim + SUPER - 1) / SUPER;
-        int *cur = c->d_counts[c->frame & 1], *nxt = c->d_counts[(c->frame + 1) & 1];
+        const PrepArgs pa = prep_args(c, c->frame, csx, csy, ty0, ty1);
+        const RenderArgs ra = render_args(c, c->frame, csx, csy, ty0);
         ++c->frame;
-        hipExtLaunchKernelGGL(k_prepare, dim3((c->n + PREP_THREADS - 1) / PREP_THREADS), dim3(PREP_THREADS), 0u, s, e0, nullptr, 0u,
-                              (const RtSphere *)c->d_spheres, (const int32_t *)c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, (int)csx, (int)csy, nsx, ty0, ty1,
-                              c->d_super_list, cur + c->ntiles, c->d_tile_list, cur, nxt, c->n_counts);
-        hipExtLaunchKernelGGL(k_render<true>, grid_binned, dim3(THREADS), 0u, s, nullptr, e1, 0u,
-                              (const SphGeom *)c->d_geom, (const SphShade *)c->d_shade, c->n, c->dim, (int)csx, (int)csy, ty0, c->d_rgba, c->d_tile_tests,
-                              (const int *)c->d_super_list, (const int *)(cur + c->ntiles), nsx, (const TileEnt *)c->d_tile_list, (const int *)cur);
+        hipExtLaunchKernelGGL(k_prepare, dim3((c->n + PREP_THREADS - 1) / PREP_THREADS), dim3(PREP_THREADS), 0u, s, e0, nullptr, 0u, pa);
+        hipExtLaunchKernelGGL(k_render<true>, grid_binned, dim3(THREADS), 0u, s, nullptr, e1, 0u, ra);
     } else {
-        hipExtLaunchKernelGGL(k_prepare, dim3((c->n + PREP_THREADS - 1) / PREP_THREADS), dim3(PREP_THREADS), 0u, s, e0, nullptr, 0u,
-                              (const RtSphere *)c->d_spheres, (const int32_t *)c->d_shifts, c->n, c->d_geom, c->d_shade, c->dim, (int)csx, (int)csy, 0, 0, 0,
-                              (int *)nullptr, (int *)nullptr, (TileEnt *)nullptr, (int *)nullptr, (int *)nullptr, 0);
-        hipExtLaunchKernelGGL(k_render<false>, grid, dim3(THREADS), 0u, s, nullptr, e1, 0u,
-                              (const SphGeom *)c->d_geom, (const SphShade *)c->d_shade, c->n, c->dim, (int)csx, (int)csy, ty0, c->d_rgba, (uint32_t *)nullptr,
-                              (const int *)nullptr, (const int *)nullptr, 0, (const TileEnt *)nullptr, (const int *)nullptr);
+        PrepArgs pa = prep_args(c, c->frame, csx, csy, 0, 0);
+        pa.super_list = nullptr; pa.super_count = nullptr; pa.tile_list = nullptr; pa.tile_count = nullptr; pa.next_counts = nullptr; pa.n_counts = 0;   // prepare only: no lists
+        RenderArgs ra = render_args(c, c->frame, csx, csy, ty0);
+        ra.tile_tests = nullptr; ra.super_list = nullptr; ra.super_count = nullptr; ra.tile_list = nullptr; ra.tile_count = nullptr; ra.nsx = 0;
+        hipExtLaunchKernelGGL(k_prepare, dim3((c->n + PREP_THREADS - 1) / PREP_THREADS), dim3(PREP_THREADS), 0u, s, e0, nullptr, 0u, pa);
+        hipExtLaunchKernelGGL(k_render<false>, grid, dim3(THREADS), 0u, s, nullptr, e1, 0u, ra);
     }
     }
     // from here on an early return must not leave a copy into caller / context memory in flight: synchronise first
@@ -610,6 +685,49 @@ int rt_anim_update_speed_angle(rt_ctx *c, int32_t update_prob, int32_t max_speed
     if (!c || !c->anim_ready) return RT_ERR_ARG;
     k_anim_speed_angle<<<(c->n + 255) / 256, 256, 0, c->stream>>>(c->n, c->d_rng, c->d_shifts, c->d_angles, update_prob, max_speed);
     HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_anim_loop(rt_ctx *c, int32_t frames, int32_t shake, int32_t p0, int32_t p1, int32_t p2, int32_t csx, int32_t csy, uint8_t *rgba_last)
+{
+    if (!c || !c->anim_ready || frames < 1 || shake < 0 || shake > 2) return RT_ERR_ARG;
+    if (c->mode != RT_MODE_BINNED || !c->idx_identity) {
+        // brute mode, or a sphere whose shift row is another sphere's (sphere.cuh:35 with idx != position): the reference's launch sequence, frame by frame
+        for (int f = 0; f < frames; ++f) {
+            int rc = RT_OK;
+            if (shake == 1) rc = rt_anim_axis_move(c, p0);
+            else if (shake == 2) { rc = rt_anim_curve_move(c); if (rc == RT_OK) rc = rt_anim_update_speed_angle(c, p1, p2); }
+            if (rc == RT_OK) rc = rt_render(c, nullptr, csx, csy, f == frames - 1 ? rgba_last : nullptr);
+            if (rc != RT_OK) return rc;
+        }
+        return RT_OK;
+    }
+    hipStream_t s = c->stream;
+    const AnimStep an{(int)shake, (int)p0, (int)p1, (int)p2, c->d_rng, c->d_shifts, c->d_angles};
+    const int ty1 = c->dim / TILE;
+    const dim3 grid(c->dim / TILE, RT_SPLIT * ty1 + 1);                 // row 0: the prepare role, the rest: a workgroup per half tile
+    hipExtLaunchKernelGGL(k_anim_prepare, dim3(16), dim3(THREADS), 0u, s, c->ev0, nullptr, 0u, prep_args(c, c->frame, csx, csy, 0, ty1), an);
+    for (int f = 0; f < frames; ++f) {
+        const int more = f + 1 < frames;
+        const RenderArgs ra = render_args(c, c->frame, csx, csy, 0);
+        const PrepArgs pa = prep_args(c, c->frame + 1u, csx, csy, 0, ty1);
+        ++c->frame;
+        hipExtLaunchKernelGGL(k_frame, grid, dim3(THREADS), 0u, s, nullptr, f == frames - 1 ? c->ev1 : nullptr, 0u, ra, pa, an, more);
+    }
+    hipError_t e = hipGetLastError();
+    const size_t nt = (size_t)c->ntiles;
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_tile_tests, c->d_tile_tests, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && rgba_last) e = hipMemcpyAsync(rgba_last, c->d_rgba, sizeof(uint32_t) * (size_t)c->dim * c->dim, hipMemcpyDeviceToHost, s);
+    const hipError_t es = hipStreamSynchronize(s);
+    if (e != hipSuccess) return -(int)e;
+    if (es != hipSuccess) return -(int)es;
+    unsigned long long tests = 0;
+    for (size_t i = 0; i < nt; ++i) tests += c->h_tile_tests[i];
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.ms_render = ms / (float)frames;
+    c->stats.mode = (uint32_t)c->mode;
+    c->stats.sphere_tests = tests * (unsigned long long)(TILE * TILE);   // (the last frame's)
     return RT_OK;
 }
 

@@ -23,7 +23,7 @@ class RtStats(C.Structure):
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_spheres", "rt_set_mode", "rt_render", "rt_render_rows", "rt_render_repeat",
            "rt_init_shifts", "rt_anim_init", "rt_anim_axis_move", "rt_anim_curve_move", "rt_anim_update_speed_angle",
-           "rt_anim_get_state", "rt_get_stats", "rt_version"]
+           "rt_anim_get_state", "rt_anim_loop", "rt_get_stats", "rt_version"]
 
 _lib = None
 
@@ -54,6 +54,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.rt_anim_curve_move.argtypes = [vp]
     lib.rt_anim_update_speed_angle.argtypes = [vp, C.c_int32, C.c_int32]
     lib.rt_anim_get_state.argtypes = [vp, vp, vp, vp]
+    lib.rt_anim_loop.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
     lib.rt_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -127,6 +128,12 @@ class RayTracer:
         sh = np.zeros((self.n, 4), dtype=np.int32); ang = np.zeros(self.n, dtype=np.float64); rng = np.zeros((self.n, 6), dtype=np.uint32)
         self._chk("rt_anim_get_state", self.lib.rt_anim_get_state(self._ctx, _ptr(sh), _ptr(ang), _ptr(rng)))
         return sh, ang, rng
+
+    def anim_loop(self, frames, shake=2, shake_width=35, update_prob=1, max_speed=18, c_shift_x=0, c_shift_y=0, download=True):
+        """generate_frame `frames` times on the device (rt_anim_loop); returns the last frame (or None); stats().ms_render = device time per frame."""
+        img = np.zeros((self.dim, self.dim, 4), dtype=np.uint8) if download else None
+        self._chk("rt_anim_loop", self.lib.rt_anim_loop(self._ctx, frames, shake, shake_width, update_prob, max_speed, c_shift_x, c_shift_y, _ptr(img)))
+        return img
 
     def render_repeat(self, shifts, frames, c_shift_x=0, c_shift_y=0, download=True):
         """The same frame `frames` times back to back; stats().ms_render is then the device time per frame."""

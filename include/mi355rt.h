@@ -81,6 +81,15 @@ int rt_anim_update_speed_angle(rt_ctx *ctx, int32_t update_prob, int32_t max_spe
 /* Read the state back (any pointer may be NULL): shifts4 n x 4 int32, angles n doubles, rng6 n x 6 uint32 {v[5], d}. */
 int rt_anim_get_state(rt_ctx *ctx, int32_t *shifts4, double *angles, uint32_t *rng6);
 
+/* generate_frame (anime_ray.cu:98-140) `frames` times, the frames staying on the device (the last one is copied to rgba_last unless NULL): per frame the
+ * spheres move -- shake 0: not at all; 1: updateSphereShiftsWithAxisMove (anime_ray.cu:119; shake_width); 2: updateSphereShiftsWithCurveMove +
+ * updateSphereCurveSpeedAngle (anime_ray.cu:121-122; update_prob, max_speed) -- and kernel<<<>>> (anime_ray.cu:126) renders them; the camera offsets are
+ * the caller's (anime_ray.cu:101-108) and stay fixed over the call.  Needs rt_anim_init.  The state and the last frame are what `frames` rounds of
+ * rt_anim_* + rt_render leave.  In binned mode the loop is ONE launch per frame (+ one in front): frame f renders while the spheres move on to frame
+ * f + 1 and are binned for it in the same launch (two list sets).  rt_stats.ms_render = device time per frame over the call. */
+int rt_anim_loop(rt_ctx *ctx, int32_t frames, int32_t shake, int32_t shake_width, int32_t update_prob, int32_t max_speed,
+                 int32_t c_shift_x, int32_t c_shift_y, uint8_t *rgba_last);
+
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 const char *rt_version(void);
 

@@ -127,6 +127,23 @@ def test_config5_shape_binned_equals_brute_and_oracle_rows():
     assert np.array_equal(a[y0:y0 + 64], want)
 
 
+def test_config5_whole_frame_equals_the_oracle():
+    """BASELINE config 5, the WHOLE 4096 x 4096 frame against the CPU oracle (sphere.cuh:34-44, anime_ray.cu:61-87) -- every one of the 16.8 M pixels, in slabs of
+    rows spread over the host's cores (the oracle's loop is the reference's: 4096 spheres per pixel; about a minute of one core)."""
+    import concurrent.futures as cf
+    dim, n = 4096, 4096
+    spheres, shifts = synth.sphere_scene(n, dim, seed=7)
+    with mi355rt.RayTracer(spheres, dim) as rt:
+        got = rt.render(shifts)
+    workers = max(1, min(16, len(os.sched_getaffinity(0))))
+    slabs = [(y, y + 128) for y in range(0, dim, 128)]
+    oracle.rt_render(spheres, shifts, dim, rows=(0, 1))                      # (the library is loaded before the threads start)
+    with cf.ThreadPoolExecutor(workers) as ex:                              # ctypes releases the GIL inside the C call
+        outs = list(ex.map(lambda r: oracle.rt_render(spheres, shifts, dim, rows=r)[r[0]:r[1]].copy(), slabs))
+    for (y0, y1), want in zip(slabs, outs):
+        assert np.array_equal(got[y0:y1], want), (y0, y1)
+
+
 def test_animation_state_kernels_follow_the_oracle():
     """sphere.cuh:50-118 on the device: initSpheres, axis move, curve move, speed / direction / angle update.
     State (XORWOW words, shifts, angles) must equal the oracle's after every step of a generate_frame-like schedule
@@ -157,6 +174,60 @@ def test_animation_state_kernels_follow_the_oracle():
         img_host = rt.render(sh, 3, -2)
         assert np.array_equal(img_dev, img_host)
         assert np.array_equal(img_dev, oracle.rt_render(spheres, sh, dim, 3, -2))
+
+
+@pytest.mark.parametrize("shake", [2, 1, 0])
+def test_animation_loop_in_one_launch_per_frame_equals_the_kernel_sequence(shake):
+    """rt_anim_loop (round 5): `frames` rounds of generate_frame (anime_ray.cu:115-131) with ONE launch per frame -- frame f renders while the workgroups of the
+    launch's first grid row move the spheres on to frame f + 1 and bin them into the other list set.  The state after the loop and the last frame must be what
+    the kernel sequence leaves (rt_anim_* + rt_render per frame) and what the oracle's restatement gives; loops of 1, 2, 3 and 7 frames (every phase of the two
+    list sets and the three counter sets), single renders in between, a brute-mode loop and a scene with a permuted idx column (both take the plain sequence)."""
+    n, dim = 700, 512
+    spheres, _ = synth.sphere_scene(n, dim, seed=13)
+    ref = oracle.RtAnim(n)
+
+    def ref_step():
+        if shake == 1:
+            ref.axis_move(35)
+        elif shake == 2:
+            ref.curve_move(); ref.speed_angle(3, 18)
+
+    with mi355rt.RayTracer(spheres, dim) as rt, mi355rt.RayTracer(spheres, dim) as seq:
+        rt.anim_init(); seq.anim_init()
+        total = 0
+        for frames in (1, 2, 3, 7, 1, 4):
+            img = rt.anim_loop(frames, shake, 35, 3, 18, 2, -3)
+            assert rt.stats().ms_render > 0
+            for _ in range(frames):
+                ref_step()
+                if shake == 1:
+                    seq.anim_axis_move(35)
+                elif shake == 2:
+                    seq.anim_curve_move(); seq.anim_update_speed_angle(3, 18)
+                want = seq.render(None, 2, -3)
+            total += frames
+            sh, ang, rng = rt.anim_state()
+            assert np.array_equal(rng, ref.rng) and np.array_equal(sh, ref.shifts) and np.array_equal(ang.view(np.uint64), ref.angles.view(np.uint64)), total
+            assert np.array_equal(img, want), total
+            assert np.array_equal(rt.render(None, 2, -3), want)              # a single frame after a loop: the counter sets were left clean
+        assert np.array_equal(img, oracle.rt_render(spheres, sh, dim, 2, -3))
+        assert shake == 0 or (np.abs(sh[:, :2]) > 0).any()
+        rt.set_mode(mi355rt.RT_MODE_BRUTE)                                   # brute mode: the plain kernel sequence behind the same entry point
+        img = rt.anim_loop(2, shake, 35, 3, 18, 2, -3)
+        ref_step(); ref_step()
+        sh, ang, rng = rt.anim_state()
+        assert np.array_equal(sh, ref.shifts) and np.array_equal(img, oracle.rt_render(spheres, sh, dim, 2, -3))
+    # idx != position (sphere.cuh:35 reads the shift row idx names): the loop falls back to the kernel sequence
+    perm = np.random.default_rng(5).permutation(n).astype(np.int32)
+    sp2 = spheres.copy(); sp2["idx"] = perm
+    ref2 = oracle.RtAnim(n)
+    with mi355rt.RayTracer(sp2, dim) as rt:
+        rt.anim_init()
+        img = rt.anim_loop(3, 2, 35, 3, 18, 0, 0)
+        for _ in range(3):
+            ref2.curve_move(); ref2.speed_angle(3, 18)
+        sh, _, _ = rt.anim_state()
+        assert np.array_equal(sh, ref2.shifts) and np.array_equal(img, oracle.rt_render(sp2, sh, dim, 0, 0))
 
 
 def test_rt_main_harness_animates(tmp_path):

@@ -17,3 +17,11 @@ with mi355rt.RayTracer(spheres, 4096) as rt:
         for _ in range(5):
             rt.render_repeat(shifts, 16, download=False); rb.append(rt.stats().ms_render)
         print(name, "16 frames back to back: median %.1f us per frame" % (statistics.median(rb) * 1e3))
+        rt.anim_init()
+        la = []
+        try:
+            for _ in range(5):
+                rt.anim_loop(32, 2, 35, 1, 18, download=False); la.append(rt.stats().ms_render)
+            print(name, "animation loop, 32 frames, one launch per frame (rt_anim_loop): median %.1f us per frame" % (statistics.median(la) * 1e3))
+        except mi355rt.RtError:
+            print(name, "no rt_anim_loop in this build")
