@@ -175,6 +175,94 @@ def secondary_measurement(torch, which, steps=60, warmup=10):
             "steps": steps, "descend_device_clock_ms": clock, "parity_checked": bool(pc["ok"]), "reference_compiled_end_result": reference_compiled_check(fixture, last, last_tested)}
 
 
+def moving_mesh_measurement(torch, quads, frames=40, shift_quads=1.0):
+    """The per-frame loop INTEGRATION.md describes, on a mesh that MOVES: sheet B of the headline's cloth pair slides `shift_quads` quads along x per frame
+    (cd_update_vertices with float-valued vertices, then cd_self_collide).  Only the STEP is timed (the clock starts after the upload has returned: a synchronous
+    copy), frame by frame, with the order hint on and off in alternating runs -- the hint carries the previous frame's wave times over BY TRIANGLE, so this is what
+    it is worth when the triangles sort into other groups every frame (the static timed region is the best a hint can be).  The last frame's pair set and
+    pairs_tested are checked against the CPU oracle."""
+    import statistics
+    import mi355_synth as synth
+    import mi355cd
+    verts, vidx = synth.cloth_pair(quads)
+    quad = 2.88 / quads
+    h = verts.shape[0] // 2
+    res = {1: [], 0: []}
+    with mi355cd.CollisionDetector(verts, vidx) as cd, mi355cd.HostPairs(1 << 22) as hp:
+        cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+        for hint in (1, 0, 1, 0):
+            cd.set_option(mi355cd.CD_OPT_ORDER_HINT, hint)
+            wall, clk = [], []
+            for f in range(frames):
+                v = verts.copy()
+                v[h:, 0] = np.float32(v[h:, 0] + np.float32(f * shift_quads * quad))          # (float-valued like the loader's output: no cell table)
+                cd.update_vertices(v)
+                t0 = time.perf_counter()
+                n, rc = cd.self_collide_into(hp.array)
+                dt = time.perf_counter() - t0
+                if rc != 0:
+                    raise RuntimeError("moving mesh: pair capacity too small")
+                if f >= 5:
+                    wall.append(dt * 1e3); clk.append(cd.fast_stats.ms_descend_clock)
+            res[hint].append((statistics.mean(wall), statistics.mean(clk)))
+            last = np.array(hp.array[:n], copy=True); last_tested = cd.fast_stats.pairs_tested; last_v = v
+        cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 1)
+    pc = parity_check(last, last_tested, last_v, vidx)
+    on = [statistics.mean(x[i] for x in res[1]) for i in (0, 1)]; off = [statistics.mean(x[i] for x in res[0]) for i in (0, 1)]
+    return {"workload": f"the headline's cloth pair, sheet B sliding {shift_quads:g} quad(s) along x per frame: cd_update_vertices + cd_self_collide per frame, {frames} frames a run, 2 runs each way",
+            "timed": "the step only (wall clock around cd_self_collide, polled completion; the upload before it is a synchronous copy and stays outside), mean over the frames after the 5th",
+            "ms_per_step": on[0], "ms_per_step_without_hint": off[0], "descend_device_clock_ms": on[1], "descend_device_clock_ms_without_hint": off[1],
+            "parity_checked": bool(pc["ok"]), "colliding_pairs_last_frame": int(pc["n_pairs"])}
+
+
+def from_obj_measurement(torch, quads):
+    """End to end FROM THE FILE, once: the counterpart of the reference's "Total Time" (main.cu:55,170-171: one event pair around loadObj ... the read-back, 187.2 ms on its
+    data against 71 ms of kernels).  The headline's mesh is written as an OBJ in the reference's dialect (`v x y z`, `f a/ta b/tb c/tc`, load_obj.h:48-56,64-80; %.9g so that
+    the parsed floats are the generator's), then cd_load_obj (threaded parser) -> cd_create (upload) -> the FIRST cd_self_collide of the context (allocations, first-touch,
+    no order hint yet), each timed on the wall clock; the pairs against the oracle on the PARSED mesh."""
+    import ctypes as C
+    import tempfile
+    import mi355_synth as synth
+    import mi355cd
+    verts, vidx = synth.cloth_pair(quads)
+    fd, path = tempfile.mkstemp(suffix=".obj", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        with os.fdopen(fd, "w") as f:
+            f.write("# bench.py from_obj: BASELINE config 3\n")
+            f.write("".join(["v %.9g %.9g %.9g\n" % (a, b, c) for a, b, c in verts.tolist()]))
+            f.write("".join(["f %d/%d %d/%d %d/%d\n" % (a + 1, a + 1, b + 1, b + 1, c + 1, c + 1) for a, b, c in vidx.tolist()]))
+        size = os.path.getsize(path)
+        lib = mi355cd.load_library()
+        threads = min(16, len(os.sched_getaffinity(0)))
+        pv, pf = C.POINTER(C.c_double)(), C.POINTER(C.c_uint32)()
+        nv, nt = C.c_uint32(0), C.c_uint32(0)
+        open(path, "rb").read()                                               # (page cache warm: the parse is timed, not the disk)
+        t0 = time.perf_counter()
+        rc = lib.cd_load_obj(path.encode(), C.byref(pv), C.byref(nv), C.byref(pf), C.byref(nt), threads)
+        t1 = time.perf_counter()
+        if rc != 0:
+            raise RuntimeError("cd_load_obj failed: %d" % rc)
+        try:
+            pverts = np.ctypeslib.as_array(pv, shape=(nv.value, 3)); pvidx = np.ctypeslib.as_array(pf, shape=(nt.value, 3))
+            same = bool(np.array_equal(pverts, verts) and np.array_equal(pvidx, vidx))
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            cd = mi355cd.CollisionDetector(pverts, pvidx)                     # cd_create: allocations + upload (main.cu:78-88)
+            t3 = time.perf_counter()
+            with cd:
+                pairs, n, rc2 = cd.self_collide(cap=1 << 22)                 # the context's FIRST step, pairs into an ordinary host buffer (main.cu:91-151)
+                t4 = time.perf_counter()
+                tested = cd.stats().pairs_tested
+                pc = parity_check(pairs[:n], tested, np.array(pverts), np.array(pvidx))
+        finally:
+            lib.cd_free_obj(pv, pf)
+    finally:
+        os.unlink(path)
+    return {"what": "OBJ file -> cd_load_obj -> cd_create -> first cd_self_collide, each once, wall clock (the reference's Total Time, main.cu:55,170-171: 187.2 ms on its data)",
+            "obj_bytes": int(size), "threads": int(threads), "parse_ms": (t1 - t0) * 1e3, "create_ms": (t3 - t2) * 1e3, "first_step_ms": (t4 - t3) * 1e3,
+            "total_ms": (t1 - t0 + t4 - t2) * 1e3, "parsed_mesh_equals_generated": same, "colliding_pairs": int(n), "parity_checked": bool(pc["ok"] and rc2 == 0)}
+
+
 def size_measurement(torch, which, steps=40, warmup=8):
     """The step ABOVE 1 M triangles on one GPU, same call and options as the headline, untimed-region extras like soup_1M:
       cloth_4M          cloth-vs-cloth with 1000 x 1000 quads per sheet = 4 000 000 triangles (the headline's surfaces, twice as fine);
@@ -397,8 +485,17 @@ def main():
     # MI355_BENCH_SELF_PEER=1 (rehearsal on ONE GPU, launched with --nproc-per-node 1): the multi-GPU code path of this
     # file and cd_multi_step run with a one-rank communicator that exchanges with itself -- never a measured configuration
     self_peer = os.environ.get("MI355_BENCH_SELF_PEER", "0") == "1" and world == 1
-    multi_path = world > 1 or self_peer
+    # MI355_BENCH_MULTI_PATH=1 with --gpus 1: the N = 1 point of a scaling curve measured on the SAME code path as N > 1 -- cd_multi_step with a one-rank RCCL
+    # communicator and no peer: box, both all-gathers, the pack launch, the two host synchronisations, no exchange.  Its `value` is the plain line's minus what that
+    # machinery costs a step; `path` in the line says which one ran.
+    multi_n1 = os.environ.get("MI355_BENCH_MULTI_PATH", "0") == "1" and world == 1 and not self_peer
+    multi_path = world > 1 or self_peer or multi_n1
     if multi_path:
+        if world == 1 and "MASTER_ADDR" not in os.environ:           # a one-rank job started plainly: the rendezvous is this process
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)        # nccl == RCCL on ROCm
         else:
@@ -466,19 +563,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # The DOMINANT kernel (the descent) is timed over the timed region in two ways: (1) by ITSELF in every step -- first wave start ->
-    # last wave end on the device's constant wall clock (cd_stats.ms_descend_clock), free; (2) with HIP events riding on its dispatch
-    # packet (cd_stats.ms_descend) in every STAMP_EVERY-th timed step -- a stamped kernel costs the step ~7 us of idle GPU around it
-    # (tools/event_cost.py), so stamping all K steps would make the measurement 3 % of what it measures.  The other kernels' times,
-    # the device time of the whole pipeline and the per-stage breakdown come from extra, untimed steps (see the end)
-    STAMP_EVERY = 8
+    # The DOMINANT kernel (the descent) is timed (1) by ITSELF in every step of the timed region -- first wave start -> last wave end on the
+    # device's constant wall clock (cd_stats.ms_descend_clock), free -- and (2) with HIP events riding on its dispatch packet (cd_stats.ms_descend)
+    # in the profiling steps right behind the timed region, with the other kernels': a stamped kernel costs its step ~7 us of idle GPU around it,
+    # so the K timed steps carry no stamp at all (round 5; the two clocks and rocprofv3's average agree to a microsecond).  The device time of the
+    # whole pipeline and the per-stage breakdown come from those extra, untimed steps too (see the end)
     engine.cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0)
     if not multi_path:
         engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
     stage = {"morton": 0.0, "sort": 0.0, "build_fused(hierarchy+refit+records)": 0.0, "traverse": 0.0}
     kern = {"descend": 0.0, "descend_device_clock": 0.0, "exact": 0.0, "build_block": 0.0}   # the two kernels inside "traverse" + the fused hierarchy / refit kernel
-    stamped_steps = 0
     tested_total = 0
     pairs_found = 0
     pipeline_ms = 0.0
@@ -488,18 +583,12 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i_step in range(args.steps):
-        stamped = (not multi_path) and i_step % STAMP_EVERY == 0
-        if stamped:
-            engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 2)     # HIP events on the descent's dispatch packet, this step only
         pairs, tested, info = step()
         st = engine.cd.fast_stats if not multi_path else engine.cd.stats()   # (refreshed by the step's own call)
         if tested is None:
             tested = st.pairs_tested
         if not multi_path:
             kern["descend_device_clock"] += st.ms_descend_clock
-            if stamped:
-                kern["descend"] += st.ms_descend; stamped_steps += 1
-                engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
         tested_total += tested
         pairs_found = pairs.shape[0]
     torch.cuda.synchronize()
@@ -533,6 +622,8 @@ def main():
             # (collision.cuh:31-44 lets each leaf query the whole tree).  The default half traversal decides each unordered pair ONCE and
             # credits 2 (box.cuh:40-43 and neighborCount are symmetric; equal to the oracle's counter in every test): the device executes
             # half as many exact box decisions as `value` says
+            "path": ("cd_multi_step (C++ over RCCL)" + (", one-rank communicator exchanging with itself: REHEARSAL" if self_peer else (", one-rank communicator, no peer" if multi_n1 else ""))) if ms is not None
+                    else ("cd_self_collide" if not multi_path else "Python rehearsal of the multi-GPU step over " + backend),
             "pairs_tested_counting": "reference-equivalent: the half traversal decides each unordered leaf pair once and credits the 2 ordered tests the reference makes",
             "box_decisions_executed_per_step": (tested_total // k) // (1 if args.traversal in (0, 1) else 2),
         }
@@ -542,7 +633,7 @@ def main():
             for _ in range(prof_steps):
                 step()
                 st = engine.cd.stats()
-                kern["exact"] += st.ms_exact * k / prof_steps; kern["build_block"] += st.ms_build_block * k / prof_steps
+                kern["exact"] += st.ms_exact * k / prof_steps; kern["build_block"] += st.ms_build_block * k / prof_steps; kern["descend"] += st.ms_descend * k / prof_steps
                 pipeline_ms += st.ms_pipeline * k / prof_steps
             engine.cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 1)  # untimed: the same step with events around every stage
             for _ in range(prof_steps):
@@ -565,7 +656,6 @@ def main():
             #   k_descend_half:           the fp32 descent, 40 B/triangle (row S5: the tree read once).
             # The other one is reported beside it.  `traffic` = HBM bytes per launch from the rocprofv3 --pmc passes
             # (profiles/traffic.json, produced by tools/refresh_profiles.sh + tools/summarise_profiles.py).
-            kern["descend"] *= k / max(1, stamped_steps)
             for k_ in kern:
                 kern[k_] /= k
             traffic_of = {}
@@ -599,10 +689,10 @@ def main():
             if cands[1]["avg_launch_ms"] > 1.05 * cands[0]["avg_launch_ms"]:
                 cands.reverse()
             line["kernel_ms"] = kern
-            line["kernel_ms_note"] = (f"descend: live over the timed region, HIP events on the kernel's dispatch packet in {stamped_steps} of the {k} timed steps (every "
-                                      f"{STAMP_EVERY}th: a stamped kernel costs its step ~7 us of idle GPU); descend_device_clock: live, EVERY timed step, the kernel's own "
-                                      f"first-wave-start -> last-wave-end on the device wall clock; exact, build_block and total_collision_ms_device: from {prof_steps} "
-                                      f"extra untimed steps with all stamps on")
+            line["kernel_ms_note"] = (f"descend_device_clock: live, EVERY step of the timed region, the kernel's own first-wave-start -> last-wave-end on the device wall clock (free); "
+                                      f"descend, exact, build_block and total_collision_ms_device: HIP events riding on the kernels' dispatch packets (on the library's stream) in {prof_steps} steps "
+                                      f"of the same loop right BEHIND the timed region -- a stamped kernel costs its step ~7 us of idle GPU, so none of the K timed steps carries one "
+                                      f"(rounds 2-4 stamped every 8th timed step: ~1 us of the headline)")
             # what the descent's steps are filled with (VERDICT r02 asked for it beside the wait share in profiles/rNN/pmc_sq_per_kernel.csv): a wave-step is one
             # pass of a wave through a hop or a descent step, a node visit one lane's box test(s) in it
             st = engine.cd.stats()
@@ -680,6 +770,8 @@ def main():
         line["cloth_1M_double"] = secondary_measurement(torch, "cloth_1M_double")
         line["cloth_4M"] = size_measurement(torch, "cloth_4M")
         line["config4_merged_8M"] = size_measurement(torch, "config4_merged_8M")
+        line["moving_mesh"] = moving_mesh_measurement(torch, args.quads)
+        line["from_obj"] = from_obj_measurement(torch, args.quads)
     if not args.no_ray and (backend == "nccl" or not multi_path):
         rtm = ray_tracer_measurement(rank=rank, world=world if multi_path else 1, dist=dist if multi_path else None, torch=torch, device=device, multi=multi_path)
         if rank == 0:

@@ -1178,6 +1178,39 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert line["config"]["last_step_rank0"]["peers"] == [1] and line["config"]["last_step_rank0"]["sent_queries"] > 0
 
 
+def test_bench_started_plainly_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` WITHOUT a launcher around it (what a driver that does not know about torch.distributed.run does): the script starts
+    `python -m torch.distributed.run --nproc-per-node 2 ... bench.py <same arguments>` itself, as a child process and before anything touches the GPU, relays rank 0's
+    line and returns the child's exit code (gloo rehearsal backend here: RCCL refuses two ranks on one device).  And --gpus 1 on the multi-GPU code path
+    (MI355_BENCH_MULTI_PATH=1: cd_multi_step with a one-rank communicator and no peer) gives the plain line's pairs and says which path ran."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MI355_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--quads", "60"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "launching" in out.stderr
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["parity_checked"] is True
+    # a launch that fails hands back the child's code: a mesh without triangles
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--quads", "0"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert bad.returncode != 0
+    # N = 1 on both paths
+    env1 = dict(env); env1.pop("MI355_DIST_BACKEND")
+    lines = {}
+    for name, extra in (("plain", {}), ("multi", {"MI355_BENCH_MULTI_PATH": "1"})):
+        o = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--quads", "100", "--no-extras", "--no-ray", "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=600, env=dict(env1, **extra), cwd=root)
+        assert o.returncode == 0, o.stdout[-2000:] + o.stderr[-2000:]
+        lines[name] = json.loads([l for l in o.stdout.splitlines() if l.startswith("{")][-1])
+    assert lines["plain"]["path"] == "cd_self_collide" and lines["multi"]["path"].startswith("cd_multi_step") and "no peer" in lines["multi"]["path"]
+    assert lines["plain"]["config"]["colliding_pairs"] == lines["multi"]["config"]["colliding_pairs"] > 0
+    assert lines["plain"]["config"]["pairs_tested_per_step"] == lines["multi"]["config"]["pairs_tested_per_step"]
+    assert lines["plain"]["parity_checked"] is True and lines["multi"]["parity_checked"] is True
+
+
 def test_every_morton_key_equal():
     """All centroids are EXACTLY one point (p1 = c + a, p2 = c + b, p3 = c - a - b with few-bit a, b): one Morton key, so the
     order and the whole tree are the index tie-break's (delta = 64 + clz(i ^ j)), across six 512-leaf blocks -- the cross nodes'
