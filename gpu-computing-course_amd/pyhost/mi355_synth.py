@@ -38,6 +38,72 @@ def soup(n: int, e: float = 0.02, seed: int = 1234):
     return verts, vidx
 
 
+class MT19937_64:
+    """std::mt19937_64 (the 64-bit Mersenne twister of Matsumoto & Nishimura, 2000; C++11 [rand.predef]) in numpy, a state block of 312 words at a
+    time -- what SURVEY.md 8(d) names for the soups (`mt19937_64(seed=1234)`); numpy's own MT19937 is the 32-bit generator.  Known answer ([rand.predef]):
+    the 10000th output of a default-seeded (5489) engine is 9981545732273789042 (tests/test_synth.py)."""
+    NN, MM = 312, 156
+    MATRIX, UM, LM = np.uint64(0xB5026F5AA96619E9), np.uint64(0xFFFFFFFF80000000), np.uint64(0x7FFFFFFF)
+
+    def __init__(self, seed: int = 5489):
+        mt = np.zeros(self.NN, dtype=np.uint64)
+        x = seed & 0xFFFFFFFFFFFFFFFF
+        for i in range(self.NN):
+            if i:
+                x = (6364136223846793005 * (x ^ (x >> 62)) + i) & 0xFFFFFFFFFFFFFFFF
+            mt[i] = x
+        self.mt = mt
+
+    def _twist(self):
+        mt, N, M = self.mt, self.NN, self.MM
+        one = np.uint64(1)
+
+        def mix(up, low, far):                                  # the recurrence for a run of positions whose three inputs are all available
+            x = (up & self.UM) | (low & self.LM)
+            return far ^ (x >> one) ^ np.where((x & one).astype(bool), self.MATRIX, np.uint64(0))
+        mt[:N - M] = mix(mt[:N - M], mt[1:N - M + 1], mt[M:])                       # i in [0, 156): mt[i + 156] is still the old block's
+        mt[N - M:N - 1] = mix(mt[N - M:N - 1], mt[N - M + 1:], mt[:M - 1])          # i in [156, 311): mt[i - 156] is the new block's
+        mt[N - 1:] = mix(mt[N - 1:], mt[:1], mt[M - 1:M])                          # i = 311 wraps to the new mt[0]
+
+    def raw(self, count: int) -> np.ndarray:
+        """The next `count` 64-bit outputs."""
+        blocks = (count + self.NN - 1) // self.NN
+        out = np.empty(blocks * self.NN, dtype=np.uint64)
+        for b in range(blocks):
+            self._twist()
+            out[b * self.NN:(b + 1) * self.NN] = self.mt
+        x = out
+        x ^= (x >> np.uint64(29)) & np.uint64(0x5555555555555555)
+        x ^= (x << np.uint64(17)) & np.uint64(0x71D67FFFEDA60000)
+        x ^= (x << np.uint64(37)) & np.uint64(0xFFF7EEE000000000)
+        x ^= x >> np.uint64(43)
+        # (a whole number of blocks is consumed: generators below draw everything they need in one call)
+        return x[:count]
+
+    def uniform(self, count: int, a: float, b: float) -> np.ndarray:
+        """std::uniform_real_distribution<double>(a, b) as libstdc++ evaluates it on a 64-bit engine: generate_canonical<double, 53> is ONE draw,
+        double(x) / 2^64 (the conversion rounds to nearest; a result of 1.0 is replaced by the double below it), then r * (b - a) + a."""
+        r = self.raw(count).astype(np.float64) / 18446744073709551616.0
+        r = np.where(r >= 1.0, np.nextafter(1.0, 0.0), r)
+        return r * (b - a) + a
+
+
+def soup_mt64(n: int, e: float = 0.02, seed: int = 1234):
+    """SURVEY.md 8(d)'s soup recipe with the generator it names: std::mt19937_64(seed); ALL centroids first (x, y, z per triangle, each uniform in its
+    interval of the generation box), then per triangle its three vertices' offsets (vertex-major, x y z), each uniform_real_distribution(-e/2, e/2);
+    vertices rounded to float, V = 3N, ID = i.  (Round 5: the survey's recorded counts -- 1 326 pairs / 117 850 tested at 100 k, 16 795 / 1 222 266 at 1 M --
+    are not reproduced by any draw order tried: the survey kept the description, not the code.  This order gives 1 326 / 117 666 and 16 992 / 1 224 320;
+    DESIGN.md 3.)  Returns (verts[V,3] f64, vidx[N,3] u32)."""
+    g = MT19937_64(seed)
+    draws = g.raw(12 * n).astype(np.float64) / 18446744073709551616.0      # one engine, one stream: 3 n centroid draws, then 9 n offsets
+    draws = np.where(draws >= 1.0, np.nextafter(1.0, 0.0), draws)
+    c = draws[:3 * n].reshape(n, 3) * (BOX_HI - BOX_LO) + BOX_LO
+    d = draws[3 * n:].reshape(n, 3, 3) * (e / 2 - (-e / 2)) + (-e / 2)
+    verts = _f32((c[:, None, :] + d).reshape(3 * n, 3))
+    vidx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    return verts, vidx
+
+
 def _sheet(nx: int, ny: int, zfun, x0, x1, y0, y1):
     """(nx x ny quads) -> (nx+1)*(ny+1) shared vertices, 2*nx*ny triangles."""
     xs = np.linspace(x0, x1, nx + 1)

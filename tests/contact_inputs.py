@@ -149,6 +149,9 @@ def end_configs():
     yield "cloth1M", synth.cloth_pair(500), 1                              # BASELINE config 3
     yield "soup1M", synth.soup(1_000_000, e=0.01, seed=1234), 1            # the bench line's second workload
     yield "cloth1M_double", cloth_pair_double(500), 1                      # config 3 with vertices NOT rounded to float32
+    # SURVEY.md 8(d)'s recipe with the generator it names, std::mt19937_64(seed = 1234) (mi355_synth.soup_mt64; round 5)
+    yield "soup100k_mt64", synth.soup_mt64(100_000, e=0.02, seed=1234), 0  # BASELINE config 2, the survey's generator
+    yield "soup1M_mt64", synth.soup_mt64(1_000_000, e=0.01, seed=1234), 1
 
 
 def cloth_pair_double(quads: int = 500):

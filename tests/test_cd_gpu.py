@@ -1691,7 +1691,7 @@ def test_device_boxes_equal_reference_compiled_vectors():
     assert ci.sha(mg) == str(ref["box_merge_sha"]) and np.array_equal(mg[:4096].view(np.uint64), ref["box_merge_head"].view(np.uint64))
 
 
-@pytest.mark.parametrize("name", ["soup100k", "cloth1M", "soup1M", "cloth1M_double"])
+@pytest.mark.parametrize("name", ["soup100k", "cloth1M", "soup1M", "cloth1M_double", "soup100k_mt64", "soup1M_mt64"])
 def test_self_collide_default_options_equals_reference_compiled_end_result(name):
     """cd_self_collide with the library's default options, two consecutive steps: the pair set (SHA-256 of the sorted keys, every
     64th key, the full list where the fixture holds it) and pairs_tested equal what the REFERENCE'S compiled predicates give for

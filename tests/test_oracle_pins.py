@@ -409,7 +409,7 @@ def end_mesh(name):
     raise KeyError(name)
 
 
-@pytest.mark.parametrize("name", ["soup100k", "cloth1M", "soup1M", "cloth1M_double"])
+@pytest.mark.parametrize("name", ["soup100k", "cloth1M", "soup1M", "cloth1M_double", "soup100k_mt64", "soup1M_mt64"])
 def test_ref_compiled_end_result(contact_ref, name):
     """The oracle's whole pipeline (Morton build + traversal, orc_self_collide) returns the reference-compiled pair set and
     pairs-tested count on BASELINE config 2 (100 k soup; the reference side is a plain O(N^2) over its predicates),
