@@ -570,6 +570,8 @@ __global__ __launch_bounds__(256) void k_top_publish_upper(unsigned long long *_
     if (tid == 0) *top_flag = top_seq;
 }
 
+// (76 VGPRs: six waves per SIMD.  Held at 72 / 64 registers for seven / eight -- amdgpu_waves_per_eu, 20 / 48 bytes of scratch -- the kernel took 19.9 / 23.8 us
+//  instead of 17.7 at 1 M triangles and 134 / 154 instead of 127 at 8 M: profiles/r05_experiments/size_scaling.log)
 __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restrict__ keys, int n, const double *__restrict__ seg, const float *__restrict__ seg32,
                                                      int nbp2, int nblocks, const LeafBox32 *__restrict__ qbox32, double *__restrict__ boxes,
                                                      NodeRec32 *__restrict__ recs32, const int32_t *__restrict__ split_of, int32_t *__restrict__ root_name,
