@@ -44,7 +44,7 @@ def per_kernel(path):
 
 
 hbm = collections.defaultdict(dict)
-for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_rdreq"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_rdreq", "rt_pmc_fetch", "rt_pmc_write", "rt_pmc_l2", "rt_pmc_rdreq"):     # (rt_*: the ray tracer's kernels, tools/rt_time.py)
     if not os.path.exists(os.path.join(src, sub, "run_counter_collection.csv")):
         continue
     for k, cs in per_kernel(os.path.join(src, sub, "run_counter_collection.csv")).items():
@@ -62,6 +62,16 @@ with open(os.path.join(dst, "pmc_hbm_per_kernel.csv"), "w") as f:
         sized = f"{hbm[k]['read_sized']:.0f}" if hbm[k]["read_sized"] is not None else ""
         f.write(f"\"{k}\",{fr * 1024:.0f},{2 * fr * 1024:.0f},{sized},{n32:.0f},{n64:.0f},{n128:.0f},{wr * 1024:.0f},{hit:.0f},{miss:.0f},{rate},{hbm[k].get('launches_FETCH_SIZE', 0)}\n")
 sq = per_kernel(os.path.join(src, "pmc_sq", "run_counter_collection.csv"))
+if os.path.exists(os.path.join(src, "rt_pmc_sq", "run_counter_collection.csv")):
+    for k, cs in per_kernel(os.path.join(src, "rt_pmc_sq", "run_counter_collection.csv")).items():
+        for c, v in cs.items():
+            sq[k].setdefault(c, v)
+# round 5: the 8 M step's tables and the ray tracer's kernel stats, as the refresh script left them
+for name in ("8M_kernel_stats.csv", "8M_pmc_per_kernel.csv", "rt_time_plain.log"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+if os.path.exists(os.path.join(src, "rt_trace", "run_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "rt_trace", "run_kernel_stats.csv"), os.path.join(dst, "rt_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "pmc_sq2", "run_counter_collection.csv")):      # scalar side + issue / wait split, a second pass (8 SQ slots per pass)
     for k, cs in per_kernel(os.path.join(src, "pmc_sq2", "run_counter_collection.csv")).items():
         for c, v in cs.items():
