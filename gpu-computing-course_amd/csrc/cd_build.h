@@ -695,13 +695,16 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
             for (int u = 0; u < 4; ++u) { tk[u] = p > REFIT_LOG && piece(u >> 1, p, u & 1, kk[u]); any_top |= tk[u]; }
             if (!__builtin_amdgcn_ballot_w64(any_top)) continue;            // (wave-uniform) no range among the wave's four nodes takes a piece of two blocks or more
             bool ready = !any_top;
+            // (a piece of the two levels directly above the blocks is two / four block boxes away: a lane that finds the flag not yet set folds those itself
+            //  instead of holding its wave for the publisher -- only a piece of eight blocks or more is worth the wait)
+            const bool must = any_top && p > REFIT_LOG + 2;
 #ifdef CROSS_FORCE_FALLBACK                                                // (test builds: nobody sees the flag, every upper-level piece is folded by the lane that needs it)
             for (uint32_t spin = 0; spin < 0u; ++spin) {
 #else
             for (uint32_t spin = 0; spin < (1u << 20); ++spin) {            // (bounded: a lane that never sees the flag folds its node itself, below)
 #endif
                 if (!ready) ready = __hip_atomic_load(top_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == top_seq;
-                if (!__builtin_amdgcn_ballot_w64(!ready)) break;            // every lane that needs the upper levels has seen this launch's number
+                if (!__builtin_amdgcn_ballot_w64(must && !ready)) break;    // every lane that has to wait has seen this launch's number
                 __builtin_amdgcn_s_sleep(2);
             }
 #pragma unroll
