@@ -1017,6 +1017,21 @@ def test_eight_million_soup_variants_agree():
     assert oracle.tri_contact_batch(verts, vidx, pr).all()
 
 
+@pytest.mark.parametrize("n", [512 * 4096, 512 * 4096 + 1, 544 * 4096 - 7, 577 * 4096 + 123])
+def test_first_sort_pass_with_chunk_totals_at_its_boundaries(n):
+    """Round 5: beyond 512 sort tiles the first onesweep pass takes a tile's offsets from chunk totals (k_tile_chunks: the per-tile digit counts of k_morton summed
+    over chunks of 32 tiles) + the rows of its own chunk, instead of every earlier tile's row.  Exactly 512 tiles (the direct sums still), 513 (one chunk of one
+    tile behind sixteen full ones), a last chunk that is full but for a ragged tile, a chunk of one tile + a ragged one: keys and permutation are the oracle's
+    stable sort in every case."""
+    verts, vidx = synth.soup(n, 0.004, 41)
+    r_keys, r_perm = oracle.sort_by_key(oracle.centroid_morton(verts, vidx))
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        cd.morton_sort()
+        keys, perm = cd.export_keys()
+        assert cd.stats().sort_passes == 2
+    assert np.array_equal(keys, r_keys) and np.array_equal(perm, r_perm)
+
+
 def test_half_key_sort_equals_full_sort_and_falls_back():
     """CD_OPT_SORT_FULL: the default hybrid (2 global passes on the top 16 key bits + in-LDS sort of run-aligned
     windows + stable fix-up of equal-high-half runs), the half-key form (4 global passes + fix-up) and all 8 passes
