@@ -289,24 +289,29 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
 // longer than LOCAL_LIMIT cannot be windowed: the kernel flags it (same word as the fix-up's overflow) and the host
 // falls back to the 4-pass half-key sort, then to 8 passes.
 // ====================================================================================================
-constexpr int LOCAL_THREADS = 1024;
-constexpr int LOCAL_WAVES   = LOCAL_THREADS / 64;
-constexpr int LOCAL_W       = 4096;                     // nominal keys per workgroup
-constexpr int LOCAL_LIMIT   = 6144;                     // longest run that can be windowed (a planar 1 M cloth in the reference's frame: runs of
-                                                        // ~500 on key bits 44..59; 441 runs, the longest 4590, on bits 48..63).  Windows of
-                                                        // 2048 keys were slower: sort 85 -> 94 us (73 KB of LDS, one workgroup per CU), 84 -> 88 us (56 KB, two per CU)
-constexpr int LOCAL_ITEMS   = (LOCAL_W + LOCAL_LIMIT) / LOCAL_THREADS;   // 10 keys per lane
-constexpr int LOCAL_CAP     = LOCAL_ITEMS * LOCAL_THREADS;               // 10240 keys: 80 KB of LDS + 16 KB of counters
+// The window configuration is a template parameter (round 5): 1024 threads x 10 keys a lane (10240 keys of LDS capacity: nominal windows of 4096 keys, runs up to
+// 6144 -- 96 KB, one workgroup a CU: what a sort of up to ~2 M keys wants, its 256-odd windows are ONE round of workgroups and their latency is the kernel), or
+// 512 threads x 10 keys (5120: windows of 2048, runs up to 3072 -- 48 KB and half the waves: TWO workgroups a CU, one computing while the other waits at one of
+// its ~20 barriers: what 4-8 M keys want, whose windows are many rounds -- 8 M: 266 -> see DESIGN.md 4a).  A run too long for the small form raises the same
+// flag as always; the host then redoes the sort with the large form before it escalates to more global passes.
+template <int THREADS_, int ITEMS_, int LIMIT_> struct LocalCfg {
+    static constexpr int THREADS = THREADS_, WAVES = THREADS_ / 64, ITEMS = ITEMS_, LIMIT = LIMIT_, CAP = ITEMS_ * THREADS_, W = CAP - LIMIT_;
+    static_assert(THREADS_ >= RADIX && THREADS_ % 64 == 0 && LIMIT_ % THREADS_ == 0 && W > 0 && ITEMS_ % 2 == 0, "window configuration");
+};
+using LocalLarge = LocalCfg<1024, 10, 6144>;            // (a planar 1 M cloth in the reference's frame: runs of ~500 on key bits 44..59; 441 runs, the longest 4590, on bits 48..63)
+using LocalSmall = LocalCfg<512, 10, 3072>;             // (8 M triangles of cloth objects: runs up to 1878 on bits 44..59; a 4 M cloth pair: 2312)
+constexpr int LOCAL_W = LocalLarge::W;                  // nominal keys per workgroup of the large form (the host's window arithmetic)
 
 __device__ __forceinline__ bool fixup_position_lds(const uint2 *item, uint32_t cnt, uint32_t j, uint32_t low, uint32_t high, uint32_t &pos);
-template <class Emit>
-__global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+template <class Emit, class CFG>
+__global__ __launch_bounds__(CFG::THREADS) void k_local_sort(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                               uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n,
                                                               int run_shift /* a run = equal key bits [run_shift, 64): what the global passes sorted by */,
                                                               uint32_t *__restrict__ overflow, Emit emit /* load(value) -> payload, store(final position, value, payload): what the fix-up hop does per key */,
                                                               uint32_t *__restrict__ zero_words /* fused step: counters of the kernels that follow, zeroed here instead of by a memset */, uint32_t n_zero,
-                                                              uint32_t win /* nominal keys per workgroup, <= LOCAL_W: n spread over the chip's CUs when that is less */)
+                                                              uint32_t win /* nominal keys per workgroup, <= CFG::W: n spread over the chip's CUs when that is less */)
 {
+    constexpr int LOCAL_THREADS = CFG::THREADS, LOCAL_WAVES = CFG::WAVES, LOCAL_ITEMS = CFG::ITEMS, LOCAL_LIMIT = CFG::LIMIT, LOCAL_CAP = CFG::CAP;
     if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < n_zero; i += LOCAL_THREADS) zero_words[i] = 0u;
     __shared__ uint2 sitem[LOCAL_CAP];                   // 80 KB: {high 32 key bits, position inside the window}
     __shared__ uint32_t wcnt[LOCAL_WAVES][RADIX];        // 16 KB
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint64_t *__
     // waves 4 item rounds per pass and two waves 5 (with equal shares rounded up to 64 it cost thirteen waves 5 rounds and
     // left three idle; the windows end at run starts, so half of them are a little over their nominal 4096 keys).  Every
     // sweep below stops at `nit` (wave-uniform; no barrier sits inside a sweep).
-    const uint32_t full = cnt >> 10, extra = ((cnt & 1023u) + 63u) >> 6;      // 1024 = 16 waves x 64 lanes
+    const uint32_t full = cnt / (uint32_t)LOCAL_THREADS, extra = ((cnt % (uint32_t)LOCAL_THREADS) + 63u) >> 6;      // (a power of two: a shift and a mask)
     const int nit = (int)(full + ((uint32_t)w < extra ? 1u : 0u));            // <= LOCAL_ITEMS
     const uint32_t base_w = ((uint32_t)w * full + min((uint32_t)w, extra)) * 64u;
     uint32_t kh[LOCAL_ITEMS], ix[LOCAL_ITEMS], rk[LOCAL_ITEMS];

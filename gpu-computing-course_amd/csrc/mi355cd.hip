@@ -95,6 +95,8 @@ struct cd_ctx {
     bool hierarchy_valid = false;           // meta[] / parent[] hold the tree of the current keys (fused calls build the records without them)
     bool last_tree_fused = false;           // the last fused call built hierarchy + refit in one pass (ms_hierarchy is then part of ms_refit)
     uint32_t stamp_mask = 15;               // CD_OPT_KERNEL_STAMPS: with stage timing off, which time stamps a fused call still takes (1 block build, 2 descent, 4 exact, 8 pipeline start): ~5 us of idle GPU each
+    uint32_t dbg_sort_windows = 0;          // CD_DBG_SORT_WINDOWS: 0 the form the size asks for, 1 always the large window form of k_local_sort, 2 always the small one (A/B, tests)
+    bool local_small_ok = true, local_small_active = false;   // the small window form has not met a run too long for it; the sort in flight used it
     uint32_t dbg_split_cross = 0;           // CD_DBG_SPLIT_CROSS: the fused build runs k_cross_meta + k_cross_records instead of k_cross_fused (A/B, tests)
     uint32_t dbg_no_fused_build = 0;        // CD_DBG_STAGEWISE_BUILD: fused entry points run k_hierarchy + the meta-reading refit (A/B)
     uint32_t *d_small = nullptr;            // 16 x u32 scratch counters (parent_wrong, check outputs)
@@ -269,6 +271,7 @@ __global__ void k_amb_vertex(const double *__restrict__ verts, uint32_t nv, AmbT
 }
 
 constexpr int BOUNDS_BLOCKS = 1024;
+constexpr uint32_t LOCAL_SMALL_MIN = 5u << 18;     // 1.31 M keys: from there k_local_sort runs its small window form (cd_sort.h) -- the large one is more than one round of workgroups (1.44 M: 309 -> 305 us a step, 2.25 M: 437 -> 424, 4 M: 686 -> 667, 8 M: 1442 -> 1374)
 
 int ensure_pairs(cd_ctx *c, TravBuf &tb, uint64_t cap)
 {
@@ -361,9 +364,19 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
         const LeafFill fill{c->d_vidx, c->d_ids, n, c->d_leaf, links_too ? c->d_parent : nullptr, links_too ? c->d_bounded : nullptr};
         // one workgroup per CU is all this kernel's LDS allows: the windows are n / 256 keys when that is less than their nominal
         // 4096 (1 M keys: 256 windows of 3907 instead of 245 of 4096 -- every CU busy, fewer windows over 4096 keys), not below 1024
-        const uint32_t per_cu = cdiv(n, 256u), win = per_cu >= (uint32_t)LOCAL_W ? (uint32_t)LOCAL_W : (per_cu < 1024u ? 1024u : per_cu);
-        k_local_sort<<<cdiv(n, win), LOCAL_THREADS, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, 48 - down, c->d_os_ticket + 16, fill,
-                                                            self_cleaning ? c->d_small : nullptr, self_cleaning ? 128u : 0u, win);
+        // (round 5) many rounds of windows -- more than LOCAL_SMALL_MIN keys -- take the small form: windows of 2048 keys in workgroups of 512 threads and 48 KB,
+        // two of which share a CU (cd_sort.h); a run too long for it (3072 keys) is answered by the large form first (judge_sort_flags)
+        const bool small = c->dbg_sort_windows == 2 || (c->dbg_sort_windows == 0 && n > LOCAL_SMALL_MIN && c->local_small_ok);
+        c->local_small_active = small;
+        if (small) {
+            const uint32_t win = (uint32_t)LocalSmall::W;
+            k_local_sort<LeafFill, LocalSmall><<<cdiv(n, win), LocalSmall::THREADS, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, 48 - down, c->d_os_ticket + 16, fill,
+                                                                                            self_cleaning ? c->d_small : nullptr, self_cleaning ? 128u : 0u, win);
+        } else {
+            const uint32_t per_cu = cdiv(n, 256u), win = per_cu >= (uint32_t)LOCAL_W ? (uint32_t)LOCAL_W : (per_cu < 1024u ? 1024u : per_cu);
+            k_local_sort<LeafFill, LocalLarge><<<cdiv(n, win), LocalLarge::THREADS, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, 48 - down, c->d_os_ticket + 16, fill,
+                                                                                            self_cleaning ? c->d_small : nullptr, self_cleaning ? 128u : 0u, win);
+        }
         c->leaves_filled = links_too;
         c->leaf_records_filled = true;
     } else if (mode != 3) {
@@ -918,7 +931,7 @@ int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs
     if (rc) return rc;
     uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
     const bool direct = pinned_pairs_id(pairs, cap_pairs) != 0;
-    const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1) | (c->order_hint ? 4u : 0u) | (c->order_ready ? 8u : 0u) /* (whether the descent's launch reads the order hint is baked in) */,
+    const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1) | (c->order_hint ? 4u : 0u) | (c->order_ready ? 8u : 0u) | (c->local_small_ok ? 16u : 0u) | (c->dbg_sort_windows << 5) /* (whether the descent's launch reads the order hint is baked in) */,
                                tb.d_pairs, tb.d_cand, tb.d_defer, direct ? (const void *)pairs : (const void *)tb.h_report, tb.cand_cap, tb.defer_cap, 0u};
     static_assert(sizeof(cd_ctx::GraphKey) == 2 * 8 + 6 * 4 + 4 * 8 + 8 + 2 * 4, "GraphKey has no padding");
     if (!c->graph_exec || std::memcmp(&key, &c->graph_key, sizeof key) != 0) {
@@ -1111,7 +1124,11 @@ namespace { int judge_sort_flags(cd_ctx *c)
 {
     for (int i = 0; i < 9; ++i) if (c->sort_flags[i]) c->scratch_clean = false;     // the flag words are cleared by the memset only
     for (int i = 0; i < 8; ++i) if (c->sort_flags[i]) return CD_ERR_SORT;
-    if (c->sort_flags[8]) { if (c->sort_mode >= 3) return CD_ERR_SORT; ++c->sort_mode; return SORT_REDO; }
+    if (c->sort_flags[8]) {
+        if (c->local_small_active && c->local_small_ok && c->sort_mode <= 1) { c->local_small_ok = false; return SORT_REDO; }   // a run too long for the small windows: the large form, same passes
+        if (c->sort_mode >= 3) return CD_ERR_SORT;
+        ++c->sort_mode; return SORT_REDO;
+    }
     return CD_OK;
 } }
 static int check_sort_flags(cd_ctx *c)
@@ -1127,7 +1144,7 @@ int cd_morton_sort(cd_ctx *c)
     int rc = enqueue_morton_sort(c);
     if (rc) return rc;
     rc = check_sort_flags(c);
-    for (int redo = 0; rc == SORT_REDO && redo < 3; ++redo) { if ((rc = enqueue_morton_sort(c))) return rc; rc = check_sort_flags(c); }
+    for (int redo = 0; rc == SORT_REDO && redo < 4; ++redo) { if ((rc = enqueue_morton_sort(c))) return rc; rc = check_sort_flags(c); }
     if (rc) return rc;
     c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
     c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
@@ -1572,6 +1589,7 @@ int cd_debug_option(cd_ctx *c, int key, int64_t value, int64_t *out)
     case CD_DBG_DIAG:            c->dbg_diag = value != 0; return CD_OK;
     case CD_DBG_STAGEWISE_BUILD: c->dbg_no_fused_build = value != 0; return CD_OK;
     case CD_DBG_SPLIT_CROSS:     c->dbg_split_cross = value != 0; return CD_OK;
+    case CD_DBG_SORT_WINDOWS:    if (value < 0 || value > 2) return CD_ERR_ARG; c->dbg_sort_windows = (uint32_t)value; c->local_small_ok = true; graph_drop(c); return CD_OK;
     case CD_DBG_REPORT_COPIES:   c->dbg_report_copies = value != 0; graph_drop(c); return CD_OK;
     case CD_DBG_POLL_SCAN:       c->dbg_poll_check = value != 0; return CD_OK;
     case CD_DBG_GET_POLL_STALE:     if (!out) return CD_ERR_ARG; *out = c->poll_stale; return CD_OK;

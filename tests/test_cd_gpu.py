@@ -1032,6 +1032,45 @@ def test_first_sort_pass_with_chunk_totals_at_its_boundaries(n):
     assert np.array_equal(keys, r_keys) and np.array_equal(perm, r_perm)
 
 
+def test_window_sort_forms_agree_and_the_small_one_hands_long_runs_to_the_large_one():
+    """Round 5: beyond 2 M keys the in-LDS window sort runs windows of 2048 keys in 512-thread workgroups (two a CU) instead of 4096 in 1024 (one a CU).
+    Both forms, forced on meshes on either side of that size (CD_DBG_SORT_WINDOWS), give the oracle's keys and permutation; a run of equal top key bits that is
+    too long for the small form (3072) but not for the large one (6144) makes the library redo the sort with the large form -- still two global passes."""
+    for n, seed in ((300_000, 51), (1_500_000, 52)):
+        verts, vidx = synth.soup(n, 0.004, seed)
+        r_keys, r_perm = oracle.sort_by_key(oracle.centroid_morton(verts, vidx))
+        for form in (1, 2, 0):
+            with mi355cd.CollisionDetector(verts, vidx) as cd:
+                cd.debug_set(mi355cd.CD_DBG_SORT_WINDOWS, form)
+                cd.morton_sort()
+                keys, perm = cd.export_keys()
+                assert cd.stats().sort_passes == 2, (n, form)
+            assert np.array_equal(keys, r_keys) and np.array_equal(perm, r_perm), (n, form)
+    # 4500 triangles whose centroids share ONE cell of the top 16 key bits (6 bits of x, 5 of y and z: 0.048 x 0.024 x 0.074 of the reference's frame) but are
+    # spread over it (their high key HALVES differ: that is another limit, FIX_MAX), inside a 2.2 M soup
+    verts, vidx = synth.soup(2_200_000, 0.004, 53)
+    rng = np.random.default_rng(54)
+    k = 4500
+    cell = synth.REF_SPAN / np.array([64.0, 32.0, 32.0])
+    c0 = synth.REF_OFF + (np.array([30, 15, 14]) + 0.5) * cell
+    cl = (c0 + (rng.random((k, 1, 3)) - 0.5) * 0.6 * cell + (rng.random((k, 3, 3)) - 0.5) * 1e-3).reshape(-1, 3)
+    verts[: 3 * k] = cl.astype(np.float32).astype(np.float64)
+    keys0 = oracle.centroid_morton(verts, vidx)
+    top = np.sort(keys0 >> np.uint64(44))
+    runs = np.diff(np.concatenate([[0], np.flatnonzero(np.diff(top)) + 1, [top.shape[0]]]))
+    assert 3072 < runs.max() <= 6144, runs.max()
+    r_keys, r_perm = oracle.sort_by_key(keys0)
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        for _ in range(2):                                                   # (the second call starts with the large form: the context remembers)
+            cd.morton_sort()
+            keys, perm = cd.export_keys()
+            assert cd.stats().sort_passes == 2
+            assert np.array_equal(keys, r_keys) and np.array_equal(perm, r_perm)
+        r = oracle.pipeline(verts, vidx)
+        pairs, npairs, rc = cd.self_collide(cap=1 << 23)
+        assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])) and cd.stats().pairs_tested == r["stats"].pairs_tested
+
+
 def test_half_key_sort_equals_full_sort_and_falls_back():
     """CD_OPT_SORT_FULL: the default hybrid (2 global passes on the top 16 key bits + in-LDS sort of run-aligned
     windows + stable fix-up of equal-high-half runs), the half-key form (4 global passes + fix-up) and all 8 passes

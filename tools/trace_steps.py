@@ -18,6 +18,8 @@ with mi355cd.CollisionDetector(v, t, ids) as cd:
     if frame: cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, frame[0], frame[1])
     cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
     for kv in sys.argv[2:]:
-        k, val = kv.split("="); cd.set_option(int(k), int(val))
+        k, val = kv.split("=")
+        if k.startswith("d"): cd.debug_set(int(k[1:]), int(val))          # dKEY=VALUE: cd_debug_option
+        else: cd.set_option(int(k), int(val))
     for _ in range(STEPS): n, rc = cd.self_collide_into(buf)
     print(mesh, sys.argv[2:], "pairs", n, "tested", cd.fast_stats.pairs_tested, "rc", rc)
