@@ -121,7 +121,12 @@ __global__ __launch_bounds__(RADIX) void k_tile_chunks(const uint32_t *__restric
     chunk_tot[(size_t)c * RADIX + d] = sum;
 }
 
-__global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+#ifndef OS_WAVES_PER_EU
+#define OS_WAVES_PER_EU 8
+#endif
+// (68 VGPRs left to itself: seven waves a SIMD, i.e. ONE 1024-thread workgroup a CU.  Held at 64 -- two workgroups a CU -- a sort of many tiles has somebody to run while a
+//  workgroup waits for its look-back: DESIGN.md 4a)
+__global__ __launch_bounds__(OS_THREADS) __attribute__((amdgpu_waves_per_eu(OS_WAVES_PER_EU, OS_WAVES_PER_EU))) void k_os_pass(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                           uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                           uint32_t n, int shift, const uint32_t *__restrict__ digit_hist /* [256] raw counts of this digit, hist_copies partial tables HIST_STRIDE words apart */,
                                                           unsigned long long *lookback /* [ntiles][256] */, uint32_t *ticket /* [pass]; ticket[8 - pass] = timeout flag */, int first_pass, int hist_copies,
@@ -294,17 +299,20 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_pass(const uint64_t *__restri
 // 512 threads x 10 keys (5120: windows of 2048, runs up to 3072 -- 48 KB and half the waves: TWO workgroups a CU, one computing while the other waits at one of
 // its ~20 barriers: what 4-8 M keys want, whose windows are many rounds -- 8 M: 266 -> see DESIGN.md 4a).  A run too long for the small form raises the same
 // flag as always; the host then redoes the sort with the large form before it escalates to more global passes.
-template <int THREADS_, int ITEMS_, int LIMIT_> struct LocalCfg {
-    static constexpr int THREADS = THREADS_, WAVES = THREADS_ / 64, ITEMS = ITEMS_, LIMIT = LIMIT_, CAP = ITEMS_ * THREADS_, W = CAP - LIMIT_;
+#ifndef LOCAL_SMALL_BLOCKS
+#define LOCAL_SMALL_BLOCKS 2
+#endif
+template <int THREADS_, int ITEMS_, int LIMIT_, int BLOCKS_> struct LocalCfg {
+    static constexpr int THREADS = THREADS_, WAVES = THREADS_ / 64, ITEMS = ITEMS_, LIMIT = LIMIT_, CAP = ITEMS_ * THREADS_, W = CAP - LIMIT_, BLOCKS = BLOCKS_ /* workgroups a CU the registers are held to */;
     static_assert(THREADS_ >= RADIX && THREADS_ % 64 == 0 && LIMIT_ % THREADS_ == 0 && W > 0 && ITEMS_ % 2 == 0, "window configuration");
 };
-using LocalLarge = LocalCfg<1024, 10, 6144>;            // (a planar 1 M cloth in the reference's frame: runs of ~500 on key bits 44..59; 441 runs, the longest 4590, on bits 48..63)
-using LocalSmall = LocalCfg<512, 10, 3072>;             // (8 M triangles of cloth objects: runs up to 1878 on bits 44..59; a 4 M cloth pair: 2312)
+using LocalLarge = LocalCfg<1024, 10, 6144, 1>;            // (a planar 1 M cloth in the reference's frame: runs of ~500 on key bits 44..59; 441 runs, the longest 4590, on bits 48..63)
+using LocalSmall = LocalCfg<512, 10, 3072, LOCAL_SMALL_BLOCKS>;             // (8 M triangles of cloth objects: runs up to 1878 on bits 44..59; a 4 M cloth pair: 2312)
 constexpr int LOCAL_W = LocalLarge::W;                  // nominal keys per workgroup of the large form (the host's window arithmetic)
 
 __device__ __forceinline__ bool fixup_position_lds(const uint2 *item, uint32_t cnt, uint32_t j, uint32_t low, uint32_t high, uint32_t &pos);
 template <class Emit, class CFG>
-__global__ __launch_bounds__(CFG::THREADS) void k_local_sort(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+__global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(CFG::BLOCKS * CFG::WAVES / 4, CFG::BLOCKS * CFG::WAVES / 4))) void k_local_sort(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                               uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n,
                                                               int run_shift /* a run = equal key bits [run_shift, 64): what the global passes sorted by */,
                                                               uint32_t *__restrict__ overflow, Emit emit /* load(value) -> payload, store(final position, value, payload): what the fix-up hop does per key */,
