@@ -771,6 +771,10 @@ def main():
         line["cloth_4M"] = size_measurement(torch, "cloth_4M")
         line["config4_merged_8M"] = size_measurement(torch, "config4_merged_8M")
         line["moving_mesh"] = moving_mesh_measurement(torch, args.quads)
+        # (the headline steps ONE mesh at rest K times; what the same call takes on a mesh that moves is said where the step is described)
+        line["config"]["step"] += (" -- on a mesh AT REST; the same step on the mesh with sheet B sliding a quad per frame (cd_update_vertices between steps, outside the timer): "
+                                   "%.4f ms with the order hint, %.4f without (moving_mesh: other geometry every frame -- longer runs for the window sort, other candidates -- not colder caches)"
+                                   % (line["moving_mesh"]["ms_per_step"], line["moving_mesh"]["ms_per_step_without_hint"]))
         line["from_obj"] = from_obj_measurement(torch, args.quads)
     if not args.no_ray and (backend == "nccl" or not multi_path):
         rtm = ray_tracer_measurement(rank=rank, world=world if multi_path else 1, dist=dist if multi_path else None, torch=torch, device=device, multi=multi_path)
