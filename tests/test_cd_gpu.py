@@ -1528,6 +1528,29 @@ def test_graph_replay_of_the_steady_state_step_gives_the_same_results():
             assert cd.stats().pairs_tested == rc_["stats"].pairs_tested
 
 
+def test_graph_replay_of_a_large_tree():
+    """CD_OPT_GRAPH on a tree of more than 2048 blocks (round 5): the captured step then also holds k_tile_chunks (chunk totals of the first sort pass),
+    the small window form of k_local_sort and k_top_publish / k_top_publish_upper in front of k_cross_fused, whose flag word every replay sets to the same
+    sequence number and k_build_block clears in between.  Replays give the oracle's pairs and counters, across new vertex positions too."""
+    verts, vidx = synth.cloth_pair(600)                                      # 1 440 000 triangles: 2813 blocks in 4096 slots, 352 sort tiles
+    r = oracle.pipeline(verts, vidx)
+    want = oracle.pair_set(r["pairs"])
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+        cd.set_option(mi355cd.CD_OPT_GRAPH, 1)
+        for it in range(5):
+            pairs, n, rc = cd.self_collide(cap=1 << 21)
+            assert rc == 0 and np.array_equal(oracle.pair_set(pairs), want) and cd.stats().pairs_tested == r["stats"].pairs_tested, it
+            assert cd.stats().traverse_launches == (SHALLOW_LAUNCHES if it == 0 else 0), it
+        v2 = verts.copy(); v2[:, 1] += 0.002 * np.sin(30.0 * v2[:, 0]); v2 = v2.astype(np.float32).astype(np.float64)
+        r2 = oracle.pipeline(v2, vidx)
+        cd.update_vertices(v2)
+        for it in range(3):
+            pairs, n, rc = cd.self_collide(cap=1 << 21)
+            assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r2["pairs"])) and cd.stats().pairs_tested == r2["stats"].pairs_tested, it
+            assert cd.stats().traverse_launches == 0
+
+
 def test_pinned_host_pair_buffer_receives_the_pairs_directly():
     """cd_alloc_host_pairs: with a pair buffer in pinned host memory from the library, the report kernel writes the pairs straight
     into it (no staging copy); same pairs as through an ordinary buffer -- below and above the 32 768 pairs that travel with the
