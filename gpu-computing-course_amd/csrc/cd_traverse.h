@@ -845,24 +845,31 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
 {
     __shared__ uint2 pbuf[EXACT_PB];
     __shared__ SatItem sq[EXACT_SQ];
-    __shared__ unsigned long long pre[NSHARD + 1];      // exclusive prefix of the shard counts
     __shared__ uint32_t pcount, sqcount;
     __shared__ unsigned long long pbase;
     __shared__ uint32_t wtested[EXACT_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) { pcount = 0; sqcount = 0; }
-    if (tid < 64) {
-        unsigned long long c = st->shard[tid].n_candidates;
+    // (round 5) A workgroup OWNS a shard of the candidate buffer -- blockIdx & 63, the shard the descent's workgroups of that number filled -- and takes every
+    // (gridDim / 64)-th chunk of 256 of it: where its candidates lie does not depend on the other shards' counts, so the first round's candidates are requested
+    // TOGETHER with the counts (unconditional loads inside the shard's area, masked by the count afterwards) -- one round trip where the prefix over the 64 counts
+    // and the search for a chunk's shard were two.  Every wave reads the 64 counts itself (one load instruction): no LDS, no barrier in front of the first fetch.
+    const uint32_t my_shard = blockIdx.x & (NSHARD - 1), my_slot = blockIdx.x / NSHARD, slots = gridDim.x / NSHARD;   // (the host launches a multiple of NSHARD workgroups)
+    const Candidates *my_cand = cand + (size_t)my_shard * shard_cap;
+    Candidates c_first[EXACT_ITEMS];
+#pragma unroll
+    for (int j = 0; j < EXACT_ITEMS; ++j) {
+        const unsigned long long k = ((unsigned long long)j * slots + my_slot) * EXACT_THREADS + tid;
+        c_first[j] = my_cand[k < shard_cap ? k : 0];
+    }
+    unsigned long long total;                                   // this shard's candidates
+    {
+        unsigned long long c = st->shard[lane].n_candidates;
         const bool over = c > shard_cap;                        // the host will grow the buffer and redo
         if (__ballot(over) != 0ull) c = 0;
-        unsigned long long v = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(v, o); if ((int)lane >= o) v += t; }
-        pre[tid + 1] = v;
-        if (tid == 0) pre[0] = 0;
+        total = (unsigned long long)__builtin_amdgcn_readlane((int)(uint32_t)c, (int)my_shard) | ((unsigned long long)__builtin_amdgcn_readlane((int)(uint32_t)(c >> 32), (int)my_shard) << 32);
     }
-    __syncthreads();
-    const unsigned long long total = pre[NSHARD];
+    __syncthreads();                                            // (pcount, sqcount)
     uint32_t tested = 0;
 
     // SAT of one queued survivor; hit -> LDS pair staging (or direct append when the staging area is full)
@@ -896,21 +903,17 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
     // thousand survivors (the usual case: the descent has filtered the rest) spread over as many workgroups as they fill, one
     // SAT batch each, instead of queueing four batches deep in a few workgroups; a million candidates still give every lane
     // EXACT_ITEMS independent loads.
-    const unsigned long long nchunks = (total + EXACT_THREADS - 1) / EXACT_THREADS;
-    for (unsigned long long c0 = blockIdx.x; c0 < nchunks; c0 += (unsigned long long)gridDim.x * EXACT_ITEMS) {   // uniform trip count per workgroup
+    const unsigned long long nchunks = (total + EXACT_THREADS - 1) / EXACT_THREADS;                                 // of this shard
+    for (unsigned long long c0 = my_slot; c0 < nchunks; c0 += (unsigned long long)slots * EXACT_ITEMS) {          // uniform trip count per workgroup
         // stage 1 on EXACT_ITEMS candidates per lane at once: their loads are independent and in flight together
         // (the stage is a chain of two dependent round trips per candidate -- latency, not bandwidth)
         Candidates c[EXACT_ITEMS]; bool ok[EXACT_ITEMS];
 #pragma unroll
         for (int j = 0; j < EXACT_ITEMS; ++j) {
-            const unsigned long long k = (c0 + (unsigned long long)j * gridDim.x) * EXACT_THREADS + tid;
+            const unsigned long long k = (c0 + (unsigned long long)j * slots) * EXACT_THREADS + tid;
             ok[j] = k < total;
-            c[j] = Candidates{0, 0};
-            if (ok[j]) {
-                int lo = 0, hi = NSHARD;                        // largest s with pre[s] <= k
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= k) lo = mid; else hi = mid; }
-                c[j] = cand[(size_t)lo * shard_cap + (k - pre[lo])];
-            }
+            c[j] = c0 == my_slot ? c_first[j] : my_cand[ok[j] ? k : 0];      // (the first round's were requested with the counts)
+            if (!ok[j]) c[j] = Candidates{0, 0};
         }
         LeafTri lt[EXACT_ITEMS]; Box lb[EXACT_ITEMS], qbox[EXACT_ITEMS]; bool certain[EXACT_ITEMS], filtered[EXACT_ITEMS]; uint32_t q_id[EXACT_ITEMS], qa[EXACT_ITEMS], qb[EXACT_ITEMS], qc[EXACT_ITEMS];
 #pragma unroll

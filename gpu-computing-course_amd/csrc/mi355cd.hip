@@ -1584,7 +1584,7 @@ int cd_debug_option(cd_ctx *c, int key, int64_t value, int64_t *out)
     if (!c) return CD_ERR_ARG;
     switch (key) {
     case CD_DBG_LDS_PAD:         c->dbg_lds_pad = (uint32_t)value; return CD_OK;
-    case CD_DBG_EXACT_BLOCKS:    if (value < 1 || value > 65535) return CD_ERR_ARG; c->exact_blocks = (int)value; return CD_OK;
+    case CD_DBG_EXACT_BLOCKS:    if (value < 1 || value > 65535) return CD_ERR_ARG; c->exact_blocks = (int)((value + NSHARD - 1) / NSHARD * NSHARD); return CD_OK;   // (a workgroup owns a shard: whole multiples of 64)
     case CD_DBG_NO_SHARED_PATH:  c->dbg_no_shared_path = value != 0; return CD_OK;
     case CD_DBG_DIAG:            c->dbg_diag = value != 0; return CD_OK;
     case CD_DBG_STAGEWISE_BUILD: c->dbg_no_fused_build = value != 0; return CD_OK;
