@@ -195,7 +195,10 @@ def moving_mesh_measurement(torch, quads, frames=40, shift_quads=1.0):
             wall, clk = [], []
             for f in range(frames):
                 v = verts.copy()
-                v[h:, 0] = np.float32(v[h:, 0] + np.float32(f * shift_quads * quad))          # (float-valued like the loader's output: no cell table)
+                # (there and back again, 20 quads out: the sheets stay inside the reference's Morton frame, morton.h:43-58 -- 26 quads out sheet B's centroids leave it, the
+                #  keys pass 2^60 and the sort takes its next form: rounds 4's tools/hint_moving.py and this leg's first version measured THAT in their last 14 frames)
+                pos = 20.0 - abs(20.0 - (f % 40))
+                v[h:, 0] = np.float32(v[h:, 0] + np.float32(pos * shift_quads * quad))        # (float-valued like the loader's output: no cell table)
                 cd.update_vertices(v)
                 t0 = time.perf_counter()
                 n, rc = cd.self_collide_into(hp.array)
@@ -209,7 +212,7 @@ def moving_mesh_measurement(torch, quads, frames=40, shift_quads=1.0):
         cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 1)
     pc = parity_check(last, last_tested, last_v, vidx)
     on = [statistics.mean(x[i] for x in res[1]) for i in (0, 1)]; off = [statistics.mean(x[i] for x in res[0]) for i in (0, 1)]
-    return {"workload": f"the headline's cloth pair, sheet B sliding {shift_quads:g} quad(s) along x per frame: cd_update_vertices + cd_self_collide per frame, {frames} frames a run, 2 runs each way",
+    return {"workload": f"the headline's cloth pair, sheet B sliding {shift_quads:g} quad(s) along x per frame, 20 quads out and back (inside the reference's Morton frame): cd_update_vertices + cd_self_collide per frame, {frames} frames a run, 2 runs each way",
             "timed": "the step only (wall clock around cd_self_collide, polled completion; the upload before it is a synchronous copy and stays outside), mean over the frames after the 5th",
             "ms_per_step": on[0], "ms_per_step_without_hint": off[0], "descend_device_clock_ms": on[1], "descend_device_clock_ms_without_hint": off[1],
             "parity_checked": bool(pc["ok"]), "colliding_pairs_last_frame": int(pc["n_pairs"])}

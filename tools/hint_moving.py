@@ -22,7 +22,8 @@ with mi355cd.CollisionDetector(verts, vidx) as cd:
             clk = []; pairs = []
             for f in range(frames):
                 v = verts.copy()
-                v[h:, 0] = np.float32(v[h:, 0] + np.float32(f * shift * quad))        # (float-valued like the loader's: no cell table)
+                pos = 20.0 - abs(20.0 - (f % 40))                                     # out and back: 26 quads out the sheet leaves the reference's Morton frame (keys beyond 2^60: the sort's next form)
+                v[h:, 0] = np.float32(v[h:, 0] + np.float32(pos * shift * quad))      # (float-valued like the loader's: no cell table)
                 cd.update_vertices(v)
                 n, rc = cd.self_collide_into(buf)
                 if f >= 5: clk.append(cd.fast_stats.ms_descend_clock * 1e3)

@@ -6,7 +6,10 @@ sys.path[:0] = [os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "g
 import numpy as np, mi355_synth as synth, mi355cd
 mesh = sys.argv[1]
 frame = None
-if mesh == "cfg4_8M":
+if mesh.startswith("cloth1M_shift"):                     # the 1 M cloth with sheet B slid along x by that many quads (tools/hint_moving.py's frames, at rest)
+    v, t = synth.cloth_pair(500); ids = None
+    h = v.shape[0] // 2; v[h:, 0] = np.float32(v[h:, 0] + np.float32(float(mesh[len("cloth1M_shift"):]) * 2.9 / 500))
+elif mesh == "cfg4_8M":
     v, t, ids, off, span = synth.config4_merged(8, 500); frame = (off, span)
 else:
   ids = None
