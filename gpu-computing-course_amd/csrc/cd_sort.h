@@ -411,7 +411,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(CF
     const uint32_t e0 = s_enc[0], e1 = s_enc[1];
     const bool found0 = p0 == 0 || e0 != 0xffffffffu, found1 = p1 >= n || e1 != 0xffffffffu;
     if (!found0 || !found1) {                            // a run longer than LOCAL_LIMIT: flag it, pass the nominal range through
-        if (tid == 0) atomicExch(overflow, 1u);
+        if (tid == 0) atomicOr(overflow, 1u);
         for (uint32_t i = p0 + tid; i < p1; i += LOCAL_THREADS) { const uint32_t t = vals_in[i]; keys_out[i] = keys_in[i]; vals_out[i] = t; emit.store(i, t, emit.load(t)); }
         return;
     }
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(CF
                 const uint32_t low = lowk[it];
                 uint32_t pos;
                 // run too long: flag it (the host redoes the sort with 8 passes) but still emit a valid permutation and valid leaves
-                if (!fixup_position_lds(sitem, cnt, j, low, high[it], pos)) { atomicExch(overflow, 1u); pos = j; }
+                if (!fixup_position_lds(sitem, cnt, j, low, high[it], pos)) { atomicOr(overflow, 1u); pos = j; }
                 keys_out[lo + pos] = ((uint64_t)high[it] << 32) | low; vals_out[lo + pos] = tv[it];
                 emit.store(lo + pos, tv[it], pl[u]);
             }

@@ -96,6 +96,7 @@ struct cd_ctx {
     bool last_tree_fused = false;           // the last fused call built hierarchy + refit in one pass (ms_hierarchy is then part of ms_refit)
     uint32_t stamp_mask = 15;               // CD_OPT_KERNEL_STAMPS: with stage timing off, which time stamps a fused call still takes (1 block build, 2 descent, 4 exact, 8 pipeline start): ~5 us of idle GPU each
     uint32_t dbg_sort_windows = 0;          // CD_DBG_SORT_WINDOWS: 0 the form the size asks for, 1 always the large window form of k_local_sort, 2 always the small one (A/B, tests)
+    bool left_frame = false; uint32_t steps_in_mode1 = 0;    // the sort went from its first form to its second because keys lay beyond bit 59 (not for a long run); sorts since then
     bool local_small_ok = true, local_small_active = false;   // the small window form has not met a run too long for it; the sort in flight used it
     uint32_t dbg_split_cross = 0;           // CD_DBG_SPLIT_CROSS: the fused build runs k_cross_meta + k_cross_records instead of k_cross_fused (A/B, tests)
     uint32_t dbg_no_fused_build = 0;        // CD_DBG_STAGEWISE_BUILD: fused entry points run k_hierarchy + the meta-reading refit (A/B)
@@ -271,6 +272,8 @@ __global__ void k_amb_vertex(const double *__restrict__ verts, uint32_t nv, AmbT
 }
 
 constexpr int BOUNDS_BLOCKS = 1024;
+constexpr uint32_t SORT_RETRY_STEPS = 64;          // sorts after which a context whose mesh had left the Morton frame tries the first sort form again
+void graph_drop(cd_ctx *c);
 constexpr uint32_t LOCAL_SMALL_MIN = 5u << 18;     // 1.31 M keys: from there k_local_sort runs its small window form (cd_sort.h) -- the large one is more than one round of workgroups (1.44 M: 309 -> 305 us a step, 2.25 M: 437 -> 424, 4 M: 686 -> 667, 8 M: 1442 -> 1374)
 
 int ensure_pairs(cd_ctx *c, TravBuf &tb, uint64_t cap)
@@ -337,6 +340,7 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
     // Three forms of the same stable 64-bit sort (cd_sort.h): hybrid = 2 global passes on the top 16 bits + an in-LDS
     // sort of run-aligned windows + the fix-up hop; half-key = 4 global passes on the high 32 bits + the fix-up hop;
     // full = 8 global passes.  The keys start in the buffer that leaves the sorted data in buffer 0.
+    if (c->sort_mode == 1 && c->left_frame && ++c->steps_in_mode1 >= SORT_RETRY_STEPS) { c->sort_mode = 0; c->steps_in_mode1 = 0; graph_drop(c); }   // (judge_sort_flags)
     const int mode = c->sort_mode;
     const bool hybrid = mode <= 1;
     const int down = mode == 0 ? 4 : 0;         // mode 0: the two global digits are key bits 44..51 and 52..59 -- 16 bits that all vary,
@@ -1125,8 +1129,12 @@ namespace { int judge_sort_flags(cd_ctx *c)
     for (int i = 0; i < 9; ++i) if (c->sort_flags[i]) c->scratch_clean = false;     // the flag words are cleared by the memset only
     for (int i = 0; i < 8; ++i) if (c->sort_flags[i]) return CD_ERR_SORT;
     if (c->sort_flags[8]) {
-        if (c->local_small_active && c->local_small_ok && c->sort_mode <= 1) { c->local_small_ok = false; return SORT_REDO; }   // a run too long for the small windows: the large form, same passes
+        const bool only_above = c->sort_flags[8] == 2u;                     // k_morton alone raised it: some key lies beyond the shifted digits (a centroid outside the Morton frame), no run was too long
+        if (!only_above && c->local_small_active && c->local_small_ok && c->sort_mode <= 1) { c->local_small_ok = false; return SORT_REDO; }   // a run too long for the small windows: the large form, same passes
         if (c->sort_mode >= 3) return CD_ERR_SORT;
+        // A mesh that leaves the frame may come back: a context that went 0 -> 1 for THAT reason tries the first form again every SORT_RETRY_STEPS steps
+        // (enqueue_morton_sort; a try that fails costs one redone step in 64).  A run that was too long stays a reason for good.
+        if (c->sort_mode == 0) { c->left_frame = only_above; c->steps_in_mode1 = 0; }
         ++c->sort_mode; return SORT_REDO;
     }
     return CD_OK;
@@ -1560,7 +1568,7 @@ int cd_set_option(cd_ctx *c, int key, int64_t value)
     if (!c) return CD_ERR_ARG;
     if (key == CD_OPT_TRAVERSAL) { if (value != 0 && value != 1 && value != 3) return CD_ERR_ARG; c->trav_variant = (int)value; return CD_OK; }
     if (key == CD_OPT_QUERIES_PER_WAVE) { if (value < 64 || value > (1 << 20) || value % 64) return CD_ERR_ARG; c->queries_per_wave = (uint32_t)value; return CD_OK; }
-    if (key == CD_OPT_SORT_FULL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->sort_mode = value == 0 ? 0 : (value == 1 ? 3 : 2); return CD_OK; }
+    if (key == CD_OPT_SORT_FULL) { if (value < 0 || value > 2) return CD_ERR_ARG; c->sort_mode = value == 0 ? 0 : (value == 1 ? 3 : 2); c->left_frame = false; return CD_OK; }
     if (key == CD_OPT_STAGE_TIMING) { c->stage_events = value != 0; return CD_OK; }
     if (key == CD_OPT_GRAPH) { c->graph_opt = value != 0; if (!c->graph_opt) graph_drop(c); return CD_OK; }
     if (key == CD_OPT_POLL) { c->poll_opt = value != 0; return CD_OK; }
@@ -1596,6 +1604,7 @@ int cd_debug_option(cd_ctx *c, int key, int64_t value, int64_t *out)
     case CD_DBG_GET_POLL_FALLBACKS: if (!out) return CD_ERR_ARG; *out = c->poll_fallbacks; return CD_OK;
     case CD_DBG_GET_POLLED_STEPS:   if (!out) return CD_ERR_ARG; *out = c->polled_steps; return CD_OK;
     case CD_DBG_GET_TREE_WAS_FUSED: if (!out) return CD_ERR_ARG; *out = c->last_tree_fused ? 1 : 0; return CD_OK;
+    case CD_DBG_GET_SORT_FORM:   if (out) *out = c->sort_mode; return CD_OK;
     case CD_DBG_GET_ORDER_STATE: {          // the order hint as it stands: 0 none built, 1 a permutation of the groups that differs from the plain order, 2 the plain order itself, -1 NOT a permutation (a bug)
         if (!out) return CD_ERR_ARG;
         *out = 0;

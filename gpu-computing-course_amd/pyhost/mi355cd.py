@@ -22,7 +22,7 @@ CD_OPT_CELL_TABLE = 7
 CD_OPT_ORDER_HINT = 8
 # cd_debug_option keys (measurement hooks / test switches; not part of the mirrored interface)
 CD_DBG_LDS_PAD, CD_DBG_EXACT_BLOCKS, CD_DBG_NO_SHARED_PATH, CD_DBG_DIAG, CD_DBG_STAGEWISE_BUILD, CD_DBG_SPLIT_CROSS = 0, 1, 2, 3, 4, 5
-CD_DBG_SORT_WINDOWS = 7
+CD_DBG_SORT_WINDOWS, CD_DBG_GET_SORT_FORM = 7, 8
 CD_DBG_POLL_SCAN, CD_DBG_GET_POLL_STALE, CD_DBG_GET_POLL_FALLBACKS, CD_DBG_GET_POLLED_STEPS, CD_DBG_GET_TREE_WAS_FUSED = 10, 11, 12, 13, 14
 CD_DBG_GET_ORDER_STATE = 15
 CD_DBG_REPORT_COPIES = 6

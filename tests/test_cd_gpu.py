@@ -1071,6 +1071,39 @@ def test_window_sort_forms_agree_and_the_small_one_hands_long_runs_to_the_large_
         assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])) and cd.stats().pairs_tested == r["stats"].pairs_tested
 
 
+def test_sort_returns_to_its_first_form_when_the_mesh_is_back_inside_the_frame():
+    """A centroid outside the reference's Morton frame sets key bits beyond 59, which the default hybrid sort (global digits = bits 44..59) does not cover: the step
+    is redone on bits 48..63 and the context stays with that form -- but, since round 5, only for 64 sorts at a time when THAT was the reason (a mesh that leaves the
+    frame may come back; bench.py's first moving-mesh leg ran its last 14 frames in the second form): it then tries the first form again.  A run that is too long for
+    the first form stays a reason for good.  Pairs and counters are the oracle's all the way."""
+    verts, vidx = synth.cloth_pair(90)
+    out = verts.copy(); out[verts.shape[0] // 2:, 0] += 0.2                                  # sheet B beyond x = 3.0845: keys beyond 2^60
+    r_in, r_out = oracle.pipeline(verts, vidx), oracle.pipeline(out, vidx)
+    assert (r_out["keys"] >> np.uint64(60)).max() > 0 and (r_in["keys"] >> np.uint64(60)).max() == 0
+
+    def step(cd, r):
+        pairs, n, rc = cd.self_collide(cap=1 << 20)
+        assert rc == 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])) and cd.stats().pairs_tested == r["stats"].pairs_tested
+
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        step(cd, r_in); assert cd.debug_get(mi355cd.CD_DBG_GET_SORT_FORM) == 0
+        cd.update_vertices(out)
+        for _ in range(3):
+            step(cd, r_out); assert cd.debug_get(mi355cd.CD_DBG_GET_SORT_FORM) == 1
+        keys, perm = cd.export_keys()
+        assert np.array_equal(keys, r_out["keys"]) and np.array_equal(perm, r_out["perm"])
+        for _ in range(70):                                                          # still outside: every 64th sort tries the first form, fails, and is redone
+            step(cd, r_out)
+        assert cd.debug_get(mi355cd.CD_DBG_GET_SORT_FORM) == 1
+        cd.update_vertices(verts)                                                     # back inside
+        forms = []
+        for _ in range(70):
+            step(cd, r_in); forms.append(cd.debug_get(mi355cd.CD_DBG_GET_SORT_FORM))
+        assert forms[0] == 1 and forms[-1] == 0 and forms == sorted(forms, reverse=True)   # one switch back, within 64 sorts
+        keys, perm = cd.export_keys()
+        assert np.array_equal(keys, r_in["keys"]) and np.array_equal(perm, r_in["perm"])
+
+
 def test_half_key_sort_equals_full_sort_and_falls_back():
     """CD_OPT_SORT_FULL: the default hybrid (2 global passes on the top 16 key bits + in-LDS sort of run-aligned
     windows + stable fix-up of equal-high-half runs), the half-key form (4 global passes + fix-up) and all 8 passes
