@@ -294,11 +294,10 @@ __global__ __launch_bounds__(OS_THREADS) __attribute__((amdgpu_waves_per_eu(OS_W
 // longer than LOCAL_LIMIT cannot be windowed: the kernel flags it (same word as the fix-up's overflow) and the host
 // falls back to the 4-pass half-key sort, then to 8 passes.
 // ====================================================================================================
-// The window configuration is a template parameter (round 5): 1024 threads x 10 keys a lane (10240 keys of LDS capacity: nominal windows of 4096 keys, runs up to
-// 6144 -- 96 KB, one workgroup a CU: what a sort of up to ~2 M keys wants, its 256-odd windows are ONE round of workgroups and their latency is the kernel), or
-// 512 threads x 10 keys (5120: windows of 2048, runs up to 3072 -- 48 KB and half the waves: TWO workgroups a CU, one computing while the other waits at one of
-// its ~20 barriers: what 4-8 M keys want, whose windows are many rounds -- 8 M: 266 -> see DESIGN.md 4a).  A run too long for the small form raises the same
-// flag as always; the host then redoes the sort with the large form before it escalates to more global passes.
+// The window configuration is a template parameter (round 5): 512 threads x 10 keys a lane (5120 keys of LDS capacity: nominal windows of 2048 keys, runs up to
+// 3072 -- 48 KB and 8 waves: TWO workgroups a CU, one computing while the other waits at one of its ~20 barriers; the default at every size: 100 k keys 18.3 -> 14.4 us,
+// 1 M 30.9 -> 27.8, 8 M 269 -> 199), or rounds 2-4's 1024 threads x 10 keys (10240: windows of 4096, runs up to 6144 -- 96 KB, one workgroup a CU).  A run too
+// long for the small form raises the same flag as always; the host then redoes the sort with the large form before it escalates to more global passes.
 #ifndef LOCAL_SMALL_BLOCKS
 #define LOCAL_SMALL_BLOCKS 2
 #endif

@@ -274,7 +274,6 @@ __global__ void k_amb_vertex(const double *__restrict__ verts, uint32_t nv, AmbT
 constexpr int BOUNDS_BLOCKS = 1024;
 constexpr uint32_t SORT_RETRY_STEPS = 64;          // sorts after which a context whose mesh had left the Morton frame tries the first sort form again
 void graph_drop(cd_ctx *c);
-constexpr uint32_t LOCAL_SMALL_MIN = 5u << 18;     // 1.31 M keys: from there k_local_sort runs its small window form (cd_sort.h) -- the large one is more than one round of workgroups (1.44 M: 309 -> 305 us a step, 2.25 M: 437 -> 424, 4 M: 686 -> 667, 8 M: 1442 -> 1374)
 
 int ensure_pairs(cd_ctx *c, TravBuf &tb, uint64_t cap)
 {
@@ -340,7 +339,7 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
     // Three forms of the same stable 64-bit sort (cd_sort.h): hybrid = 2 global passes on the top 16 bits + an in-LDS
     // sort of run-aligned windows + the fix-up hop; half-key = 4 global passes on the high 32 bits + the fix-up hop;
     // full = 8 global passes.  The keys start in the buffer that leaves the sorted data in buffer 0.
-    if (c->sort_mode == 1 && c->left_frame && ++c->steps_in_mode1 >= SORT_RETRY_STEPS) { c->sort_mode = 0; c->steps_in_mode1 = 0; graph_drop(c); }   // (judge_sort_flags)
+    if (c->sort_mode == 1 && c->left_frame && ++c->steps_in_mode1 >= SORT_RETRY_STEPS) { c->sort_mode = 0; c->steps_in_mode1 = 0; c->local_small_ok = true; graph_drop(c); }   // (judge_sort_flags; the second form's runs are 16 x longer: the small windows get their chance again too)
     const int mode = c->sort_mode;
     const bool hybrid = mode <= 1;
     const int down = mode == 0 ? 4 : 0;         // mode 0: the two global digits are key bits 44..51 and 52..59 -- 16 bits that all vary,
@@ -368,12 +367,14 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
         const LeafFill fill{c->d_vidx, c->d_ids, n, c->d_leaf, links_too ? c->d_parent : nullptr, links_too ? c->d_bounded : nullptr};
         // one workgroup per CU is all this kernel's LDS allows: the windows are n / 256 keys when that is less than their nominal
         // 4096 (1 M keys: 256 windows of 3907 instead of 245 of 4096 -- every CU busy, fewer windows over 4096 keys), not below 1024
-        // (round 5) many rounds of windows -- more than LOCAL_SMALL_MIN keys -- take the small form: windows of 2048 keys in workgroups of 512 threads and 48 KB,
-        // two of which share a CU (cd_sort.h); a run too long for it (3072 keys) is answered by the large form first (judge_sort_flags)
-        const bool small = c->dbg_sort_windows == 2 || (c->dbg_sort_windows == 0 && n > LOCAL_SMALL_MIN && c->local_small_ok);
+        // (round 5) the SMALL form by default: windows of 2048 keys in workgroups of 512 threads and 48 KB, two of which share a CU (cd_sort.h) -- faster at every
+        // size measured (100 k: 18.3 -> 14.4 us, 1 M cloth: 30.9 -> 27.8, 8 M: 269 -> 199); a run too long for it (3072 keys) is answered by the large form
+        // (windows of 4096, runs up to 6144, one 1024-thread workgroup a CU) before the sort escalates to more global passes (judge_sort_flags)
+        const bool small = c->dbg_sort_windows == 2 || (c->dbg_sort_windows == 0 && c->local_small_ok);
         c->local_small_active = small;
         if (small) {
-            const uint32_t win = (uint32_t)LocalSmall::W;
+            // (windows of n / 512 keys when that is less than the nominal 2048 -- two workgroups on every CU --, not below 512)
+            const uint32_t per_half_cu = cdiv(n, 512u), win = per_half_cu >= (uint32_t)LocalSmall::W ? (uint32_t)LocalSmall::W : (per_half_cu < 512u ? 512u : per_half_cu);
             k_local_sort<LeafFill, LocalSmall><<<cdiv(n, win), LocalSmall::THREADS, 0, s>>>(c->d_keys[1], c->d_perm[1], c->d_keys[0], c->d_perm[0], n, 48 - down, c->d_os_ticket + 16, fill,
                                                                                             self_cleaning ? c->d_small : nullptr, self_cleaning ? 128u : 0u, win);
         } else {

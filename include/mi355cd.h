@@ -232,8 +232,8 @@ enum {
     CD_DBG_STAGEWISE_BUILD    = 4,   /* fused entry points build the tree stage by stage (k_hierarchy + refit) instead of in one pass         */
     CD_DBG_SPLIT_CROSS        = 5,   /* the fused build's cross nodes by k_cross_meta + k_cross_records instead of k_cross_fused               */
     CD_DBG_REPORT_COPIES      = 6,   /* 1: the report kernel copies the first pairs into the host buffer (32 workgroups), as before round 4, instead of the exact kernel posting them (A/B) */
-    CD_DBG_SORT_WINDOWS       = 7,   /* the in-LDS window sort behind the two global passes: 0 the form the size asks for (default), 1 always windows of 4096 keys (one 1024-thread        */
-                                     /* workgroup a CU), 2 always windows of 2048 keys (512 threads, two workgroups a CU).  Same keys and permutation either way (A/B, tests)            */
+    CD_DBG_SORT_WINDOWS       = 7,   /* the in-LDS window sort behind the two global passes: 0 (default) windows of 2048 keys (512 threads, two workgroups a CU) until a run is too long   */
+                                     /* for them, then 4096; 1 always windows of 4096 keys (one 1024-thread workgroup a CU); 2 always 2048.  Same keys and permutation either way (A/B, tests) */
     CD_DBG_GET_SORT_FORM      = 8,   /* the form the next sort takes: 0 two global passes on key bits 44..59 + window sorts (default), 1 the same on bits 48..63 (a key beyond 2^60: a  */
                                      /* centroid outside the Morton frame; retried as 0 every 64 sorts), 2 four passes + fix-up, 3 all eight passes (runs too long for the forms before)   */
     CD_DBG_POLL_SCAN          = 10,  /* polled completion: poison the pair area before a step, scan it the moment the sequence word is seen   */

@@ -1036,7 +1036,7 @@ def test_window_sort_forms_agree_and_the_small_one_hands_long_runs_to_the_large_
     """Round 5: beyond 2 M keys the in-LDS window sort runs windows of 2048 keys in 512-thread workgroups (two a CU) instead of 4096 in 1024 (one a CU).
     Both forms, forced on meshes on either side of that size (CD_DBG_SORT_WINDOWS), give the oracle's keys and permutation; a run of equal top key bits that is
     too long for the small form (3072) but not for the large one (6144) makes the library redo the sort with the large form -- still two global passes."""
-    for n, seed in ((300_000, 51), (1_500_000, 52)):
+    for n, seed in ((300_000, 51), (1_500_000, 52), (9_000, 55)):
         verts, vidx = synth.soup(n, 0.004, seed)
         r_keys, r_perm = oracle.sort_by_key(oracle.centroid_morton(verts, vidx))
         for form in (1, 2, 0):

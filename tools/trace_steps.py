@@ -9,6 +9,8 @@ frame = None
 if mesh.startswith("cloth1M_shift"):                     # the 1 M cloth with sheet B slid along x by that many quads (tools/hint_moving.py's frames, at rest)
     v, t = synth.cloth_pair(500); ids = None
     h = v.shape[0] // 2; v[h:, 0] = np.float32(v[h:, 0] + np.float32(float(mesh[len("cloth1M_shift"):]) * 2.9 / 500))
+elif mesh.startswith("clothq"):                          # cloth_pair(Q): clothq158 = 100 k triangles, clothq350 = 490 k ...
+    v, t = synth.cloth_pair(int(mesh[6:])); ids = None
 elif mesh == "cfg4_8M":
     v, t, ids, off, span = synth.config4_merged(8, 500); frame = (off, span)
 else:
