@@ -32,3 +32,24 @@ def test_soup_mt64_is_the_recipe_of_the_survey():
 
 
 SOUP_MT64_SHA16 = "ed8fd5983c635885"
+
+
+def test_config4_merged_is_the_concatenation_of_the_shards():
+    """BASELINE config 4 as ONE mesh (bench.py's config4_merged_8M, at a small size here): the shards of cloth_shard(r) concatenated with global vertex indices and
+    triangle IDs, neighbours overlapping by 10 % of their width along x, and the Morton frame of the merged centroids (off = min, span = (max - min)(1 + 2^-20))."""
+    world, quads = 4, 20
+    verts, vidx, ids, off, span = synth.config4_merged(world, quads)
+    nt = 2 * 2 * quads * quads
+    assert vidx.shape == (world * nt, 3) and np.array_equal(ids, np.arange(world * nt, dtype=np.uint32))
+    nv = verts.shape[0] // world
+    for r in range(world):
+        v, t, i, vb = synth.cloth_shard(r, quads)
+        assert vb == r * nv and np.array_equal(verts[r * nv:(r + 1) * nv], v)
+        assert np.array_equal(vidx[r * nt:(r + 1) * nt], t + np.uint32(vb)) and np.array_equal(ids[r * nt:(r + 1) * nt], i)
+    x0 = [verts[r * nv:(r + 1) * nv, 0].min() for r in range(world)]; x1 = [verts[r * nv:(r + 1) * nv, 0].max() for r in range(world)]
+    for r in range(world - 1):
+        assert x0[r + 1] < x1[r] and abs((x1[r] - x0[r + 1]) / (x1[r] - x0[r]) - 0.10) < 0.01           # 10 % overlap between neighbours
+    cen = (verts[vidx[:, 0]] + verts[vidx[:, 1]] + verts[vidx[:, 2]]) / 3
+    assert np.array_equal(off, cen.min(0)) and np.allclose(span, (cen.max(0) - cen.min(0)) * (1 + 2.0 ** -20), rtol=0, atol=0)
+    e = (cen - off) / span * 1048576.0
+    assert e.min() >= 0 and e.max() < 1048576.0                             # every centroid inside the frame: keys below 2^60
