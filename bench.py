@@ -281,14 +281,22 @@ def size_measurement(torch, which, steps=40, warmup=8):
         verts, vidx = synth.cloth_pair(1000)
         label = "cloth-vs-cloth, 2 sheets x 1000x1000 quads = 4 000 000 triangles, self-collision"
     else:
-        verts, vidx, ids, off, span = synth.config4_merged(8, 500); frame = (off, span)
+        verts, vidx, ids, off5, span5 = synth.config4_merged(8, 500); frame = "auto"
         label = "BASELINE config 4's eight 1 M-triangle cloth objects (10 % x-overlap between neighbours) merged into ONE mesh of 8 000 000 triangles, self-collision on one GPU"
     nt = int(vidx.shape[0])
     cap = 1 << 22
+    frame_info = {"mode": "CD_FRAME_REFERENCE (morton.h:43-58: the mesh lies in the reference's frame)"}
     with mi355cd.CollisionDetector(verts, vidx, ids) as cd, mi355cd.HostPairs(cap) as hp:
-        if frame is not None:
-            cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, frame[0], frame[1])
         cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+        if frame is not None:
+            # The reference's constants do not fit this mesh: the library derives the frame (CD_FRAME_AUTO, the adaptive frame of cd_math.h) in a first step and the
+            # bench KEEPS what it computed (cd_get_morton_frame -> cd_set_morton_frame_layout), as the reference keeps its constants -- nothing is restated here.
+            cd.set_morton_frame(mi355cd.CD_FRAME_AUTO)
+            cd.self_collide_into(hp.array)
+            foff, fspan, flay = cd.keep_auto_frame()
+            frame_info = {"mode": "CD_FRAME_AUTO computed in a first step, then kept (cd_get_morton_frame -> cd_set_morton_frame_layout)", "offset": [float(x) for x in foff], "span": [float(x) for x in fspan],
+                          "layout_word": hex(flay), "layout": {"axes_by_weight": [int(flay & 3), int((flay >> 2) & 3), int((flay >> 4) & 3)], "leading_bits_of_A": int((flay >> 8) & 255),
+                                                                "pairs_AB": int((flay >> 16) & 255), "triples_ABC": int((flay >> 24) & 255)}}
         for _ in range(warmup):
             n, rc = cd.self_collide_into(hp.array)
         torch.cuda.synchronize()
@@ -315,12 +323,30 @@ def size_measurement(torch, which, steps=40, warmup=8):
             stage["morton"] += st.ms_morton / prof; stage["sort"] += st.ms_sort / prof
             stage["build_fused(hierarchy+refit+records)"] += (st.ms_hierarchy + st.ms_refit) / prof; stage["traverse"] += st.ms_traverse / prof
         sort_passes = int(st.sort_passes)
+        lane_use = {"node_visits_per_step": int(st.node_visits), "wave_steps_per_step": int(st.wave_steps), "lanes_busy_of_64": st.node_visits / float(max(st.wave_steps, 1)),
+                    "node_visits_per_query": st.node_visits / float(nt)}
+        frame_ab = None
+        if frame is not None:
+            # the same mesh in round 5's frame (per-axis normalisation with morton.h:70-89's fixed interleave: cells of 400 : 1 on this mesh) -- what the adaptive frame is worth
+            cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
+            cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, off5, span5)
+            for _ in range(4):
+                cd.self_collide_into(hp.array)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(12):
+                cd.self_collide_into(hp.array)
+            torch.cuda.synchronize(); dt5 = (time.perf_counter() - t0) / 12
+            cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 15)
+            d5 = 0.0
+            for _ in range(4):
+                cd.self_collide_into(hp.array); st5 = cd.stats(); d5 += st5.ms_descend / 4
+            frame_ab = {"per_axis_fixed_interleave(round 5)": {"ms_per_step": dt5 * 1e3, "descend_ms": d5, "node_visits_per_query": st5.node_visits / float(nt), "sort_passes": int(st5.sort_passes)}}
     if ids is None:
         pc = parity_check(last, last_tested, verts, vidx)
     else:
-        pc = parity_check(last, last_tested, verts, vidx, ids, off=frame[0], span=frame[1])
+        pc = parity_check(last, last_tested, verts, vidx, ids, off=off5, span=span5)
     ach = TOTAL_BYTES_PER_TRI * nt / (pipeline * 1e-3) / 1e9
-    return {"workload": label, "triangles": nt, "ms_per_step": dt * 1e3 / steps, "pairs_tested_per_s": tested / dt, "pairs_tested_per_step": int(last_tested), "colliding_pairs": int(n),
+    return {"workload": label, "triangles": nt, "morton_frame": frame_info, "descent_lane_use": lane_use, **({"frame_ab": frame_ab} if frame_ab else {}), "ms_per_step": dt * 1e3 / steps, "pairs_tested_per_s": tested / dt, "pairs_tested_per_step": int(last_tested), "colliding_pairs": int(n),
             "steps": steps, "total_collision_ms_device": pipeline, "kernel_ms": kern, "stage_ms": stage, "sort_passes": sort_passes,
             "kernel_ms_note": f"from {prof} extra untimed steps with all kernel stamps on (HIP events on the kernels' own dispatch packets); stage_ms from {prof} more with per-stage events (their sum exceeds the device time by the event gaps)",
             "whole_path": {"bytes": TOTAL_BYTES_PER_TRI * nt, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS},

@@ -222,8 +222,9 @@ __device__ __forceinline__ void build_half_order(uint32_t x, uint32_t chunk, uin
 struct alignas(16) LeafTri { uint32_t id, v0, v1, v2; };
 
 // ---------------------------------------------------------------- centroid AABB (CD_FRAME_AUTO)
-// Stage 1: per-workgroup min/max of centroids; stage 2 (one workgroup) folds the partials and
-// writes frame = {off[3], span[3]}.  span is widened by 2^-20 relative so that the max maps below 2^20.
+// Stage 1: per-workgroup min/max of centroids + the adaptive frame's statistic (cd_math.h); stage 2 (fold_frame: k_morton's workgroups
+// themselves, or k_frame_from_bounds) folds the partials and forms frame = {off[3], span[3], layout word, 0}.  span is widened by 2^-20
+// relative so that the max maps below the last cell's end.
 __device__ __forceinline__ d3 centroid_of(const double *__restrict__ verts, const uint32_t *__restrict__ vidx, uint32_t t)
 {
     const uint32_t a = vidx[3 * (size_t)t], b = vidx[3 * (size_t)t + 1], c = vidx[3 * (size_t)t + 2];
@@ -236,26 +237,30 @@ __device__ __forceinline__ double wave_min(double v) { for (int o = 32; o; o >>=
 __device__ __forceinline__ double wave_max(double v) { for (int o = 32; o; o >>= 1) { double t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
 
 // BOX: also the min / max over the triangles' VERTICES -- the box of all leaves (what node 0 of the tree will hold),
-// known before there is a tree: the multi-GPU step exchanges it first (cd_multi.h).  partial: 12 x gridDim.x.
-constexpr int BOUNDS_STRIDE = 12;
+// known before there is a tree: the multi-GPU step exchanges it first (cd_multi.h).
+// partial: BOUNDS_STRIDE values x gridDim.x blocks, value-major: centroid lo[3] hi[3], vertex lo[3] hi[3] (BOX), and the adaptive
+// frame's statistic (cd_math.h) as 64-bit INTEGERS in the same slots: sum[3] of flog2(box extent), cnt[3] of the boxes that are not flat.
+constexpr int BOUNDS_STRIDE = 18, BOUNDS_STAT = 12;
+__device__ __forceinline__ long long wave_sum_ll(long long v) { for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o); return v; }
 template <bool BOX>
 __global__ __launch_bounds__(256) void k_centroid_bounds(const double *__restrict__ verts, const uint32_t *__restrict__ vidx, uint32_t n,
-                                                         double *__restrict__ partial /* BOUNDS_STRIDE x gridDim.x: centroid lo[3] hi[3], vertex lo[3] hi[3], each for every block */)
+                                                         double *__restrict__ partial /* BOUNDS_STRIDE x gridDim.x */)
 {
     __shared__ double sm[4][BOUNDS_STRIDE];
     constexpr int SETS = BOX ? 2 : 1;
     double lo[SETS][3], hi[SETS][3];
+    long long ssum[3] = {0, 0, 0}, scnt[3] = {0, 0, 0};
     for (int q = 0; q < SETS; ++q) for (int a = 0; a < 3; ++a) { lo[q][a] = 1e300; hi[q][a] = -1e300; }
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
         const uint32_t ia = vidx[3 * (size_t)t], ib = vidx[3 * (size_t)t + 1], ic = vidx[3 * (size_t)t + 2];
         const d3 p1 = load_vertex(verts, ia), p2 = load_vertex(verts, ib), p3 = load_vertex(verts, ic);
         const double c[3] = {(p1.x + p2.x + p3.x) / 3, (p1.y + p2.y + p3.y) / 3, (p1.z + p2.z + p3.z) / 3};      // load_obj.h:90
         for (int a = 0; a < 3; ++a) { lo[0][a] = c[a] < lo[0][a] ? c[a] : lo[0][a]; hi[0][a] = c[a] > hi[0][a] ? c[a] : hi[0][a]; }
-        if (BOX) {
-            const Box b = box_set(p1, p2, p3);
-            const double bl[3] = {b.x1, b.y1, b.z1}, bh[3] = {b.x2, b.y2, b.z2};
+        const Box b = box_set(p1, p2, p3);
+        const double bl[3] = {b.x1, b.y1, b.z1}, bh[3] = {b.x2, b.y2, b.z2};
+        for (int a = 0; a < 3; ++a) { const double e = bh[a] - bl[a]; if (e > FLOG_MIN) { ssum[a] += flog2_fixed(e); scnt[a] += 1; } }
+        if (BOX)
             for (int a = 0; a < 3; ++a) { lo[SETS - 1][a] = bl[a] < lo[SETS - 1][a] ? bl[a] : lo[SETS - 1][a]; hi[SETS - 1][a] = bh[a] > hi[SETS - 1][a] ? bh[a] : hi[SETS - 1][a]; }
-        }
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int q = 0; q < SETS; ++q)
@@ -263,58 +268,95 @@ __global__ __launch_bounds__(256) void k_centroid_bounds(const double *__restric
             const double l = wave_min(lo[q][a]), h = wave_max(hi[q][a]);
             if (lane == 0) { sm[w][6 * q + a] = l; sm[w][6 * q + 3 + a] = h; }
         }
+    for (int a = 0; a < 3; ++a) {
+        const long long s = wave_sum_ll(ssum[a]), c = wave_sum_ll(scnt[a]);
+        if (lane == 0) { sm[w][BOUNDS_STAT + a] = __longlong_as_double(s); sm[w][BOUNDS_STAT + 3 + a] = __longlong_as_double(c); }
+    }
     __syncthreads();
     if (threadIdx.x < 6 * SETS) {
         const bool is_lo = (threadIdx.x % 6) < 3;
         double v = sm[0][threadIdx.x];
         for (int ww = 1; ww < 4; ++ww) { const double t = sm[ww][threadIdx.x]; v = is_lo ? (t < v ? t : v) : (t > v ? t : v); }
         partial[threadIdx.x * gridDim.x + blockIdx.x] = v;                   // value-major: the folds below read consecutive blocks
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + 6) {
+        const int k = BOUNDS_STAT + (int)threadIdx.x - 64;
+        long long v = 0;
+        for (int ww = 0; ww < 4; ++ww) v += __double_as_longlong(sm[ww][k]);
+        partial[k * gridDim.x + blockIdx.x] = __longlong_as_double(v);
     }
 }
-// One workgroup of 256 folds the per-block partials (it used to be three threads walking all of them one dependent
-// load after the other: 180 us for 1024 blocks).  min / max are exact and order-independent, so any order gives the
-// same frame.
-// frame (may be NULL): off[3], span[3] from the centroid bounds.  box (may be NULL): {x1,x2,y1,y2,z1,z2} from the vertex bounds
-// (partials written by k_centroid_bounds<true>).
-__global__ __launch_bounds__(256) void k_frame_from_bounds(const double *__restrict__ partial, uint32_t nblocks, double *__restrict__ frame,
-                                                           double *__restrict__ box)
+// The fold of the per-block partials into the frame, by the calling workgroup (T threads, T / 64 <= 16 waves; every thread calls).
+// min / max are exact and order-independent, the statistic is integer: any order gives the same frame.
+// Returns (in every thread, after its barriers) through `sf`: off[3], span[3], the layout word's bits in sf[6] -- and, when box != nullptr, the vertex box in box[0..5].
+template <int T>
+__device__ __forceinline__ void fold_frame(const double *__restrict__ partial, uint32_t nblocks, bool with_box, double (*smw)[BOUNDS_STRIDE], double *sf /* [8] shared */, double *sbox /* [6] shared, or nullptr */)
 {
-    __shared__ double sm[4][BOUNDS_STRIDE];
-    const int sets = box ? 2 : 1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int sets = with_box ? 2 : 1;
     for (int q = 0; q < sets; ++q) {
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (uint32_t b = threadIdx.x; b < nblocks; b += 256) {
+        for (uint32_t b = threadIdx.x; b < nblocks; b += T) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const double l = partial[(6 * q + a) * nblocks + b], h = partial[(6 * q + 3 + a) * nblocks + b];
                 lo[a] = l < lo[a] ? l : lo[a]; hi[a] = h > hi[a] ? h : hi[a];
             }
         }
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         for (int a = 0; a < 3; ++a) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); }
-        if (lane == 0) for (int a = 0; a < 3; ++a) { sm[w][6 * q + a] = lo[a]; sm[w][6 * q + 3 + a] = hi[a]; }
+        if (lane == 0) for (int a = 0; a < 3; ++a) { smw[w][6 * q + a] = lo[a]; smw[w][6 * q + 3 + a] = hi[a]; }
+    }
+    {
+        long long st[6] = {0, 0, 0, 0, 0, 0};
+        for (uint32_t b = threadIdx.x; b < nblocks; b += T) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) st[k] += __double_as_longlong(partial[(BOUNDS_STAT + k) * nblocks + b]);
+        }
+        for (int k = 0; k < 6; ++k) { const long long v = wave_sum_ll(st[k]); if (lane == 0) smw[w][BOUNDS_STAT + k] = __longlong_as_double(v); }
     }
     __syncthreads();
-    if (threadIdx.x < 3 * sets) {
-        const int q = threadIdx.x / 3, a = threadIdx.x % 3;
-        double l = sm[0][6 * q + a], h = sm[0][6 * q + 3 + a];
-        for (int ww = 1; ww < 4; ++ww) { const double l2 = sm[ww][6 * q + a], h2 = sm[ww][6 * q + 3 + a]; l = l2 < l ? l2 : l; h = h2 > h ? h2 : h; }
-        if (q == 0) {
-            if (frame) {
-                double span = (h - l) * (1.0 + 1.0 / 1048576.0);
-                if (!(span > 0.0)) span = 1.0;
-                frame[a] = l;
-                frame[3 + a] = span;
+    if (threadIdx.x == 0) {
+        double lo[3], hi[3]; long long sum[3], cnt[3];
+        for (int a = 0; a < 3; ++a) {
+            double l = smw[0][a], h = smw[0][3 + a]; long long s = 0, c = 0;
+            for (int ww = 0; ww < T / 64; ++ww) {
+                const double l2 = smw[ww][a], h2 = smw[ww][3 + a]; l = l2 < l ? l2 : l; h = h2 > h ? h2 : h;
+                s += __double_as_longlong(smw[ww][BOUNDS_STAT + a]); c += __double_as_longlong(smw[ww][BOUNDS_STAT + 3 + a]);
             }
-        } else { box[2 * a] = l; box[2 * a + 1] = h; }
+            lo[a] = l; hi[a] = h; sum[a] = s; cnt[a] = c;
+            double span = (h - l) * (1.0 + 1.0 / 1048576.0);                  // widened by 2^-20 relative: the max maps below the last cell's end
+            if (!(span > 0.0)) span = 1.0;
+            sf[a] = l; sf[3 + a] = span;
+        }
+        sf[6] = __longlong_as_double((long long)frame_layout(lo, hi, sum, cnt));
+        sf[7] = 0.0;
+    } else if (with_box && threadIdx.x >= 64 && threadIdx.x < 64 + 3) {
+        const int a = (int)threadIdx.x - 64;
+        double l = smw[0][6 + a], h = smw[0][9 + a];
+        for (int ww = 1; ww < T / 64; ++ww) { const double l2 = smw[ww][6 + a], h2 = smw[ww][9 + a]; l = l2 < l ? l2 : l; h = h2 > h ? h2 : h; }
+        sbox[2 * a] = l; sbox[2 * a + 1] = h;
     }
+    __syncthreads();
+}
+// One workgroup of 256 folds the per-block partials (it used to be three threads walking all of them one dependent
+// load after the other: 180 us for 1024 blocks).
+// frame (may be NULL): off[3], span[3], layout word, 0 -- FRAME_WORDS doubles.  box (may be NULL): {x1,x2,y1,y2,z1,z2} from the vertex bounds
+// (partials written by k_centroid_bounds<true>).
+constexpr int FRAME_WORDS = 8;
+__global__ __launch_bounds__(256) void k_frame_from_bounds(const double *__restrict__ partial, uint32_t nblocks, double *__restrict__ frame,
+                                                           double *__restrict__ box)
+{
+    __shared__ double sm[4][BOUNDS_STRIDE];
+    __shared__ double sf[FRAME_WORDS], sbox[6];
+    fold_frame<256>(partial, nblocks, box != nullptr, sm, sf, sbox);
+    if (frame && threadIdx.x < FRAME_WORDS) frame[threadIdx.x] = sf[threadIdx.x];
+    if (box && threadIdx.x < 6) box[threadIdx.x] = sbox[threadIdx.x];
 }
 
 // ---------------------------------------------------------------- Morton keys (load_obj.h:89-101, morton.h:70-89)
 // Grid-stride; the workgroup also accumulates the radix sort's digit histograms (cd_sort.h) of the keys it writes.
 constexpr int MORTON_THREADS = 1024;                  // one sort tile (SORT_TILE = 4096 keys) per workgroup pass: 4 keys per thread
 __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restrict__ verts, const uint32_t *__restrict__ vidx, uint32_t n,
-                                                           const double *__restrict__ frame /* off[3], span[3] */,
+                                                           const double *__restrict__ frame /* off[3], span[3], layout word, 0 (FRAME_WORDS) */,
                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ ghist /* [HIST_COPIES][8][256] */, int first_digit,
                                                            int down /* shifted hybrid sort: digits taken `down` bits lower */, uint32_t *__restrict__ overflow,
                                                            const double *__restrict__ partial /* auto frame: k_centroid_bounds' per-block bounds, else NULL */, uint32_t nparts,
@@ -324,42 +366,24 @@ __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restr
 {
     __shared__ uint32_t h[8][RADIX];
     __shared__ double smw[MORTON_THREADS / 64][BOUNDS_STRIDE];
-    __shared__ double sframe[6];
+    __shared__ double sframe[FRAME_WORDS], sbox[6];
     for (int i = threadIdx.x; i < 8 * RADIX; i += MORTON_THREADS) (&h[0][0])[i] = 0;
-    // Auto frame: EVERY workgroup folds the per-block bounds itself (min / max are exact and order-independent: the same
-    // frame in all of them) -- 48 KB of L2 reads and a microsecond, against a one-workgroup kernel of its own in front of
+    // Auto frame: EVERY workgroup folds the per-block bounds itself (min / max are exact and order-independent, the statistic is integer:
+    // the same frame in all of them) -- 72 KB of L2 reads and a microsecond, against a one-workgroup kernel of its own in front of
     // this one (k_frame_from_bounds: ~6 us + a launch gap).  Workgroup 0 stores the frame (and the vertex box) for the others.
     if (partial) {                                                              // (uniform)
-        const int sets = box_out ? 2 : 1;
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        for (int q = 0; q < sets; ++q) {
-            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-            for (uint32_t b = threadIdx.x; b < nparts; b += MORTON_THREADS) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const double l = partial[(6 * q + a) * nparts + b], hh = partial[(6 * q + 3 + a) * nparts + b];
-                    lo[a] = l < lo[a] ? l : lo[a]; hi[a] = hh > hi[a] ? hh : hi[a];
-                }
-            }
-            for (int a = 0; a < 3; ++a) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); }
-            if (lane == 0) for (int a = 0; a < 3; ++a) { smw[w][6 * q + a] = lo[a]; smw[w][6 * q + 3 + a] = hi[a]; }
+        fold_frame<MORTON_THREADS>(partial, nparts, box_out != nullptr, smw, sframe, sbox);
+        if (blockIdx.x == 0) {
+            if (frame_out && threadIdx.x < FRAME_WORDS) frame_out[threadIdx.x] = sframe[threadIdx.x];
+            if (box_out && threadIdx.x < 6) box_out[threadIdx.x] = sbox[threadIdx.x];
         }
-        __syncthreads();
-        if (threadIdx.x < 3 * sets) {
-            const int q = threadIdx.x / 3, a = threadIdx.x % 3;
-            double l = smw[0][6 * q + a], hh = smw[0][6 * q + 3 + a];
-            for (int ww = 1; ww < MORTON_THREADS / 64; ++ww) { const double l2 = smw[ww][6 * q + a], h2 = smw[ww][6 * q + 3 + a]; l = l2 < l ? l2 : l; hh = h2 > hh ? h2 : hh; }
-            if (q == 0) {
-                double span = (hh - l) * (1.0 + 1.0 / 1048576.0);                 // (as k_frame_from_bounds)
-                if (!(span > 0.0)) span = 1.0;
-                sframe[a] = l; sframe[3 + a] = span;
-                if (blockIdx.x == 0 && frame_out) { frame_out[a] = l; frame_out[3 + a] = span; }
-            } else if (blockIdx.x == 0) { box_out[2 * a] = l; box_out[2 * a + 1] = hh; }
-        }
-        __syncthreads();
         frame = sframe;
     }
     __syncthreads();
+    // the key layout of the frame (cd_math.h): 0 = the reference's interleave (morton.h:70-89, bit-identical), else the adaptive one
+    const unsigned long long layout = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(uint32_t)__double_as_longlong(frame[6])) |
+                                      ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(__double_as_longlong(frame[6]) >> 32)) << 32);
+    const KeyLayout kl = key_layout(layout, frame, frame + 3);
     uint64_t above = 0;
     // a workgroup takes whole sort tiles (SORT_TILE consecutive keys): beside the digit histograms of ALL keys it leaves, per tile,
     // the counts of the first global digit -- with those the sort's first pass needs no rendezvous between its tiles
@@ -371,7 +395,7 @@ __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restr
             const uint32_t t = tile * SORT_TILE + it * MORTON_THREADS + threadIdx.x;
             if (t < n) {
                 const d3 c = centroid_of(verts, vidx, t);
-                const uint64_t k = morton3d(c.x, c.y, c.z, frame, frame + 3);
+                const uint64_t k = layout ? morton3d_layout(c.x, c.y, c.z, kl) : morton3d(c.x, c.y, c.z, frame, frame + 3);
                 keys[t] = k;
                 hist_add(h, k, first_digit, down);
                 above |= k;

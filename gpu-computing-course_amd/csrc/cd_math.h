@@ -146,4 +146,109 @@ __device__ __forceinline__ uint64_t morton3d(double x, double y, double z, const
     return (expand64(d2u64(ex)) << 2) | (expand64(d2u64(ey)) << 1) | expand64(d2u64(ez));
 }
 
+// ---------------------------------------------------------------- the ADAPTIVE frame (CD_FRAME_AUTO since round 6)
+// Not reference behaviour: the reference has one frame, the constants of morton.h:43-58, and interleaves 20 bits an axis x, y, z
+// (morton3d above: CD_FRAME_REFERENCE / CD_FRAME_CUSTOM, bit-identical to morton3D).  The pair set does not depend on the keys
+// ("key freedom": a leaf is reached iff its own box overlaps the query's), the TREE does: per-axis normalisation of a
+// 21 x 0.05 x 2.2 mesh (round 5's AUTO) gave cells of 400 : 1 and 44 node visits a query where this walks 29 (tools/sim/frame_study.py);
+// an isotropic frame walks ~33 and leaves the thin axes' leading key bits constant -- the sort's 16 global bits (cd_sort.h) would hold 10
+// that vary.  Here the 60 key bits are DEALT to the axes, all of them vary, and the cells of every level are as near to cubes as powers
+// of two allow IN UNITS OF THE TRIANGLES' OWN EXTENT along each axis: a box query of size s meets a cell of length L with probability
+// ~ (L + s); halving the cell along an axis costs (L + 2 s) / (L + s) -- least along the axis with the largest L / s, not the largest L.
+// (A cloth is thin along one axis and so are its triangles: its sheets lie on top of each other there, and what separates them is worth a
+// split early.  1 M cloth pair: 25.1 visits a query, the reference's hand-made frame 26.6, cubes by extent alone 30.9.)
+//   statistic  per axis the mean of log2(box extent) over the triangles whose box is not flat on that axis, 8 fraction bits, piecewise
+//              linear (flog2_fixed), summed as INTEGERS -- any order of summation gives the same sums, so this code and the oracle's
+//              restatement (the CPU checker used by the tests) agree bit for bit;
+//   E[a]       = flog2(extent of the centroids) + min(Lref - Lmean[a], LAYOUT_CAP): an axis whose triangles are thinner than those of the
+//              axis where they are largest counts as longer by that ratio, at most 2^LAYOUT_CAP (every box flat on the axis: the cap);
+//   layout     axes ordered by E, A >= B >= C (ties: the lower axis first); nA = round(E[A] - E[B]) leading bits split A alone,
+//              nAB = round(E[B] - E[C]) pairs (A, B) follow, nABC triples (A, B, C) take the rest; one or two bits left over go to nA / nAB.
+// layout word: bit 63 set | A | B << 2 | C << 4 | nA << 8 | nAB << 16 | nABC << 24;   0 = the reference's interleave.
+constexpr unsigned long long LAYOUT_VALID = 1ull << 63;
+constexpr int LAYOUT_CAP = 4;
+constexpr double FLOG_MIN = 1e-300;                     // below this an extent counts as 0 (no subnormals in the statistic)
+// 256 log2(x), piecewise linear between powers of two; x > 0 and normal
+__device__ __forceinline__ long long flog2_fixed(double x)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (((long long)((u >> 52) & 0x7ffull) - 1023) << 8) + (long long)((u >> 44) & 0xffull);
+}
+__device__ inline unsigned long long frame_layout(const double lo[3], const double hi[3], const long long sum[3], const long long cnt[3])
+{
+    const long long NONE = -(1ll << 40), CAPF = (long long)LAYOUT_CAP << 8;
+    long long E[3], Lm[3], Lref = NONE; int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 3; ++a) {
+        Lm[a] = NONE;
+        if (cnt[a] > 0) { Lm[a] = sum[a] >= 0 ? sum[a] / cnt[a] : -((-sum[a] + cnt[a] - 1) / cnt[a]); if (Lm[a] > Lref) Lref = Lm[a]; }   // floor
+    }
+    for (int a = 0; a < 3; ++a) {
+        const double e = hi[a] - lo[a];
+        if (!(e > FLOG_MIN)) { E[a] = NONE; continue; }
+        long long d = CAPF;
+        if (Lm[a] != NONE) { d = Lref - Lm[a]; if (d > CAPF) d = CAPF; }
+        if (Lref == NONE) d = 0;                                              // every box flat on every axis: points
+        E[a] = flog2_fixed(e) + d;
+    }
+    for (int i = 1; i < 3; ++i) for (int j = i; j > 0 && E[ord[j]] > E[ord[j - 1]]; --j) { const int t = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = t; }   // stable, descending
+    const long long EA = E[ord[0]], EB = E[ord[1]], EC = E[ord[2]];
+    long long nA = EA == NONE ? 0 : (EB == NONE ? 60 : (EA - EB + 128) >> 8);
+    if (nA > 60) nA = 60;
+    long long rem = 60 - nA;
+    long long nAB = EB == NONE ? 0 : (EC == NONE ? 30 : (EB - EC + 128) >> 8);
+    if (2 * nAB > rem) nAB = rem / 2;
+    rem -= 2 * nAB;
+    const long long nABC = rem / 3, left = rem % 3;
+    if (left == 1) ++nA;
+    if (left == 2) ++nAB;
+    return LAYOUT_VALID | (unsigned long long)ord[0] | ((unsigned long long)ord[1] << 2) | ((unsigned long long)ord[2] << 4) |
+           ((unsigned long long)nA << 8) | ((unsigned long long)nAB << 16) | ((unsigned long long)nABC << 24);
+}
+// is `w` a layout word morton3d_layout can take?  (0: the reference's interleave)
+__host__ __device__ inline bool layout_ok(unsigned long long w)
+{
+    if (w == 0ull) return true;
+    if (!(w >> 63) || ((w >> 32) & 0x7fffffffull) || ((w >> 6) & 3ull)) return false;
+    const int A = (int)(w & 3), B = (int)((w >> 2) & 3), C = (int)((w >> 4) & 3), nA = (int)((w >> 8) & 255), p = (int)((w >> 16) & 255), t = (int)((w >> 24) & 255);
+    return A < 3 && B < 3 && C < 3 && A != B && A != C && B != C && t <= 20 && p <= 30 && nA + 2 * p + 3 * t <= 60;
+}
+// spread the low 32 bits to the even positions
+__device__ __forceinline__ uint64_t expand2(uint64_t v)
+{
+    v &= 0xffffffffULL;
+    v = (v | v << 16) & 0x0000ffff0000ffffULL;
+    v = (v | v << 8)  & 0x00ff00ff00ff00ffULL;
+    v = (v | v << 4)  & 0x0f0f0f0f0f0f0f0fULL;
+    v = (v | v << 2)  & 0x3333333333333333ULL;
+    v = (v | v << 1)  & 0x5555555555555555ULL;
+    return v;
+}
+// A layout word decoded once (wave-uniform: scalar registers) for a loop over keys.
+struct KeyLayout {
+    int A, B, C, t, p, nA;                              // t triples, p pairs, nA leading bits
+    double offA, offB, offC, spanA, spanB, spanC, scA, scB, scC;
+    uint64_t topA, topB, topC;
+};
+__device__ __forceinline__ KeyLayout key_layout(unsigned long long w, const double *off, const double *span)
+{
+    KeyLayout k;
+    k.A = (int)(w & 3); k.B = (int)((w >> 2) & 3); k.C = (int)((w >> 4) & 3);
+    k.nA = (int)((w >> 8) & 255); k.p = (int)((w >> 16) & 255); k.t = (int)((w >> 24) & 255);
+    const int bA = k.nA + k.p + k.t, bB = k.p + k.t, bC = k.t;
+    k.offA = off[k.A]; k.offB = off[k.B]; k.offC = off[k.C]; k.spanA = span[k.A]; k.spanB = span[k.B]; k.spanC = span[k.C];
+    k.scA = __longlong_as_double((long long)(1023 + bA) << 52); k.scB = __longlong_as_double((long long)(1023 + bB) << 52); k.scC = __longlong_as_double((long long)(1023 + bC) << 52);   // 2^bits
+    k.topA = (1ull << bA) - 1; k.topB = (1ull << bB) - 1; k.topC = (1ull << bC) - 1;
+    return k;
+}
+__device__ __forceinline__ uint64_t morton3d_layout(double x, double y, double z, const KeyLayout &k)
+{
+    const double cA = k.A == 0 ? x : (k.A == 1 ? y : z), cB = k.B == 0 ? x : (k.B == 1 ? y : z), cC = k.C == 0 ? x : (k.C == 1 ? y : z);
+    uint64_t ia = d2u64(((cA - k.offA) / k.spanA) * k.scA), ib = d2u64(((cB - k.offB) / k.spanB) * k.scB), ic = d2u64(((cC - k.offC) / k.spanC) * k.scC);
+    ia = ia > k.topA ? k.topA : ia; ib = ib > k.topB ? k.topB : ib; ic = ic > k.topC ? k.topC : ic;   // a centroid beyond the frame takes the last cell: the key stays below 2^60
+    const uint64_t mt = (1ull << k.t) - 1, mp = (1ull << k.p) - 1;
+    const uint64_t triples = (expand64(ia & mt) << 2) | (expand64(ib & mt) << 1) | expand64(ic & mt);
+    const uint64_t pairs = (expand2((ia >> k.t) & mp) << 1) | expand2((ib >> k.t) & mp);
+    return ((ia >> (k.p + k.t)) << (2 * k.p + 3 * k.t)) | (pairs << (3 * k.t)) | triples;
+}
+
 }  // namespace cd

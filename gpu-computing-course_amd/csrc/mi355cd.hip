@@ -65,7 +65,7 @@ struct cd_ctx {
     uint32_t dbg_no_shared_path = 0;        // CD_DBG_NO_SHARED_PATH: k_descend without the shared root path (A/B)
     uint32_t dbg_diag = 0;                  // CD_DBG_DIAG: the DIAG instance of the descent kernel runs, which also fills the diagnostic counters (cd_debug_counters)
     uint32_t dbg_lds_pad = 0;               // CD_DBG_LDS_PAD: extra dynamic LDS bytes per traversal workgroup (occupancy experiments)
-    double frame_host[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};   // morton.h:45,51,57
+    double frame_host[FRAME_WORDS] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36, 0.0, 0.0};   // morton.h:45,51,57; [6]: the bits of the key layout word (cd_math.h; 0 = the reference's interleave)
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     // inputs
@@ -195,10 +195,12 @@ uint64_t pinned_pairs_id(const uint32_t *pairs, uint64_t cap)
 constexpr uint64_t SPEC_PAIRS = 1u << 15;     // pairs that come back together with the counters, zero-copy (256 KB)
 
 // morton.h:70-89 / :7-29 on explicit inputs (cd_morton3d_points, cd_expand64_values): the device functions k_morton uses
-__global__ void k_morton_points(const double *__restrict__ xyz, uint64_t n, const double *__restrict__ frame, uint64_t *__restrict__ keys)
+__global__ void k_morton_points(const double *__restrict__ xyz, uint64_t n, const double *__restrict__ frame /* FRAME_WORDS */, uint64_t *__restrict__ keys)
 {
+    const unsigned long long layout = (unsigned long long)__double_as_longlong(frame[6]);
+    const KeyLayout kl = key_layout(layout, frame, frame + 3);
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        keys[i] = morton3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], frame, frame + 3);
+        keys[i] = layout ? morton3d_layout(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], kl) : morton3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], frame, frame + 3);
 }
 __global__ void k_expand_values(const uint64_t *__restrict__ v, uint64_t n, uint64_t *__restrict__ out)
 {
@@ -1050,7 +1052,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     c->d_os_ticket = c->d_os_hist + HIST_COPIES * 8 * RADIX;
     c->d_os_look = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_os) + look_off);
     c->d_os_look_lo = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_os) + lo_off);
-    ALLOC(c->d_frame, sizeof(double) * 6);
+    ALLOC(c->d_frame, sizeof(double) * FRAME_WORDS);
     ALLOC(c->d_partial, sizeof(double) * BOUNDS_STRIDE * BOUNDS_BLOCKS);
     ALLOC(c->d_leaf, sizeof(LeafTri) * n);
     // a failed sort may leave slots unwritten for one (discarded) run: keep their vertex ids in range
@@ -1081,7 +1083,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     bool ok = hipMemcpy(c->d_verts, verts_xyz, sizeof(double) * 3 * (size_t)nv, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(c->d_vidx, vidx3, sizeof(uint32_t) * 3 * n, hipMemcpyHostToDevice) == hipSuccess &&
               (!ids || hipMemcpy(c->d_ids, ids, sizeof(uint32_t) * n, hipMemcpyHostToDevice) == hipSuccess) &&
-              hipMemcpy(c->d_frame, c->frame_host, sizeof(double) * 6, hipMemcpyHostToDevice) == hipSuccess;
+              hipMemcpy(c->d_frame, c->frame_host, sizeof(double) * FRAME_WORDS, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { free_all(c); delete c; return -(int)hipGetLastError(); }
     { const int rc = amb_refresh(c); if (rc) { free_all(c); delete c; return rc; } }
     *out = c;
@@ -1107,19 +1109,48 @@ int cd_update_vertices(cd_ctx *c, const double *verts_xyz)
     return amb_refresh(c);
 }
 
+static int install_frame(cd_ctx *c, int mode, const double off[3], const double span[3], unsigned long long layout)
+{
+    if (off) for (int a = 0; a < 3; ++a) { c->frame_host[a] = off[a]; c->frame_host[3 + a] = span[a]; }
+    std::memcpy(&c->frame_host[6], &layout, sizeof layout); c->frame_host[7] = 0.0;
+    c->frame_mode = mode;
+    HIPCHK(hipStreamSynchronize(c->stream));                                // (nothing of an earlier call may still read the old frame)
+    HIPCHK(hipMemcpy(c->d_frame, c->frame_host, sizeof(double) * FRAME_WORDS, hipMemcpyHostToDevice));
+    c->stage = ST_CREATED;
+    return CD_OK;
+}
 int cd_set_morton_frame(cd_ctx *c, int mode, const double offset[3], const double span[3])
 {
     if (!c) return CD_ERR_ARG;
     if (mode == CD_FRAME_REFERENCE) {
         const double ref[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};
-        memcpy(c->frame_host, ref, sizeof ref);
-    } else if (mode == CD_FRAME_CUSTOM) {
+        return install_frame(c, mode, ref, ref + 3, 0ull);
+    }
+    if (mode == CD_FRAME_CUSTOM) {
         if (!offset || !span) return CD_ERR_ARG;
-        for (int a = 0; a < 3; ++a) { c->frame_host[a] = offset[a]; c->frame_host[3 + a] = span[a]; }
-    } else if (mode != CD_FRAME_AUTO) return CD_ERR_ARG;
-    c->frame_mode = mode;
-    HIPCHK(hipMemcpy(c->d_frame, c->frame_host, sizeof(double) * 6, hipMemcpyHostToDevice));
-    c->stage = ST_CREATED;
+        return install_frame(c, mode, offset, span, 0ull);                  // morton.h:70-89's interleave in the caller's frame
+    }
+    if (mode != CD_FRAME_AUTO) return CD_ERR_ARG;
+    return install_frame(c, mode, nullptr, nullptr, 0ull);                  // (the step computes the frame and writes it to d_frame)
+}
+// A frame WITH its key layout (cd_math.h), as cd_get_morton_frame returned it -- from this context after a step in CD_FRAME_AUTO (a frame computed
+// once and kept: the AUTO pass over the triangles, ~11 us at 1 M, leaves the step), or from another one (all ranks of a job in one frame).
+int cd_set_morton_frame_layout(cd_ctx *c, const double offset[3], const double span[3], uint64_t layout)
+{
+    if (!c || !offset || !span || !layout_ok(layout)) return CD_ERR_ARG;
+    for (int a = 0; a < 3; ++a) if (!(span[a] > 0.0)) return CD_ERR_ARG;
+    return install_frame(c, CD_FRAME_CUSTOM, offset, span, layout);
+}
+// The frame the last sort used: offset, span and key layout (0: the reference's interleave).
+int cd_get_morton_frame(cd_ctx *c, double offset[3], double span[3], uint64_t *layout)
+{
+    if (!c) return CD_ERR_ARG;
+    if (c->stage < ST_SORTED) return CD_ERR_ORDER;
+    double f[FRAME_WORDS];
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(f, c->d_frame, sizeof f, hipMemcpyDeviceToHost));
+    for (int a = 0; a < 3; ++a) { if (offset) offset[a] = f[a]; if (span) span[a] = f[3 + a]; }
+    if (layout) std::memcpy(layout, &f[6], sizeof *layout);
     return CD_OK;
 }
 
@@ -1457,7 +1488,7 @@ int cd_debug_records(cd_ctx *c, void *recs, void *qboxes, int32_t *root)
 }
 
 // morton3D / expand64Bits themselves, on caller-supplied inputs; no context (one-shot device buffers on the null stream)
-static int morton_batch(const void *in, size_t in_bytes, uint64_t n, const double frame[6], uint64_t *out)
+static int morton_batch(const void *in, size_t in_bytes, uint64_t n, const double frame[FRAME_WORDS], uint64_t *out)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return CD_ERR_NO_DEVICE;
@@ -1465,9 +1496,9 @@ static int morton_batch(const void *in, size_t in_bytes, uint64_t n, const doubl
     int rc = CD_OK;
     hipError_t e = hipMalloc(&d_in, in_bytes);
     if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(uint64_t) * n);
-    if (e == hipSuccess && frame) e = hipMalloc(&d_frame, sizeof(double) * 6);
+    if (e == hipSuccess && frame) e = hipMalloc(&d_frame, sizeof(double) * FRAME_WORDS);
     if (e == hipSuccess) e = hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess && frame) e = hipMemcpy(d_frame, frame, sizeof(double) * 6, hipMemcpyHostToDevice);
+    if (e == hipSuccess && frame) e = hipMemcpy(d_frame, frame, sizeof(double) * FRAME_WORDS, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         const uint32_t blocks = cdiv(n, 256) < 4096u ? cdiv(n, 256) : 4096u;
         if (frame) k_morton_points<<<blocks, 256>>>(static_cast<const double *>(d_in), n, d_frame, d_out);
@@ -1483,8 +1514,17 @@ int cd_morton3d_points(const double *xyz, uint64_t n, const double offset[3], co
 {
     if (!xyz || !keys || (!offset) != (!span)) return CD_ERR_ARG;
     if (n == 0) return CD_OK;
-    double frame[6] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36};           // morton.h:45,51,57
+    double frame[FRAME_WORDS] = {0.004501, -0.476622, -0.381965, 3.08, 0.76, 2.36, 0.0, 0.0};           // morton.h:45,51,57
     if (offset) for (int a = 0; a < 3; ++a) { frame[a] = offset[a]; frame[3 + a] = span[a]; }
+    return morton_batch(xyz, sizeof(double) * 3 * n, n, frame, keys);
+}
+// the same in a frame with a key layout (cd_math.h morton3d_layout: what k_morton computes in such a frame); layout 0 = cd_morton3d_points
+int cd_morton3d_points_layout(const double *xyz, uint64_t n, const double offset[3], const double span[3], uint64_t layout, uint64_t *keys)
+{
+    if (!xyz || !keys || !offset || !span || !layout_ok(layout)) return CD_ERR_ARG;
+    if (n == 0) return CD_OK;
+    double frame[FRAME_WORDS] = {offset[0], offset[1], offset[2], span[0], span[1], span[2], 0.0, 0.0};
+    std::memcpy(&frame[6], &layout, sizeof layout);
     return morton_batch(xyz, sizeof(double) * 3 * n, n, frame, keys);
 }
 int cd_expand64_values(const uint64_t *v, uint64_t n, uint64_t *out)

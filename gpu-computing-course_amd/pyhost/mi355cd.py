@@ -56,12 +56,12 @@ class CdMultiInfo(C.Structure):
 
 
 EXPORTS = [
-    "cd_load_obj", "cd_free_obj", "cd_create", "cd_destroy", "cd_update_vertices", "cd_set_morton_frame", "cd_morton_sort",
+    "cd_load_obj", "cd_free_obj", "cd_create", "cd_destroy", "cd_update_vertices", "cd_set_morton_frame", "cd_get_morton_frame", "cd_set_morton_frame_layout", "cd_morton_sort",
     "cd_build_hierarchy", "cd_refit_boxes", "cd_check_internal", "cd_check_leaves",
     "cd_check_triangle_idx", "cd_find_collisions", "cd_build_tree", "cd_self_collide", "cd_sorted_pairs", "cd_collision_triangles", "cd_brute_force",
     "cd_test_pairs", "cd_export_keys", "cd_export_tree", "cd_get_stats", "cd_debug_counters", "cd_debug_records", "cd_num_triangles",
     "cd_set_option", "cd_set_vertex_id_base", "cd_root_box", "cd_pack_queries", "cd_find_collisions_queries", "cd_version",
-    "cd_debug_option", "cd_debug_hint", "cd_debug_hint_set", "cd_morton3d_points", "cd_expand64_values", "cd_box_pairs", "cd_tri_contact_points", "cd_alloc_host_pairs", "cd_free_host_pairs",
+    "cd_debug_option", "cd_debug_hint", "cd_debug_hint_set", "cd_morton3d_points", "cd_morton3d_points_layout", "cd_expand64_values", "cd_box_pairs", "cd_tri_contact_points", "cd_alloc_host_pairs", "cd_free_host_pairs",
     "cd_multi_unique_id", "cd_multi_create", "cd_multi_create_from_comm", "cd_multi_destroy", "cd_multi_set_flags", "cd_multi_step",
 ]
 
@@ -93,6 +93,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_destroy.restype = None
     lib.cd_update_vertices.argtypes = [vp, vp]
     lib.cd_set_morton_frame.argtypes = [vp, C.c_int, vp, vp]
+    lib.cd_get_morton_frame.argtypes = [vp, vp, vp, u64p]
+    lib.cd_set_morton_frame_layout.argtypes = [vp, vp, vp, C.c_uint64]
     lib.cd_morton_sort.argtypes = [vp]
     lib.cd_build_hierarchy.argtypes = [vp, u32p]
     lib.cd_refit_boxes.argtypes = [vp]
@@ -124,6 +126,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.cd_free_host_pairs.argtypes = [u32p]
     lib.cd_free_host_pairs.restype = None
     lib.cd_morton3d_points.argtypes = [vp, C.c_uint64, vp, vp, vp]
+    lib.cd_morton3d_points_layout.argtypes = [vp, C.c_uint64, vp, vp, C.c_uint64, vp]
     lib.cd_expand64_values.argtypes = [vp, C.c_uint64, vp]
     lib.cd_debug_option.argtypes = [vp, C.c_int, C.c_int64, C.POINTER(C.c_int64)]
     lib.cd_box_pairs.argtypes = [vp, vp, C.c_uint64, vp, vp]
@@ -194,6 +197,22 @@ class CollisionDetector:
         off = None if offset is None else np.ascontiguousarray(offset, dtype=np.float64)
         sp = None if span is None else np.ascontiguousarray(span, dtype=np.float64)
         self._chk("cd_set_morton_frame", self.lib.cd_set_morton_frame(self._ctx, mode, _ptr(off), _ptr(sp)))
+
+    def get_morton_frame(self):
+        """(offset[3], span[3], layout word) of the frame the last sort used (cd_get_morton_frame)."""
+        off = np.zeros(3, dtype=np.float64); sp = np.zeros(3, dtype=np.float64); lay = C.c_uint64(0)
+        self._chk("cd_get_morton_frame", self.lib.cd_get_morton_frame(self._ctx, _ptr(off), _ptr(sp), C.byref(lay)))
+        return off, sp, int(lay.value)
+
+    def set_morton_frame_layout(self, offset, span, layout: int):
+        off = np.ascontiguousarray(offset, dtype=np.float64); sp = np.ascontiguousarray(span, dtype=np.float64)
+        self._chk("cd_set_morton_frame_layout", self.lib.cd_set_morton_frame_layout(self._ctx, _ptr(off), _ptr(sp), int(layout)))
+
+    def keep_auto_frame(self):
+        """The frame CD_FRAME_AUTO computed in the last sort becomes the context's fixed frame (the AUTO pass over the triangles leaves the step)."""
+        off, sp, lay = self.get_morton_frame()
+        self.set_morton_frame_layout(off, sp, lay)
+        return off, sp, lay
 
     def set_option(self, key: int, value: int):
         self._chk("cd_set_option", self.lib.cd_set_option(self._ctx, key, value))
@@ -420,6 +439,17 @@ def morton3d_points(xyz, offset=None, span=None) -> np.ndarray:
     rc = load_library().cd_morton3d_points(_ptr(p), p.shape[0], _ptr(off), _ptr(sp), _ptr(keys))
     if rc != CD_OK:
         raise CdError("cd_morton3d_points", rc)
+    return keys
+
+
+def morton3d_points_layout(xyz, offset, span, layout: int) -> np.ndarray:
+    """The key of explicit points in a frame with a key layout (cd_morton3d_points_layout; layout 0 = morton3d_points)."""
+    p = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    off = np.ascontiguousarray(offset, dtype=np.float64); sp = np.ascontiguousarray(span, dtype=np.float64)
+    keys = np.zeros(p.shape[0], dtype=np.uint64)
+    rc = load_library().cd_morton3d_points_layout(_ptr(p), p.shape[0], _ptr(off), _ptr(sp), int(layout), _ptr(keys))
+    if rc != CD_OK:
+        raise CdError("cd_morton3d_points_layout", rc)
     return keys
 
 

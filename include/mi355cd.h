@@ -46,7 +46,8 @@ enum {
 /* Morton normalisation frame (morton.h:43-58 hard-codes one data set's bounds). */
 enum {
     CD_FRAME_REFERENCE = 0,    /* the constants of morton.h:45,51,57 -> keys bit-identical to morton3D */
-    CD_FRAME_AUTO      = 1,    /* AABB of the centroids, computed on the device                        */
+    CD_FRAME_AUTO      = 1,    /* from the mesh, computed on the device in every step: AABB of the centroids AND the
+                                  key layout that suits it (below: "the adaptive frame")                      */
     CD_FRAME_CUSTOM    = 2     /* caller-supplied offset[3], span[3]                                   */
 };
 
@@ -96,8 +97,23 @@ void cd_destroy(cd_ctx *ctx);                                               /* m
 int cd_update_vertices(cd_ctx *ctx, const double *verts_xyz);
 
 /* morton.h:43-58: choose the normalisation frame (default CD_FRAME_REFERENCE). offset/span are
- * read only for CD_FRAME_CUSTOM. */
+ * read only for CD_FRAME_CUSTOM.  REFERENCE and CUSTOM interleave 20 bits an axis x, y, z exactly as morton.h:70-89.
+ *
+ * The adaptive frame (CD_FRAME_AUTO; not reference behaviour -- morton.h has its constants and nothing else).  For a mesh
+ * those constants do not fit, the library takes offset / span from the bounds of the centroids and DEALS the 60 key bits to
+ * the axes so that the cells of every tree level are near cubes in units of the triangles' own mean extent per axis (a thin,
+ * long mesh normalised per axis with the fixed interleave gets cells of 400 : 1 and a poor tree).  The pair set does not
+ * depend on the keys (any correct BVH gives the reference's set); the tree's cost does.  A layout is one 64-bit word:
+ * bit 63 set | A | B << 2 | C << 4 | nA << 8 | nAB << 16 | nABC << 24 -- axes A, B, C (0 = x, 1 = y, 2 = z, by decreasing
+ * weight); the key is, from its top bit down, nA bits of A's cell index, nAB pairs (A, B), nABC triples (A, B, C);
+ * nA + 2 nAB + 3 nABC <= 60.  0 = the reference's interleave.  Derivation and numbers: csrc/cd_math.h, DESIGN.md. */
 int cd_set_morton_frame(cd_ctx *ctx, int mode, const double offset[3], const double span[3]);
+/* The frame the last sort used -- offset, span, key layout (any may be NULL) -- and a frame WITH a layout installed as
+ * CD_FRAME_CUSTOM: a frame CD_FRAME_AUTO computed once and the caller keeps (the AUTO pass over the triangles, ~11 us at
+ * 1 M, leaves the step; a centroid that later leaves the frame takes the last cell of its axis), or one frame for all
+ * the ranks of a job.  CD_ERR_ORDER before the first sort; CD_ERR_ARG for a word that is not a layout. */
+int cd_get_morton_frame(cd_ctx *ctx, double offset[3], double span[3], uint64_t *layout);
+int cd_set_morton_frame_layout(cd_ctx *ctx, const double offset[3], const double span[3], uint64_t layout);
 
 /* morton.h:70-89 morton3D(x, y, z) and morton.h:7-29 expand64Bits(v) themselves, on n caller-supplied inputs (host
  * pointers; no context): the device functions cd_morton_sort uses, exposed so that the reference's own functions can be
@@ -105,6 +121,8 @@ int cd_set_morton_frame(cd_ctx *ctx, int mode, const double offset[3], const dou
  * offset / span: both NULL = the constants of morton.h:45,51,57, else a custom frame.  Defined where the reference is
  * undefined: a negative or NaN normalised coordinate maps to cell 0 (morton.h:78's assert is compiled out in Release). */
 int cd_morton3d_points(const double *xyz, uint64_t n, const double offset[3], const double span[3], uint64_t *keys);
+/* the same in a frame with a key layout (what cd_morton_sort computes per centroid in such a frame; layout 0 = the call above) */
+int cd_morton3d_points_layout(const double *xyz, uint64_t n, const double offset[3], const double span[3], uint64_t layout, uint64_t *keys);
 int cd_expand64_values(const uint64_t *v, uint64_t n, uint64_t *out);
 
 /* box.cuh:40-43 checkBoxOverlap(a, b), box.cuh:24-32 Box::merge(a, b) and tri_contact.cuh:19-78 checkTriangleContact themselves, on n

@@ -95,6 +95,148 @@ void orc_expand64_batch(const uint64_t *v, uint64_t n, uint64_t *out)
     for (uint64_t i = 0; i < n; ++i) out[i] = orc_expand64(v[i]);
 }
 
+/* ------------------------------------------------------------------ the ADAPTIVE frame (CD_FRAME_AUTO since round 6)
+ * NOT reference behaviour: the reference has one frame, the constants of morton.h:43-58, and interleaves 20 bits an axis x, y, z
+ * (the functions above; CD_FRAME_REFERENCE / CD_FRAME_CUSTOM).  For a mesh those constants do not fit the library derives a frame
+ * from the mesh, and -- SURVEY section 7, "key freedom": the pair set does not depend on the keys -- deals the 60 key bits to the
+ * axes so that the cells of every level of the tree are as near to cubes as powers of two allow, IN UNITS OF THE TRIANGLES' OWN
+ * EXTENT along each axis:
+ *   a box query of size s meets a cell of length L with probability ~ (L + s); halving the cell along an axis costs
+ *   (L + 2 s) / (L + s) -- least along the axis with the largest L / s, not the largest L.  A cloth is thin along one axis AND so
+ *   are its triangles: its sheets lie on top of each other there, and what separates them is worth a split early.
+ * Statistic: per axis the mean of log2(box extent) over the triangles whose box is not flat on that axis, in fixed point
+ * (flog2_: 8 fraction bits, piecewise linear) and summed as INTEGERS -- any order of summation gives the same sums, so device
+ * and oracle agree bit for bit.  An axis whose triangles are thinner than those of the axis where they are largest counts as
+ * longer by that ratio, at most 2^ORC_LAYOUT_CAP (an axis on which every box is flat: the cap): E[a] = flog2(extent of the
+ * centroids) + min(Lref - Lmean[a], cap).  Then
+ *   axes ordered by E, A >= B >= C (ties: the lower axis first);
+ *   nA  = round(E[A] - E[B]) leading bits split A alone;  nAB = round(E[B] - E[C]) pairs of bits (A, B) follow;
+ *   nABC triples (A, B, C) take the rest of the 60 bits; one or two bits left over go to nA / nAB.
+ * Per-axis normalisation with the fixed x, y, z interleave (round 5) made cells of 400 : 1 on a thin, long mesh: 44 node visits a
+ * query where this layout walks 29 (tools/sim/frame_study.py).  An isotropic frame walks ~33 and leaves the thin axes' leading key
+ * bits constant -- the sort's 16 global bits would hold 10 that vary.  Here all 60 vary.
+ * This restatement is what the device code (cd_math.h: frame_layout, morton3d_layout) is checked against.
+ * layout word: bit 63 set | A | B << 2 | C << 4 | nA << 8 | nAB << 16 | nABC << 24;  0 = the reference's interleave. */
+#define ORC_LAYOUT_VALID (1ull << 63)
+#define ORC_LAYOUT_CAP 4
+/* 256 log2(x), piecewise linear between powers of two; x > 0 and normal */
+static inline int64_t flog2_(double x)
+{
+    uint64_t u; memcpy(&u, &x, sizeof u);
+    return (((int64_t)((u >> 52) & 0x7ff) - 1023) << 8) + (int64_t)((u >> 44) & 0xff);
+}
+#define ORC_FLOG_MIN 1e-300       /* below this an extent counts as 0 (no subnormals in the statistic) */
+/* the statistic of one triangle box: adds flog2(extent) to sum[a] and 1 to cnt[a] for every axis on which the box is not flat */
+static inline void layout_stat_(const double *p1, const double *p2, const double *p3, int64_t sum[3], int64_t cnt[3])
+{
+    for (int a = 0; a < 3; ++a) {
+        const double e = fmax3_(p1[a], p2[a], p3[a]) - fmin3_(p1[a], p2[a], p3[a]);
+        if (e > ORC_FLOG_MIN) { sum[a] += flog2_(e); cnt[a] += 1; }
+    }
+}
+/* (cap_bits: ORC_LAYOUT_CAP in the product's rule; a parameter for tools/sim/frame_study.py, which prices the rule) */
+uint64_t orc_frame_layout_cap(const double lo[3], const double hi[3], const int64_t sum[3], const int64_t cnt[3], int cap_bits)
+{
+    const int64_t NONE = -((int64_t)1 << 40);
+    int64_t E[3], Lm[3], Lref = NONE; int ord[3] = { 0, 1, 2 };
+    for (int a = 0; a < 3; ++a) {
+        Lm[a] = NONE;
+        if (cnt[a] > 0) { Lm[a] = sum[a] >= 0 ? sum[a] / cnt[a] : -((-sum[a] + cnt[a] - 1) / cnt[a]); if (Lm[a] > Lref) Lref = Lm[a]; }   /* floor */
+    }
+    for (int a = 0; a < 3; ++a) {
+        const double e = hi[a] - lo[a];
+        if (!(e > ORC_FLOG_MIN)) { E[a] = NONE; continue; }
+        int64_t d = (int64_t)cap_bits << 8;
+        if (Lm[a] != NONE) { d = Lref - Lm[a]; if (d > ((int64_t)cap_bits << 8)) d = (int64_t)cap_bits << 8; }
+        if (Lref == NONE) d = 0;                                         /* every box flat on every axis: points */
+        E[a] = flog2_(e) + d;
+    }
+    /* stable insertion sort, descending */
+    for (int i = 1; i < 3; ++i) for (int j = i; j > 0 && E[ord[j]] > E[ord[j - 1]]; --j) { int t = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = t; }
+    const int64_t EA = E[ord[0]], EB = E[ord[1]], EC = E[ord[2]];
+    int64_t nA = EA == NONE ? 0 : (EB == NONE ? 60 : (EA - EB + 128) >> 8);
+    if (nA > 60) nA = 60;
+    int64_t rem = 60 - nA;
+    int64_t nAB = EB == NONE ? 0 : (EC == NONE ? 30 : (EB - EC + 128) >> 8);
+    if (2 * nAB > rem) nAB = rem / 2;
+    rem -= 2 * nAB;
+    const int64_t nABC = rem / 3, left = rem % 3;
+    if (left == 1) ++nA;
+    if (left == 2) ++nAB;
+    return ORC_LAYOUT_VALID | (uint64_t)ord[0] | ((uint64_t)ord[1] << 2) | ((uint64_t)ord[2] << 4) | ((uint64_t)nA << 8) | ((uint64_t)nAB << 16) | ((uint64_t)nABC << 24);
+}
+uint64_t orc_frame_layout(const double lo[3], const double hi[3], const int64_t sum[3], const int64_t cnt[3]) { return orc_frame_layout_cap(lo, hi, sum, cnt, ORC_LAYOUT_CAP); }
+/* the statistic of a mesh (what orc_auto_frame feeds orc_frame_layout), and the centroids' bounds */
+void orc_layout_stat(const double *verts, const uint32_t *vidx, uint32_t n, double lo[3], double hi[3], int64_t sum[3], int64_t cnt[3])
+{
+    for (int a = 0; a < 3; ++a) { lo[a] = 1e300; hi[a] = -1e300; sum[a] = 0; cnt[a] = 0; }
+    for (uint32_t t = 0; t < n; ++t) {
+        const double *p1 = verts + 3 * (size_t)vidx[3 * t + 0], *p2 = verts + 3 * (size_t)vidx[3 * t + 1], *p3 = verts + 3 * (size_t)vidx[3 * t + 2];
+        for (int a = 0; a < 3; ++a) { const double c = (p1[a] + p2[a] + p3[a]) / 3; if (c < lo[a]) lo[a] = c; if (c > hi[a]) hi[a] = c; }
+        layout_stat_(p1, p2, p3, sum, cnt);
+    }
+}
+/* spread the low 32 bits to the even positions */
+static inline uint64_t expand2_(uint64_t v)
+{
+    v &= 0xffffffffULL;
+    v = (v | v << 16) & 0x0000ffff0000ffffULL;
+    v = (v | v << 8)  & 0x00ff00ff00ff00ffULL;
+    v = (v | v << 4)  & 0x0f0f0f0f0f0f0f0fULL;
+    v = (v | v << 2)  & 0x3333333333333333ULL;
+    v = (v | v << 1)  & 0x5555555555555555ULL;
+    return v;
+}
+static inline uint64_t cell_(double c, double off, double span, int bits)
+{
+    if (bits == 0) return 0;
+    const double scale = (double)(1ull << bits);                       /* exact */
+    const uint64_t v = d2u64(((c - off) / span) * scale), top = (1ull << bits) - 1;
+    return v > top ? top : v;                                          /* a centroid beyond the frame takes the last cell: the key stays below 2^60 */
+}
+uint64_t orc_morton3d_layout(double x, double y, double z, const double off[3], const double span[3], uint64_t layout)
+{
+    if (!(layout & ORC_LAYOUT_VALID)) return orc_morton3d(x, y, z, off, span);
+    const double c[3] = { x, y, z };
+    const int A = (int)(layout & 3), B = (int)((layout >> 2) & 3), C = (int)((layout >> 4) & 3);
+    const int nA = (int)((layout >> 8) & 255), p = (int)((layout >> 16) & 255), t = (int)((layout >> 24) & 255);
+    const uint64_t ia = cell_(c[A], off[A], span[A], nA + p + t), ib = cell_(c[B], off[B], span[B], p + t), ic = cell_(c[C], off[C], span[C], t);
+    const uint64_t mt = (1ull << t) - 1, mp = (1ull << p) - 1;
+    const uint64_t triples = (orc_expand64(ia & mt) << 2) | (orc_expand64(ib & mt) << 1) | orc_expand64(ic & mt);
+    const uint64_t pairs = (expand2_((ia >> t) & mp) << 1) | expand2_((ib >> t) & mp);
+    const uint64_t top = (nA + p + t) >= 64 ? 0 : (ia >> (p + t));
+    return (2 * p + 3 * t >= 64 ? 0 : (top << (2 * p + 3 * t))) | (pairs << (3 * t)) | triples;
+}
+/* The whole AUTO frame as the device forms it: bounds of the centroids, span widened by 2^-20 (span 1 where the extent is 0), the statistic, layout.
+ * frame: off[3], span[3]; returns the layout word. */
+uint64_t orc_auto_frame(const double *verts, const uint32_t *vidx, uint32_t n, double frame[6])
+{
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    int64_t sum[3] = { 0, 0, 0 }, cnt[3] = { 0, 0, 0 };
+    for (uint32_t t = 0; t < n; ++t) {
+        const double *p1 = verts + 3 * (size_t)vidx[3 * t + 0], *p2 = verts + 3 * (size_t)vidx[3 * t + 1], *p3 = verts + 3 * (size_t)vidx[3 * t + 2];
+        for (int a = 0; a < 3; ++a) { const double c = (p1[a] + p2[a] + p3[a]) / 3; if (c < lo[a]) lo[a] = c; if (c > hi[a]) hi[a] = c; }
+        layout_stat_(p1, p2, p3, sum, cnt);
+    }
+    for (int a = 0; a < 3; ++a) {
+        double span = (hi[a] - lo[a]) * (1.0 + 1.0 / 1048576.0);
+        if (!(span > 0.0)) span = 1.0;
+        frame[a] = lo[a]; frame[3 + a] = span;
+    }
+    return orc_frame_layout(lo, hi, sum, cnt);
+}
+void orc_centroid_morton_layout(const double *verts, const uint32_t *vidx, uint32_t n, const double off[3], const double span[3], uint64_t layout, uint64_t *keys)
+{
+    for (uint32_t t = 0; t < n; ++t) {
+        const double *p1 = verts + 3 * (size_t)vidx[3 * t + 0], *p2 = verts + 3 * (size_t)vidx[3 * t + 1], *p3 = verts + 3 * (size_t)vidx[3 * t + 2];
+        keys[t] = orc_morton3d_layout((p1[0] + p2[0] + p3[0]) / 3, (p1[1] + p2[1] + p3[1]) / 3, (p1[2] + p2[2] + p3[2]) / 3, off, span, layout);
+    }
+}
+void orc_morton3d_layout_batch(const double *xyz, uint64_t n, const double off[3], const double span[3], uint64_t layout, uint64_t *keys)
+{
+    for (uint64_t i = 0; i < n; ++i) keys[i] = orc_morton3d_layout(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], off, span, layout);
+}
+
 /* load_obj.h:89-101: centroid = (p1+p2+p3)/3 per axis, then morton3D.  centroids may be NULL. */
 void orc_centroid_morton(const double *verts, const uint32_t *vidx, uint32_t n,
                          const double off[3], const double span[3],

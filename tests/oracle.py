@@ -47,6 +47,13 @@ def lib(omp: bool = False) -> C.CDLL:
     L.orc_expand64_batch.argtypes = [vp, C.c_uint64, vp]; L.orc_expand64_batch.restype = None
     L.orc_centroid_morton.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp]; L.orc_centroid_morton.restype = None
     L.orc_sort_by_key.argtypes = [vp, vp, C.c_uint32]; L.orc_sort_by_key.restype = None
+    L.orc_frame_layout.argtypes = [vp, vp, vp, vp]; L.orc_frame_layout.restype = C.c_uint64
+    L.orc_frame_layout_cap.argtypes = [vp, vp, vp, vp, C.c_int]; L.orc_frame_layout_cap.restype = C.c_uint64
+    L.orc_layout_stat.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp]; L.orc_layout_stat.restype = None
+    L.orc_morton3d_layout.argtypes = [C.c_double, C.c_double, C.c_double, vp, vp, C.c_uint64]; L.orc_morton3d_layout.restype = C.c_uint64
+    L.orc_auto_frame.argtypes = [vp, vp, C.c_uint32, vp]; L.orc_auto_frame.restype = C.c_uint64
+    L.orc_centroid_morton_layout.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_uint64, vp]; L.orc_centroid_morton_layout.restype = None
+    L.orc_morton3d_layout_batch.argtypes = [vp, C.c_uint64, vp, vp, C.c_uint64, vp]; L.orc_morton3d_layout_batch.restype = None
     L.orc_clz64.argtypes = [C.c_uint64]; L.orc_clz64.restype = C.c_int
     L.orc_delta.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]; L.orc_delta.restype = C.c_int
     L.orc_find_split.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]; L.orc_find_split.restype = C.c_int
@@ -133,6 +140,63 @@ def centroid_morton(verts, vidx, off=REF_OFF, span=REF_SPAN, want_centroids=Fals
     cen = np.zeros((n, 3), dtype=np.float64) if want_centroids else None
     lib().orc_centroid_morton(_p(verts), _p(vidx), n, _p(off), _p(span), _p(keys), _p(cen))
     return (keys, cen) if want_centroids else keys
+
+
+# ---- the adaptive frame (CD_FRAME_AUTO since round 6; not reference behaviour: oracle/cd_oracle.c, "the ADAPTIVE frame")
+def frame_layout(lo, hi, stat_sum, stat_cnt) -> int:
+    """layout word from the centroids' bounds and the box statistic (per axis: sum of the fixed-point log2 of the triangles' box extents, their number)."""
+    lo = np.ascontiguousarray(lo, dtype=np.float64); hi = np.ascontiguousarray(hi, dtype=np.float64)
+    ss = np.ascontiguousarray(stat_sum, dtype=np.int64); sc = np.ascontiguousarray(stat_cnt, dtype=np.int64)
+    return int(lib().orc_frame_layout(_p(lo), _p(hi), _p(ss), _p(sc)))
+
+
+def layout_stat(verts, vidx):
+    """centroid bounds lo[3], hi[3] and the box statistic sum[3], cnt[3] (int64) of a mesh."""
+    verts = np.ascontiguousarray(verts, dtype=np.float64); vidx = np.ascontiguousarray(vidx, dtype=np.uint32)
+    lo = np.zeros(3); hi = np.zeros(3); ss = np.zeros(3, dtype=np.int64); sc = np.zeros(3, dtype=np.int64)
+    lib().orc_layout_stat(_p(verts), _p(vidx), vidx.shape[0], _p(lo), _p(hi), _p(ss), _p(sc))
+    return lo, hi, ss, sc
+
+
+def frame_layout_cap(lo, hi, stat_sum, stat_cnt, cap_bits) -> int:
+    lo = np.ascontiguousarray(lo, dtype=np.float64); hi = np.ascontiguousarray(hi, dtype=np.float64)
+    ss = np.ascontiguousarray(stat_sum, dtype=np.int64); sc = np.ascontiguousarray(stat_cnt, dtype=np.int64)
+    return int(lib().orc_frame_layout_cap(_p(lo), _p(hi), _p(ss), _p(sc), int(cap_bits)))
+
+
+def layout_word(order, nA, nAB, nABC) -> int:
+    return (1 << 63) | order[0] | (order[1] << 2) | (order[2] << 4) | (nA << 8) | (nAB << 16) | (nABC << 24)
+
+
+def layout_fields(layout: int):
+    """(axis order A, B, C), nA, nAB, nABC of a layout word; None for 0 (the reference's interleave)."""
+    if not layout >> 63:
+        return None
+    return ((layout & 3, (layout >> 2) & 3, (layout >> 4) & 3), (layout >> 8) & 255, (layout >> 16) & 255, (layout >> 24) & 255)
+
+
+def auto_frame(verts, vidx):
+    """off[3], span[3], layout word of the frame CD_FRAME_AUTO gives this mesh."""
+    verts = np.ascontiguousarray(verts, dtype=np.float64); vidx = np.ascontiguousarray(vidx, dtype=np.uint32)
+    fr = np.zeros(6, dtype=np.float64)
+    lay = int(lib().orc_auto_frame(_p(verts), _p(vidx), vidx.shape[0], _p(fr)))
+    return fr[:3].copy(), fr[3:].copy(), lay
+
+
+def centroid_morton_layout(verts, vidx, off, span, layout):
+    verts = np.ascontiguousarray(verts, dtype=np.float64); vidx = np.ascontiguousarray(vidx, dtype=np.uint32)
+    off = np.ascontiguousarray(off, dtype=np.float64); span = np.ascontiguousarray(span, dtype=np.float64)
+    keys = np.zeros(vidx.shape[0], dtype=np.uint64)
+    lib().orc_centroid_morton_layout(_p(verts), _p(vidx), vidx.shape[0], _p(off), _p(span), int(layout), _p(keys))
+    return keys
+
+
+def morton3d_layout_batch(xyz, off, span, layout):
+    p = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    off = np.ascontiguousarray(off, dtype=np.float64); span = np.ascontiguousarray(span, dtype=np.float64)
+    keys = np.zeros(p.shape[0], dtype=np.uint64)
+    lib().orc_morton3d_layout_batch(_p(p), p.shape[0], _p(off), _p(span), int(layout), _p(keys))
+    return keys
 
 
 def sort_by_key(keys):
@@ -292,9 +356,10 @@ def self_collide(verts, vidx, ids=None, off=REF_OFF, span=REF_SPAN, threads=1, c
     return (pairs[:min(st.n_pairs, cap)] if pairs is not None else None), st, tm
 
 
-def pipeline(verts, vidx, ids=None, off=REF_OFF, span=REF_SPAN, tiebreak=1):
-    """Stage-by-stage oracle run; returns a dict with every intermediate for parity tests."""
-    keys0 = centroid_morton(verts, vidx, off, span)
+def pipeline(verts, vidx, ids=None, off=REF_OFF, span=REF_SPAN, tiebreak=1, layout=0):
+    """Stage-by-stage oracle run; returns a dict with every intermediate for parity tests.  layout: the key layout of an
+    adaptive frame (auto_frame); 0 = the reference's interleave (morton.h:70-89)."""
+    keys0 = centroid_morton_layout(verts, vidx, off, span, layout) if layout else centroid_morton(verts, vidx, off, span)
     keys, perm = sort_by_key(keys0)
     left, right, parent, rf, rl, wrong = build_hierarchy(keys, tiebreak)
     boxes, bounded, cc = refit(verts, vidx, perm, left, right, parent)

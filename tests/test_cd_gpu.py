@@ -101,21 +101,126 @@ def test_cloth_pair_shared_vertices(variant):
 
 
 def test_auto_frame_and_custom_ids():
+    """CD_FRAME_AUTO (the adaptive frame, cd_math.h): frame and key layout as the oracle's restatement forms them, bit for bit; keys, tree, boxes and pairs of that
+    frame; the frame kept (cd_get_morton_frame -> cd_set_morton_frame_layout) gives the same keys; morton.h:70-89's interleave in the same offset / span does not."""
     verts, vidx = synth.soup(20000, 0.04, 5)
     verts = verts * 37.0 + 1000.0                           # far outside the reference frame
     ids = (np.arange(vidx.shape[0], dtype=np.uint32)[::-1] * 3 + 7).astype(np.uint32)
-    cen = (verts[vidx[:, 0]] + verts[vidx[:, 1]] + verts[vidx[:, 2]]) / 3
-    lo, hi = cen.min(0), cen.max(0)
-    span = (hi - lo) * (1.0 + 1.0 / 1048576.0)
+    off, span, lay = oracle.auto_frame(verts, vidx)
     cd, g = _stagewise(verts, vidx, ids, frame=mi355cd.CD_FRAME_AUTO)
-    r = oracle.pipeline(verts, vidx, ids, off=lo, span=span)
+    goff, gspan, glay = cd.get_morton_frame()
+    assert glay == lay and np.array_equal(goff, off) and np.array_equal(gspan, span)
+    r = oracle.pipeline(verts, vidx, ids, off=off, span=span, layout=lay)
     _assert_tree_equal(g, r)
     pairs, npairs, rc = cd.find_collisions()
     assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"])) and npairs > 0
-    # custom frame == what auto computed
-    cd2, g2 = _stagewise(verts, vidx, ids, frame=mi355cd.CD_FRAME_CUSTOM, off=lo, span=span)
-    assert np.array_equal(g2["keys"], g["keys"])
-    cd.close(); cd2.close()
+    # the frame kept == what auto computed
+    cd2 = mi355cd.CollisionDetector(verts, vidx, ids)
+    cd2.set_morton_frame_layout(off, span, lay)
+    cd2.morton_sort()
+    assert np.array_equal(cd2.export_keys()[0], g["keys"]) and cd2.get_morton_frame()[2] == lay
+    # the reference's interleave in the same offset / span: other keys (layout 0), the same pairs
+    cd3, g3 = _stagewise(verts, vidx, ids, frame=mi355cd.CD_FRAME_CUSTOM, off=off, span=span)
+    assert cd3.get_morton_frame()[2] == 0 and not np.array_equal(g3["keys"], g["keys"])
+    assert np.array_equal(g3["keys"], oracle.pipeline(verts, vidx, ids, off=off, span=span)["keys"])
+    p3, n3, _ = cd3.find_collisions()
+    assert np.array_equal(oracle.pair_set(p3), oracle.pair_set(pairs))
+    # words that are not layouts are refused
+    for bad in (1, (1 << 63) | 0 | (0 << 2) | (1 << 4), oracle.layout_word((0, 1, 2), 30, 10, 5), oracle.layout_word((0, 1, 2), 0, 0, 21), oracle.layout_word((0, 1, 2), 0, 31, 0) ,
+                oracle.layout_word((0, 1, 3), 0, 0, 20), oracle.layout_word((0, 1, 2), 0, 0, 20) | (1 << 40)):
+        with pytest.raises(mi355cd.CdError):
+            cd2.set_morton_frame_layout(off, span, bad)
+    with mi355cd.CollisionDetector(verts, vidx, ids) as fresh:
+        with pytest.raises(mi355cd.CdError) as e:
+            fresh.get_morton_frame()
+        assert e.value.rc == mi355cd.CD_ERR_ORDER
+    cd.close(); cd2.close(); cd3.close()
+
+
+def _flat_sheets(k=6, q=40):
+    vs, ts, o = [], [], 0
+    for s in range(k):
+        v, t = synth._sheet(q, q, lambda X, Y: 0.0 * X + 0.01 * s, 0.003 * s, 4.0 + 0.003 * s, 0.0, 1.0)
+        vs.append(v[:, [0, 2, 1]]); ts.append(t + np.uint32(o)); o += v.shape[0]
+    return np.ascontiguousarray(np.concatenate(vs).astype(np.float32).astype(np.float64)), np.ascontiguousarray(np.concatenate(ts).astype(np.uint32))
+
+
+@pytest.mark.parametrize("mesh", ["thin_long", "flat_sheets", "soup", "line", "one_point", "full_double", "huge_coordinates"])
+def test_auto_frame_is_the_oracles_on_every_shape_of_mesh(mesh):
+    """The statistic is summed as integers and min / max are exact: whatever order the device reduces in, frame and layout equal the sequential restatement's.
+    thin_long: config 4's shape; flat_sheets: every box flat along y (no statistic there: the cap); line: two axes without extent; one_point: none."""
+    ids = None
+    if mesh == "thin_long": verts, vidx, ids, _, _ = synth.config4_merged(8, 24)
+    elif mesh == "flat_sheets": verts, vidx = _flat_sheets()
+    elif mesh == "soup": verts, vidx = synth.soup(30000, 0.03, 9)
+    elif mesh == "line":
+        n = 5000; x = np.arange(3 * n, dtype=np.float64) * 0.25
+        verts = np.stack([x, np.full(3 * n, 2.0), np.full(3 * n, -1.0)], 1); vidx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    elif mesh == "one_point":
+        verts = np.tile(np.array([[1.0, 2.0, 3.0]]), (300, 1)); vidx = np.arange(300, dtype=np.uint32).reshape(100, 3)
+    elif mesh == "full_double": verts, vidx = synth.cloth_pair(60, round_f32=False)
+    else:
+        verts, vidx = synth.soup(20000, 0.04, 5); verts = verts * 1e12 - 3e13
+    off, span, lay = oracle.auto_frame(verts, vidx)
+    with mi355cd.CollisionDetector(verts, vidx, ids) as cd:
+        cd.set_morton_frame(mi355cd.CD_FRAME_AUTO)
+        pairs, n, rc = cd.self_collide(cap=1 << 20)
+        goff, gspan, glay = cd.get_morton_frame()
+        assert glay == lay and np.array_equal(goff, off) and np.array_equal(gspan, span), (oracle.layout_fields(glay), oracle.layout_fields(lay))
+        keys, perm = cd.export_keys()
+        r = oracle.pipeline(verts, vidx, ids, off=off, span=span, layout=lay)
+        assert np.array_equal(keys, r["keys"]) and np.array_equal(perm, r["perm"])
+        assert rc == 0 and n == r["stats"].n_pairs and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+        assert cd.stats().pairs_tested == r["stats"].pairs_tested
+
+
+def test_adaptive_keys_of_explicit_points_match_the_oracle():
+    """cd_morton3d_points_layout (what k_morton computes per centroid in a frame with a layout) against the restatement: layouts of every shape, points inside,
+    on cell boundaries +- 1 ulp, outside the frame, NaN; and layout (x, y, z), 0, 0, 20 against the reference-pinned morton3D itself."""
+    rng = np.random.default_rng(77)
+    words = [oracle.layout_word((0, 2, 1), 3, 3, 17), oracle.layout_word((2, 0, 1), 0, 3, 18), oracle.layout_word((1, 0, 2), 60, 0, 0), oracle.layout_word((0, 1, 2), 0, 30, 0),
+             oracle.layout_word((2, 1, 0), 10, 10, 10), oracle.layout_word((1, 2, 0), 5, 2, 7), oracle.layout_word((0, 1, 2), 0, 0, 20), oracle.layout_word((1, 2, 0), 0, 0, 0)]
+    for w in words:
+        off = rng.normal(size=3) * 5; span = np.exp(rng.normal(size=3) * 2)
+        (A, B, C), nA, p, t = oracle.layout_fields(w)
+        pts = rng.random((40000, 3)) * span + off
+        edge = (rng.integers(0, 1 << min(nA + p + t, 40), size=(20000, 3)) / float(1 << min(nA + p + t, 40))) * span + off     # cell boundaries of axis A's grid (and whatever they are on the others)
+        edge = np.concatenate([edge, np.nextafter(edge, np.inf), np.nextafter(edge, -np.inf)])
+        out = np.concatenate([off - span * rng.random((500, 3)), off + span * (1 + rng.random((500, 3))), np.full((4, 3), np.nan), np.array([[1e300, -1e300, 0.0]])])
+        allp = np.concatenate([pts, edge, out])
+        got = mi355cd.morton3d_points_layout(allp, off, span, w)
+        assert np.array_equal(got, oracle.morton3d_layout_batch(allp, off, span, w)), oracle.layout_fields(w)
+        assert int(got.max()) < 1 << 60
+    pts = rng.random((100000, 3)) * oracle.REF_SPAN + oracle.REF_OFF
+    assert np.array_equal(mi355cd.morton3d_points_layout(pts, oracle.REF_OFF, oracle.REF_SPAN, oracle.layout_word((0, 1, 2), 0, 0, 20)), oracle.morton3d_batch(pts))
+    assert np.array_equal(mi355cd.morton3d_points_layout(pts, oracle.REF_OFF, oracle.REF_SPAN, 0), mi355cd.morton3d_points(pts))
+
+
+def test_thin_long_mesh_sorts_in_two_passes_and_walks_a_better_tree():
+    """a thin, long mesh (config 4 merged, 21 x 0.05 x 2.2, 320 k triangles) in CD_FRAME_AUTO -- the oracle's pair set and pairs tested, the
+    hybrid sort in its FIRST form (two global passes, small windows), and a tree that costs at least a quarter fewer node visits than round 5's per-axis frame
+    (same call, CD_FRAME_CUSTOM with the per-axis spans = morton.h:70-89's interleave).  The frame kept afterwards: same keys, same result, no AUTO pass."""
+    verts, vidx, ids, lo, span5 = synth.config4_merged(8, 100)
+    r = oracle.pipeline(verts, vidx, ids, off=lo, span=span5)
+    want = oracle.pair_set(r["pairs"])
+    with mi355cd.CollisionDetector(verts, vidx, ids) as cd:
+        cd.set_morton_frame(mi355cd.CD_FRAME_AUTO)
+        pairs, n, rc = cd.self_collide(cap=1 << 20)
+        st = cd.stats()
+        assert rc == 0 and np.array_equal(oracle.pair_set(pairs), want) and st.pairs_tested == r["stats"].pairs_tested
+        assert st.sort_passes == 2 and cd.debug_get(mi355cd.CD_DBG_GET_SORT_FORM) == 0
+        visits_auto = st.node_visits
+        keys_auto = cd.export_keys()[0]
+        off, sp, lay = cd.keep_auto_frame()
+        (A, B, C), nA, p, t = oracle.layout_fields(lay)
+        assert (A, B, C) == (0, 2, 1) and nA + 2 * p + 3 * t == 60 and p <= 4
+        pairs, n, rc = cd.self_collide(cap=1 << 20)
+        assert rc == 0 and np.array_equal(oracle.pair_set(pairs), want) and np.array_equal(cd.export_keys()[0], keys_auto) and cd.stats().sort_passes == 2
+        cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, lo, span5)
+        pairs, n, rc = cd.self_collide(cap=1 << 20)
+        st5 = cd.stats()
+        assert rc == 0 and np.array_equal(oracle.pair_set(pairs), want) and st5.pairs_tested == st.pairs_tested
+        assert visits_auto < 0.8 * st5.node_visits, (visits_auto, st5.node_visits)
 
 
 def test_pair_set_is_frame_independent():
