@@ -139,7 +139,12 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
                                                            AmbTable amb, const uint8_t *__restrict__ vamb,
                                                            const uint32_t *__restrict__ hint_perm, const uint8_t *__restrict__ hint_tri, uint32_t *__restrict__ hint_cost /* all NULL, or the
                                                                           half traversal's order hint (cd_bvh.h): sorted position -> triangle, the time class the last traversal left with
-                                                                          every triangle; out: per group of 64 leaves -- one wave of this kernel -- the max over its leaves */)
+                                                                          every triangle; out: per group of 64 leaves -- one wave of this kernel -- the max over its leaves */,
+                                                           unsigned long long *__restrict__ leaf_side /* one bit a leaf: it is the LEFT child of recs[j] (else the right child of recs[j - 1]) */,
+                                                           int store_qbox /* 0: qbox32[] is not written (round 6: 32 of this kernel's 106 bytes a leaf, and the kernel is bound by its stores from 4 M leaves up).
+                                                                             Nothing on the default path reads it: the half traversal takes its query boxes out of the records, k_cross_fused its
+                                                                             leaf-level pieces too (below).  Who does read it -- the from-the-root descent, the packers, k_exact on a mesh with a cell
+                                                                             table, k_cross_records -- asks the host for it (mi355cd.hip: qbox_wanted / ensure_qbox) */)
 {
     {
         const uint32_t G = gridDim.x * REFIT_BLK;
@@ -158,6 +163,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
     DKey (*dt)[DL_STRIDE] = reinterpret_cast<DKey (*)[DL_STRIDE]>(scratch);
     float (*nb)[6] = reinterpret_cast<float (*)[6]>(scratch);
     __shared__ int16_t lsplit[REFIT_BLK];
+    __shared__ uint8_t lcov[REFIT_BLK];             // leaf b0 + t is a child of an IN-BLOCK node: that node's thread writes the leaf's box, in its record
     __shared__ unsigned long long lexact[REFIT_BLK / 64], lcertain[REFIT_BLK / 64];
     __shared__ unsigned long long acc[6];
     __shared__ int32_t lcross[64];
@@ -165,6 +171,7 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
     const int b = blockIdx.x, b0 = b * REFIT_BLK, tid = threadIdx.x;
     const int j = b0 + tid;
     if (tid == 0) { lcount = 0; b32_store(t[0], b32_identity()); }
+    lcov[tid] = 0;
     if (tid < 6) acc[tid] = (tid & 1) ? 0ull : ~0ull;                      // x1 x2 y1 y2 z1 z2: min, max, min, max, min, max
     // adjacent deltas of the positions b0-1 .. b0+512 (thread t: position b0-1+t; threads 0 and 1 also take the last two)
     for (int x = tid; x < DL_STRIDE; x += REFIT_BLK) {
@@ -185,9 +192,11 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
         certain = e.certain;
         exact = certain && box_is_fp32(mine);
         if (!exact || n == 1) store_box(boxes, (n - 1) + j, mine);        // an exact box is its fp32 copy (leaf_box64, cd_bvh.h); n == 1: the leaf is node 0
-        float4 *qp = reinterpret_cast<float4 *>(qbox32 + j);
-        qp[0] = make_float4(m32.lx, m32.ly, m32.lz, m32.hx);
-        qp[1] = make_float4(m32.hy, m32.hz, __uint_as_float((exact ? LB_EXACT : 0u) | (certain ? LB_CERTAIN : 0u) | (box_overlap(mine, mine) ? LB_SELF : 0u)), 0.f);
+        if (store_qbox) {                                                  // (uniform)
+            float4 *qp = reinterpret_cast<float4 *>(qbox32 + j);
+            qp[0] = make_float4(m32.lx, m32.ly, m32.lz, m32.hx);
+            qp[1] = make_float4(m32.hy, m32.hz, __uint_as_float((exact ? LB_EXACT : 0u) | (certain ? LB_CERTAIN : 0u) | (box_overlap(mine, mine) ? LB_SELF : 0u)), 0.f);
+        }
     }
     b32_store(t[REFIT_BLK + tid], m32);
     {
@@ -232,6 +241,14 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
         for (int o = 32; o; o >>= 1) { const uint32_t u = (uint32_t)__shfl_xor((int)c, o); c = u > c ? u : c; }
         if ((tid & 63) == 0 && j < n) hint_cost[j >> 6] = c;
     }
+    // Which record holds leaf j's box: the parent rule of k_cross_fused for a range of one leaf -- leaf j is the left child of the record named j when
+    // delta(j, j + 1) > delta(j - 1, j) (-1 past the ends), else the right child of the record named j - 1.  One bit a leaf, a ballot a wave: what the cross
+    // nodes' range queries need to find a leaf's fp32 box in the RECORDS (this kernel writes it there for every leaf: below) now that qbox32[] is not stored.
+    const bool is_left = j < n && (dt[0][tid + 1] >> DK_SHIFT) > (dt[0][tid] >> DK_SHIFT);
+    {
+        const unsigned long long sm = __builtin_amdgcn_ballot_w64(is_left);
+        if ((tid & 63) == 0 && j < n) leaf_side[j >> 6] = sm;
+    }
     const int i = j;                                                       // internal node with the same index
     int first = 0, last = 0, split = 0; bool have = false, cross = false;
     if (i < n - 1) {
@@ -257,6 +274,8 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
             const int omask = (1 << DK_SHIFT) - 1;
             split = b0 - 1 + (((m1 >> DK_SHIFT) < (m0 >> DK_SHIFT)) ? a1 + ((int)m1 & omask) : a + ((int)m0 & omask));
             split_of[i] = split;
+            if (split == first) lcov[split - b0] = 1;                       // its leaf children's boxes go out with its record
+            if (split + 1 == last) lcov[split + 1 - b0] = 1;
         }
         lsplit[tid] = have ? (int16_t)(split - b0) : (int16_t)-1;
         if (cross) {
@@ -268,6 +287,14 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
     __syncthreads();                                                        // every node has its range and split: the table is dead
     b32_store(nb[tid], seg_query32(t, have ? first - b0 : 1, have ? last - b0 : 0));   // the node's own box (an empty query for the others)
     __syncthreads();                                                        // nb[], lsplit[], acc[], lcount of the whole block
+    // A leaf whose parent is a CROSS node (its range leaves the block: k_cross_fused writes that record) puts its box into its half of that record itself --
+    // box, link ~j, and in the last word its EXACT (bit 0) / CERTAIN (bit 1) flags for the record's owner, who overwrites the half with the same box and the
+    // final words.  After this kernel EVERY leaf's fp32 box is in the record half leaf_side[] names.
+    if (j < n && n > 1 && !lcov[tid]) {
+        float4 *h = const_cast<float4 *>(is_left ? rec_left(recs32, n, (uint32_t)j) : rec_right(recs32, n, (uint32_t)(j - 1)));
+        h[0] = make_float4(m32.lx, m32.ly, m32.lz, m32.hx);
+        h[1] = make_float4(m32.hy, m32.hz, __int_as_float(~j), __uint_as_float((exact ? 1u : 0u) | (certain ? 2u : 0u)));
+    }
     if (have) {
         // children (bvh.cuh:174-195): the left child is leaf `split` or internal node `split`, the right one leaf / node split + 1
         const bool leafL = split == first, leafR = split + 1 == last;
@@ -297,6 +324,23 @@ __global__ __launch_bounds__(REFIT_BLK) void k_build_block(const double *__restr
     if (tid == 0) lbase = atomicAdd(cross_count, cnt);
     __syncthreads();
     if ((uint32_t)tid < cnt && lbase + tid < cross_cap) cross_list[lbase + tid] = lcross[tid];
+}
+
+// qbox32[] on request (round 6): the fused build no longer stores it (k_build_block, store_qbox); a reader that the build did not know of -- cd_pack_queries, external
+// queries, the deep pass behind a half traversal, cd_debug_records -- gets it from this pass over the leaves: the same box, encoding and flags k_build_block forms.
+__global__ __launch_bounds__(256) void k_fill_qbox(const double *__restrict__ verts, const LeafTri *__restrict__ leaf, int n, LeafBox32 *__restrict__ qbox32,
+                                                   AmbTable amb, const uint8_t *__restrict__ vamb)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const LeafTri lt = leaf[j];
+    const d3 A = load_vertex(verts, lt.v0), B = load_vertex(verts, lt.v1), C = load_vertex(verts, lt.v2);
+    const Box mine = box_set(A, B, C);
+    const Enc32 e = enc_leaf32(amb, mine, A, B, C, vamb, lt.v0, lt.v1, lt.v2);
+    const bool exact = e.certain && box_is_fp32(mine);
+    float4 *qp = reinterpret_cast<float4 *>(qbox32 + j);
+    qp[0] = make_float4(e.lx, e.ly, e.lz, e.hx);
+    qp[1] = make_float4(e.hy, e.hz, __uint_as_float((exact ? LB_EXACT : 0u) | (e.certain ? LB_CERTAIN : 0u) | (box_overlap(mine, mine) ? LB_SELF : 0u)), 0.f);
 }
 
 // Box of heap node k at level p (2^p leaves) for the cross nodes' queries: the leaves' fp32 boxes (levels below
@@ -573,7 +617,7 @@ __global__ __launch_bounds__(256) void k_top_publish_upper(unsigned long long *_
 // (76 VGPRs: six waves per SIMD.  Held at 72 / 64 registers for seven / eight -- amdgpu_waves_per_eu, 20 / 48 bytes of scratch -- the kernel took 19.9 / 23.8 us
 //  instead of 17.7 at 1 M triangles and 134 / 154 instead of 127 at 8 M: profiles/r05_experiments/size_scaling.log)
 __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restrict__ keys, int n, const double *__restrict__ seg, const float *__restrict__ seg32,
-                                                     int nbp2, int nblocks, const LeafBox32 *__restrict__ qbox32, double *__restrict__ boxes,
+                                                     int nbp2, int nblocks, const unsigned long long *__restrict__ leaf_side /* k_build_block: which record half holds a leaf's box */, double *__restrict__ boxes,
                                                      NodeRec32 *__restrict__ recs32, const int32_t *__restrict__ split_of, int32_t *__restrict__ root_name,
                                                      const int32_t *__restrict__ dense, const uint32_t *__restrict__ dense_total, uint32_t dense_cap,
                                                      unsigned long long *top_pub /* [3 * nbp2 / 4] the upper levels, published by workgroup 0 */, uint32_t *top_flag, uint32_t top_seq,
@@ -668,12 +712,17 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
         // (unconditional loads at valid positions, consumed after the pieces: a load whose value decides a branch is waited for on
         //  the spot -- written as `if (flags & EXACT) ...` these were up to two round trips in front of the pieces')
         const bool own = live && gl == 0;
-        const uint32_t flagL = qbox32[own && leafL ? first : 0].flags, flagR = qbox32[own && leafR ? last : 0].flags;
+        // (a leaf child's EXACT / CERTAIN flags: k_build_block left them in the last word of the half this node is about to write -- the leaf's parent is THIS cross node)
+        const uint32_t pwL = reinterpret_cast<const uint32_t *>(rec_left(recs32, n, (uint32_t)(own && leafL ? split : 0)))[7];
+        const uint32_t pwR = reinterpret_cast<const uint32_t *>(rec_right(recs32, n, (uint32_t)(own && leafR ? split : 0)))[7];
+        const uint32_t flagL = ((pwL & 1u) ? LB_EXACT : 0u) | ((pwL & 2u) ? LB_CERTAIN : 0u), flagR = ((pwR & 1u) ? LB_EXACT : 0u) | ((pwR & 2u) ? LB_CERTAIN : 0u);
         const int32_t soL = split_of[own && !leafL && !crossL ? split : 0], soR = split_of[own && !leafR && !crossR ? split + 1 : 0];
         // ---- the records: each group answers the two range queries of its own node.  A range [l, r] is the union of at most one
         // left and one right piece per level of the iterative bottom-up query; what a piece is made of depends on its level:
-        //   levels 0 .. 2: one / two / four leaf boxes (qbox32; round 5: k_build_block is bound by its writes, and the levels 1 and 2 of its trees were
-        //   18 bytes a leaf); levels 3 .. 9: one stored node of a block's tree (seg32); levels >= 10: one published node (top_pub).
+        //   levels 0 .. 2: one / two / four leaf boxes (round 5: k_build_block is bound by its writes, and the levels 1 and 2 of its trees were 18 bytes a
+        //   leaf; round 6: qbox32[], another 32, is not written either -- a leaf's box is in the RECORDS, the left half of recs[j] or the right half of
+        //   recs[j - 1] by leaf_side[]'s bit: both halves and the bit word are fetched together, unconditionally, and selected afterwards);
+        //   levels 3 .. 9: one stored node of a block's tree (seg32); levels >= 10: one published node (top_pub).
         // The memory items of a child range are 14 + 14 = 28, of the node 56: lane gl fetches items gl and gl + 16 of either child
         // -- four 24-byte loads per lane, all unconditional (an item that is not taken reads a valid dummy and is dropped), ONE round
         // trip for the whole group.  (Before: a lane per level and a branch per kind of level -- divergent branches run one after
@@ -730,6 +779,7 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
             constexpr int SMIN = SEG32_MIN_LEVEL, LEAF_ITEMS = 2 * ((1 << SMIN) - 1), N_ITEMS = LEAF_ITEMS + 2 * (REFIT_LOG + 1 - SMIN);
             static_assert(XG == 16 && N_ITEMS <= 2 * XG, "a lane fetches items gl and gl + 16 of either child");
             B32 it[4]; bool tk[4];
+            static_assert(LEAF_ITEMS <= XG, "the leaf items are a lane's FIRST item of either child (r = 0, 2)");
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int h = r >> 1, t = gl + 16 * (r & 1);                // item t of child h
@@ -738,14 +788,24 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
                 else { const int u = t - LEAF_ITEMS; p = SMIN + (u >> 1); side = u & 1; e = 0; if (p > REFIT_LOG) p = REFIT_LOG; }
                 long long k;
                 bool take = t < N_ITEMS && piece(h, p, side, k);
-                const float *ptr;
-                if (p < SMIN) {
-                    const long long jj = take ? ((k << p) - P + e) : 0;     // leaf e of the piece (the leaf's fp32 box: the first 24 bytes of its 32)
+                // (every load unconditional, addresses by select: a load inside a divergent branch is waited for inside it -- a round trip per arm)
+                const bool leafitem = (r & 1) == 0 && p < SMIN;             // ((r & 1): compile time -- a lane's second items are never leaf items)
+                uint32_t jl = 0u;
+                if (leafitem) {
+                    const long long jj = take ? ((k << p) - P + e) : 0;     // leaf e of the piece
                     take = take && jj < n;                                  // (past the last leaf: nothing there)
-                    ptr = reinterpret_cast<const float *>(qbox32 + (take ? jj : 0));
-                } else ptr = seg32 + 6 * (size_t)(take ? k : (P >> p));
+                    jl = take ? (uint32_t)jj : 0u;
+                }
+                // a leaf's box: the first 24 bytes of the left half of recs[jl] or of the right half of recs[jl - 1] (clamped: the half that is not the leaf's is fetched and dropped)
+                const float *p1 = leafitem ? reinterpret_cast<const float *>(rec_left(recs32, n, jl + 1u < (uint32_t)n ? jl : 0u)) : seg32 + 6 * (size_t)(take ? k : (P >> p));
+                const B32 v1 = b32_load(p1);
+                if ((r & 1) == 0) {
+                    const B32 vr = b32_load(leafitem ? reinterpret_cast<const float *>(rec_right(recs32, n, jl > 0u ? jl - 1u : 0u)) : p1);
+                    const unsigned long long sw = leaf_side[jl >> 6];
+                    const bool rt = leafitem && ((sw >> (jl & 63u)) & 1ull) == 0ull;
+                    it[r] = B32{rt ? vr.lx : v1.lx, rt ? vr.ly : v1.ly, rt ? vr.lz : v1.lz, rt ? vr.hx : v1.hx, rt ? vr.hy : v1.hy, rt ? vr.hz : v1.hz};
+                } else it[r] = v1;
                 tk[r] = take;
-                it[r] = b32_load(ptr);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (tk[r]) { if (r < 2) accL = b32_merge(accL, it[r]); else accR = b32_merge(accR, it[r]); }

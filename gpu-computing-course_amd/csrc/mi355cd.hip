@@ -83,6 +83,9 @@ struct cd_ctx {
     unsigned long long *d_top_pub = nullptr; uint32_t top_seq = 0;          // k_cross_fused: the upper levels of the fp32 tree as its first workgroup publishes them, and the launch counter its flag word carries
     LeafTri *d_leaf = nullptr; NodeMeta *d_meta = nullptr; int32_t *d_parent = nullptr; double *d_seg = nullptr; float *d_seg32 = nullptr; uint32_t nbp2 = 1; int32_t *d_cross = nullptr; uint32_t cross_cap = 0;   // segment tree over leaf boxes: nbp2*512 heap nodes
     double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec32 *d_recs32 = nullptr; LeafBox32 *d_qbox = nullptr;
+    unsigned long long *d_leaf_side = nullptr;   // fused build: one bit a leaf -- its box is in the left half of recs[j] (else the right half of recs[j - 1]); what k_cross_fused reads instead of qbox[]
+    bool qbox_valid = false;                // d_qbox holds THIS tree's query boxes (the fused build stores them only when somebody is known to read them: qbox_wanted / ensure_qbox)
+    uint32_t dbg_store_qbox = 0;            // CD_DBG_STORE_QBOX: the fused build always stores qbox[] (A/B, tests)
     // the cell table of the current vertices (cd_bvh.h AmbTable; amb_refresh): keys == nullptr while every coordinate is an fp32 value
     AmbTable amb = {nullptr, 0u, 0u};
     unsigned long long *d_amb_keys = nullptr, *d_amb_vals = nullptr; uint64_t amb_cap = 0; uint32_t *d_amb_flag = nullptr;
@@ -139,7 +142,7 @@ struct cd_ctx {
     uint32_t poll_stale = 0;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
     struct GraphKey { uint64_t cap, spec_n; int sort_mode, variant, frame_mode; uint32_t nt, exact_blocks, dbg; const void *p_pairs, *p_cand, *p_defer, *p_report; uint64_t cand_cap; uint32_t defer_cap, pad; } graph_key = {};   // (no padding bytes: compared with memcmp)
-    struct GraphPost { bool leaves_filled, leaf_records_filled, hierarchy_valid, internal_boxes_valid, last_tree_fused, events_ride, scratch_clean; uint32_t sort_passes; } graph_post = {};
+    struct GraphPost { bool leaves_filled, leaf_records_filled, hierarchy_valid, internal_boxes_valid, last_tree_fused, events_ride, scratch_clean, qbox_valid; uint32_t sort_passes; } graph_post = {};
     uint64_t graph_replays = 0, graph_captures = 0;
     bool all_verts_referenced = false;      // every vertex belongs to a triangle (checked at cd_create; the topology never changes afterwards)
     int wall_clock_khz = 0;                 // hipDeviceAttributeWallClockRate: ticks of s_memrealtime per millisecond
@@ -161,7 +164,7 @@ void free_all(cd_ctx *c)
     for (int i = 0; i < 2; ++i) { hipFree(c->d_keys[i]); hipFree(c->d_perm[i]); }
     hipFree(c->d_counts); hipFree(c->d_chunk_tot); hipFree(c->d_os); hipFree(c->d_frame); hipFree(c->d_partial);
     hipFree(c->d_top_pub); hipFree(c->d_leaf); hipFree(c->d_meta); hipFree(c->d_parent); hipFree(c->d_seg); hipFree(c->d_seg32); hipFree(c->d_cross); hipFree(c->d_boxes);
-    hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox); hipFree(c->d_split_of); hipFree(c->d_cost); hipFree(c->d_order); hipFree(c->d_tri_cost);
+    hipFree(c->d_bounded); hipFree(c->d_recs32); hipFree(c->d_qbox); hipFree(c->d_leaf_side); hipFree(c->d_split_of); hipFree(c->d_cost); hipFree(c->d_order); hipFree(c->d_tri_cost);
     hipFree(c->d_amb_keys); hipFree(c->d_amb_flag); hipFree(c->d_vamb);
     for (TravBuf &tb : c->tb) {
         if (tb.d_pairs) hipFree(reinterpret_cast<char *>(tb.d_pairs) - sizeof(Report));
@@ -418,6 +421,21 @@ int enqueue_hierarchy(cd_ctx *c, bool poison_boxes)
 
 // fused: k_build_block (cd_build.h) builds hierarchy, fp32 boxes and records of its 512-leaf block itself, k_cross_meta /
 // k_cross_records those of the cross nodes: no k_hierarchy before it, meta[] / parent[] / internal FP64 boxes are not written.
+// Does anybody the build knows of read qbox[] after it?  The half traversal takes its query boxes out of the records and k_cross_fused its leaf pieces too (cd_build.h);
+// the from-the-root descent (variant 1, and variant 0's tree comes from the stage-wise build anyway), k_cross_records, k_exact's FP64 path on a mesh with a cell table
+// and the multi-GPU step's packers / external pass do read it.  Everybody else asks ensure_qbox() when the time comes.
+static bool qbox_wanted(const cd_ctx *c)
+{
+    return c->trav_variant != 3 || c->dbg_split_cross || c->dbg_store_qbox || c->amb.keys != nullptr || c->amb.mask != 0u || c->attached_multi != nullptr;
+}
+int ensure_qbox(cd_ctx *c)
+{
+    if (c->qbox_valid) return 0;
+    k_fill_qbox<<<cdiv(c->nt, 256), 256, 0, c->stream>>>(c->d_verts, c->d_leaf, (int)c->nt, c->d_qbox, c->amb, (const uint8_t *)c->vamb);
+    HIPCHK(hipGetLastError());
+    c->qbox_valid = true;
+    return 0;
+}
 int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
 {
     const uint32_t n = c->nt;
@@ -449,21 +467,25 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         //  tenth of it and the locality it gives up costs more -- 4 M cloth 173 -> 176 us, 8 M 454 -> 471 us with the hint)
         const bool hint = c->order_hint && c->trav_variant >= 3 && n > 64u && c->nbp2 > 1 && !c->dbg_split_cross && (c->nbp2 <= (uint32_t)TOP_IN_BLOCK || c->order_hint_large);
         const uint32_t *hp = hint ? c->d_perm[0] : nullptr; const uint8_t *ht = hint ? c->d_tri_cost : nullptr; uint32_t *hc = hint ? c->d_cost : nullptr;
+        const int store_q = qbox_wanted(c) ? 1 : 0;
+        c->qbox_valid = store_q != 0;
         if (stamp)
             hipExtLaunchKernelGGL(k_build_block, dim3(nblocks), dim3(REFIT_BLK), 0u, s, c->ev[EV_BLK0], c->ev[EV_BLK1], 0u,
                                   (const double *)c->d_verts, (const LeafTri *)c->d_leaf, (int)n, (const uint64_t *)c->d_keys[0], c->d_split_of,
                                   c->d_boxes, c->d_recs32, c->d_qbox, c->d_root, c->d_seg, c->d_seg32, (int)c->nbp2,
-                                  cross_list, cross_count, c->cross_cap, zp, seg_min, c->amb, (const uint8_t *)c->vamb, hp, ht, hc);
+                                  cross_list, cross_count, c->cross_cap, zp, seg_min, c->amb, (const uint8_t *)c->vamb, hp, ht, hc, c->d_leaf_side, store_q);
         else                                        // (no time stamps: a plain launch, which a stream capture can record -- graph_step)
             k_build_block<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_keys[0], c->d_split_of, c->d_boxes, c->d_recs32, c->d_qbox, c->d_root,
                                                         c->d_seg, c->d_seg32, (int)c->nbp2, cross_list, cross_count, c->cross_cap, zp, seg_min, c->amb, (const uint8_t *)c->vamb,
-                                                        hp, ht, hc);
+                                                        hp, ht, hc, c->d_leaf_side, store_q);
         c->order_pending = hint;
         c->scratch_clean = self_cleaning;       // (judge_sort_flags takes it back when the sort has raised a flag)
-    } else
+    } else {
+        c->qbox_valid = true;
         k_refit_seg_local<<<nblocks, REFIT_BLK, 0, s>>>(c->d_verts, c->d_leaf, (int)n, c->d_meta, c->d_boxes, c->d_bounded,
                                                        c->d_recs32, c->d_qbox, c->d_root, write_internal ? 1 : 0, c->d_seg, (int)c->nbp2,
                                                        cross_list, cross_count, c->cross_cap, c->amb, (const uint8_t *)c->vamb);
+    }
     // fused build, a tree of 2 blocks or more: the cross nodes' ranges, splits, links and records in ONE launch (k_cross_fused, cd_build.h)
     if (fused && n > 1 && c->nbp2 > 1 && !c->dbg_split_cross) {
         const uint32_t xb = (uint32_t)nblocks < 8u ? 8u : ((uint32_t)nblocks > 1790u ? 1790u : (uint32_t)nblocks);   // 16 nodes per workgroup and round, ~13 per block; with the two workgroups below at most what the chip holds at once (7 workgroups per CU)
@@ -485,11 +507,11 @@ int enqueue_refit(cd_ctx *c, bool write_internal, bool fused = false)
         }
         if (done)
             hipExtLaunchKernelGGL(k_cross_fused, dim3(nord + xb + 2u /* [the order hint's 8,] then: the first workgroup publishes the upper levels, the last folds the FP64 box of all leaves */), dim3(256), xlds, s, nullptr, done, 0u,
-                                  (const uint64_t *)c->d_keys[0], (int)n, (const double *)c->d_seg, (const float *)c->d_seg32, (int)c->nbp2, nblocks, (const LeafBox32 *)c->d_qbox, c->d_boxes,
+                                  (const uint64_t *)c->d_keys[0], (int)n, (const double *)c->d_seg, (const float *)c->d_seg32, (int)c->nbp2, nblocks, (const unsigned long long *)c->d_leaf_side, c->d_boxes,
                                   c->d_recs32, (const int32_t *)c->d_split_of, c->d_root, (const int32_t *)c->d_cross, (const uint32_t *)cross_count, c->cross_cap,
                                   c->d_top_pub, top_flag, c->top_seq, nord, ogroups, (const uint32_t *)c->d_cost, c->d_order);
         else
-            k_cross_fused<<<nord + xb + 2u, 256, xlds, s>>>(c->d_keys[0], (int)n, c->d_seg, c->d_seg32, (int)c->nbp2, nblocks, c->d_qbox, c->d_boxes,
+            k_cross_fused<<<nord + xb + 2u, 256, xlds, s>>>(c->d_keys[0], (int)n, c->d_seg, c->d_seg32, (int)c->nbp2, nblocks, c->d_leaf_side, c->d_boxes,
                                                             c->d_recs32, c->d_split_of, c->d_root, c->d_cross, cross_count, c->cross_cap, c->d_top_pub, top_flag, c->top_seq,
                                                             nord, ogroups, c->d_cost, c->d_order);
         if (nord) c->order_ready = true;
@@ -754,6 +776,9 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
         if (!c->hierarchy_valid && (rc = enqueue_hierarchy(c, false))) return rc;
         if ((rc = enqueue_refit(c, true, false))) return rc;
     }
+    // (the from-the-root descent reads its query boxes from qbox[], k_exact the leaf boxes of candidates that are not certain -- external queries against a tree whose
+    //  build did not store them: filled here, once per tree)
+    if (c->trav_variant != 0 && (external || c->trav_variant < 3) && (rc = ensure_qbox(c))) return rc;
     uint32_t launches = 0;
     float deep_ms = 0.f;
     HostCounters h = {};
@@ -792,6 +817,7 @@ int run_traversal(cd_ctx *c, TravBuf &tb, const void *d_ext, uint64_t nq_ext, ui
                 HIPCHK(hipMalloc(&tb.d_deep, sizeof(int32_t) * (size_t)DEEP_STACK * deep_lanes));
                 tb.deep_items = deep_lanes;
             }
+            if (c->trav_variant != 0 && (rc = ensure_qbox(c))) return rc;      // (the deep pass continues with the from-the-root descent)
             HIPCHK(evrec(c, EV_DEEP0));
             HIPCHK(hipMemsetAsync(&tb.d_state->n_deferred, 0, sizeof(uint32_t), s));
             // candidate shards restart from 0: the shallow pass's candidates have all been consumed by k_exact
@@ -938,7 +964,7 @@ int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs
     if (rc) return rc;
     uint64_t spec_n = pairs ? (cap_pairs < SPEC_PAIRS ? cap_pairs : SPEC_PAIRS) : 0;
     const bool direct = pinned_pairs_id(pairs, cap_pairs) != 0;
-    const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1) | (c->order_hint ? 4u : 0u) | (c->order_ready ? 8u : 0u) | (c->local_small_ok ? 16u : 0u) | (c->dbg_sort_windows << 5) /* (whether the descent's launch reads the order hint is baked in) */,
+    const cd_ctx::GraphKey key{cap_pairs, spec_n, c->sort_mode, c->trav_variant, c->frame_mode, c->nt, (uint32_t)c->exact_blocks, c->dbg_no_shared_path | (c->dbg_split_cross << 1) | (c->order_hint ? 4u : 0u) | (c->order_ready ? 8u : 0u) | (c->local_small_ok ? 16u : 0u) | (c->dbg_sort_windows << 5) | (qbox_wanted(c) ? 128u : 0u) /* (whether the descent's launch reads the order hint is baked in) */,
                                tb.d_pairs, tb.d_cand, tb.d_defer, direct ? (const void *)pairs : (const void *)tb.h_report, tb.cand_cap, tb.defer_cap, 0u};
     static_assert(sizeof(cd_ctx::GraphKey) == 2 * 8 + 6 * 4 + 4 * 8 + 8 + 2 * 4, "GraphKey has no padding");
     if (!c->graph_exec || std::memcmp(&key, &c->graph_key, sizeof key) != 0) {
@@ -960,14 +986,14 @@ int graph_step(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs
         if (hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) { graph_drop(c); (void)hipGetLastError(); c->scratch_clean = false; return CD_OK; }
         std::memset(&c->graph_key, 0, sizeof c->graph_key);
         c->graph_key = key;
-        c->graph_post = cd_ctx::GraphPost{c->leaves_filled, c->leaf_records_filled, c->hierarchy_valid, c->internal_boxes_valid, c->last_tree_fused, c->events_ride, c->scratch_clean,
+        c->graph_post = cd_ctx::GraphPost{c->leaves_filled, c->leaf_records_filled, c->hierarchy_valid, c->internal_boxes_valid, c->last_tree_fused, c->events_ride, c->scratch_clean, c->qbox_valid,
                                           c->stats.sort_passes};
         ++c->graph_captures;
     }
     // what the enqueue functions leave behind on the host side, as the capture left it
     const cd_ctx::GraphPost &gp = c->graph_post;
     c->leaves_filled = gp.leaves_filled; c->leaf_records_filled = gp.leaf_records_filled; c->hierarchy_valid = gp.hierarchy_valid;
-    c->internal_boxes_valid = gp.internal_boxes_valid; c->last_tree_fused = gp.last_tree_fused; c->events_ride = gp.events_ride; c->scratch_clean = gp.scratch_clean;
+    c->internal_boxes_valid = gp.internal_boxes_valid; c->last_tree_fused = gp.last_tree_fused; c->events_ride = gp.events_ride; c->scratch_clean = gp.scratch_clean; c->qbox_valid = gp.qbox_valid;
     c->stats.sort_passes = gp.sort_passes;
     HIPCHK(hipGraphLaunch(c->graph_exec, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1070,6 +1096,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_bounded, sizeof(uint32_t) * n);
     ALLOC(c->d_recs32, sizeof(NodeRec32) * n);
     ALLOC(c->d_qbox, sizeof(LeafBox32) * n);
+    ALLOC(c->d_leaf_side, sizeof(unsigned long long) * ((n + 63) / 64 + 1));
     ALLOC(c->d_split_of, sizeof(int32_t) * n);
     { const size_t groups = ((size_t)n + 63) / 64;
       ALLOC(c->d_cost, sizeof(uint32_t) * groups); ALLOC(c->d_order, sizeof(uint32_t) * groups); ALLOC(c->d_tri_cost, n);
@@ -1482,7 +1509,7 @@ int cd_debug_records(cd_ctx *c, void *recs, void *qboxes, int32_t *root)
     if (c->stage < ST_REFIT) return CD_ERR_ORDER;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (recs) HIPCHK(hipMemcpy(recs, c->d_recs32, sizeof(NodeRec32) * (size_t)c->nt, hipMemcpyDeviceToHost));
-    if (qboxes) HIPCHK(hipMemcpy(qboxes, c->d_qbox, sizeof(LeafBox32) * (size_t)c->nt, hipMemcpyDeviceToHost));
+    if (qboxes) { const int rq = ensure_qbox(c); if (rq) return rq; HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipMemcpy(qboxes, c->d_qbox, sizeof(LeafBox32) * (size_t)c->nt, hipMemcpyDeviceToHost)); }
     if (root) HIPCHK(hipMemcpy(root, c->d_root, sizeof(int32_t), hipMemcpyDeviceToHost));
     return CD_OK;
 }
@@ -1640,6 +1667,7 @@ int cd_debug_option(cd_ctx *c, int key, int64_t value, int64_t *out)
     case CD_DBG_SPLIT_CROSS:     c->dbg_split_cross = value != 0; return CD_OK;
     case CD_DBG_SORT_WINDOWS:    if (value < 0 || value > 2) return CD_ERR_ARG; c->dbg_sort_windows = (uint32_t)value; c->local_small_ok = true; graph_drop(c); return CD_OK;
     case CD_DBG_REPORT_COPIES:   c->dbg_report_copies = value != 0; graph_drop(c); return CD_OK;
+    case CD_DBG_STORE_QBOX:      c->dbg_store_qbox = value != 0; graph_drop(c); return CD_OK;
     case CD_DBG_POLL_SCAN:       c->dbg_poll_check = value != 0; return CD_OK;
     case CD_DBG_GET_POLL_STALE:     if (!out) return CD_ERR_ARG; *out = c->poll_stale; return CD_OK;
     case CD_DBG_GET_POLL_FALLBACKS: if (!out) return CD_ERR_ARG; *out = c->poll_fallbacks; return CD_OK;
@@ -1689,6 +1717,7 @@ int cd_pack_queries(cd_ctx *c, const double box[6], void *d_out, uint64_t cap, u
     // packing does not disturb the statistics of the traversal before it
     double *d_box = reinterpret_cast<double *>(c->d_small + 104);
     unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(c->d_small + 116);
+    { const int rq = ensure_qbox(c); if (rq) return rq; }
     HIPCHK(hipMemcpyAsync(d_box, box, sizeof(double) * 6, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
     k_pack_queries<<<cdiv(c->nt, PACK_THREADS), PACK_THREADS, 0, s>>>(c->d_verts, c->d_leaf, c->d_boxes, c->d_qbox, (int)c->nt, d_box, 1, -1, nullptr,

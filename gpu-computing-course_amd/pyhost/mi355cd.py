@@ -26,6 +26,7 @@ CD_DBG_SORT_WINDOWS, CD_DBG_GET_SORT_FORM = 7, 8
 CD_DBG_POLL_SCAN, CD_DBG_GET_POLL_STALE, CD_DBG_GET_POLL_FALLBACKS, CD_DBG_GET_POLLED_STEPS, CD_DBG_GET_TREE_WAS_FUSED = 10, 11, 12, 13, 14
 CD_DBG_GET_ORDER_STATE = 15
 CD_DBG_REPORT_COPIES = 6
+CD_DBG_STORE_QBOX = 9
 
 QUERY_DTYPE = np.dtype([("v", "<f8", (9,)), ("id", "<u4"), ("vidx", "<u4", (3,))])
 assert QUERY_DTYPE.itemsize == 88

@@ -254,6 +254,8 @@ enum {
                                      /* for them, then 4096; 1 always windows of 4096 keys (one 1024-thread workgroup a CU); 2 always 2048.  Same keys and permutation either way (A/B, tests) */
     CD_DBG_GET_SORT_FORM      = 8,   /* the form the next sort takes: 0 two global passes on key bits 44..59 + window sorts (default), 1 the same on bits 48..63 (a key beyond 2^60: a  */
                                      /* centroid outside the Morton frame; retried as 0 every 64 sorts), 2 four passes + fix-up, 3 all eight passes (runs too long for the forms before)   */
+    CD_DBG_STORE_QBOX         = 9,   /* 1: the fused build always stores the per-leaf query boxes (qbox[]); default 0: only when a reader is known -- the half traversal and the cross    */
+                                     /* nodes take leaf boxes out of the records (round 6: 32 of the block build's 106 bytes a leaf).  Same records, same results (A/B, tests)              */
     CD_DBG_POLL_SCAN          = 10,  /* polled completion: poison the pair area before a step, scan it the moment the sequence word is seen   */
     CD_DBG_GET_POLL_STALE     = 11,  /* ... steps in which the scan found a pair missing (must stay 0)                                        */
     CD_DBG_GET_POLL_FALLBACKS = 12,  /* ... polled waits that ran into the 20 ms budget and ended in a stream synchronise                     */

@@ -971,18 +971,23 @@ def test_multi_step_slab_allocation_failure_in_the_growth_round_fails_together_a
 
 def _assert_fused_records_equal_stagewise(verts, vidx, ids=None, split_cross_too=True, auto_frame=False):
     got = {}
-    for fused in (1, 0, 2):                                 # 2: the fused build with k_cross_meta + k_cross_records (CD_DBG_SPLIT_CROSS: the three-launch form of the cross stage)
+    # 1: the fused build as it runs by default (round 6: WITHOUT storing qbox[] -- the cross nodes take leaf boxes out of the records, the query boxes compared here
+    #    come from k_fill_qbox on request); 2: with k_cross_meta + k_cross_records (CD_DBG_SPLIT_CROSS: the three-launch form of the cross stage, which reads qbox[]);
+    # 3: the default build with qbox[] stored by k_build_block (CD_DBG_STORE_QBOX)
+    for fused in (1, 0, 2, 3):
         with mi355cd.CollisionDetector(verts, vidx, ids) as cd:
             if auto_frame:
                 cd.set_morton_frame(mi355cd.CD_FRAME_AUTO)
             cd.debug_set(mi355cd.CD_DBG_STAGEWISE_BUILD, 0 if fused else 1)
             cd.debug_set(mi355cd.CD_DBG_SPLIT_CROSS, 1 if fused == 2 else 0)
+            cd.debug_set(mi355cd.CD_DBG_STORE_QBOX, 1 if fused == 3 else 0)
             cd.build_tree()
             assert cd.debug_get(mi355cd.CD_DBG_GET_TREE_WAS_FUSED) == (1 if fused else 0)      # the build that was asked for is the build that ran
             got[fused] = cd.debug_records() + (cd.root_box(),)
     if split_cross_too:
         _compare_records(vidx.shape[0], got[2], got[0])
     _compare_records(vidx.shape[0], got[1], got[0])
+    _compare_records(vidx.shape[0], got[3], got[0])
 
 
 def _compare_records(n, a, b):
@@ -1051,6 +1056,39 @@ def test_fused_build_writes_the_records_of_the_stagewise_build(kind):
     else:
         verts, vidx = synth.soup(512 * 7 + 1, 0.05, 9)
     _assert_fused_records_equal_stagewise(verts, vidx)
+
+
+def test_readers_of_the_query_boxes_get_them_on_request():
+    """Round 6: the default fused build does not store qbox[] (k_build_block is bound by its stores at size; nothing on the half traversal's path reads them).  Whoever
+    does read them afterwards gets them filled on request: the from-the-root descent (variant switched AFTER the build), the packer, external queries, the deep pass."""
+    verts, vidx = synth.cloth_pair(70)
+    r = oracle.pipeline(verts, vidx)
+    want = oracle.pair_set(r["pairs"])
+    with mi355cd.CollisionDetector(verts, vidx) as cd:
+        pairs, n, rc = cd.self_collide(cap=1 << 18)
+        assert rc == 0 and np.array_equal(oracle.pair_set(pairs), want) and cd.stats().pairs_tested == r["stats"].pairs_tested
+        for variant in (1, 0, 3):
+            cd.set_option(mi355cd.CD_OPT_TRAVERSAL, variant)
+            p2, n2, rc2 = cd.find_collisions(cap=1 << 18)
+            assert rc2 == 0 and np.array_equal(oracle.pair_set(p2), want) and cd.stats().pairs_tested == r["stats"].pairs_tested, variant
+    # the packer and external queries (the mesh against itself: the ID rule lets each pair through once = the same set); no cd_multi attached: nothing told the build
+    import torch
+    import mi355_multi as multi
+    e = multi.HipEngine(verts, vidx, None, torch.device("cuda", 0), frame=mi355cd.CD_FRAME_REFERENCE)
+    pairs, n, tested = e.self_collide(1 << 18)
+    q = e.pack_queries(e.root_box())                        # every leaf's box overlaps the root's... unless it is flat: at least most of them
+    assert q.numel() // multi.QUERY_BYTES > 0.9 * vidx.shape[0]
+    p3, n3, t3 = e.find_collisions_queries(q, 1 << 18)
+    assert np.array_equal(oracle.pair_set(p3), want)
+    e.close()
+    # the deep pass behind a half traversal (a comb whose chain overflows a lane's stack)
+    off = np.zeros(3); span = np.full(3, 1048576.0)
+    cv, ct = _comb([1 << (59 - k) for k in range(60)], big_first=True)
+    rc_ = oracle.pipeline(cv, ct, off=off, span=span)
+    with mi355cd.CollisionDetector(cv, ct) as cd:
+        cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, off, span)
+        pairs, n, rc = cd.self_collide()
+        assert cd.stats().stack_overflows > 0 and np.array_equal(oracle.pair_set(pairs), oracle.pair_set(rc_["pairs"])) and cd.stats().pairs_tested == rc_["stats"].pairs_tested
 
 
 def test_device_pair_post_processing():
