@@ -545,12 +545,11 @@ def main():
     # neighborCount compares vertex INDICES: a per-rank base makes them global for the cross-rank pass
     engine = multi.HipEngine(verts, vidx, ids, device, frame, vertex_id_base=vbase if multi_path else 0)
     if multi_path:
-        # The reference normalises Morton keys with constants of its data set (morton.h:43-58); a shard of config 4 is that data set
-        # shifted along x, so its frame is the reference's, shifted with it -- fixed at set-up like the reference's, not recomputed from the
-        # centroids in every step (CD_FRAME_AUTO: a pass over the triangles in front of the keys, ~11 us of a 0.31 ms step).
-        width = 2.88 * 0.9
-        off = np.array([0.004501 + rank * width, -0.476622, -0.381965]); span = np.array([3.08, 0.76, 2.36])
-        engine.cd.set_morton_frame(mi355cd.CD_FRAME_CUSTOM, off, span)
+        # The reference normalises Morton keys with constants of its data set (morton.h:43-58), fixed once.  A shard of config 4 lies outside that frame for rank > 0:
+        # the library derives the rank's frame itself (CD_FRAME_AUTO: the adaptive frame of cd_math.h) in one build at set-up, and the bench KEEPS it -- fixed like the
+        # reference's constants, not recomputed from the centroids in every step (the AUTO pass over the triangles is ~11 us of a 0.31 ms step).
+        engine.cd.build_tree()
+        engine.cd.keep_auto_frame()
     if args.traversal is not None:
         engine.cd.set_option(mi355cd.CD_OPT_TRAVERSAL, args.traversal)
     if args.no_order_hint:
@@ -774,6 +773,42 @@ def main():
                                             f"({line['cpu_baseline']['omp']['cores']}) this process' CPU share supports")
         else:
             line["config"]["last_step_rank0"] = info
+            # ---- the N > 1 line carries what the N = 1 line carries (north_star wants 1 / 2 / 4 / 8 GPUs "as absolute numbers and as fraction of
+            # the HBM roofline, next to the CPU path"): `roofline` = the WHOLE PATH of the whole job, SURVEY 8(d)'s 460 B a triangle x the triangles of all ranks over the
+            # step's wall time, against N x 8 TB/s; inside it rank 0's local pipeline kernel by kernel (the kernels cd_multi_step enqueues for the rank's own shard are
+            # cd_self_collide's: stamped here in a few untimed cd_self_collide steps on rank 0's shard -- no collective involved, the other ranks are in their checker leg).
+            total_tris = int(nt) * world
+            ach = TOTAL_BYTES_PER_TRI * total_tris / (ms_per_step * 1e-3) / 1e9
+            engine.cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0); engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 15)
+            lk = {"build_block": 0.0, "descend": 0.0, "exact": 0.0}; lpipe = 0.0; lsteps = 10
+            for _ in range(3):
+                engine.cd.self_collide_into(pair_buf)
+            for _ in range(lsteps):
+                engine.cd.self_collide_into(pair_buf); st = engine.cd.stats()
+                lk["build_block"] += st.ms_build_block / lsteps; lk["descend"] += st.ms_descend / lsteps; lk["exact"] += st.ms_exact / lsteps; lpipe += st.ms_pipeline / lsteps
+            dom = max((("k_descend_half", lk["descend"], TRAVERSAL_BYTES_PER_TRI), ("k_build_block", lk["build_block"], BUILD_BYTES_PER_TRI)), key=lambda x: x[1])
+            dom_ach = dom[2] * nt / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
+            line["kernel_ms"] = lk
+            line["kernel_ms_note"] = (f"rank 0's LOCAL pipeline: HIP events on the kernels' dispatch packets in {lsteps} untimed cd_self_collide steps on rank 0's shard behind the timed region "
+                                      "(the same kernels cd_multi_step enqueues for the rank's own triangles; the cross pass and the exchange are in phase_ms)")
+            line["roofline"] = {"bound": "hbm", "kernel": "whole path, whole job: every rank's Morton keys + sort + hierarchy + refit + traversal of its shard and of the queries it received",
+                                "achieved": ach, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * world), "traffic": None,
+                                "algorithmic_bytes_per_step": TOTAL_BYTES_PER_TRI * total_tris, "triangles_all_ranks": total_tris, "avg_step_ms": ms_per_step,
+                                "what": f"SURVEY 8(d): 460 B a triangle x {total_tris} triangles / ms_per_step (wall, max over ranks) against {world} x {HBM_PEAK_GBS / 1000:.0f} TB/s",
+                                "rank0_local_pipeline": {"total_collision_ms_device": lpipe, "frac_of_one_gpu": (TOTAL_BYTES_PER_TRI * nt / (lpipe * 1e-3) / 1e9 / HBM_PEAK_GBS) if lpipe > 0 else None,
+                                                         "dominant_kernel": {"kernel_symbol": dom[0], "avg_launch_ms": dom[1], "algorithmic_bytes_per_launch": dom[2] * nt,
+                                                                             "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom_ach / HBM_PEAK_GBS}}}
+            engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 15)
+            if not args.no_cpu_baseline:
+                # the CPU path beside it: the oracle on ONE shard (rank 0's), one core and the best OpenMP thread count -- a RATE (pairs tested / s), the same for one
+                # shard or N of them on the same cores; the job's N shards one after the other take N x its total_collision_ms
+                cb = cpu_baseline(verts, vidx)
+                cb["sample"] = f"ONE shard of the job (rank 0's {int(nt)} triangles; the job has {world}): " + cb["sample"]
+                cb["job_total_collision_ms_on_these_cores"] = cb["total_collision_ms"] * world
+                line["cpu_baseline"] = cb
+                line["speedup_vs_cpu_1core"] = line["value"] / cb["value"]
+                if "omp" in cb:
+                    line["speedup_vs_cpu_allcores"] = line["value"] / cb["omp"]["value"]
     if multi_path and not args.no_parity:
         # checker leg on EVERY rank: the oracle on this rank's mesh merged with its lower neighbour's (the only rank whose triangles have
         # smaller ids and overlap this one's); the rank owns exactly the oracle pairs whose larger id is its own (tri_contact.cuh:81)

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restr
     }
     // a centroid outside the Morton frame sets key bits the shifted digits do not cover (bits 64 - down .. 63): the
     // shifted hybrid sort then does not apply -- same flag, same repair (the next form) as a run too long to window
-    if (down && (above >> (64 - down))) atomicOr(overflow, 2u);          // (bit 1: a key beyond the shifted digits -- the mesh has left the frame; bit 0: a run too long: the window sorts)
+    if (down && (above >> (64 - down))) atomicOr(overflow, SORTF_ABOVE);   // a key beyond the shifted digits -- the mesh has left the frame (cd_sort.h: the flag word's bits)
     __syncthreads();
     for (int i = threadIdx.x + first_digit * RADIX; i < 8 * RADIX; i += MORTON_THREADS) {
         const uint32_t v = (&h[0][0])[i];
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void k_sort_fixup_fill(const uint64_t *__restr
     uint32_t pos;
     // run too long: flag it (the host redoes the sort with 8 passes) but still emit a VALID permutation and valid
     // leaves -- the rest of the fused pipeline runs on this output before the host sees the flag
-    if (!fixup_position(keys_in, n, i, k0, pos)) { atomicOr(overflow, 1u); pos = i; }
+    if (!fixup_position(keys_in, n, i, k0, pos)) { atomicOr(overflow, SORTF_FIXUP); pos = i; }
     keys_out[pos] = k0;
     vals_out[pos] = t;
     fill_leaf(pos, t, vidx, ids, n, leaf, parent, bounded, nullptr);

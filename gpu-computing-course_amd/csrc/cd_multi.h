@@ -195,7 +195,11 @@ void multi_free(cd_multi *m)
     delete m;
 }
 
-int multi_alloc(cd_multi *m)
+// What a rank needs to AGREE with the others (creation's all-gather of the capacities, a step's status word): the second stream, a row, the matrix and its pinned
+// copy -- a few hundred bytes, allocated FIRST, so that a rank whose larger allocations fail afterwards can still tell the others (round-3 advisor: the agreement used
+// to be skipped when any of the first allocations failed, and the peers waited in ncclAllGather).  A rank that cannot even have these cannot tell anybody anything:
+// that is a rank that died, and the job's launcher deals with it.
+int multi_alloc_agreement(cd_multi *m)
 {
     const size_t W = (size_t)m->world;
     if (m->flags & CD_MULTI_PRIORITY_STREAM) {
@@ -203,6 +207,17 @@ int multi_alloc(cd_multi *m)
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(hipStreamCreateWithPriority(&m->xstream, hipStreamNonBlocking, greatest));
     } else HIPCHK(hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&m->d_row, sizeof(unsigned long long) * (W + 1)));
+    HIPCHK(hipMalloc(&m->d_matrix, sizeof(unsigned long long) * W * (W + 1)));
+    HIPCHK(hipHostMalloc(&m->h_matrix, sizeof(unsigned long long) * W * (W + 1), hipHostMallocDefault));
+    HIPCHK(hipMalloc(&m->d_myroot, sizeof(double) * 6));
+    HIPCHK(hipMalloc(&m->d_roots, sizeof(double) * 6 * W));
+    return CD_OK;
+}
+int multi_alloc(cd_multi *m)
+{
+    const size_t W = (size_t)m->world;
+    if (m->flags & CD_MULTI_INJECT_ALLOC_FAILURE) { m->flags &= ~CD_MULTI_INJECT_ALLOC_FAILURE; return -(int)hipErrorOutOfMemory; }   // test hook (at creation: this rank's first allocation fails)
     HIPCHK(hipEventCreateWithFlags(&m->ev_payload, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&m->ev_tree));                                                    // (a kernel's stop event: with time stamps)
@@ -211,12 +226,7 @@ int multi_alloc(cd_multi *m)
     for (int i = 0; i < ME_COUNT; ++i) HIPCHK(hipEventCreate(&m->ev[i]));
     HIPCHK(hipMalloc(&m->d_arrive, sizeof(uint32_t) * 16));
     HIPCHK(hipMemset(m->d_arrive, 0, sizeof(uint32_t) * 16));
-    HIPCHK(hipMalloc(&m->d_myroot, sizeof(double) * 6));
     HIPCHK(hipMalloc(&m->d_partial, sizeof(double) * BOUNDS_STRIDE * BOUNDS_BLOCKS));
-    HIPCHK(hipMalloc(&m->d_roots, sizeof(double) * 6 * W));
-    HIPCHK(hipMalloc(&m->d_row, sizeof(unsigned long long) * (W + 1)));
-    HIPCHK(hipMalloc(&m->d_matrix, sizeof(unsigned long long) * W * (W + 1)));
-    HIPCHK(hipHostMalloc(&m->h_matrix, sizeof(unsigned long long) * W * (W + 1), hipHostMallocDefault));
     HIPCHK(hipHostMalloc(&m->h_roots, sizeof(double) * 6 * W, hipHostMallocDefault));
     // the external pass has its own counters, candidates, pairs and deferred list (TravBuf [1])
     TravBuf &tb = m->c->tb[1];
@@ -278,13 +288,15 @@ static int multi_create_common(cd_multi **out, cd_ctx *ctx, ncclComm_t comm, boo
     if (!m) return CD_ERR_ARG;
     m->c = ctx; m->comm = comm; m->own_comm = own; m->rank = rank; m->world = world; m->flags = flags;
     m->qcap = query_cap_per_peer ? query_cap_per_peer : (uint64_t)(ctx->nt / 8 + 1024);
-    int rc = multi_alloc(m);
+    RcclApi *r = rccl();
+    int rc = r ? multi_alloc_agreement(m) : CD_ERR_RCCL;
+    if (rc) { if (!own) m->comm = nullptr; multi_free(m); return rc; }     // (cannot agree on anything: see multi_alloc_agreement)
+    rc = multi_alloc(m);
     // The per-peer capacity must be the SAME on every rank (the decision to grow it is taken by all from the shared matrix):
     // shards of unequal size -- or callers with different arguments -- would start with different values, so the ranks agree
     // on the largest request here, once (creation is a collective already: ncclCommInitRank).  A rank whose allocations failed
     // still joins (with 0), so nobody waits for it; it then returns its error.
-    RcclApi *r = rccl();
-    if (r && m->xstream && m->d_row && m->d_matrix && m->h_matrix) {
+    {
         const unsigned long long mine = rc ? 0ull : (unsigned long long)m->qcap;
         k_set_word<<<1, 1, 0, m->xstream>>>(m->d_row, mine);
         const ncclResult_t ar = r->AllGather(m->d_row, m->d_matrix, 1, ncclUint64, m->comm, m->xstream);
@@ -297,7 +309,7 @@ static int multi_create_common(cd_multi **out, cd_ctx *ctx, ncclComm_t comm, boo
             for (int p = 0; p < world; ++p) { if (m->h_matrix[p] == 0) peer_failed = true; m->qcap = std::max<uint64_t>(m->qcap, m->h_matrix[p]); }
             if (peer_failed) rc = CD_ERR_PEER;
         }
-    } else if (!rc) rc = CD_ERR_RCCL;
+    }
     if (!rc) rc = multi_slabs(m);
     if (rc) { if (!own) m->comm = nullptr; multi_free(m); return rc; }     // (an owned communicator is destroyed by multi_free, ONCE)
     ctx->attached_multi = m;
@@ -339,10 +351,26 @@ int cd_multi_set_flags(cd_multi *m, int flags) { if (!m) return CD_ERR_ARG; m->f
 int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs, cd_multi_info *info)
 {
     if (!m) return CD_ERR_ARG;
-    if (!m->c) return CD_ERR_ORDER;                                           // the context was destroyed under this cd_multi
     RcclApi *r = rccl();
-    if (!r) return CD_ERR_RCCL;
+    if (!r) return CD_ERR_RCCL;                                               // (cannot happen: a cd_multi exists only where librccl was loaded)
+    if (!m->c) {
+        // The context was destroyed under this cd_multi (cd_destroy detaches it): this rank has nothing to step -- but its peers are in the step's collectives.  It
+        // joins them with an empty box, no queries and CD_ERR_ORDER in its status word; every rank reads it from the matrix and leaves the step before anything
+        // is sent (round-3 advisor: the bare return left the peers waiting in ncclAllGather).
+        const size_t RWo = (size_t)m->world + 1;
+        hipStream_t xs = m->xstream;
+        (void)hipMemsetAsync(m->d_myroot, 0, sizeof(double) * 6, xs);
+        (void)r->AllGather(m->d_myroot, m->d_roots, 6, ncclDouble, m->comm, xs);
+        (void)hipMemsetAsync(m->d_row, 0, sizeof(unsigned long long) * RWo, xs);
+        k_set_word<<<1, 1, 0, xs>>>(m->d_row + m->world, (unsigned long long)(uint32_t)(-CD_ERR_ORDER));
+        (void)r->AllGather(m->d_row, m->d_matrix, RWo, ncclUint64, m->comm, xs);
+        (void)hipStreamSynchronize(xs);
+        (void)hipGetLastError();
+        if (info) { std::memset(info, 0, sizeof *info); info->world = (uint32_t)m->world; info->failed_rank_plus1 = (uint32_t)m->rank + 1u; }
+        return CD_ERR_ORDER;
+    }
     cd_ctx *c = m->c;
+    sort_retry_tick(c);
     hipStream_t s = c->stream;
     const int W = m->world, me = m->rank;
     const size_t RW = (size_t)W + 1;                                          // a row of the matrix: W counts | the rank's status word
@@ -543,7 +571,7 @@ int cd_multi_step(cd_multi *m, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
         LATE_HIP(hipGetLastError());
         if (fast_path) std::memcpy(c->sort_flags, reinterpret_cast<const Report *>(t0.h_report)->sort_flags, sizeof c->sort_flags);
         const int js = judge_sort_flags(c);                                                // (escalates c->sort_mode when a run was too long for this form)
-        if (js == SORT_REDO && redo < 3) continue;
+        if (js == SORT_REDO && redo < SORT_REDO_MAX) continue;
         if (js != CD_OK) return late(js == SORT_REDO ? CD_ERR_SORT : js);
         break;
     }

@@ -16,6 +16,11 @@ constexpr int SORT_ITEMS   = 16;                       // keys per thread
 constexpr int SORT_TILE    = SORT_THREADS * SORT_ITEMS; // 4096 keys per workgroup
 constexpr int RADIX_BITS   = 8;
 constexpr int RADIX        = 1 << RADIX_BITS;
+// The sort's flag word (one word, or-ed by the kernels of a sort, read by the host with the step's report: mi355cd.hip judge_sort_flags) -- WHY this form of the
+// sort cannot finish, so that the host goes to the form that can instead of trying them one after the other:
+constexpr uint32_t SORTF_RUN = 1u;        // a run of equal global digits is too long for k_local_sort's windows -> the larger windows, then the half-key form (no windows)
+constexpr uint32_t SORTF_ABOVE = 2u;      // a key has bits above the shifted global digits (a centroid outside the Morton frame) -> the digits at key bits 48..63
+constexpr uint32_t SORTF_FIXUP = 4u;      // more than FIX_MAX keys share their high half: no form with a fix-up hop can finish -> all eight passes
 
 // In-place exclusive scan of `total` uint32 by ONE workgroup of 1024 threads (the unique-flag scan of the pair
 // post-processing, cd_post.h): each thread owns a contiguous chunk, wave shuffles + LDS for the chunk sums.
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(CF
     const uint32_t e0 = s_enc[0], e1 = s_enc[1];
     const bool found0 = p0 == 0 || e0 != 0xffffffffu, found1 = p1 >= n || e1 != 0xffffffffu;
     if (!found0 || !found1) {                            // a run longer than LOCAL_LIMIT: flag it, pass the nominal range through
-        if (tid == 0) atomicOr(overflow, 1u);
+        if (tid == 0) atomicOr(overflow, SORTF_RUN);
         for (uint32_t i = p0 + tid; i < p1; i += LOCAL_THREADS) { const uint32_t t = vals_in[i]; keys_out[i] = keys_in[i]; vals_out[i] = t; emit.store(i, t, emit.load(t)); }
         return;
     }
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(CF
                 const uint32_t low = lowk[it];
                 uint32_t pos;
                 // run too long: flag it (the host redoes the sort with 8 passes) but still emit a valid permutation and valid leaves
-                if (!fixup_position_lds(sitem, cnt, j, low, high[it], pos)) { atomicOr(overflow, 1u); pos = j; }
+                if (!fixup_position_lds(sitem, cnt, j, low, high[it], pos)) { atomicOr(overflow, SORTF_FIXUP); pos = j; }
                 keys_out[lo + pos] = ((uint64_t)high[it] << 32) | low; vals_out[lo + pos] = tv[it];
                 emit.store(lo + pos, tv[it], pl[u]);
             }

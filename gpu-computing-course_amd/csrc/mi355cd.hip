@@ -136,6 +136,10 @@ struct cd_ctx {
     bool poll_opt = true;
     unsigned long long report_seq = 0;      // last sequence number handed to a k_report
     uint32_t polled_steps = 0, poll_fallbacks = 0;
+    // why a polled wait ran into its 20 ms budget (two such fall-backs in 360 000 stressed steps went unexplained): at the time-out the stream was still BUSY (the step itself was
+    // late: queued behind other work, or the device stalled) / the stream had DRAINED and the word arrived with the synchronise (late in flight) / the word was not there even after the
+    // stream had drained (LOST: the one that would be a bug of the protocol); and the longest polled wait that did end in the word, in microseconds
+    uint32_t poll_fb_busy = 0, poll_fb_late_word = 0, poll_fb_lost = 0, poll_max_wait_us = 0;
     // CD_DBG_POLL_SCAN (tools/poll_stress.py, tests): the pair area the report kernel writes is filled with 0xff before every step and scanned the moment the
     // sequence word is seen -- a pair that is still 0xff then was overtaken by the word (poll_stale counts such steps: CD_DBG_GET_POLL_STALE; _FALLBACKS: the fall-backs to the stream)
     bool dbg_poll_check = false;
@@ -344,7 +348,6 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
     // Three forms of the same stable 64-bit sort (cd_sort.h): hybrid = 2 global passes on the top 16 bits + an in-LDS
     // sort of run-aligned windows + the fix-up hop; half-key = 4 global passes on the high 32 bits + the fix-up hop;
     // full = 8 global passes.  The keys start in the buffer that leaves the sorted data in buffer 0.
-    if (c->sort_mode == 1 && c->left_frame && ++c->steps_in_mode1 >= SORT_RETRY_STEPS) { c->sort_mode = 0; c->steps_in_mode1 = 0; c->local_small_ok = true; graph_drop(c); }   // (judge_sort_flags; the second form's runs are 16 x longer: the small windows get their chance again too)
     const int mode = c->sort_mode;
     const bool hybrid = mode <= 1;
     const int down = mode == 0 ? 4 : 0;         // mode 0: the two global digits are key bits 44..51 and 52..59 -- 16 bits that all vary,
@@ -686,10 +689,21 @@ int wait_report(cd_ctx *c, TravBuf &tb, unsigned long long seq)
         }
         if (*p == seq) {
             std::atomic_thread_fence(std::memory_order_acquire);
+            if ((c->polled_steps & 15u) == 0) {                               // (a clock read every 16th step: what the longest ordinary wait is)
+                const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+                if ((uint64_t)us > c->poll_max_wait_us) c->poll_max_wait_us = (uint32_t)us;
+            }
             if ((++c->polled_steps & 63u) == 0) HIPCHK(hipStreamSynchronize(c->stream));
             return 0;
         }
         ++c->poll_fallbacks;
+        const hipError_t q = hipStreamQuery(c->stream);                       // busy: the step is late; drained: the word is
+        (void)hipGetLastError();
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (q == hipErrorNotReady) ++c->poll_fb_busy;
+        else if (*p == seq) ++c->poll_fb_late_word;
+        else ++c->poll_fb_lost;
+        return 0;
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
@@ -1086,6 +1100,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     ALLOC(c->d_meta, sizeof(NodeMeta) * n);
     ALLOC(c->d_parent, sizeof(int32_t) * 2 * n);
     { uint32_t nb = cdiv(nt, REFIT_BLK); c->nbp2 = 1; while (c->nbp2 < nb) c->nbp2 <<= 1; }
+    if (c->nbp2 / (uint32_t)TOP_IN_BLOCK > (uint32_t)TOP_MAX_SPANS) { free_all(c); delete c; return CD_ERR_ARG; }   // k_top_publish_upper folds the span roots in LDS sized for 2^30 leaves (cd_build.h)
     ALLOC(c->d_seg, sizeof(double) * 6 * (size_t)c->nbp2 * REFIT_BLK);
     ALLOC(c->d_top_pub, top_pub_bytes(c));
     if (hipMemset(c->d_top_pub, 0, top_pub_bytes(c)) != hipSuccess) { free_all(c); delete c; return -(int)hipGetLastError(); }
@@ -1182,22 +1197,34 @@ int cd_get_morton_frame(cd_ctx *c, double offset[3], double span[3], uint64_t *l
 }
 
 // the onesweep look-back spins are bounded; a timeout sets one of the words d_os_ticket[8..15]
-constexpr int SORT_REDO = 77;                   // internal: a run was too long for this form of the sort, redo with the next one
+constexpr int SORT_REDO = 77;                   // internal: this form of the sort could not finish, redo with the one the flags ask for
+constexpr int SORT_REDO_MAX = 4;                // redos one call can need: small windows -> large windows -> half-key -> full is three (judge_sort_flags); one to spare
 namespace { int judge_sort_flags(cd_ctx *c)
 {
     for (int i = 0; i < 9; ++i) if (c->sort_flags[i]) c->scratch_clean = false;     // the flag words are cleared by the memset only
     for (int i = 0; i < 8; ++i) if (c->sort_flags[i]) return CD_ERR_SORT;
-    if (c->sort_flags[8]) {
-        const bool only_above = c->sort_flags[8] == 2u;                     // k_morton alone raised it: some key lies beyond the shifted digits (a centroid outside the Morton frame), no run was too long
-        if (!only_above && c->local_small_active && c->local_small_ok && c->sort_mode <= 1) { c->local_small_ok = false; return SORT_REDO; }   // a run too long for the small windows: the large form, same passes
-        if (c->sort_mode >= 3) return CD_ERR_SORT;
-        // A mesh that leaves the frame may come back: a context that went 0 -> 1 for THAT reason tries the first form again every SORT_RETRY_STEPS steps
-        // (enqueue_morton_sort; a try that fails costs one redone step in 64).  A run that was too long stays a reason for good.
-        if (c->sort_mode == 0) { c->left_frame = only_above; c->steps_in_mode1 = 0; }
-        ++c->sort_mode; return SORT_REDO;
+    const uint32_t f = c->sort_flags[8];
+    if (!f) return CD_OK;
+    // The flags say WHY (cd_sort.h): the next form is the one that can finish, not the next in line (round 5 walked 0 -> 1 -> 2 -> 3: a mesh with 17 coincident centroids
+    // took four redos, one more than the multi-GPU step allowed itself).
+    if (c->sort_mode >= 3) return CD_ERR_SORT;                              // (the full form raises nothing)
+    if (f & SORTF_FIXUP) { c->sort_mode = 3; c->left_frame = false; return SORT_REDO; }      // too many equal high halves: only the eight passes do without a fix-up hop
+    if (f & SORTF_RUN) {
+        // a run too long for the small windows: the large form, same passes -- unless keys also lie above the digits (then another form is due anyway)
+        if (!(f & SORTF_ABOVE) && c->local_small_active && c->local_small_ok && c->sort_mode <= 1) { c->local_small_ok = false; return SORT_REDO; }
+        c->sort_mode = 2; c->left_frame = false; return SORT_REDO;          // no windows: four global passes + fix-up (digits at bits 48..63 only make runs longer)
     }
-    return CD_OK;
+    // SORTF_ABOVE alone: some key lies beyond the shifted digits (a centroid outside the Morton frame), no run was too long.  A mesh that leaves the frame may come
+    // back: a context that went 0 -> 1 for THAT reason tries the first form again every SORT_RETRY_STEPS steps (sort_retry_tick; a try that fails costs one redone step in 64).
+    if (c->sort_mode == 0) { c->sort_mode = 1; c->left_frame = true; c->steps_in_mode1 = 0; return SORT_REDO; }
+    c->sort_mode = 2; c->left_frame = false; return SORT_REDO;
 } }
+// Once per CALL of a stepping entry point (not per redo), BEFORE a graph step computes its key: a context whose mesh had left the Morton frame (sort form 1) tries
+// the first form again every SORT_RETRY_STEPS steps.  (Round 5 counted inside enqueue_morton_sort, which a graph replay does not run: ADVICE r05.)
+static void sort_retry_tick(cd_ctx *c)
+{
+    if (c->sort_mode == 1 && c->left_frame && ++c->steps_in_mode1 >= SORT_RETRY_STEPS) { c->sort_mode = 0; c->steps_in_mode1 = 0; c->local_small_ok = true; graph_drop(c); }   // (the second form's runs are 16 x longer: the small windows get their chance again too)
+}
 static int check_sort_flags(cd_ctx *c)
 {
     HIPCHK(hipMemcpyAsync(c->sort_flags, c->d_os_ticket + 8, sizeof c->sort_flags, hipMemcpyDeviceToHost, c->stream));
@@ -1208,10 +1235,12 @@ static int check_sort_flags(cd_ctx *c)
 int cd_morton_sort(cd_ctx *c)
 {
     if (!c) return CD_ERR_ARG;
+    sort_retry_tick(c);
     int rc = enqueue_morton_sort(c);
     if (rc) return rc;
     rc = check_sort_flags(c);
-    for (int redo = 0; rc == SORT_REDO && redo < 4; ++redo) { if ((rc = enqueue_morton_sort(c))) return rc; rc = check_sort_flags(c); }
+    for (int redo = 0; rc == SORT_REDO && redo < SORT_REDO_MAX; ++redo) { if ((rc = enqueue_morton_sort(c))) return rc; rc = check_sort_flags(c); }
+    if (rc == SORT_REDO) rc = CD_ERR_SORT;
     if (rc) return rc;
     c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
     c->stats.ms_sort = elapsed(c, EV_MORTON1, EV_SORT1);
@@ -1290,9 +1319,15 @@ int cd_find_collisions(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t 
     return run_traversal(c, c->tb[0], nullptr, 0, pairs, cap_pairs, n_pairs);
 }
 
+static int build_tree_impl(cd_ctx *c, int redo);
 int cd_build_tree(cd_ctx *c)
 {
     if (!c) return CD_ERR_ARG;
+    sort_retry_tick(c);
+    return build_tree_impl(c, 0);
+}
+static int build_tree_impl(cd_ctx *c, int redo)
+{
     int rc;
     Prezeroed fused(c);                                                    // one memset for every counter of the pipeline
     rc = enqueue_morton_sort(c, !fused_build_next(c));
@@ -1302,7 +1337,7 @@ int cd_build_tree(cd_ctx *c)
     HIPCHK(hipMemcpyAsync(c->root_box_host, c->d_boxes, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     rc = judge_sort_flags(c);
-    if (rc == SORT_REDO) return cd_build_tree(c);                    // at most three times: sort_mode has been escalated
+    if (rc == SORT_REDO) return redo < SORT_REDO_MAX ? build_tree_impl(c, redo + 1) : CD_ERR_SORT;     // (the form has been changed: judge_sort_flags)
     if (rc) return rc;
     if (c->stage_events) {
         c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
@@ -1315,9 +1350,15 @@ int cd_build_tree(cd_ctx *c)
     return CD_OK;
 }
 
+static int self_collide_impl(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs, int redo);
 int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs)
 {
     if (!c || (cap_pairs && !pairs)) return CD_ERR_ARG;
+    sort_retry_tick(c);                                                    // (before a graph step computes its key)
+    return self_collide_impl(c, pairs, cap_pairs, n_pairs, 0);
+}
+static int self_collide_impl(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_pairs, int redo)
+{
     int rc;
     if (graph_eligible(c)) {                                               // CD_OPT_GRAPH: the steady-state step as one graph launch
         bool handled = false;
@@ -1331,7 +1372,7 @@ int cd_self_collide(cd_ctx *c, uint32_t *pairs, uint64_t cap_pairs, uint64_t *n_
     fused.done();
     if (rc < 0) return rc;
     { const int rs = judge_sort_flags(c);                                   // flags came back with the traversal counters
-      if (rs == SORT_REDO) return cd_self_collide(c, pairs, cap_pairs, n_pairs);   // at most three times: sort_mode has been escalated
+      if (rs == SORT_REDO) return redo < SORT_REDO_MAX ? self_collide_impl(c, pairs, cap_pairs, n_pairs, redo + 1) : CD_ERR_SORT;   // (the form has been changed: judge_sort_flags)
       if (rs) return rs; }
     if (c->stage_events) {
         c->stats.ms_morton = elapsed(c, EV_MORTON0, EV_MORTON1);
@@ -1672,6 +1713,8 @@ int cd_debug_option(cd_ctx *c, int key, int64_t value, int64_t *out)
     case CD_DBG_GET_POLL_STALE:     if (!out) return CD_ERR_ARG; *out = c->poll_stale; return CD_OK;
     case CD_DBG_GET_POLL_FALLBACKS: if (!out) return CD_ERR_ARG; *out = c->poll_fallbacks; return CD_OK;
     case CD_DBG_GET_POLLED_STEPS:   if (!out) return CD_ERR_ARG; *out = c->polled_steps; return CD_OK;
+    case CD_DBG_GET_POLL_FB_WHY:    if (!out) return CD_ERR_ARG; *out = (int64_t)c->poll_fb_busy | ((int64_t)c->poll_fb_late_word << 16) | ((int64_t)c->poll_fb_lost << 32); return CD_OK;
+    case CD_DBG_GET_POLL_MAX_WAIT_US: if (!out) return CD_ERR_ARG; *out = c->poll_max_wait_us; return CD_OK;
     case CD_DBG_GET_TREE_WAS_FUSED: if (!out) return CD_ERR_ARG; *out = c->last_tree_fused ? 1 : 0; return CD_OK;
     case CD_DBG_GET_SORT_FORM:   if (out) *out = c->sort_mode; return CD_OK;
     case CD_DBG_GET_ORDER_STATE: {          // the order hint as it stands: 0 none built, 1 a permutation of the groups that differs from the plain order, 2 the plain order itself, -1 NOT a permutation (a bug)

@@ -70,7 +70,9 @@ inline bool parse_float(const char *p, const char *e, float &out, const char *&q
         }
     }
     char *qq = nullptr;
-    out = std::strtof(p, &qq);                              // correctly rounded, as %f (the buffer ends in white space + NUL: it stops inside the line or at its end)
+    out = std::strtof(p, &qq);                              // correctly rounded, as %f.  p is at the field's first character (never white space), so strtof stops at the first character that is
+                                                            // not part of a number -- at the latest the line's '\n': every line of the buffer ENDS in one (a mapped file because it ends in '\n', else the
+                                                            // copy with one appended + NUL), so it never reads past the line, let alone the mapping
     if (qq == p) return false;
     q = qq;
     return true;
@@ -92,6 +94,7 @@ inline bool parse_v(const char *p, const char *e, float out[3])
 inline bool parse_int(const char *p, const char *e, long &v, const char *&q)
 {
     const char *s = p; bool neg = false;
+    while (s < e && (*s == ' ' || *s == '\t' || *s == '\r')) ++s;    // %d / strtol skip white space in front of the number ("f 1/ 2 3/ 4 5/ 6" is six integers to sscanf): inside the line only
     if (s < e && (*s == '-' || *s == '+')) { neg = *s == '-'; ++s; }
     if (s >= e || *s < '0' || *s > '9') return false;
     unsigned long long w = 0;

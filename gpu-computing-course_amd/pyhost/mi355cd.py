@@ -25,6 +25,7 @@ CD_DBG_LDS_PAD, CD_DBG_EXACT_BLOCKS, CD_DBG_NO_SHARED_PATH, CD_DBG_DIAG, CD_DBG_
 CD_DBG_SORT_WINDOWS, CD_DBG_GET_SORT_FORM = 7, 8
 CD_DBG_POLL_SCAN, CD_DBG_GET_POLL_STALE, CD_DBG_GET_POLL_FALLBACKS, CD_DBG_GET_POLLED_STEPS, CD_DBG_GET_TREE_WAS_FUSED = 10, 11, 12, 13, 14
 CD_DBG_GET_ORDER_STATE = 15
+CD_DBG_GET_POLL_FB_WHY, CD_DBG_GET_POLL_MAX_WAIT_US = 16, 17
 CD_DBG_REPORT_COPIES = 6
 CD_DBG_STORE_QBOX = 9
 

@@ -10,6 +10,10 @@ and must be agreed at creation).  INJECT: that rank sets CD_MULTI_INJECT_FAILURE
 error from that step (the rank itself CD_ERR_INJECTED, the others CD_ERR_PEER), none may block, and the following steps must be
 right again.  With ":alloc" the rank sets CD_MULTI_INJECT_ALLOC_FAILURE instead: its next allocation of the send / receive slabs
 fails -- give a QCAP small enough that the step has to grow them -- the rank returns the allocation's error, the others CD_ERR_PEER.
+INJECT "R:create": rank R's cd_multi_create meets an allocation failure (the flag at creation) -- it still joins creation's agreement on the capacities, with 0:
+every rank's creation returns (R the allocation's error, the others CD_ERR_PEER), nobody waits in the all-gather.  INJECT "R:S:orphan": before step S rank R's
+context is destroyed under its cd_multi; its cd_multi_step joins the step's collectives with an empty box and CD_ERR_ORDER in its status word: R returns
+CD_ERR_ORDER, the others CD_ERR_PEER, nobody blocks (give STEPS = S + 1: the orphan stays one).
 Checks, and exits non-zero on failure: union of all ranks' pairs == oracle on the merged mesh, no duplicates, summed
 pairs_tested == the single tree's, sent/received totals consistent across ranks, peers as the root boxes say."""
 import json
@@ -36,8 +40,10 @@ def main():
     quads_of = [int(q) for q in sys.argv[1].split(",")]
     quads_of = quads_of * W if len(quads_of) == 1 else quads_of
     inj = sys.argv[5].split(":") if len(sys.argv) > 5 else None
-    inject = (int(inj[0]), int(inj[1])) if inj else None
+    inject_create = int(inj[0]) if inj and inj[1] == "create" else None
+    inject = (int(inj[0]), int(inj[1])) if inj and inject_create is None else None
     inject_alloc = bool(inj) and len(inj) > 2 and inj[2] == "alloc"
+    orphan = bool(inj) and len(inj) > 2 and inj[2] == "orphan"
     width = 2.88
     shards, vbase, tbase = [], 0, 0
     for r in range(W):
@@ -57,12 +63,23 @@ def main():
     assert uid[8:16] == b"loopback", "libmi355cd.so did not load the loopback library"
     results, errors = [None] * W, [None] * W
 
+    create_rcs = [0] * W
+
     def rank_main(r):
         try:
-            with mi355cd.MultiStep(cds[r], uid, r, W, query_cap_per_peer=qcap, flags=mi355cd.CD_MULTI_TIMING) as ms:
+            try:
+                ms_ = mi355cd.MultiStep(cds[r], uid, r, W, query_cap_per_peer=qcap,
+                                        flags=mi355cd.CD_MULTI_TIMING | (mi355cd.CD_MULTI_INJECT_ALLOC_FAILURE if inject_create == r else 0))
+            except mi355cd.CdError as e:
+                create_rcs[r] = e.rc
+                results[r] = []
+                return
+            with ms_ as ms:
                 out = []
                 for it in range(steps):
-                    if inject and inject == (r, it):
+                    if inject and inject == (r, it) and orphan:
+                        cds[r].close()                      # cd_destroy under the cd_multi: the step below must still join its peers' collectives
+                    elif inject and inject == (r, it):
                         ms.set_flags(mi355cd.CD_MULTI_TIMING | (mi355cd.CD_MULTI_INJECT_ALLOC_FAILURE if inject_alloc else mi355cd.CD_MULTI_INJECT_FAILURE))
                     try:
                         pairs, n, rc, info = ms.step(cap=1 << 21)
@@ -83,6 +100,24 @@ def main():
         print(json.dumps({"ok": False, "hung": hung, "errors": errors}))
         os._exit(2)
 
+    if inject_create is not None:
+        want = [-2 if r == inject_create else mi355cd.CD_ERR_PEER for r in range(W)]          # -2: -hipErrorOutOfMemory
+        ok = create_rcs == want
+        print(json.dumps({"ok": ok, "create_rcs": create_rcs, "want": want}))
+        for cd in cds:
+            cd.close()
+        sys.exit(0 if ok else 1)
+    if orphan:
+        it = inject[1]
+        rcs = [results[r][it][2] for r in range(W)]
+        want = [mi355cd.CD_ERR_ORDER if r == inject[0] else mi355cd.CD_ERR_PEER for r in range(W)]
+        before_ok = all(results[r][k][2] == 0 for r in range(W) for k in range(it))
+        ok = rcs == want and before_ok
+        print(json.dumps({"ok": ok, "orphan_step_rcs": rcs, "want": want, "steps_before_ok": before_ok}))
+        for r, cd in enumerate(cds):
+            if r != inject[0]:
+                cd.close()
+        sys.exit(0 if ok else 1)
     roots = [cd.root_box() for cd in cds]
     want_peers = [sum(1 for s in range(W) if s != r and multi.boxes_overlap(roots[r], roots[s])) for r in range(W)]
     verts = np.concatenate([s[0] for s in shards]); vidx = np.concatenate([s[1] + np.uint32(s[3]) for s in shards])

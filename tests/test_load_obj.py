@@ -26,13 +26,14 @@ def test_generated_obj_round_trip(tmp_path):
 def test_float_parsing_matches_percent_f(tmp_path):
     """`%f` reads a float: 0.1 must become float32(0.1) widened, not the double 0.1 (load_obj.h:38,50-52)."""
     lines = ["# comment", "vt 0.5 0.5", "v 0.1 -0.2 3.0000001", "v 1e-3 2.5E2 -7", "v   4   5\t6  ", "vn 0 0 1",
-             "f 1/1 2/2 3/3", "g group", "f 3/9 2/8 1/7"]
+             "f 1/1 2/2 3/3", "g group", "f 3/9 2/8 1/7",
+             "f 1/ 2 3/ 4 2/\t6"]                 # white space after the slash: six integers to sscanf "%d/%d" (load_obj.h:68), as to strtol (ADVICE r05)
     p = tmp_path / "a.obj"
     p.write_text("\n".join(lines))                                           # no trailing newline on purpose
     v, f = mi355cd.load_obj(str(p), 1)
     want = np.array([[0.1, -0.2, 3.0000001], [1e-3, 2.5e2, -7], [4, 5, 6]], dtype=np.float32).astype(np.float64)
     assert np.array_equal(v, want)
-    assert f.tolist() == [[0, 1, 2], [2, 1, 0]]
+    assert f.tolist() == [[0, 1, 2], [2, 1, 0], [0, 2, 1]]
 
 
 def _round_to_float32(text):

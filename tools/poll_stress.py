@@ -38,8 +38,10 @@ for name, (verts, vidx) in cases:
             n, rc = cd.self_collide_into(buf)
             if rc != 0 or n != n0 or not np.array_equal(oracle.pair_set(buf[:n]), want): mism += 1
         stale = cd.debug_get(mi355cd.CD_DBG_GET_POLL_STALE); fb = cd.debug_get(mi355cd.CD_DBG_GET_POLL_FALLBACKS)
-        print(f"{name}: {n0} pairs, {steps} polled steps: pair-set mismatches {mism}, steps with a pair not yet in host memory {stale}, fallbacks to the stream {fb}", flush=True)
-        bad += mism + stale
+        why = cd.debug_get(mi355cd.CD_DBG_GET_POLL_FB_WHY); busy, late_word, lost = why & 0xffff, (why >> 16) & 0xffff, (why >> 32) & 0xffff
+        print(f"{name}: {n0} pairs, {steps} polled steps: pair-set mismatches {mism}, steps with a pair not yet in host memory {stale}, fallbacks to the stream {fb} "
+              f"(stream still busy at the 20 ms time-out {busy}, word late in flight {late_word}, word LOST {lost}), longest ordinary polled wait {cd.debug_get(mi355cd.CD_DBG_GET_POLL_MAX_WAIT_US)} us", flush=True)
+        bad += mism + stale + lost
 stop = True
 if load: th.join()
 print("BAD" if bad else "clean")
