@@ -291,38 +291,39 @@ __global__ __launch_bounds__(256) void k_centroid_bounds(const double *__restric
 template <int T>
 __device__ __forceinline__ void fold_frame(const double *__restrict__ partial, uint32_t nblocks, bool with_box, double (*smw)[BOUNDS_STRIDE], double *sf /* [8] shared */, double *sbox /* [6] shared, or nullptr */)
 {
+    // A WAVE per value (k = 0 .. 17: which of the 18 rows of `partial`), the kind of fold uniform in the wave: a lane folds every 64th block of the row, then ONE wave
+    // reduction.  (Round 6's first form -- every thread all 18 values, 18 wave reductions interleaved -- took 127 VGPRs with spills inside k_morton, whose own loop needs 47.)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int sets = with_box ? 2 : 1;
-    for (int q = 0; q < sets; ++q) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (uint32_t b = threadIdx.x; b < nblocks; b += T) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double l = partial[(6 * q + a) * nblocks + b], h = partial[(6 * q + 3 + a) * nblocks + b];
-                lo[a] = l < lo[a] ? l : lo[a]; hi[a] = h > hi[a] ? h : hi[a];
-            }
+#pragma unroll 1
+    for (int k = w; k < BOUNDS_STRIDE; k += T / 64) {                         // (k is wave-uniform)
+        if (!with_box && k >= 6 && k < BOUNDS_STAT) continue;
+        const double *row = partial + (size_t)k * nblocks;
+        if (k >= BOUNDS_STAT) {
+            long long v = 0;
+#pragma unroll 1
+            for (uint32_t b = lane; b < nblocks; b += 64) v += __double_as_longlong(row[b]);
+            v = wave_sum_ll(v);
+            if (lane == 0) smw[0][k] = __longlong_as_double(v);
+        } else if ((k % 6) < 3) {
+            double v = 1e300;
+#pragma unroll 1
+            for (uint32_t b = lane; b < nblocks; b += 64) { const double t = row[b]; v = t < v ? t : v; }
+            v = wave_min(v);
+            if (lane == 0) smw[0][k] = v;
+        } else {
+            double v = -1e300;
+#pragma unroll 1
+            for (uint32_t b = lane; b < nblocks; b += 64) { const double t = row[b]; v = t > v ? t : v; }
+            v = wave_max(v);
+            if (lane == 0) smw[0][k] = v;
         }
-        for (int a = 0; a < 3; ++a) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); }
-        if (lane == 0) for (int a = 0; a < 3; ++a) { smw[w][6 * q + a] = lo[a]; smw[w][6 * q + 3 + a] = hi[a]; }
-    }
-    {
-        long long st[6] = {0, 0, 0, 0, 0, 0};
-        for (uint32_t b = threadIdx.x; b < nblocks; b += T) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) st[k] += __double_as_longlong(partial[(BOUNDS_STAT + k) * nblocks + b]);
-        }
-        for (int k = 0; k < 6; ++k) { const long long v = wave_sum_ll(st[k]); if (lane == 0) smw[w][BOUNDS_STAT + k] = __longlong_as_double(v); }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         double lo[3], hi[3]; long long sum[3], cnt[3];
         for (int a = 0; a < 3; ++a) {
-            double l = smw[0][a], h = smw[0][3 + a]; long long s = 0, c = 0;
-            for (int ww = 0; ww < T / 64; ++ww) {
-                const double l2 = smw[ww][a], h2 = smw[ww][3 + a]; l = l2 < l ? l2 : l; h = h2 > h ? h2 : h;
-                s += __double_as_longlong(smw[ww][BOUNDS_STAT + a]); c += __double_as_longlong(smw[ww][BOUNDS_STAT + 3 + a]);
-            }
-            lo[a] = l; hi[a] = h; sum[a] = s; cnt[a] = c;
+            const double l = smw[0][a], h = smw[0][3 + a];
+            lo[a] = l; hi[a] = h; sum[a] = __double_as_longlong(smw[0][BOUNDS_STAT + a]); cnt[a] = __double_as_longlong(smw[0][BOUNDS_STAT + 3 + a]);
             double span = (h - l) * (1.0 + 1.0 / 1048576.0);                  // widened by 2^-20 relative: the max maps below the last cell's end
             if (!(span > 0.0)) span = 1.0;
             sf[a] = l; sf[3 + a] = span;
@@ -331,9 +332,7 @@ __device__ __forceinline__ void fold_frame(const double *__restrict__ partial, u
         sf[7] = 0.0;
     } else if (with_box && threadIdx.x >= 64 && threadIdx.x < 64 + 3) {
         const int a = (int)threadIdx.x - 64;
-        double l = smw[0][6 + a], h = smw[0][9 + a];
-        for (int ww = 1; ww < T / 64; ++ww) { const double l2 = smw[ww][6 + a], h2 = smw[ww][9 + a]; l = l2 < l ? l2 : l; h = h2 > h ? h2 : h; }
-        sbox[2 * a] = l; sbox[2 * a + 1] = h;
+        sbox[2 * a] = smw[0][6 + a]; sbox[2 * a + 1] = smw[0][9 + a];
     }
     __syncthreads();
 }
@@ -355,6 +354,10 @@ __global__ __launch_bounds__(256) void k_frame_from_bounds(const double *__restr
 // ---------------------------------------------------------------- Morton keys (load_obj.h:89-101, morton.h:70-89)
 // Grid-stride; the workgroup also accumulates the radix sort's digit histograms (cd_sort.h) of the keys it writes.
 constexpr int MORTON_THREADS = 1024;                  // one sort tile (SORT_TILE = 4096 keys) per workgroup pass: 4 keys per thread
+// LAYOUT: the frame may carry a key layout (cd_math.h: the adaptive frame -- always so in CD_FRAME_AUTO, where the layout is formed on the device); false: the reference's interleave
+// only (CD_FRAME_REFERENCE, CD_FRAME_CUSTOM without a layout: the host knows).  Two instances so that the reference's path keeps its registers: with both paths in one body the kernel
+// took 91 VGPRs instead of 48 -- one 1024-thread workgroup a CU instead of two, 13.5 -> 16.2 us at 1 M keys.
+template <bool LAYOUT>
 __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restrict__ verts, const uint32_t *__restrict__ vidx, uint32_t n,
                                                            const double *__restrict__ frame /* off[3], span[3], layout word, 0 (FRAME_WORDS) */,
                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ ghist /* [HIST_COPIES][8][256] */, int first_digit,
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restr
     // Auto frame: EVERY workgroup folds the per-block bounds itself (min / max are exact and order-independent, the statistic is integer:
     // the same frame in all of them) -- 72 KB of L2 reads and a microsecond, against a one-workgroup kernel of its own in front of
     // this one (k_frame_from_bounds: ~6 us + a launch gap).  Workgroup 0 stores the frame (and the vertex box) for the others.
-    if (partial) {                                                              // (uniform)
+    if (LAYOUT && partial) {                                                    // (uniform; the host launches the LAYOUT instance for an auto frame)
         fold_frame<MORTON_THREADS>(partial, nparts, box_out != nullptr, smw, sframe, sbox);
         if (blockIdx.x == 0) {
             if (frame_out && threadIdx.x < FRAME_WORDS) frame_out[threadIdx.x] = sframe[threadIdx.x];
@@ -381,9 +384,12 @@ __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restr
     }
     __syncthreads();
     // the key layout of the frame (cd_math.h): 0 = the reference's interleave (morton.h:70-89, bit-identical), else the adaptive one
-    const unsigned long long layout = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(uint32_t)__double_as_longlong(frame[6])) |
-                                      ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(__double_as_longlong(frame[6]) >> 32)) << 32);
-    const KeyLayout kl = key_layout(layout, frame, frame + 3);
+    unsigned long long layout = 0ull;
+    KeyLayout kl = {};
+    if constexpr (LAYOUT) {
+        layout = (unsigned long long)__double_as_longlong(uniform_f64(frame[6]));
+        kl = key_layout(layout, frame, frame + 3);
+    }
     uint64_t above = 0;
     // a workgroup takes whole sort tiles (SORT_TILE consecutive keys): beside the digit histograms of ALL keys it leaves, per tile,
     // the counts of the first global digit -- with those the sort's first pass needs no rendezvous between its tiles
@@ -394,8 +400,12 @@ __global__ __launch_bounds__(MORTON_THREADS) void k_morton(const double *__restr
         for (int it = 0; it < SORT_TILE / MORTON_THREADS; ++it) {
             const uint32_t t = tile * SORT_TILE + it * MORTON_THREADS + threadIdx.x;
             if (t < n) {
-                const d3 c = centroid_of(verts, vidx, t);
-                const uint64_t k = layout ? morton3d_layout(c.x, c.y, c.z, kl) : morton3d(c.x, c.y, c.z, frame, frame + 3);
+                uint64_t k;
+                if constexpr (LAYOUT) {                                   // (the host launches this instance only for a frame WITH a layout: an auto frame, or cd_set_morton_frame_layout's)
+                    const uint32_t ia = vidx[3 * (size_t)t], ib = vidx[3 * (size_t)t + 1], ic = vidx[3 * (size_t)t + 2];
+                    const d3 p1 = load_vertex(verts, ia), p2 = load_vertex(verts, ib), p3 = load_vertex(verts, ic);
+                    k = morton3d_layout(p1.x + p2.x + p3.x, p1.y + p2.y + p3.y, p1.z + p2.z + p3.z, kl);      // the vertex sum: no division per key (cd_math.h)
+                } else { const d3 c = centroid_of(verts, vidx, t); k = morton3d(c.x, c.y, c.z, frame, frame + 3); }
                 keys[t] = k;
                 hist_add(h, k, first_digit, down);
                 above |= k;

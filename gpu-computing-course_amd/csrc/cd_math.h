@@ -174,24 +174,30 @@ __device__ __forceinline__ long long flog2_fixed(double x)
     const unsigned long long u = (unsigned long long)__double_as_longlong(x);
     return (((long long)((u >> 52) & 0x7ffull) - 1023) << 8) + (long long)((u >> 44) & 0xffull);
 }
+// (written on scalars, no arrays: with E[ord[j]] indexed at run time this function alone took > 100 VGPRs and put k_morton at 127 with spills)
+__device__ __forceinline__ long long layout_mean(long long sum, long long cnt, long long none)
+{
+    // floor of the mean, by ONE IEEE division of two exactly represented integers (|sum| < 2^53): the same on every machine, and a tenth of the instructions of a 64-bit integer division
+    return cnt > 0 ? (long long)floor((double)sum / (double)cnt) : none;
+}
 __device__ inline unsigned long long frame_layout(const double lo[3], const double hi[3], const long long sum[3], const long long cnt[3])
 {
     const long long NONE = -(1ll << 40), CAPF = (long long)LAYOUT_CAP << 8;
-    long long E[3], Lm[3], Lref = NONE; int ord[3] = {0, 1, 2};
-    for (int a = 0; a < 3; ++a) {
-        Lm[a] = NONE;
-        if (cnt[a] > 0) { Lm[a] = sum[a] >= 0 ? sum[a] / cnt[a] : -((-sum[a] + cnt[a] - 1) / cnt[a]); if (Lm[a] > Lref) Lref = Lm[a]; }   // floor
-    }
-    for (int a = 0; a < 3; ++a) {
-        const double e = hi[a] - lo[a];
-        if (!(e > FLOG_MIN)) { E[a] = NONE; continue; }
+    const long long L0 = layout_mean(sum[0], cnt[0], NONE), L1 = layout_mean(sum[1], cnt[1], NONE), L2 = layout_mean(sum[2], cnt[2], NONE);
+    long long Lref = L0 > L1 ? L0 : L1; Lref = L2 > Lref ? L2 : Lref;
+    auto weight = [&](double e, long long Lm) -> long long {
+        if (!(e > FLOG_MIN)) return NONE;
         long long d = CAPF;
-        if (Lm[a] != NONE) { d = Lref - Lm[a]; if (d > CAPF) d = CAPF; }
+        if (Lm != NONE) { d = Lref - Lm; if (d > CAPF) d = CAPF; }
         if (Lref == NONE) d = 0;                                              // every box flat on every axis: points
-        E[a] = flog2_fixed(e) + d;
-    }
-    for (int i = 1; i < 3; ++i) for (int j = i; j > 0 && E[ord[j]] > E[ord[j - 1]]; --j) { const int t = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = t; }   // stable, descending
-    const long long EA = E[ord[0]], EB = E[ord[1]], EC = E[ord[2]];
+        return flog2_fixed(e) + d;
+    };
+    long long EA = weight(hi[0] - lo[0], L0), EB = weight(hi[1] - lo[1], L1), EC = weight(hi[2] - lo[2], L2);
+    int A = 0, B = 1, C = 2;
+    // stable, descending (an insertion sort of three: swap only on a strict '>', so ties keep the lower axis first)
+    if (EB > EA) { const long long t = EA; EA = EB; EB = t; const int u = A; A = B; B = u; }
+    if (EC > EB) { const long long t = EB; EB = EC; EC = t; const int u = B; B = C; C = u; }
+    if (EB > EA) { const long long t = EA; EA = EB; EB = t; const int u = A; A = B; B = u; }
     long long nA = EA == NONE ? 0 : (EB == NONE ? 60 : (EA - EB + 128) >> 8);
     if (nA > 60) nA = 60;
     long long rem = 60 - nA;
@@ -201,7 +207,7 @@ __device__ inline unsigned long long frame_layout(const double lo[3], const doub
     const long long nABC = rem / 3, left = rem % 3;
     if (left == 1) ++nA;
     if (left == 2) ++nAB;
-    return LAYOUT_VALID | (unsigned long long)ord[0] | ((unsigned long long)ord[1] << 2) | ((unsigned long long)ord[2] << 4) |
+    return LAYOUT_VALID | (unsigned long long)A | ((unsigned long long)B << 2) | ((unsigned long long)C << 4) |
            ((unsigned long long)nA << 8) | ((unsigned long long)nAB << 16) | ((unsigned long long)nABC << 24);
 }
 // is `w` a layout word morton3d_layout can take?  (0: the reference's interleave)
@@ -224,26 +230,40 @@ __device__ __forceinline__ uint64_t expand2(uint64_t v)
     return v;
 }
 // A layout word decoded once (wave-uniform: scalar registers) for a loop over keys.
+// The cell of a triangle along axis a, in a frame WITH a layout, is   floor(((p1 + p2 + p3) - 3 off) * (2^bits / (3 span)))   clamped to [0, 2^bits - 1]:
+// the vertex SUM against thrice the offset, times one factor per axis formed once per frame -- no division per key.  (morton.h's ((c - off) / span) * 2^20 on the
+// centroid c = (p1 + p2 + p3) / 3 is six FP64 divisions a key, ~90 of the ~150 vector instructions k_morton<false> spends on one: they stay where the reference's
+// bits are the contract, CD_FRAME_REFERENCE / CD_FRAME_CUSTOM.  Here the contract is this library's own -- the oracle restates it -- and the clamp makes it safe
+// against the last cell's end whatever the rounding.)
 struct KeyLayout {
     int A, B, C, t, p, nA;                              // t triples, p pairs, nA leading bits
-    double offA, offB, offC, spanA, spanB, spanC, scA, scB, scC;
+    double off3A, off3B, off3C, kA, kB, kC;             // 3 off, 2^bits / (3 span)
     uint64_t topA, topB, topC;
 };
+// (a wave-uniform double into scalar registers: the compiler cannot see that a value read from LDS or through a pointer is uniform)
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ KeyLayout key_layout(unsigned long long w, const double *off, const double *span)
 {
     KeyLayout k;
     k.A = (int)(w & 3); k.B = (int)((w >> 2) & 3); k.C = (int)((w >> 4) & 3);
     k.nA = (int)((w >> 8) & 255); k.p = (int)((w >> 16) & 255); k.t = (int)((w >> 24) & 255);
     const int bA = k.nA + k.p + k.t, bB = k.p + k.t, bC = k.t;
-    k.offA = off[k.A]; k.offB = off[k.B]; k.offC = off[k.C]; k.spanA = span[k.A]; k.spanB = span[k.B]; k.spanC = span[k.C];
-    k.scA = __longlong_as_double((long long)(1023 + bA) << 52); k.scB = __longlong_as_double((long long)(1023 + bB) << 52); k.scC = __longlong_as_double((long long)(1023 + bC) << 52);   // 2^bits
+    auto two_to = [](int b) { return __longlong_as_double((long long)(1023 + b) << 52); };                // 2^b, exact
+    k.off3A = uniform_f64(3.0 * off[k.A]); k.off3B = uniform_f64(3.0 * off[k.B]); k.off3C = uniform_f64(3.0 * off[k.C]);
+    k.kA = uniform_f64(two_to(bA) / (3.0 * span[k.A])); k.kB = uniform_f64(two_to(bB) / (3.0 * span[k.B])); k.kC = uniform_f64(two_to(bC) / (3.0 * span[k.C]));
     k.topA = (1ull << bA) - 1; k.topB = (1ull << bB) - 1; k.topC = (1ull << bC) - 1;
     return k;
 }
-__device__ __forceinline__ uint64_t morton3d_layout(double x, double y, double z, const KeyLayout &k)
+// sx, sy, sz: the SUM of the triangle's three vertices per axis, p1 + p2 + p3 in that order (load_obj.h:90's numerator)
+__device__ __forceinline__ uint64_t morton3d_layout(double sx, double sy, double sz, const KeyLayout &k)
 {
-    const double cA = k.A == 0 ? x : (k.A == 1 ? y : z), cB = k.B == 0 ? x : (k.B == 1 ? y : z), cC = k.C == 0 ? x : (k.C == 1 ? y : z);
-    uint64_t ia = d2u64(((cA - k.offA) / k.spanA) * k.scA), ib = d2u64(((cB - k.offB) / k.spanB) * k.scB), ic = d2u64(((cC - k.offC) / k.spanC) * k.scC);
+    const double cA = k.A == 0 ? sx : (k.A == 1 ? sy : sz), cB = k.B == 0 ? sx : (k.B == 1 ? sy : sz), cC = k.C == 0 ? sx : (k.C == 1 ? sy : sz);
+    uint64_t ia = d2u64((cA - k.off3A) * k.kA), ib = d2u64((cB - k.off3B) * k.kB), ic = d2u64((cC - k.off3C) * k.kC);
     ia = ia > k.topA ? k.topA : ia; ib = ib > k.topB ? k.topB : ib; ic = ic > k.topC ? k.topC : ic;   // a centroid beyond the frame takes the last cell: the key stays below 2^60
     const uint64_t mt = (1ull << k.t) - 1, mp = (1ull << k.p) - 1;
     const uint64_t triples = (expand64(ia & mt) << 2) | (expand64(ib & mt) << 1) | expand64(ic & mt);

@@ -856,11 +856,13 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
     // and the search for a chunk's shard were two.  Every wave reads the 64 counts itself (one load instruction): no LDS, no barrier in front of the first fetch.
     const uint32_t my_shard = blockIdx.x & (NSHARD - 1), my_slot = blockIdx.x / NSHARD, slots = gridDim.x / NSHARD;   // (the host launches a multiple of NSHARD workgroups)
     const Candidates *my_cand = cand + (size_t)my_shard * shard_cap;
-    Candidates c_first[EXACT_ITEMS];
+    // (as two arrays of words, not an array of structs: round 5's Candidates c_first[] stayed in scratch memory -- 48 bytes a lane and four stores that waited for the loads)
+    uint32_t cfq[EXACT_ITEMS], cfl[EXACT_ITEMS];
 #pragma unroll
     for (int j = 0; j < EXACT_ITEMS; ++j) {
         const unsigned long long k = ((unsigned long long)j * slots + my_slot) * EXACT_THREADS + tid;
-        c_first[j] = my_cand[k < shard_cap ? k : 0];
+        const uint2 w = reinterpret_cast<const uint2 *>(my_cand)[k < shard_cap ? k : 0];
+        cfq[j] = w.x; cfl[j] = w.y;
     }
     unsigned long long total;                                   // this shard's candidates
     {
@@ -912,7 +914,8 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
         for (int j = 0; j < EXACT_ITEMS; ++j) {
             const unsigned long long k = (c0 + (unsigned long long)j * slots) * EXACT_THREADS + tid;
             ok[j] = k < total;
-            c[j] = c0 == my_slot ? c_first[j] : my_cand[ok[j] ? k : 0];      // (the first round's were requested with the counts)
+            if (c0 == my_slot) c[j] = Candidates{cfq[j], cfl[j]};            // (the first round's were requested with the counts; workgroup-uniform branch)
+            else c[j] = my_cand[ok[j] ? k : 0];
             if (!ok[j]) c[j] = Candidates{0, 0};
         }
         LeafTri lt[EXACT_ITEMS]; Box lb[EXACT_ITEMS], qbox[EXACT_ITEMS]; bool certain[EXACT_ITEMS], filtered[EXACT_ITEMS]; uint32_t q_id[EXACT_ITEMS], qa[EXACT_ITEMS], qb[EXACT_ITEMS], qc[EXACT_ITEMS];

@@ -355,8 +355,15 @@ int enqueue_morton_sort(cd_ctx *c, bool links_too = true, bool frame_ready = fal
     const int first_digit = hybrid ? 6 : (mode == 2 ? 4 : 0);
     int cur = mode == 3 ? 0 : 1;
     const uint32_t mblocks = c->ntiles < 2048u ? c->ntiles : 2048u;         // a workgroup per sort tile (4096 keys)
-    k_morton<<<mblocks, MORTON_THREADS, 0, s>>>(c->d_verts, c->d_vidx, n, auto_frame ? nullptr : c->d_frame /* (auto: the kernel folds the partial bounds itself and WRITES d_frame) */, c->d_keys[cur], c->d_os_hist, first_digit, down, c->d_os_ticket + 16,
-                                                auto_frame ? c->d_partial : nullptr, (uint32_t)BOUNDS_BLOCKS, c->d_frame, nullptr, c->d_counts);
+    unsigned long long host_layout = 0ull; std::memcpy(&host_layout, &c->frame_host[6], sizeof host_layout);
+    const double *mframe = auto_frame ? nullptr : c->d_frame;               // (auto: the kernel folds the partial bounds itself and WRITES d_frame)
+    const double *mpart = auto_frame ? c->d_partial : nullptr;
+    if (auto_frame || host_layout != 0ull)
+        k_morton<true><<<mblocks, MORTON_THREADS, 0, s>>>(c->d_verts, c->d_vidx, n, mframe, c->d_keys[cur], c->d_os_hist, first_digit, down, c->d_os_ticket + 16,
+                                                          mpart, (uint32_t)BOUNDS_BLOCKS, c->d_frame, nullptr, c->d_counts);
+    else
+        k_morton<false><<<mblocks, MORTON_THREADS, 0, s>>>(c->d_verts, c->d_vidx, n, mframe, c->d_keys[cur], c->d_os_hist, first_digit, down, c->d_os_ticket + 16,
+                                                           mpart, (uint32_t)BOUNDS_BLOCKS, c->d_frame, nullptr, c->d_counts);
     HIPCHK(evrec(c, EV_MORTON1));
     // onesweep: one pass over the data per digit; the digit histograms came with the keys
     // (more than 512 tiles: the first pass adds up chunk totals of the per-tile counts instead of every earlier tile's row -- cd_sort.h)
@@ -1586,7 +1593,8 @@ int cd_morton3d_points(const double *xyz, uint64_t n, const double offset[3], co
     if (offset) for (int a = 0; a < 3; ++a) { frame[a] = offset[a]; frame[3 + a] = span[a]; }
     return morton_batch(xyz, sizeof(double) * 3 * n, n, frame, keys);
 }
-// the same in a frame with a key layout (cd_math.h morton3d_layout: what k_morton computes in such a frame); layout 0 = cd_morton3d_points
+// the same in a frame with a key layout (cd_math.h morton3d_layout: what k_morton computes in such a frame -- xyz is then the SUM of a triangle's three vertices
+// per axis, not the centroid: cd_math.h, KeyLayout); layout 0 = cd_morton3d_points
 int cd_morton3d_points_layout(const double *xyz, uint64_t n, const double offset[3], const double span[3], uint64_t layout, uint64_t *keys)
 {
     if (!xyz || !keys || !offset || !span || !layout_ok(layout)) return CD_ERR_ARG;

@@ -105,7 +105,8 @@ int cd_update_vertices(cd_ctx *ctx, const double *verts_xyz);
  * long mesh normalised per axis with the fixed interleave gets cells of 400 : 1 and a poor tree).  The pair set does not
  * depend on the keys (any correct BVH gives the reference's set); the tree's cost does.  A layout is one 64-bit word:
  * bit 63 set | A | B << 2 | C << 4 | nA << 8 | nAB << 16 | nABC << 24 -- axes A, B, C (0 = x, 1 = y, 2 = z, by decreasing
- * weight); the key is, from its top bit down, nA bits of A's cell index, nAB pairs (A, B), nABC triples (A, B, C);
+ * weight); the key is, from its top bit down, nA bits of A's cell index, nAB pairs (A, B), nABC triples (A, B, C); a cell index along
+ * an axis with b bits is floor(((p1 + p2 + p3) - 3 offset) * (2^b / (3 span))) clamped to [0, 2^b - 1];
  * nA + 2 nAB + 3 nABC <= 60.  0 = the reference's interleave.  Derivation and numbers: csrc/cd_math.h, DESIGN.md. */
 int cd_set_morton_frame(cd_ctx *ctx, int mode, const double offset[3], const double span[3]);
 /* The frame the last sort used -- offset, span, key layout (any may be NULL) -- and a frame WITH a layout installed as
@@ -121,7 +122,8 @@ int cd_set_morton_frame_layout(cd_ctx *ctx, const double offset[3], const double
  * offset / span: both NULL = the constants of morton.h:45,51,57, else a custom frame.  Defined where the reference is
  * undefined: a negative or NaN normalised coordinate maps to cell 0 (morton.h:78's assert is compiled out in Release). */
 int cd_morton3d_points(const double *xyz, uint64_t n, const double offset[3], const double span[3], uint64_t *keys);
-/* the same in a frame with a key layout (what cd_morton_sort computes per centroid in such a frame; layout 0 = the call above) */
+/* the same in a frame with a key layout: what cd_morton_sort computes per triangle in such a frame, where xyz is the SUM p1 + p2 + p3 of the triangle's vertices per
+ * axis (a cell there is floor((sum - 3 offset) * (2^bits / (3 span))), no division per key: csrc/cd_math.h); layout 0 = the call above, xyz the centroid */
 int cd_morton3d_points_layout(const double *xyz, uint64_t n, const double offset[3], const double span[3], uint64_t layout, uint64_t *keys);
 int cd_expand64_values(const uint64_t *v, uint64_t n, uint64_t *out);
 

@@ -141,7 +141,7 @@ uint64_t orc_frame_layout_cap(const double lo[3], const double hi[3], const int6
     int64_t E[3], Lm[3], Lref = NONE; int ord[3] = { 0, 1, 2 };
     for (int a = 0; a < 3; ++a) {
         Lm[a] = NONE;
-        if (cnt[a] > 0) { Lm[a] = sum[a] >= 0 ? sum[a] / cnt[a] : -((-sum[a] + cnt[a] - 1) / cnt[a]); if (Lm[a] > Lref) Lref = Lm[a]; }   /* floor */
+        if (cnt[a] > 0) { Lm[a] = (int64_t)floor((double)sum[a] / (double)cnt[a]); if (Lm[a] > Lref) Lref = Lm[a]; }   /* floor of the mean: one IEEE division of exactly represented integers */
     }
     for (int a = 0; a < 3; ++a) {
         const double e = hi[a] - lo[a];
@@ -187,13 +187,17 @@ static inline uint64_t expand2_(uint64_t v)
     v = (v | v << 1)  & 0x5555555555555555ULL;
     return v;
 }
-static inline uint64_t cell_(double c, double off, double span, int bits)
+/* The cell of a triangle along an axis, in a frame WITH a layout:  floor(((p1 + p2 + p3) - 3 off) * (2^bits / (3 span)))  clamped to [0, 2^bits - 1] -- the vertex
+ * SUM s against thrice the offset, times one factor per axis and frame: no division per key (the device's reason: cd_math.h).  Every operation is one IEEE operation
+ * on both sides (3.0 * off, 3.0 * span, 2^bits / that, s - that, times that). */
+static inline uint64_t cell_(double s, double off, double span, int bits)
 {
     if (bits == 0) return 0;
-    const double scale = (double)(1ull << bits);                       /* exact */
-    const uint64_t v = d2u64(((c - off) / span) * scale), top = (1ull << bits) - 1;
+    const double off3 = 3.0 * off, k = (double)(1ull << bits) / (3.0 * span);
+    const uint64_t v = d2u64((s - off3) * k), top = (1ull << bits) - 1;
     return v > top ? top : v;                                          /* a centroid beyond the frame takes the last cell: the key stays below 2^60 */
 }
+/* sx, sy, sz: p1 + p2 + p3 per axis, in that order.  layout 0: x, y, z are taken as the centroid itself and the key is morton.h:70-89's (orc_morton3d). */
 uint64_t orc_morton3d_layout(double x, double y, double z, const double off[3], const double span[3], uint64_t layout)
 {
     if (!(layout & ORC_LAYOUT_VALID)) return orc_morton3d(x, y, z, off, span);
@@ -229,7 +233,8 @@ void orc_centroid_morton_layout(const double *verts, const uint32_t *vidx, uint3
 {
     for (uint32_t t = 0; t < n; ++t) {
         const double *p1 = verts + 3 * (size_t)vidx[3 * t + 0], *p2 = verts + 3 * (size_t)vidx[3 * t + 1], *p3 = verts + 3 * (size_t)vidx[3 * t + 2];
-        keys[t] = orc_morton3d_layout((p1[0] + p2[0] + p3[0]) / 3, (p1[1] + p2[1] + p3[1]) / 3, (p1[2] + p2[2] + p3[2]) / 3, off, span, layout);
+        if (layout & ORC_LAYOUT_VALID) keys[t] = orc_morton3d_layout(p1[0] + p2[0] + p3[0], p1[1] + p2[1] + p3[1], p1[2] + p2[2] + p3[2], off, span, layout);
+        else keys[t] = orc_morton3d((p1[0] + p2[0] + p3[0]) / 3, (p1[1] + p2[1] + p3[1]) / 3, (p1[2] + p2[2] + p3[2]) / 3, off, span);
     }
 }
 void orc_morton3d_layout_batch(const double *xyz, uint64_t n, const double off[3], const double span[3], uint64_t layout, uint64_t *keys)

@@ -192,6 +192,7 @@ def centroid_morton_layout(verts, vidx, off, span, layout):
 
 
 def morton3d_layout_batch(xyz, off, span, layout):
+    """keys of explicit points in a frame with a layout; xyz are then vertex SUMS p1 + p2 + p3 (layout 0: centroids, morton.h:70-89)"""
     p = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
     off = np.ascontiguousarray(off, dtype=np.float64); span = np.ascontiguousarray(span, dtype=np.float64)
     keys = np.zeros(p.shape[0], dtype=np.uint64)

@@ -175,25 +175,26 @@ def test_auto_frame_is_the_oracles_on_every_shape_of_mesh(mesh):
 
 
 def test_adaptive_keys_of_explicit_points_match_the_oracle():
-    """cd_morton3d_points_layout (what k_morton computes per centroid in a frame with a layout) against the restatement: layouts of every shape, points inside,
-    on cell boundaries +- 1 ulp, outside the frame, NaN; and layout (x, y, z), 0, 0, 20 against the reference-pinned morton3D itself."""
+    """cd_morton3d_points_layout (what k_morton computes per triangle in a frame with a layout; the points are vertex SUMS there) against the restatement: layouts of
+    every shape, sums inside, on cell boundaries +- 1 ulp, outside the frame, NaN; and layout 0 against the reference-pinned morton3D itself."""
     rng = np.random.default_rng(77)
     words = [oracle.layout_word((0, 2, 1), 3, 3, 17), oracle.layout_word((2, 0, 1), 0, 3, 18), oracle.layout_word((1, 0, 2), 60, 0, 0), oracle.layout_word((0, 1, 2), 0, 30, 0),
              oracle.layout_word((2, 1, 0), 10, 10, 10), oracle.layout_word((1, 2, 0), 5, 2, 7), oracle.layout_word((0, 1, 2), 0, 0, 20), oracle.layout_word((1, 2, 0), 0, 0, 0)]
     for w in words:
         off = rng.normal(size=3) * 5; span = np.exp(rng.normal(size=3) * 2)
         (A, B, C), nA, p, t = oracle.layout_fields(w)
-        pts = rng.random((40000, 3)) * span + off
-        edge = (rng.integers(0, 1 << min(nA + p + t, 40), size=(20000, 3)) / float(1 << min(nA + p + t, 40))) * span + off     # cell boundaries of axis A's grid (and whatever they are on the others)
+        pts = (rng.random((40000, 3)) * span + off) * 3
+        nb = min(nA + p + t, 40)
+        edge = ((rng.integers(0, 1 << nb, size=(20000, 3)) / float(1 << nb)) * span + off) * 3      # near cell boundaries of axis A's grid (and whatever they are on the others)
         edge = np.concatenate([edge, np.nextafter(edge, np.inf), np.nextafter(edge, -np.inf)])
-        out = np.concatenate([off - span * rng.random((500, 3)), off + span * (1 + rng.random((500, 3))), np.full((4, 3), np.nan), np.array([[1e300, -1e300, 0.0]])])
+        out = np.concatenate([(off - span * rng.random((500, 3))) * 3, (off + span * (1 + rng.random((500, 3)))) * 3, np.full((4, 3), np.nan), np.array([[1e300, -1e300, 0.0]])])
         allp = np.concatenate([pts, edge, out])
         got = mi355cd.morton3d_points_layout(allp, off, span, w)
         assert np.array_equal(got, oracle.morton3d_layout_batch(allp, off, span, w)), oracle.layout_fields(w)
         assert int(got.max()) < 1 << 60
     pts = rng.random((100000, 3)) * oracle.REF_SPAN + oracle.REF_OFF
-    assert np.array_equal(mi355cd.morton3d_points_layout(pts, oracle.REF_OFF, oracle.REF_SPAN, oracle.layout_word((0, 1, 2), 0, 0, 20)), oracle.morton3d_batch(pts))
     assert np.array_equal(mi355cd.morton3d_points_layout(pts, oracle.REF_OFF, oracle.REF_SPAN, 0), mi355cd.morton3d_points(pts))
+    assert np.array_equal(mi355cd.morton3d_points(pts), oracle.morton3d_batch(pts))
 
 
 def test_thin_long_mesh_sorts_in_two_passes_and_walks_a_better_tree():

@@ -33,12 +33,20 @@ def _cells_from_key(keys, w):
 
 
 def test_reference_interleave_is_the_layout_xyz_0_0_20():
-    """layout (x, y, z), 0, 0, 20 in any frame gives morton.h:70-89's key for every in-frame point: the adaptive path contains the reference's."""
+    """layout (x, y, z), 0, 0, 20 gives morton.h:70-89's key for every in-frame centroid that is not within rounding of a cell boundary: the adaptive path contains the
+    reference's interleave.  (A layout frame forms its cells from the vertex SUM, floor((s - 3 off) * (2^20 / (3 span))), where morton.h divides twice: the two agree
+    except where the exact value sits within a few ulps of an integer.)"""
     rng = np.random.default_rng(3)
-    pts = rng.random((200_000, 3)) * oracle.REF_SPAN * 0.999 + oracle.REF_OFF
+    c = rng.random((200_000, 3)) * oracle.REF_SPAN * 0.999 + oracle.REF_OFF
+    p1 = c + rng.normal(size=c.shape) * 0.01; p2 = c + rng.normal(size=c.shape) * 0.01; p3 = 3 * c - p1 - p2
+    s = (p1 + p2) + p3
+    cen = s / 3
+    exact = ((cen.astype(np.longdouble) - oracle.REF_OFF) / oracle.REF_SPAN) * 1048576
+    far = (np.abs(exact - np.rint(exact)) > 1e-6).all(1)
+    assert far.mean() > 0.99
     w = oracle.layout_word((0, 1, 2), 0, 0, 20)
-    assert np.array_equal(oracle.morton3d_layout_batch(pts, oracle.REF_OFF, oracle.REF_SPAN, w), oracle.morton3d_batch(pts))
-    assert np.array_equal(oracle.morton3d_layout_batch(pts, oracle.REF_OFF, oracle.REF_SPAN, 0), oracle.morton3d_batch(pts))     # 0: the reference's own path
+    assert np.array_equal(oracle.morton3d_layout_batch(s[far], oracle.REF_OFF, oracle.REF_SPAN, w), oracle.morton3d_batch(cen[far]))
+    assert np.array_equal(oracle.morton3d_layout_batch(cen, oracle.REF_OFF, oracle.REF_SPAN, 0), oracle.morton3d_batch(cen))     # 0: the reference's own path, on the centroid
 
 
 @pytest.mark.parametrize("w", [oracle.layout_word((0, 2, 1), 3, 3, 17), oracle.layout_word((2, 0, 1), 0, 3, 18), oracle.layout_word((1, 0, 2), 60, 0, 0),
@@ -46,13 +54,13 @@ def test_reference_interleave_is_the_layout_xyz_0_0_20():
 def test_key_is_the_interleave_the_layout_word_says(w):
     rng = np.random.default_rng(int(w & 0xffffffff))
     off = np.array([-3.0, 10.0, 0.25]); span = np.array([7.0, 0.5, 123.0])
-    pts = rng.random((50_000, 3)) * span + off
+    pts = (rng.random((50_000, 3)) * span + off) * 3                        # vertex sums: thrice a point of the frame
     keys = oracle.morton3d_layout_batch(pts, off, span, w)
     cells, bits = _cells_from_key(keys, w)
     A, B, C, nA, p, t = _fields(w)
     for ax, nb in zip((A, B, C), bits):
-        want = np.floor(((pts[:, ax] - off[ax]) / span[ax]) * float(1 << nb)).astype(np.uint64)
-        want = np.minimum(want, np.uint64((1 << nb) - 1))
+        want = np.floor((pts[:, ax] - 3.0 * off[ax]) * (float(1 << nb) / (3.0 * span[ax]))).astype(np.uint64)      # the definition, operation by operation
+        want = np.minimum(want, np.uint64((1 << nb) - 1)) if nb else np.zeros_like(want)
         assert np.array_equal(cells[ax], want), (ax, nb)
     assert int(keys.max()).bit_length() <= nA + 2 * p + 3 * t <= 60
 
@@ -60,7 +68,7 @@ def test_key_is_the_interleave_the_layout_word_says(w):
 def test_points_outside_the_frame_take_the_edge_cells():
     w = oracle.layout_word((0, 2, 1), 3, 3, 17)
     off = np.zeros(3); span = np.ones(3)
-    pts = np.array([[-1.0, -1.0, -1.0], [2.0, 2.0, 2.0], [np.nan, 0.5, 0.5], [0.5, 1e300, -1e300]])
+    pts = np.array([[-1.0, -1.0, -1.0], [2.0, 2.0, 2.0], [np.nan, 0.5, 0.5], [0.5, 1e300, -1e300]]) * 3     # (vertex sums)
     keys = oracle.morton3d_layout_batch(pts, off, span, w)
     cells, bits = _cells_from_key(keys, w)
     assert [int(c[0]) for c in cells] == [0, 0, 0]
