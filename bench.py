@@ -758,6 +758,32 @@ def main():
                 engine.cd.set_option(mi355cd.CD_OPT_ORDER_HINT, 1)
                 line["order_hint"].update({"ms_per_step_without": off_ms, "pairs_tested_per_s_without": (tested_total / k) / (off_ms * 1e-3),
                                            "descend_device_clock_ms_without": off_clock / off_steps, "steps_without": off_steps})
+            if not args.no_extras:
+                # The headline runs in CD_FRAME_REFERENCE: the constants of morton.h:43-58, keys bit-identical to morton3D (the mesh is the reference's data set's shape).
+                # What the same step costs in the frame the LIBRARY derives for the mesh (CD_FRAME_AUTO, the adaptive frame of cd_math.h, computed in one step and kept):
+                engine.cd.set_morton_frame(mi355cd.CD_FRAME_AUTO)
+                step()
+                aoff, aspan, alay = engine.cd.keep_auto_frame()
+                for _ in range(10):
+                    step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                a_steps, a_clock = min(k, 100), 0.0
+                for _ in range(a_steps):
+                    apairs, _, _ = step()
+                    a_clock += engine.cd.fast_stats.ms_descend_clock
+                torch.cuda.synchronize()
+                a_ms = (time.perf_counter() - t1) * 1e3 / a_steps
+                ast = engine.cd.stats()
+                line["adaptive_frame"] = {"what": "the headline's mesh and step in CD_FRAME_AUTO's frame (computed once by the library, then kept) instead of the reference's constants",
+                                          "ms_per_step": a_ms, "descend_device_clock_ms": a_clock / a_steps, "steps": a_steps, "sort_passes": int(ast.sort_passes),
+                                          "node_visits_per_query": ast.node_visits / float(nt), "layout_word": hex(alay),
+                                          "layout": {"axes_by_weight": [int(alay & 3), int((alay >> 2) & 3), int((alay >> 4) & 3)], "leading_bits_of_A": int((alay >> 8) & 255),
+                                                     "pairs_AB": int((alay >> 16) & 255), "triples_ABC": int((alay >> 24) & 255)},
+                                          "same_pairs_as_the_headline": bool(np.array_equal(np.sort(np.asarray(apairs, dtype=np.uint64)[:, 0] << np.uint64(32) | np.asarray(apairs, dtype=np.uint64)[:, 1]),
+                                                                                            np.sort(last_pairs.astype(np.uint64)[:, 0] << np.uint64(32) | last_pairs.astype(np.uint64)[:, 1]))),
+                                          "pairs_tested_equal": bool(int(ast.pairs_tested) == int(last_tested))}
+                engine.cd.set_morton_frame(mi355cd.CD_FRAME_REFERENCE)
             if not args.no_parity:
                 # checker leg: the LAST TIMED step's pair set + pairs-tested count against the oracle (one more CPU pass, with pairs)
                 pc = parity_check(last_pairs, last_tested, verts, vidx)
