@@ -589,6 +589,11 @@ def main():
             return pair_buf[:n], None, {}
         return multi.collide_step(engine, dist, rank, world, cap, comm_device)
 
+    # The warm-up steps are the TIMED step: same options (round 6: until now they ran with the library's default per-stage events and kernel stamps -- barrier packets and idle
+    # gaps the timed steps do not have -- and the first two timed steps of every run came out 5 % long, whatever W was: 2 % of the driver's 20-step line; per_step_wall_ms shows it)
+    engine.cd.set_option(mi355cd.CD_OPT_STAGE_TIMING, 0)
+    if not multi_path:
+        engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 0)
     for _ in range(args.warmup):
         step()
     # The DOMINANT kernel (the descent) is timed (1) by ITSELF in every step of the timed region -- first wave start -> last wave end on the
@@ -610,13 +615,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_desc = []                                                    # the descent kernel's own device-clock duration, step by step
+    step_wall = []                                                    # per-step wall clock (a step ends when the host has its pairs: the stamps cost two clock reads a step)
+    t_prev = t0
     for i_step in range(args.steps):
         pairs, tested, info = step()
+        t_now = time.perf_counter(); step_wall.append((t_now - t_prev) * 1e3); t_prev = t_now
         st = engine.cd.fast_stats if not multi_path else engine.cd.stats()   # (refreshed by the step's own call)
         if tested is None:
             tested = st.pairs_tested
         if not multi_path:
             kern["descend_device_clock"] += st.ms_descend_clock
+            step_desc.append(st.ms_descend_clock)
         tested_total += tested
         pairs_found = pairs.shape[0]
     torch.cuda.synchronize()
@@ -655,6 +665,12 @@ def main():
             "pairs_tested_counting": "reference-equivalent: the half traversal decides each unordered leaf pair once and credits the 2 ordered tests the reference makes",
             "box_decisions_executed_per_step": (tested_total // k) // (1 if args.traversal in (0, 1) else 2),
         }
+        # where the K steps' time went, step by step (the driver's 20-step runs sit ~2 % above this file's 200-step default)
+        sw = sorted(step_wall)
+        line["per_step_wall_ms"] = {"min": sw[0], "median": sw[len(sw) // 2], "max": sw[-1], "first_8": step_wall[:8], "last_4": step_wall[-4:],
+                                    "mean_first_quarter": sum(step_wall[:max(1, k // 4)]) / max(1, k // 4), "mean_last_quarter": sum(step_wall[-max(1, k // 4):]) / max(1, k // 4),
+                                    "descend_device_clock_first_8": step_desc[:8], "descend_device_clock_last_4": step_desc[-4:],
+                                    "note": "a step ends when the host has its pairs; the descent's duration is the kernel's own (device wall clock): where the first steps of a run are long, the kernel is"}
         if not multi_path:
             prof_steps = min(k, 20)
             engine.cd.set_option(mi355cd.CD_OPT_KERNEL_STAMPS, 15)   # untimed: the same step with every kernel stamp + pipeline start / end
