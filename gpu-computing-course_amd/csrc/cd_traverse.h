@@ -562,7 +562,9 @@ constexpr uint32_t HALF_FLUSH_AT = HALF_QCAP - 64;   // an enqueue adds at most 
 //  back sooner: 53.8 -> 52.4 us at 1 M triangles.  Two waves: 53.2 us)
 constexpr int HALF_THREADS = 64;
 
-template <bool DIAG, bool TIES /* the mesh has a cell table (cd_bvh.h): hits between boxes that are not both CERTAIN are looked at comparison by comparison */>
+constexpr int HALF_SMALL_N = 1 << 27;        // up to here a record's byte offset (32 bytes a node) fits 32 bits: the !BIG instances
+template <bool DIAG, bool TIES /* the mesh has a cell table (cd_bvh.h): hits between boxes that are not both CERTAIN are looked at comparison by comparison */,
+          bool BIG /* n > HALF_SMALL_N: phase 2 forms 64-bit record addresses */>
 __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, int n, const NodeRec32 *__restrict__ recs,
                                                                   TravState *__restrict__ st,
                                                                   Candidates *__restrict__ cand, unsigned long long shard_cap,
@@ -749,7 +751,9 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
         while (true) {
             // work sharing inside the wave (see k_descend): a busy lane hands the top of its stack, with its query, to an idle lane
             if (SHARE_MIN_IDLE <= 64) {
-                const bool idle = (node == -1), donor = (node != -1) & (sptr > 0);
+                // (a lane without a node has an empty stack -- it pops before it goes idle, and a taker starts with none: "donor" is sptr > 0, ONE compare, which the
+                //  ballot takes as it is; an i1 made of ANDs and ORs it would first write out as 0 / 1 and compare again)
+                const bool idle = (node == -1), donor = (sptr > 0);
                 const unsigned long long m_idle = __builtin_amdgcn_ballot_w64(idle), m_don = __builtin_amdgcn_ballot_w64(donor);
                 if (m_don != 0ull && __popcll(m_idle) >= SHARE_MIN_IDLE) {        // (wave-uniform)
                     const uint32_t nx = min((uint32_t)__popcll(m_don), (uint32_t)__popcll(m_idle));
@@ -774,7 +778,14 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
             // one descent step per active lane, straight-line selects (see k_descend)
             // (idle lanes fetch record 0 and ignore it: one select for the address instead of fifteen register clears)
             const uint32_t rn = active ? (uint32_t)node : 0u;
-            const float4 *rpl = rec_left(recs, n, rn), *rpr = rec_right(recs, n, rn);
+            // (!BIG: a 32-bit byte offset from the two arrays' wave-uniform bases -- the loads take it beside the base in scalar registers, three address instructions a step less)
+            const float4 *rpl, *rpr;
+            if constexpr (BIG) { rpl = rec_left(recs, n, rn); rpr = rec_right(recs, n, rn); }
+            else {
+                const uint32_t roff = rn << 5;
+                rpl = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rec_left(recs, n, 0)) + roff);
+                rpr = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rec_right(recs, n, 0)) + roff);
+            }
             const float4 a = rpl[0], b = rpl[1], c = rpr[0], d = rpr[1];
             const int32_t cl = __float_as_int(b.z), cr = __float_as_int(d.z);
             const uint32_t lw = __float_as_uint(d.w);
@@ -787,7 +798,8 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
             if (band(band(active, !bor(intL, intR)), sptr > 0)) { --sptr; nxt = lds_stack[sptr][lane]; }
             node = active ? nxt : -1;
             const bool candL = band(ol, cl < 0), candR = band(orr, cr < 0);
-            if (__builtin_amdgcn_ballot_w64(bor(candL, candR)) != 0ull) {        // (most steps meet no leaf: one test instead of two)
+            // (most steps meet no leaf: one test instead of two -- written as the compare of a register for the ballot's sake, see `donor`: a leaf link is negative)
+            if (__builtin_amdgcn_ballot_w64(((ol ? cl : 0) | (orr ? cr : 0)) < 0) != 0ull) {
                 enqueue(candL, qi, (uint32_t)~cl | cand_word(candL, (lw & REC_L_CERTAIN) != 0u, a.x, a.y, a.z, a.w, b.x, b.y));
                 enqueue(candR, qi, (uint32_t)~cr | cand_word(candR, (lw & REC_R_CERTAIN) != 0u, c.x, c.y, c.z, c.w, d.x, d.y));
             }

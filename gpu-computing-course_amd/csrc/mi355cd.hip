@@ -85,6 +85,7 @@ struct cd_ctx {
     double *d_boxes = nullptr; uint32_t *d_bounded = nullptr; NodeRec32 *d_recs32 = nullptr; LeafBox32 *d_qbox = nullptr;
     unsigned long long *d_leaf_side = nullptr;   // fused build: one bit a leaf -- its box is in the left half of recs[j] (else the right half of recs[j - 1]); what k_cross_fused reads instead of qbox[]
     bool qbox_valid = false;                // d_qbox holds THIS tree's query boxes (the fused build stores them only when somebody is known to read them: qbox_wanted / ensure_qbox)
+    uint32_t dbg_big_offsets = 0;           // CD_DBG_BIG_OFFSETS: k_descend_half's 64-bit-address instance whatever n is (tests)
     uint32_t dbg_store_qbox = 0;            // CD_DBG_STORE_QBOX: the fused build always stores qbox[] (A/B, tests)
     // the cell table of the current vertices (cd_bvh.h AmbTable; amb_refresh): keys == nullptr while every coordinate is an fp32 value
     AmbTable amb = {nullptr, 0u, 0u};
@@ -610,14 +611,17 @@ void launch_pass(cd_ctx *c, TravBuf &tb, const QuerySrc &src, uint32_t items, ui
             const uint32_t *h_order = (c->order_hint && c->order_ready) ? c->d_order : nullptr;      // (the order hint: cd_bvh.h, build_half_order)
             const bool h_rec = c->order_hint && (c->nbp2 <= (uint32_t)TOP_IN_BLOCK || c->order_hint_large);      // (the waves leave their times only where a build will read them)
             const uint32_t *h_perm = h_rec ? c->d_perm[0] : nullptr; uint8_t *h_tri = h_rec ? c->d_tri_cost : nullptr;
-#define LAUNCH_HALF(DIAG, TIES)                                                                                                             \
-            do { if (plain) k_descend_half<DIAG, TIES><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, h_order, h_perm, h_tri); \
-                 else hipExtLaunchKernelGGL((k_descend_half<DIAG, TIES>), hgrid, hblock, (uint32_t)pad, s, e0, e1, 0u, src, n, (const NodeRec32 *)c->d_recs32, \
+#define LAUNCH_HALF_(DIAG, TIES, BIG)                                                                                                           \
+            do { if (plain) k_descend_half<DIAG, TIES, BIG><<<hgrid, hblock, pad, s>>>(src, n, c->d_recs32, tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, h_order, h_perm, h_tri); \
+                 else hipExtLaunchKernelGGL((k_descend_half<DIAG, TIES, BIG>), hgrid, hblock, (uint32_t)pad, s, e0, e1, 0u, src, n, (const NodeRec32 *)c->d_recs32, \
                                             tb.d_state, tb.d_cand, (unsigned long long)shard_cap, dl, dcap, h_order, h_perm, h_tri); } while (0)
             const bool ties = c->amb.keys != nullptr || c->amb.mask != 0u;                      // (a graph capture bakes the instance in: amb_refresh drops the graph when the table comes or goes)
+            const bool big = n > HALF_SMALL_N || c->dbg_big_offsets;                            // (CD_DBG_BIG_OFFSETS: the tests run the 64-bit instance on trees of any size)
+#define LAUNCH_HALF(DIAG, TIES) do { if (big) LAUNCH_HALF_(DIAG, TIES, true); else LAUNCH_HALF_(DIAG, TIES, false); } while (0)
             if (c->dbg_diag) { if (ties) LAUNCH_HALF(true, true); else LAUNCH_HALF(true, false); }
             else { if (ties) LAUNCH_HALF(false, true); else LAUNCH_HALF(false, false); }
 #undef LAUNCH_HALF
+#undef LAUNCH_HALF_
         }
         else if (qpw == 64)
             hipExtLaunchKernelGGL((k_descend<EXTERNAL, DEEP, false>), grid, dim3(DESC_THREADS), (uint32_t)pad, s, e0, e1, 0u,
@@ -1717,6 +1721,7 @@ int cd_debug_option(cd_ctx *c, int key, int64_t value, int64_t *out)
     case CD_DBG_SORT_WINDOWS:    if (value < 0 || value > 2) return CD_ERR_ARG; c->dbg_sort_windows = (uint32_t)value; c->local_small_ok = true; graph_drop(c); return CD_OK;
     case CD_DBG_REPORT_COPIES:   c->dbg_report_copies = value != 0; graph_drop(c); return CD_OK;
     case CD_DBG_STORE_QBOX:      c->dbg_store_qbox = value != 0; graph_drop(c); return CD_OK;
+    case CD_DBG_BIG_OFFSETS:     c->dbg_big_offsets = value != 0; graph_drop(c); return CD_OK;
     case CD_DBG_POLL_SCAN:       c->dbg_poll_check = value != 0; return CD_OK;
     case CD_DBG_GET_POLL_STALE:     if (!out) return CD_ERR_ARG; *out = c->poll_stale; return CD_OK;
     case CD_DBG_GET_POLL_FALLBACKS: if (!out) return CD_ERR_ARG; *out = c->poll_fallbacks; return CD_OK;

@@ -28,6 +28,7 @@ CD_DBG_GET_ORDER_STATE = 15
 CD_DBG_GET_POLL_FB_WHY, CD_DBG_GET_POLL_MAX_WAIT_US = 16, 17
 CD_DBG_REPORT_COPIES = 6
 CD_DBG_STORE_QBOX = 9
+CD_DBG_BIG_OFFSETS = 18
 
 QUERY_DTYPE = np.dtype([("v", "<f8", (9,)), ("id", "<u4"), ("vidx", "<u4", (3,))])
 assert QUERY_DTYPE.itemsize == 88

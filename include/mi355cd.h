@@ -265,6 +265,7 @@ enum {
     CD_DBG_GET_POLL_FB_WHY    = 16,  /* ... why those waits ran out: bits 0..15 the stream was still busy at the time-out (the step was late), 16..31 the stream had drained and    */
                                      /* the word came with the synchronise (late in flight), 32..47 the word was not there after the drain (LOST: must stay 0)                          */
     CD_DBG_GET_POLL_MAX_WAIT_US = 17, /* ... the longest polled wait that ended in the word (sampled every 16th step), microseconds                                                   */
+    CD_DBG_BIG_OFFSETS        = 18,  /* 1: the half traversal runs the instance that forms 64-bit record addresses (what trees of more than 2^27 leaves get) on a tree of any size (tests)  */
     CD_DBG_GET_TREE_WAS_FUSED = 14,  /* 1: the tree that is there was made by the one-pass build                                              */
     CD_DBG_GET_ORDER_STATE    = 15   /* the order hint (CD_OPT_ORDER_HINT) as it stands: 0 none built yet; 1 a permutation of the groups of 64 leaves that differs from the plain order;    */
                                      /* 2 the plain order itself; -1 not a permutation (must never be)                                                                                        */

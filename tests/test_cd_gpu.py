@@ -393,6 +393,27 @@ def test_half_traversal_chain_overflows_into_the_deep_pass():
             assert np.array_equal(oracle.pair_set(p2), oracle.pair_set(pairs)) and cd.stats().pairs_tested == st.pairs_tested
 
 
+def test_half_traversal_instance_for_trees_beyond_2_27_leaves_gives_the_same_step():
+    """k_descend_half forms record addresses from a 32-bit byte offset up to 2^27 leaves and from 64-bit indices beyond (cd_traverse.h, HALF_SMALL_N).  No test
+    mesh is that large: CD_DBG_BIG_OFFSETS runs the 64-bit instance on trees of any size -- the same pairs, counters and node visits, with and without a cell table,
+    in the polled graph step and the stage-wise call."""
+    for verts, vidx in (synth.cloth_pair(60), synth.soup(50_000, 0.02, 5), (synth.cloth_pair(40)[0] * (1 + 2.0 ** -30) + 0.1, synth.cloth_pair(40)[1])):
+        r = oracle.pipeline(verts, vidx)
+        with mi355cd.CollisionDetector(verts, vidx) as cd:
+            got = []
+            for big in (0, 1, 0):
+                cd.debug_set(mi355cd.CD_DBG_BIG_OFFSETS, big)
+                for _ in range(3):
+                    pairs, n, rc = cd.self_collide()
+                st = cd.stats()
+                assert rc == 0 and n == r["stats"].n_pairs and st.pairs_tested == r["stats"].pairs_tested
+                assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+                p2, n2, _ = cd.find_collisions()
+                assert np.array_equal(oracle.pair_set(p2), oracle.pair_set(r["pairs"]))
+                got.append((st.node_visits, st.n_candidates if hasattr(st, "n_candidates") else 0))
+            assert got[0] == got[1] == got[2]
+
+
 def test_exact_test_kernel_one_million_pairs():
     """tri_contact (17-axis SAT) + neighbour gate + ID rule on 1 M explicit pairs, bit-match vs oracle."""
     verts, vidx = synth.cloth_pair(60)

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "gpu-computing-course_amd")
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import time
-    sys.path.insert(0, os.path.join(PKG, "pyhost"))
+    sys.path.insert(0, os.environ.get("MI355CD_PYHOST", os.path.join(PKG, "pyhost")))       # an older build's bindings (ab/pyhost_NAME/) when its ABI is older
     import numpy as np, mi355cd, mi355_synth as synth
     out = {}
     buf = np.empty((1 << 22, 2), dtype=np.uint32)
@@ -32,6 +32,8 @@ for r in range(rounds):
         env = dict(os.environ)
         if nm != "default":
             env["MI355CD_LIB"] = os.path.join(PKG, "ab", f"libmi355cd_{nm}.so")
+            if os.path.isdir(os.path.join(PKG, "ab", f"pyhost_{nm}")):
+                env["MI355CD_PYHOST"] = os.path.join(PKG, "ab", f"pyhost_{nm}")
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True, timeout=600)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         if not line:

@@ -38,3 +38,16 @@ for name, (verts, vidx) in (("cloth1M", synth.cloth_pair(500)), ("soup1M", synth
                 per = [makespan(dur[taken[x::8]], 1024) for x in range(8)]
                 line += f" | list scheduling of these times in the order taken, per XCD on 1024 slots: {min(per):.1f} .. {max(per):.1f} us; longest-first on the SAME times: {max(makespan(np.sort(dur[taken[x::8]])[::-1], 1024) for x in range(8)):.1f}"
             print(line, flush=True)
+            if taken is not None:
+                # what if the K longest groups of an XCD ran as TWO waves of 32 queries each (the other 32 lanes take shared subtrees)?  A half keeps a wave's fixed part
+                # (phase 0, the shared chain, hand-over: ~8 us at full occupancy) and half of the rest.
+                for fixed in (6.0, 10.0):
+                    out = []
+                    for K in (0, 8, 32, 64, 128, 256):
+                        per = []
+                        for x in range(8):
+                            d = np.sort(dur[taken[x::8]])[::-1]
+                            halves = np.minimum(d[:K], fixed) + np.maximum(d[:K] - fixed, 0) / 2
+                            per.append(makespan(np.sort(np.concatenate([halves, halves, d[K:]]))[::-1], 1024))
+                        out.append(f"K={K}: {max(per):.1f}")
+                    print(f"    split model (fixed part {fixed} us), longest-first list scheduling, worst XCD: " + "  ".join(out), flush=True)
