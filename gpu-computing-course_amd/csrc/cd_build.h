@@ -778,6 +778,7 @@ __global__ __launch_bounds__(256, 2) void k_cross_fused(const uint64_t *__restri
             // per side of the levels SEG32_MIN_LEVEL .. REFIT_LOG of a block's tree (seg32); levels above the blocks: the published nodes (above)
             constexpr int SMIN = SEG32_MIN_LEVEL, LEAF_ITEMS = 2 * ((1 << SMIN) - 1), N_ITEMS = LEAF_ITEMS + 2 * (REFIT_LOG + 1 - SMIN);
             static_assert(XG == 16 && N_ITEMS <= 2 * XG, "a lane fetches items gl and gl + 16 of either child");
+            static_assert(REFIT_BLK == (1 << REFIT_LOG) && SMIN >= 1 && SMIN <= REFIT_LOG, "item t >= LEAF_ITEMS is side (t - LEAF_ITEMS) & 1 of level SMIN + (t - LEAF_ITEMS) / 2 <= REFIT_LOG of a 2^REFIT_LOG-leaf block");
             B32 it[4]; bool tk[4];
             static_assert(LEAF_ITEMS <= XG, "the leaf items are a lane's FIRST item of either child (r = 0, 2)");
 #pragma unroll

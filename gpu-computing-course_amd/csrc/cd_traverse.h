@@ -776,8 +776,7 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
             if (m_act2 == 0ull) break;
             ++steps; wvisits += (uint32_t)__popcll(m_act2);
             // one descent step per active lane, straight-line selects (see k_descend)
-            // (idle lanes fetch record 0 and ignore it: one select for the address instead of fifteen register clears)
-            const uint32_t rn = active ? (uint32_t)node : 0u;
+            const uint32_t rn = (uint32_t)node;
             // (!BIG: a 32-bit byte offset from the two arrays' wave-uniform bases -- the loads take it beside the base in scalar registers, three address instructions a step less)
             const float4 *rpl, *rpr;
             if constexpr (BIG) { rpl = rec_left(recs, n, rn); rpr = rec_right(recs, n, rn); }
@@ -786,7 +785,10 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
                 rpl = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rec_left(recs, n, 0)) + roff);
                 rpr = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rec_right(recs, n, 0)) + roff);
             }
-            const float4 a = rpl[0], b = rpl[1], c = rpr[0], d = rpr[1];
+            // (only the lanes with a node load: the others' a .. d stay indeterminate and every use below is ANDed with `active` -- no select for a harmless address,
+            //  no register clears, and the texture unit steps through 18 lanes' addresses a step on average instead of 64)
+            float4 a, b, c, d;
+            if (active) { a = rpl[0]; b = rpl[1]; c = rpr[0]; d = rpr[1]; }
             const int32_t cl = __float_as_int(b.z), cr = __float_as_int(d.z);
             const uint32_t lw = __float_as_uint(d.w);
             const bool ol  = active & (qlo0 < a.w) & (a.x < qhi0) & (qlo1 < b.x) & (a.y < qhi1) & (qlo2 < b.y) & (a.z < qhi2);
