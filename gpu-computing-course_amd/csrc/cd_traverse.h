@@ -13,10 +13,14 @@ constexpr int NSHARD = 64;
 struct alignas(128) CtrShard {
     unsigned long long pairs_tested;   // leaf AABB hits (reach neighborCount / SAT)
     unsigned long long node_visits;
-    unsigned long long n_candidates;   // candidates reserved in this shard of the candidate buffer (may exceed its capacity)
+    unsigned long long n_candidates;   // entries reserved in this shard of the candidate buffer (may exceed its capacity): low 32 bits the 8-byte candidates, from the shard's
+                                       // front; high 32 bits the 32-byte SAT-ready pairs (FatPair below), from its end -- one atomic reserves both
     unsigned long long wave_steps;     // descent-loop iterations summed over waves (lane utilisation = node_visits / (64 * wave_steps))
     unsigned long long pad[12];        // [4] / [11]: the descent's own clock (earliest start as its complement, latest end); the rest: diagnostics (DIAG instances of the kernels)
 };
+// slots of 8 bytes the reservations of one shard's counter word take
+__host__ __device__ __forceinline__ unsigned long long cand_slots(unsigned long long w) { return (w & 0xffffffffull) + 4ull * (w >> 32); }
+__host__ __device__ __forceinline__ unsigned long long cand_entries(unsigned long long w) { return (w & 0xffffffffull) + (w >> 32); }
 struct alignas(128) TravState {
     unsigned long long n_pairs;        // collision.cuh:40 `count`
     uint32_t n_deferred;               // (query, subtree) items the LDS stack could not hold (deep pass redoes them)
@@ -62,8 +66,8 @@ __global__ __launch_bounds__(REPORT_THREADS) void k_report(const TravState *__re
         const int lane = threadIdx.x;                                   // NSHARD == 64: lane = shard
         const CtrShard sh = st->shard[lane];
         const unsigned long long tested = wave_sum_u64(sh.pairs_tested), visits = wave_sum_u64(sh.node_visits);
-        const unsigned long long steps = wave_sum_u64(sh.wave_steps), cands = wave_sum_u64(sh.n_candidates);
-        unsigned long long mx = sh.n_candidates, c0 = sh.pad[4], c1 = sh.pad[11];
+        const unsigned long long steps = wave_sum_u64(sh.wave_steps), cands = wave_sum_u64(cand_entries(sh.n_candidates));
+        unsigned long long mx = cand_slots(sh.n_candidates), c0 = sh.pad[4], c1 = sh.pad[11];      // (max_shard_candidates: in 8-byte slots, what the capacity is counted in)
         for (int o = 32; o; o >>= 1) {
             const unsigned long long u = __shfl_xor(mx, o); mx = u > mx ? u : mx;
             const unsigned long long u0 = __shfl_xor(c0, o); c0 = u0 > c0 ? u0 : c0;
@@ -267,6 +271,14 @@ constexpr uint32_t CAND_CERTAIN = 0x80000000u;
 // the pair as tested -- k_exact sends it straight to the SAT
 constexpr uint32_t CAND_FILTERED = 0x40000000u;
 constexpr uint32_t CAND_LEAF_MASK = 0x3fffffffu;
+// A pair the half traversal has decided, counted and filtered leaves the descent with BOTH leaves' records (which its filter had to fetch anyway): k_exact starts the six
+// vertex loads of the SAT straight from the entry -- one dependent round trip (the two leaf records by index) less in a kernel that is a chain of them.  32-byte entries,
+// reserved from the END of the workgroup's shard downwards (entry k: slots cap - 4 (k + 1) .. cap - 4 k - 1; the 8-byte candidates grow from the front; the two meet
+// only in a step whose shard overflowed, which is redone).  shard_cap is a multiple of 4 (mi355cd.hip), the buffer 256-byte aligned.
+struct alignas(16) FatPair { LeafTri a, b; };
+static_assert(sizeof(FatPair) == 4 * sizeof(Candidates), "a SAT-ready pair takes four candidate slots");
+__device__ __forceinline__ FatPair *fat_slot(Candidates *shard, unsigned long long shard_cap, unsigned long long k) { return reinterpret_cast<FatPair *>(shard + shard_cap) - (k + 1); }
+__device__ __forceinline__ const FatPair *fat_slot(const Candidates *shard, unsigned long long shard_cap, unsigned long long k) { return reinterpret_cast<const FatPair *>(shard + shard_cap) - (k + 1); }
 
 // queries_per_wave: size of the contiguous chunk of queries one wave works through (multiple of 64).
 // (one wave per workgroup, as k_descend_half: the waves of this kernel never meet)
@@ -610,22 +622,28 @@ __global__ __launch_bounds__(HALF_THREADS, 8) void k_descend_half(QuerySrc src, 
     auto flush = [&](uint32_t count) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         Candidates cd0 = Candidates{0, 0};
-        bool keep = lane < count;
+        bool keep = lane < count, fat = false;
         if (keep) cd0 = queue[qcount - count + lane];
+        FatPair fp;
         if (keep && (cd0.leaf & CAND_CERTAIN)) {
             tested += 2u;                                                      // collision.cuh:31-32, decided exactly by the descent, both directions
-            const LeafTri lt = src.leaf[cd0.leaf & CAND_LEAF_MASK];
-            const LeafTri ql = src.leaf[cd0.q];
-            keep = neighbor_count(ql.v0, ql.v1, ql.v2, lt.v0, lt.v1, lt.v2) < 1 && ql.id != lt.id;   // collision.cuh:38, tri_contact.cuh:81
-            cd0.leaf |= CAND_FILTERED;
+            fp.b = src.leaf[cd0.leaf & CAND_LEAF_MASK];
+            fp.a = src.leaf[cd0.q];
+            keep = fat = neighbor_count(fp.a.v0, fp.a.v1, fp.a.v2, fp.b.v0, fp.b.v1, fp.b.v2) < 1 && fp.a.id != fp.b.id;   // collision.cuh:38, tri_contact.cuh:81
         }
         qcount -= count;
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(keep);
         if (mk != 0ull) {
+            // survivors of the filter go as SAT-ready pairs (FatPair) to the end of the shard, what still needs the FP64 box test as a candidate to its front
+            const unsigned long long mf = __builtin_amdgcn_ballot_w64(fat), mt = mk & ~mf;
             unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(&sh->n_candidates, (unsigned long long)__popcll(mk));
-            base = __shfl(base, 0) + __popcll(mk & lt_mask);
-            if (keep && base < shard_cap) my_cand[base] = cd0;
+            if (lane == 0) base = atomicAdd(&sh->n_candidates, (unsigned long long)__popcll(mt) | ((unsigned long long)__popcll(mf) << 32));
+            const uint32_t base_t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base), base_f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+            if (fat) { const uint32_t k = base_f + (uint32_t)__popcll(mf & lt_mask); if (4ull * ((unsigned long long)k + 1ull) <= shard_cap) *fat_slot(my_cand, shard_cap, k) = fp; }
+            if (mt != 0ull) {                                                     // (wave-uniform; rare: a mesh whose vertices are fp32 values has none)
+                const uint32_t k = base_t + (uint32_t)__popcll(mt & lt_mask);
+                if (keep && !fat && k < shard_cap) my_cand[k] = cd0;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
@@ -878,42 +896,62 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
         const uint2 w = reinterpret_cast<const uint2 *>(my_cand)[k < shard_cap ? k : 0];
         cfq[j] = w.x; cfl[j] = w.y;
     }
-    unsigned long long total;                                   // this shard's candidates
+    // ... and so is the workgroup's first chunk of SAT-ready pairs (k_descend_half's survivors: FatPair, from the end of the shard)
+    uint4 ff0, ff1;
+    {
+        const unsigned long long k = (unsigned long long)my_slot * EXACT_THREADS + tid;
+        const uint4 *fp = reinterpret_cast<const uint4 *>(fat_slot(my_cand, shard_cap, 4ull * (k + 1ull) <= shard_cap ? k : 0ull));
+        ff0 = fp[0]; ff1 = fp[1];
+    }
+    unsigned long long total, total_fat;                        // this shard's candidates and SAT-ready pairs
     {
         unsigned long long c = st->shard[lane].n_candidates;
-        const bool over = c > shard_cap;                        // the host will grow the buffer and redo
+        const bool over = cand_slots(c) > shard_cap;            // the host will grow the buffer and redo
         if (__ballot(over) != 0ull) c = 0;
-        total = (unsigned long long)__builtin_amdgcn_readlane((int)(uint32_t)c, (int)my_shard) | ((unsigned long long)__builtin_amdgcn_readlane((int)(uint32_t)(c >> 32), (int)my_shard) << 32);
+        total = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)c, (int)my_shard);
+        total_fat = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(c >> 32), (int)my_shard);
     }
     __syncthreads();                                            // (pcount, sqcount)
     uint32_t tested = 0;
 
-    // SAT of one queued survivor; hit -> LDS pair staging (or direct append when the staging area is full)
-    auto run_sat = [&](const SatItem it) {
-        LeafTri lt = leaf[it.leaf];
-        uint32_t q_id; d3 P1, P2, P3;
-        if (EXTERNAL) {
-            const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + it.q;
-            P1 = d3{q->v[0], q->v[1], q->v[2]}; P2 = d3{q->v[3], q->v[4], q->v[5]}; P3 = d3{q->v[6], q->v[7], q->v[8]};
-            q_id = q->id;
-        } else {
-            LeafTri ql = leaf[it.q];
-            // half traversal: the pair is unordered; the reference tests it with the smaller ID as the query
-            // (tri_contact.cuh:81 lets only that direction through), so that triangle goes in front
-            if (half && ql.id > lt.id) { const LeafTri t = ql; ql = lt; lt = t; }
-            q_id = ql.id;
-            P1 = load_vertex(verts, ql.v0); P2 = load_vertex(verts, ql.v1); P3 = load_vertex(verts, ql.v2);
-        }
-        if (tri_contact(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) {
-            const uint32_t slot = atomicAdd(&pcount, 1u);                      // LDS
-            if (slot < EXACT_PB) pbuf[slot] = make_uint2(q_id, lt.id);
-            else {                                                             // staging full: append directly (collision.cuh:40)
-                const unsigned long long cur = atomicAdd(&st->n_pairs, 1ull);
-                if (cur < cap) { pairs[2 * cur] = q_id; pairs[2 * cur + 1] = lt.id; }
-                if (post && cur < post_n) reinterpret_cast<uint2 *>(post)[cur] = make_uint2(q_id, lt.id);
-            }
+    // a contact -> LDS pair staging (or direct append when the staging area is full)
+    auto contact = [&](uint32_t q_id, uint32_t l_id) {
+        const uint32_t slot = atomicAdd(&pcount, 1u);                          // LDS
+        if (slot < EXACT_PB) pbuf[slot] = make_uint2(q_id, l_id);
+        else {                                                                 // staging full: append directly (collision.cuh:40)
+            const unsigned long long cur = atomicAdd(&st->n_pairs, 1ull);
+            if (cur < cap) { pairs[2 * cur] = q_id; pairs[2 * cur + 1] = l_id; }
+            if (post && cur < post_n) reinterpret_cast<uint2 *>(post)[cur] = make_uint2(q_id, l_id);
         }
     };
+    // SAT of two leaves of this mesh.  Half traversal: the pair is unordered; the reference tests it with the smaller ID as the query
+    // (tri_contact.cuh:81 lets only that direction through), so that triangle goes in front
+    auto sat_leaves = [&](LeafTri ql, LeafTri lt) {
+        if (half && ql.id > lt.id) { const LeafTri t = ql; ql = lt; lt = t; }
+        const d3 P1 = load_vertex(verts, ql.v0), P2 = load_vertex(verts, ql.v1), P3 = load_vertex(verts, ql.v2);
+        if (tri_contact(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) contact(ql.id, lt.id);
+    };
+    // SAT of one queued survivor
+    auto run_sat = [&](const SatItem it) {
+        const LeafTri lt = leaf[it.leaf];
+        if (EXTERNAL) {
+            const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + it.q;
+            const d3 P1 = d3{q->v[0], q->v[1], q->v[2]}, P2 = d3{q->v[3], q->v[4], q->v[5]}, P3 = d3{q->v[6], q->v[7], q->v[8]};
+            const uint32_t q_id = q->id;
+            if (tri_contact(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) contact(q_id, lt.id);
+        } else sat_leaves(leaf[it.q], lt);
+    };
+
+    // ---- the SAT-ready pairs first (the usual step has nothing else): chunks of 256 dealt round-robin over the shard's workgroups, every lane one SAT
+    if (!EXTERNAL) {
+        const unsigned long long nfchunks = (total_fat + EXACT_THREADS - 1) / EXACT_THREADS;
+        for (unsigned long long cf = my_slot; cf < nfchunks; cf += slots) {
+            const unsigned long long k = cf * EXACT_THREADS + tid;
+            uint4 e0 = ff0, e1 = ff1;
+            if (cf != my_slot) { const uint4 *fp = reinterpret_cast<const uint4 *>(fat_slot(my_cand, shard_cap, k < total_fat ? k : 0ull)); e0 = fp[0]; e1 = fp[1]; }   // (workgroup-uniform branch)
+            if (k < total_fat) sat_leaves(LeafTri{e0.x, e0.y, e0.z, e0.w}, LeafTri{e1.x, e1.y, e1.z, e1.w});
+        }
+    }
 
     // Chunks of 256 candidates are dealt round-robin over the workgroups, EXACT_ITEMS chunks per workgroup and round: a few
     // thousand survivors (the usual case: the descent has filtered the rest) spread over as many workgroups as they fill, one

@@ -781,7 +781,7 @@ int grow_shards(cd_ctx *c, TravBuf &tb, const HostCounters &h) { return grow_can
 int grow_candidates(cd_ctx *c, TravBuf &tb, uint64_t max_shard)
 {
     hipFree(tb.d_cand); tb.d_cand = nullptr; tb.cand_cap = 0;
-    const uint64_t want = (max_shard + max_shard / 4 + 1024) * NSHARD;
+    const uint64_t want = ((max_shard + max_shard / 4 + 1024 + 3) & ~3ull) * NSHARD;          // (a shard: a multiple of 4 slots -- FatPair entries are counted from its end, cd_traverse.h)
     HIPCHK(hipMalloc(&tb.d_cand, sizeof(Candidates) * want));
     tb.cand_cap = want;
     return 0;
@@ -1127,7 +1127,7 @@ int cd_create(cd_ctx **out, const double *verts_xyz, uint32_t nv, const uint32_t
     { const size_t groups = ((size_t)n + 63) / 64;
       ALLOC(c->d_cost, sizeof(uint32_t) * groups); ALLOC(c->d_order, sizeof(uint32_t) * groups); ALLOC(c->d_tri_cost, n);
       if (hipMemset(c->d_cost, 0, sizeof(uint32_t) * groups) != hipSuccess || hipMemset(c->d_tri_cost, 0, n) != hipSuccess) { free_all(c); delete c; return CD_ERR_ARG; } }   // (no times yet: the first hint is half_vblock's own order)
-    c->tb[0].cand_cap = ((4 * n > (1u << 20) ? 4 * n : (1u << 20)) + NSHARD - 1) / NSHARD * NSHARD;
+    c->tb[0].cand_cap = ((4 * n > (1u << 20) ? 4 * n : (1u << 20)) + 4 * NSHARD - 1) / (4 * NSHARD) * (4 * NSHARD);    // (a shard: a multiple of 4 slots, cd_traverse.h: FatPair)
     ALLOC(c->tb[0].d_cand, sizeof(Candidates) * c->tb[0].cand_cap);
     c->tb[0].defer_cap = 1u << 16;
     ALLOC(c->tb[0].d_defer, sizeof(uint2) * c->tb[0].defer_cap);

@@ -302,6 +302,27 @@ def test_dense_collisions_fill_the_candidate_queue():
             assert cd.stats().pairs_tested == r["stats"].pairs_tested
 
 
+def test_survivors_that_overflow_their_shards_make_the_step_grow_the_buffer_and_redo():
+    """The half traversal's survivors leave as 32-byte SAT-ready pairs from the END of their shard of the candidate buffer, what still needs the FP64 box test as
+    8-byte candidates from its front (cd_traverse.h, FatPair).  2.1 M survivors x 4 slots against the 2^20 slots a 12 000-triangle context starts with: every
+    shard overflows, nothing is written past one, the host grows the buffer and redoes the pass -- the oracle's pairs, and again without growth in the next step.
+    A mesh with a cell table sends both kinds through one shard."""
+    verts, vidx = synth.soup(12000, 0.6, 77)
+    for scale in (1.0, 1.0 + 2.0 ** -30):                               # (x (1 + 2^-30): no coordinate is an fp32 value any more -- cell table, candidates that are not certain)
+        v = verts * scale
+        r = oracle.pipeline(v, vidx)
+        with mi355cd.CollisionDetector(v, vidx) as cd:
+            for step in range(3):
+                pairs, n, rc = cd.self_collide(cap=1 << 20)
+                st = cd.stats()
+                assert rc == 0 and n == r["stats"].n_pairs and st.pairs_tested == r["stats"].pairs_tested
+                assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
+                assert 4 * st.candidates > (1 << 20) and 2 * st.candidates <= r["stats"].pairs_tested + 2 * 12000
+            cd.set_option(mi355cd.CD_OPT_TRAVERSAL, 1)                   # the descent from the root hands its survivors over as flagged 8-byte candidates
+            p1, n1, _ = cd.find_collisions(cap=1 << 20)
+            assert n1 == n and np.array_equal(oracle.pair_set(p1), oracle.pair_set(r["pairs"])) and cd.stats().pairs_tested == r["stats"].pairs_tested
+
+
 def test_capacity_overflow_and_stage_order():
     verts, vidx = synth.soup(20000, 0.05, 3)
     with mi355cd.CollisionDetector(verts, vidx) as cd:
@@ -410,7 +431,7 @@ def test_half_traversal_instance_for_trees_beyond_2_27_leaves_gives_the_same_ste
                 assert np.array_equal(oracle.pair_set(pairs), oracle.pair_set(r["pairs"]))
                 p2, n2, _ = cd.find_collisions()
                 assert np.array_equal(oracle.pair_set(p2), oracle.pair_set(r["pairs"]))
-                got.append((st.node_visits, st.n_candidates if hasattr(st, "n_candidates") else 0))
+                got.append((st.node_visits, st.candidates))
             assert got[0] == got[1] == got[2]
 
 
