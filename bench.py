@@ -562,14 +562,33 @@ def main():
 
     comm_device = None if backend == "nccl" else "cpu"
     ms = None
+    multi_fallback = None
     if multi_path and backend == "nccl":
         # the product path: cd_multi_step (C++ over RCCL).  Rank 0 makes the ncclUniqueId, torch.distributed hands it round.
         uid = torch.zeros(128, dtype=torch.uint8, device=device)
         if rank == 0:
             uid = torch.frombuffer(bytearray(mi355cd.multi_unique_id()), dtype=torch.uint8).to(device)
         dist.broadcast(uid, src=0)
-        ms = mi355cd.MultiStep(engine.cd, bytes(uid.cpu().numpy().tobytes()), rank, world, query_cap_per_peer=nt // 8 + 1024,
-                               flags=mi355cd.CD_MULTI_SELF_PEER if self_peer else 0)
+        # If the library cannot set its step up on some rank (librccl.so not loadable, ncclCommInitRank refused, an allocation ...) EVERY rank drops to the same step orchestrated
+        # from Python over torch.distributed's RCCL communicator (pyhost/mi355_multi.collide_step: the same kernels behind the same C ABI, exchange by all_to_all_single) -- the
+        # line then says so (`multi_fallback`) instead of the run dying without a line.  MI355_BENCH_NO_CD_MULTI=1 takes that path on purpose (tests).
+        rc_create = 0
+        if os.environ.get("MI355_BENCH_NO_CD_MULTI", "0") == "1":
+            rc_create = 1
+        else:
+            try:
+                ms = mi355cd.MultiStep(engine.cd, bytes(uid.cpu().numpy().tobytes()), rank, world, query_cap_per_peer=nt // 8 + 1024,
+                                       flags=mi355cd.CD_MULTI_SELF_PEER if self_peer else 0)
+            except mi355cd.CdError as e:
+                rc_create = int(e.rc) or 1
+        worst = torch.tensor([abs(rc_create)], dtype=torch.int64, device=device)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        if int(worst.item()) != 0:
+            if ms is not None:
+                ms.close()
+                ms = None
+            multi_fallback = (f"cd_multi_create did not succeed on every rank (this rank: {rc_create}, worst: -{int(worst.item())}): the step is orchestrated from Python over "
+                              "torch.distributed (RCCL) -- mi355_multi.collide_step: same kernels, exchange by all_to_all_single, payloads on the device")
     last_info = {}
 
     def step():
@@ -661,7 +680,8 @@ def main():
             # credits 2 (box.cuh:40-43 and neighborCount are symmetric; equal to the oracle's counter in every test): the device executes
             # half as many exact box decisions as `value` says
             "path": ("cd_multi_step (C++ over RCCL)" + (", one-rank communicator exchanging with itself: REHEARSAL" if self_peer else (", one-rank communicator, no peer" if multi_n1 else ""))) if ms is not None
-                    else ("cd_self_collide" if not multi_path else "Python rehearsal of the multi-GPU step over " + backend),
+                    else ("cd_self_collide" if not multi_path else ("Python orchestration of the multi-GPU step over torch.distributed (RCCL), device payloads: FALLBACK" if multi_fallback
+                                                                    else "Python rehearsal of the multi-GPU step over " + backend)),
             "pairs_tested_counting": "reference-equivalent: the half traversal decides each unordered leaf pair once and credits the 2 ordered tests the reference makes",
             "box_decisions_executed_per_step": (tested_total // k) // (1 if args.traversal in (0, 1) else 2),
         }
@@ -907,7 +927,10 @@ def main():
             observed = dist.get_world_size()
         if rank == 0:
             line["backend"] = ("rccl (C++: cd_multi_step of libmi355cd.so issues ncclAllGather / ncclSend / ncclRecv)" if ms is not None
-                               else f"{backend} (REHEARSAL: Python orchestration, payloads staged through the host)")
+                               else ("rccl through torch.distributed (Python orchestration, payloads on the device): FALLBACK" if multi_fallback
+                                     else f"{backend} (REHEARSAL: Python orchestration, payloads staged through the host)"))
+            if multi_fallback:
+                line["multi_fallback"] = multi_fallback
             line["world_size_observed"] = observed
             line["phase_ms"] = phase
             line["phase_ms_note"] = ("max over ranks, from 5 extra untimed steps with events at the phase boundaries.  The phases are NOT additive: allgather / "

@@ -1503,7 +1503,7 @@ def test_bench_started_plainly_launches_its_own_ranks():
     # N = 1 on both paths
     env1 = dict(env); env1.pop("MI355_DIST_BACKEND")
     lines = {}
-    for name, extra in (("plain", {}), ("multi", {"MI355_BENCH_MULTI_PATH": "1"})):
+    for name, extra in (("plain", {}), ("multi", {"MI355_BENCH_MULTI_PATH": "1"}), ("fallback", {"MI355_BENCH_MULTI_PATH": "1", "MI355_BENCH_NO_CD_MULTI": "1"})):
         o = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "10", "--quads", "250", "--no-extras", "--no-ray"],
                            capture_output=True, text=True, timeout=600, env=dict(env1, **extra), cwd=root)
         assert o.returncode == 0, o.stdout[-2000:] + o.stderr[-2000:]
@@ -1512,6 +1512,11 @@ def test_bench_started_plainly_launches_its_own_ranks():
     assert lines["plain"]["config"]["colliding_pairs"] == lines["multi"]["config"]["colliding_pairs"] > 0
     assert lines["plain"]["config"]["pairs_tested_per_step"] == lines["multi"]["config"]["pairs_tested_per_step"]
     assert lines["plain"]["parity_checked"] is True and lines["multi"]["parity_checked"] is True
+    # a rank on which the library cannot set its step up: every rank drops to the step orchestrated from Python over torch.distributed, and the line says so
+    fb = lines["fallback"]
+    assert "FALLBACK" in fb["path"] and "multi_fallback" in fb and fb["parity_checked"] is True and fb["backend"].startswith("rccl through torch.distributed")
+    assert fb["config"]["colliding_pairs"] == lines["plain"]["config"]["colliding_pairs"] and fb["config"]["pairs_tested_per_step"] == lines["plain"]["config"]["pairs_tested_per_step"]
+    assert "roofline" in fb and "cpu_baseline" in fb and fb["value"] > 0
     # the N = 1 point of a scaling curve on the N > 1 code path: the same keys as the N > 1 line, and a value near the plain line's (the multi-GPU step pays two host
     # synchronisations and two one-rank all-gathers a step where the plain step polls a word: what that costs at 250 k triangles is printed, and bounded)
     _assert_multi_line_is_gradeable(lines["multi"], 1)
