@@ -111,6 +111,70 @@ __device__ __forceinline__ bool tri_contact(const d3 P1, const d3 P2, const d3 P
     return true;
 }
 
+// The same verdict with the hardware's FP64 max / min (k_exact: the SAT of ~100 k survivors is 6.8 of its 14.6 us, and a third of an axis' ~65 instructions
+// are the compare + two selects + wait states of each of its eight compare-selects).  v_max_f64 / v_min_f64 return what mathop.cuh's compare-selects return whenever
+// neither operand is a NaN -- up to the SIGN of a zero (max(+0, -0)) and which of two EQUAL operands comes back, and the projections' results only ever meet a `>`,
+// which sees neither.  With a NaN among an axis' dot products (non-finite vertices, or products that overflow to inf - inf) the two differ, on purpose in the
+// reference (mathop.cuh:17-44 is NaN-asymmetric): `nan` says whether any evaluated axis had one, and tri_contact_fast then takes the verdict from tri_contact itself.
+// (inline asm: fmax() would be canonicalised -- an extra v_max_f64 x, x per loaded operand under IEEE mode)
+__device__ __forceinline__ double hw_max64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double hw_min64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ bool project3_hw(const d3 ax, const d3 p1, const d3 p2, const d3 p3, bool &nan)
+{
+    const double P1 = dot(ax, p1), P2 = dot(ax, p2), P3 = dot(ax, p3);
+    nan |= __builtin_isunordered(P1, P2) | __builtin_isunordered(P3, P3);
+    const double mx1 = hw_max64(hw_max64(P1, P2), P3), mn1 = hw_min64(hw_min64(P1, P2), P3);
+    if (mn1 > 0) return false;
+    if (0 > mx1) return false;
+    return true;
+}
+__device__ __forceinline__ bool project6_hw(const d3 ax, const d3 p1, const d3 p2, const d3 p3, const d3 q1, const d3 q2, const d3 q3, bool &nan)
+{
+    const double P1 = dot(ax, p1), P2 = dot(ax, p2), P3 = dot(ax, p3);
+    const double Q1 = dot(ax, q1), Q2 = dot(ax, q2), Q3 = dot(ax, q3);
+    nan |= __builtin_isunordered(P1, P2) | __builtin_isunordered(P3, Q1) | __builtin_isunordered(Q2, Q3);
+    const double mx1 = hw_max64(hw_max64(P1, P2), P3), mn1 = hw_min64(hw_min64(P1, P2), P3);
+    const double mx2 = hw_max64(hw_max64(Q1, Q2), Q3), mn2 = hw_min64(hw_min64(Q1, Q2), Q3);
+    if (mn1 > mx2) return false;
+    if (mn2 > mx1) return false;
+    return true;
+}
+__device__ __forceinline__ bool tri_contact_hw(const d3 P1, const d3 P2, const d3 P3, const d3 Q1, const d3 Q2, const d3 Q3, bool &nan)
+{
+    const d3 p1 = d3{0.0, 0.0, 0.0};
+    const d3 p2 = sub(P2, P1), p3 = sub(P3, P1);
+    const d3 q1 = sub(Q1, P1), q2 = sub(Q2, P1), q3 = sub(Q3, P1);
+    const d3 e1 = sub(p2, p1), e2 = sub(p3, p2), e3 = sub(p1, p3);
+    const d3 f1 = sub(q2, q1), f2 = sub(q3, q2), f3 = sub(q1, q3);
+    const d3 n1 = cross(e1, e2);
+    if (!project3_hw(n1, q1, q2, q3, nan)) return false;
+    const d3 m1 = cross(f1, f2);
+    if (!project3_hw(m1, neg(q1), sub(p2, q1), sub(p3, q1), nan)) return false;
+    if (!project6_hw(cross(e1, f1), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(e1, f2), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(e1, f3), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(e2, f1), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(e2, f2), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(e2, f3), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(e3, f1), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(e3, f2), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(e3, f3), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(e1, n1), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(e2, n1), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(e3, n1), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(f1, m1), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(f2, m1), p1, p2, p3, q1, q2, q3, nan)) return false;
+    if (!project6_hw(cross(f3, m1), p1, p2, p3, q1, q2, q3, nan)) return false;
+    return true;
+}
+__device__ __forceinline__ bool tri_contact_fast(const d3 P1, const d3 P2, const d3 P3, const d3 Q1, const d3 Q2, const d3 Q3)
+{
+    bool nan = false;
+    bool c = tri_contact_hw(P1, P2, P3, Q1, Q2, Q3, nan);
+    if (nan) c = tri_contact(P1, P2, P3, Q1, Q2, Q3);                    // (a lane at a time, and rare: a NaN among the projections)
+    return c;
+}
+
 __device__ __forceinline__ d3 load_vertex(const double *__restrict__ verts, uint32_t i)
 {
     const double *p = verts + 3 * (size_t)i;

@@ -915,7 +915,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
     uint32_t tested = 0;
 
     // a contact -> LDS pair staging (or direct append when the staging area is full)
-    auto contact = [&](uint32_t q_id, uint32_t l_id) {
+    auto contact = [&](uint32_t q_id, uint32_t l_id) __attribute__((always_inline)) {
         const uint32_t slot = atomicAdd(&pcount, 1u);                          // LDS
         if (slot < EXACT_PB) pbuf[slot] = make_uint2(q_id, l_id);
         else {                                                                 // staging full: append directly (collision.cuh:40)
@@ -926,19 +926,19 @@ __global__ __launch_bounds__(EXACT_THREADS) void k_exact(QuerySrc src, int n, co
     };
     // SAT of two leaves of this mesh.  Half traversal: the pair is unordered; the reference tests it with the smaller ID as the query
     // (tri_contact.cuh:81 lets only that direction through), so that triangle goes in front
-    auto sat_leaves = [&](LeafTri ql, LeafTri lt) {
+    auto sat_leaves = [&](LeafTri ql, LeafTri lt) __attribute__((always_inline)) {
         if (half && ql.id > lt.id) { const LeafTri t = ql; ql = lt; lt = t; }
         const d3 P1 = load_vertex(verts, ql.v0), P2 = load_vertex(verts, ql.v1), P3 = load_vertex(verts, ql.v2);
-        if (tri_contact(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) contact(ql.id, lt.id);
+        if (tri_contact_fast(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) contact(ql.id, lt.id);
     };
     // SAT of one queued survivor
-    auto run_sat = [&](const SatItem it) {
+    auto run_sat = [&](const SatItem it) __attribute__((always_inline)) {
         const LeafTri lt = leaf[it.leaf];
         if (EXTERNAL) {
             const ExtQuery *q = reinterpret_cast<const ExtQuery *>(src.ext) + it.q;
             const d3 P1 = d3{q->v[0], q->v[1], q->v[2]}, P2 = d3{q->v[3], q->v[4], q->v[5]}, P3 = d3{q->v[6], q->v[7], q->v[8]};
             const uint32_t q_id = q->id;
-            if (tri_contact(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) contact(q_id, lt.id);
+            if (tri_contact_fast(P1, P2, P3, load_vertex(verts, lt.v0), load_vertex(verts, lt.v1), load_vertex(verts, lt.v2))) contact(q_id, lt.id);
         } else sat_leaves(leaf[it.q], lt);
     };
 

@@ -235,8 +235,9 @@ __global__ void k_tri_contact_points(const double *__restrict__ t, uint64_t n, u
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const double *p = t + 18 * i;
-        out[i] = tri_contact(d3{p[0], p[1], p[2]}, d3{p[3], p[4], p[5]}, d3{p[6], p[7], p[8]},
-                             d3{p[9], p[10], p[11]}, d3{p[12], p[13], p[14]}, d3{p[15], p[16], p[17]}) ? 1 : 0;
+        // (the form k_exact runs: hardware max / min, tri_contact itself where a projection is a NaN -- cd_math.h; the reference-compiled verdicts of tests/golden pin THIS)
+        out[i] = tri_contact_fast(d3{p[0], p[1], p[2]}, d3{p[3], p[4], p[5]}, d3{p[6], p[7], p[8]},
+                                  d3{p[9], p[10], p[11]}, d3{p[12], p[13], p[14]}, d3{p[15], p[16], p[17]}) ? 1 : 0;
     }
 }
 

@@ -97,6 +97,30 @@ def tri_pairs():
     return np.ascontiguousarray(np.concatenate(out)), np.concatenate(fam)
 
 
+N_NONFINITE = 1 << 16
+SPECIALS = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e300, -1e300, 1e-300, 1e155, -1e155, 1.7e308, 5e-324, 1.0, -1.0])
+
+
+def nonfinite_pairs() -> np.ndarray:
+    """f64[N_NONFINITE, 6, 3]: near pairs in which 0 .. 18 coordinates are replaced by NaN, +-inf, +-0, huge, tiny and ordinary values, an eighth of them scaled as a whole
+    by 1e150 / 1e-150 / 1e200 (overflow to inf - inf and underflow INSIDE the cross and dot products).  What tri_contact.cuh does with them is decided by mathop.cuh's
+    NaN-asymmetric compare-selects: round 6's fixture (tests/golden/contact_nonfinite_ref.npz, made by the reference compiled here) pins it for the device's
+    hardware-max / min form and its fall-back (cd_math.h, tri_contact_fast)."""
+    n = N_NONFINITE
+    t = _near_pairs(n, 7001).reshape(n, 18)
+    how_many = np.array([0, 1, 2, 4, 9, 18, 3, 6])[ints(n, 7002, 0, 7)]
+    where = ints(n * 18, 7003, 0, 17).reshape(n, 18)                      # positions drawn with repetition: "up to" how_many distinct ones
+    what = SPECIALS[ints(n * 18, 7004, 0, len(SPECIALS) - 1)].reshape(n, 18)
+    rows = np.arange(n)
+    for k in range(18):
+        on = how_many > k
+        t[rows[on], where[on, k]] = what[on, k]
+    scale = np.array([1e150, 1e-150, 1e200, 1.0])[ints(n // 8, 7005, 0, 3)]
+    with np.errstate(over="ignore", invalid="ignore"):
+        t[: n // 8] *= scale[:, None]
+    return np.ascontiguousarray(t.reshape(n, 6, 3))
+
+
 def box_pairs():
     """N_BOX box pairs {x1,x2,y1,y2,z1,z2}: half on a small integer lattice (touching faces, zero-thickness boxes, identical
     boxes: where the strict '> 0' of box.cuh:41 decides), a quarter float32-valued, a quarter full doubles."""

@@ -2007,6 +2007,23 @@ def test_device_exact_test_equals_reference_compiled_vectors():
     assert 1000 < int(got.sum()) < int(helper.sum())                                    # the neighbour gate removes some of the helper's hits
 
 
+def test_exact_test_with_hardware_min_max_falls_back_where_a_projection_is_not_a_number():
+    """k_exact's SAT takes max / min of an axis' projections with v_max_f64 / v_min_f64 (cd_math.h, tri_contact_fast) -- the compare-selects of mathop.cuh:17-44
+    whenever no projection is a NaN, up to the sign of a zero -- and returns to tri_contact itself for a pair that has one.  65 536 pairs whose coordinates are NaN,
+    +-inf, +-0, huge (products overflow: inf - inf), tiny (products underflow) or ordinary, in every mixture (contact_inputs.nonfinite_pairs): the verdicts of the
+    REFERENCE's tri_contact.cuh compiled unmodified (tests/golden/contact_nonfinite_ref.npz), through the points kernel and through cd_test_pairs."""
+    ref = np.load(os.path.join(GOLD, "contact_nonfinite_ref.npz"))
+    tri = ci.nonfinite_pairs()
+    n = tri.shape[0]
+    assert ci.sha(tri) == str(ref["tri_in_sha"]) and int(np.isnan(tri).any(axis=(1, 2)).sum()) == int(ref["pairs_with_a_nan"]) > n // 8
+    want = _unbits(ref["tri_contact_bits"], n)
+    assert int(want.sum()) == int(ref["contacts"]) > 1000
+    got = mi355cd.tri_contact_points(tri)                                               # tri_contact_fast: what k_exact runs
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, (bad[:8], tri[bad[:2]])
+    assert np.array_equal(oracle.tri_contact_points(tri), want)                        # (and the CPU restatement, on the same box)
+
+
 def test_device_boxes_equal_reference_compiled_vectors():
     ref = np.load(os.path.join(GOLD, "contact_ref.npz"))
     a, b = ci.box_pairs()

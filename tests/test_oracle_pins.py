@@ -350,6 +350,22 @@ def test_ref_compiled_tri_contact(contact_ref):
     assert (got[fam == 0] == 0).any() and (got[fam == 2] == 0).any() and (got[fam == 5] == 0).any() and (got[fam == 6] == 0).any()
 
 
+def test_ref_compiled_tri_contact_on_non_finite_coordinates():
+    """Round 6: 65 536 pairs with NaN, +-inf, +-0, huge and tiny coordinates (contact_inputs.nonfinite_pairs; mathop.cuh:17-44's compare-selects are NaN-asymmetric, and
+    what tri_contact.cuh returns for such a pair follows from them): the restatement gives the reference-compiled verdict on every one
+    (tests/golden/contact_nonfinite_ref.npz, generator make_contact_nonfinite_ref.py).  The device's hardware-max / min SAT and its fall-back are held to the same
+    fixture in tests/test_cd_gpu.py."""
+    ref = np.load(os.path.join(GOLD, "contact_nonfinite_ref.npz"))
+    tri = ci.nonfinite_pairs()
+    n = tri.shape[0]
+    assert n == ci.N_NONFINITE and ci.sha(tri) == str(ref["tri_in_sha"])
+    want = _unbits(ref["tri_contact_bits"], n)
+    got = oracle.tri_contact_points(tri)
+    assert np.array_equal(got, want) and int(want.sum()) == int(ref["contacts"])
+    nan = np.isnan(tri).any(axis=(1, 2))
+    assert int(nan.sum()) == int(ref["pairs_with_a_nan"]) and want[nan].any() and (want[nan] == 0).any()       # pairs with a NaN decide both ways
+
+
 def test_ref_compiled_helper_and_neighbor_count(contact_ref):
     verts, va, ida, vb, idb = ci.indexed_pairs()
     blob = np.concatenate([verts.view(np.uint8).ravel(), va.view(np.uint8).ravel(), ida.view(np.uint8), vb.view(np.uint8).ravel(), idb.view(np.uint8)])
